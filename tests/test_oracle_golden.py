@@ -1,0 +1,58 @@
+"""Pins oracle/avmoe_oracle.py against vectors captured from the real reference modules
+(tests/golden/*.npz, written by oracle/gen_golden.py).  CPU only."""
+import pytest
+import torch
+
+from oracle import avmoe_oracle as O
+from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close
+
+NAMES = golden_names()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_vectors(name):
+    meta, cfg, t = load_golden(name)
+    P, B = split_params(t)
+    training = bool(meta["module_train"])
+    noise = t.get("noise")
+    fwd, grads = O.moe_forward_backward(P, B, t["X"], t["Y"], cfg, t["grad_out"], training=training,
+                                        noise=noise, lb_weight=meta["lb_weight"])
+    assert torch.equal(fwd["idx"], t["idx"]), "router argmax must be bit-exact"
+    assert _rel(fwd["out"], t["out"]) < 2e-5
+    assert _rel(fwd["probs"], t["probs"]) < 1e-5
+    if cfg.lb_loss:
+        assert abs(float(fwd["lb"]) - float(t["lb"])) < 1e-4 * max(1.0, abs(float(t["lb"])))
+    assert_grads_close(grads, t, rtol=2e-4)
+    if training and cfg.use_bn:
+        for k, v in fwd["new_buffers"].items():
+            ref = t[f"newbuffer.{k}"]
+            assert torch.allclose(v.to(ref.dtype), ref, rtol=1e-5, atol=1e-6), k
+
+
+def test_fixture_set_covers_every_variant():
+    whiches = {load_golden(n)[0]["which"] for n in NAMES}
+    assert {"ave", "avqa", "avvp", "avs", "avs_ms3"} <= whiches
+
+
+def test_zero_gates_give_exact_zero():
+    """freshly constructed adapters (gates = 0) output exactly 0."""
+    cfg = O.AdapterConfig(Cx=32, Nx=10, Cy=16, Ny=12, reduction=4, groups=2, K=4)
+    P, B = O.init_params(cfg, seed=3, randomize=False)
+    X = torch.randn(3, cfg.Nx, cfg.Cx)
+    Y = torch.randn(3, cfg.Ny, cfg.Cy)
+    out = O.moe_forward(P, B, X, Y, cfg)["out"]
+    assert float(out.abs().max()) == 0.0
+
+
+def test_single_expert_probs_are_one_and_lb_of_uniform():
+    cfg = O.AdapterConfig(Cx=32, Nx=10, Cy=16, Ny=12, reduction=4, groups=2, K=4, E_m=1, E_s=0)
+    P, B = O.init_params(cfg, seed=4)
+    r = O.moe_forward(P, B, torch.randn(2, 10, 32), torch.randn(2, 12, 16), cfg)
+    assert torch.all(r["probs"] == 1.0)
+    E = 4
+    lb = O.load_balancing_loss(torch.full((5, E), 1.0 / E))
+    assert abs(float(lb) - E * torch.log(torch.tensor(float(E))).item()) < 1e-5
