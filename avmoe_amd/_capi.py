@@ -1,0 +1,67 @@
+"""ctypes binding of include/avmoe.h (libavmoe_hip.so).  Loading fails loudly: there is no CPU or
+PyTorch fallback for the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libavmoe_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avmoe.h")
+
+F32, BF16 = 0, 1
+K_MAJOR, MN_MAJOR = 0, 1
+
+
+class AvmoeError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "nb1", "nb2", "dtype", "out_dtype", "a_layout",
+                                         "b_layout", "accumulate", "ksplit", "tile")] + \
+               [("alpha", C.c_float)] + \
+               [(n, C.c_int64) for n in ("lda", "ldb", "sA1", "sA2", "sB1", "sB2", "sCi", "sCj", "sC1", "sC2",
+                                         "sRS1", "sRS2", "sDi", "sD1", "sD2")]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Built on demand if the .so is absent (hipcc needed); never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        from . import build as _b
+        _b.build()
+    if not os.path.isfile(LIB_PATH):
+        raise AvmoeError(f"{LIB_PATH} is missing: build it with `python -m avmoe_amd.build` "
+                         "(the adapter path has no fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.avmoe_abi_version.restype = C.c_int
+    L.avmoe_last_error.restype = C.c_char_p
+    L.avmoe_gemm_workspace_bytes.restype = C.c_size_t
+    L.avmoe_gemm_workspace_bytes.argtypes = [C.POINTER(GemmDesc)]
+    L.avmoe_gemm.restype = C.c_int
+    L.avmoe_gemm.argtypes = [C.POINTER(GemmDesc)] + [C.c_void_p] * 7
+    from . import _capi_moe
+    _capi_moe.declare(L)
+    _lib = L
+    return L
+
+
+def check(status: int, what: str = "avmoe"):
+    if status != 0:
+        msg = lib().avmoe_last_error()
+        raise AvmoeError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def exported_symbols():
+    """Every function include/avmoe.h declares (parsed from the header) -- the CPU test checks that
+    the built library exports each of them."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(avmoe_[a-z0-9_]+)\s*\(", txt)))

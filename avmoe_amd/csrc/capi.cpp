@@ -1,0 +1,37 @@
+// C ABI (include/avmoe.h) -> internal C++ entry points.  No exceptions cross this boundary.
+#include "../../include/avmoe.h"
+#include "common.h"
+#include "gemm.h"
+
+using namespace avmoe;
+
+static GemmArgs to_args(const avmoe_gemm_desc* d) {
+  GemmArgs a;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.nb1 = d->nb1; a.nb2 = d->nb2;
+  a.dtype = d->dtype; a.out_dtype = d->out_dtype; a.a_layout = d->a_layout; a.b_layout = d->b_layout;
+  a.accumulate = d->accumulate; a.ksplit = d->ksplit; a.tile = d->tile; a.alpha = d->alpha;
+  a.lda = d->lda; a.ldb = d->ldb; a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2;
+  a.sCi = d->sCi; a.sCj = d->sCj; a.sC1 = d->sC1; a.sC2 = d->sC2;
+  a.sRS1 = d->sRS1; a.sRS2 = d->sRS2; a.sDi = d->sDi; a.sD1 = d->sD1; a.sD2 = d->sD2;
+  return a;
+}
+
+extern "C" {
+
+int avmoe_abi_version(void) { return AVMOE_ABI_VERSION; }
+const char* avmoe_last_error(void) { return last_error(); }
+
+size_t avmoe_gemm_workspace_bytes(const avmoe_gemm_desc* desc) {
+  if (!desc) return 0;
+  return gemm_slab_bytes(to_args(desc));
+}
+
+int avmoe_gemm(const avmoe_gemm_desc* desc, const void* A, const void* B, void* C, const float* row_scale,
+               const void* D, void* workspace, void* stream) {
+  if (!desc) { set_last_error("avmoe_gemm: null desc"); return ERR_BAD_ARG; }
+  GemmArgs a = to_args(desc);
+  a.A = A; a.B = B; a.C = C; a.row_scale = row_scale; a.D = D; a.slabs = (float*)workspace;
+  return launch_gemm(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

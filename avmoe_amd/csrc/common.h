@@ -1,0 +1,39 @@
+// Shared host-side helpers: status codes and the thread-local error message behind avmoe_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+namespace avmoe {
+
+enum Status : int {
+  OK = 0,
+  ERR_BAD_ARG = -1,        // null pointer / inconsistent descriptor
+  ERR_UNSUPPORTED = -2,    // valid request the library does not implement
+  ERR_ALIGNMENT = -3,      // pointer / stride alignment contract violated
+  ERR_WORKSPACE = -4,      // workspace too small
+  ERR_LAUNCH = -5,         // HIP launch failure
+};
+
+void set_last_error(const char* fmt, ...);
+const char* last_error();
+
+#define AVMOE_CHECK_LAUNCH(what)                                                         \
+  do {                                                                                   \
+    hipError_t e__ = hipGetLastError();                                                  \
+    if (e__ != hipSuccess) {                                                             \
+      ::avmoe::set_last_error("%s: %s", what, hipGetErrorString(e__));                   \
+      return ::avmoe::ERR_LAUNCH;                                                        \
+    }                                                                                    \
+  } while (0)
+
+#define AVMOE_TRY(expr)                 \
+  do {                                  \
+    int s__ = (expr);                   \
+    if (s__ != 0) return s__;           \
+  } while (0)
+
+static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace avmoe

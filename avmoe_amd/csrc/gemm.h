@@ -1,0 +1,61 @@
+// Generic strided / batched MFMA GEMM engine for gfx950 (MI355X).
+//
+// Every wide contraction of the adapter path -- remap, latent-token attention hops, grouped
+// down/up projections, their input- and weight-gradient products -- is expressed as one call of
+// this engine (see DESIGN.md "bottleneck-space algebra"), so the full-width token tensors are only
+// ever touched by MFMA tiles.
+//
+//   C[b][i][j] (+)= alpha * sum_k A[b][i][k] * B[b][j][k]   (+ row_scale[b][i] * D[b][i][j])
+//
+// Operand layouts (per operand):
+//   K_MAJOR  : k is the contiguous index  (element (i,k) at  i*ld + k)
+//   MN_MAJOR : i is the contiguous index  (element (i,k) at  k*ld + i)   -- read through LDS with
+//              ds_read_b64_tr_b16 (bf16) / strided ds_read_b32 (f32)
+// C is addressed with explicit (sCi, sCj) strides; one of them must be 1.
+//
+// Contract for callers (checked in gemm.hip::validate):
+//   * base pointers 16-byte aligned, ld * sizeof(T) and batch strides * sizeof(T) multiples of 16
+//   * K_MAJOR operands: every row readable (finite) up to roundup(K, 16/sizeof(T)) elements; at
+//     least one of the two operands is ZERO in that padding
+//   * MN_MAJOR operands: every k-row readable up to roundup(M or N, 16/sizeof(T)) elements
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace avmoe {
+
+enum GemmDtype { GEMM_F32 = 0, GEMM_BF16 = 1 };
+enum GemmLayout { K_MAJOR = 0, MN_MAJOR = 1 };
+
+struct GemmArgs {
+  const void* A = nullptr;
+  const void* B = nullptr;
+  void* C = nullptr;
+  int M = 0, N = 0, K = 0;
+  int nb1 = 1, nb2 = 1;                 // batch = nb1 * nb2 ; b = b1 * nb2 + b2
+  int dtype = GEMM_F32;                 // A, B (and D) element type
+  int out_dtype = GEMM_F32;             // C element type
+  int a_layout = K_MAJOR, b_layout = K_MAJOR;
+  long lda = 0, ldb = 0;
+  long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0;   // batch strides, elements
+  long sCi = 0, sCj = 1, sC1 = 0, sC2 = 0;   // C strides, elements
+  float alpha = 1.f;
+  int accumulate = 0;                   // C += ...
+  // optional epilogue term  row_scale[b][i] * D[b][i][j]   (D: dtype `dtype`, j contiguous)
+  const float* row_scale = nullptr;
+  long sRS1 = 0, sRS2 = 0;
+  const void* D = nullptr;
+  long sDi = 0, sD1 = 0, sD2 = 0;
+  // split-K: partial sums go to fp32 slabs [ksplit][batch][M][N] in `slabs`, then a reduce pass
+  int ksplit = 1;
+  float* slabs = nullptr;
+  int tile = 0;                         // 0 = auto, 64 or 128 = force block tile
+};
+
+// Returns 0 on success, negative avmoe status otherwise (message through set_last_error).
+int launch_gemm(const GemmArgs& args, hipStream_t stream);
+
+// Bytes of fp32 slab workspace a split-K launch of `args` needs (0 when ksplit <= 1).
+size_t gemm_slab_bytes(const GemmArgs& args);
+
+}  // namespace avmoe

@@ -1,0 +1,514 @@
+// Generic strided / batched MFMA GEMM engine for gfx950 -- see gemm.h for the contract.
+//
+// Block = 256 threads = 4 waves (2 x 2), block tile BM x BN, K staged 128 bytes per row per step
+// through two LDS buffers (global -> VGPR prefetch of tile t+1 is issued before the MFMAs of tile t
+// and written to the other buffer after them: one barrier per K tile).
+//
+// MFMA shapes: bf16 -> v_mfma_f32_16x16x32_bf16 ; f32 -> v_mfma_f32_16x16x4_f32 (exact fp32).
+//   A operand: lane l supplies A[i = l&15][k-slot of quarter q = l>>4]
+//   B operand: lane l supplies B[j = l&15][same k-slot]
+//   C/D      : lane l holds C[i = 4q + reg][j = l&15]
+// k-slot mapping (identical for both operands, any order is fine for a sum):
+//   bf16: step ks, element e (0..7) -> k = 32 ks + 8 q + e
+//   f32 : chunk kc, element e (0..3) -> k = 16 kc + 4 q + e   (one 16x16x4 MFMA per e)
+// MN_MAJOR operands sit in LDS as [k][i]; bf16 fragments come out of it with the gfx950 transposing
+// read ds_read_b64_tr_b16 (two reads of 4 k-rows x 16 columns per 16-lane group), f32 with ds_read_b32.
+//
+// The epilogue goes through LDS so that global stores (and the optional D read) are whole rows:
+// 16 B per lane along the contiguous index of C.
+#include "gemm.h"
+#include "common.h"
+#include <algorithm>
+
+namespace avmoe {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct DevArgs {
+  const char* A; const char* B; char* C; const char* D; const float* rs; float* slabs;
+  int M, N, K, nb2, ksplit, kper, nbatch, tiles_n;
+  long lda, ldb, sA1, sA2, sB1, sB2, sCi, sCj, sC1, sC2, sRS1, sRS2, sDi, sD1, sD2;
+  float alpha; int accumulate, out_bf16, vec_c, vec_d;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+  return __builtin_bit_cast(float, ((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float x) {
+  return __builtin_bit_cast(unsigned short, (__bf16)x);
+}
+
+// zero the elements >= valid of a 16-byte chunk (K tail of a K_MAJOR operand)
+template <typename T>
+__device__ __forceinline__ u32x4 mask_tail(u32x4 v, int valid) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (e >= valid) v[e] = 0u;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (2 * e >= valid) v[e] = 0u;
+      else if (2 * e + 1 >= valid) v[e] &= 0xFFFFu;
+    }
+  }
+  return v;
+}
+
+template <typename T, int BM, int BN, bool AMN, bool BMN>
+__global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
+  constexpr int ESZ = sizeof(T);
+  constexpr int BK = 128 / ESZ;      // K elements per stage
+  constexpr int EPC = 16 / ESZ;      // elements per 16-byte chunk
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int A_ROWB = AMN ? BM * ESZ + 16 : 144;
+  constexpr int A_BYTES = (AMN ? BK : BM) * A_ROWB;
+  constexpr int B_ROWB = BMN ? BN * ESZ + 16 : 144;
+  constexpr int B_BYTES = (BMN ? BK : BN) * B_ROWB;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_CPR = BM * ESZ / 16, B_CPR = BN * ESZ / 16;   // chunks per LDS row (MN_MAJOR)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+  const int split = blockIdx.y % p.ksplit, b = blockIdx.y / p.ksplit;
+  const int b1 = b / p.nb2, b2 = b % p.nb2;
+  const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2) * ESZ;
+  const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2) * ESZ;
+  const int kbeg = split * p.kper;
+  const int kend = min(p.K, kbeg + p.kper);
+  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  u32x4 ra[BM / 32], rb[BN / 32];
+
+  auto gload = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int c = tid + 256 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if constexpr (!AMN) {
+        const int row = c >> 3, cc = c & 7;
+        const int gr = min(m0 + row, p.M - 1);
+        const int k = k0 + cc * EPC;
+        if (k < kend) {
+          v = *(const u32x4*)(Ab + ((long)gr * p.lda + k) * ESZ);
+          if (k + EPC > kend) v = mask_tail<T>(v, kend - k);
+        }
+      } else {
+        const int krow = c / A_CPR, cc = c % A_CPR;
+        const int k = k0 + krow, i0 = m0 + cc * EPC;
+        if (k < kend && i0 < p.M) v = *(const u32x4*)(Ab + ((long)k * p.lda + i0) * ESZ);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int c = tid + 256 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if constexpr (!BMN) {
+        const int row = c >> 3, cc = c & 7;
+        const int gr = min(n0 + row, p.N - 1);
+        const int k = k0 + cc * EPC;
+        if (k < kend) {
+          v = *(const u32x4*)(Bb + ((long)gr * p.ldb + k) * ESZ);
+          if (k + EPC > kend) v = mask_tail<T>(v, kend - k);
+        }
+      } else {
+        const int krow = c / B_CPR, cc = c % B_CPR;
+        const int k = k0 + krow, j0 = n0 + cc * EPC;
+        if (k < kend && j0 < p.N) v = *(const u32x4*)(Bb + ((long)k * p.ldb + j0) * ESZ);
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto lstore = [&](int buf) {
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (!AMN) *(u32x4*)(sA + (c >> 3) * A_ROWB + (c & 7) * 16) = ra[i];
+      else *(u32x4*)(sA + (c / A_CPR) * A_ROWB + (c % A_CPR) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (!BMN) *(u32x4*)(sB + (c >> 3) * B_ROWB + (c & 7) * 16) = rb[i];
+      else *(u32x4*)(sB + (c / B_CPR) * B_ROWB + (c % B_CPR) * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* sA = smem + buf * STAGE;
+    const char* sB = sA + A_BYTES;
+    if constexpr (ESZ == 2) {
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if constexpr (!AMN) {
+            af[tm] = *(const bf16x8*)(sA + (wm0 + 16 * tm + r) * A_ROWB + ks * 64 + q * 16);
+          } else {
+            const char* ad = sA + (ks * 32 + 8 * q + (r >> 2)) * A_ROWB + (wm0 + 16 * tm + 4 * (r & 3)) * 2;
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad));
+            s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + 4 * A_ROWB));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+            af[tm] = __builtin_bit_cast(bf16x8, w);
+          }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          if constexpr (!BMN) {
+            bfr[tn] = *(const bf16x8*)(sB + (wn0 + 16 * tn + r) * B_ROWB + ks * 64 + q * 16);
+          } else {
+            const char* ad = sB + (ks * 32 + 8 * q + (r >> 2)) * B_ROWB + (wn0 + 16 * tn + 4 * (r & 3)) * 2;
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad));
+            s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + 4 * B_ROWB));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+            bfr[tn] = __builtin_bit_cast(bf16x8, w);
+          }
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < BK / 16; ++kc) {
+        f32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if constexpr (!AMN) {
+            af[tm] = *(const f32x4*)(sA + (wm0 + 16 * tm + r) * A_ROWB + kc * 64 + q * 16);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              af[tm][e] = *(const float*)(sA + (16 * kc + 4 * q + e) * A_ROWB + (wm0 + 16 * tm + r) * 4);
+          }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          if constexpr (!BMN) {
+            bfr[tn] = *(const f32x4*)(sB + (wn0 + 16 * tn + r) * B_ROWB + kc * 64 + q * 16);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              bfr[tn][e] = *(const float*)(sB + (16 * kc + 4 * q + e) * B_ROWB + (wn0 + 16 * tn + r) * 4);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][e], bfr[tn][e], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  };
+
+  if (nkt > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) gload(kt + 1);
+    compute(kt & 1);
+    if (kt + 1 < nkt) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS ----
+  constexpr int CLD = BN + 4;
+  float* Cs = (float*)smem;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        Cs[(wm0 + 16 * tm + 4 * q + e) * CLD + wn0 + 16 * tn + r] = acc[tm][tn][e];
+  __syncthreads();
+
+  if (p.ksplit > 1) {
+    float* dst = p.slabs + ((long)split * p.nbatch + b) * (long)p.M * p.N;
+    constexpr int TPR = BN / 4, RPP = 256 / TPR;
+#pragma unroll 1
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+      const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
+      const int gi = m0 + i, gj = n0 + j;
+      if (gi < p.M && gj < p.N) {
+        const f32x4 v = *(const f32x4*)&Cs[i * CLD + j];
+        float* d = dst + (long)gi * p.N + gj;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (gj + e < p.N) d[e] = v[e];
+      }
+    }
+    return;
+  }
+
+  char* Cb = p.C + ((long)b1 * p.sC1 + (long)b2 * p.sC2) * (p.out_bf16 ? 2 : 4);
+  const char* Db = p.D ? p.D + ((long)b1 * p.sD1 + (long)b2 * p.sD2) * ESZ : nullptr;
+  const float* rsb = p.rs ? p.rs + (long)b1 * p.sRS1 + (long)b2 * p.sRS2 : nullptr;
+
+  auto load_out = [&](const char* ptr) -> float {
+    return p.out_bf16 ? bf16_bits_to_f32(*(const unsigned short*)ptr) : *(const float*)ptr;
+  };
+  auto store_out = [&](char* ptr, float v) {
+    if (p.out_bf16) *(unsigned short*)ptr = f32_to_bf16_bits(v);
+    else *(float*)ptr = v;
+  };
+  auto load_d = [&](long off) -> float {
+    if constexpr (ESZ == 2) return bf16_bits_to_f32(*(const unsigned short*)(Db + off * 2));
+    else return *(const float*)(Db + off * 4);
+  };
+  const int osz = p.out_bf16 ? 2 : 4;
+
+  if (p.sCj == 1) {
+    constexpr int TPR = BN / 4, RPP = 256 / TPR;
+#pragma unroll 1
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+      const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
+      const int gi = m0 + i, gj = n0 + j;
+      if (gi >= p.M || gj >= p.N) continue;
+      f32x4 v = *(const f32x4*)&Cs[i * CLD + j];
+      const float rsv = rsb ? rsb[gi] : 0.f;
+      char* cp = Cb + ((long)gi * p.sCi + gj) * osz;
+      const bool full = (gj + 3 < p.N);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (Db) {
+        if (full && p.vec_d) {
+          if constexpr (ESZ == 2) {
+            const u32x2 dv = *(const u32x2*)(Db + ((long)gi * p.sDi + gj) * 2);
+            v[0] += rsv * bf16_bits_to_f32(dv[0] & 0xFFFFu);
+            v[1] += rsv * bf16_bits_to_f32(dv[0] >> 16);
+            v[2] += rsv * bf16_bits_to_f32(dv[1] & 0xFFFFu);
+            v[3] += rsv * bf16_bits_to_f32(dv[1] >> 16);
+          } else {
+            const f32x4 dv = *(const f32x4*)(Db + ((long)gi * p.sDi + gj) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rsv * dv[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (gj + e < p.N) v[e] += rsv * load_d((long)gi * p.sDi + gj + e);
+        }
+      }
+      if (full && p.vec_c) {
+        if (p.out_bf16) {
+          if (p.accumulate) {
+            const u32x2 o = *(const u32x2*)cp;
+            v[0] += bf16_bits_to_f32(o[0] & 0xFFFFu); v[1] += bf16_bits_to_f32(o[0] >> 16);
+            v[2] += bf16_bits_to_f32(o[1] & 0xFFFFu); v[3] += bf16_bits_to_f32(o[1] >> 16);
+          }
+          u32x2 o;
+          o[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+          o[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+          *(u32x2*)cp = o;
+        } else {
+          if (p.accumulate) {
+            const f32x4 o = *(const f32x4*)cp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += o[e];
+          }
+          *(f32x4*)cp = v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (gj + e < p.N) {
+            float x = v[e];
+            if (p.accumulate) x += load_out(cp + e * osz);
+            store_out(cp + e * osz, x);
+          }
+        }
+      }
+    }
+  } else {   // sCi == 1 : C stored transposed (i contiguous)
+    constexpr int TPC = BM / 4, CPP = 256 / TPC;
+#pragma unroll 1
+    for (int pass = 0; pass < BN / CPP; ++pass) {
+      const int j = pass * CPP + tid / TPC, i = (tid % TPC) * 4;
+      const int gi = m0 + i, gj = n0 + j;
+      if (gi >= p.M || gj >= p.N) continue;
+      char* cp = Cb + ((long)gj * p.sCj + gi) * osz;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (gi + e < p.M) {
+          float x = p.alpha * Cs[(i + e) * CLD + j];
+          if (Db) x += (rsb ? rsb[gi + e] : 0.f) * load_d((long)(gi + e) * p.sDi + gj);
+          if (p.accumulate) x += load_out(cp + e * osz);
+          store_out(cp + e * osz, x);
+        }
+      }
+    }
+  }
+}
+
+// split-K second pass: C = alpha * sum_s slab[s] (+ row_scale * D) (+ C)
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p) {
+  const long per = (long)p.M * p.N;
+  const long total = per * p.nbatch;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int b = (int)(idx / per);
+    const long rem = idx % per;
+    const int i = (int)(rem / p.N), j = (int)(rem % p.N);
+    float s = 0.f;
+    for (int sp = 0; sp < p.ksplit; ++sp) s += p.slabs[(long)sp * total + idx];
+    s *= p.alpha;
+    const int b1 = b / p.nb2, b2 = b % p.nb2;
+    if (p.D) {
+      const float rsv = p.rs ? p.rs[(long)b1 * p.sRS1 + (long)b2 * p.sRS2 + i] : 0.f;
+      const long off = (long)b1 * p.sD1 + (long)b2 * p.sD2 + (long)i * p.sDi + j;
+      float dv;
+      if constexpr (sizeof(T) == 2) dv = bf16_bits_to_f32(((const unsigned short*)p.D)[off]);
+      else dv = ((const float*)p.D)[off];
+      s += rsv * dv;
+    }
+    const long coff = (long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)i * p.sCi + (long)j * p.sCj;
+    if (p.out_bf16) {
+      unsigned short* c = (unsigned short*)p.C + coff;
+      if (p.accumulate) s += bf16_bits_to_f32(*c);
+      *c = f32_to_bf16_bits(s);
+    } else {
+      float* c = (float*)p.C + coff;
+      if (p.accumulate) s += *c;
+      *c = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, bool AMN, bool BMN>
+static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
+  constexpr int ESZ = sizeof(T);
+  constexpr int BK = 128 / ESZ;
+  constexpr int A_BYTES = (AMN ? BK : BM) * (AMN ? BM * ESZ + 16 : 144);
+  constexpr int B_BYTES = (BMN ? BK : BN) * (BMN ? BN * ESZ + 16 : 144);
+  constexpr int STAGES = 2 * (A_BYTES + B_BYTES);
+  constexpr int EPI = BM * (BN + 4) * 4;
+  constexpr int LDS = STAGES > EPI ? STAGES : EPI;
+  static bool attr_done = false;
+  auto kern = gemm_kernel<T, BM, BN, AMN, BMN>;
+  if (!attr_done) {
+    if (LDS > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) {
+        set_last_error("gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+        return ERR_LAUNCH;
+      }
+    }
+    attr_done = true;
+  }
+  const int tiles_m = cdiv(d.M, BM);
+  dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, d);
+  AVMOE_CHECK_LAUNCH("gemm_kernel");
+  return OK;
+}
+
+template <typename T, int BM, int BN>
+static int launch_layout(const GemmArgs& a, const DevArgs& d, int bz, hipStream_t s) {
+  const bool amn = a.a_layout == MN_MAJOR, bmn = a.b_layout == MN_MAJOR;
+  if (!amn && !bmn) return launch_inst<T, BM, BN, false, false>(d, bz, s);
+  if (!amn && bmn) return launch_inst<T, BM, BN, false, true>(d, bz, s);
+  if (amn && !bmn) return launch_inst<T, BM, BN, true, false>(d, bz, s);
+  return launch_inst<T, BM, BN, true, true>(d, bz, s);
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+size_t gemm_slab_bytes(const GemmArgs& a) {
+  if (a.ksplit <= 1) return 0;
+  return (size_t)a.ksplit * a.nb1 * a.nb2 * (size_t)a.M * a.N * sizeof(float);
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  if (!a.A || !a.B || !a.C) { set_last_error("gemm: null operand"); return ERR_BAD_ARG; }
+  if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nb1 <= 0 || a.nb2 <= 0) {
+    set_last_error("gemm: bad extents M=%d N=%d K=%d batch=%dx%d", a.M, a.N, a.K, a.nb1, a.nb2);
+    return ERR_BAD_ARG;
+  }
+  if (a.dtype != GEMM_F32 && a.dtype != GEMM_BF16) { set_last_error("gemm: dtype"); return ERR_UNSUPPORTED; }
+  if (!(a.sCj == 1 || a.sCi == 1)) { set_last_error("gemm: C needs a unit stride"); return ERR_UNSUPPORTED; }
+  const int esz = a.dtype == GEMM_BF16 ? 2 : 4;
+  auto mult16 = [&](long elems) { return (elems * esz) % 16 == 0; };
+  if (!aligned16(a.A) || !aligned16(a.B) || !mult16(a.lda) || !mult16(a.ldb) || !mult16(a.sA1) ||
+      !mult16(a.sA2) || !mult16(a.sB1) || !mult16(a.sB2)) {
+    set_last_error("gemm: operand alignment contract violated (A=%p B=%p lda=%ld ldb=%ld)", a.A, a.B, a.lda, a.ldb);
+    return ERR_ALIGNMENT;
+  }
+  if (a.ksplit > 1 && !a.slabs) { set_last_error("gemm: split-K without slab workspace"); return ERR_WORKSPACE; }
+  if ((a.row_scale != nullptr) != (a.D != nullptr)) { set_last_error("gemm: row_scale and D go together"); return ERR_BAD_ARG; }
+
+  DevArgs d;
+  d.A = (const char*)a.A; d.B = (const char*)a.B; d.C = (char*)a.C; d.D = (const char*)a.D;
+  d.rs = a.row_scale; d.slabs = a.slabs;
+  d.M = a.M; d.N = a.N; d.K = a.K; d.nb2 = a.nb2; d.ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  d.nbatch = a.nb1 * a.nb2;
+  d.lda = a.lda; d.ldb = a.ldb; d.sA1 = a.sA1; d.sA2 = a.sA2; d.sB1 = a.sB1; d.sB2 = a.sB2;
+  d.sCi = a.sCi; d.sCj = a.sCj; d.sC1 = a.sC1; d.sC2 = a.sC2;
+  d.sRS1 = a.sRS1; d.sRS2 = a.sRS2; d.sDi = a.sDi; d.sD1 = a.sD1; d.sD2 = a.sD2;
+  d.alpha = a.alpha; d.accumulate = a.accumulate; d.out_bf16 = a.out_dtype == GEMM_BF16;
+  const int osz = d.out_bf16 ? 2 : 4;
+  const int vecb = 4 * osz;    // bytes of a 4-element output vector
+  d.vec_c = (a.sCj == 1) && (((uintptr_t)a.C) % vecb == 0) && ((a.sCi * osz) % vecb == 0) &&
+            ((a.sC1 * osz) % vecb == 0) && ((a.sC2 * osz) % vecb == 0);
+  d.vec_d = a.D && (((uintptr_t)a.D) % (4 * esz) == 0) && ((a.sDi * esz) % (4 * esz) == 0) &&
+            ((a.sD1 * esz) % (4 * esz) == 0) && ((a.sD2 * esz) % (4 * esz) == 0);
+  const int bk = 128 / esz;
+  d.kper = d.ksplit > 1 ? (int)round_up(cdiv(a.K, d.ksplit), bk) : (a.K > 0 ? (int)round_up(a.K, bk) : bk);
+
+  int tile = a.tile;
+  if (tile == 0) tile = (a.M > 64 && a.N > 64) ? 128 : 64;
+  const int bz = d.nbatch * d.ksplit;
+  if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
+  int st;
+  if (tile == 128) {
+    d.tiles_n = cdiv(a.N, 128);
+    st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 128, 128>(a, d, bz, stream)
+                              : launch_layout<float, 128, 128>(a, d, bz, stream);
+  } else if (tile == 64) {
+    d.tiles_n = cdiv(a.N, 64);
+    st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 64, 64>(a, d, bz, stream)
+                              : launch_layout<float, 64, 64>(a, d, bz, stream);
+  } else {
+    set_last_error("gemm: tile %d not built", tile);
+    return ERR_UNSUPPORTED;
+  }
+  if (st != OK) return st;
+  if (d.ksplit > 1) {
+    const long total = (long)d.nbatch * a.M * a.N;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    if (a.dtype == GEMM_BF16) hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3(blocks), dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d);
+    AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
+  }
+  return OK;
+}
+
+}  // namespace avmoe

@@ -1,0 +1,203 @@
+"""GPU parity of the generic MFMA GEMM engine (avmoe_gemm) against torch.matmul in fp64 on the same
+inputs: all four operand-layout combinations, both dtypes, both tiles, ragged M/N/K, batching with
+broadcast operands, transposed C, accumulate, the row_scale*D epilogue and split-K."""
+import ctypes as C
+import itertools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=False, out_bf16=False,
+              accumulate=False, epilogue=False, ksplit=1, bcast_a=False, seed=0, exact_ints=False):
+    from avmoe_amd import _capi as capi
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tdt = torch.bfloat16 if dtype == capi.BF16 else torch.float32
+    epc = 8 if dtype == capi.BF16 else 4
+    nb = nb1 * nb2
+
+    def rnd(*shape):
+        if exact_ints:
+            return torch.randint(-3, 4, shape, generator=g).double()
+        return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+    Kp, Mp, Np = -(-K // epc) * epc, -(-M // epc) * epc, -(-N // epc) * epc
+    A = rnd(1 if bcast_a else nb, M, K)
+    Bm = rnd(nb, N, K)
+    # device storage with padded leading dims; padding holds finite garbage (7.0) except A's K padding
+    if a_mn:
+        Ad = torch.full((A.shape[0], K, Mp), 7.0, dtype=tdt)
+        Ad[:, :, :M] = A.transpose(1, 2).to(tdt)
+        lda, sA = Mp, K * Mp
+    else:
+        Ad = torch.zeros((A.shape[0], M, Kp), dtype=tdt)
+        Ad[:, :, :K] = A.to(tdt)
+        lda, sA = Kp, M * Kp
+    if b_mn:
+        Bd = torch.full((nb, K, Np), 7.0, dtype=tdt)
+        Bd[:, :, :N] = Bm.transpose(1, 2).to(tdt)
+        ldb, sB = Np, K * Np
+    else:
+        Bd = torch.full((nb, N, Kp), 7.0, dtype=tdt)      # garbage in the K padding: the engine masks it
+        Bd[:, :, :K] = Bm.to(tdt)
+        ldb, sB = Kp, N * Kp
+    Ad, Bd = Ad.to(dev), Bd.to(dev)
+    Ar = (Ad[:, :, :M].transpose(1, 2) if a_mn else Ad[:, :, :K]).double().cpu()
+    Br = (Bd[:, :, :N].transpose(1, 2) if b_mn else Bd[:, :, :K]).double().cpu()
+    ref = 0.5 * torch.matmul(Ar.expand(nb, M, K), Br.transpose(1, 2))
+
+    odt = torch.bfloat16 if out_bf16 else torch.float32
+    Cd = torch.zeros((nb, N, M) if c_transposed else (nb, M, N), dtype=odt)
+    if accumulate:
+        C0 = torch.randn(Cd.shape, generator=g).to(odt)
+        Cd.copy_(C0)
+        ref = ref + (C0.double().transpose(1, 2) if c_transposed else C0.double())
+    Cd = Cd.to(dev)
+    rs = Dd = None
+    if epilogue:
+        rs = torch.randn(nb, M, generator=g, dtype=torch.float32)
+        Dm = torch.randn(nb, M, N, generator=g).to(tdt)
+        ref = ref + rs.double()[:, :, None] * Dm.double()
+        rs, Dd = rs.to(dev), Dm.to(dev)
+
+    d = capi.GemmDesc()
+    d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb1, nb2
+    d.dtype, d.out_dtype = dtype, (capi.BF16 if out_bf16 else capi.F32)
+    d.a_layout, d.b_layout = int(a_mn), int(b_mn)
+    d.accumulate, d.ksplit, d.tile, d.alpha = int(accumulate), ksplit, tile, 0.5
+    d.lda, d.ldb = lda, ldb
+    d.sA1, d.sA2 = (0, 0) if bcast_a else (sA * nb2, sA)
+    d.sB1, d.sB2 = sB * nb2, sB
+    if c_transposed:
+        d.sCi, d.sCj = 1, M
+    else:
+        d.sCi, d.sCj = N, 1
+    d.sC1, d.sC2 = M * N * nb2, M * N
+    d.sRS1, d.sRS2, d.sDi, d.sD1, d.sD2 = M * nb2, M, N, M * N * nb2, M * N
+    ws = None
+    nbytes = L.avmoe_gemm_workspace_bytes(C.byref(d))
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = L.avmoe_gemm(C.byref(d), Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(),
+                      rs.data_ptr() if rs is not None else None, Dd.data_ptr() if Dd is not None else None,
+                      ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
+    capi.check(st, "avmoe_gemm")
+    torch.cuda.synchronize()
+    got = Cd.double().cpu()
+    if c_transposed:
+        got = got.transpose(1, 2)
+    return got, ref
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == 0 else 1e-4     # bf16 inputs are exact in the fp64 reference; fp32 accumulate
+
+
+LAYOUTS = list(itertools.product([False, True], [False, True]))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+def test_exact_integer_tiles_asymmetric(dtype, a_mn, b_mn):
+    """Small-integer operands: every product and partial sum is exact, so any fragment-layout slip
+    (row/col swap, k permutation mismatch between operands) shows up as a hard mismatch."""
+    for tile in (64, 128):
+        got, ref = _run_gemm(80, 48, 96, dtype, a_mn, b_mn, tile=tile, exact_ints=True, seed=tile)
+        assert torch.equal(got, ref), f"tile {tile}: max err {(got - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+@pytest.mark.parametrize("shape", [(200, 136, 196), (64, 24, 40), (333, 70, 1030), (16, 16, 8)])
+def test_ragged_shapes(dtype, a_mn, b_mn, shape):
+    M, N, K = shape
+    got, ref = _run_gemm(M, N, K, dtype, a_mn, b_mn, seed=M + N + K)
+    err = (got - ref).abs().max() / (ref.abs().max() + 1e-9)
+    assert err < _tol(dtype), float(err)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_batched_broadcast_and_two_level_batch(dtype):
+    got, ref = _run_gemm(72, 40, 64, dtype, False, True, nb1=3, nb2=2, bcast_a=True, seed=5)
+    assert (got - ref).abs().max() / ref.abs().max() < _tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("tile", [64, 128])
+def test_transposed_c_accumulate_epilogue(dtype, tile):
+    got, ref = _run_gemm(150, 90, 72, dtype, False, False, nb1=2, tile=tile, c_transposed=True,
+                         accumulate=True, seed=7)
+    assert (got - ref).abs().max() / ref.abs().max() < _tol(dtype)
+    got, ref = _run_gemm(150, 92, 72, dtype, True, False, nb1=2, tile=tile, accumulate=True, epilogue=True, seed=8)
+    assert (got - ref).abs().max() / ref.abs().max() < _tol(dtype)
+    got, ref = _run_gemm(150, 92, 72, dtype, False, True, tile=tile, out_bf16=True, accumulate=True,
+                         epilogue=True, seed=9)
+    assert (got - ref).abs().max() / ref.abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_split_k(dtype):
+    got, ref = _run_gemm(96, 40, 5000, dtype, True, True, nb1=2, ksplit=7, epilogue=True, accumulate=True, seed=11)
+    assert (got - ref).abs().max() / ref.abs().max() < 5 * _tol(dtype)
+    got, ref = _run_gemm(70, 130, 700, dtype, False, False, ksplit=3, c_transposed=True, seed=12)
+    assert (got - ref).abs().max() / ref.abs().max() < 5 * _tol(dtype)
+
+
+def test_alignment_contract_is_enforced():
+    from avmoe_amd import _capi as capi
+    L = capi.lib()
+    d = capi.GemmDesc()
+    d.M = d.N = d.K = 16
+    d.nb1 = d.nb2 = 1
+    d.lda = d.ldb = 18           # 72-byte rows: not a multiple of 16
+    d.sCi, d.sCj, d.alpha = 16, 1, 1.0
+    x = torch.zeros(1024, device="cuda:0")
+    st = L.avmoe_gemm(C.byref(d), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, None, None, None)
+    assert st == -3 and b"alignment" in L.avmoe_last_error()
+
+
+def test_gemm_throughput_report(capsys):
+    """Not a pass/fail perf gate -- prints achieved TFLOP/s for the path's main GEMM shapes (cfg-2)."""
+    from avmoe_amd import _capi as capi
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    rows = []
+    for (name, M, N, K, nb, a_mn, b_mn) in [
+        ("X@[W|T] tokens x C -> 320", 327680, 320, 768, 1, False, False),
+        ("post: tokens x 160 -> C", 327680, 768, 160, 1, False, False),
+        ("token contraction (per sample)", 64, 768, 1024, 320, True, True),
+        ("square 4096", 4096, 4096, 4096, 1, False, False),
+    ]:
+        for dtype in (capi.BF16, capi.F32):
+            tdt = torch.bfloat16 if dtype == capi.BF16 else torch.float32
+            A = torch.randn((nb, K, M) if a_mn else (nb, M, K), device=dev).to(tdt)
+            B = torch.randn((nb, K, N) if b_mn else (nb, N, K), device=dev).to(tdt)
+            Cc = torch.empty((nb, M, N), device=dev, dtype=tdt)
+            d = capi.GemmDesc()
+            d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb, 1
+            d.dtype = d.out_dtype = dtype
+            d.a_layout, d.b_layout = int(a_mn), int(b_mn)
+            d.ksplit, d.alpha = 1, 1.0
+            d.lda, d.ldb = (M if a_mn else K), (N if b_mn else K)
+            d.sA1, d.sB1, d.sC1 = M * K, N * K, M * N
+            d.sCi, d.sCj = N, 1
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):
+                capi.check(L.avmoe_gemm(C.byref(d), A.data_ptr(), B.data_ptr(), Cc.data_ptr(), None, None, None, st))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                capi.check(L.avmoe_gemm(C.byref(d), A.data_ptr(), B.data_ptr(), Cc.data_ptr(), None, None, None, st))
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            fl = 2.0 * M * N * K * nb
+            by = (A.numel() + B.numel() + Cc.numel()) * A.element_size()
+            rows.append(f"{name:34s} {'bf16' if dtype else 'f32 '} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  "
+                        f"{by / ms / 1e6:8.1f} GB/s")
+    with capsys.disabled():
+        print("\n[gemm throughput]\n" + "\n".join(rows))
