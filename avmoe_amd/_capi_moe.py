@@ -1,5 +1,98 @@
-"""ctypes declarations for the MoE-adapter section of the ABI (filled in as the ABI grows)."""
+"""ctypes declarations + thin helpers for the MoE-adapter section of include/avmoe.h."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+MAX_EXPERTS = 16
+VARIANT = {"ave": 0, "avqa": 0, "avvp": 1, "avs": 2}
+SELF_ATTN = {"none": 0, "v2": 1, "nxn": 2}
+
+
+class MoeDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("S", "N", "C", "M", "Cy", "E_m", "E_s", "d", "groups", "K", "use_bn",
+                                         "use_gate", "ln_before", "ln_post", "variant", "self_attn", "lb_loss",
+                                         "dtype", "training")] + \
+               [(n, C.c_float) for n in ("bn_eps", "ln_eps", "bn_momentum")]
+
+
+_EXPERT_FIELDS = ("gate", "my_tokens", "gate_lat", "down_w", "up_w", "bn1_w", "bn1_b", "bn2_w", "bn2_b",
+                  "lnb_w", "lnb_b", "lnp_w", "lnp_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv")
+_TOP_FIELDS = ("conv_w", "conv_b", "fc_w", "fc_b", "r0_w", "r0_b", "r2_w", "r2_b", "r4_w", "r4_b")
+
+
+class ExpertPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _EXPERT_FIELDS]
+
+
+class MoePtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _TOP_FIELDS] + [("e", ExpertPtrs * MAX_EXPERTS)]
+
+
+# state_dict leaf (relative to the expert prefix) -> ExpertPtrs field
+EXPERT_KEY_TO_FIELD = {
+    "gate": "gate", "my_tokens": "my_tokens", "gate_av": "gate_lat", "gate_self": "gate_lat",
+    "down_sampler.weight": "down_w", "up_sampler.weight": "up_w",
+    "bn1.weight": "bn1_w", "bn1.bias": "bn1_b", "bn2.weight": "bn2_w", "bn2.bias": "bn2_b",
+    "ln_before.weight": "lnb_w", "ln_before.bias": "lnb_b", "ln_post.weight": "lnp_w", "ln_post.bias": "lnp_b",
+    "bn1.running_mean": "bn1_rm", "bn1.running_var": "bn1_rv", "bn2.running_mean": "bn2_rm", "bn2.running_var": "bn2_rv",
+}
+TOP_KEY_TO_FIELD = {
+    "conv_adapter.weight": "conv_w", "conv_adapter.bias": "conv_b", "fc.weight": "fc_w", "fc.bias": "fc_b",
+    "router.0.weight": "r0_w", "router.0.bias": "r0_b", "router.2.weight": "r2_w", "router.2.bias": "r2_b",
+    "router.4.weight": "r4_w", "router.4.bias": "r4_b",
+}
 
 
 def declare(L):
-    return
+    L.avmoe_moe_saved_bytes.restype = C.c_size_t
+    L.avmoe_moe_saved_bytes.argtypes = [C.POINTER(MoeDesc)]
+    L.avmoe_moe_scratch_bytes.restype = C.c_size_t
+    L.avmoe_moe_scratch_bytes.argtypes = [C.POINTER(MoeDesc)]
+    L.avmoe_moe_forward.restype = C.c_int
+    L.avmoe_moe_forward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.avmoe_moe_backward.restype = C.c_int
+    L.avmoe_moe_backward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_void_p,
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoePtrs),
+                                     C.c_void_p]
+    L.avmoe_moe_buffer_info.restype = C.c_int
+    L.avmoe_moe_buffer_info.argtypes = [C.POINTER(MoeDesc), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+
+def expert_prefixes(E_m: int, E_s: int) -> List[str]:
+    return [f"multimodal_experts.{j}" for j in range(E_m)] + [f"singlemodal_experts.{j}" for j in range(E_s)]
+
+
+def make_ptrs(tensors: Dict[str, "object"], E_m: int, E_s: int) -> MoePtrs:
+    """Fill a MoePtrs from {state_dict key: CUDA fp32 tensor}.  Missing keys stay NULL.  The caller keeps
+    the tensors alive for the duration of the call."""
+    import torch
+    P = MoePtrs()
+    for k, f in TOP_KEY_TO_FIELD.items():
+        t = tensors.get(k)
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_contiguous(), k
+            setattr(P, f, t.data_ptr())
+    for j, pre in enumerate(expert_prefixes(E_m, E_s)):
+        for leaf, f in EXPERT_KEY_TO_FIELD.items():
+            t = tensors.get(f"{pre}.{leaf}")
+            if t is not None:
+                assert t.dtype == torch.float32 and t.is_contiguous(), (pre, leaf)
+                setattr(P.e[j], f, t.data_ptr())
+    return P
+
+
+def buffer_table(L, desc: MoeDesc):
+    """[(name, region, offset, bytes)] of the workspace layout for `desc`."""
+    out = []
+    i = 0
+    while True:
+        name, region, off, nb = C.c_char_p(), C.c_int32(), C.c_size_t(), C.c_size_t()
+        st = L.avmoe_moe_buffer_info(C.byref(desc), i, C.byref(name), C.byref(region), C.byref(off), C.byref(nb))
+        if st != 0:
+            break
+        out.append((name.value.decode(), region.value, off.value, nb.value))
+        i += 1
+    return out

@@ -2,6 +2,7 @@
 #include "../../include/avmoe.h"
 #include "common.h"
 #include "gemm.h"
+#include "moe_run.h"
 
 using namespace avmoe;
 
@@ -32,6 +33,48 @@ int avmoe_gemm(const avmoe_gemm_desc* desc, const void* A, const void* B, void* 
   GemmArgs a = to_args(desc);
   a.A = A; a.B = B; a.C = C; a.row_scale = row_scale; a.D = D; a.slabs = (float*)workspace;
   return launch_gemm(a, (hipStream_t)stream);
+}
+
+
+size_t avmoe_moe_saved_bytes(const avmoe_moe_desc* desc) {
+  Plan pl;
+  return make_plan(desc, &pl) == OK ? pl.saved_bytes : 0;
+}
+size_t avmoe_moe_scratch_bytes(const avmoe_moe_desc* desc) {
+  Plan pl;
+  return make_plan(desc, &pl) == OK ? pl.scratch_bytes : 0;
+}
+
+int avmoe_moe_forward(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
+                      const float* noise, void* out, float* probs, int64_t* idx, float* lb, void* saved, void* scratch,
+                      void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!X || !Y || !params || !out || !saved || !scratch) { set_last_error("avmoe_moe_forward: null pointer"); return ERR_BAD_ARG; }
+  return moe_forward(pl, X, Y, *params, noise, out, probs, idx, lb, (char*)saved, (char*)scratch, (hipStream_t)stream);
+}
+
+int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
+                       const void* dOut, float lb_weight, void* saved, void* scratch, void* dX, void* dY,
+                       const avmoe_moe_ptrs* grads, void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads) {
+    set_last_error("avmoe_moe_backward: null pointer"); return ERR_BAD_ARG;
+  }
+  return moe_backward(pl, X, Y, *params, dOut, lb_weight, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream);
+}
+
+int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region, size_t* offset,
+                          size_t* bytes) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (index < 0 || index >= pl.nbuf) { set_last_error("buffer index %d out of range", index); return ERR_BAD_ARG; }
+  if (name) *name = pl.info[index].name;
+  if (region) *region = pl.info[index].region;
+  if (offset) *offset = pl.info[index].offset;
+  if (bytes) *bytes = pl.info[index].bytes;
+  return OK;
 }
 
 }  // extern "C"

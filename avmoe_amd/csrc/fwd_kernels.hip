@@ -1,0 +1,935 @@
+// Forward bottleneck-space kernels (everything between the GEMMs).  Arithmetic and names follow
+// oracle/algebra_ref.py::AlgebraRef.forward; reference lines are cited there and in DESIGN.md.
+//
+// Buffers of the operand type T (float | __bf16) are passed as void* and cast inside the kernel.
+#include "kernels.h"
+#include "device_utils.h"
+#include <algorithm>
+
+namespace avmoe {
+
+#define DISPATCH_T(bf16, KERN, grid, block, shmem, st, ...)                                   \
+  do {                                                                                        \
+    if (bf16) hipLaunchKernelGGL((KERN<__bf16>), grid, block, shmem, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERN<float>), grid, block, shmem, st, __VA_ARGS__);              \
+  } while (0)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T> __device__ __forceinline__ float roundT(float v);
+template <> __device__ __forceinline__ float roundT<float>(float v) { return v; }
+template <> __device__ __forceinline__ float roundT<__bf16>(float v) { return bf2f(f2bf(v)); }
+
+static inline unsigned grid1d(long n, int cap = 4096) { return (unsigned)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
+
+// ---------------------------------------------------------------------------------------------
+// generic helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void kk_fill_f32(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+int k_fill_f32(float* p, long n, float v, hipStream_t st) {
+  if (n <= 0) return OK;
+  hipLaunchKernelGGL(kk_fill_f32, dim3(grid1d(n)), dim3(256), 0, st, p, n, v);
+  AVMOE_CHECK_LAUNCH("fill_f32");
+  return OK;
+}
+
+template <typename T>
+__global__ void kk_cast(const float* src, long rows, int cols, long ld_src, void* dst_, long ld_dst) {
+  T* dst = (T*)dst_;
+  const long total = rows * ld_dst;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ld_dst;
+    const int c = (int)(i % ld_dst);
+    stT<T>(dst, i, c < cols ? src[r * ld_src + c] : 0.f);
+  }
+}
+int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, void* dst, long ld_dst, hipStream_t st) {
+  const long total = rows * ld_dst;
+  if (total <= 0) return OK;
+  DISPATCH_T(bf16_out, kk_cast, dim3(grid1d(total)), dim3(256), 0, st, src, rows, cols, ld_src, dst, ld_dst);
+  AVMOE_CHECK_LAUNCH("cast");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation: remap operands   (conv_adapter / fc: net_trans_v3.py:445-446,469-470)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void kk_prep_remap(const float* Wc, const float* bc, const float* Wf, void* WcK_, void* WcT_, void* WfT_,
+                              int N, int M, int Mk, int Np, int C, int Cy) {
+  T* WcK = (T*)WcK_; T* WcT = (T*)WcT_; T* WfT = (T*)WfT_;
+  const long n1 = (long)N * Mk, n2 = (long)(M + 1) * Np, n3 = (long)C * Cy;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3; i += (long)gridDim.x * 256) {
+    if (i < n1) {                                   // WcK[n] = [Wc[n,:] | bc[n] | 1 | 0..]
+      const int n = (int)(i / Mk), m = (int)(i % Mk);
+      stT<T>(WcK, i, m < M ? Wc[(long)n * M + m] : (m == M ? bc[n] : (m == M + 1 ? 1.f : 0.f)));
+    } else if (i < n1 + n2) {                       // WcT[m] = Wc[:,m]^T ; row M = bc
+      const long j = i - n1;
+      const int m = (int)(j / Np), n = (int)(j % Np);
+      stT<T>(WcT, j, n < N ? (m < M ? Wc[(long)n * M + m] : bc[n]) : 0.f);
+    } else {
+      const long j = i - n1 - n2;
+      stT<T>(WfT, j, Wf[j]);
+    }
+  }
+}
+
+// rw[c] = sum_y WfT[c][y] (T-rounded weights, so the folded bias matches the GEMM operands);
+// wbar[m] = mean_n Wc[n][m]; scal[0] = mean(bc)
+template <typename T>
+__global__ void kk_prep_remap2(const void* WfT_, const float* Wc, const float* bc, float* rw, float* wbar, float* scal,
+                               int N, int M, int Mb, int C, int Cy) {
+  const T* WfT = (const T*)WfT_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
+    float s = 0.f;
+    for (int y = lane; y < Cy; y += 64) s += ldT<T>(WfT, (long)c * Cy + y);
+    s = wave_sum(s);
+    if (lane == 0) rw[c] = s;
+  }
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < Mb; m += gridDim.x * 256) {
+    float s = 0.f;
+    if (m < M) for (int n = 0; n < N; ++n) s += Wc[(long)n * M + m];
+    wbar[m] = m < M ? s / (float)N : 0.f;
+  }
+  if (blockIdx.x == 0 && wave == 0) {
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += bc[n];
+    s = wave_sum(s);
+    if (lane == 0) scal[0] = s / (float)N;
+  }
+}
+
+int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, const float* Wf, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!Wc || !bc || !Wf) { set_last_error("moe: conv_adapter / fc parameters missing"); return ERR_BAD_ARG; }
+  const long tot = (long)d.N * d.Mk + (long)(d.M + 1) * d.Np + (long)d.C * d.Cy;
+  DISPATCH_T(d.bf16, kk_prep_remap, dim3(grid1d(tot)), dim3(256), 0, st, Wc, bc, Wf, (void*)(saved + pl.o_WcK),
+             (void*)(saved + pl.o_WcT), (void*)(saved + pl.o_WfT), d.N, d.M, d.Mk, d.Np, d.C, d.Cy);
+  DISPATCH_T(d.bf16, kk_prep_remap2, dim3(64), dim3(256), 0, st, (const void*)(saved + pl.o_WfT), Wc, bc,
+             (float*)(saved + pl.o_rw), (float*)(saved + pl.o_wbar), (float*)(saved + pl.o_scal), d.N, d.M, d.Mb, d.C, d.Cy);
+  AVMOE_CHECK_LAUNCH("prep_remap");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation: experts.  One block per row (i, e, jp) of Wt = Wd * gamma_before  (LayerNorm
+// folded into the down projection: net_trans_v3.py:392-395), plus the stacked latent tokens in T.
+// ---------------------------------------------------------------------------------------------
+struct PrepExpArgs {
+  P16 down, lnbw, lnbb, tok;
+  int e_of_lat[MAX_E];
+  int E, g, dg, dgp, Cg, C, K, KL, ln_before;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) kk_prep_experts(PrepExpArgs a, void* Wt_, float* wsum, float* dconst, void* T0T_) {
+  T* Wt = (T*)Wt_; T* T0T = (T*)T0T_;
+  __shared__ float red[4];
+  const int nrow = a.g * a.E * a.dgp;
+  if ((int)blockIdx.x < nrow) {
+    const int row = blockIdx.x;
+    const int i = row / (a.E * a.dgp), e = (row / a.dgp) % a.E, jp = row % a.dgp;
+    const float* Wd = a.down.p[e];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x; c < a.Cg; c += 256) {
+      const float w = jp < a.dg ? Wd[(long)(i * a.dg + jp) * a.Cg + c] : 0.f;
+      const float gm = a.ln_before ? a.lnbw.p[e][i * a.Cg + c] : 1.f;
+      const float bt = a.ln_before ? a.lnbb.p[e][i * a.Cg + c] : 0.f;
+      const float wt = roundT<T>(w * gm);
+      stT<T>(Wt, (long)row * a.Cg + c, wt);
+      s1 += wt;
+      s2 += w * bt;
+    }
+    s1 = block_sum256(s1, red);
+    s2 = block_sum256(s2, red);
+    if (threadIdx.x == 0) { wsum[row] = s1; dconst[row] = s2; }
+  } else {
+    const int r = blockIdx.x - nrow;
+    if (r < a.KL) {
+      const int l = r / a.K, k = r % a.K;
+      const float* tk = a.tok.p[a.e_of_lat[l]];
+      for (int c = threadIdx.x; c < a.C; c += 256) stT<T>(T0T, (long)r * a.C + c, tk[(long)k * a.C + c]);
+    }
+  }
+}
+
+int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  PrepExpArgs a;
+  for (int e = 0; e < MAX_E; ++e) {
+    a.down.p[e] = prm.e[e].down_w; a.lnbw.p[e] = prm.e[e].lnb_w; a.lnbb.p[e] = prm.e[e].lnb_b;
+    a.tok.p[e] = prm.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e];
+  }
+  for (int e = 0; e < d.E; ++e) {
+    const avmoe_expert_ptrs& x = prm.e[e];
+    if (!x.down_w || !x.up_w) { set_last_error("moe: expert %d has no down/up weights", e); return ERR_BAD_ARG; }
+    if (d.ln_before && (!x.lnb_w || !x.lnb_b)) { set_last_error("moe: expert %d lacks ln_before", e); return ERR_BAD_ARG; }
+    if (d.ln_post && (!x.lnp_w || !x.lnp_b)) { set_last_error("moe: expert %d lacks ln_post", e); return ERR_BAD_ARG; }
+    if (d.use_gate && !x.gate) { set_last_error("moe: expert %d lacks gate", e); return ERR_BAD_ARG; }
+    if (d.use_bn && (!x.bn1_w || !x.bn1_b || !x.bn2_w || !x.bn2_b || !x.bn1_rm || !x.bn1_rv || !x.bn2_rm || !x.bn2_rv)) {
+      set_last_error("moe: expert %d lacks BatchNorm parameters / running statistics", e); return ERR_BAD_ARG;
+    }
+    if (d.lat_of_e[e] >= 0 && (!x.my_tokens || !x.gate_lat)) { set_last_error("moe: expert %d lacks my_tokens / gate_av", e); return ERR_BAD_ARG; }
+  }
+  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.C = d.C; a.K = d.K; a.KL = d.KL; a.ln_before = d.ln_before;
+  const int nblk = d.g * d.E * d.dgp + d.KL;
+  DISPATCH_T(d.bf16, kk_prep_experts, dim3(nblk), dim3(256), 0, st, a, (void*)(saved + pl.o_Wt),
+             (float*)(saved + pl.o_wsum), (float*)(saved + pl.o_dconst), (void*)(saved + pl.o_T0T));
+  AVMOE_CHECK_LAUNCH("prep_experts");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// token statistics: row sum / sum of squares (one wave per row, 16-byte loads), column means
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) kk_rowstats(const void* X_, long rows, int C, float* out) {
+  const T* X = (const T*)X_;
+  constexpr int EPV = 16 / sizeof(T);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const u32x4_t* p = (const u32x4_t*)(X + row * C);
+    float s = 0.f, ss = 0.f;
+    for (int v = lane; v < C / EPV; v += 64) {
+      const u32x4_t w = p[v];
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        // NB: __builtin_bit_cast(float, w[e]) on a vector-element lvalue miscompiles (ROCm 7.2): go through a scalar
+        for (int e = 0; e < 4; ++e) { const unsigned int bits = w[e]; const float x = __uint_as_float(bits); s += x; ss += x * x; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = bf2f((unsigned short)(w[e] & 0xFFFFu)), x1 = bf2f((unsigned short)(w[e] >> 16));
+          s += x0 + x1; ss += x0 * x0 + x1 * x1;
+        }
+      }
+    }
+    s = wave_sum(s); ss = wave_sum(ss);
+    if (lane == 0) { out[row] = s; out[rows + row] = ss; }
+  }
+}
+int k_rowstats(int bf16, const void* X, long rows, int C, float* out, hipStream_t st) {
+  if (rows <= 0) return OK;
+  DISPATCH_T(bf16, kk_rowstats, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, X, rows, C, out);
+  AVMOE_CHECK_LAUNCH("rowstats");
+  return OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) kk_colmean(const void* X_, int N, int C, float* out, long out_ld) {
+  const T* X = (const T*)X_;
+  const int s = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const T* p = X + (long)s * N * C + c;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc += ldT<T>(p, (long)n * C);
+  out[(long)s * out_ld + c] = acc / (float)N;
+}
+int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out_ld, hipStream_t st) {
+  DISPATCH_T(bf16, kk_colmean, dim3(cdiv(C, 256), S), dim3(256), 0, st, X, N, C, out, out_ld);
+  AVMOE_CHECK_LAUNCH("colmean");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hop 1 helpers
+// ---------------------------------------------------------------------------------------------
+// Rext[s][kc][M] = qr[kc], [M+1] = qb[kc], rest of the padding 0 ; BmX[s][Kcy][:] = wbar ;
+// Text[s][KL][:] = 1 (ones row), Text[s][KL+1][:] = 0 (dm1/N row, written by the backward)
+template <typename T>
+__global__ void kk_fill_ext(void* Rext_, const float* qrqb, void* BmX_, const float* wbar, void* Text_, int S, int Kcy,
+                            int Kcyb, int M, int Mk, int Mb, int KL, int KLT, int C) {
+  T* Rext = (T*)Rext_; T* BmX = (T*)BmX_; T* Text = (T*)Text_;
+  const int padw = Mk - M;
+  const long n1 = (long)S * Kcy * padw, n2 = (long)S * Mb, n3 = (long)S * 2 * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3; i += (long)gridDim.x * 256) {
+    if (i < n1) {
+      const int w = (int)(i % padw);
+      const long row = i / padw;                  // s * Kcy + kc
+      const int kc = (int)(row % Kcy);
+      stT<T>(Rext, row * Mk + M + w, w == 0 ? qrqb[kc] : (w == 1 ? qrqb[Kcy + kc] : 0.f));
+    } else if (i < n1 + n2) {
+      const long j = i - n1;
+      const int s = (int)(j / Mb), m = (int)(j % Mb);
+      stT<T>(BmX, ((long)s * Kcyb + Kcy) * Mb + m, wbar[m]);
+    } else {
+      const long j = i - n1 - n2;
+      const int s = (int)(j / (2 * C)), rr = (int)((j / C) % 2), c = (int)(j % C);
+      stT<T>(Text, ((long)s * KLT + KL + rr) * C + c, rr == 0 ? 1.f : 0.f);
+    }
+  }
+}
+int k_fill_ext(const Plan& pl, char* saved, hipStream_t st) {
+  const Dims& d = pl.d;
+  const long tot = (long)d.S * d.Kcy * (d.Mk - d.M) + (long)d.S * d.Mb + (long)d.S * 2 * d.C;
+  DISPATCH_T(d.bf16, kk_fill_ext, dim3(grid1d(tot)), dim3(256), 0, st, (void*)(saved + pl.o_Rext),
+             (const float*)(saved + pl.o_qrqb), (void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_wbar),
+             (void*)(saved + pl.o_Text), d.S, d.Kcy, d.Kcyb, d.M, d.Mk, d.Mb, d.KL, d.KLT, d.C);
+  AVMOE_CHECK_LAUNCH("fill_ext");
+  return OK;
+}
+
+// qr[kc] = T0[kc] . rw ; qb[kc] = T0[kc] . bf   (one wave per latent row)
+template <typename T>
+__global__ void __launch_bounds__(256) kk_qrqb(const void* T0T_, const float* rw, const float* bf, float* qrqb, int Kcy, int C) {
+  const T* T0T = (const T*)T0T_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kc = blockIdx.x * 4 + wave;
+  if (kc >= Kcy) return;
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < C; c += 64) { const float t = ldT<T>(T0T, (long)kc * C + c); a += t * rw[c]; b += t * bf[c]; }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { qrqb[kc] = a; qrqb[Kcy + kc] = b; }
+}
+int k_qrqb(const Plan& pl, char* saved, const float* bf, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (d.Kcy <= 0) return OK;
+  DISPATCH_T(d.bf16, kk_qrqb, dim3(cdiv(d.Kcy, 4)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T),
+             (const float*)(saved + pl.o_rw), bf, (float*)(saved + pl.o_qrqb), d.Kcy, d.C);
+  AVMOE_CHECK_LAUNCH("qrqb");
+  return OK;
+}
+
+// row softmax (unscaled logits, net_trans_v3.py:381): f32 in -> T out, padding columns zeroed
+template <typename T>
+__global__ void __launch_bounds__(256) kk_softmax_rows(const float* in, long rows, int n, int ld_in, void* out_, int ld_out) {
+  T* out = (T*)out_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* p = in + row * ld_in;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, p[j]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int j = lane; j < n; j += 64) sm += __expf(p[j] - mx);
+    sm = wave_sum(sm);
+    const float inv = 1.f / sm;
+    for (int j = lane; j < ld_out; j += 64) stT<T>(out, row * ld_out + j, j < n ? __expf(p[j] - mx) * inv : 0.f);
+  }
+}
+int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, hipStream_t st) {
+  if (rows <= 0) return OK;
+  DISPATCH_T(bf16_out, kk_softmax_rows, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, in, rows,
+             n, ld_in, out, ld_out);
+  AVMOE_CHECK_LAUNCH("softmax_rows");
+  return OK;
+}
+
+// Text[s][row] = T0 + TV + ab (x) rw + bf   (cross-modal slots)  |  T0 + TV  (latent-on-X slots)
+// and the router's second mean  rin[s][C + c] = TV[s][Kcy] + mean(bc) rw + bf
+struct FinishTArgs {
+  P16 tok; int e_of_lat[MAX_E];
+  int S, C, K, KL, KLT, Kcy, Kcyb, Kcx, Mb, M, src, lat0;
+};
+template <typename T>
+__global__ void kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, const float* rw, const float* bf,
+                            const float* scal, void* Text_, float* rin) {
+  const T* BmX = (const T*)BmX_;
+  T* Text = (T*)Text_;
+  const int rows = a.src == 0 ? a.Kcyb : a.Kcx;
+  const long total = (long)a.S * rows * a.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % a.C);
+    const int kr = (int)((i / a.C) % rows);
+    const int s = (int)(i / ((long)a.C * rows));
+    const float tv = TV[i];
+    if (a.src == 0 && kr == a.Kcy) {
+      rin[(long)s * 2 * a.C + a.C + c] = tv + scal[0] * rw[c] + bf[c];
+      continue;
+    }
+    const int slot = a.lat0 + kr / a.K, k = kr % a.K;
+    float v = a.tok.p[a.e_of_lat[slot]][(long)k * a.C + c] + tv;
+    if (a.src == 0) v += ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) * rw[c] + bf[c];
+    stT<T>(Text, ((long)s * a.KLT + (long)slot * a.K + k) * a.C + c, v);
+  }
+}
+int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src, hipStream_t st) {
+  const Dims& d = pl.d;
+  FinishTArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.tok.p[e] = prm.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e]; }
+  a.S = d.S; a.C = d.C; a.K = d.K; a.KL = d.KL; a.KLT = d.KLT; a.Kcy = d.Kcy; a.Kcyb = d.Kcyb; a.Kcx = d.Kcx;
+  a.Mb = d.Mb; a.M = d.M; a.src = src; a.lat0 = src == 0 ? 0 : d.Ey;
+  const int rows = src == 0 ? d.Kcyb : d.Kcx;
+  if (rows <= 0) return OK;
+  const long total = (long)d.S * rows * d.C;
+  DISPATCH_T(d.bf16, kk_finish_T, dim3(grid1d(total, 8192)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_TV),
+             (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_rw), (const float*)prm.fc_b,
+             (const float*)(saved + pl.o_scal), (void*)(saved + pl.o_Text), (float*)(saved + pl.o_rin));
+  AVMOE_CHECK_LAUNCH("finish_T");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// router  (net_trans_v3.py:460-466,477-479): one block per frame, fp32, fixed reduction order.
+// ---------------------------------------------------------------------------------------------
+struct RouterArgs {
+  const float *W1, *b1, *W2, *b2, *W3, *b3, *noise;
+  int C2, E, S;
+};
+__global__ void __launch_bounds__(256) kk_router(RouterArgs a, const float* rin, float* rh1, float* rh2, float* probs,
+                                                 float* probs_out, int64_t* idx_out) {
+  extern __shared__ float sm[];
+  float* s_in = sm;                 // C2
+  float* s_h1 = sm + a.C2;          // 128
+  float* s_h2 = s_h1 + 128;         // 32
+  float* s_lg = s_h2 + 32;          // E
+  const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < a.C2; i += 256) s_in[i] = rin[(long)s * a.C2 + i];
+  __syncthreads();
+  for (int j = wave; j < 128; j += 4) {
+    float acc = 0.f;
+    for (int i = lane; i < a.C2; i += 64) acc += a.W1[(long)j * a.C2 + i] * s_in[i];
+    acc = wave_sum(acc);
+    if (lane == 0) { const float h = fmaxf(acc + a.b1[j], 0.f); s_h1[j] = h; rh1[(long)s * 128 + j] = h; }
+  }
+  __syncthreads();
+  for (int j = wave; j < 32; j += 4) {
+    float acc = 0.f;
+    for (int i = lane; i < 128; i += 64) acc += a.W2[j * 128 + i] * s_h1[i];
+    acc = wave_sum(acc);
+    if (lane == 0) { const float h = fmaxf(acc + a.b2[j], 0.f); s_h2[j] = h; rh2[(long)s * 32 + j] = h; }
+  }
+  __syncthreads();
+  for (int j = wave; j < a.E; j += 4) {
+    float acc = lane < 32 ? a.W3[j * 32 + lane] * s_h2[lane] : 0.f;
+    acc = wave_sum(acc);
+    if (lane == 0) s_lg[j] = acc + a.b3[j] + (a.noise ? a.noise[(long)s * a.E + j] : 0.f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = s_lg[0];
+    for (int e = 1; e < a.E; ++e) mx = fmaxf(mx, s_lg[e]);
+    float sum = 0.f;
+    for (int e = 0; e < a.E; ++e) sum += expf(s_lg[e] - mx);
+    int best = 0; float bp = -1.f;
+    for (int e = 0; e < a.E; ++e) {
+      const float p = expf(s_lg[e] - mx) / sum;
+      probs[(long)s * a.E + e] = p;
+      if (probs_out) probs_out[(long)s * a.E + e] = p;
+      if (p > bp) { bp = p; best = e; }            // strict '>' : first maximum wins (torch.argmax)
+    }
+    if (idx_out) idx_out[s] = best;
+  }
+}
+// load-balancing loss  -sum_e log(mean_s p[s,e])  (reference quirk: PVT_AVSModel_v2.py:314-318)
+__global__ void __launch_bounds__(256) kk_lb_loss(const float* probs, int S, int E, float* lb) {
+  __shared__ float red[4];
+  float total = 0.f;
+  for (int e = 0; e < E; ++e) {
+    float acc = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) acc += probs[(long)s * E + e];
+    acc = block_sum256(acc, red);
+    total += -logf(acc / (float)S);
+  }
+  if (threadIdx.x == 0) *lb = total;
+}
+int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
+             int64_t* idx_out, float* lb_out, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!prm.r0_w || !prm.r0_b || !prm.r2_w || !prm.r2_b || !prm.r4_w || !prm.r4_b) {
+    set_last_error("moe: router parameters missing"); return ERR_BAD_ARG;
+  }
+  RouterArgs a{prm.r0_w, prm.r0_b, prm.r2_w, prm.r2_b, prm.r4_w, prm.r4_b, noise, 2 * d.C, d.E, d.S};
+  const size_t sh = (size_t)(2 * d.C + 128 + 32 + d.E) * sizeof(float);
+  hipLaunchKernelGGL(kk_router, dim3(d.S), dim3(256), sh, st, a, (const float*)(saved + pl.o_rin),
+                     (float*)(saved + pl.o_rh1), (float*)(saved + pl.o_rh2), (float*)(saved + pl.o_probs), probs_out, idx_out);
+  AVMOE_CHECK_LAUNCH("router");
+  if (lb_out) {
+    if (d.lb_loss) hipLaunchKernelGGL(kk_lb_loss, dim3(1), dim3(256), 0, st, (const float*)(saved + pl.o_probs), d.S, d.E, lb_out);
+    else hipLaunchKernelGGL(kk_fill_f32, dim3(1), dim3(256), 0, st, lb_out, 1L, 0.f);
+    AVMOE_CHECK_LAUNCH("lb_loss");
+  }
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PRE_SMALL: hop-2 softmax, LayerNorm statistics from K-space, LN-folded down projection, BN1 sums.
+// grid (blocks per sample, S); one wave walks tokens; experts outermost (per-sample K x K and K x DD
+// matrices of the current expert are staged in LDS).       net_trans_v3.py:385-395
+// ---------------------------------------------------------------------------------------------
+struct PreArgs {
+  P16 glat;
+  int lat_of_e[MAX_E];
+  int S, N, C, E, K, El, KLT, KLp, DD, DZ, dgp, g, NT, ln_before;
+  float ln_eps;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) kk_pre_small(PreArgs a, float* Z, const float* L2, const float* sxs, const float* TT,
+                                                    const float* TW, const float* Tsum, const float* wsum,
+                                                    const float* dconst, void* aout_, float* rmu, float* colpart) {
+  T* aout = (T*)aout_;
+  extern __shared__ float sm[];
+  const int K = a.K, DD = a.DD;
+  float* s_TT = sm;                        // K*K
+  float* s_TW = s_TT + K * K;              // K*DD
+  float* s_tb = s_TW + K * DD;             // K
+  float* s_a = s_tb + K;                   // 4 * K   per-wave softmax scratch
+  float* s_red = s_a + 4 * K;              // 4 * 2 * DD
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (a.N + gridDim.x - 1) / gridDim.x;
+  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  constexpr int DR = 4, KR = 2;
+
+  for (int e = 0; e < a.E; ++e) {
+    const int l = a.lat_of_e[e];
+    float gv = 0.f;
+    __syncthreads();
+    if (l >= 0) {
+      gv = a.glat.p[e][0];
+      const float* tt = TT + ((long)s * a.El + l) * K * K;                  // TT[s][l]
+      for (int i = threadIdx.x; i < K * K; i += 256) s_TT[i] = tt[i];
+      for (int i = threadIdx.x; i < K * DD; i += 256) {
+        const int k = i / DD, dd = i % DD;
+        const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
+        s_TW[i] = TW[((long)s * a.KLT + (long)l * K + k) * a.DZ + col];
+      }
+      for (int i = threadIdx.x; i < K; i += 256) s_tb[i] = Tsum[(long)s * a.KLT + (long)l * K + i] / (float)a.C;
+    }
+    __syncthreads();
+    float csum[DR], csq[DR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { csum[u] = 0.f; csq[u] = 0.f; }
+    for (int n = n_beg + wave; n < n_end; n += 4) {
+      const long t = (long)s * a.N + n;
+      float Sx = sxs[t], Sxx = sxs[a.NT + t];
+      float* aw = s_a + wave * K;
+      if (l >= 0) {
+        const float* l2 = L2 + t * a.KLp + (long)l * K;
+        float lv[KR], av[KR];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < KR; ++u) { const int k = lane + 64 * u; lv[u] = k < K ? l2[k] : -INFINITY; mx = fmaxf(mx, lv[u]); }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < KR; ++u) { const int k = lane + 64 * u; av[u] = k < K ? __expf(lv[u] - mx) : 0.f; sum += av[u]; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        float u1 = 0.f, u2 = 0.f;
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+          const int k = lane + 64 * u;
+          if (k < K) {
+            av[u] = roundT<T>(av[u] * inv);
+            stT<T>(aout, t * a.KLp + (long)l * K + k, av[u]);
+            aw[k] = av[u];
+            u1 += av[u] * s_tb[k];
+            u2 += av[u] * lv[u];
+          }
+        }
+        wave_lds_sync();
+        float u3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+          const int k = lane + 64 * u;
+          if (k < K) {
+            float w = 0.f;
+            for (int k2 = 0; k2 < K; ++k2) w += s_TT[k2 * K + k] * aw[k2];     // TT symmetric: row k2, column k
+            u3 += av[u] * w;
+          }
+        }
+        u1 = wave_sum(u1); u2 = wave_sum(u2); u3 = wave_sum(u3);
+        Sx += gv * (float)a.C * u1;
+        Sxx += 2.f * gv * u2 + gv * gv * u3;
+      }
+      float mu = 0.f, r = 1.f;
+      if (a.ln_before) {
+        mu = Sx / (float)a.C;
+        const float var = Sxx / (float)a.C - mu * mu;
+        r = rsqrtf(fmaxf(var, 0.f) + a.ln_eps);
+      }
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        if (dd < DD) {
+          const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
+          float zr = Z[t * a.DZ + col];
+          if (l >= 0) {
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) acc += aw[k] * s_TW[k * DD + dd];
+            zr += gv * acc;
+          }
+          const float z = a.ln_before ? r * (zr - mu * wsum[col]) + dconst[col] : zr;
+          Z[t * a.DZ + col] = z;
+          csum[u] += z; csq[u] += z * z;
+        }
+      }
+      if (lane == 0) { rmu[t * a.E + e] = r; rmu[(long)a.NT * a.E + t * a.E + e] = mu; }
+    }
+    // block-level column partials of this expert's columns
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DR; ++u) {
+      const int dd = lane + 64 * u;
+      if (dd < DD) { s_red[(wave * 2 + 0) * DD + dd] = csum[u]; s_red[(wave * 2 + 1) * DD + dd] = csq[u]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * DD; i += 256) {
+      const int which = i / DD, dd = i % DD;
+      const float v = s_red[(0 * 2 + which) * DD + dd] + s_red[(1 * 2 + which) * DD + dd] +
+                      s_red[(2 * 2 + which) * DD + dd] + s_red[(3 * 2 + which) * DD + dd];
+      const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
+      colpart[((long)blk * 4 + which) * a.DZ + col] = v;
+    }
+  }
+}
+
+static void tok_grid(const Dims& d, dim3* grid) { *grid = dim3((unsigned)(d.nblk_tok / d.S), (unsigned)d.S); }
+
+int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  PreArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.K = d.K; a.El = d.El; a.KLT = d.KLT; a.KLp = d.KLp; a.DD = d.DD; a.DZ = d.DZ;
+  a.dgp = d.dgp; a.g = d.g; a.NT = d.NT; a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
+  const size_t sh = (size_t)(d.K * d.K + d.K * d.DD + d.K + 4 * d.K + 8 * d.DD) * sizeof(float);
+  dim3 grid; tok_grid(d, &grid);
+  if (sh > 65536) {
+    static bool done[2] = {false, false};
+    if (!done[d.bf16]) {
+      hipError_t e = d.bf16 ? hipFuncSetAttribute((const void*)kk_pre_small<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                            : hipFuncSetAttribute((const void*)kk_pre_small<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { set_last_error("pre_small: LDS attribute: %s", hipGetErrorString(e)); return ERR_LAUNCH; }
+      done[d.bf16] = true;
+    }
+  }
+  if (sh > 160 * 1024) { set_last_error("pre_small: K=%d, DD=%d need %zu B of LDS", d.K, d.DD, sh); return ERR_UNSUPPORTED; }
+  DISPATCH_T(d.bf16, kk_pre_small, grid, dim3(256), sh, st, a, (float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2),
+             (const float*)(saved + pl.o_sx), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW),
+             (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst),
+             (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu), (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("pre_small");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN1 finalize: column partials -> batch mean / biased var -> (mean, rstd, scale, shift); running
+// statistics updated in place (momentum, unbiased var).  Eval mode uses the running statistics.
+// net_trans_v3.py:397-398 ; torch BatchNorm2d semantics.
+// ---------------------------------------------------------------------------------------------
+struct Bn1Args {
+  P16 w, b; W16 rm, rv;
+  int E, g, dg, dgp, DZ, nblk, NT, use_bn, training;
+  float eps, momentum;
+};
+__global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.DZ) return;
+  const int i = col / (a.E * a.dgp), e = (col / a.dgp) % a.E, jp = col % a.dgp;
+  float mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
+  if (jp < a.dg) {
+    const int j = i * a.dg + jp;
+    if (!a.use_bn) { mean = 0.f; rstd = 1.f; sc = 1.f; sh = 0.f; }
+    else {
+      float var;
+      if (a.training) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 0) * a.DZ + col]; s1 += colpart[((long)b * 4 + 1) * a.DZ + col]; }
+        const double m = s0 / a.NT;
+        const double v = fmax(s1 / a.NT - m * m, 0.0);
+        mean = (float)m; var = (float)v;
+        const double unb = a.NT > 1 ? v * ((double)a.NT / (a.NT - 1)) : v;
+        a.rm.p[e][j] = (1.f - a.momentum) * a.rm.p[e][j] + a.momentum * mean;
+        a.rv.p[e][j] = (1.f - a.momentum) * a.rv.p[e][j] + a.momentum * (float)unb;
+      } else { mean = a.rm.p[e][j]; var = a.rv.p[e][j]; }
+      rstd = rsqrtf(var + a.eps);
+      sc = a.w.p[e][j] * rstd;
+      sh = a.b.p[e][j] - mean * sc;
+    }
+  }
+  bn1[col] = mean; bn1[a.DZ + col] = rstd; bn1[2 * a.DZ + col] = sc; bn1[3 * a.DZ + col] = sh;
+}
+int k_bn1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  Bn1Args a;
+  for (int e = 0; e < MAX_E; ++e) { a.w.p[e] = prm.e[e].bn1_w; a.b.p[e] = prm.e[e].bn1_b; a.rm.p[e] = prm.e[e].bn1_rm; a.rv.p[e] = prm.e[e].bn1_rv; }
+  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.DZ = d.DZ; a.nblk = d.nblk_tok; a.NT = d.NT; a.use_bn = d.use_bn;
+  a.training = d.training; a.eps = d.bn_eps; a.momentum = d.bn_momentum;
+  hipLaunchKernelGGL(kk_bn1_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colpart),
+                     (float*)(saved + pl.o_bn1));
+  AVMOE_CHECK_LAUNCH("bn1_finalize");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MID: z' = act(z * scale + shift) -> Zp (T, operand of the second-moment GEMM) + column sums of z'
+// (thread <-> column, rows looped: no reduction inside the block).   net_trans_v3.py:397-400
+// ---------------------------------------------------------------------------------------------
+struct MidArgs { int relu_of_e[MAX_E]; int E, dgp, DZ, NT; };
+template <typename T>
+__global__ void __launch_bounds__(256) kk_mid(MidArgs a, const float* Z, const float* bn1, void* Zp_, float* colpart, int rows_per_blk) {
+  T* Zp = (T*)Zp_;
+  const long r0 = (long)blockIdx.x * rows_per_blk, r1 = min((long)a.NT, r0 + rows_per_blk);
+  for (int col = threadIdx.x; col < a.DZ; col += 256) {
+    const float sc = bn1[2 * a.DZ + col], sh = bn1[3 * a.DZ + col];
+    const bool relu = a.relu_of_e[(col / a.dgp) % a.E];
+    float acc = 0.f;
+    for (long t = r0; t < r1; ++t) {
+      float y = Z[t * a.DZ + col] * sc + sh;
+      if (relu) y = fmaxf(y, 0.f);
+      y = roundT<T>(y);
+      stT<T>(Zp, t * a.DZ + col, y);
+      acc += y;
+    }
+    colpart[((long)blockIdx.x * 4 + 0) * a.DZ + col] = acc;
+  }
+}
+__global__ void kk_colsum_finalize(const float* colpart, int nblk, int DZ, int slot, float scale, float* out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= DZ) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += colpart[((long)b * 4 + slot) * DZ + col];
+  out[col] = (float)(s * scale);
+}
+int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  const Dims& d = pl.d;
+  MidArgs a;
+  for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
+  a.E = d.E; a.dgp = d.dgp; a.DZ = d.DZ; a.NT = d.NT;
+  const int nblk = d.nblk_tok;
+  const int rpb = cdiv(d.NT, nblk);
+  DISPATCH_T(d.bf16, kk_mid, dim3(nblk), dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (void*)(scratch + pl.o_Zp), (float*)(scratch + pl.o_colpart), rpb);
+  hipLaunchKernelGGL(kk_colsum_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, (const float*)(scratch + pl.o_colpart), nblk,
+                     d.DZ, 0, 1.f / (float)d.NT, (float*)(saved + pl.o_mz));
+  AVMOE_CHECK_LAUNCH("mid");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// POST_PREP (weight space): BN2 statistics of o = Wu z' from the d-space moments, folded output
+// weights Bpost, and the d-space Gram / sums the LayerNorm-post statistics need.
+// net_trans_v3.py:401-403,430-434
+// ---------------------------------------------------------------------------------------------
+struct PostPrepArgs {
+  P16 up, w2, b2, lpw, lpb; W16 rm, rv;
+  int E, g, dg, dgp, Cg, C, KPp, NT, use_bn, training, ln_post;
+  float eps, momentum;
+};
+// thread per (e, c): mo, rs2, k2, h2
+__global__ void kk_bn2_stats(PostPrepArgs a, const float* mz, const float* Szz, float* bn2) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.E * a.C) return;
+  const int e = idx / a.C, c = idx % a.C, i = c / a.Cg;
+  float mo = 0.f, rs2 = 1.f, k2 = 1.f, h2 = 0.f;
+  if (a.use_bn) {
+    float v2;
+    if (a.training) {
+      const float* wu = a.up.p[e] + (long)c * a.dg;
+      const int cb = i * a.E + e;
+      const float* m = mz + (long)cb * a.dgp;
+      const float* S = Szz + (long)cb * a.dgp * a.dgp;
+      double dmo = 0.0, eo2 = 0.0;
+      for (int j = 0; j < a.dg; ++j) {
+        dmo += (double)wu[j] * m[j];
+        double row = 0.0;
+        for (int l = 0; l < a.dg; ++l) row += (double)S[j * a.dgp + l] * wu[l];
+        eo2 += (double)wu[j] * row;
+      }
+      mo = (float)dmo;
+      const double v = fmax(eo2 - dmo * dmo, 0.0);
+      v2 = (float)v;
+      const double unb = a.NT > 1 ? v * ((double)a.NT / (a.NT - 1)) : v;
+      a.rm.p[e][c] = (1.f - a.momentum) * a.rm.p[e][c] + a.momentum * mo;
+      a.rv.p[e][c] = (1.f - a.momentum) * a.rv.p[e][c] + a.momentum * (float)unb;
+    } else { mo = a.rm.p[e][c]; v2 = a.rv.p[e][c]; }
+    rs2 = rsqrtf(v2 + a.eps);
+    k2 = a.w2.p[e][c] * rs2;
+    h2 = a.b2.p[e][c] - mo * k2;
+  }
+  const long EC = (long)a.E * a.C;
+  bn2[idx] = mo; bn2[EC + idx] = rs2; bn2[2 * EC + idx] = k2; bn2[3 * EC + idx] = h2;
+}
+// thread per (c, k'): Bpost[c][k']
+template <typename T>
+__global__ void kk_build_bpost(PostPrepArgs a, const float* bn2, void* Bpost_) {
+  T* Bpost = (T*)Bpost_;
+  const long total = (long)a.C * a.KPp;
+  const long EC = (long)a.E * a.C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx / a.KPp), kp = (int)(idx % a.KPp);
+    float v = 0.f;
+    if (kp < a.E * a.dgp) {
+      const int e = kp / a.dgp, jp = kp % a.dgp;
+      if (jp < a.dg) {
+        const float gp = a.ln_post ? a.lpw.p[e][c] : 1.f;
+        v = gp * a.up.p[e][(long)c * a.dg + jp] * bn2[2 * EC + (long)e * a.C + c];
+      }
+    } else if (kp < a.E * a.dgp + 3 * a.E) {
+      const int r = kp - a.E * a.dgp, e = r / 3, w = r % 3;
+      const float gp = a.ln_post ? a.lpw.p[e][c] : 1.f;
+      const float bp = a.ln_post ? a.lpb.p[e][c] : 0.f;
+      const float h2 = bn2[3 * EC + (long)e * a.C + c];
+      v = w == 0 ? gp * h2 : (w == 1 ? gp : bp);
+    }
+    stT<T>(Bpost, idx, v);
+  }
+}
+// block per (i, e): G = Wh^T Wh, usum, vh, H1, H2 partial (per group)
+__global__ void __launch_bounds__(256) kk_gq(PostPrepArgs a, const float* bn2, float* Gq, float* uvh) {
+  const int cb = blockIdx.x, i = cb / a.E, e = cb % a.E;
+  const long EC = (long)a.E * a.C;
+  const float* k2 = bn2 + 2 * EC + (long)e * a.C + (long)i * a.Cg;
+  const float* h2 = bn2 + 3 * EC + (long)e * a.C + (long)i * a.Cg;
+  const float* wu = a.up.p[e] + (long)i * a.Cg * a.dg;
+  const int DZ = a.g * a.E * a.dgp;
+  for (int pr = threadIdx.x; pr < a.dgp * a.dgp; pr += 256) {
+    const int j = pr / a.dgp, l = pr % a.dgp;
+    float acc = 0.f;
+    if (j < a.dg && l < a.dg)
+      for (int c = 0; c < a.Cg; ++c) { const float k = k2[c]; acc += (wu[(long)c * a.dg + j] * k) * (wu[(long)c * a.dg + l] * k); }
+    Gq[(long)cb * a.dgp * a.dgp + pr] = acc;
+  }
+  for (int j = threadIdx.x; j < a.dgp; j += 256) {
+    float us = 0.f, vh = 0.f;
+    if (j < a.dg) for (int c = 0; c < a.Cg; ++c) { const float wh = wu[(long)c * a.dg + j] * k2[c]; us += wh; vh += wh * h2[c]; }
+    uvh[(long)cb * a.dgp + j] = us;
+    uvh[DZ + (long)cb * a.dgp + j] = vh;
+  }
+  if (threadIdx.x == 0) {
+    float H1 = 0.f, H2 = 0.f;
+    for (int c = 0; c < a.Cg; ++c) { H1 += h2[c]; H2 += h2[c] * h2[c]; }
+    uvh[2 * DZ + cb] = H1;                       // [i][e] partials; consumers add the groups
+    uvh[2 * DZ + a.g * a.E + cb] = H2;
+  }
+}
+static void fill_postprep(const Dims& d, const avmoe_moe_ptrs& prm, PostPrepArgs* a) {
+  for (int e = 0; e < MAX_E; ++e) {
+    a->up.p[e] = prm.e[e].up_w; a->w2.p[e] = prm.e[e].bn2_w; a->b2.p[e] = prm.e[e].bn2_b;
+    a->lpw.p[e] = prm.e[e].lnp_w; a->lpb.p[e] = prm.e[e].lnp_b; a->rm.p[e] = prm.e[e].bn2_rm; a->rv.p[e] = prm.e[e].bn2_rv;
+  }
+  a->E = d.E; a->g = d.g; a->dg = d.dg; a->dgp = d.dgp; a->Cg = d.Cg; a->C = d.C; a->KPp = d.KPp; a->NT = d.NT;
+  a->use_bn = d.use_bn; a->training = d.training; a->ln_post = d.ln_post; a->eps = d.bn_eps; a->momentum = d.bn_momentum;
+}
+int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  PostPrepArgs a; fill_postprep(d, prm, &a);
+  hipLaunchKernelGGL(kk_bn2_stats, dim3(cdiv((long)d.E * d.C, 256)), dim3(256), 0, st, a, (const float*)(saved + pl.o_mz),
+                     (const float*)(saved + pl.o_Szz), (float*)(saved + pl.o_bn2));
+  DISPATCH_T(d.bf16, kk_build_bpost, dim3(grid1d((long)d.C * d.KPp)), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2),
+             (void*)(saved + pl.o_Bpost));
+  hipLaunchKernelGGL(kk_gq, dim3(d.g * d.E), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2), (float*)(saved + pl.o_Gq),
+                     (float*)(saved + pl.o_uvh));
+  AVMOE_CHECK_LAUNCH("post_prep");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// POST_SMALL: LayerNorm-post statistics from the d-space quadratic form, gate * prob, and the row of
+// Apost for the single output GEMM.   net_trans_v3.py:430-434,485-486
+// ---------------------------------------------------------------------------------------------
+struct PostArgs {
+  P16 gate; int relu_of_e[MAX_E];
+  int S, N, C, E, DD, DZ, dgp, g, KPp, NT, ln_post, use_gate;
+  float ln_eps;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) kk_post_small(PostArgs a, const float* Z, const float* bn1, const float* Gq, const float* uvh,
+                                                     const float* probs, void* Apost_, float* rpmup) {
+  T* Apost = (T*)Apost_;
+  extern __shared__ float sm[];
+  const int DD = a.DD, dgp = a.dgp;
+  float* s_G = sm;                         // g * dgp * dgp
+  float* s_us = s_G + a.g * dgp * dgp;     // DD
+  float* s_vh = s_us + DD;                 // DD
+  float* s_sc = s_vh + DD;                 // DD
+  float* s_sh = s_sc + DD;                 // DD
+  float* s_z = s_sh + DD;                  // 4 * DD
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (a.N + gridDim.x - 1) / gridDim.x;
+  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
+  constexpr int DR = 4;
+  for (int e = 0; e < a.E; ++e) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.g * dgp * dgp; i += 256) {
+      const int gi = i / (dgp * dgp);
+      s_G[i] = Gq[((long)(gi * a.E + e)) * dgp * dgp + (i % (dgp * dgp))];
+    }
+    float H1 = 0.f, H2 = 0.f;
+    for (int gi = 0; gi < a.g; ++gi) { H1 += uvh[2 * a.DZ + gi * a.E + e]; H2 += uvh[2 * a.DZ + a.g * a.E + gi * a.E + e]; }
+    for (int dd = threadIdx.x; dd < DD; dd += 256) {
+      const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
+      s_us[dd] = uvh[col]; s_vh[dd] = uvh[a.DZ + col];
+      s_sc[dd] = bn1[2 * a.DZ + col]; s_sh[dd] = bn1[3 * a.DZ + col];
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float q = probs[(long)s * a.E + e] * gate;
+    for (int n = n_beg + wave; n < n_end; n += 4) {
+      const long t = (long)s * a.N + n;
+      float zv[DR];
+      float* zs = s_z + wave * DD;
+      wave_lds_sync();
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        zv[u] = 0.f;
+        if (dd < DD) {
+          const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
+          float y = Z[t * a.DZ + col] * s_sc[dd] + s_sh[dd];
+          if (relu) y = fmaxf(y, 0.f);
+          zv[u] = y; zs[dd] = y;
+        }
+      }
+      wave_lds_sync();
+      float rp = 1.f, mup = 0.f;
+      if (a.ln_post) {
+        float so = 0.f, soo = 0.f;
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+          const int dd = lane + 64 * u;
+          if (dd < DD) {
+            const int gi = dd / dgp, jp = dd % dgp;
+            const float* Gg = s_G + gi * dgp * dgp;
+            float w = 0.f;
+            for (int l2 = 0; l2 < dgp; ++l2) w += Gg[l2 * dgp + jp] * zs[gi * dgp + l2];   // G symmetric
+            so += zv[u] * s_us[dd];
+            soo += zv[u] * (w + 2.f * s_vh[dd]);
+          }
+        }
+        so = wave_sum(so) + H1; soo = wave_sum(soo) + H2;
+        mup = so / (float)a.C;
+        const float varp = soo / (float)a.C - mup * mup;
+        rp = rsqrtf(fmaxf(varp, 0.f) + a.ln_eps);
+      }
+      const float qr = q * rp;
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        if (dd < DD) stT<T>(Apost, (t * a.g + dd / dgp) * a.KPp + e * dgp + (dd % dgp), qr * zv[u]);
+      }
+      if (lane < a.g) {
+        const long base = (t * a.g + lane) * a.KPp + a.E * dgp + 3 * e;
+        stT<T>(Apost, base + 0, qr); stT<T>(Apost, base + 1, -qr * mup); stT<T>(Apost, base + 2, q);
+      }
+      if (lane == 0) { rpmup[t * a.E + e] = rp; rpmup[(long)a.NT * a.E + t * a.E + e] = mup; }
+    }
+  }
+}
+int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  PostArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.g = d.g; a.KPp = d.KPp; a.NT = d.NT;
+  a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
+  const size_t sh = (size_t)(d.g * d.dgp * d.dgp + 8 * d.DD) * sizeof(float);
+  dim3 grid; tok_grid(d, &grid);
+  DISPATCH_T(d.bf16, kk_post_small, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
+             (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
+  AVMOE_CHECK_LAUNCH("post_small");
+  return OK;
+}
+
+}  // namespace avmoe

@@ -1,0 +1,52 @@
+// Launch wrappers of the bottleneck-space kernels (everything that is not a GEMM).
+// Naming follows oracle/algebra_ref.py; buffer layouts are documented in moe_plan.h.
+#pragma once
+#include "moe_plan.h"
+#include <hip/hip_runtime.h>
+
+namespace avmoe {
+
+struct P16 { const float* p[MAX_E]; };
+struct W16 { float* p[MAX_E]; };
+
+// All wrappers return 0 or a negative status; `bf16` selects the operand type T.
+// ---- forward: weight preparation -------------------------------------------------------------
+int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, const float* Wf, hipStream_t st);
+int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st);
+// ---- forward: token statistics ---------------------------------------------------------------
+int k_rowstats(int bf16, const void* X, long rows, int C, float* out_sum_sq /* [2][rows] */, hipStream_t st);
+int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out_ld, hipStream_t st);
+// ---- forward: hop 1 ---------------------------------------------------------------------------
+int k_fill_ext(const Plan& pl, char* saved, hipStream_t st);
+int k_qrqb(const Plan& pl, char* saved, const float* fc_b, hipStream_t st);
+int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, hipStream_t st);
+int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src /*0 y, 1 x*/,
+               hipStream_t st);
+// ---- forward: router --------------------------------------------------------------------------
+int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
+             int64_t* idx_out, float* lb_out, hipStream_t st);
+// ---- forward: per token -----------------------------------------------------------------------
+int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int k_bn1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
+int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+
+// ---- backward ---------------------------------------------------------------------------------
+int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
+                     const avmoe_moe_ptrs& grads, hipStream_t st);
+int k_post_prep_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
+                    const avmoe_moe_ptrs& grads, hipStream_t st);
+int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+              hipStream_t st);
+int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
+                    const avmoe_moe_ptrs& grads, hipStream_t st);
+int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                 float lb_weight, hipStream_t st);
+int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, hipStream_t st);
+
+// generic helpers
+int k_fill_f32(float* p, long n, float v, hipStream_t st);
+int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, void* dst, long ld_dst, hipStream_t st);
+
+}  // namespace avmoe

@@ -1,0 +1,160 @@
+// Forward orchestration of one MoEAdapter site: a fixed sequence of engine GEMMs and bottleneck-space
+// kernels on the caller's stream (no allocation, no host sync: capturable in a hipGraph).
+// Stage names follow oracle/algebra_ref.py::AlgebraRef.forward.
+#include "moe_run.h"
+
+namespace avmoe {
+
+int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap) {
+  const int tile = (g.tile ? g.tile : ((g.M > 64 && g.N > 64) ? 128 : 64));
+  const long tiles = (long)cdiv(g.M, tile) * cdiv(g.N, tile) * g.nb1 * g.nb2;
+  const int bk = g.dtype == GEMM_BF16 ? 64 : 32;
+  long ks = std::max<long>(1, 768 / std::max<long>(tiles, 1));
+  ks = std::min<long>(ks, std::max<long>(1, g.K / (4 * bk)));
+  ks = std::min<long>(ks, 64);
+  const size_t per = (size_t)g.nb1 * g.nb2 * g.M * g.N;
+  while (ks > 1 && per * ks > slab_floats_cap) --ks;
+  return (int)ks;
+}
+
+int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const float* noise, void* out,
+                float* probs_out, int64_t* idx_out, float* lb_out, char* sv, char* sc, hipStream_t st) {
+  const Dims& d = pl.d;
+  const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
+  float* slabs = (float*)(sc + pl.o_slabs);
+  const size_t slab_cap = slab_floats(d);
+  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
+
+  // ---- weights-derived operands --------------------------------------------------------------
+  AVMOE_TRY(k_prep_remap(pl, sv, prm.conv_w, prm.conv_b, prm.fc_w, st));
+  AVMOE_TRY(k_prep_experts(pl, sv, prm, st));
+  // ---- token statistics of X: row sums (LayerNorm), column means (router) ---------------------
+  AVMOE_TRY(k_rowstats(d.bf16, X, d.NT, d.C, (float*)(sv + pl.o_sx), st));
+  AVMOE_TRY(k_colmean(d.bf16, X, d.S, d.N, d.C, (float*)(sv + pl.o_rin), 2L * d.C, st));
+
+  // ---- hop 1, cross-modal experts: latent tokens read the (never materialised) remapped Y -----
+  if (d.Kcy > 0) {
+    GemmArgs g = base();                                   // Q = T0 Wf
+    g.A = sv + pl.o_T0T; g.B = sv + pl.o_WfT; g.C = sv + pl.o_Qx;
+    g.M = d.Kcy; g.N = d.Cy; g.K = d.C; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.Cy;
+    g.sCi = d.Cy; g.out_dtype = dt;
+    AVMOE_TRY(launch_gemm(g, st));
+    AVMOE_TRY(k_qrqb(pl, sv, prm.fc_b, st));
+  }
+  AVMOE_TRY(k_fill_ext(pl, sv, st));
+  if (d.Kcy > 0) {
+    {                                                      // R[s] = Q Y[s]^T
+      GemmArgs g = base();
+      g.A = sv + pl.o_Qx; g.B = Y; g.C = sv + pl.o_Rext;
+      g.M = d.Kcy; g.N = d.M; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.nb1 = d.S; g.sB1 = (long)d.M * d.Cy;
+      g.sCi = d.Mk; g.sC1 = (long)d.Kcy * d.Mk; g.out_dtype = dt;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+    {                                                      // L1[s] = [R | qr | qb] [Wc | bc | 1]^T
+      GemmArgs g = base();
+      g.A = sv + pl.o_Rext; g.B = sv + pl.o_WcK; g.C = sc + pl.o_L1;
+      g.M = d.Kcy; g.N = d.N; g.K = d.M + 2; g.lda = d.Mk; g.ldb = d.Mk; g.nb1 = d.S; g.sA1 = (long)d.Kcy * d.Mk;
+      g.sCi = d.Np; g.sC1 = (long)d.Kcy * d.Np;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcy, d.N, d.Np, sv + pl.o_A1y, d.Np, st));
+    {                                                      // [Bm | ab][s] = A1[s] [Wc | bc]
+      GemmArgs g = base();
+      g.A = sv + pl.o_A1y; g.B = sv + pl.o_WcT; g.C = sv + pl.o_BmX;
+      g.M = d.Kcy; g.N = d.M + 1; g.K = d.N; g.lda = d.Np; g.ldb = d.Np; g.nb1 = d.S; g.sA1 = (long)d.Kcy * d.Np;
+      g.sCi = d.Mb; g.sC1 = (long)d.Kcyb * d.Mb; g.out_dtype = dt;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+  }
+  {                                                        // V[s] = [Bm ; wbar][s] Y[s]   (token contraction)
+    GemmArgs g = base();
+    g.A = sv + pl.o_BmX; g.B = Y; g.C = sv + pl.o_V;
+    g.M = d.Kcyb; g.N = d.Cy; g.K = d.M; g.lda = d.Mb; g.b_layout = MN_MAJOR; g.ldb = d.Cy; g.nb1 = d.S;
+    g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.M * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.Kcyb * d.Cy; g.out_dtype = dt;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  {                                                        // TV = V Wf^T
+    GemmArgs g = base();
+    g.A = sv + pl.o_V; g.B = sv + pl.o_WfT; g.C = sc + pl.o_TV;
+    g.M = d.S * d.Kcyb; g.N = d.C; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.sCi = d.C;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  AVMOE_TRY(k_finish_T(pl, sv, sc, prm, 0, st));
+
+  // ---- hop 1, latent self attention on X (AVS v2) ----------------------------------------------
+  if (d.Kcx > 0) {
+    const char* T0x = sv + pl.o_T0T + (size_t)d.Kcy * d.C * d.esz;
+    {
+      GemmArgs g = base();
+      g.A = T0x; g.B = X; g.C = sc + pl.o_L1;
+      g.M = d.Kcx; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.sB1 = (long)d.N * d.C;
+      g.sCi = d.Np; g.sC1 = (long)d.Kcx * d.Np;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcx, d.N, d.Np, sv + pl.o_A1x, d.Np, st));
+    {
+      GemmArgs g = base();
+      g.A = sv + pl.o_A1x; g.B = X; g.C = sc + pl.o_TV;
+      g.M = d.Kcx; g.N = d.C; g.K = d.N; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S;
+      g.sA1 = (long)d.Kcx * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.Kcx * d.C;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+    AVMOE_TRY(k_finish_T(pl, sv, sc, prm, 1, st));
+  }
+
+  // ---- router -----------------------------------------------------------------------------------
+  AVMOE_TRY(k_router(pl, sv, prm, noise, probs_out, idx_out, lb_out, st));
+
+  // ---- per-sample K-space matrices of the latent tokens ------------------------------------------
+  AVMOE_TRY(k_rowstats(d.bf16, sv + pl.o_Text, (long)d.S * d.KLT, d.C, (float*)(sv + pl.o_Tsum), st));
+  if (d.El > 0) {                                          // TT[s][l] = T T^T
+    GemmArgs g = base();
+    g.A = sv + pl.o_Text; g.B = sv + pl.o_Text; g.C = sv + pl.o_TT;
+    g.M = d.K; g.N = d.K; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.nb2 = d.El;
+    g.sA1 = g.sB1 = (long)d.KLT * d.C; g.sA2 = g.sB2 = (long)d.K * d.C;
+    g.sCi = d.K; g.sC1 = (long)d.El * d.K * d.K; g.sC2 = (long)d.K * d.K;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  auto down_gemm = [&](const void* rows, long nrows, void* dst) {      // rows (nrows, C) -> (nrows, DZ) through Wt
+    GemmArgs g = base();
+    g.A = rows; g.B = sv + pl.o_Wt; g.C = dst;
+    g.M = (int)nrows; g.N = d.E * d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb2 = d.g;
+    g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC2 = (long)d.E * d.dgp;
+    return launch_gemm(g, st);
+  };
+  AVMOE_TRY(down_gemm(sv + pl.o_Text, (long)d.S * d.KLT, sv + pl.o_TW));   // TW (all latent rows x all experts)
+  // ---- the X-side GEMMs ------------------------------------------------------------------------
+  AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z));                                // Zx = X Wt^T
+  if (d.KL > 0) {                                          // L2[s] = X[s] T[s]^T
+    GemmArgs g = base();
+    g.A = X; g.B = sv + pl.o_Text; g.C = sv + pl.o_L2;
+    g.M = d.N; g.N = d.KL; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S;
+    g.sA1 = (long)d.N * d.C; g.sB1 = (long)d.KLT * d.C; g.sCi = d.KLp; g.sC1 = (long)d.N * d.KLp;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  // ---- bottleneck space --------------------------------------------------------------------------
+  AVMOE_TRY(k_pre_small(pl, sv, sc, prm, st));
+  AVMOE_TRY(k_bn1_finalize(pl, sv, sc, prm, st));
+  AVMOE_TRY(k_mid(pl, sv, sc, st));
+  if (d.use_bn && d.training) {                            // Szz[i][e] = Zp^T Zp / NT   (token contraction)
+    GemmArgs g = base();
+    g.A = sc + pl.o_Zp; g.B = sc + pl.o_Zp; g.C = sv + pl.o_Szz;
+    g.M = d.dgp; g.N = d.dgp; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = g.ldb = d.DZ;
+    g.nb2 = d.g * d.E; g.sA2 = g.sB2 = d.dgp; g.sCi = d.dgp; g.sC2 = (long)d.dgp * d.dgp;
+    g.alpha = 1.f / (float)d.NT;
+    g.ksplit = choose_ksplit(g, slab_cap);
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  AVMOE_TRY(k_post_prep(pl, sv, sc, prm, st));
+  AVMOE_TRY(k_post_small(pl, sv, sc, prm, st));
+  {                                                        // out = Apost Bpost^T  (mixture, gates, BN2, LN-post folded in)
+    GemmArgs g = base();
+    g.A = sv + pl.o_Apost; g.B = sv + pl.o_Bpost; g.C = out;
+    g.M = d.NT; g.N = d.Cg; g.K = d.KP; g.lda = (long)d.g * d.KPp; g.ldb = d.KPp; g.nb2 = d.g;
+    g.sA2 = d.KPp; g.sB2 = (long)d.Cg * d.KPp; g.sCi = d.C; g.sC2 = d.Cg; g.out_dtype = dt;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  return OK;
+}
+
+}  // namespace avmoe

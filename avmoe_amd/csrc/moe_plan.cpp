@@ -1,0 +1,111 @@
+#include "moe_plan.h"
+#include <algorithm>
+#include <cstring>
+
+namespace avmoe {
+
+size_t slab_floats(const Dims& d) {
+  // worst split-K user: weight-gradient contractions over all tokens.  Sized generously:
+  // ksplit_max * (largest small output), see moe_forward/backward for the actual launches.
+  const size_t out1 = (size_t)d.g * d.E * d.dgp * d.dgp;              // Szz / dGq
+  const size_t out2 = (size_t)d.C * d.KPp;                            // dBpost
+  const size_t out3 = (size_t)d.g * d.E * d.dgp * d.Cg;               // dWt
+  const size_t out4 = (size_t)d.N * d.Mk + (size_t)d.C * d.Cy;        // dWc, dWf
+  const size_t out5 = (size_t)(d.KL ? d.KL : 1) * (d.Cy > d.C ? d.Cy : d.C);
+  size_t m = std::max(std::max(out1, out2), std::max(std::max(out3, out4), out5));
+  return m * 64 + 1024;
+}
+
+int make_plan(const avmoe_moe_desc* q, Plan* pl) {
+  if (!q || !pl) { set_last_error("moe: null descriptor"); return ERR_BAD_ARG; }
+  std::memset(pl, 0, sizeof(Plan));
+  Dims& d = pl->d;
+  d.S = q->S; d.N = q->N; d.C = q->C; d.M = q->M; d.Cy = q->Cy;
+  d.E_m = q->E_m; d.E_s = q->E_s; d.E = q->E_m + q->E_s;
+  d.g = q->groups; d.d = q->d; d.K = q->K;
+  d.use_bn = q->use_bn; d.use_gate = q->use_gate; d.ln_before = q->ln_before; d.ln_post = q->ln_post;
+  d.variant = q->variant; d.self_attn = q->self_attn; d.lb_loss = q->lb_loss; d.training = q->training;
+  d.bf16 = q->dtype == AVMOE_BF16;
+  d.bn_eps = q->bn_eps; d.ln_eps = q->ln_eps; d.bn_momentum = q->bn_momentum;
+  if (q->dtype != AVMOE_F32 && q->dtype != AVMOE_BF16) { set_last_error("moe: dtype %d", q->dtype); return ERR_BAD_ARG; }
+  if (d.S <= 0 || d.N <= 0 || d.C <= 0 || d.M <= 0 || d.Cy <= 0) {
+    set_last_error("moe: non-positive extent S=%d N=%d C=%d M=%d Cy=%d", d.S, d.N, d.C, d.M, d.Cy);
+    return ERR_BAD_ARG;
+  }
+  if (d.E <= 0 || d.E > MAX_E || d.E_m < 0 || d.E_s < 0) {
+    set_last_error("moe: expert count %d+%d outside 1..%d", d.E_m, d.E_s, MAX_E);
+    return ERR_BAD_ARG;
+  }
+  if (d.g <= 0 || d.d <= 0 || d.d % d.g || d.C % d.g) {
+    set_last_error("moe: bottleneck %d / channels %d not divisible by groups %d", d.d, d.C, d.g);
+    return ERR_BAD_ARG;
+  }
+  if ((d.C / d.g) % 8 || d.Cy % 8) {
+    set_last_error("moe: C/groups (%d) and Cy (%d) must be multiples of 8 (16-byte rows)", d.C / d.g, d.Cy);
+    return ERR_UNSUPPORTED;
+  }
+  if (d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN) {
+    set_last_error("moe: the AVVP N x N unimodal attention block is not built yet");
+    return ERR_UNSUPPORTED;
+  }
+  const bool v2 = d.self_attn == AVMOE_SELF_ATTN_LATENT_V2;
+  if ((d.E_m > 0 || v2) && (d.K <= 0 || d.K > 128)) {
+    set_last_error("moe: num_tk K=%d outside 1..128", d.K);
+    return ERR_UNSUPPORTED;
+  }
+  d.esz = d.bf16 ? 2 : 4;
+  d.NT = d.S * d.N;
+  d.dg = d.d / d.g;
+  d.dgp = (int)round_up(d.dg, 8);
+  d.Cg = d.C / d.g;
+  d.DD = d.g * d.dgp;
+  d.DZ = d.E * d.DD;
+  if (d.DD > 256) { set_last_error("moe: padded bottleneck %d > 256", d.DD); return ERR_UNSUPPORTED; }
+  d.El = 0;
+  for (int e = 0; e < d.E; ++e) {
+    const bool multimodal = e < d.E_m;
+    d.relu_of_e[e] = multimodal;
+    d.lat_of_e[e] = -1;
+    if (multimodal || v2) {
+      d.lat_of_e[e] = d.El;
+      d.e_of_lat[d.El] = e;
+      d.src_of_lat[d.El] = multimodal ? 0 : 1;
+      d.El++;
+    }
+  }
+  d.Ey = d.E_m;
+  d.Ex = d.El - d.Ey;
+  if (d.El == 0) d.K = d.K > 0 ? d.K : 1;
+  d.KL = d.El * d.K;
+  d.KLT = d.KL + 2;
+  d.KLp = (int)round_up(d.KL + 2, 8);
+  d.Kcy = d.Ey * d.K;
+  d.Kcyb = d.Kcy + 1;
+  d.Kcx = d.Ex * d.K;
+  d.KP = d.E * d.dgp + 3 * d.E;
+  d.KPp = (int)round_up(d.KP, 8);
+  d.Mk = (int)round_up(d.M + 2, 8);
+  d.Mb = (int)round_up(d.M + 1, 8);
+  d.Np = (int)round_up(d.N, 8);
+  // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
+  int bps = std::max(1, std::min(cdiv(d.N, 64), cdiv(2048, d.S)));
+  d.nblk_tok = bps * d.S;
+
+  size_t off[2] = {0, 0};
+  int n = 0;
+#define X(name, region, eb, cnt)                                                   \
+  {                                                                                \
+    const size_t bytes = (size_t)(eb) * (size_t)(cnt);                             \
+    pl->o_##name = off[region];                                                    \
+    pl->info[n++] = BufInfo{#name, region, off[region], bytes};                    \
+    off[region] += (size_t)round_up((long)bytes, 256);                             \
+  }
+  AVMOE_BUFFERS(X)
+#undef X
+  pl->nbuf = n;
+  pl->saved_bytes = off[0] + 256;
+  pl->scratch_bytes = off[1] + 256;
+  return OK;
+}
+
+}  // namespace avmoe

@@ -1,0 +1,141 @@
+// Dimensions and workspace layout of one MoEAdapter site.
+//
+// `saved` persists from forward to backward (the Python facade keeps it in the autograd context);
+// `scratch` is transient per call.  Both are caller-allocated (C ABI: the library never allocates).
+// Every buffer has a name so tests can pull any intermediate out of the workspace and compare it with
+// the same-named tensor of oracle/algebra_ref.py (avmoe_moe_buffer_info).
+#pragma once
+#include "../../include/avmoe.h"
+#include "common.h"
+#include <stddef.h>
+
+namespace avmoe {
+
+constexpr int MAX_E = AVMOE_MAX_EXPERTS;
+
+struct Dims {
+  // raw
+  int S, N, C, M, Cy, E, E_m, E_s, g, d, K;
+  int use_bn, use_gate, ln_before, ln_post, variant, self_attn, lb_loss, training, bf16;
+  float bn_eps, ln_eps, bn_momentum;
+  // derived
+  int esz;        // bytes of an activation / operand element (T)
+  int NT;         // S * N tokens
+  int dg, dgp;    // bottleneck per group, padded to 8
+  int Cg;         // channels per group
+  int DD;         // g * dgp : padded bottleneck width of one expert
+  int DZ;         // E * DD : row width of Z / Zx   (layout [group][expert][dgp])
+  int El, Ey, Ex; // latent experts: total / source Y (cross-modal) / source X (AVS v2)
+  int KL;         // El * K latent rows per sample (latent experts in expert order)
+  int KLT;        // KL + 2 : rows of the extended token matrix Text[s] (ones row, dm1/N row)
+  int KLp;        // row width of L2 / a / dL2ext  (>= KL + 2, multiple of 8)
+  int Kcy, Kcyb;  // Ey * K ; Kcy + 1 (extra wbar / ybar row)
+  int Kcx;        // Ex * K
+  int KP, KPp;    // post GEMM depth per group: E*dgp + 3E, padded to 8
+  int Mk;         // width of Rext / WcK : M + 2 (qr, qb / bc, 1 columns), padded to 8
+  int Mb;         // width of Bm_ext: M + 1 (ab column), padded to 8
+  int Np;         // N padded to 8
+  int lat_of_e[MAX_E];   // latent slot of expert e or -1
+  int e_of_lat[MAX_E];
+  int src_of_lat[MAX_E]; // 0 = Y (cross-modal), 1 = X (v2)
+  int relu_of_e[MAX_E];
+  int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
+};
+
+// name, region (0 saved / 1 scratch), element bytes expr (4 or d.esz), element count expr
+#define AVMOE_BUFFERS(X)                                                                      \
+  /* ---- weights-derived operands (rebuilt every forward) ---- */                             \
+  X(WcK, 0, d.esz, (size_t)d.N * d.Mk)              /* [n][m | bc | 1]                */       \
+  X(WcT, 0, d.esz, (size_t)(d.M + 1) * d.Np)        /* [m | bc-row][n]                */       \
+  X(WfT, 0, d.esz, (size_t)d.C * d.Cy)              /* fc.weight in T                 */       \
+  X(rw, 0, 4, (size_t)d.C)                          /* Wf 1                           */       \
+  X(wbar, 0, 4, (size_t)d.Mb)                       /* mean_n Wc ; [Mb-1] unused      */       \
+  X(scal, 0, 4, 64)                                 /* bcbar, ...                     */       \
+  X(T0T, 0, d.esz, (size_t)(d.KL ? d.KL : 1) * d.C) /* stacked my_tokens in T         */       \
+  X(Wt, 0, d.esz, (size_t)d.g * d.E * d.dgp * d.Cg) /* [i][e][jp][c] = Wd*gamma_b     */       \
+  X(wsum, 0, 4, (size_t)d.DZ)                                                                   \
+  X(dconst, 0, 4, (size_t)d.DZ)                                                                 \
+  /* ---- hop 1 (cross-modal experts, source = remapped Y) ---- */                             \
+  X(Qx, 0, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)  /* T0 Wf                        */      \
+  X(qrqb, 0, 4, (size_t)2 * (d.Kcy ? d.Kcy : 1))                                               \
+  X(Rext, 0, d.esz, (size_t)d.S * (d.Kcy ? d.Kcy : 1) * d.Mk)                                  \
+  X(A1y, 0, d.esz, (size_t)d.S * (d.Kcy ? d.Kcy : 1) * d.Np)                                   \
+  X(BmX, 0, d.esz, (size_t)d.S * d.Kcyb * d.Mb)     /* [A1 Wc | ab] + wbar row        */       \
+  X(V, 0, d.esz, (size_t)d.S * d.Kcyb * d.Cy)                                                  \
+  X(A1x, 0, d.esz, (size_t)d.S * (d.Kcx ? d.Kcx : 1) * d.Np)                                   \
+  X(Text, 0, d.esz, (size_t)d.S * d.KLT * d.C)      /* T[s] rows + ones row + dm1 row */       \
+  X(Tsum, 0, 4, (size_t)2 * d.S * d.KLT)            /* row sum / sumsq of Text        */       \
+  X(TT, 0, 4, (size_t)d.S * (d.El ? d.El : 1) * d.K * d.K)                                     \
+  X(TW, 0, 4, (size_t)d.S * d.KLT * d.DZ)           /* Text rows through Wt           */       \
+  /* ---- router ---- */                                                                       \
+  X(rin, 0, 4, (size_t)d.S * 2 * d.C)                                                           \
+  X(rh1, 0, 4, (size_t)d.S * 128)                                                               \
+  X(rh2, 0, 4, (size_t)d.S * 32)                                                                \
+  X(probs, 0, 4, (size_t)d.S * d.E)                                                             \
+  /* ---- per token ---- */                                                                    \
+  X(sx, 0, 4, (size_t)2 * d.NT)                     /* row sum / sumsq of X           */       \
+  X(Z, 0, 4, (size_t)d.NT * d.DZ)                   /* Zx then z (in place)           */       \
+  X(L2, 0, 4, (size_t)d.NT * d.KLp)                                                             \
+  X(a, 0, d.esz, (size_t)d.NT * d.KLp)                                                          \
+  X(rmu, 0, 4, (size_t)2 * d.NT * d.E)              /* r, mu  per (token, expert)     */       \
+  X(rpmup, 0, 4, (size_t)2 * d.NT * d.E)            /* rp, mup                        */       \
+  X(bn1, 0, 4, (size_t)4 * d.DZ)                    /* mean, rstd, scale, shift       */       \
+  X(mz, 0, 4, (size_t)d.DZ)                                                                     \
+  X(Szz, 0, 4, (size_t)d.g * d.E * d.dgp * d.dgp)                                               \
+  X(bn2, 0, 4, (size_t)4 * d.E * d.C)               /* mo, rs2, k2, h2   [e][c]       */       \
+  X(Bpost, 0, d.esz, (size_t)d.C * d.KPp)                                                       \
+  X(Gq, 0, 4, (size_t)d.g * d.E * d.dgp * d.dgp)    /* Wh^T Wh per (i,e)              */       \
+  X(uvh, 0, 4, (size_t)2 * d.DZ + 2 * d.E)          /* usum, vh, H1[e], H2[e]         */       \
+  X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
+  /* ---- transient ---- */                                                                    \
+  X(L1, 1, 4, (size_t)d.S * (d.Kcy > d.Kcx ? d.Kcy : (d.Kcx ? d.Kcx : 1)) * d.Np)              \
+  X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \
+  X(Zp, 1, d.esz, (size_t)d.NT * d.DZ)              /* z' (fwd) ; reused in bwd       */       \
+  X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
+  X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
+  X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \
+  /* ---- backward only ---- */                                                                \
+  X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)                                                      \
+  X(dBp, 1, 4, (size_t)d.C * d.KPp)                                                             \
+  X(dzp, 1, 4, (size_t)d.NT * d.DZ)                 /* dz' -> dy -> dz (in place)     */       \
+  X(dGq, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp)                                               \
+  X(dSzz, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp)  /* sym(dSzz)/ntot                 */       \
+  X(dsm, 1, 4, (size_t)8 * d.DZ + 4 * d.E + 64)     /* dusum,dvh,dmz,bn1 sums,...     */       \
+  X(dp, 1, 4, (size_t)d.S * d.E + d.S * 2 * d.C)    /* dp[s][e] ; drin[s][2C]         */       \
+  X(dL2x, 1, d.esz, (size_t)d.NT * d.KLp)           /* [dL2 | dsx | 1]                */       \
+  X(aw, 1, d.esz, (size_t)d.NT * d.KLp)             /* du3 * a                        */       \
+  X(rs2x, 1, 4, (size_t)d.NT)                       /* 2 * sum_e dsxx                 */       \
+  X(dTW, 1, d.esz, (size_t)d.S * d.KLT * d.DZ)                                                  \
+  X(dTT, 1, d.esz, (size_t)d.S * (d.El ? d.El : 1) * d.K * d.K)                                 \
+  X(dtbar, 1, 4, (size_t)d.S * d.KLT)                                                           \
+  X(dWt, 1, 4, (size_t)d.g * d.E * d.dgp * d.Cg)                                                \
+  X(dT, 1, 4, (size_t)d.S * (d.KL ? d.KL : 1) * d.C)                                            \
+  X(dTt, 1, d.esz, (size_t)d.S * (d.KL ? d.KL : 1) * d.C)  /* dT in T (GEMM operand)   */     \
+  X(dV, 1, d.esz, (size_t)d.S * d.Kcyb * d.Cy)                                                  \
+  X(dBm, 1, 4, (size_t)d.S * d.Kcyb * d.Mb)                                                     \
+  X(dBmT, 1, d.esz, (size_t)d.S * d.Kcyb * d.Mb)                                                \
+  X(dA1, 1, 4, (size_t)d.S * (d.Kcy > d.Kcx ? d.Kcy : (d.Kcx ? d.Kcx : 1)) * d.Np)             \
+  X(dL1, 1, d.esz, (size_t)d.S * (d.Kcy > d.Kcx ? d.Kcy : (d.Kcx ? d.Kcx : 1)) * d.Np)         \
+  X(dRT, 1, d.esz, (size_t)d.S * d.M * (d.Kcy ? round_up(d.Kcy, 8) : 8))                       \
+  X(dQ, 1, 4, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy + 4 * (d.Kcy ? d.Kcy : 1))                    \
+  X(dWcs, 1, 4, (size_t)d.N * d.Mk + (size_t)d.C * d.Cy + 4 * d.C + 4 * d.N + d.Mb)            \
+  X(dT0, 1, 4, (size_t)(d.KL ? d.KL : 1) * d.C)
+
+size_t slab_floats(const Dims& d);
+
+struct BufInfo { const char* name; int region; size_t offset, bytes; };
+
+struct Plan {
+  Dims d;
+#define X(name, region, eb, cnt) size_t o_##name;
+  AVMOE_BUFFERS(X)
+#undef X
+  size_t saved_bytes, scratch_bytes;
+  int nbuf;
+  BufInfo info[96];
+};
+
+// Validates the descriptor and fills the plan.  Returns 0 or a negative status.
+int make_plan(const avmoe_moe_desc* desc, Plan* plan);
+
+}  // namespace avmoe

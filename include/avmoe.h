@@ -52,6 +52,66 @@ size_t avmoe_gemm_workspace_bytes(const avmoe_gemm_desc* desc);
 int avmoe_gemm(const avmoe_gemm_desc* desc, const void* A, const void* B, void* C,
                const float* row_scale, const void* D, void* workspace, void* stream);
 
+
+/* ---- the adapter site: MoEAdapter.forward / backward -------------------------------------------
+ * Replaces  MoEAdapter.forward(x, vis_token[, is_training])  (AVE net_trans_v3.py:468-487,
+ * AVQA net_avst_v2.py:381-399, AVVP mgn.py:185-217, AVS PVT_AVSModel_v2.py:283-312) and its autograd.
+ *
+ * Tensors are TOKEN-MAJOR and contiguous: X (S, N, C), Y (S, M, Cy), out / dOut / dX (S, N, C),
+ * dY (S, M, Cy), element type desc.dtype (AVMOE_F32 | AVMOE_BF16).  [The reference hands the module
+ * (S, C, N, 1) permuted VIEWS of exactly this memory -- net_trans_v3.py:695.]
+ * Parameters / buffers / their gradients are fp32, one pointer per reference state_dict entry.      */
+#define AVMOE_MAX_EXPERTS 16
+enum { AVMOE_VARIANT_AVE = 0, AVMOE_VARIANT_AVVP = 1, AVMOE_VARIANT_AVS = 2 };   /* AVQA == AVE math */
+enum { AVMOE_SELF_ATTN_NONE = 0, AVMOE_SELF_ATTN_LATENT_V2 = 1, AVMOE_SELF_ATTN_NXN = 2 };
+
+typedef struct avmoe_moe_desc {
+  int32_t S, N, C;          /* this modality: frames, tokens, channels  (C = input_dim = linear_out) */
+  int32_t M, Cy;            /* other modality: tokens (conv_dim_in), channels (linear_in)            */
+  int32_t E_m, E_s;         /* opt.num_multimodal_experts, opt.num_singlemodal_experts               */
+  int32_t d, groups, K;     /* bottleneck = C // reduction_factor, opt.num_conv_group, num_tk         */
+  int32_t use_bn, use_gate, ln_before, ln_post;
+  int32_t variant, self_attn, lb_loss;
+  int32_t dtype;            /* activations */
+  int32_t training;         /* 1: BatchNorm batch statistics + running-stat update ; 0: running stats */
+  float bn_eps, ln_eps, bn_momentum;
+} avmoe_moe_desc;
+
+typedef struct avmoe_expert_ptrs {        /* <list>.{j}.*  ; unused entries NULL                     */
+  float *gate, *my_tokens, *gate_lat;     /* gate ; my_tokens ; gate_av | gate_self                   */
+  float *down_w, *up_w;                   /* down_sampler.weight (d, C/g) ; up_sampler.weight (C, d/g)*/
+  float *bn1_w, *bn1_b, *bn2_w, *bn2_b;
+  float *lnb_w, *lnb_b, *lnp_w, *lnp_b;   /* ln_before.* ; ln_post.*                                  */
+  float *bn1_rm, *bn1_rv, *bn2_rm, *bn2_rv; /* running_mean / running_var (updated in place in training) */
+} avmoe_expert_ptrs;
+
+typedef struct avmoe_moe_ptrs {
+  float *conv_w, *conv_b, *fc_w, *fc_b;   /* conv_adapter.{weight (N, M), bias} ; fc.{weight (C, Cy), bias} */
+  float *r0_w, *r0_b, *r2_w, *r2_b, *r4_w, *r4_b;   /* router.{0,2,4}.*                               */
+  avmoe_expert_ptrs e[AVMOE_MAX_EXPERTS]; /* multimodal experts first, then singlemodal               */
+} avmoe_moe_ptrs;
+
+size_t avmoe_moe_saved_bytes(const avmoe_moe_desc* desc);     /* 0 + error string on a bad descriptor */
+size_t avmoe_moe_scratch_bytes(const avmoe_moe_desc* desc);
+
+/* out (S,N,C) ; probs (S,E) f32 ; idx (S) int64 = first-max argmax of probs ; lb: 1 float (0 if !lb_loss).
+ * noise: optional (S,E) f32 already scaled by 0.01 (AVS logit noise), or NULL.                       */
+int avmoe_moe_forward(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
+                      const float* noise, void* out, float* probs, int64_t* idx, float* lb,
+                      void* saved, void* scratch, void* stream);
+
+/* Gradients of  <out, dOut> + lb_weight * lb .  Every pointer in `grads` that is non-NULL is OVERWRITTEN
+ * with the gradient of the matching parameter; dX / dY are overwritten.  `saved` must be the buffer the
+ * matching forward filled.                                                                           */
+int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
+                       const void* dOut, float lb_weight, void* saved, void* scratch,
+                       void* dX, void* dY, const avmoe_moe_ptrs* grads, void* stream);
+
+/* Workspace introspection for tests: buffer `index` -> name / region (0 saved, 1 scratch) / offset / bytes.
+ * Returns 0, or AVMOE_ERR_BAD_ARG when index is past the last buffer.                                 */
+int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region,
+                          size_t* offset, size_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

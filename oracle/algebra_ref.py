@@ -160,6 +160,7 @@ class AlgebraRef:
             else:
                 z = zraw
             e["zraw"] = zraw
+            e["z"] = z
             # ---- BN1 (+ReLU for cross-modal experts) ----
             if cfg.use_bn:
                 g1 = P[f"{pre}.bn1.weight"].reshape(g, dg)

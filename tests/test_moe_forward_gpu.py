@@ -1,0 +1,50 @@
+"""GPU parity of avmoe_moe_forward (the HIP path behind the C ABI) against the golden vectors captured
+from the reference and, stage by stage, against oracle/algebra_ref.py."""
+import pytest
+import torch
+
+from oracle.algebra_ref import AlgebraRef
+from tests.golden_util import golden_names, load_golden, split_params
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED = [n for n in golden_names() if not n.startswith("avvp")]
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_forward_fp32_matches_reference_vectors(name, capsys):
+    from tests.moe_gpu_util import MoeRun, compare_forward_intermediates
+    meta, cfg, t = load_golden(name)
+    P, B = split_params(t)
+    training = bool(meta["module_train"])
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=training, noise=t.get("noise")).forward()
+    out = run.out.float().cpu()
+    err = float((out - t["out"]).abs().max() / t["out"].abs().max())
+    ok = err < 1e-3 and torch.equal(run.idx.cpu(), t["idx"])
+    if not ok:
+        A = AlgebraRef(cfg, P, B)
+        A.forward(t["X"], t["Y"], training=training, noise=t.get("noise"))
+        with capsys.disabled():
+            print(f"\n[{name}] out rel err {err:.3e}")
+            compare_forward_intermediates(run, A)
+    assert torch.equal(run.idx.cpu(), t["idx"]), "router argmax must be bit-exact"
+    assert err < 1e-3, err                      # north_star: within 1e-3 rel fp32
+    assert float((run.probs.cpu() - t["probs"]).abs().max()) < 1e-5
+    if cfg.lb_loss:
+        assert abs(float(run.lb.cpu()) - float(t["lb"])) < 1e-4 * max(1.0, abs(float(t["lb"])))
+    if training and cfg.use_bn:
+        for k, v in run.buffers.items():
+            assert torch.allclose(v.cpu(), t[f"newbuffer.{k}"], rtol=2e-4, atol=2e-5), k
+
+
+@pytest.mark.parametrize("name", ["ave_train", "ave_wide_train", "avs_v2_train"])
+def test_forward_bf16_close_to_reference_vectors(name):
+    """bf16 I/O + fp32 accumulate: compared with the fp32 reference output at bf16-level tolerance."""
+    from tests.moe_gpu_util import MoeRun
+    meta, cfg, t = load_golden(name)
+    P, B = split_params(t)
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=True, training=bool(meta["module_train"]), noise=t.get("noise")).forward()
+    out = run.out.float().cpu()
+    err = float((out - t["out"]).abs().max() / t["out"].abs().max())
+    assert err < 4e-2, err
+    assert torch.equal(run.idx.cpu(), t["idx"])
