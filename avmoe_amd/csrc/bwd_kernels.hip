@@ -1,0 +1,1044 @@
+// Backward bottleneck-space kernels.  Every formula is the one in oracle/algebra_ref.py::AlgebraRef.backward
+// (validated there against autograd); stage names match.  Full-width tensors are only touched by GEMMs.
+#include "kernels.h"
+#include "device_utils.h"
+#include <algorithm>
+
+namespace avmoe {
+
+#define DISPATCH_T(bf16, KERN, grid, block, shmem, st, ...)                                   \
+  do {                                                                                        \
+    if (bf16) hipLaunchKernelGGL((KERN<__bf16>), grid, block, shmem, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERN<float>), grid, block, shmem, st, __VA_ARGS__);              \
+  } while (0)
+
+__device__ __forceinline__ void wave_lds_sync_b() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename T> __device__ __forceinline__ float roundTb(float v);
+template <> __device__ __forceinline__ float roundTb<float>(float v) { return v; }
+template <> __device__ __forceinline__ float roundTb<__bf16>(float v) { return bf2f(f2bf(v)); }
+
+static inline unsigned grid1db(long n, int cap = 4096) { return (unsigned)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
+static void tok_grid_b(const Dims& d, dim3* grid) { *grid = dim3((unsigned)(d.nblk_tok / d.S), (unsigned)d.S); }
+static int lds_attr(const void* fn, size_t bytes, const char* what) {
+  if (bytes <= 65536) return OK;
+  if (bytes > 160 * 1024) { set_last_error("%s needs %zu B of LDS", what, bytes); return ERR_UNSUPPORTED; }
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_last_error("%s: LDS attribute: %s", what, hipGetErrorString(e)); return ERR_LAUNCH; }
+  return OK;
+}
+
+constexpr int DR = 4;   // ceil(DD / 64) upper bound (DD <= 256)
+constexpr int KR = 2;   // ceil(K / 64) upper bound (K <= 128)
+
+// reduce per-wave column accumulators of one expert into colpart[blk][slot0 / slot0+1]
+__device__ __forceinline__ void flush_cols(float* s_red, const float (&c0)[DR], const float (&c1)[DR], int DD, int dgp, int E,
+                                           int e, int DZ, float* colpart, int blk, int slot0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < DR; ++u) {
+    const int dd = lane + 64 * u;
+    if (dd < DD) { s_red[(wave * 2 + 0) * DD + dd] = c0[u]; s_red[(wave * 2 + 1) * DD + dd] = c1[u]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * DD; i += 256) {
+    const int which = i / DD, dd = i % DD;
+    const float v = s_red[(0 * 2 + which) * DD + dd] + s_red[(1 * 2 + which) * DD + dd] +
+                    s_red[(2 * 2 + which) * DD + dd] + s_red[(3 * 2 + which) * DD + dd];
+    const int col = (dd / dgp) * E * dgp + e * dgp + (dd % dgp);
+    colpart[((long)blk * 4 + slot0 + which) * DZ + col] = v;
+  }
+}
+// block sum of up to 4 per-wave scalars held by lane 0 -> blkscal[blk][e][0..3]
+__device__ __forceinline__ void flush_scal(float* s_sc, float v0, float v1, float v2, float v3, float* out4, unsigned mask) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { s_sc[wave * 4 + 0] = v0; s_sc[wave * 4 + 1] = v1; s_sc[wave * 4 + 2] = v2; s_sc[wave * 4 + 3] = v3; }
+  __syncthreads();
+  if (threadIdx.x < 4 && ((mask >> threadIdx.x) & 1u))
+    out4[threadIdx.x] = s_sc[threadIdx.x] + s_sc[4 + threadIdx.x] + s_sc[8 + threadIdx.x] + s_sc[12 + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// POST_SMALL backward: dApost -> dq, direct dz', LayerNorm-post statistic gradients.
+// ---------------------------------------------------------------------------------------------
+struct PostBwdArgs {
+  P16 gate; int relu_of_e[MAX_E];
+  int S, N, C, E, DD, DZ, dgp, g, KPp, NT, ln_post, use_gate;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) kk_post_small_bwd(PostBwdArgs a, const float* Z, const float* bn1, const float* Gq,
+                                                         const float* uvh, const float* probs, const float* rpmup,
+                                                         const float* dAp, float* dzp, void* Zp_, void* Zw_,
+                                                         float* colpart, float* blkscal) {
+  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_;
+  extern __shared__ float smb[];
+  const int DD = a.DD, dgp = a.dgp;
+  float* s_G = smb;
+  float* s_us = s_G + a.g * dgp * dgp;
+  float* s_vh = s_us + DD;
+  float* s_sc = s_vh + DD;
+  float* s_sh = s_sc + DD;
+  float* s_z = s_sh + DD;                  // 4 * DD
+  float* s_red = s_z + 4 * DD;             // 8 * DD
+  float* s_scal = s_red + 8 * DD;          // 16
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (a.N + gridDim.x - 1) / gridDim.x;
+  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = 0; e < a.E; ++e) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.g * dgp * dgp; i += 256) {
+      const int gi = i / (dgp * dgp);
+      s_G[i] = Gq[((long)(gi * a.E + e)) * dgp * dgp + (i % (dgp * dgp))];
+    }
+    for (int dd = threadIdx.x; dd < DD; dd += 256) {
+      const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
+      s_us[dd] = uvh[col]; s_vh[dd] = uvh[a.DZ + col];
+      s_sc[dd] = bn1[2 * a.DZ + col]; s_sh[dd] = bn1[3 * a.DZ + col];
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float q = probs[(long)s * a.E + e] * gate;
+    float c0[DR], c1[DR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { c0[u] = 0.f; c1[u] = 0.f; }
+    float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
+    for (int n = n_beg + wave; n < n_end; n += 4) {
+      const long t = (long)s * a.N + n;
+      float zv[DR], dAz[DR];
+      float* zs = s_z + wave * DD;
+      wave_lds_sync_b();
+      float zz = 0.f;
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        zv[u] = 0.f; dAz[u] = 0.f;
+        if (dd < DD) {
+          const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
+          float y = Z[t * a.DZ + col] * s_sc[dd] + s_sh[dd];
+          if (relu) y = fmaxf(y, 0.f);
+          zv[u] = y; zs[dd] = y;
+          dAz[u] = dAp[(t * a.g + dd / dgp) * a.KPp + e * dgp + (dd % dgp)];
+          zz += dAz[u] * y;
+        }
+      }
+      wave_lds_sync_b();
+      zz = wave_sum(zz);
+      float da1 = 0.f, da2 = 0.f, da3 = 0.f;
+      for (int gi = 0; gi < a.g; ++gi) {
+        const float* p = dAp + (t * a.g + gi) * a.KPp + a.E * dgp + 3 * e;
+        da1 += p[0]; da2 += p[1]; da3 += p[2];
+      }
+      const float rp = rpmup[t * a.E + e], mup = rpmup[(long)a.NT * a.E + t * a.E + e];
+      const float dq = rp * zz + rp * da1 - rp * mup * da2 + da3;
+      float dSo = 0.f, dSoo = 0.f;
+      if (a.ln_post) {
+        const float drp = q * zz + q * da1 - q * mup * da2;
+        float dmup = -q * rp * da2;
+        const float dvarp = drp * (-0.5f) * rp * rp * rp;
+        dSoo = dvarp / (float)a.C;
+        dmup -= 2.f * mup * dvarp;
+        dSo = dmup / (float)a.C;
+      }
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        if (dd < DD) {
+          const int gi = dd / dgp, jp = dd % dgp;
+          const int col = gi * a.E * dgp + e * dgp + jp;
+          float dz = q * rp * dAz[u];
+          if (a.ln_post) {
+            const float* Gg = s_G + gi * dgp * dgp;
+            float w = 0.f;
+            for (int l2 = 0; l2 < dgp; ++l2) w += Gg[l2 * dgp + jp] * zs[gi * dgp + l2];
+            dz += dSo * s_us[dd] + dSoo * (2.f * w + 2.f * s_vh[dd]);
+            c0[u] += dSo * zv[u];
+            c1[u] += dSoo * zv[u];
+          }
+          dzp[t * a.DZ + col] = dz;
+          stT<T>(Zp, t * a.DZ + col, zv[u]);
+          stT<T>(Zw, t * a.DZ + col, dSoo * zv[u]);
+        }
+      }
+      sdq += dq; sdSo += dSo; sdSoo += dSoo;
+    }
+    flush_cols(s_red, c0, c1, DD, dgp, a.E, e, a.DZ, colpart, blk, 0);
+    flush_scal(s_scal, sdq, sdSo, sdSoo, 0.f, blkscal + ((long)blk * a.E + e) * 4, 0x7u);
+  }
+}
+
+// finalize: dusum, dvh (column sums), dp[s][e], dH1[e], dH2[e], grads.gate
+struct PostFinArgs { P16 gate; W16 ggate; int S, E, DZ, nblk, bps, use_gate; };
+__global__ void __launch_bounds__(256) kk_post_bwd_finalize(PostFinArgs a, const float* colpart, const float* blkscal,
+                                                            const float* probs, float* dsm, float* dp) {
+  // dsm layout: [0]=dusum [1]=dvh [2]=dmz/NT [3]=mdy [4]=mdyz [5]=ddconst [6]=dwsum [7]=spare (each DZ) ; then dH1[E], dH2[E]
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 0) * a.DZ + col]; s1 += colpart[((long)b * 4 + 1) * a.DZ + col]; }
+    dsm[col] = (float)s0; dsm[a.DZ + col] = (float)(2.0 * s1);
+  }
+  if (blockIdx.x == 0) {
+    __shared__ float red[4];
+    for (int e = 0; e < a.E; ++e) {
+      float h1 = 0.f, h2 = 0.f, gsum = 0.f;
+      for (int s = threadIdx.x; s < a.S; s += 256) {
+        float dq = 0.f;
+        for (int b = 0; b < a.bps; ++b) {
+          const float* p = blkscal + (((long)s * a.bps + b) * a.E + e) * 4;
+          dq += p[0]; h1 += p[1]; h2 += p[2];
+        }
+        const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+        dp[(long)s * a.E + e] = gate * dq;
+        gsum += probs[(long)s * a.E + e] * dq;
+      }
+      h1 = block_sum256(h1, red); h2 = block_sum256(h2, red); gsum = block_sum256(gsum, red);
+      if (threadIdx.x == 0) {
+        dsm[8 * a.DZ + e] = h1; dsm[8 * a.DZ + a.E + e] = h2;
+        if (a.use_gate && a.ggate.p[e]) a.ggate.p[e][0] = gsum;
+      }
+    }
+  }
+}
+
+int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                     hipStream_t st) {
+  const Dims& d = pl.d;
+  PostBwdArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.g = d.g; a.KPp = d.KPp; a.NT = d.NT;
+  a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  const size_t sh = (size_t)(d.g * d.dgp * d.dgp + 16 * d.DD + 16) * sizeof(float);
+  AVMOE_TRY(lds_attr(d.bf16 ? (const void*)kk_post_small_bwd<__bf16> : (const void*)kk_post_small_bwd<float>, sh, "post_small_bwd"));
+  dim3 grid; tok_grid_b(d, &grid);
+  DISPATCH_T(d.bf16, kk_post_small_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
+             (const float*)(saved + pl.o_rpmup), (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp),
+             (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
+  PostFinArgs f;
+  for (int e = 0; e < MAX_E; ++e) { f.gate.p[e] = prm.e[e].gate; f.ggate.p[e] = grads.e[e].gate; }
+  f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S; f.use_gate = d.use_gate;
+  hipLaunchKernelGGL(kk_post_bwd_finalize, dim3(std::max(1, cdiv(d.DZ, 256))), dim3(256), 0, st, f,
+                     (const float*)(scratch + pl.o_colpart), (const float*)(scratch + pl.o_blkscal),
+                     (const float*)(saved + pl.o_probs), (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_dp));
+  AVMOE_CHECK_LAUNCH("post_small_bwd");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// POST_PREP backward (weight space): dBpost, dG, dusum, dvh, dH -> up_sampler / bn2 / ln_post grads,
+// and the moment gradients dmz / NT, 2 dSzz / NT that flow back to every token.
+// ---------------------------------------------------------------------------------------------
+struct PostPrepBwdArgs {
+  P16 up, w2, lpw; W16 gup, gw2, gb2, glpw, glpb;
+  int E, g, dg, dgp, Cg, C, KPp, NT, DZ, use_bn, training, ln_post;
+};
+__global__ void __launch_bounds__(256) kk_post_prep_bwd_a(PostPrepBwdArgs a, const float* bn2, const float* dBp, const float* dGq,
+                                                          const float* dsm, const float* mz, const float* Szz, float* dmodv) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.E * a.C) return;
+  const int e = idx / a.C, c = idx % a.C, i = c / a.Cg, cb = i * a.E + e;
+  const long EC = (long)a.E * a.C;
+  const float mo = bn2[idx], rs2 = bn2[EC + idx], k2 = bn2[2 * EC + idx], h2 = bn2[3 * EC + idx];
+  const float* wu = a.up.p[e] + (long)c * a.dg;
+  const float gp = a.ln_post ? a.lpw.p[e][c] : 1.f;
+  const float* dBrow = dBp + (long)c * a.KPp;
+  const float* dBmain = dBrow + e * a.dgp;
+  const float dBh = dBrow[a.E * a.dgp + 3 * e + 0], dBg = dBrow[a.E * a.dgp + 3 * e + 1], dBb = dBrow[a.E * a.dgp + 3 * e + 2];
+  const float* dG = dGq + (long)cb * a.dgp * a.dgp;
+  const float* dus = dsm + (long)cb * a.dgp;
+  const float* dvh = dsm + a.DZ + (long)cb * a.dgp;
+  float dH1 = 0.f, dH2 = 0.f;
+  if (a.ln_post) { dH1 = dsm[8 * a.DZ + e]; dH2 = dsm[8 * a.DZ + a.E + e]; }
+  auto dWh_of = [&](int j) -> float {
+    float v = gp * dBmain[j];
+    if (a.ln_post) {
+      float acc = 0.f;
+      for (int l = 0; l < a.dg; ++l) acc += dG[j * a.dgp + l] * (wu[l] * k2);
+      v += 2.f * acc + dus[j] + dvh[j] * h2;
+    }
+    return v;
+  };
+  float dk2 = 0.f, dgp_acc = 0.f, dh2 = gp * dBh;
+  for (int j = 0; j < a.dg; ++j) {
+    const float dWh = dWh_of(j);
+    dk2 += dWh * wu[j];
+    dgp_acc += dBmain[j] * (wu[j] * k2);
+    if (a.ln_post) dh2 += dvh[j] * (wu[j] * k2);
+  }
+  if (a.ln_post) {
+    dh2 += dH1 + 2.f * h2 * dH2;
+    if (a.glpw.p[e]) a.glpw.p[e][c] = dgp_acc + dBh * h2 + dBg;
+    if (a.glpb.p[e]) a.glpb.p[e][c] = dBb;
+  }
+  float dmo = 0.f, dv2 = 0.f;
+  if (a.use_bn) {
+    if (a.gb2.p[e]) a.gb2.p[e][c] = dh2;
+    dmo = -k2 * dh2;
+    dk2 -= mo * dh2;
+    if (a.gw2.p[e]) a.gw2.p[e][c] = dk2 * rs2;
+    dv2 = dk2 * a.w2.p[e][c] * (-0.5f) * rs2 * rs2 * rs2;
+    if (a.training) dmo -= 2.f * mo * dv2; else { dmo = 0.f; dv2 = 0.f; }
+  }
+  dmodv[idx] = dmo; dmodv[EC + idx] = dv2;
+  const float* m = mz + (long)cb * a.dgp;
+  const float* S = Szz + (long)cb * a.dgp * a.dgp;
+  float* gu = a.gup.p[e] ? a.gup.p[e] + (long)c * a.dg : nullptr;
+  for (int j = 0; j < a.dg; ++j) {
+    float v = dWh_of(j) * k2;
+    if (a.use_bn && a.training) {
+      float acc = 0.f;
+      for (int l = 0; l < a.dg; ++l) acc += S[j * a.dgp + l] * wu[l];
+      v += dmo * m[j] + 2.f * dv2 * acc;
+    }
+    if (gu) gu[j] = v;
+  }
+}
+// block per (i, e): dmz / NT and 2 dSzz / NT
+__global__ void __launch_bounds__(256) kk_post_prep_bwd_b(PostPrepBwdArgs a, const float* dmodv, float* dsm, float* sdSzz) {
+  const int cb = blockIdx.x, i = cb / a.E, e = cb % a.E;
+  const long EC = (long)a.E * a.C;
+  const float* dmo = dmodv + (long)e * a.C + (long)i * a.Cg;
+  const float* dv2 = dmodv + EC + (long)e * a.C + (long)i * a.Cg;
+  const float* wu = a.up.p[e] + (long)i * a.Cg * a.dg;
+  const float inv = 1.f / (float)a.NT;
+  for (int pr = threadIdx.x; pr < a.dgp * a.dgp; pr += 256) {
+    const int j = pr / a.dgp, l = pr % a.dgp;
+    float acc = 0.f;
+    if (j < a.dg && l < a.dg) for (int c = 0; c < a.Cg; ++c) acc += dv2[c] * wu[(long)c * a.dg + j] * wu[(long)c * a.dg + l];
+    sdSzz[(long)cb * a.dgp * a.dgp + pr] = 2.f * acc * inv;
+  }
+  for (int j = threadIdx.x; j < a.dgp; j += 256) {
+    float acc = 0.f;
+    if (j < a.dg) for (int c = 0; c < a.Cg; ++c) acc += dmo[c] * wu[(long)c * a.dg + j];
+    dsm[2 * a.DZ + (long)cb * a.dgp + j] = acc * inv;
+  }
+}
+int k_post_prep_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                    hipStream_t st) {
+  const Dims& d = pl.d;
+  PostPrepBwdArgs a;
+  for (int e = 0; e < MAX_E; ++e) {
+    a.up.p[e] = prm.e[e].up_w; a.w2.p[e] = prm.e[e].bn2_w; a.lpw.p[e] = prm.e[e].lnp_w;
+    a.gup.p[e] = grads.e[e].up_w; a.gw2.p[e] = grads.e[e].bn2_w; a.gb2.p[e] = grads.e[e].bn2_b;
+    a.glpw.p[e] = grads.e[e].lnp_w; a.glpb.p[e] = grads.e[e].lnp_b;
+  }
+  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.C = d.C; a.KPp = d.KPp; a.NT = d.NT; a.DZ = d.DZ;
+  a.use_bn = d.use_bn; a.training = d.training; a.ln_post = d.ln_post;
+  hipLaunchKernelGGL(kk_post_prep_bwd_a, dim3(cdiv((long)d.E * d.C, 256)), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2),
+                     (const float*)(scratch + pl.o_dBp), (const float*)(scratch + pl.o_dGq), (const float*)(scratch + pl.o_dsm),
+                     (const float*)(saved + pl.o_mz), (const float*)(saved + pl.o_Szz), (float*)(scratch + pl.o_dmodv));
+  hipLaunchKernelGGL(kk_post_prep_bwd_b, dim3(d.g * d.E), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dmodv),
+                     (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_sdSzz));
+  AVMOE_CHECK_LAUNCH("post_prep_bwd");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MID backward: total dz' (direct + BN2-moment terms), ReLU mask, BN1 reduction sums.
+// ---------------------------------------------------------------------------------------------
+struct MidBwdArgs {
+  int relu_of_e[MAX_E]; W16 gw1, gb1;
+  int S, N, E, DD, DZ, dgp, dg, g, NT, use_bn, training, nblk;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) kk_mid_bwd(MidBwdArgs a, const float* Z, const float* bn1, const float* dsm,
+                                                  const float* sdSzz, float* dzp, float* colpart) {
+  extern __shared__ float smb[];
+  const int DD = a.DD, dgp = a.dgp;
+  float* s_S = smb;                        // g * dgp * dgp
+  float* s_z = s_S + a.g * dgp * dgp;      // 4 * DD
+  float* s_red = s_z + 4 * DD;             // 8 * DD
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (a.N + gridDim.x - 1) / gridDim.x;
+  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool moments = a.use_bn && a.training;
+  for (int e = 0; e < a.E; ++e) {
+    __syncthreads();
+    if (moments)
+      for (int i = threadIdx.x; i < a.g * dgp * dgp; i += 256) {
+        const int gi = i / (dgp * dgp);
+        s_S[i] = sdSzz[((long)(gi * a.E + e)) * dgp * dgp + (i % (dgp * dgp))];
+      }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    float c0[DR], c1[DR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { c0[u] = 0.f; c1[u] = 0.f; }
+    for (int n = n_beg + wave; n < n_end; n += 4) {
+      const long t = (long)s * a.N + n;
+      float yv[DR], zh[DR];
+      float* zs = s_z + wave * DD;
+      wave_lds_sync_b();
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        yv[u] = 0.f; zh[u] = 0.f;
+        if (dd < DD) {
+          const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
+          const float z = Z[t * a.DZ + col];
+          zh[u] = (z - bn1[col]) * bn1[a.DZ + col];
+          const float y = z * bn1[2 * a.DZ + col] + bn1[3 * a.DZ + col];
+          yv[u] = y;
+          zs[dd] = relu ? fmaxf(y, 0.f) : y;
+        }
+      }
+      wave_lds_sync_b();
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        if (dd < DD) {
+          const int gi = dd / dgp, jp = dd % dgp;
+          const int col = gi * a.E * dgp + e * dgp + jp;
+          float dz = dzp[t * a.DZ + col];
+          if (moments) {
+            const float* Sg = s_S + gi * dgp * dgp;
+            float w = 0.f;
+            for (int l2 = 0; l2 < dgp; ++l2) w += Sg[l2 * dgp + jp] * zs[gi * dgp + l2];
+            dz += dsm[2 * a.DZ + col] + w;
+          }
+          const float dy = (relu && yv[u] <= 0.f) ? 0.f : dz;
+          dzp[t * a.DZ + col] = dy;
+          c0[u] += dy;
+          c1[u] += dy * zh[u];
+        }
+      }
+    }
+    flush_cols(s_red, c0, c1, DD, dgp, a.E, e, a.DZ, colpart, blk, 2);
+  }
+}
+__global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* dsm) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.DZ) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 2) * a.DZ + col]; s1 += colpart[((long)b * 4 + 3) * a.DZ + col]; }
+  dsm[3 * a.DZ + col] = (float)(s0 / a.NT);
+  dsm[4 * a.DZ + col] = (float)(s1 / a.NT);
+  const int i = col / (a.E * a.dgp), e = (col / a.dgp) % a.E, jp = col % a.dgp;
+  if (a.use_bn && jp < a.dg) {
+    const int j = i * a.dg + jp;
+    if (a.gw1.p[e]) a.gw1.p[e][j] = (float)s1;
+    if (a.gb1.p[e]) a.gb1.p[e][j] = (float)s0;
+  }
+}
+int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  const Dims& d = pl.d;
+  MidBwdArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.relu_of_e[e] = d.relu_of_e[e]; a.gw1.p[e] = grads.e[e].bn1_w; a.gb1.p[e] = grads.e[e].bn1_b; }
+  a.S = d.S; a.N = d.N; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.dg = d.dg; a.g = d.g; a.NT = d.NT;
+  a.use_bn = d.use_bn; a.training = d.training; a.nblk = d.nblk_tok;
+  const size_t sh = (size_t)(d.g * d.dgp * d.dgp + 12 * d.DD) * sizeof(float);
+  AVMOE_TRY(lds_attr(d.bf16 ? (const void*)kk_mid_bwd<__bf16> : (const void*)kk_mid_bwd<float>, sh, "mid_bwd"));
+  dim3 grid; tok_grid_b(d, &grid);
+  DISPATCH_T(d.bf16, kk_mid_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (float*)(scratch + pl.o_dzp),
+             (float*)(scratch + pl.o_colpart));
+  hipLaunchKernelGGL(kk_mid_bwd_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colpart),
+                     (float*)(scratch + pl.o_dsm));
+  AVMOE_CHECK_LAUNCH("mid_bwd");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PRE_SMALL backward: BN1 input gradient, folded-LayerNorm statistics, hop-2 softmax.
+// ---------------------------------------------------------------------------------------------
+struct PreBwdArgs {
+  P16 glat; int lat_of_e[MAX_E];
+  int S, N, C, E, K, Kp, El, KL, KLT, KLp, DD, DZ, dgp, g, NT, ln_before, use_bn, training;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) kk_pre_small_bwd(PreBwdArgs a, const float* Z, const float* L2, const float* TT,
+                                                        const float* TW, const float* Tsum, const float* wsum,
+                                                        const float* dconst, const void* ain_, const float* rmu,
+                                                        const float* bn1, const float* dsm, const float* dy_in, void* dZx_,
+                                                        void* dL2x_, void* aw_, void* ag_, float* dsxs, float* rs2x,
+                                                        float* colpart, float* blkscal, float* dtbp) {
+  const T* ain = (const T*)ain_;
+  T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
+  extern __shared__ float smb[];
+  const int K = a.K, DD = a.DD;
+  float* s_TT = smb;                       // K*K
+  float* s_TW = s_TT + K * K;              // K*DD     [k][dd]
+  float* s_TWt = s_TW + K * DD;            // DD*K     [dd][k]
+  float* s_tb = s_TWt + K * DD;            // K
+  float* s_a = s_tb + K;                   // 4*K
+  float* s_dz = s_a + 4 * K;               // 4*DD
+  float* s_red = s_dz + 4 * DD;            // 8*DD
+  float* s_scal = s_red + 8 * DD;          // 16
+  float* s_tbr = s_scal + 16;              // 4*K  (dtbar per wave)
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (a.N + gridDim.x - 1) / gridDim.x;
+  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool bn_train = a.use_bn && a.training;
+  for (int e = 0; e < a.E; ++e) {
+    const int l = a.lat_of_e[e];
+    float gv = 0.f;
+    __syncthreads();
+    if (l >= 0) {
+      gv = a.glat.p[e][0];
+      const float* tt = TT + ((long)s * a.El + l) * K * K;
+      for (int i = threadIdx.x; i < K * K; i += 256) s_TT[i] = tt[i];
+      for (int i = threadIdx.x; i < K * DD; i += 256) {
+        const int k = i / DD, dd = i % DD;
+        const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
+        const float v = TW[((long)s * a.KLT + (long)l * a.Kp + k) * a.DZ + col];
+        s_TW[i] = v; s_TWt[dd * K + k] = v;
+      }
+      for (int i = threadIdx.x; i < K; i += 256) s_tb[i] = Tsum[(long)s * a.KLT + (long)l * a.Kp + i] / (float)a.C;
+    }
+    __syncthreads();
+    float c0[DR], c1[DR], tbacc[KR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { c0[u] = 0.f; c1[u] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < KR; ++u) tbacc[u] = 0.f;
+    float sdg = 0.f;
+    for (int n = n_beg + wave; n < n_end; n += 4) {
+      const long t = (long)s * a.N + n;
+      const float r = a.ln_before ? rmu[t * a.E + e] : 1.f;
+      const float mu = a.ln_before ? rmu[(long)a.NT * a.E + t * a.E + e] : 0.f;
+      float* dzs = s_dz + wave * DD;
+      float* aw = s_a + wave * K;
+      float dzraw[DR];
+      float s_dr = 0.f, s_dmu = 0.f;
+      wave_lds_sync_b();
+#pragma unroll
+      for (int u = 0; u < DR; ++u) {
+        const int dd = lane + 64 * u;
+        dzraw[u] = 0.f;
+        if (dd < DD) {
+          const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
+          const float z = Z[t * a.DZ + col];
+          float dz = dy_in[t * a.DZ + col];
+          if (a.use_bn) {
+            const float sc = bn1[2 * a.DZ + col];
+            if (bn_train) {
+              const float zh = (z - bn1[col]) * bn1[a.DZ + col];
+              dz = sc * (dz - dsm[3 * a.DZ + col] - zh * dsm[4 * a.DZ + col]);
+            } else dz = sc * dz;
+          }
+          if (a.ln_before) {
+            const float zc = (z - dconst[col]) / r;          // zraw - mu * wsum
+            c0[u] += dz;                                      // d dconst
+            c1[u] += -r * mu * dz;                            // d wsum
+            s_dr += dz * zc;
+            s_dmu += dz * wsum[col];
+            dzraw[u] = r * dz;
+          } else dzraw[u] = dz;
+          stT<T>(dZx, t * a.DZ + col, dzraw[u]);
+          dzs[dd] = dzraw[u];
+        }
+      }
+      float dSx = 0.f, dSxx = 0.f;
+      if (a.ln_before) {
+        s_dr = wave_sum(s_dr); s_dmu = wave_sum(s_dmu);
+        float dmu = -r * s_dmu;
+        const float dvar = s_dr * (-0.5f) * r * r * r;
+        dSxx = dvar / (float)a.C;
+        dmu -= 2.f * mu * dvar;
+        dSx = dmu / (float)a.C;
+      }
+      if (lane == 0) {
+        if (e == 0) { dsxs[t] = dSx; dsxs[a.NT + t] = dSxx; }
+        else { dsxs[t] += dSx; dsxs[a.NT + t] += dSxx; }
+      }
+      if (l >= 0) {
+        const float* l2 = L2 + t * a.KLp + (long)l * a.Kp;
+        float av[KR], lv[KR];
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+          const int k = lane + 64 * u;
+          av[u] = 0.f; lv[u] = 0.f;
+          if (k < K) { av[u] = ldT<T>(ain, t * a.KLp + (long)l * a.Kp + k); lv[u] = l2[k]; aw[k] = av[u]; }
+        }
+        wave_lds_sync_b();
+        float u1 = 0.f, u2 = 0.f, u3 = 0.f, ta[KR];
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+          const int k = lane + 64 * u;
+          ta[u] = 0.f;
+          if (k < K) {
+            float w = 0.f;
+            for (int k2 = 0; k2 < K; ++k2) w += s_TT[k2 * K + k] * aw[k2];
+            ta[u] = w;                                        // (TT a)_k
+            u1 += av[u] * s_tb[k]; u2 += av[u] * lv[u]; u3 += av[u] * w;
+          }
+        }
+        u1 = wave_sum(u1); u2 = wave_sum(u2); u3 = wave_sum(u3);
+        float dgp = 0.f;
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+          const int dd = lane + 64 * u;
+          if (dd < DD) {
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) acc += aw[k] * s_TW[k * DD + dd];
+            dgp += dzraw[u] * acc;
+          }
+        }
+        dgp = wave_sum(dgp);
+        sdg += dSx * (float)a.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgp;
+        const float du1 = dSx * gv * (float)a.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
+        float da[KR], sada = 0.f;
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+          const int k = lane + 64 * u;
+          da[u] = 0.f;
+          if (k < K) {
+            float acc = 0.f;
+            for (int dd = 0; dd < DD; ++dd) acc += s_TWt[dd * K + k] * dzs[dd];
+            da[u] = gv * acc + du1 * s_tb[k] + du2 * lv[u] + 2.f * du3 * ta[u];
+            sada += av[u] * da[u];
+            tbacc[u] += du1 * av[u];
+          }
+        }
+        sada = wave_sum(sada);
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+          const int k = lane + 64 * u;
+          const long o = t * a.KLp + (long)l * a.Kp + k;
+          if (k < K) {
+            stT<T>(dL2x, o, du2 * av[u] + av[u] * (da[u] - sada));
+            stT<T>(aw_o, o, du3 * av[u]);
+            stT<T>(ag_o, o, gv * av[u]);
+          } else if (k < a.Kp) { stT<T>(dL2x, o, 0.f); stT<T>(aw_o, o, 0.f); stT<T>(ag_o, o, 0.f); }
+        }
+      }
+      if (e == a.E - 1 && lane == 0) {
+        stT<T>(dL2x, t * a.KLp + a.KL, dsxs[t]);
+        stT<T>(dL2x, t * a.KLp + a.KL + 1, 1.f);
+        rs2x[t] = 2.f * dsxs[a.NT + t];
+      }
+    }
+    flush_cols(s_red, c0, c1, DD, a.dgp, a.E, e, a.DZ, colpart, blk, 0);
+    flush_scal(s_scal, 0.f, 0.f, 0.f, sdg, blkscal + ((long)blk * a.E + e) * 4, 0x8u);
+    if (l >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < KR; ++u) { const int k = lane + 64 * u; if (k < K) s_tbr[wave * K + k] = tbacc[u]; }
+      __syncthreads();
+      for (int k = threadIdx.x; k < K; k += 256)
+        dtbp[(long)blk * a.KL + (long)l * a.Kp + k] = s_tbr[k] + s_tbr[K + k] + s_tbr[2 * K + k] + s_tbr[3 * K + k];
+    }
+  }
+}
+struct PreFinArgs { W16 gglat; int lat_of_e[MAX_E]; int S, E, DZ, KL, nblk, bps; };
+__global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const float* colpart, const float* blkscal,
+                                                           const float* dtbp, float* dsm, float* dtbar) {
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 0) * a.DZ + col]; s1 += colpart[((long)b * 4 + 1) * a.DZ + col]; }
+    dsm[5 * a.DZ + col] = (float)s0; dsm[6 * a.DZ + col] = (float)s1;
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)a.S * a.KL; i += (long)gridDim.x * 256) {
+    const int s = (int)(i / a.KL), kc = (int)(i % a.KL);
+    float acc = 0.f;
+    for (int b = 0; b < a.bps; ++b) acc += dtbp[((long)s * a.bps + b) * a.KL + kc];
+    dtbar[i] = acc;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ float red[4];
+    for (int e = 0; e < a.E; ++e) {
+      if (a.lat_of_e[e] < 0) continue;
+      float acc = 0.f;
+      for (int b = threadIdx.x; b < a.nblk; b += 256) acc += blkscal[((long)b * a.E + e) * 4 + 3];
+      acc = block_sum256(acc, red);
+      if (threadIdx.x == 0 && a.gglat.p[e]) a.gglat.p[e][0] = acc;
+    }
+  }
+}
+int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                    hipStream_t st) {
+  const Dims& d = pl.d;
+  PreBwdArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.K = d.K; a.Kp = d.Kp; a.El = d.El; a.KL = d.KL; a.KLT = d.KLT; a.KLp = d.KLp; a.DD = d.DD;
+  a.DZ = d.DZ; a.dgp = d.dgp; a.g = d.g; a.NT = d.NT; a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.training = d.training;
+  const size_t sh = (size_t)(d.K * d.K + 2 * d.K * d.DD + d.K + 4 * d.K + 4 * d.DD + 8 * d.DD + 16 + 4 * d.K) * sizeof(float);
+  AVMOE_TRY(lds_attr(d.bf16 ? (const void*)kk_pre_small_bwd<__bf16> : (const void*)kk_pre_small_bwd<float>, sh, "pre_small_bwd"));
+  dim3 grid; tok_grid_b(d, &grid);
+  DISPATCH_T(d.bf16, kk_pre_small_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2),
+             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
+             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a),
+             (const float*)(saved + pl.o_rmu), (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm),
+             (const float*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw),
+             (void*)(scratch + pl.o_ag), (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x),
+             (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
+  PreFinArgs f;
+  for (int e = 0; e < MAX_E; ++e) { f.gglat.p[e] = grads.e[e].gate_lat; f.lat_of_e[e] = d.lat_of_e[e]; }
+  f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.KL = d.KL; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S;
+  hipLaunchKernelGGL(kk_pre_bwd_finalize, dim3(std::max(1, cdiv(std::max((long)d.DZ, (long)d.S * d.KL), 256))), dim3(256), 0, st, f,
+                     (const float*)(scratch + pl.o_colpart), (const float*)(scratch + pl.o_blkscal),
+                     (const float*)(scratch + pl.o_dtbp), (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_dtbar));
+  AVMOE_CHECK_LAUNCH("pre_small_bwd");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// router backward (mixture weights, LB loss, 3-layer MLP)   net_trans_v3.py:460-466,477-478
+// rbw layout: dlog [S][E] | dh2r [S][32] | dh1 [S][128] | drin [S][2C]
+// ---------------------------------------------------------------------------------------------
+struct RouterBwdArgs { const float *W1, *W2, *W3; int C2, E, S, lb_loss; float lb_weight; };
+__global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const float* probs, const float* dp, const float* rh1,
+                                                       const float* rh2, float* rbw, void* drinT_, int bf16, void* Text_, int KLT,
+                                                       int KL, int C, int N) {
+  __shared__ float s_dl[MAX_E], s_d2[32], s_d1[128], s_pm[MAX_E];
+  const int s = blockIdx.x;
+  float* dlog = rbw + (long)s * a.E;
+  float* dh2 = rbw + (long)a.S * a.E + (long)s * 32;
+  float* dh1 = rbw + (long)a.S * (a.E + 32) + (long)s * 128;
+  float* drin = rbw + (long)a.S * (a.E + 32 + 128) + (long)s * a.C2;
+  if (threadIdx.x < a.E) {                       // column means of p for the LB loss
+    float acc = 0.f;
+    for (int ss = 0; ss < a.S; ++ss) acc += probs[(long)ss * a.E + threadIdx.x];
+    s_pm[threadIdx.x] = acc / (float)a.S;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float dot = 0.f, dpv[MAX_E];
+    for (int e = 0; e < a.E; ++e) {
+      dpv[e] = dp[(long)s * a.E + e];
+      if (a.lb_loss) dpv[e] += a.lb_weight * (-1.f / ((float)a.S * s_pm[e]));
+      dot += probs[(long)s * a.E + e] * dpv[e];
+    }
+    for (int e = 0; e < a.E; ++e) { const float v = probs[(long)s * a.E + e] * (dpv[e] - dot); s_dl[e] = v; dlog[e] = v; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float acc = 0.f;
+    for (int e = 0; e < a.E; ++e) acc += s_dl[e] * a.W3[e * 32 + threadIdx.x];
+    const float v = rh2[(long)s * 32 + threadIdx.x] > 0.f ? acc : 0.f;
+    s_d2[threadIdx.x] = v; dh2[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float acc = 0.f;
+    for (int j = 0; j < 32; ++j) acc += s_d2[j] * a.W2[j * 128 + threadIdx.x];
+    const float v = rh1[(long)s * 128 + threadIdx.x] > 0.f ? acc : 0.f;
+    s_d1[threadIdx.x] = v; dh1[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.C2; i += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < 128; ++j) acc += s_d1[j] * a.W1[(long)j * a.C2 + i];
+    drin[i] = acc;
+    if (bf16) ((unsigned short*)drinT_)[(long)s * a.C2 + i] = f2bf(acc); else ((float*)drinT_)[(long)s * a.C2 + i] = acc;
+    if (i < C) {                                   // dm1 / N  into the extra row of Text[s]
+      const long o = ((long)s * KLT + KL + 1) * C + i;
+      const float v = acc / (float)N;
+      if (bf16) ((unsigned short*)Text_)[o] = f2bf(v); else ((float*)Text_)[o] = v;
+    }
+  }
+}
+// weight gradients: thread per weight element, loop over frames
+__global__ void kk_router_bwd_b(int S, int E, int C2, const float* rbw, const float* rin, const float* rh1, const float* rh2,
+                                float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
+  const float* dlog = rbw;
+  const float* dh2 = rbw + (long)S * E;
+  const float* dh1 = rbw + (long)S * (E + 32);
+  const long n1 = 128L * C2, n2 = 32 * 128, n3 = (long)E * 32, nb = 128 + 32 + E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + nb; i += (long)gridDim.x * 256) {
+    float acc = 0.f;
+    if (i < n1) {
+      const int j = (int)(i / C2), c = (int)(i % C2);
+      for (int s = 0; s < S; ++s) acc += dh1[(long)s * 128 + j] * rin[(long)s * C2 + c];
+      if (gW1) gW1[i] = acc;
+    } else if (i < n1 + n2) {
+      const long k = i - n1; const int j = (int)(k / 128), c = (int)(k % 128);
+      for (int s = 0; s < S; ++s) acc += dh2[(long)s * 32 + j] * rh1[(long)s * 128 + c];
+      if (gW2) gW2[k] = acc;
+    } else if (i < n1 + n2 + n3) {
+      const long k = i - n1 - n2; const int j = (int)(k / 32), c = (int)(k % 32);
+      for (int s = 0; s < S; ++s) acc += dlog[(long)s * E + j] * rh2[(long)s * 32 + c];
+      if (gW3) gW3[k] = acc;
+    } else {
+      const long k = i - n1 - n2 - n3;
+      if (k < 128) { for (int s = 0; s < S; ++s) acc += dh1[(long)s * 128 + k]; if (gb1) gb1[k] = acc; }
+      else if (k < 160) { for (int s = 0; s < S; ++s) acc += dh2[(long)s * 32 + (k - 128)]; if (gb2) gb2[k - 128] = acc; }
+      else { for (int s = 0; s < S; ++s) acc += dlog[(long)s * E + (k - 160)]; if (gb3) gb3[k - 160] = acc; }
+    }
+  }
+}
+int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                 float lb_weight, hipStream_t st) {
+  const Dims& d = pl.d;
+  RouterBwdArgs a{prm.r0_w, prm.r2_w, prm.r4_w, 2 * d.C, d.E, d.S, d.lb_loss, lb_weight};
+  hipLaunchKernelGGL(kk_router_bwd_a, dim3(d.S), dim3(256), 0, st, a, (const float*)(saved + pl.o_probs),
+                     (const float*)(scratch + pl.o_dp), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
+                     (float*)(scratch + pl.o_rbw), (void*)(scratch + pl.o_drinT), d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL,
+                     d.C, d.N);
+  const long tot = 128L * 2 * d.C + 32 * 128 + (long)d.E * 32 + 160 + d.E;
+  hipLaunchKernelGGL(kk_router_bwd_b, dim3(grid1db(tot)), dim3(256), 0, st, d.S, d.E, 2 * d.C, (const float*)(scratch + pl.o_rbw),
+                     (const float*)(saved + pl.o_rin), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
+                     grads.r0_w, grads.r0_b, grads.r2_w, grads.r2_b, grads.r4_w, grads.r4_b);
+  AVMOE_CHECK_LAUNCH("router_bwd");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row softmax backward: dl = a * (da - sum(a * da)); optional transposed copy out_t[n][row_in_group]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) kk_softmax_rows_bwd(const void* a_, const float* da, long rows, int n, int ld, void* out_,
+                                                           void* outT_, int grp, int ld_t) {
+  const T* a = (const T*)a_;
+  T* out = (T*)out_; T* outT = (T*)outT_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float dot = 0.f;
+    for (int j = lane; j < n; j += 64) dot += ldT<T>(a, row * ld + j) * da[row * ld + j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < ld; j += 64) {
+      const float v = j < n ? ldT<T>(a, row * ld + j) * (da[row * ld + j] - dot) : 0.f;
+      stT<T>(out, row * ld + j, v);
+      if (outT && j < n) stT<T>(outT, ((row / grp) * n + j) * ld_t + (row % grp), v);
+    }
+  }
+}
+int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, void* out_t, int grp,
+                       int ldT, hipStream_t st) {
+  if (rows <= 0) return OK;
+  DISPATCH_T(bf16, kk_softmax_rows_bwd, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, a, da, rows, n, ld,
+             out_dl, out_t, grp, ldT);
+  AVMOE_CHECK_LAUNCH("softmax_rows_bwd");
+  return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hop-1 backward glue
+// ---------------------------------------------------------------------------------------------
+// dT += dtbar / C ; split into the cross-modal block dTy (T, Kcyb rows: last = dm2) and the latent-on-X block dTx (T);
+// dabx[s][kc'] = dTy[s][kc'] . rw
+template <typename T>
+__global__ void __launch_bounds__(256) kk_finish_dT(const float* dT, const float* dtbar, const float* rbw_drin, const float* rw,
+                                                    void* dTy_, void* dTx_, float* dabx, int S, int KL, int Kcy, int Kcyb, int Kcx,
+                                                    int C) {
+  T* dTy = (T*)dTy_; T* dTx = (T*)dTx_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long rows = (long)S * (Kcyb + Kcx);
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const int s = (int)(r / (Kcyb + Kcx)), q = (int)(r % (Kcyb + Kcx));
+    float dot = 0.f;
+    if (q < Kcyb) {
+      for (int c = lane; c < C; c += 64) {
+        float v;
+        if (q < Kcy) v = dT[((long)s * KL + q) * C + c] + dtbar[(long)s * KL + q] / (float)C;
+        else v = rbw_drin[(long)s * 2 * C + C + c];                                    // dm2
+        v = roundTb<T>(v);
+        stT<T>(dTy, ((long)s * Kcyb + q) * C + c, v);
+        dot += v * rw[c];
+      }
+      dot = wave_sum(dot);
+      if (lane == 0) dabx[(long)s * Kcyb + q] = dot;
+    } else {
+      const int kx = q - Kcyb;
+      for (int c = lane; c < C; c += 64)
+        stT<T>(dTx, ((long)s * Kcx + kx) * C + c, dT[((long)s * KL + Kcy + kx) * C + c] + dtbar[(long)s * KL + Kcy + kx] / (float)C);
+    }
+  }
+}
+// column reductions over frames: dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar/C) ; drw[c], dbf[c] from dTy and abx
+template <typename T>
+__global__ void kk_dT_colsums(const float* dT, const float* dtbar, const void* dTy_, const void* BmX_, const float* scal, float* dT0,
+                              float* dvec, int S, int KL, int Kcy, int Kcyb, int C, int Mb, int M) {
+  const T* dTy = (const T*)dTy_; const T* BmX = (const T*)BmX_;
+  const long n1 = (long)KL * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + C; i += (long)gridDim.x * 256) {
+    if (i < n1) {
+      const int kc = (int)(i / C);
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] / (float)C;
+      dT0[i] = acc;
+    } else {
+      const int c = (int)(i - n1);
+      float drw = 0.f, dbf = 0.f;
+      for (int s = 0; s < S; ++s)
+        for (int q = 0; q < Kcyb; ++q) {
+          const float v = ldT<T>(dTy, ((long)s * Kcyb + q) * C + c);
+          const float ab = q < Kcy ? ldT<T>(BmX, ((long)s * Kcyb + q) * Mb + M) : scal[0];
+          drw += v * ab; dbf += v;
+        }
+      dvec[c] = drw; dvec[C + c] = dbf;
+    }
+  }
+}
+// dBmT = T([dBm | dabx | 0]) ; dwbar[m] = sum_s dBm[s][Kcy][m] ; dbcbar = sum_s dabx[s][Kcy]
+template <typename T>
+__global__ void kk_prep_dBm(const float* dBm, const float* dabx, void* dBmT_, float* dvec, int S, int Kcy, int Kcyb, int M, int Mb,
+                            int C) {
+  T* dBmT = (T*)dBmT_;
+  const long tot = (long)S * Kcyb * Mb;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot + Mb + 1; i += (long)gridDim.x * 256) {
+    if (i < tot) {
+      const int m = (int)(i % Mb);
+      const long row = i / Mb;
+      const int q = (int)(row % Kcyb);
+      float v = 0.f;
+      if (q < Kcy) v = m < M ? dBm[i] : (m == M ? dabx[row] : 0.f);
+      stT<T>(dBmT, i, v);
+    } else if (i < tot + Mb) {
+      const int m = (int)(i - tot);
+      float acc = 0.f;
+      if (m < M) for (int s = 0; s < S; ++s) acc += dBm[((long)s * Kcyb + Kcy) * Mb + m];
+      dvec[2 * C + m] = acc;
+    } else {
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += dabx[(long)s * Kcyb + Kcy];
+      dvec[2 * C + Mb] = acc;
+    }
+  }
+}
+// dqr[kc] = sum_{s,n} dL1 bc[n] ; dqb[kc] = sum_{s,n} dL1     (partials per (s,kc) row, then over s)
+template <typename T>
+__global__ void __launch_bounds__(256) kk_dqrqb_part(const void* dL1_, const float* bc, float* part, long rows, int n, int ld) {
+  const T* dL1 = (const T*)dL1_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float a = 0.f, b = 0.f;
+    for (int j = lane; j < n; j += 64) { const float v = ldT<T>(dL1, row * ld + j); a += v * bc[j]; b += v; }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) { part[row] = a; part[rows + row] = b; }
+  }
+}
+__global__ void kk_dqrqb_fin(const float* part, float* out, int S, int Kcyb) {
+  const int kc = blockIdx.x * 256 + threadIdx.x;
+  if (kc >= Kcyb) return;
+  const long rows = (long)S * Kcyb;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < S; ++s) { a += part[(long)s * Kcyb + kc]; b += part[rows + (long)s * Kcyb + kc]; }
+  out[kc] = a; out[Kcyb + kc] = b;
+}
+// final assembly of the remap / token parameter gradients
+struct Hop1FinArgs { W16 gtok; int e_of_lat[MAX_E]; int S, N, M, Mk, Mb, C, Cy, K, Kp, KL, Kcy, Kcyb; };
+template <typename T>
+__global__ void kk_hop1_finalize(Hop1FinArgs a, const float* dWcK, const float* dWf, const float* dvec, const float* dT0,
+                                 const float* dqp_fin, const void* T0T_, const float* rw, const float* bf, float* gWc, float* gbc,
+                                 float* gWf, float* gbf) {
+  const T* T0T = (const T*)T0T_;
+  const float* drw0 = dvec; const float* dbf0 = dvec + a.C; const float* dwbar = dvec + 2 * a.C;
+  const float dbcbar = dvec[2 * a.C + a.Mb];
+  const float* dqr = dqp_fin; const float* dqb = dqp_fin + a.Kcyb;
+  const long n1 = (long)a.N * a.M, n2 = a.N, n3 = (long)a.C * a.Cy, n4 = a.C, n5 = (long)a.KL * a.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + n4 + n5; i += (long)gridDim.x * 256) {
+    if (i < n1) {
+      const int n = (int)(i / a.M), m = (int)(i % a.M);
+      if (gWc) gWc[i] = dWcK[(long)n * a.Mk + m] + dwbar[m] / (float)a.N;
+    } else if (i < n1 + n2) {
+      const int n = (int)(i - n1);
+      if (gbc) gbc[n] = dWcK[(long)n * a.Mk + a.M] + dbcbar / (float)a.N;
+    } else if (i < n1 + n2 + n3) {
+      const long k = i - n1 - n2;
+      const int c = (int)(k / a.Cy);
+      float drw = drw0[c];
+      for (int kc = 0; kc < a.Kcy; ++kc) drw += ldT<T>(T0T, (long)kc * a.C + c) * dqr[kc];
+      if (gWf) gWf[k] = dWf[k] + drw;                  // rw = Wf 1  =>  every column of row c gets drw[c]
+    } else if (i < n1 + n2 + n3 + n4) {
+      const int c = (int)(i - n1 - n2 - n3);
+      float v = dbf0[c];
+      for (int kc = 0; kc < a.Kcy; ++kc) v += ldT<T>(T0T, (long)kc * a.C + c) * dqb[kc];
+      if (gbf) gbf[c] = v;
+    } else {
+      const long k = i - n1 - n2 - n3 - n4;
+      const int kc = (int)(k / a.C), c = (int)(k % a.C);
+      float v = dT0[k];
+      if (kc < a.Kcy) v += dqr[kc] * rw[c] + dqb[kc] * bf[c];
+      float* gt = a.gtok.p[a.e_of_lat[kc / a.Kp]];
+      if (gt && (kc % a.Kp) < a.K) gt[(long)(kc % a.Kp) * a.C + c] = v;
+    }
+  }
+}
+
+// down projection / ln_before gradients from dWt (+ dwsum, ddconst)
+struct DownBwdArgs { P16 down, lnbw, lnbb; W16 gdown, glnbw, glnbb; int E, g, dg, dgp, Cg, DZ, ln_before; };
+__global__ void kk_down_bwd(DownBwdArgs a, const float* dWt, const float* dsm) {
+  const long tot = (long)a.E * a.g * a.Cg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % a.Cg), gi = (int)((i / a.Cg) % a.g), e = (int)(i / ((long)a.Cg * a.g));
+    const float gb = a.ln_before ? a.lnbw.p[e][gi * a.Cg + c] : 1.f;
+    const float bb = a.ln_before ? a.lnbb.p[e][gi * a.Cg + c] : 0.f;
+    float dgb = 0.f, dbb = 0.f;
+    for (int jp = 0; jp < a.dg; ++jp) {
+      const int row = (gi * a.E + e) * a.dgp + jp;
+      float dwt = dWt[(long)row * a.Cg + c];
+      float ddc = 0.f;
+      if (a.ln_before) { dwt += dsm[6 * a.DZ + row]; ddc = dsm[5 * a.DZ + row]; }
+      const float wd = a.down.p[e][(long)(gi * a.dg + jp) * a.Cg + c];
+      if (a.gdown.p[e]) a.gdown.p[e][(long)(gi * a.dg + jp) * a.Cg + c] = dwt * gb + ddc * bb;
+      dgb += dwt * wd; dbb += ddc * wd;
+    }
+    if (a.ln_before) {
+      if (a.glnbw.p[e]) a.glnbw.p[e][gi * a.Cg + c] = dgb;
+      if (a.glnbb.p[e]) a.glnbb.p[e][gi * a.Cg + c] = dbb;
+    }
+  }
+}
+
+// ---- host wrappers for the glue ---------------------------------------------------------------
+int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  const Dims& d = pl.d;
+  const float* drin = (const float*)(scratch + pl.o_rbw) + (long)d.S * (d.E + 32 + 128);
+  const long rows = (long)d.S * (d.Kcyb + d.Kcx);
+  DISPATCH_T(d.bf16, kk_finish_dT, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st,
+             (const float*)(scratch + pl.o_dT), (const float*)(scratch + pl.o_dtbar), drin, (const float*)(saved + pl.o_rw),
+             (void*)(scratch + pl.o_dTy), (void*)(scratch + pl.o_dTx), (float*)(scratch + pl.o_dabx), d.S, d.KL, d.Kcy, d.Kcyb, d.Kcx, d.C);
+  DISPATCH_T(d.bf16, kk_dT_colsums, dim3(grid1db((long)d.KL * d.C + d.C)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
+             (const float*)(scratch + pl.o_dtbar), (const void*)(scratch + pl.o_dTy), (const void*)(saved + pl.o_BmX),
+             (const float*)(saved + pl.o_scal), (float*)(scratch + pl.o_dT0), (float*)(scratch + pl.o_dvec), d.S, d.KL, d.Kcy, d.Kcyb,
+             d.C, d.Mb, d.M);
+  AVMOE_CHECK_LAUNCH("finish_dT");
+  return OK;
+}
+int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
+  const Dims& d = pl.d;
+  const long tot = (long)d.S * d.Kcyb * d.Mb + d.Mb + 1;
+  DISPATCH_T(d.bf16, kk_prep_dBm, dim3(grid1db(tot)), dim3(256), 0, st, (const float*)(scratch + pl.o_dBm),
+             (const float*)(scratch + pl.o_dabx), (void*)(scratch + pl.o_dBmT), (float*)(scratch + pl.o_dvec), d.S, d.Kcy, d.Kcyb, d.M,
+             d.Mb, d.C);
+  AVMOE_CHECK_LAUNCH("prep_dBm");
+  return OK;
+}
+int k_dqrqb(const Plan& pl, char* scratch, const float* bc, hipStream_t st) {
+  const Dims& d = pl.d;
+  const long rows = (long)d.S * d.Kcyb;
+  float* part = (float*)(scratch + pl.o_dqp);
+  DISPATCH_T(d.bf16, kk_dqrqb_part, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st,
+             (const void*)(scratch + pl.o_dL1), bc, part, rows, d.N, d.Np);
+  hipLaunchKernelGGL(kk_dqrqb_fin, dim3(cdiv(d.Kcyb, 256)), dim3(256), 0, st, (const float*)part, part + 2 * rows, d.S, d.Kcyb);
+  AVMOE_CHECK_LAUNCH("dqrqb");
+  return OK;
+}
+int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  const Dims& d = pl.d;
+  Hop1FinArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gtok.p[e] = grads.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e]; }
+  a.S = d.S; a.N = d.N; a.M = d.M; a.Mk = d.Mk; a.Mb = d.Mb; a.C = d.C; a.Cy = d.Cy; a.K = d.K; a.Kp = d.Kp; a.KL = d.KL; a.Kcy = d.Kcy; a.Kcyb = d.Kcyb;
+  const long tot = (long)d.N * d.M + d.N + (long)d.C * d.Cy + d.C + (long)d.KL * d.C;
+  const float* dqp_fin = (const float*)(scratch + pl.o_dqp) + 2L * d.S * d.Kcyb;
+  DISPATCH_T(d.bf16, kk_hop1_finalize, dim3(grid1db(tot)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWcK),
+             (const float*)(scratch + pl.o_dWf), (const float*)(scratch + pl.o_dvec), (const float*)(scratch + pl.o_dT0), dqp_fin,
+             (const void*)(saved + pl.o_T0T), (const float*)(saved + pl.o_rw), (const float*)prm.fc_b, grads.conv_w, grads.conv_b,
+             grads.fc_w, grads.fc_b);
+  AVMOE_CHECK_LAUNCH("hop1_finalize");
+  return OK;
+}
+int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  const Dims& d = pl.d;
+  DownBwdArgs a;
+  for (int e = 0; e < MAX_E; ++e) {
+    a.down.p[e] = prm.e[e].down_w; a.lnbw.p[e] = prm.e[e].lnb_w; a.lnbb.p[e] = prm.e[e].lnb_b;
+    a.gdown.p[e] = grads.e[e].down_w; a.glnbw.p[e] = grads.e[e].lnb_w; a.glnbb.p[e] = grads.e[e].lnb_b;
+  }
+  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.DZ = d.DZ; a.ln_before = d.ln_before;
+  hipLaunchKernelGGL(kk_down_bwd, dim3(grid1db((long)d.E * d.g * d.Cg)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWt),
+                     (const float*)(scratch + pl.o_dsm));
+  AVMOE_CHECK_LAUNCH("down_bwd");
+  return OK;
+}
+
+}  // namespace avmoe

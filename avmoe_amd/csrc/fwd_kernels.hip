@@ -125,7 +125,7 @@ int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, 
 struct PrepExpArgs {
   P16 down, lnbw, lnbb, tok;
   int e_of_lat[MAX_E];
-  int E, g, dg, dgp, Cg, C, K, KL, ln_before;
+  int E, g, dg, dgp, Cg, C, K, Kp, KL, ln_before;
 };
 
 template <typename T>
@@ -153,9 +153,9 @@ __global__ void __launch_bounds__(256) kk_prep_experts(PrepExpArgs a, void* Wt_,
   } else {
     const int r = blockIdx.x - nrow;
     if (r < a.KL) {
-      const int l = r / a.K, k = r % a.K;
+      const int l = r / a.Kp, k = r % a.Kp;
       const float* tk = a.tok.p[a.e_of_lat[l]];
-      for (int c = threadIdx.x; c < a.C; c += 256) stT<T>(T0T, (long)r * a.C + c, tk[(long)k * a.C + c]);
+      for (int c = threadIdx.x; c < a.C; c += 256) stT<T>(T0T, (long)r * a.C + c, k < a.K ? tk[(long)k * a.C + c] : 0.f);
     }
   }
 }
@@ -178,7 +178,7 @@ int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipSt
     }
     if (d.lat_of_e[e] >= 0 && (!x.my_tokens || !x.gate_lat)) { set_last_error("moe: expert %d lacks my_tokens / gate_av", e); return ERR_BAD_ARG; }
   }
-  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.C = d.C; a.K = d.K; a.KL = d.KL; a.ln_before = d.ln_before;
+  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.C = d.C; a.K = d.K; a.Kp = d.Kp; a.KL = d.KL; a.ln_before = d.ln_before;
   const int nblk = d.g * d.E * d.dgp + d.KL;
   DISPATCH_T(d.bf16, kk_prep_experts, dim3(nblk), dim3(256), 0, st, a, (void*)(saved + pl.o_Wt),
              (float*)(saved + pl.o_wsum), (float*)(saved + pl.o_dconst), (void*)(saved + pl.o_T0T));
@@ -241,26 +241,30 @@ int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out
 // ---------------------------------------------------------------------------------------------
 // hop 1 helpers
 // ---------------------------------------------------------------------------------------------
-// Rext[s][kc][M] = qr[kc], [M+1] = qb[kc], rest of the padding 0 ; BmX[s][Kcy][:] = wbar ;
+// Rext[s][kc][M] = qr[kc], [M+1] = qb[kc], rest of the padding 0, row Kcy all 0 ; BmX[s][Kcy][:] = wbar ;
 // Text[s][KL][:] = 1 (ones row), Text[s][KL+1][:] = 0 (dm1/N row, written by the backward)
 template <typename T>
 __global__ void kk_fill_ext(void* Rext_, const float* qrqb, void* BmX_, const float* wbar, void* Text_, int S, int Kcy,
                             int Kcyb, int M, int Mk, int Mb, int KL, int KLT, int C) {
   T* Rext = (T*)Rext_; T* BmX = (T*)BmX_; T* Text = (T*)Text_;
   const int padw = Mk - M;
-  const long n1 = (long)S * Kcy * padw, n2 = (long)S * Mb, n3 = (long)S * 2 * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3; i += (long)gridDim.x * 256) {
+  const long n1 = (long)S * Kcy * padw, n1b = (long)S * Mk, n2 = (long)S * Mb, n3 = (long)S * 2 * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n1b + n2 + n3; i += (long)gridDim.x * 256) {
     if (i < n1) {
       const int w = (int)(i % padw);
       const long row = i / padw;                  // s * Kcy + kc
-      const int kc = (int)(row % Kcy);
-      stT<T>(Rext, row * Mk + M + w, w == 0 ? qrqb[kc] : (w == 1 ? qrqb[Kcy + kc] : 0.f));
-    } else if (i < n1 + n2) {
+      const int kc = (int)(row % Kcy), s = (int)(row / Kcy);
+      stT<T>(Rext, ((long)s * Kcyb + kc) * Mk + M + w, w == 0 ? qrqb[kc] : (w == 1 ? qrqb[Kcy + kc] : 0.f));
+    } else if (i < n1 + n1b) {
       const long j = i - n1;
+      const int s = (int)(j / Mk), m = (int)(j % Mk);
+      stT<T>(Rext, ((long)s * Kcyb + Kcy) * Mk + m, 0.f);
+    } else if (i < n1 + n1b + n2) {
+      const long j = i - n1 - n1b;
       const int s = (int)(j / Mb), m = (int)(j % Mb);
       stT<T>(BmX, ((long)s * Kcyb + Kcy) * Mb + m, wbar[m]);
     } else {
-      const long j = i - n1 - n2;
+      const long j = i - n1 - n1b - n2;
       const int s = (int)(j / (2 * C)), rr = (int)((j / C) % 2), c = (int)(j % C);
       stT<T>(Text, ((long)s * KLT + KL + rr) * C + c, rr == 0 ? 1.f : 0.f);
     }
@@ -268,7 +272,7 @@ __global__ void kk_fill_ext(void* Rext_, const float* qrqb, void* BmX_, const fl
 }
 int k_fill_ext(const Plan& pl, char* saved, hipStream_t st) {
   const Dims& d = pl.d;
-  const long tot = (long)d.S * d.Kcy * (d.Mk - d.M) + (long)d.S * d.Mb + (long)d.S * 2 * d.C;
+  const long tot = (long)d.S * d.Kcy * (d.Mk - d.M) + (long)d.S * d.Mk + (long)d.S * d.Mb + (long)d.S * 2 * d.C;
   DISPATCH_T(d.bf16, kk_fill_ext, dim3(grid1d(tot)), dim3(256), 0, st, (void*)(saved + pl.o_Rext),
              (const float*)(saved + pl.o_qrqb), (void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_wbar),
              (void*)(saved + pl.o_Text), d.S, d.Kcy, d.Kcyb, d.M, d.Mk, d.Mb, d.KL, d.KLT, d.C);
@@ -297,12 +301,18 @@ int k_qrqb(const Plan& pl, char* saved, const float* bf, hipStream_t st) {
   return OK;
 }
 
-// row softmax (unscaled logits, net_trans_v3.py:381): f32 in -> T out, padding columns zeroed
+// row softmax (unscaled logits, net_trans_v3.py:381): f32 in -> T out, padding columns zeroed.  Rows come
+// in groups of `grp` of which the first `valid` are real; the others are written as zeros.
 template <typename T>
-__global__ void __launch_bounds__(256) kk_softmax_rows(const float* in, long rows, int n, int ld_in, void* out_, int ld_out) {
+__global__ void __launch_bounds__(256) kk_softmax_rows(const float* in, long rows, int n, int ld_in, void* out_, int ld_out,
+                                                       int grp, int valid, int slot, int kvalid) {
   T* out = (T*)out_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    if ((int)(row % grp) >= valid || (int)((row % grp) % slot) >= kvalid) {
+      for (int j = lane; j < ld_out; j += 64) stT<T>(out, row * ld_out + j, 0.f);
+      continue;
+    }
     const float* p = in + row * ld_in;
     float mx = -INFINITY;
     for (int j = lane; j < n; j += 64) mx = fmaxf(mx, p[j]);
@@ -314,10 +324,11 @@ __global__ void __launch_bounds__(256) kk_softmax_rows(const float* in, long row
     for (int j = lane; j < ld_out; j += 64) stT<T>(out, row * ld_out + j, j < n ? __expf(p[j] - mx) * inv : 0.f);
   }
 }
-int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, hipStream_t st) {
+int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, int grp, int valid,
+                   int slot, int kvalid, hipStream_t st) {
   if (rows <= 0) return OK;
   DISPATCH_T(bf16_out, kk_softmax_rows, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, in, rows,
-             n, ld_in, out, ld_out);
+             n, ld_in, out, ld_out, grp, valid, slot, kvalid);
   AVMOE_CHECK_LAUNCH("softmax_rows");
   return OK;
 }
@@ -326,7 +337,7 @@ int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, v
 // and the router's second mean  rin[s][C + c] = TV[s][Kcy] + mean(bc) rw + bf
 struct FinishTArgs {
   P16 tok; int e_of_lat[MAX_E];
-  int S, C, K, KL, KLT, Kcy, Kcyb, Kcx, Mb, M, src, lat0;
+  int S, C, K, Kp, KL, KLT, Kcy, Kcyb, Kcx, Mb, M, src, lat0;
 };
 template <typename T>
 __global__ void kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, const float* rw, const float* bf,
@@ -344,17 +355,20 @@ __global__ void kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, co
       rin[(long)s * 2 * a.C + a.C + c] = tv + scal[0] * rw[c] + bf[c];
       continue;
     }
-    const int slot = a.lat0 + kr / a.K, k = kr % a.K;
-    float v = a.tok.p[a.e_of_lat[slot]][(long)k * a.C + c] + tv;
-    if (a.src == 0) v += ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) * rw[c] + bf[c];
-    stT<T>(Text, ((long)s * a.KLT + (long)slot * a.K + k) * a.C + c, v);
+    const int slot = a.lat0 + kr / a.Kp, k = kr % a.Kp;
+    float v = 0.f;                                   // padding rows of a slot stay exactly zero
+    if (k < a.K) {
+      v = a.tok.p[a.e_of_lat[slot]][(long)k * a.C + c] + tv;
+      if (a.src == 0) v += ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) * rw[c] + bf[c];
+    }
+    stT<T>(Text, ((long)s * a.KLT + (long)slot * a.Kp + k) * a.C + c, v);
   }
 }
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src, hipStream_t st) {
   const Dims& d = pl.d;
   FinishTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.tok.p[e] = prm.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e]; }
-  a.S = d.S; a.C = d.C; a.K = d.K; a.KL = d.KL; a.KLT = d.KLT; a.Kcy = d.Kcy; a.Kcyb = d.Kcyb; a.Kcx = d.Kcx;
+  a.S = d.S; a.C = d.C; a.K = d.K; a.Kp = d.Kp; a.KL = d.KL; a.KLT = d.KLT; a.Kcy = d.Kcy; a.Kcyb = d.Kcyb; a.Kcx = d.Kcx;
   a.Mb = d.Mb; a.M = d.M; a.src = src; a.lat0 = src == 0 ? 0 : d.Ey;
   const int rows = src == 0 ? d.Kcyb : d.Kcx;
   if (rows <= 0) return OK;
@@ -457,7 +471,7 @@ int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float
 struct PreArgs {
   P16 glat;
   int lat_of_e[MAX_E];
-  int S, N, C, E, K, El, KLT, KLp, DD, DZ, dgp, g, NT, ln_before;
+  int S, N, C, E, K, Kp, El, KLT, KLp, DD, DZ, dgp, g, NT, ln_before;
   float ln_eps;
 };
 
@@ -490,9 +504,9 @@ __global__ void __launch_bounds__(256) kk_pre_small(PreArgs a, float* Z, const f
       for (int i = threadIdx.x; i < K * DD; i += 256) {
         const int k = i / DD, dd = i % DD;
         const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
-        s_TW[i] = TW[((long)s * a.KLT + (long)l * K + k) * a.DZ + col];
+        s_TW[i] = TW[((long)s * a.KLT + (long)l * a.Kp + k) * a.DZ + col];
       }
-      for (int i = threadIdx.x; i < K; i += 256) s_tb[i] = Tsum[(long)s * a.KLT + (long)l * K + i] / (float)a.C;
+      for (int i = threadIdx.x; i < K; i += 256) s_tb[i] = Tsum[(long)s * a.KLT + (long)l * a.Kp + i] / (float)a.C;
     }
     __syncthreads();
     float csum[DR], csq[DR];
@@ -503,7 +517,7 @@ __global__ void __launch_bounds__(256) kk_pre_small(PreArgs a, float* Z, const f
       float Sx = sxs[t], Sxx = sxs[a.NT + t];
       float* aw = s_a + wave * K;
       if (l >= 0) {
-        const float* l2 = L2 + t * a.KLp + (long)l * K;
+        const float* l2 = L2 + t * a.KLp + (long)l * a.Kp;
         float lv[KR], av[KR];
         float mx = -INFINITY;
 #pragma unroll
@@ -521,11 +535,11 @@ __global__ void __launch_bounds__(256) kk_pre_small(PreArgs a, float* Z, const f
           const int k = lane + 64 * u;
           if (k < K) {
             av[u] = roundT<T>(av[u] * inv);
-            stT<T>(aout, t * a.KLp + (long)l * K + k, av[u]);
+            stT<T>(aout, t * a.KLp + (long)l * a.Kp + k, av[u]);
             aw[k] = av[u];
             u1 += av[u] * s_tb[k];
             u2 += av[u] * lv[u];
-          }
+          } else if (k < a.Kp) stT<T>(aout, t * a.KLp + (long)l * a.Kp + k, 0.f);
         }
         wave_lds_sync();
         float u3 = 0.f;
@@ -590,7 +604,7 @@ int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   const Dims& d = pl.d;
   PreArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
-  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.K = d.K; a.El = d.El; a.KLT = d.KLT; a.KLp = d.KLp; a.DD = d.DD; a.DZ = d.DZ;
+  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.K = d.K; a.Kp = d.Kp; a.El = d.El; a.KLT = d.KLT; a.KLp = d.KLp; a.DD = d.DD; a.DZ = d.DZ;
   a.dgp = d.dgp; a.g = d.g; a.NT = d.NT; a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
   const size_t sh = (size_t)(d.K * d.K + d.K * d.DD + d.K + 4 * d.K + 8 * d.DD) * sizeof(float);
   dim3 grid; tok_grid(d, &grid);

@@ -19,7 +19,8 @@ int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out
 // ---- forward: hop 1 ---------------------------------------------------------------------------
 int k_fill_ext(const Plan& pl, char* saved, hipStream_t st);
 int k_qrqb(const Plan& pl, char* saved, const float* fc_b, hipStream_t st);
-int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, hipStream_t st);
+int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, int grp, int valid,
+                   int slot, int kvalid, hipStream_t st);
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src /*0 y, 1 x*/,
                hipStream_t st);
 // ---- forward: router --------------------------------------------------------------------------
@@ -43,7 +44,14 @@ int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
                     const avmoe_moe_ptrs& grads, hipStream_t st);
 int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                  float lb_weight, hipStream_t st);
-int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, hipStream_t st);
+int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, void* out_t, int grp,
+                       int ldT, hipStream_t st);
+int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st);
+int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st);
+int k_dqrqb(const Plan& pl, char* scratch, const float* conv_b, hipStream_t st);
+int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                    hipStream_t st);
+int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st);
 
 // generic helpers
 int k_fill_f32(float* p, long n, float v, hipStream_t st);

@@ -1,12 +1,266 @@
-// Backward orchestration (filled in below).
+// Backward orchestration of one MoEAdapter site.  Mirrors oracle/algebra_ref.py::AlgebraRef.backward:
+// phase 1 the two GEMMs against dOut, phases 2-4 bottleneck / weight space, phase 5 GEMMs against X,
+// phase 6 the hop-1 (latent token) chain back to Y and the remap parameters.  Stream-ordered, no
+// allocation, no host sync.
 #include "moe_run.h"
 
 namespace avmoe {
 
+#define MEMSET0(ptr, bytes)                                                                 \
+  do {                                                                                      \
+    hipError_t e__ = hipMemsetAsync((ptr), 0, (bytes), st);                                 \
+    if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; } \
+  } while (0)
+
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, float lb_weight,
-                 char* saved, char* scratch, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st) {
-  set_last_error("moe_backward: not built yet");
-  return ERR_UNSUPPORTED;
+                 char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  const Dims& d = pl.d;
+  const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
+  float* slabs = (float*)(sc + pl.o_slabs);
+  const size_t slab_cap = slab_floats(d);
+  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
+  auto run = [&](GemmArgs& g, bool split) {
+    if (split) g.ksplit = choose_ksplit(g, slab_cap);
+    return launch_gemm(g, st);
+  };
+  const size_t esz = d.esz;
+
+  // ---- phase 1: dApost = dOut Bpost ; dBpost = dOut^T Apost -------------------------------------
+  {
+    GemmArgs g = base();
+    g.A = dOut; g.B = sv + pl.o_Bpost; g.C = sc + pl.o_dAp;
+    g.M = d.NT; g.N = d.KP; g.K = d.Cg; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.KPp; g.nb2 = d.g;
+    g.sA2 = d.Cg; g.sB2 = (long)d.Cg * d.KPp; g.sCi = (long)d.g * d.KPp; g.sC2 = d.KPp;
+    AVMOE_TRY(run(g, false));
+  }
+  {
+    GemmArgs g = base();
+    g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
+    g.M = d.Cg; g.N = d.KP; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = (long)d.g * d.KPp; g.nb2 = d.g;
+    g.sA2 = d.Cg; g.sB2 = d.KPp; g.sCi = d.KPp; g.sC2 = (long)d.Cg * d.KPp;
+    AVMOE_TRY(run(g, true));
+  }
+  // ---- phase 2: bottleneck space (LayerNorm-post statistics), then weight space ------------------
+  AVMOE_TRY(k_post_small_bwd(pl, sv, sc, prm, grads, st));
+  if (d.ln_post) {                                         // dG[i][e] = sum_t dSoo z' z'^T
+    GemmArgs g = base();
+    g.A = sc + pl.o_Zw; g.B = sc + pl.o_Zp; g.C = sc + pl.o_dGq;
+    g.M = d.dgp; g.N = d.dgp; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = g.ldb = d.DZ;
+    g.nb2 = d.g * d.E; g.sA2 = g.sB2 = d.dgp; g.sCi = d.dgp; g.sC2 = (long)d.dgp * d.dgp;
+    AVMOE_TRY(run(g, true));
+  }
+  AVMOE_TRY(k_post_prep_bwd(pl, sv, sc, prm, grads, st));
+  // ---- phase 3: ReLU / BN1 ; router --------------------------------------------------------------
+  AVMOE_TRY(k_mid_bwd(pl, sv, sc, prm, grads, st));
+  AVMOE_TRY(k_router_bwd(pl, sv, sc, prm, grads, lb_weight, st));
+  // ---- phase 4: folded LayerNorm / hop-2 softmax ---------------------------------------------------
+  MEMSET0(sc + pl.o_dtbp, (size_t)d.nblk_tok * (d.KL ? d.KL : 1) * 4);
+  AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));
+  const char* dZx = sc + pl.o_Zw;
+
+  // ---- phase 5: GEMMs against X --------------------------------------------------------------------
+  {                                                        // dX = dZx Wt + 2 dSxx X
+    GemmArgs g = base();
+    g.A = dZx; g.B = sv + pl.o_Wt; g.C = dX;
+    g.M = d.NT; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb2 = d.g;
+    g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.C; g.sC2 = d.Cg; g.out_dtype = dt;
+    g.row_scale = (const float*)(sc + pl.o_rs2x); g.D = X; g.sDi = d.C; g.sD2 = d.Cg;
+    AVMOE_TRY(run(g, false));
+  }
+  {                                                        // dX += [dL2 | dsx | 1] [T ; 1 ; dm1/N]
+    GemmArgs g = base();
+    g.A = sc + pl.o_dL2x; g.B = sv + pl.o_Text; g.C = dX;
+    g.M = d.N; g.N = d.C; g.K = d.KLT; g.lda = d.KLp; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S;
+    g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.KLT * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
+    AVMOE_TRY(run(g, false));
+  }
+  MEMSET0(sc + pl.o_dTW, (size_t)d.S * d.KLT * d.DZ * esz);
+  for (int l = 0; l < d.El; ++l) {                         // dTW[s][slot l] = gate * a^T dzraw  (own expert's columns)
+    const int e = d.e_of_lat[l];
+    GemmArgs g = base();
+    g.A = sc + pl.o_ag + (size_t)l * d.Kp * esz; g.B = dZx + (size_t)e * d.dgp * esz;
+    g.C = sc + pl.o_dTW + ((size_t)l * d.Kp * d.DZ + (size_t)e * d.dgp) * esz;
+    g.M = d.K; g.N = d.dgp; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.DZ; g.nb1 = d.S; g.nb2 = d.g;
+    g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.N * d.DZ; g.sB2 = (long)d.E * d.dgp;
+    g.sCi = d.DZ; g.sC1 = (long)d.KLT * d.DZ; g.sC2 = (long)d.E * d.dgp; g.out_dtype = dt;
+    AVMOE_TRY(run(g, false));
+  }
+  {                                                        // dWt = dZx^T X  + dTW^T Text
+    GemmArgs g = base();
+    g.A = dZx; g.B = X; g.C = sc + pl.o_dWt;
+    g.M = d.E * d.dgp; g.N = d.Cg; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.DZ; g.ldb = d.C; g.nb2 = d.g;
+    g.sA2 = (long)d.E * d.dgp; g.sB2 = d.Cg; g.sCi = d.Cg; g.sC2 = (long)d.E * d.dgp * d.Cg;
+    AVMOE_TRY(run(g, true));
+    if (d.El > 0) {
+      GemmArgs h = g;
+      h.A = sc + pl.o_dTW; h.B = sv + pl.o_Text; h.K = d.S * d.KLT; h.accumulate = 1; h.ksplit = 1;
+      AVMOE_TRY(run(h, true));
+    }
+  }
+  if (d.El > 0) {
+    {                                                      // dT[s] = dL2[s]^T X[s]
+      GemmArgs g = base();
+      g.A = sc + pl.o_dL2x; g.B = X; g.C = sc + pl.o_dT;
+      g.M = d.KL; g.N = d.C; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.C; g.nb1 = d.S;
+      g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.KL * d.C;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dT += dTW Wt
+      GemmArgs g = base();
+      g.A = sc + pl.o_dTW; g.B = sv + pl.o_Wt; g.C = sc + pl.o_dT;
+      g.M = d.KL; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
+      g.sA1 = (long)d.KLT * d.DZ; g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg;
+      g.sCi = d.C; g.sC1 = (long)d.KL * d.C; g.sC2 = d.Cg; g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dTT[s][l] = sum_t du3 a a^T   (symmetric)
+      GemmArgs g = base();
+      g.A = sc + pl.o_aw; g.B = sv + pl.o_a; g.C = sc + pl.o_dTT;
+      g.M = d.K; g.N = d.K; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = g.ldb = d.KLp; g.nb1 = d.S; g.nb2 = d.El;
+      g.sA1 = g.sB1 = (long)d.N * d.KLp; g.sA2 = g.sB2 = d.Kp;
+      g.sCi = d.Kp; g.sC1 = (long)d.El * d.K * d.Kp; g.sC2 = (long)d.K * d.Kp; g.out_dtype = dt;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dT += 2 dTT T
+      GemmArgs g = base();
+      g.A = sc + pl.o_dTT; g.B = sv + pl.o_Text; g.C = sc + pl.o_dT;
+      g.M = d.K; g.N = d.C; g.K = d.K; g.lda = d.Kp; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S; g.nb2 = d.El;
+      g.sA1 = (long)d.El * d.K * d.Kp; g.sA2 = (long)d.K * d.Kp; g.sB1 = (long)d.KLT * d.C; g.sB2 = (long)d.Kp * d.C;
+      g.sCi = d.C; g.sC1 = (long)d.KL * d.C; g.sC2 = (long)d.Kp * d.C; g.alpha = 2.f; g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+  }
+  AVMOE_TRY(k_finish_dT(pl, sv, sc, st));                  // + dtbar / C ; dTy (T, with the dm2 row) ; dTx ; dT0 ; drw, dbf
+  AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
+
+  // ---- phase 6a: cross-modal hop-1 chain back to Y and the remap parameters -------------------------
+  {                                                        // dV = dTy Wf   (row Kcy: d ybar)
+    GemmArgs g = base();
+    g.A = sc + pl.o_dTy; g.B = sv + pl.o_WfT; g.C = sc + pl.o_dV;
+    g.M = d.S * d.Kcyb; g.N = d.Cy; g.K = d.C; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.Cy; g.sCi = d.Cy; g.out_dtype = dt;
+    AVMOE_TRY(run(g, false));
+  }
+  {                                                        // dWf = dTy^T V
+    GemmArgs g = base();
+    g.A = sc + pl.o_dTy; g.B = sv + pl.o_V; g.C = sc + pl.o_dWf;
+    g.M = d.C; g.N = d.Cy; g.K = d.S * d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = d.Cy; g.sCi = d.Cy;
+    AVMOE_TRY(run(g, true));
+  }
+  {                                                        // dBm[s] = dV[s] Y[s]^T
+    GemmArgs g = base();
+    g.A = sc + pl.o_dV; g.B = Y; g.C = sc + pl.o_dBm;
+    g.M = d.Kcyb; g.N = d.M; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.nb1 = d.S;
+    g.sA1 = (long)d.Kcyb * d.Cy; g.sB1 = (long)d.M * d.Cy; g.sCi = d.Mb; g.sC1 = (long)d.Kcyb * d.Mb;
+    AVMOE_TRY(run(g, false));
+  }
+  {                                                        // dY[s] = [Bm ; wbar][s]^T dV[s]
+    GemmArgs g = base();
+    g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
+    g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
+    g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
+    AVMOE_TRY(run(g, false));
+  }
+  AVMOE_TRY(k_prep_dBm(pl, sc, st));
+  MEMSET0(sc + pl.o_dWcK, (size_t)d.N * d.Mk * 4);
+  MEMSET0(sc + pl.o_dqp, ((size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb) * 4);
+  if (d.Kcy > 0) {
+    {                                                      // dA1[s] = [dBm | dab][s] [Wc | bc]^T
+      GemmArgs g = base();
+      g.A = sc + pl.o_dBmT; g.B = sv + pl.o_WcK; g.C = sc + pl.o_L1;
+      g.M = d.Kcyb; g.N = d.N; g.K = d.M + 1; g.lda = d.Mb; g.ldb = d.Mk; g.nb1 = d.S;
+      g.sA1 = (long)d.Kcyb * d.Mb; g.sCi = d.Np; g.sC1 = (long)d.Kcyb * d.Np;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dWcK[:, :M+1] += A1^T [dBm | dab]
+      GemmArgs g = base();
+      g.A = sv + pl.o_A1y; g.B = sc + pl.o_dBmT; g.C = sc + pl.o_dWcK;
+      g.M = d.N; g.N = d.M + 1; g.K = d.S * d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.Mb;
+      g.sCi = d.Mk; g.accumulate = 1;
+      AVMOE_TRY(run(g, true));
+    }
+    AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_A1y, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcyb, d.N, d.Np,
+                                 sc + pl.o_dL1, nullptr, 1, 1, st));
+    MEMSET0(sc + pl.o_dRT, (size_t)d.S * d.M * d.Kcyp * esz);
+    {                                                      // dR[s]^T = (dL1[s] Wc)^T   stored [m][kc]
+      GemmArgs g = base();
+      g.A = sc + pl.o_dL1; g.B = sv + pl.o_WcT; g.C = sc + pl.o_dRT;
+      g.M = d.Kcy; g.N = d.M; g.K = d.N; g.lda = d.Np; g.ldb = d.Np; g.nb1 = d.S; g.sA1 = (long)d.Kcyb * d.Np;
+      g.sCi = 1; g.sCj = d.Kcyp; g.sC1 = (long)d.M * d.Kcyp; g.out_dtype = dt;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dWcK[:, :M+2] += dL1^T [R | qr | qb]
+      GemmArgs g = base();
+      g.A = sc + pl.o_dL1; g.B = sv + pl.o_Rext; g.C = sc + pl.o_dWcK;
+      g.M = d.N; g.N = d.M + 2; g.K = d.S * d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.Mk;
+      g.sCi = d.Mk; g.accumulate = 1;
+      AVMOE_TRY(run(g, true));
+    }
+    AVMOE_TRY(k_dqrqb(pl, sc, prm.conv_b, st));
+    {                                                      // dQ = sum_s dR[s] Y[s]
+      GemmArgs g = base();
+      g.A = sc + pl.o_dRT; g.B = Y; g.C = sc + pl.o_dQ;
+      g.M = d.Kcy; g.N = d.Cy; g.K = d.S * d.M; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Kcyp; g.ldb = d.Cy; g.sCi = d.Cy;
+      AVMOE_TRY(run(g, true));
+    }
+    AVMOE_TRY(k_cast(d.bf16, (const float*)(sc + pl.o_dQ), d.Kcy, d.Cy, d.Cy, sc + pl.o_dQT, d.Cy, st));
+    {                                                      // dY[s] += dR[s]^T Q
+      GemmArgs g = base();
+      g.A = sc + pl.o_dRT; g.B = sv + pl.o_Qx; g.C = dY;
+      g.M = d.M; g.N = d.Cy; g.K = d.Kcy; g.lda = d.Kcyp; g.b_layout = MN_MAJOR; g.ldb = d.Cy; g.nb1 = d.S;
+      g.sA1 = (long)d.M * d.Kcyp; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt; g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dT0[y slots] += dQ Wf^T
+      GemmArgs g = base();
+      g.A = sc + pl.o_dQT; g.B = sv + pl.o_WfT; g.C = sc + pl.o_dT0;
+      g.M = d.Kcy; g.N = d.C; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.sCi = d.C; g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dWf += T0^T dQ
+      GemmArgs g = base();
+      g.A = sv + pl.o_T0T; g.B = sc + pl.o_dQT; g.C = sc + pl.o_dWf;
+      g.M = d.C; g.N = d.Cy; g.K = d.Kcy; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = d.Cy; g.sCi = d.Cy;
+      g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+  }
+  // ---- phase 6b: latent self attention on X (AVS v2) ----------------------------------------------
+  if (d.Kcx > 0) {
+    const char* T0x = sv + pl.o_T0T + (size_t)d.Kcy * d.C * esz;
+    {                                                      // dA1x[s] = dTx[s] X[s]^T
+      GemmArgs g = base();
+      g.A = sc + pl.o_dTx; g.B = X; g.C = sc + pl.o_L1;
+      g.M = d.Kcx; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S;
+      g.sA1 = (long)d.Kcx * d.C; g.sB1 = (long)d.N * d.C; g.sCi = d.Np; g.sC1 = (long)d.Kcx * d.Np;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dX[s] += A1x[s]^T dTx[s]
+      GemmArgs g = base();
+      g.A = sv + pl.o_A1x; g.B = sc + pl.o_dTx; g.C = dX;
+      g.M = d.N; g.N = d.C; g.K = d.Kcx; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.C; g.nb1 = d.S;
+      g.sA1 = (long)d.Kcx * d.Np; g.sB1 = (long)d.Kcx * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+    MEMSET0(sc + pl.o_dL1xT, (size_t)d.NT * d.Kcxp * esz);
+    AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_A1x, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcx, d.N, d.Np,
+                                 sc + pl.o_dL1, sc + pl.o_dL1xT, d.Kcx, d.Kcxp, st));
+    {                                                      // dT0[x slots] += sum_{s,n} dL1x^T X
+      GemmArgs g = base();
+      g.A = sc + pl.o_dL1xT; g.B = X; g.C = sc + pl.o_dT0 + (size_t)d.Kcy * d.C * 4;
+      g.M = d.Kcx; g.N = d.C; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Kcxp; g.ldb = d.C; g.sCi = d.C;
+      g.accumulate = 1;
+      AVMOE_TRY(run(g, true));
+    }
+    {                                                      // dX += dL1x^T T0x
+      GemmArgs g = base();
+      g.A = sc + pl.o_dL1xT; g.B = T0x; g.C = dX;
+      g.M = d.NT; g.N = d.C; g.K = d.Kcx; g.lda = d.Kcxp; g.b_layout = MN_MAJOR; g.ldb = d.C; g.sCi = d.C; g.out_dtype = dt;
+      g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+  }
+  AVMOE_TRY(k_hop1_finalize(pl, sv, sc, prm, grads, st));
+  return OK;
 }
 
 }  // namespace avmoe

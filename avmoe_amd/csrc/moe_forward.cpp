@@ -47,21 +47,22 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       GemmArgs g = base();
       g.A = sv + pl.o_Qx; g.B = Y; g.C = sv + pl.o_Rext;
       g.M = d.Kcy; g.N = d.M; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.nb1 = d.S; g.sB1 = (long)d.M * d.Cy;
-      g.sCi = d.Mk; g.sC1 = (long)d.Kcy * d.Mk; g.out_dtype = dt;
+      g.sCi = d.Mk; g.sC1 = (long)d.Kcyb * d.Mk; g.out_dtype = dt;
       AVMOE_TRY(launch_gemm(g, st));
     }
     {                                                      // L1[s] = [R | qr | qb] [Wc | bc | 1]^T
       GemmArgs g = base();
       g.A = sv + pl.o_Rext; g.B = sv + pl.o_WcK; g.C = sc + pl.o_L1;
-      g.M = d.Kcy; g.N = d.N; g.K = d.M + 2; g.lda = d.Mk; g.ldb = d.Mk; g.nb1 = d.S; g.sA1 = (long)d.Kcy * d.Mk;
-      g.sCi = d.Np; g.sC1 = (long)d.Kcy * d.Np;
+      g.M = d.Kcy; g.N = d.N; g.K = d.M + 2; g.lda = d.Mk; g.ldb = d.Mk; g.nb1 = d.S; g.sA1 = (long)d.Kcyb * d.Mk;
+      g.sCi = d.Np; g.sC1 = (long)d.Kcyb * d.Np;
       AVMOE_TRY(launch_gemm(g, st));
     }
-    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcy, d.N, d.Np, sv + pl.o_A1y, d.Np, st));
+    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcyb, d.N, d.Np, sv + pl.o_A1y, d.Np,
+                             d.Kcyb, d.Kcy, d.Kp, d.K, st));
     {                                                      // [Bm | ab][s] = A1[s] [Wc | bc]
       GemmArgs g = base();
       g.A = sv + pl.o_A1y; g.B = sv + pl.o_WcT; g.C = sv + pl.o_BmX;
-      g.M = d.Kcy; g.N = d.M + 1; g.K = d.N; g.lda = d.Np; g.ldb = d.Np; g.nb1 = d.S; g.sA1 = (long)d.Kcy * d.Np;
+      g.M = d.Kcy; g.N = d.M + 1; g.K = d.N; g.lda = d.Np; g.ldb = d.Np; g.nb1 = d.S; g.sA1 = (long)d.Kcyb * d.Np;
       g.sCi = d.Mb; g.sC1 = (long)d.Kcyb * d.Mb; g.out_dtype = dt;
       AVMOE_TRY(launch_gemm(g, st));
     }
@@ -91,7 +92,8 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       g.sCi = d.Np; g.sC1 = (long)d.Kcx * d.Np;
       AVMOE_TRY(launch_gemm(g, st));
     }
-    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcx, d.N, d.Np, sv + pl.o_A1x, d.Np, st));
+    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcx, d.N, d.Np, sv + pl.o_A1x, d.Np,
+                             d.Kcx, d.Kcx, d.Kp, d.K, st));
     {
       GemmArgs g = base();
       g.A = sv + pl.o_A1x; g.B = X; g.C = sc + pl.o_TV;
@@ -111,7 +113,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     GemmArgs g = base();
     g.A = sv + pl.o_Text; g.B = sv + pl.o_Text; g.C = sv + pl.o_TT;
     g.M = d.K; g.N = d.K; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.nb2 = d.El;
-    g.sA1 = g.sB1 = (long)d.KLT * d.C; g.sA2 = g.sB2 = (long)d.K * d.C;
+    g.sA1 = g.sB1 = (long)d.KLT * d.C; g.sA2 = g.sB2 = (long)d.Kp * d.C;
     g.sCi = d.K; g.sC1 = (long)d.El * d.K * d.K; g.sC2 = (long)d.K * d.K;
     AVMOE_TRY(launch_gemm(g, st));
   }

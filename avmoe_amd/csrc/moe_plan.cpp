@@ -76,12 +76,15 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Ey = d.E_m;
   d.Ex = d.El - d.Ey;
   if (d.El == 0) d.K = d.K > 0 ? d.K : 1;
-  d.KL = d.El * d.K;
+  d.Kp = (int)round_up(d.K, 8);
+  d.KL = d.El * d.Kp;          // latent rows per sample, each slot padded to Kp rows (pad rows are zero)
   d.KLT = d.KL + 2;
   d.KLp = (int)round_up(d.KL + 2, 8);
-  d.Kcy = d.Ey * d.K;
+  d.Kcy = d.Ey * d.Kp;
   d.Kcyb = d.Kcy + 1;
-  d.Kcx = d.Ex * d.K;
+  d.Kcx = d.Ex * d.Kp;
+  d.Kcyp = (int)round_up(d.Kcy > 0 ? d.Kcy : 1, 8);
+  d.Kcxp = (int)round_up(d.Kcx > 0 ? d.Kcx : 1, 8);
   d.KP = d.E * d.dgp + 3 * d.E;
   d.KPp = (int)round_up(d.KP, 8);
   d.Mk = (int)round_up(d.M + 2, 8);

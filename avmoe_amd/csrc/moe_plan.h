@@ -26,11 +26,12 @@ struct Dims {
   int DD;         // g * dgp : padded bottleneck width of one expert
   int DZ;         // E * DD : row width of Z / Zx   (layout [group][expert][dgp])
   int El, Ey, Ex; // latent experts: total / source Y (cross-modal) / source X (AVS v2)
-  int KL;         // El * K latent rows per sample (latent experts in expert order)
+  int KL;         // El * Kp latent rows per sample (latent experts in expert order, slots padded to Kp rows)
   int KLT;        // KL + 2 : rows of the extended token matrix Text[s] (ones row, dm1/N row)
   int KLp;        // row width of L2 / a / dL2ext  (>= KL + 2, multiple of 8)
-  int Kcy, Kcyb;  // Ey * K ; Kcy + 1 (extra wbar / ybar row)
-  int Kcx;        // Ex * K
+  int Kcy, Kcyb;  // Ey * Kp ; Kcy + 1 (extra wbar / ybar row)
+  int Kcx;        // Ex * Kp
+  int Kp, Kcyp, Kcxp;  // K, Kcy, Kcx padded to 8 (row strides of dTT / dRT / dL1xT)
   int KP, KPp;    // post GEMM depth per group: E*dgp + 3E, padded to 8
   int Mk;         // width of Rext / WcK : M + 2 (qr, qb / bc, 1 columns), padded to 8
   int Mb;         // width of Bm_ext: M + 1 (ab column), padded to 8
@@ -49,18 +50,18 @@ struct Dims {
   X(WcT, 0, d.esz, (size_t)(d.M + 1) * d.Np)        /* [m | bc-row][n]                */       \
   X(WfT, 0, d.esz, (size_t)d.C * d.Cy)              /* fc.weight in T                 */       \
   X(rw, 0, 4, (size_t)d.C)                          /* Wf 1                           */       \
-  X(wbar, 0, 4, (size_t)d.Mb)                       /* mean_n Wc ; [Mb-1] unused      */       \
-  X(scal, 0, 4, 64)                                 /* bcbar, ...                     */       \
+  X(wbar, 0, 4, (size_t)d.Mb)                       /* mean_n Wc                      */       \
+  X(scal, 0, 4, 64)                                 /* [0] = mean(bc)                 */       \
   X(T0T, 0, d.esz, (size_t)(d.KL ? d.KL : 1) * d.C) /* stacked my_tokens in T         */       \
   X(Wt, 0, d.esz, (size_t)d.g * d.E * d.dgp * d.Cg) /* [i][e][jp][c] = Wd*gamma_b     */       \
   X(wsum, 0, 4, (size_t)d.DZ)                                                                   \
   X(dconst, 0, 4, (size_t)d.DZ)                                                                 \
-  /* ---- hop 1 (cross-modal experts, source = remapped Y) ---- */                             \
+  /* ---- hop 1 (cross-modal experts, source = remapped Y); Kcyb rows per sample ---- */       \
   X(Qx, 0, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)  /* T0 Wf                        */      \
   X(qrqb, 0, 4, (size_t)2 * (d.Kcy ? d.Kcy : 1))                                               \
-  X(Rext, 0, d.esz, (size_t)d.S * (d.Kcy ? d.Kcy : 1) * d.Mk)                                  \
-  X(A1y, 0, d.esz, (size_t)d.S * (d.Kcy ? d.Kcy : 1) * d.Np)                                   \
-  X(BmX, 0, d.esz, (size_t)d.S * d.Kcyb * d.Mb)     /* [A1 Wc | ab] + wbar row        */       \
+  X(Rext, 0, d.esz, (size_t)d.S * d.Kcyb * d.Mk)    /* [R | qr | qb] ; last row 0     */       \
+  X(A1y, 0, d.esz, (size_t)d.S * d.Kcyb * d.Np)     /* softmax_n ; last row 0         */       \
+  X(BmX, 0, d.esz, (size_t)d.S * d.Kcyb * d.Mb)     /* [A1 Wc | ab] ; last row wbar   */       \
   X(V, 0, d.esz, (size_t)d.S * d.Kcyb * d.Cy)                                                  \
   X(A1x, 0, d.esz, (size_t)d.S * (d.Kcx ? d.Kcx : 1) * d.Np)                                   \
   X(Text, 0, d.esz, (size_t)d.S * d.KLT * d.C)      /* T[s] rows + ones row + dm1 row */       \
@@ -85,41 +86,54 @@ struct Dims {
   X(bn2, 0, 4, (size_t)4 * d.E * d.C)               /* mo, rs2, k2, h2   [e][c]       */       \
   X(Bpost, 0, d.esz, (size_t)d.C * d.KPp)                                                       \
   X(Gq, 0, 4, (size_t)d.g * d.E * d.dgp * d.dgp)    /* Wh^T Wh per (i,e)              */       \
-  X(uvh, 0, 4, (size_t)2 * d.DZ + 2 * d.E)          /* usum, vh, H1[e], H2[e]         */       \
+  X(uvh, 0, 4, (size_t)2 * d.DZ + 2 * d.g * d.E)    /* usum, vh, H1[i][e], H2[i][e]   */       \
   X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
   /* ---- transient ---- */                                                                    \
-  X(L1, 1, 4, (size_t)d.S * (d.Kcy > d.Kcx ? d.Kcy : (d.Kcx ? d.Kcx : 1)) * d.Np)              \
+  X(L1, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)    /* L1 ; dA1 in bwd */  \
   X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \
-  X(Zp, 1, d.esz, (size_t)d.NT * d.DZ)              /* z' (fwd) ; reused in bwd       */       \
+  X(Zp, 1, d.esz, (size_t)d.NT * d.DZ)              /* z'                              */       \
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
   X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
   X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \
   /* ---- backward only ---- */                                                                \
   X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)                                                      \
   X(dBp, 1, 4, (size_t)d.C * d.KPp)                                                             \
-  X(dzp, 1, 4, (size_t)d.NT * d.DZ)                 /* dz' -> dy -> dz (in place)     */       \
+  X(dzp, 1, 4, (size_t)d.NT * d.DZ)                 /* dz' -> dy (in place)           */       \
+  X(blkscal, 1, 4, (size_t)d.nblk_tok * d.E * 4)    /* per-block scalar partials      */       \
   X(dGq, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp)                                               \
-  X(dSzz, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp)  /* sym(dSzz)/ntot                 */       \
-  X(dsm, 1, 4, (size_t)8 * d.DZ + 4 * d.E + 64)     /* dusum,dvh,dmz,bn1 sums,...     */       \
-  X(dp, 1, 4, (size_t)d.S * d.E + d.S * 2 * d.C)    /* dp[s][e] ; drin[s][2C]         */       \
+  X(sdSzz, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp) /* 2 dSzz / NT                    */       \
+  X(dsm, 1, 4, (size_t)8 * d.DZ + 8 * d.E)          /* dusum,dvh,dmz/NT,mdy,mdyz,ddconst,dwsum ; dH1,dH2 */ \
+  X(dmodv, 1, 4, (size_t)2 * d.E * d.C)             /* dmo, dv2 per (e, c)            */       \
+  X(dp, 1, 4, (size_t)d.S * d.E)                                                                \
+  X(rbw, 1, 4, (size_t)d.S * (d.E + 32 + 128 + 2 * d.C))   /* dlog, dh2r, dh1, drin   */       \
+  X(drinT, 1, d.esz, (size_t)d.S * 2 * d.C)                                                     \
+  X(dsxs, 1, 4, (size_t)2 * d.NT)                                                               \
+  X(rs2x, 1, 4, (size_t)d.NT)                       /* 2 * sum_e dSxx                 */       \
   X(dL2x, 1, d.esz, (size_t)d.NT * d.KLp)           /* [dL2 | dsx | 1]                */       \
   X(aw, 1, d.esz, (size_t)d.NT * d.KLp)             /* du3 * a                        */       \
-  X(rs2x, 1, 4, (size_t)d.NT)                       /* 2 * sum_e dsxx                 */       \
+  X(ag, 1, d.esz, (size_t)d.NT * d.KLp)             /* gate_lat * a                   */       \
+  X(dtbp, 1, 4, (size_t)d.nblk_tok * (d.KL ? d.KL : 1))                                         \
+  X(dtbar, 1, 4, (size_t)d.S * (d.KL ? d.KL : 1))                                               \
   X(dTW, 1, d.esz, (size_t)d.S * d.KLT * d.DZ)                                                  \
-  X(dTT, 1, d.esz, (size_t)d.S * (d.El ? d.El : 1) * d.K * d.K)                                 \
-  X(dtbar, 1, 4, (size_t)d.S * d.KLT)                                                           \
+  X(dTT, 1, d.esz, (size_t)d.S * (d.El ? d.El : 1) * d.K * d.Kp)                                \
   X(dWt, 1, 4, (size_t)d.g * d.E * d.dgp * d.Cg)                                                \
   X(dT, 1, 4, (size_t)d.S * (d.KL ? d.KL : 1) * d.C)                                            \
-  X(dTt, 1, d.esz, (size_t)d.S * (d.KL ? d.KL : 1) * d.C)  /* dT in T (GEMM operand)   */     \
+  X(dTy, 1, d.esz, (size_t)d.S * d.Kcyb * d.C)      /* y-slots of dT + dm2 row, in T  */       \
+  X(dTx, 1, d.esz, (size_t)d.S * (d.Kcx ? d.Kcx : 1) * d.C)                                     \
+  X(dT0, 1, 4, (size_t)(d.KL ? d.KL : 1) * d.C)                                                 \
+  X(dabx, 1, 4, (size_t)d.S * d.Kcyb)                                                           \
   X(dV, 1, d.esz, (size_t)d.S * d.Kcyb * d.Cy)                                                  \
   X(dBm, 1, 4, (size_t)d.S * d.Kcyb * d.Mb)                                                     \
   X(dBmT, 1, d.esz, (size_t)d.S * d.Kcyb * d.Mb)                                                \
-  X(dA1, 1, 4, (size_t)d.S * (d.Kcy > d.Kcx ? d.Kcy : (d.Kcx ? d.Kcx : 1)) * d.Np)             \
-  X(dL1, 1, d.esz, (size_t)d.S * (d.Kcy > d.Kcx ? d.Kcy : (d.Kcx ? d.Kcx : 1)) * d.Np)         \
-  X(dRT, 1, d.esz, (size_t)d.S * d.M * (d.Kcy ? round_up(d.Kcy, 8) : 8))                       \
-  X(dQ, 1, 4, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy + 4 * (d.Kcy ? d.Kcy : 1))                    \
-  X(dWcs, 1, 4, (size_t)d.N * d.Mk + (size_t)d.C * d.Cy + 4 * d.C + 4 * d.N + d.Mb)            \
-  X(dT0, 1, 4, (size_t)(d.KL ? d.KL : 1) * d.C)
+  X(dL1, 1, d.esz, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)                      \
+  X(dL1xT, 1, d.esz, (size_t)d.NT * d.Kcxp)                                                     \
+  X(dRT, 1, d.esz, (size_t)d.S * d.M * d.Kcyp)                                                  \
+  X(dQ, 1, 4, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                               \
+  X(dQT, 1, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                          \
+  X(dqp, 1, 4, (size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb)                                           \
+  X(dWcK, 1, 4, (size_t)d.N * d.Mk)                                                             \
+  X(dWf, 1, 4, (size_t)d.C * d.Cy)                                                              \
+  X(dvec, 1, 4, (size_t)2 * d.C + d.Mb + 64)        /* drw, dbf, dwbar, dbcbar        */
 
 size_t slab_floats(const Dims& d);
 

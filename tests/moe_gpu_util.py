@@ -103,7 +103,8 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
     sv = A.sv
     lat = [j for j, ex in enumerate(A.experts) if ex.latent]
     El = len(lat)
-    KL = El * K
+    Kp = -(-K // 8) * 8                     # latent slots are padded to Kp rows (padding rows are zero)
+    KL = El * Kp
     KLT, KLp = KL + 2, -(-(KL + 2) // 8) * 8
     DZ = E * g * dgp
     KP = E * dgp + 3 * E
@@ -134,11 +135,11 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
         tag = f"e{j}."
         if ex.latent:
             l = lat.index(j)
-            rec(tag + "T", Text[:, l * K:(l + 1) * K], e["T"])
+            rec(tag + "T", Text[:, l * Kp:l * Kp + K], e["T"])
             rec(tag + "TT", TT[:, l], e["TT"])
-            rec(tag + "TW", TW[:, l * K:(l + 1) * K, :, j, :dg], e["TW"])
-            rec(tag + "L2", L2[:, :, l * K:(l + 1) * K], e["L2"])
-            rec(tag + "a", a[:, :, l * K:(l + 1) * K], e["a"])
+            rec(tag + "TW", TW[:, l * Kp:l * Kp + K, :, j, :dg], e["TW"])
+            rec(tag + "L2", L2[:, :, l * Kp:l * Kp + K], e["L2"])
+            rec(tag + "a", a[:, :, l * Kp:l * Kp + K], e["a"])
         rec(tag + "z", Z[:, :, :, j, :dg], e["z"])
         if cfg.ln_before:
             rec(tag + "r", rmu[0, :, :, j], e["r"])
