@@ -47,6 +47,11 @@ def lib():
     L.avmoe_gemm_workspace_bytes.argtypes = [C.POINTER(GemmDesc)]
     L.avmoe_gemm.restype = C.c_int
     L.avmoe_gemm.argtypes = [C.POINTER(GemmDesc)] + [C.c_void_p] * 7
+    L.avmoe_prof_enable.argtypes = [C.c_int]
+    L.avmoe_prof_enable.restype = None
+    L.avmoe_prof_reset.restype = None
+    L.avmoe_prof_report.restype = C.c_size_t
+    L.avmoe_prof_report.argtypes = [C.c_char_p, C.c_size_t]
     from . import _capi_moe
     _capi_moe.declare(L)
     _lib = L
@@ -65,3 +70,13 @@ def exported_symbols():
     txt = open(HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(avmoe_[a-z0-9_]+)\s*\(", txt)))
+
+
+def prof_report():
+    """Per-kernel-family timing collected while avmoe_prof_enable(1) was on (list of dicts)."""
+    import json
+    L = lib()
+    n = L.avmoe_prof_report(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    L.avmoe_prof_report(buf, n + 1)
+    return json.loads(buf.value.decode())

@@ -54,7 +54,7 @@ def declare(L):
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.avmoe_moe_backward.restype = C.c_int
     L.avmoe_moe_backward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_void_p,
-                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoePtrs),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoePtrs),
                                      C.c_void_p]
     L.avmoe_moe_buffer_info.restype = C.c_int
     L.avmoe_moe_buffer_info.argtypes = [C.POINTER(MoeDesc), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),

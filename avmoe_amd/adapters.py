@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's adapter modules, running on the HIP path.
+
+`MoEAdapter` / `ExpertAdapter` keep the reference's constructor arguments, `forward` signatures, return
+tuples and `state_dict` key names for each of its five task copies, so the task models (AVE / AVQA /
+AVVP / AVS) can import them instead of their own classes and load released checkpoints unchanged:
+
+    AVE   AVMOE/AVE/nets/net_trans_v3.py:296-487           -> avmoe_amd.adapters.MoEAdapter (= ave)
+    AVQA  AVMOE/AVQA/net_grd_avst/net_avst_v2.py:215-399   -> avmoe_amd.adapters.MoEAdapterAVQA
+    AVVP  AVMOE/AVVP/nets/mgn.py:39-224                    -> avmoe_amd.adapters.MoEAdapterAVVP
+    AVS   AVMOE/AVS/avs_scripts/avs_{s4,ms3}/model/PVT_AVSModel_v2.py:90-318 -> avmoe_amd.adapters.MoEAdapterAVS
+
+The submodules (`conv_adapter`, `fc`, `router`, `multimodal_experts.{j}.bn1`, ...) are real torch modules
+used ONLY as parameter containers (same names, shapes and default initialisation as the reference); their
+own `forward` is never called.  All arithmetic happens in avmoe_amd/lib/libavmoe_hip.so through
+`AdapterFunction` (a `torch.autograd.Function` over the C ABI).  There is no eager / CPU fallback: a
+missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _capi as capi
+from . import _capi_moe as cm
+
+_SCRATCH: Dict[tuple, torch.Tensor] = {}
+
+
+def _scratch(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device transient workspace, grown on demand and reused (all users are stream-ordered)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(),)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _SCRATCH[key] = buf
+    return buf
+
+
+class AdapterFunction(torch.autograd.Function):
+    """out, probs, lb = f(X, Y, noise, *params) on token-major X:(S,N,C), Y:(S,M,Cy)."""
+
+    @staticmethod
+    def forward(ctx, module, X, Y, noise, names, *params):
+        if not (X.is_cuda and Y.is_cuda):
+            raise capi.AvmoeError("avmoe_amd runs on MI355X only: tensors must live on a GPU (no CPU fallback)")
+        if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
+            raise capi.AvmoeError(f"activations must both be float32 or bfloat16, got {X.dtype} / {Y.dtype}")
+        L = capi.lib()
+        X = X.contiguous()
+        Y = Y.contiguous()
+        S, N, Cc = X.shape
+        desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
+        tensors = dict(zip(names, params))
+        for k, v in tensors.items():
+            if v.dtype != torch.float32 or not v.is_contiguous() or v.device != X.device:
+                raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {X.device}")
+        bufs = module._buffer_tensors()
+        ptrs = cm.make_ptrs({**tensors, **bufs}, module.num_multimodal_experts, module.num_singlemodal_experts)
+        nsaved = L.avmoe_moe_saved_bytes(C.byref(desc))
+        if nsaved == 0:
+            raise capi.AvmoeError(L.avmoe_last_error().decode())
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=X.device)
+        scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
+        out = torch.empty_like(X)
+        E = module.num_multimodal_experts + module.num_singlemodal_experts
+        probs = torch.empty(S, E, device=X.device, dtype=torch.float32)
+        idx = torch.empty(S, device=X.device, dtype=torch.int64)
+        lb = torch.zeros((), device=X.device, dtype=torch.float32)
+        if noise is not None:
+            noise = noise.to(torch.float32).contiguous()
+        st = L.avmoe_moe_forward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs),
+                                 noise.data_ptr() if noise is not None else None, out.data_ptr(), probs.data_ptr(),
+                                 idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+                                 torch.cuda.current_stream(X.device).cuda_stream)
+        capi.check(st, "avmoe_moe_forward")
+        ctx.module, ctx.desc, ctx.names, ctx.saved_ws = module, desc, names, saved
+        ctx.save_for_backward(X, Y, *params)
+        ctx.mark_non_differentiable(probs, idx)
+        return out, probs, idx, lb
+
+    @staticmethod
+    def backward(ctx, d_out, _d_probs, _d_idx, d_lb):
+        L = capi.lib()
+        X, Y, *params = ctx.saved_tensors
+        module, desc = ctx.module, ctx.desc
+        tensors = dict(zip(ctx.names, params))
+        ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors()}, module.num_multimodal_experts,
+                            module.num_singlemodal_experts)
+        grads = {k: (torch.empty_like(v) if ctx.needs_input_grad[5 + i] else None)
+                 for i, (k, v) in enumerate(tensors.items())}
+        gptrs = cm.make_ptrs({k: v for k, v in grads.items() if v is not None}, module.num_multimodal_experts,
+                             module.num_singlemodal_experts)
+        d_out = d_out.to(X.dtype).contiguous()
+        dX = torch.empty_like(X)
+        dY = torch.empty_like(Y)
+        lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
+        scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
+        st = L.avmoe_moe_backward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs), d_out.data_ptr(),
+                                  lbg.data_ptr() if lbg is not None else None, ctx.saved_ws.data_ptr(),
+                                  scratch.data_ptr(), dX.data_ptr(), dY.data_ptr(), C.byref(gptrs),
+                                  torch.cuda.current_stream(X.device).cuda_stream)
+        capi.check(st, "avmoe_moe_backward")
+        return (None, dX, dY, None, None) + tuple(grads[k] for k in ctx.names)
+
+
+class ExpertAdapter(nn.Module):
+    """Parameter container with the reference's ExpertAdapter state (net_trans_v3.py:296-374).  It only
+    runs as part of a MoEAdapter (the experts of one site are evaluated together on the GPU)."""
+
+    def __init__(self, input_dim, output_dim, adapter_kind, reduction_factor=16, opt=None, use_bn=True,
+                 use_gate=True, num_tk=87, is_multimodal=True, variant="ave"):
+        super().__init__()
+        if adapter_kind != "bottleneck":
+            # "basic" exists in the reference (net_trans_v3.py:365-371) but is never instantiated
+            raise NotImplementedError(f"adapter_kind={adapter_kind!r}")
+        self.adapter_kind, self.use_bn, self.is_multimodal, self.opt, self.num_tk = \
+            adapter_kind, bool(use_bn), is_multimodal, opt, num_tk
+        g = opt.num_conv_group
+        self.gate = nn.Parameter(torch.zeros(1)) if use_gate else None
+        self.down_sample_size = input_dim // reduction_factor
+        if is_multimodal:
+            self.my_tokens = nn.Parameter(torch.rand((num_tk, input_dim)))
+            self.gate_av = nn.Parameter(torch.zeros(1))
+        elif variant == "avvp":
+            self.gate_av = nn.Parameter(torch.zeros(1))                       # mgn.py:83
+        elif variant == "avs" and getattr(opt, "is_self_attention", 0):
+            ver = getattr(opt, "self_attention_version", "v1")
+            if ver == "v2":                                                   # PVT_AVSModel_v2.py:143-145
+                self.my_tokens = nn.Parameter(torch.rand((num_tk, input_dim)))
+                self.gate_self = nn.Parameter(torch.zeros(1))
+            else:
+                raise NotImplementedError("self_attention_version 'v1' (nn.MultiheadAttention across frames, "
+                                          "PVT_AVSModel_v2.py:141-142,211-214) is not built")
+        elif getattr(opt, "is_self_attention", 0):
+            raise NotImplementedError("opt.is_self_attention=1 (nn.MultiheadAttention, net_trans_v3.py:346-347) is not built")
+        self.down_sampler = nn.Conv2d(input_dim, self.down_sample_size, 1, groups=g, bias=False)
+        self.up_sampler = nn.Conv2d(self.down_sample_size, output_dim, 1, groups=g, bias=False)
+        if use_bn:
+            self.bn1 = nn.BatchNorm2d(self.down_sample_size)
+            self.bn2 = nn.BatchNorm2d(output_dim)
+        if opt.is_before_layernorm:
+            self.ln_before = nn.LayerNorm(output_dim)
+        if opt.is_post_layernorm:
+            self.ln_post = nn.LayerNorm(output_dim)
+
+    def forward(self, x, vis_token=None):
+        raise capi.AvmoeError("ExpertAdapter runs inside MoEAdapter.forward on the HIP path; it has no standalone forward")
+
+
+class MoEAdapter(nn.Module):
+    """AVE signature (net_trans_v3.py:438-487).  forward(x, vis_token) -> (out (S,C,N,1), expert_indices (S,1))."""
+
+    variant = "ave"
+
+    def __init__(self, input_dim, output_dim, adapter_kind, dim_list, layer_idx, reduction_factor=16, opt=None,
+                 use_bn=True, use_gate=True, num_tk=87, conv_dim_in=0, conv_dim_out=0, linear_in=0, linear_out=0):
+        super().__init__()
+        if input_dim != output_dim or linear_out != input_dim:
+            raise ValueError("the adapter sites have input_dim == output_dim == linear_out (net_trans_v3.py:599-637)")
+        self.opt, self.use_bn, self.use_gate, self.num_tk = opt, bool(use_bn), bool(use_gate), num_tk
+        self.input_dim, self.reduction_factor = input_dim, reduction_factor
+        self.conv_adapter = nn.Conv2d(conv_dim_in, conv_dim_out, kernel_size=1)
+        self.fc = nn.Linear(linear_in, linear_out)
+        self.num_multimodal_experts = opt.num_multimodal_experts
+        self.num_singlemodal_experts = opt.num_singlemodal_experts
+        mk = lambda mm: ExpertAdapter(input_dim, output_dim, adapter_kind, reduction_factor, opt, use_bn, use_gate,
+                                      num_tk, is_multimodal=mm, variant=self.variant)
+        self.multimodal_experts = nn.ModuleList([mk(True) for _ in range(self.num_multimodal_experts)])
+        self.singlemodal_experts = nn.ModuleList([mk(False) for _ in range(self.num_singlemodal_experts)])
+        E = self.num_multimodal_experts + self.num_singlemodal_experts
+        self.router = nn.Sequential(nn.Linear(input_dim + linear_out, 128), nn.ReLU(), nn.Linear(128, 32), nn.ReLU(),
+                                    nn.Linear(32, E))
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _self_attn(self):
+        if self.variant == "avvp":
+            return "nxn"
+        if self.variant == "avs" and getattr(self.opt, "is_self_attention", 0) and \
+                getattr(self.opt, "self_attention_version", "v1") == "v2":
+            return "v2"
+        return "none"
+
+    def _desc(self, S, N, M, bf16):
+        d = cm.MoeDesc()
+        d.S, d.N, d.C, d.M, d.Cy = S, N, self.input_dim, M, self.fc.in_features
+        if N != self.conv_adapter.out_channels or M != self.conv_adapter.in_channels:
+            raise capi.AvmoeError(f"token counts ({N}, {M}) do not match conv_adapter "
+                                  f"({self.conv_adapter.out_channels}, {self.conv_adapter.in_channels})")
+        d.E_m, d.E_s = self.num_multimodal_experts, self.num_singlemodal_experts
+        d.d, d.groups, d.K = self.input_dim // self.reduction_factor, self.opt.num_conv_group, self.num_tk
+        d.use_bn, d.use_gate = int(self.use_bn), int(self.use_gate)
+        d.ln_before, d.ln_post = int(bool(self.opt.is_before_layernorm)), int(bool(self.opt.is_post_layernorm))
+        d.variant, d.self_attn = cm.VARIANT[self.variant], cm.SELF_ATTN[self._self_attn()]
+        d.lb_loss = int(self.variant in ("avvp", "avs") and getattr(self.opt, "use_load_balacing_loss", 0) == 1)
+        d.dtype, d.training = (capi.BF16 if bf16 else capi.F32), int(self.training)
+        bn = self.multimodal_experts[0].bn1 if (self.use_bn and self.num_multimodal_experts) else \
+            (self.singlemodal_experts[0].bn1 if self.use_bn else None)
+        d.bn_eps = bn.eps if bn is not None else 1e-5
+        d.bn_momentum = bn.momentum if bn is not None else 0.1
+        experts = list(self.multimodal_experts) + list(self.singlemodal_experts)
+        d.ln_eps = experts[0].ln_before.eps if self.opt.is_before_layernorm else 1e-5
+        return d
+
+    def _param_tensors(self):
+        return {k: v for k, v in self.named_parameters()}
+
+    def _buffer_tensors(self):
+        return {k: v for k, v in self.named_buffers() if v.is_floating_point()}
+
+    def _run(self, x, vis_token, noise=None):
+        # the reference hands (S, C, N, 1) permuted views of token-major memory (net_trans_v3.py:695-698)
+        X = x.squeeze(-1).permute(0, 2, 1)
+        Y = vis_token.squeeze(-1).permute(0, 2, 1)
+        P = self._param_tensors()
+        names = tuple(P.keys())
+        out, probs, idx, lb = AdapterFunction.apply(self, X, Y, noise, names, *P.values())
+        if self.training and self.use_bn:
+            with torch.no_grad():
+                for k, v in self.named_buffers():
+                    if k.endswith("num_batches_tracked"):
+                        v += 1
+        return out.permute(0, 2, 1).unsqueeze(-1), probs, idx, lb
+
+    def forward(self, x, vis_token=None):
+        out, _probs, idx, _lb = self._run(x, vis_token)
+        return out, idx.unsqueeze(-1)                                         # net_trans_v3.py:487
+
+
+class MoEAdapterAVQA(MoEAdapter):
+    """AVQA signature: no num_tk argument, K comes from opt.num_tokens (net_avst_v2.py:233,350-351)."""
+
+    variant = "avqa"
+
+    def __init__(self, input_dim, output_dim, adapter_kind, dim_list, layer_idx, reduction_factor=16, opt=None,
+                 use_bn=True, use_gate=True, conv_dim_in=0, conv_dim_out=0, linear_in=0, linear_out=0):
+        super().__init__(input_dim, output_dim, adapter_kind, dim_list, layer_idx, reduction_factor, opt, use_bn,
+                         use_gate, opt.num_tokens, conv_dim_in, conv_dim_out, linear_in, linear_out)
+
+
+class MoEAdapterAVVP(MoEAdapter):
+    """AVVP signature (mgn.py:161-217): r / bn / gate / K come from `opt`; forward -> (out, load_balancing_loss)."""
+
+    variant = "avvp"
+
+    def __init__(self, input_dim, output_dim, adapter_kind, dim_list, layer_idx, opt=None, conv_dim_in=0,
+                 conv_dim_out=0, linear_in=0, linear_out=0):
+        super().__init__(input_dim, output_dim, adapter_kind, dim_list, layer_idx, opt.Adapter_downsample, opt,
+                         bool(opt.is_bn), bool(opt.is_gate), opt.num_tokens, conv_dim_in, conv_dim_out, linear_in,
+                         linear_out)
+
+    def forward(self, x, vis_token=None):
+        out, _probs, _idx, lb = self._run(x, vis_token)
+        return out, (lb if self.opt.use_load_balacing_loss == 1 else 0.)       # mgn.py:212-217
+
+
+class MoEAdapterAVS(MoEAdapter):
+    """AVS signature (PVT_AVSModel_v2.py:253-312): forward(x, vis_token, is_training=True) ->
+    (out, expert_indices (S,1), gating_probs (S,1,E), load_balancing_loss)."""
+
+    variant = "avs"
+
+    def forward(self, x, vis_token=None, is_training=True):
+        noise = None
+        if is_training:                                                        # PVT_AVSModel_v2.py:294-296
+            E = self.num_multimodal_experts + self.num_singlemodal_experts
+            noise = torch.randn(x.shape[0], E, device=x.device, dtype=torch.float32) * 0.01
+        out, probs, idx, lb = self._run(x, vis_token, noise)
+        return out, idx.unsqueeze(-1), probs.unsqueeze(1), (lb if self.opt.use_load_balacing_loss == 1 else 0.)

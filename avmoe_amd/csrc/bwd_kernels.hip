@@ -2,6 +2,7 @@
 // (validated there against autograd); stage names match.  Full-width tensors are only touched by GEMMs.
 #include "kernels.h"
 #include "device_utils.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace avmoe {
@@ -178,10 +179,8 @@ struct PostFinArgs { P16 gate; W16 ggate; int S, E, DZ, nblk, bps, use_gate; };
 __global__ void __launch_bounds__(256) kk_post_bwd_finalize(PostFinArgs a, const float* colpart, const float* blkscal,
                                                             const float* probs, float* dsm, float* dp) {
   // dsm layout: [0]=dusum [1]=dvh [2]=dmz/NT [3]=mdy [4]=mdyz [5]=ddconst [6]=dwsum [7]=spare (each DZ) ; then dH1[E], dH2[E]
-  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 0) * a.DZ + col]; s1 += colpart[((long)b * 4 + 1) * a.DZ + col]; }
-    dsm[col] = (float)s0; dsm[a.DZ + col] = (float)(2.0 * s1);
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {   // colpart = block-summed (k_reduce_colpart)
+    dsm[col] = colpart[col]; dsm[a.DZ + col] = 2.f * colpart[a.DZ + col];
   }
   if (blockIdx.x == 0) {
     __shared__ float red[4];
@@ -208,6 +207,7 @@ __global__ void __launch_bounds__(256) kk_post_bwd_finalize(PostFinArgs a, const
 
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                      hipStream_t st) {
+  ProfScope ps_("k_post_small_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PostBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
@@ -223,8 +223,9 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   PostFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gate.p[e] = prm.e[e].gate; f.ggate.p[e] = grads.e[e].gate; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S; f.use_gate = d.use_gate;
+  AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
   hipLaunchKernelGGL(kk_post_bwd_finalize, dim3(std::max(1, cdiv(d.DZ, 256))), dim3(256), 0, st, f,
-                     (const float*)(scratch + pl.o_colpart), (const float*)(scratch + pl.o_blkscal),
+                     (const float*)(scratch + pl.o_colsum), (const float*)(scratch + pl.o_blkscal),
                      (const float*)(saved + pl.o_probs), (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_dp));
   AVMOE_CHECK_LAUNCH("post_small_bwd");
   return OK;
@@ -321,6 +322,7 @@ __global__ void __launch_bounds__(256) kk_post_prep_bwd_b(PostPrepBwdArgs a, con
 }
 int k_post_prep_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                     hipStream_t st) {
+  ProfScope ps_("k_post_prep_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PostPrepBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) {
@@ -416,8 +418,7 @@ __global__ void __launch_bounds__(256) kk_mid_bwd(MidBwdArgs a, const float* Z, 
 __global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* dsm) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= a.DZ) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 2) * a.DZ + col]; s1 += colpart[((long)b * 4 + 3) * a.DZ + col]; }
+  const double s0 = colpart[2 * a.DZ + col], s1 = colpart[3 * a.DZ + col];   // block-summed (k_reduce_colpart)
   dsm[3 * a.DZ + col] = (float)(s0 / a.NT);
   dsm[4 * a.DZ + col] = (float)(s1 / a.NT);
   const int i = col / (a.E * a.dgp), e = (col / a.dgp) % a.E, jp = col % a.dgp;
@@ -428,6 +429,7 @@ __global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* d
   }
 }
 int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  ProfScope ps_("k_mid_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   MidBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.relu_of_e[e] = d.relu_of_e[e]; a.gw1.p[e] = grads.e[e].bn1_w; a.gb1.p[e] = grads.e[e].bn1_b; }
@@ -439,7 +441,8 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
   DISPATCH_T(d.bf16, kk_mid_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
              (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (float*)(scratch + pl.o_dzp),
              (float*)(scratch + pl.o_colpart));
-  hipLaunchKernelGGL(kk_mid_bwd_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colpart),
+  AVMOE_TRY(k_reduce_colpart(pl, scratch, 2, 2, st));
+  hipLaunchKernelGGL(kk_mid_bwd_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colsum),
                      (float*)(scratch + pl.o_dsm));
   AVMOE_CHECK_LAUNCH("mid_bwd");
   return OK;
@@ -631,10 +634,8 @@ __global__ void __launch_bounds__(256) kk_pre_small_bwd(PreBwdArgs a, const floa
 struct PreFinArgs { W16 gglat; int lat_of_e[MAX_E]; int S, E, DZ, KL, nblk, bps; };
 __global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const float* colpart, const float* blkscal,
                                                            const float* dtbp, float* dsm, float* dtbar) {
-  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 0) * a.DZ + col]; s1 += colpart[((long)b * 4 + 1) * a.DZ + col]; }
-    dsm[5 * a.DZ + col] = (float)s0; dsm[6 * a.DZ + col] = (float)s1;
+  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {   // block-summed (k_reduce_colpart)
+    dsm[5 * a.DZ + col] = colpart[col]; dsm[6 * a.DZ + col] = colpart[a.DZ + col];
   }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)a.S * a.KL; i += (long)gridDim.x * 256) {
     const int s = (int)(i / a.KL), kc = (int)(i % a.KL);
@@ -655,6 +656,7 @@ __global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const f
 }
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                     hipStream_t st) {
+  ProfScope ps_("k_pre_small_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PreBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
@@ -673,8 +675,9 @@ int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   PreFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gglat.p[e] = grads.e[e].gate_lat; f.lat_of_e[e] = d.lat_of_e[e]; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.KL = d.KL; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S;
+  AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
   hipLaunchKernelGGL(kk_pre_bwd_finalize, dim3(std::max(1, cdiv(std::max((long)d.DZ, (long)d.S * d.KL), 256))), dim3(256), 0, st, f,
-                     (const float*)(scratch + pl.o_colpart), (const float*)(scratch + pl.o_blkscal),
+                     (const float*)(scratch + pl.o_colsum), (const float*)(scratch + pl.o_blkscal),
                      (const float*)(scratch + pl.o_dtbp), (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_dtbar));
   AVMOE_CHECK_LAUNCH("pre_small_bwd");
   return OK;
@@ -684,7 +687,7 @@ int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
 // router backward (mixture weights, LB loss, 3-layer MLP)   net_trans_v3.py:460-466,477-478
 // rbw layout: dlog [S][E] | dh2r [S][32] | dh1 [S][128] | drin [S][2C]
 // ---------------------------------------------------------------------------------------------
-struct RouterBwdArgs { const float *W1, *W2, *W3; int C2, E, S, lb_loss; float lb_weight; };
+struct RouterBwdArgs { const float *W1, *W2, *W3; int C2, E, S, lb_loss; const float* lb_grad; };
 __global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const float* probs, const float* dp, const float* rh1,
                                                        const float* rh2, float* rbw, void* drinT_, int bf16, void* Text_, int KLT,
                                                        int KL, int C, int N) {
@@ -704,7 +707,7 @@ __global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const fl
     float dot = 0.f, dpv[MAX_E];
     for (int e = 0; e < a.E; ++e) {
       dpv[e] = dp[(long)s * a.E + e];
-      if (a.lb_loss) dpv[e] += a.lb_weight * (-1.f / ((float)a.S * s_pm[e]));
+      if (a.lb_loss && a.lb_grad) dpv[e] += a.lb_grad[0] * (-1.f / ((float)a.S * s_pm[e]));
       dot += probs[(long)s * a.E + e] * dpv[e];
     }
     for (int e = 0; e < a.E; ++e) { const float v = probs[(long)s * a.E + e] * (dpv[e] - dot); s_dl[e] = v; dlog[e] = v; }
@@ -766,9 +769,10 @@ __global__ void kk_router_bwd_b(int S, int E, int C2, const float* rbw, const fl
   }
 }
 int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
-                 float lb_weight, hipStream_t st) {
+                 const float* lb_grad, hipStream_t st) {
+  ProfScope ps_("k_router_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
-  RouterBwdArgs a{prm.r0_w, prm.r2_w, prm.r4_w, 2 * d.C, d.E, d.S, d.lb_loss, lb_weight};
+  RouterBwdArgs a{prm.r0_w, prm.r2_w, prm.r4_w, 2 * d.C, d.E, d.S, d.lb_loss, lb_grad};
   hipLaunchKernelGGL(kk_router_bwd_a, dim3(d.S), dim3(256), 0, st, a, (const float*)(saved + pl.o_probs),
                      (const float*)(scratch + pl.o_dp), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
                      (float*)(scratch + pl.o_rbw), (void*)(scratch + pl.o_drinT), d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL,
@@ -803,6 +807,7 @@ __global__ void __launch_bounds__(256) kk_softmax_rows_bwd(const void* a_, const
 }
 int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, void* out_t, int grp,
                        int ldT, hipStream_t st) {
+  ProfScope ps_("k_softmax_rows_bwd", 0.0, 0.0, st);
   if (rows <= 0) return OK;
   DISPATCH_T(bf16, kk_softmax_rows_bwd, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, a, da, rows, n, ld,
              out_dl, out_t, grp, ldT);
@@ -843,30 +848,42 @@ __global__ void __launch_bounds__(256) kk_finish_dT(const float* dT, const float
     }
   }
 }
-// column reductions over frames: dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar/C) ; drw[c], dbf[c] from dTy and abx
-template <typename T>
-__global__ void kk_dT_colsums(const float* dT, const float* dtbar, const void* dTy_, const void* BmX_, const float* scal, float* dT0,
-                              float* dvec, int S, int KL, int Kcy, int Kcyb, int C, int Mb, int M) {
-  const T* dTy = (const T*)dTy_; const T* BmX = (const T*)BmX_;
+// dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)      (thread per (kc, c); frames looped, coalesced over c)
+__global__ void kk_dT0(const float* dT, const float* dtbar, float* dT0, int S, int KL, int C) {
   const long n1 = (long)KL * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + C; i += (long)gridDim.x * 256) {
-    if (i < n1) {
-      const int kc = (int)(i / C);
-      float acc = 0.f;
-      for (int s = 0; s < S; ++s) acc += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] / (float)C;
-      dT0[i] = acc;
-    } else {
-      const int c = (int)(i - n1);
-      float drw = 0.f, dbf = 0.f;
-      for (int s = 0; s < S; ++s)
-        for (int q = 0; q < Kcyb; ++q) {
-          const float v = ldT<T>(dTy, ((long)s * Kcyb + q) * C + c);
-          const float ab = q < Kcy ? ldT<T>(BmX, ((long)s * Kcyb + q) * Mb + M) : scal[0];
-          drw += v * ab; dbf += v;
-        }
-      dvec[c] = drw; dvec[C + c] = dbf;
-    }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += (long)gridDim.x * 256) {
+    const int kc = (int)(i / C);
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] / (float)C;
+    dT0[i] = acc;
   }
+}
+// drw[c] = sum_r dTy[r][c] abx[r] ; dbf[c] = sum_r dTy[r][c]   over the S*Kcyb rows r, in two stages:
+// grid (ceil(C/256), nchunk) -> rowpart[chunk][2][C], then a sum over chunks.
+template <typename T>
+__global__ void __launch_bounds__(256) kk_dTy_colsums_a(const void* dTy_, const void* BmX_, const float* scal, float* rowpart, long rows,
+                                                        int rows_per_chunk, int Kcy, int Kcyb, int C, int Mb, int M) {
+  const T* dTy = (const T*)dTy_; const T* BmX = (const T*)BmX_;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float drw = 0.f, dbf = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    const int q = (int)(r % Kcyb);
+    const float v = ldT<T>(dTy, r * C + c);
+    const float ab = q < Kcy ? ldT<T>(BmX, r * Mb + M) : scal[0];
+    drw += v * ab; dbf += v;
+  }
+  rowpart[((long)blockIdx.y * 2 + 0) * C + c] = drw;
+  rowpart[((long)blockIdx.y * 2 + 1) * C + c] = dbf;
+}
+__global__ void kk_dTy_colsums_b(const float* rowpart, int nchunk, int C, float* dvec) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * C) return;
+  const int which = i / C, c = i % C;
+  double acc = 0.0;
+  for (int k = 0; k < nchunk; ++k) acc += rowpart[((long)k * 2 + which) * C + c];
+  dvec[(long)which * C + c] = (float)acc;
 }
 // dBmT = T([dBm | dabx | 0]) ; dwbar[m] = sum_s dBm[s][Kcy][m] ; dbcbar = sum_s dabx[s][Kcy]
 template <typename T>
@@ -987,10 +1004,19 @@ int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   DISPATCH_T(d.bf16, kk_finish_dT, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st,
              (const float*)(scratch + pl.o_dT), (const float*)(scratch + pl.o_dtbar), drin, (const float*)(saved + pl.o_rw),
              (void*)(scratch + pl.o_dTy), (void*)(scratch + pl.o_dTx), (float*)(scratch + pl.o_dabx), d.S, d.KL, d.Kcy, d.Kcyb, d.Kcx, d.C);
-  DISPATCH_T(d.bf16, kk_dT_colsums, dim3(grid1db((long)d.KL * d.C + d.C)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
-             (const float*)(scratch + pl.o_dtbar), (const void*)(scratch + pl.o_dTy), (const void*)(saved + pl.o_BmX),
-             (const float*)(saved + pl.o_scal), (float*)(scratch + pl.o_dT0), (float*)(scratch + pl.o_dvec), d.S, d.KL, d.Kcy, d.Kcyb,
-             d.C, d.Mb, d.M);
+  if (d.KL > 0)
+    hipLaunchKernelGGL(kk_dT0, dim3(grid1db((long)d.KL * d.C, 8192)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
+                       (const float*)(scratch + pl.o_dtbar), (float*)(scratch + pl.o_dT0), d.S, d.KL, d.C);
+  {
+    const long nrows = (long)d.S * d.Kcyb;
+    const int nchunk = (int)std::min<long>(512, std::max<long>(1, nrows / 32));
+    const int rpc = cdiv(nrows, nchunk);
+    DISPATCH_T(d.bf16, kk_dTy_colsums_a, dim3(cdiv(d.C, 256), nchunk), dim3(256), 0, st, (const void*)(scratch + pl.o_dTy),
+               (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_scal), (float*)(scratch + pl.o_rowpart), nrows, rpc,
+               d.Kcy, d.Kcyb, d.C, d.Mb, d.M);
+    hipLaunchKernelGGL(kk_dTy_colsums_b, dim3(cdiv(2 * d.C, 256)), dim3(256), 0, st, (const float*)(scratch + pl.o_rowpart), nchunk,
+                       d.C, (float*)(scratch + pl.o_dvec));
+  }
   AVMOE_CHECK_LAUNCH("finish_dT");
   return OK;
 }
@@ -1004,6 +1030,7 @@ int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
   return OK;
 }
 int k_dqrqb(const Plan& pl, char* scratch, const float* bc, hipStream_t st) {
+  ProfScope ps_("k_dqrqb", 0.0, 0.0, st);
   const Dims& d = pl.d;
   const long rows = (long)d.S * d.Kcyb;
   float* part = (float*)(scratch + pl.o_dqp);
@@ -1014,6 +1041,7 @@ int k_dqrqb(const Plan& pl, char* scratch, const float* bc, hipStream_t st) {
   return OK;
 }
 int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  ProfScope ps_("k_hop1_finalize", 0.0, 0.0, st);
   const Dims& d = pl.d;
   Hop1FinArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gtok.p[e] = grads.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e]; }
@@ -1028,6 +1056,7 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   return OK;
 }
 int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  ProfScope ps_("k_down_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   DownBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) {

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "moe_run.h"
+#include "prof.h"
 
 using namespace avmoe;
 
@@ -55,14 +56,14 @@ int avmoe_moe_forward(const avmoe_moe_desc* desc, const void* X, const void* Y, 
 }
 
 int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
-                       const void* dOut, float lb_weight, void* saved, void* scratch, void* dX, void* dY,
+                       const void* dOut, const float* lb_grad, void* saved, void* scratch, void* dX, void* dY,
                        const avmoe_moe_ptrs* grads, void* stream) {
   Plan pl;
   AVMOE_TRY(make_plan(desc, &pl));
   if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads) {
     set_last_error("avmoe_moe_backward: null pointer"); return ERR_BAD_ARG;
   }
-  return moe_backward(pl, X, Y, *params, dOut, lb_weight, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream);
+  return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream);
 }
 
 int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region, size_t* offset,
@@ -76,5 +77,10 @@ int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char*
   if (bytes) *bytes = pl.info[index].bytes;
   return OK;
 }
+
+
+void avmoe_prof_enable(int on) { prof_enable(on != 0); }
+void avmoe_prof_reset(void) { prof_reset(); }
+size_t avmoe_prof_report(char* buf, size_t cap) { return prof_report(buf, cap); }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 // Buffers of the operand type T (float | __bf16) are passed as void* and cast inside the kernel.
 #include "kernels.h"
 #include "device_utils.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace avmoe {
@@ -33,9 +34,38 @@ __global__ void kk_fill_f32(float* p, long n, float v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
 int k_fill_f32(float* p, long n, float v, hipStream_t st) {
+  ProfScope ps_("k_fill_f32", 0.0, 0.0, st);
   if (n <= 0) return OK;
   hipLaunchKernelGGL(kk_fill_f32, dim3(grid1d(n)), dim3(256), 0, st, p, n, v);
   AVMOE_CHECK_LAUNCH("fill_f32");
+  return OK;
+}
+
+// Sum the per-block column partials colpart[nblk][4][DZ] over blocks: grid (ceil(DZ/64), nslots), 1024 threads;
+// wave w adds the blocks b = w (mod 16) for its 64 columns (coalesced 256-B rows, independent loads), then the
+// 16 waves are combined in double through LDS.  out[slot][col].
+__global__ void __launch_bounds__(1024) kk_reduce_colpart(const float* colpart, int nblk, int DZ, float* out) {
+  __shared__ double red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane, slot = blockIdx.y;
+  float acc = 0.f;
+  if (col < DZ)
+    for (int b = wave; b < nblk; b += 16) acc += colpart[((long)b * 4 + slot) * DZ + col];
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < DZ) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    out[(long)slot * DZ + col] = (float)s;
+  }
+}
+int k_reduce_colpart(const Plan& pl, char* scratch, int slot0, int nslots, hipStream_t st) {
+  const Dims& d = pl.d;
+  hipLaunchKernelGGL(kk_reduce_colpart, dim3(cdiv(d.DZ, 64), nslots), dim3(1024), 0, st,
+                     (const float*)(scratch + pl.o_colpart) + (long)slot0 * d.DZ, d.nblk_tok, d.DZ,
+                     (float*)(scratch + pl.o_colsum) + (long)slot0 * d.DZ);
+  AVMOE_CHECK_LAUNCH("reduce_colpart");
   return OK;
 }
 
@@ -50,6 +80,7 @@ __global__ void kk_cast(const float* src, long rows, int cols, long ld_src, void
   }
 }
 int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, void* dst, long ld_dst, hipStream_t st) {
+  ProfScope ps_("k_cast", 0.0, 0.0, st);
   const long total = rows * ld_dst;
   if (total <= 0) return OK;
   DISPATCH_T(bf16_out, kk_cast, dim3(grid1d(total)), dim3(256), 0, st, src, rows, cols, ld_src, dst, ld_dst);
@@ -107,6 +138,7 @@ __global__ void kk_prep_remap2(const void* WfT_, const float* Wc, const float* b
 }
 
 int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, const float* Wf, hipStream_t st) {
+  ProfScope ps_("k_prep_remap", 0.0, 0.0, st);
   const Dims& d = pl.d;
   if (!Wc || !bc || !Wf) { set_last_error("moe: conv_adapter / fc parameters missing"); return ERR_BAD_ARG; }
   const long tot = (long)d.N * d.Mk + (long)(d.M + 1) * d.Np + (long)d.C * d.Cy;
@@ -161,6 +193,7 @@ __global__ void __launch_bounds__(256) kk_prep_experts(PrepExpArgs a, void* Wt_,
 }
 
 int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_prep_experts", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PrepExpArgs a;
   for (int e = 0; e < MAX_E; ++e) {
@@ -216,6 +249,7 @@ __global__ void __launch_bounds__(256) kk_rowstats(const void* X_, long rows, in
   }
 }
 int k_rowstats(int bf16, const void* X, long rows, int C, float* out, hipStream_t st) {
+  ProfScope ps_("k_rowstats", 0.0, 0.0, st);
   if (rows <= 0) return OK;
   DISPATCH_T(bf16, kk_rowstats, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, X, rows, C, out);
   AVMOE_CHECK_LAUNCH("rowstats");
@@ -233,6 +267,7 @@ __global__ void __launch_bounds__(256) kk_colmean(const void* X_, int N, int C, 
   out[(long)s * out_ld + c] = acc / (float)N;
 }
 int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out_ld, hipStream_t st) {
+  ProfScope ps_("k_colmean", 0.0, 0.0, st);
   DISPATCH_T(bf16, kk_colmean, dim3(cdiv(C, 256), S), dim3(256), 0, st, X, N, C, out, out_ld);
   AVMOE_CHECK_LAUNCH("colmean");
   return OK;
@@ -271,6 +306,7 @@ __global__ void kk_fill_ext(void* Rext_, const float* qrqb, void* BmX_, const fl
   }
 }
 int k_fill_ext(const Plan& pl, char* saved, hipStream_t st) {
+  ProfScope ps_("k_fill_ext", 0.0, 0.0, st);
   const Dims& d = pl.d;
   const long tot = (long)d.S * d.Kcy * (d.Mk - d.M) + (long)d.S * d.Mk + (long)d.S * d.Mb + (long)d.S * 2 * d.C;
   DISPATCH_T(d.bf16, kk_fill_ext, dim3(grid1d(tot)), dim3(256), 0, st, (void*)(saved + pl.o_Rext),
@@ -293,6 +329,7 @@ __global__ void __launch_bounds__(256) kk_qrqb(const void* T0T_, const float* rw
   if (lane == 0) { qrqb[kc] = a; qrqb[Kcy + kc] = b; }
 }
 int k_qrqb(const Plan& pl, char* saved, const float* bf, hipStream_t st) {
+  ProfScope ps_("k_qrqb", 0.0, 0.0, st);
   const Dims& d = pl.d;
   if (d.Kcy <= 0) return OK;
   DISPATCH_T(d.bf16, kk_qrqb, dim3(cdiv(d.Kcy, 4)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T),
@@ -326,6 +363,7 @@ __global__ void __launch_bounds__(256) kk_softmax_rows(const float* in, long row
 }
 int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, int grp, int valid,
                    int slot, int kvalid, hipStream_t st) {
+  ProfScope ps_("k_softmax_rows", 0.0, 0.0, st);
   if (rows <= 0) return OK;
   DISPATCH_T(bf16_out, kk_softmax_rows, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, in, rows,
              n, ld_in, out, ld_out, grp, valid, slot, kvalid);
@@ -446,6 +484,7 @@ __global__ void __launch_bounds__(256) kk_lb_loss(const float* probs, int S, int
 }
 int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
              int64_t* idx_out, float* lb_out, hipStream_t st) {
+  ProfScope ps_("k_router", 0.0, 0.0, st);
   const Dims& d = pl.d;
   if (!prm.r0_w || !prm.r0_b || !prm.r2_w || !prm.r2_b || !prm.r4_w || !prm.r4_b) {
     set_last_error("moe: router parameters missing"); return ERR_BAD_ARG;
@@ -601,6 +640,7 @@ __global__ void __launch_bounds__(256) kk_pre_small(PreArgs a, float* Z, const f
 static void tok_grid(const Dims& d, dim3* grid) { *grid = dim3((unsigned)(d.nblk_tok / d.S), (unsigned)d.S); }
 
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_pre_small", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PreArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
@@ -647,8 +687,7 @@ __global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {
     else {
       float var;
       if (a.training) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int b = 0; b < a.nblk; ++b) { s0 += colpart[((long)b * 4 + 0) * a.DZ + col]; s1 += colpart[((long)b * 4 + 1) * a.DZ + col]; }
+        const double s0 = colpart[col], s1 = colpart[a.DZ + col];      // already summed over blocks (k_reduce_colpart)
         const double m = s0 / a.NT;
         const double v = fmax(s1 / a.NT - m * m, 0.0);
         mean = (float)m; var = (float)v;
@@ -664,12 +703,14 @@ __global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {
   bn1[col] = mean; bn1[a.DZ + col] = rstd; bn1[2 * a.DZ + col] = sc; bn1[3 * a.DZ + col] = sh;
 }
 int k_bn1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_bn1_finalize", 0.0, 0.0, st);
   const Dims& d = pl.d;
   Bn1Args a;
   for (int e = 0; e < MAX_E; ++e) { a.w.p[e] = prm.e[e].bn1_w; a.b.p[e] = prm.e[e].bn1_b; a.rm.p[e] = prm.e[e].bn1_rm; a.rv.p[e] = prm.e[e].bn1_rv; }
   a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.DZ = d.DZ; a.nblk = d.nblk_tok; a.NT = d.NT; a.use_bn = d.use_bn;
   a.training = d.training; a.eps = d.bn_eps; a.momentum = d.bn_momentum;
-  hipLaunchKernelGGL(kk_bn1_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colpart),
+  if (d.use_bn && d.training) AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
+  hipLaunchKernelGGL(kk_bn1_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colsum),
                      (float*)(saved + pl.o_bn1));
   AVMOE_CHECK_LAUNCH("bn1_finalize");
   return OK;
@@ -698,14 +739,13 @@ __global__ void __launch_bounds__(256) kk_mid(MidArgs a, const float* Z, const f
     colpart[((long)blockIdx.x * 4 + 0) * a.DZ + col] = acc;
   }
 }
-__global__ void kk_colsum_finalize(const float* colpart, int nblk, int DZ, int slot, float scale, float* out) {
+__global__ void kk_colsum_finalize(const float* colsum, int DZ, int slot, float scale, float* out) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= DZ) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += colpart[((long)b * 4 + slot) * DZ + col];
-  out[col] = (float)(s * scale);
+  out[col] = colsum[(long)slot * DZ + col] * scale;
 }
 int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  ProfScope ps_("k_mid", 0.0, 0.0, st);
   const Dims& d = pl.d;
   MidArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
@@ -714,7 +754,8 @@ int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   const int rpb = cdiv(d.NT, nblk);
   DISPATCH_T(d.bf16, kk_mid, dim3(nblk), dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
              (void*)(scratch + pl.o_Zp), (float*)(scratch + pl.o_colpart), rpb);
-  hipLaunchKernelGGL(kk_colsum_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, (const float*)(scratch + pl.o_colpart), nblk,
+  AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 1, st));
+  hipLaunchKernelGGL(kk_colsum_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, (const float*)(scratch + pl.o_colsum),
                      d.DZ, 0, 1.f / (float)d.NT, (float*)(saved + pl.o_mz));
   AVMOE_CHECK_LAUNCH("mid");
   return OK;
@@ -826,6 +867,7 @@ static void fill_postprep(const Dims& d, const avmoe_moe_ptrs& prm, PostPrepArgs
   a->use_bn = d.use_bn; a->training = d.training; a->ln_post = d.ln_post; a->eps = d.bn_eps; a->momentum = d.bn_momentum;
 }
 int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_post_prep", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PostPrepArgs a; fill_postprep(d, prm, &a);
   hipLaunchKernelGGL(kk_bn2_stats, dim3(cdiv((long)d.E * d.C, 256)), dim3(256), 0, st, a, (const float*)(saved + pl.o_mz),
@@ -932,6 +974,7 @@ __global__ void __launch_bounds__(256) kk_post_small(PostArgs a, const float* Z,
   }
 }
 int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_post_small", 0.0, 0.0, st);
   const Dims& d = pl.d;
   PostArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }

@@ -18,7 +18,9 @@
 // 16 B per lane along the contiguous index of C.
 #include "gemm.h"
 #include "common.h"
+#include "prof.h"
 #include <algorithm>
+#include <typeinfo>
 
 namespace avmoe {
 
@@ -426,6 +428,15 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   }
   const int tiles_m = cdiv(d.M, BM);
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
+  static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
+  static char name[64];
+  if (!name[0]) snprintf(name, sizeof(name), "%s_%s_%d", names[AMN][BMN], sizeof(T) == 2 ? "bf16" : "f32", BM);
+  const double nb = (double)d.nbatch;
+  const double esz = sizeof(T), osz = d.ksplit > 1 ? 4.0 : (d.out_bf16 ? 2.0 : 4.0);
+  // algorithmic bytes: every operand element once (broadcast operands counted once), C written once (+ read if accumulating)
+  const double abytes = ((d.sA1 == 0 && d.sA2 == 0 ? 1.0 : nb) * d.M * (double)d.K + (d.sB1 == 0 && d.sB2 == 0 ? 1.0 : nb) * d.N * (double)d.K) * esz +
+                        nb * d.M * (double)d.N * osz * (d.accumulate ? 2.0 : 1.0) + (d.D ? nb * d.M * (double)d.N * esz : 0.0);
+  ProfScope ps(name, abytes, 2.0 * nb * d.M * (double)d.N * d.K, stream);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, d);
   AVMOE_CHECK_LAUNCH("gemm_kernel");
   return OK;
@@ -504,6 +515,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (d.ksplit > 1) {
     const long total = (long)d.nbatch * a.M * a.N;
     const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    ProfScope ps("gemm_splitk_reduce", (double)total * 4.0 * (d.ksplit + 1), 0.0, stream);
     if (a.dtype == GEMM_BF16) hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3(blocks), dim3(256), 0, stream, d);
     else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d);
     AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");

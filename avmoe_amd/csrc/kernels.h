@@ -43,7 +43,7 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
                     const avmoe_moe_ptrs& grads, hipStream_t st);
 int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
-                 float lb_weight, hipStream_t st);
+                 const float* lb_grad, hipStream_t st);
 int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, void* out_t, int grp,
                        int ldT, hipStream_t st);
 int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st);
@@ -54,6 +54,7 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
 int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st);
 
 // generic helpers
+int k_reduce_colpart(const Plan& pl, char* scratch, int slot0, int nslots, hipStream_t st);   // colpart -> colsum
 int k_fill_f32(float* p, long n, float v, hipStream_t st);
 int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, void* dst, long ld_dst, hipStream_t st);
 

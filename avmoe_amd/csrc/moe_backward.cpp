@@ -12,7 +12,7 @@ namespace avmoe {
     if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; } \
   } while (0)
 
-int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, float lb_weight,
+int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, const float* lb_grad,
                  char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
@@ -52,7 +52,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_post_prep_bwd(pl, sv, sc, prm, grads, st));
   // ---- phase 3: ReLU / BN1 ; router --------------------------------------------------------------
   AVMOE_TRY(k_mid_bwd(pl, sv, sc, prm, grads, st));
-  AVMOE_TRY(k_router_bwd(pl, sv, sc, prm, grads, lb_weight, st));
+  AVMOE_TRY(k_router_bwd(pl, sv, sc, prm, grads, lb_grad, st));
   // ---- phase 4: folded LayerNorm / hop-2 softmax ---------------------------------------------------
   MEMSET0(sc + pl.o_dtbp, (size_t)d.nblk_tok * (d.KL ? d.KL : 1) * 4);
   AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));

@@ -1,0 +1,112 @@
+"""Data-parallel training of the adapter sites: one process per GPU, batches sharded over clips, and ONE
+exchange per optimizer step -- an all-reduce (sum, then / world) of adapter + router gradients only.  The
+backbones are frozen, so nothing else is communicated.  `torch.distributed` backend "nccl" is RCCL on ROCm
+(xGMI inside a node); "gloo" is used by the CPU tests.
+
+The reference has no distributed training: its multi-GPU mode is `nn.DataParallel` (AVVP/main.py:421,
+AVQA/net_grd_avst/main_avst_v2.py:321, AVS/avs_scripts/avs_s4/train_v2.py:140), which reduces gradients to
+GPU 0 every step and computes BatchNorm statistics per replica.  Per-rank BatchNorm statistics are therefore
+reference semantics and are kept; only the gradient reduction is re-designed:
+
+  * gradients live in a few flat fp32 buckets (`param.grad` are views into them), so the exchange is a
+    handful of large all-reduces instead of one small one per tensor -- xGMI is point-to-point, large
+    messages are what keeps the links busy;
+  * buckets are filled in reverse registration order (the order the backward produces gradients) and each
+    bucket's all-reduce is launched asynchronously as soon as its last gradient has been accumulated, so
+    communication overlaps the rest of the backward;
+  * on gradient-accumulation micro-steps (`sync=False`) nothing is sent (reference accum_itr semantics,
+    AVE/main_trans_v3.py:136-138).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter], device, dtype):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, device=device, dtype=dtype)
+        off = 0
+        for p in params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class AdapterGradReducer:
+    """Bucketed, overlapped gradient all-reduce for the trainable parameters of adapter sites.
+
+        red = AdapterGradReducer(model.parameters(), bucket_mb=32)
+        for micro, batch in enumerate(loader):
+            red.begin(sync=(micro + 1) % accum == 0)     # arm the hooks for this backward
+            loss(model(batch)).backward()
+            red.finish()                                   # wait for the buckets (no-op when sync=False)
+            if sync: opt.step(); red.zero_grad()
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
+                 process_group: Optional[dist.ProcessGroup] = None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        ps = [p for p in params if p.requires_grad]
+        if not ps:
+            raise ValueError("no trainable parameters")
+        cap = int(bucket_mb * (1 << 20))
+        self.buckets: List[_Bucket] = []
+        cur, cur_bytes = [], 0
+        for p in reversed(ps):                       # backward produces gradients roughly in reverse order
+            if cur and cur_bytes + p.numel() * 4 > cap:
+                self.buckets.append(_Bucket(cur, p.device, torch.float32))
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+        if cur:
+            self.buckets.append(_Bucket(cur, ps[0].device, torch.float32))
+        self._sync = True
+        self._owner = {}
+        for b in self.buckets:
+            for p in b.params:
+                self._owner[p] = b
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        b = self._owner[p]
+        # autograd may have replaced .grad (first accumulation into a None grad): keep the bucket view authoritative
+        if p.grad.data_ptr() < b.flat.data_ptr() or p.grad.data_ptr() >= b.flat.data_ptr() + b.flat.numel() * 4:
+            off = 0
+            for q in b.params:
+                if q is p:
+                    b.flat[off:off + p.numel()].view_as(p).copy_(p.grad)
+                    p.grad = b.flat[off:off + p.numel()].view_as(p)
+                    break
+                off += q.numel()
+        b.pending -= 1
+        if b.pending == 0 and self._sync and self.world > 1:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def begin(self, sync: bool = True):
+        self._sync = sync
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.work = None
+
+    def finish(self):
+        if not self._sync or self.world == 1:
+            return
+        for b in self.buckets:
+            if b.work is None:                       # a parameter received no gradient this step: reduce anyway
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.work.wait()
+            b.flat.div_(self.world)
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b.flat.zero_()
+
+    def message_bytes(self) -> int:
+        return sum(b.flat.numel() * 4 for b in self.buckets)

@@ -100,17 +100,26 @@ int avmoe_moe_forward(const avmoe_moe_desc* desc, const void* X, const void* Y, 
                       const float* noise, void* out, float* probs, int64_t* idx, float* lb,
                       void* saved, void* scratch, void* stream);
 
-/* Gradients of  <out, dOut> + lb_weight * lb .  Every pointer in `grads` that is non-NULL is OVERWRITTEN
+/* Gradients of  <out, dOut> + (*lb_grad) * lb .  Every pointer in `grads` that is non-NULL is OVERWRITTEN
  * with the gradient of the matching parameter; dX / dY are overwritten.  `saved` must be the buffer the
- * matching forward filled.                                                                           */
+ * matching forward filled.  lb_grad: DEVICE pointer to the upstream gradient of the load-balancing loss
+ * (one float; read on the stream, so no host sync), or NULL for 0.                                    */
 int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
-                       const void* dOut, float lb_weight, void* saved, void* scratch,
+                       const void* dOut, const float* lb_grad, void* saved, void* scratch,
                        void* dX, void* dY, const avmoe_moe_ptrs* grads, void* stream);
 
 /* Workspace introspection for tests: buffer `index` -> name / region (0 saved, 1 scratch) / offset / bytes.
  * Returns 0, or AVMOE_ERR_BAD_ARG when index is past the last buffer.                                 */
 int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region,
                           size_t* offset, size_t* bytes);
+
+
+/* ---- optional per-launch timing (HIP events on the launch stream; off by default; process-wide) --------
+ * avmoe_prof_report writes a JSON array of {"name","calls","total_ms","alg_bytes","flops"} per kernel family
+ * into buf (NUL-terminated, truncated to cap) and returns the full length.  Used by bench.py for the roofline. */
+void avmoe_prof_enable(int on);
+void avmoe_prof_reset(void);
+size_t avmoe_prof_report(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -69,8 +69,9 @@ class MoeRun:
         self.dY = torch.empty_like(self.Y)
         self.grads = {k: torch.full_like(v, float("nan")) for k, v in self.params.items()}
         self.gptrs = cm.make_ptrs(self.grads, self.cfg.E_m, self.cfg.E_s)
+        self.lbw = torch.full((1,), float(lb_weight), device=dev, dtype=torch.float32)
         st = self.L.avmoe_moe_backward(C.byref(self.desc), self.X.data_ptr(), self.Y.data_ptr(), C.byref(self.ptrs),
-                                       self.dOut.data_ptr(), C.c_float(lb_weight), self.saved.data_ptr(),
+                                       self.dOut.data_ptr(), self.lbw.data_ptr(), self.saved.data_ptr(),
                                        self.scratch.data_ptr(), self.dX.data_ptr(), self.dY.data_ptr(),
                                        C.byref(self.gptrs), torch.cuda.current_stream().cuda_stream)
         capi.check(st, "avmoe_moe_backward")

@@ -1,0 +1,64 @@
+"""The reference-shaped nn.Module API end to end on the GPU: same constructor call, (S,C,N,1) permuted views in,
+reference return tuples out, autograd through the HIP path, in-place BatchNorm buffer updates."""
+import pytest
+import torch
+
+from tests.golden_util import load_golden, split_params, assert_grads_close
+from tests.test_adapters_api import build_module
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["ave_train", "ave_eval", "avqa_train", "avs_train_nonoise", "avs_v2_train", "ave_noln_nogate"])
+def test_module_forward_backward_matches_reference_vectors(name):
+    meta, cfg, t = load_golden(name)
+    P, B = split_params(t)
+    dev = torch.device("cuda:0")
+    m = build_module(meta["which"], cfg).to(dev)
+    m.load_state_dict({**P, **B}, strict=True)
+    m.train(bool(meta["module_train"]))
+    X = t["X"].to(dev).requires_grad_(True)
+    Y = t["Y"].to(dev).requires_grad_(True)
+    xin, yin = X.permute(0, 2, 1).unsqueeze(-1), Y.permute(0, 2, 1).unsqueeze(-1)
+    if meta["which"].startswith("avs"):
+        out, idx, probs, lb = m(xin, yin, is_training=False)
+        assert probs.shape == (X.shape[0], 1, cfg.E)
+        assert torch.allclose(probs.reshape(-1, cfg.E).cpu(), t["probs"], atol=1e-5)
+    else:
+        out, idx = m(xin, yin)
+        lb = 0.0
+    assert out.shape == xin.shape and idx.shape == (X.shape[0], 1) and idx.dtype == torch.int64
+    assert torch.equal(idx.reshape(-1).cpu(), t["idx"])
+    out_tm = out.squeeze(-1).permute(0, 2, 1)
+    assert out_tm.is_contiguous()                      # the caller's residual add needs no copy
+    assert float((out_tm.cpu() - t["out"]).abs().max() / t["out"].abs().max()) < 1e-3
+    loss = (out_tm * t["grad_out"].to(dev)).sum()
+    if torch.is_tensor(lb) and meta["lb_weight"]:
+        loss = loss + meta["lb_weight"] * lb
+    loss.backward()
+    grads = {"X": X.grad.cpu(), "Y": Y.grad.cpu()}
+    for k, v in m.named_parameters():
+        assert v.grad is not None, k
+        grads[k] = v.grad.cpu()
+    assert_grads_close(grads, t, rtol=1e-3)
+    if meta["module_train"] and cfg.use_bn:
+        for k, v in m.named_buffers():
+            ref = t[f"newbuffer.{k}"]
+            assert torch.allclose(v.cpu().to(ref.dtype), ref, rtol=2e-4, atol=2e-5), k
+
+
+def test_frozen_parameters_get_no_gradient_and_bf16_runs():
+    meta, cfg, t = load_golden("ave_train")
+    P, B = split_params(t)
+    dev = torch.device("cuda:0")
+    m = build_module("ave", cfg).to(dev)
+    m.load_state_dict({**P, **B})
+    for k, v in m.named_parameters():
+        v.requires_grad_("router" in k)
+    X = t["X"].to(dev, torch.bfloat16)
+    Y = t["Y"].to(dev, torch.bfloat16)
+    out, idx = m(X.permute(0, 2, 1).unsqueeze(-1), Y.permute(0, 2, 1).unsqueeze(-1))
+    assert out.dtype == torch.bfloat16
+    out.float().sum().backward()
+    for k, v in m.named_parameters():
+        assert (v.grad is not None) == ("router" in k), k
