@@ -35,144 +35,7 @@ static int lds_attr(const void* fn, size_t bytes, const char* what) {
 constexpr int DR = 4;   // ceil(DD / 64) upper bound (DD <= 256)
 constexpr int KR = 2;   // ceil(K / 64) upper bound (K <= 128)
 
-// reduce per-wave column accumulators of one expert into colpart[blk][slot0 / slot0+1]
-__device__ __forceinline__ void flush_cols(float* s_red, const float (&c0)[DR], const float (&c1)[DR], int DD, int dgp, int E,
-                                           int e, int DZ, float* colpart, int blk, int slot0) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < DR; ++u) {
-    const int dd = lane + 64 * u;
-    if (dd < DD) { s_red[(wave * 2 + 0) * DD + dd] = c0[u]; s_red[(wave * 2 + 1) * DD + dd] = c1[u]; }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * DD; i += 256) {
-    const int which = i / DD, dd = i % DD;
-    const float v = s_red[(0 * 2 + which) * DD + dd] + s_red[(1 * 2 + which) * DD + dd] +
-                    s_red[(2 * 2 + which) * DD + dd] + s_red[(3 * 2 + which) * DD + dd];
-    const int col = (dd / dgp) * E * dgp + e * dgp + (dd % dgp);
-    colpart[((long)blk * 4 + slot0 + which) * DZ + col] = v;
-  }
-}
-// block sum of up to 4 per-wave scalars held by lane 0 -> blkscal[blk][e][0..3]
-__device__ __forceinline__ void flush_scal(float* s_sc, float v0, float v1, float v2, float v3, float* out4, unsigned mask) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) { s_sc[wave * 4 + 0] = v0; s_sc[wave * 4 + 1] = v1; s_sc[wave * 4 + 2] = v2; s_sc[wave * 4 + 3] = v3; }
-  __syncthreads();
-  if (threadIdx.x < 4 && ((mask >> threadIdx.x) & 1u))
-    out4[threadIdx.x] = s_sc[threadIdx.x] + s_sc[4 + threadIdx.x] + s_sc[8 + threadIdx.x] + s_sc[12 + threadIdx.x];
-}
-
-// ---------------------------------------------------------------------------------------------
-// POST_SMALL backward: dApost -> dq, direct dz', LayerNorm-post statistic gradients.
-// ---------------------------------------------------------------------------------------------
-struct PostBwdArgs {
-  P16 gate; int relu_of_e[MAX_E];
-  int S, N, C, E, DD, DZ, dgp, g, KPp, NT, ln_post, use_gate;
-};
-template <typename T>
-__global__ void __launch_bounds__(256) kk_post_small_bwd(PostBwdArgs a, const float* Z, const float* bn1, const float* Gq,
-                                                         const float* uvh, const float* probs, const float* rpmup,
-                                                         const float* dAp, float* dzp, void* Zp_, void* Zw_,
-                                                         float* colpart, float* blkscal) {
-  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_;
-  extern __shared__ float smb[];
-  const int DD = a.DD, dgp = a.dgp;
-  float* s_G = smb;
-  float* s_us = s_G + a.g * dgp * dgp;
-  float* s_vh = s_us + DD;
-  float* s_sc = s_vh + DD;
-  float* s_sh = s_sc + DD;
-  float* s_z = s_sh + DD;                  // 4 * DD
-  float* s_red = s_z + 4 * DD;             // 8 * DD
-  float* s_scal = s_red + 8 * DD;          // 16
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (a.N + gridDim.x - 1) / gridDim.x;
-  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int e = 0; e < a.E; ++e) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < a.g * dgp * dgp; i += 256) {
-      const int gi = i / (dgp * dgp);
-      s_G[i] = Gq[((long)(gi * a.E + e)) * dgp * dgp + (i % (dgp * dgp))];
-    }
-    for (int dd = threadIdx.x; dd < DD; dd += 256) {
-      const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
-      s_us[dd] = uvh[col]; s_vh[dd] = uvh[a.DZ + col];
-      s_sc[dd] = bn1[2 * a.DZ + col]; s_sh[dd] = bn1[3 * a.DZ + col];
-    }
-    __syncthreads();
-    const bool relu = a.relu_of_e[e];
-    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
-    const float q = probs[(long)s * a.E + e] * gate;
-    float c0[DR], c1[DR];
-#pragma unroll
-    for (int u = 0; u < DR; ++u) { c0[u] = 0.f; c1[u] = 0.f; }
-    float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
-    for (int n = n_beg + wave; n < n_end; n += 4) {
-      const long t = (long)s * a.N + n;
-      float zv[DR], dAz[DR];
-      float* zs = s_z + wave * DD;
-      wave_lds_sync_b();
-      float zz = 0.f;
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        zv[u] = 0.f; dAz[u] = 0.f;
-        if (dd < DD) {
-          const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
-          float y = Z[t * a.DZ + col] * s_sc[dd] + s_sh[dd];
-          if (relu) y = fmaxf(y, 0.f);
-          zv[u] = y; zs[dd] = y;
-          dAz[u] = dAp[(t * a.g + dd / dgp) * a.KPp + e * dgp + (dd % dgp)];
-          zz += dAz[u] * y;
-        }
-      }
-      wave_lds_sync_b();
-      zz = wave_sum(zz);
-      float da1 = 0.f, da2 = 0.f, da3 = 0.f;
-      for (int gi = 0; gi < a.g; ++gi) {
-        const float* p = dAp + (t * a.g + gi) * a.KPp + a.E * dgp + 3 * e;
-        da1 += p[0]; da2 += p[1]; da3 += p[2];
-      }
-      const float rp = rpmup[t * a.E + e], mup = rpmup[(long)a.NT * a.E + t * a.E + e];
-      const float dq = rp * zz + rp * da1 - rp * mup * da2 + da3;
-      float dSo = 0.f, dSoo = 0.f;
-      if (a.ln_post) {
-        const float drp = q * zz + q * da1 - q * mup * da2;
-        float dmup = -q * rp * da2;
-        const float dvarp = drp * (-0.5f) * rp * rp * rp;
-        dSoo = dvarp / (float)a.C;
-        dmup -= 2.f * mup * dvarp;
-        dSo = dmup / (float)a.C;
-      }
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        if (dd < DD) {
-          const int gi = dd / dgp, jp = dd % dgp;
-          const int col = gi * a.E * dgp + e * dgp + jp;
-          float dz = q * rp * dAz[u];
-          if (a.ln_post) {
-            const float* Gg = s_G + gi * dgp * dgp;
-            float w = 0.f;
-            for (int l2 = 0; l2 < dgp; ++l2) w += Gg[l2 * dgp + jp] * zs[gi * dgp + l2];
-            dz += dSo * s_us[dd] + dSoo * (2.f * w + 2.f * s_vh[dd]);
-            c0[u] += dSo * zv[u];
-            c1[u] += dSoo * zv[u];
-          }
-          dzp[t * a.DZ + col] = dz;
-          stT<T>(Zp, t * a.DZ + col, zv[u]);
-          stT<T>(Zw, t * a.DZ + col, dSoo * zv[u]);
-        }
-      }
-      sdq += dq; sdSo += dSo; sdSoo += dSoo;
-    }
-    flush_cols(s_red, c0, c1, DD, dgp, a.E, e, a.DZ, colpart, blk, 0);
-    flush_scal(s_scal, sdq, sdSo, sdSoo, 0.f, blkscal + ((long)blk * a.E + e) * 4, 0x7u);
-  }
-}
+// (the per-token backward kernels live in tile_kernels.hip; this file keeps their finalize / weight-space parts)
 
 // finalize: dusum, dvh (column sums), dp[s][e], dH1[e], dH2[e], grads.gate
 struct PostFinArgs { P16 gate; W16 ggate; int S, E, DZ, nblk, bps, use_gate; };
@@ -205,21 +68,9 @@ __global__ void __launch_bounds__(256) kk_post_bwd_finalize(PostFinArgs a, const
   }
 }
 
-int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
-                     hipStream_t st) {
-  ProfScope ps_("k_post_small_bwd", 0.0, 0.0, st);
+int k_post_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                              hipStream_t st) {
   const Dims& d = pl.d;
-  PostBwdArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.g = d.g; a.KPp = d.KPp; a.NT = d.NT;
-  a.ln_post = d.ln_post; a.use_gate = d.use_gate;
-  const size_t sh = (size_t)(d.g * d.dgp * d.dgp + 16 * d.DD + 16) * sizeof(float);
-  AVMOE_TRY(lds_attr(d.bf16 ? (const void*)kk_post_small_bwd<__bf16> : (const void*)kk_post_small_bwd<float>, sh, "post_small_bwd"));
-  dim3 grid; tok_grid_b(d, &grid);
-  DISPATCH_T(d.bf16, kk_post_small_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
-             (const float*)(saved + pl.o_rpmup), (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp),
-             (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
   PostFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gate.p[e] = prm.e[e].gate; f.ggate.p[e] = grads.e[e].gate; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S; f.use_gate = d.use_gate;
@@ -348,73 +199,6 @@ struct MidBwdArgs {
   int relu_of_e[MAX_E]; W16 gw1, gb1;
   int S, N, E, DD, DZ, dgp, dg, g, NT, use_bn, training, nblk;
 };
-template <typename T>
-__global__ void __launch_bounds__(256) kk_mid_bwd(MidBwdArgs a, const float* Z, const float* bn1, const float* dsm,
-                                                  const float* sdSzz, float* dzp, float* colpart) {
-  extern __shared__ float smb[];
-  const int DD = a.DD, dgp = a.dgp;
-  float* s_S = smb;                        // g * dgp * dgp
-  float* s_z = s_S + a.g * dgp * dgp;      // 4 * DD
-  float* s_red = s_z + 4 * DD;             // 8 * DD
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (a.N + gridDim.x - 1) / gridDim.x;
-  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool moments = a.use_bn && a.training;
-  for (int e = 0; e < a.E; ++e) {
-    __syncthreads();
-    if (moments)
-      for (int i = threadIdx.x; i < a.g * dgp * dgp; i += 256) {
-        const int gi = i / (dgp * dgp);
-        s_S[i] = sdSzz[((long)(gi * a.E + e)) * dgp * dgp + (i % (dgp * dgp))];
-      }
-    __syncthreads();
-    const bool relu = a.relu_of_e[e];
-    float c0[DR], c1[DR];
-#pragma unroll
-    for (int u = 0; u < DR; ++u) { c0[u] = 0.f; c1[u] = 0.f; }
-    for (int n = n_beg + wave; n < n_end; n += 4) {
-      const long t = (long)s * a.N + n;
-      float yv[DR], zh[DR];
-      float* zs = s_z + wave * DD;
-      wave_lds_sync_b();
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        yv[u] = 0.f; zh[u] = 0.f;
-        if (dd < DD) {
-          const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
-          const float z = Z[t * a.DZ + col];
-          zh[u] = (z - bn1[col]) * bn1[a.DZ + col];
-          const float y = z * bn1[2 * a.DZ + col] + bn1[3 * a.DZ + col];
-          yv[u] = y;
-          zs[dd] = relu ? fmaxf(y, 0.f) : y;
-        }
-      }
-      wave_lds_sync_b();
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        if (dd < DD) {
-          const int gi = dd / dgp, jp = dd % dgp;
-          const int col = gi * a.E * dgp + e * dgp + jp;
-          float dz = dzp[t * a.DZ + col];
-          if (moments) {
-            const float* Sg = s_S + gi * dgp * dgp;
-            float w = 0.f;
-            for (int l2 = 0; l2 < dgp; ++l2) w += Sg[l2 * dgp + jp] * zs[gi * dgp + l2];
-            dz += dsm[2 * a.DZ + col] + w;
-          }
-          const float dy = (relu && yv[u] <= 0.f) ? 0.f : dz;
-          dzp[t * a.DZ + col] = dy;
-          c0[u] += dy;
-          c1[u] += dy * zh[u];
-        }
-      }
-    }
-    flush_cols(s_red, c0, c1, DD, dgp, a.E, e, a.DZ, colpart, blk, 2);
-  }
-}
 __global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* dsm) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= a.DZ) return;
@@ -428,19 +212,12 @@ __global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* d
     if (a.gb1.p[e]) a.gb1.p[e][j] = (float)s0;
   }
 }
-int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
-  ProfScope ps_("k_mid_bwd", 0.0, 0.0, st);
+int k_mid_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
   MidBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.relu_of_e[e] = d.relu_of_e[e]; a.gw1.p[e] = grads.e[e].bn1_w; a.gb1.p[e] = grads.e[e].bn1_b; }
   a.S = d.S; a.N = d.N; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.dg = d.dg; a.g = d.g; a.NT = d.NT;
   a.use_bn = d.use_bn; a.training = d.training; a.nblk = d.nblk_tok;
-  const size_t sh = (size_t)(d.g * d.dgp * d.dgp + 12 * d.DD) * sizeof(float);
-  AVMOE_TRY(lds_attr(d.bf16 ? (const void*)kk_mid_bwd<__bf16> : (const void*)kk_mid_bwd<float>, sh, "mid_bwd"));
-  dim3 grid; tok_grid_b(d, &grid);
-  DISPATCH_T(d.bf16, kk_mid_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-             (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (float*)(scratch + pl.o_dzp),
-             (float*)(scratch + pl.o_colpart));
   AVMOE_TRY(k_reduce_colpart(pl, scratch, 2, 2, st));
   hipLaunchKernelGGL(kk_mid_bwd_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colsum),
                      (float*)(scratch + pl.o_dsm));
@@ -451,186 +228,6 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 // ---------------------------------------------------------------------------------------------
 // PRE_SMALL backward: BN1 input gradient, folded-LayerNorm statistics, hop-2 softmax.
 // ---------------------------------------------------------------------------------------------
-struct PreBwdArgs {
-  P16 glat; int lat_of_e[MAX_E];
-  int S, N, C, E, K, Kp, El, KL, KLT, KLp, DD, DZ, dgp, g, NT, ln_before, use_bn, training;
-};
-template <typename T>
-__global__ void __launch_bounds__(256) kk_pre_small_bwd(PreBwdArgs a, const float* Z, const float* L2, const float* TT,
-                                                        const float* TW, const float* Tsum, const float* wsum,
-                                                        const float* dconst, const void* ain_, const float* rmu,
-                                                        const float* bn1, const float* dsm, const float* dy_in, void* dZx_,
-                                                        void* dL2x_, void* aw_, void* ag_, float* dsxs, float* rs2x,
-                                                        float* colpart, float* blkscal, float* dtbp) {
-  const T* ain = (const T*)ain_;
-  T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
-  extern __shared__ float smb[];
-  const int K = a.K, DD = a.DD;
-  float* s_TT = smb;                       // K*K
-  float* s_TW = s_TT + K * K;              // K*DD     [k][dd]
-  float* s_TWt = s_TW + K * DD;            // DD*K     [dd][k]
-  float* s_tb = s_TWt + K * DD;            // K
-  float* s_a = s_tb + K;                   // 4*K
-  float* s_dz = s_a + 4 * K;               // 4*DD
-  float* s_red = s_dz + 4 * DD;            // 8*DD
-  float* s_scal = s_red + 8 * DD;          // 16
-  float* s_tbr = s_scal + 16;              // 4*K  (dtbar per wave)
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (a.N + gridDim.x - 1) / gridDim.x;
-  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool bn_train = a.use_bn && a.training;
-  for (int e = 0; e < a.E; ++e) {
-    const int l = a.lat_of_e[e];
-    float gv = 0.f;
-    __syncthreads();
-    if (l >= 0) {
-      gv = a.glat.p[e][0];
-      const float* tt = TT + ((long)s * a.El + l) * K * K;
-      for (int i = threadIdx.x; i < K * K; i += 256) s_TT[i] = tt[i];
-      for (int i = threadIdx.x; i < K * DD; i += 256) {
-        const int k = i / DD, dd = i % DD;
-        const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
-        const float v = TW[((long)s * a.KLT + (long)l * a.Kp + k) * a.DZ + col];
-        s_TW[i] = v; s_TWt[dd * K + k] = v;
-      }
-      for (int i = threadIdx.x; i < K; i += 256) s_tb[i] = Tsum[(long)s * a.KLT + (long)l * a.Kp + i] / (float)a.C;
-    }
-    __syncthreads();
-    float c0[DR], c1[DR], tbacc[KR];
-#pragma unroll
-    for (int u = 0; u < DR; ++u) { c0[u] = 0.f; c1[u] = 0.f; }
-#pragma unroll
-    for (int u = 0; u < KR; ++u) tbacc[u] = 0.f;
-    float sdg = 0.f;
-    for (int n = n_beg + wave; n < n_end; n += 4) {
-      const long t = (long)s * a.N + n;
-      const float r = a.ln_before ? rmu[t * a.E + e] : 1.f;
-      const float mu = a.ln_before ? rmu[(long)a.NT * a.E + t * a.E + e] : 0.f;
-      float* dzs = s_dz + wave * DD;
-      float* aw = s_a + wave * K;
-      float dzraw[DR];
-      float s_dr = 0.f, s_dmu = 0.f;
-      wave_lds_sync_b();
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        dzraw[u] = 0.f;
-        if (dd < DD) {
-          const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
-          const float z = Z[t * a.DZ + col];
-          float dz = dy_in[t * a.DZ + col];
-          if (a.use_bn) {
-            const float sc = bn1[2 * a.DZ + col];
-            if (bn_train) {
-              const float zh = (z - bn1[col]) * bn1[a.DZ + col];
-              dz = sc * (dz - dsm[3 * a.DZ + col] - zh * dsm[4 * a.DZ + col]);
-            } else dz = sc * dz;
-          }
-          if (a.ln_before) {
-            const float zc = (z - dconst[col]) / r;          // zraw - mu * wsum
-            c0[u] += dz;                                      // d dconst
-            c1[u] += -r * mu * dz;                            // d wsum
-            s_dr += dz * zc;
-            s_dmu += dz * wsum[col];
-            dzraw[u] = r * dz;
-          } else dzraw[u] = dz;
-          stT<T>(dZx, t * a.DZ + col, dzraw[u]);
-          dzs[dd] = dzraw[u];
-        }
-      }
-      float dSx = 0.f, dSxx = 0.f;
-      if (a.ln_before) {
-        s_dr = wave_sum(s_dr); s_dmu = wave_sum(s_dmu);
-        float dmu = -r * s_dmu;
-        const float dvar = s_dr * (-0.5f) * r * r * r;
-        dSxx = dvar / (float)a.C;
-        dmu -= 2.f * mu * dvar;
-        dSx = dmu / (float)a.C;
-      }
-      if (lane == 0) {
-        if (e == 0) { dsxs[t] = dSx; dsxs[a.NT + t] = dSxx; }
-        else { dsxs[t] += dSx; dsxs[a.NT + t] += dSxx; }
-      }
-      if (l >= 0) {
-        const float* l2 = L2 + t * a.KLp + (long)l * a.Kp;
-        float av[KR], lv[KR];
-#pragma unroll
-        for (int u = 0; u < KR; ++u) {
-          const int k = lane + 64 * u;
-          av[u] = 0.f; lv[u] = 0.f;
-          if (k < K) { av[u] = ldT<T>(ain, t * a.KLp + (long)l * a.Kp + k); lv[u] = l2[k]; aw[k] = av[u]; }
-        }
-        wave_lds_sync_b();
-        float u1 = 0.f, u2 = 0.f, u3 = 0.f, ta[KR];
-#pragma unroll
-        for (int u = 0; u < KR; ++u) {
-          const int k = lane + 64 * u;
-          ta[u] = 0.f;
-          if (k < K) {
-            float w = 0.f;
-            for (int k2 = 0; k2 < K; ++k2) w += s_TT[k2 * K + k] * aw[k2];
-            ta[u] = w;                                        // (TT a)_k
-            u1 += av[u] * s_tb[k]; u2 += av[u] * lv[u]; u3 += av[u] * w;
-          }
-        }
-        u1 = wave_sum(u1); u2 = wave_sum(u2); u3 = wave_sum(u3);
-        float dgp = 0.f;
-#pragma unroll
-        for (int u = 0; u < DR; ++u) {
-          const int dd = lane + 64 * u;
-          if (dd < DD) {
-            float acc = 0.f;
-            for (int k = 0; k < K; ++k) acc += aw[k] * s_TW[k * DD + dd];
-            dgp += dzraw[u] * acc;
-          }
-        }
-        dgp = wave_sum(dgp);
-        sdg += dSx * (float)a.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgp;
-        const float du1 = dSx * gv * (float)a.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
-        float da[KR], sada = 0.f;
-#pragma unroll
-        for (int u = 0; u < KR; ++u) {
-          const int k = lane + 64 * u;
-          da[u] = 0.f;
-          if (k < K) {
-            float acc = 0.f;
-            for (int dd = 0; dd < DD; ++dd) acc += s_TWt[dd * K + k] * dzs[dd];
-            da[u] = gv * acc + du1 * s_tb[k] + du2 * lv[u] + 2.f * du3 * ta[u];
-            sada += av[u] * da[u];
-            tbacc[u] += du1 * av[u];
-          }
-        }
-        sada = wave_sum(sada);
-#pragma unroll
-        for (int u = 0; u < KR; ++u) {
-          const int k = lane + 64 * u;
-          const long o = t * a.KLp + (long)l * a.Kp + k;
-          if (k < K) {
-            stT<T>(dL2x, o, du2 * av[u] + av[u] * (da[u] - sada));
-            stT<T>(aw_o, o, du3 * av[u]);
-            stT<T>(ag_o, o, gv * av[u]);
-          } else if (k < a.Kp) { stT<T>(dL2x, o, 0.f); stT<T>(aw_o, o, 0.f); stT<T>(ag_o, o, 0.f); }
-        }
-      }
-      if (e == a.E - 1 && lane == 0) {
-        stT<T>(dL2x, t * a.KLp + a.KL, dsxs[t]);
-        stT<T>(dL2x, t * a.KLp + a.KL + 1, 1.f);
-        rs2x[t] = 2.f * dsxs[a.NT + t];
-      }
-    }
-    flush_cols(s_red, c0, c1, DD, a.dgp, a.E, e, a.DZ, colpart, blk, 0);
-    flush_scal(s_scal, 0.f, 0.f, 0.f, sdg, blkscal + ((long)blk * a.E + e) * 4, 0x8u);
-    if (l >= 0) {
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < KR; ++u) { const int k = lane + 64 * u; if (k < K) s_tbr[wave * K + k] = tbacc[u]; }
-      __syncthreads();
-      for (int k = threadIdx.x; k < K; k += 256)
-        dtbp[(long)blk * a.KL + (long)l * a.Kp + k] = s_tbr[k] + s_tbr[K + k] + s_tbr[2 * K + k] + s_tbr[3 * K + k];
-    }
-  }
-}
 struct PreFinArgs { W16 gglat; int lat_of_e[MAX_E]; int S, E, DZ, KL, nblk, bps; };
 __global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const float* colpart, const float* blkscal,
                                                            const float* dtbp, float* dsm, float* dtbar) {
@@ -654,24 +251,9 @@ __global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const f
     }
   }
 }
-int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
-                    hipStream_t st) {
-  ProfScope ps_("k_pre_small_bwd", 0.0, 0.0, st);
+int k_pre_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                             hipStream_t st) {
   const Dims& d = pl.d;
-  PreBwdArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
-  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.K = d.K; a.Kp = d.Kp; a.El = d.El; a.KL = d.KL; a.KLT = d.KLT; a.KLp = d.KLp; a.DD = d.DD;
-  a.DZ = d.DZ; a.dgp = d.dgp; a.g = d.g; a.NT = d.NT; a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.training = d.training;
-  const size_t sh = (size_t)(d.K * d.K + 2 * d.K * d.DD + d.K + 4 * d.K + 4 * d.DD + 8 * d.DD + 16 + 4 * d.K) * sizeof(float);
-  AVMOE_TRY(lds_attr(d.bf16 ? (const void*)kk_pre_small_bwd<__bf16> : (const void*)kk_pre_small_bwd<float>, sh, "pre_small_bwd"));
-  dim3 grid; tok_grid_b(d, &grid);
-  DISPATCH_T(d.bf16, kk_pre_small_bwd, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2),
-             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
-             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a),
-             (const float*)(saved + pl.o_rmu), (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm),
-             (const float*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw),
-             (void*)(scratch + pl.o_ag), (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x),
-             (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
   PreFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gglat.p[e] = grads.e[e].gate_lat; f.lat_of_e[e] = d.lat_of_e[e]; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.KL = d.KL; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S;

@@ -502,169 +502,7 @@ int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float
   return OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// PRE_SMALL: hop-2 softmax, LayerNorm statistics from K-space, LN-folded down projection, BN1 sums.
-// grid (blocks per sample, S); one wave walks tokens; experts outermost (per-sample K x K and K x DD
-// matrices of the current expert are staged in LDS).       net_trans_v3.py:385-395
-// ---------------------------------------------------------------------------------------------
-struct PreArgs {
-  P16 glat;
-  int lat_of_e[MAX_E];
-  int S, N, C, E, K, Kp, El, KLT, KLp, DD, DZ, dgp, g, NT, ln_before;
-  float ln_eps;
-};
-
-template <typename T>
-__global__ void __launch_bounds__(256) kk_pre_small(PreArgs a, float* Z, const float* L2, const float* sxs, const float* TT,
-                                                    const float* TW, const float* Tsum, const float* wsum,
-                                                    const float* dconst, void* aout_, float* rmu, float* colpart) {
-  T* aout = (T*)aout_;
-  extern __shared__ float sm[];
-  const int K = a.K, DD = a.DD;
-  float* s_TT = sm;                        // K*K
-  float* s_TW = s_TT + K * K;              // K*DD
-  float* s_tb = s_TW + K * DD;             // K
-  float* s_a = s_tb + K;                   // 4 * K   per-wave softmax scratch
-  float* s_red = s_a + 4 * K;              // 4 * 2 * DD
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (a.N + gridDim.x - 1) / gridDim.x;
-  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  constexpr int DR = 4, KR = 2;
-
-  for (int e = 0; e < a.E; ++e) {
-    const int l = a.lat_of_e[e];
-    float gv = 0.f;
-    __syncthreads();
-    if (l >= 0) {
-      gv = a.glat.p[e][0];
-      const float* tt = TT + ((long)s * a.El + l) * K * K;                  // TT[s][l]
-      for (int i = threadIdx.x; i < K * K; i += 256) s_TT[i] = tt[i];
-      for (int i = threadIdx.x; i < K * DD; i += 256) {
-        const int k = i / DD, dd = i % DD;
-        const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
-        s_TW[i] = TW[((long)s * a.KLT + (long)l * a.Kp + k) * a.DZ + col];
-      }
-      for (int i = threadIdx.x; i < K; i += 256) s_tb[i] = Tsum[(long)s * a.KLT + (long)l * a.Kp + i] / (float)a.C;
-    }
-    __syncthreads();
-    float csum[DR], csq[DR];
-#pragma unroll
-    for (int u = 0; u < DR; ++u) { csum[u] = 0.f; csq[u] = 0.f; }
-    for (int n = n_beg + wave; n < n_end; n += 4) {
-      const long t = (long)s * a.N + n;
-      float Sx = sxs[t], Sxx = sxs[a.NT + t];
-      float* aw = s_a + wave * K;
-      if (l >= 0) {
-        const float* l2 = L2 + t * a.KLp + (long)l * a.Kp;
-        float lv[KR], av[KR];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < KR; ++u) { const int k = lane + 64 * u; lv[u] = k < K ? l2[k] : -INFINITY; mx = fmaxf(mx, lv[u]); }
-        mx = wave_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int u = 0; u < KR; ++u) { const int k = lane + 64 * u; av[u] = k < K ? __expf(lv[u] - mx) : 0.f; sum += av[u]; }
-        sum = wave_sum(sum);
-        const float inv = 1.f / sum;
-        float u1 = 0.f, u2 = 0.f;
-        wave_lds_sync();
-#pragma unroll
-        for (int u = 0; u < KR; ++u) {
-          const int k = lane + 64 * u;
-          if (k < K) {
-            av[u] = roundT<T>(av[u] * inv);
-            stT<T>(aout, t * a.KLp + (long)l * a.Kp + k, av[u]);
-            aw[k] = av[u];
-            u1 += av[u] * s_tb[k];
-            u2 += av[u] * lv[u];
-          } else if (k < a.Kp) stT<T>(aout, t * a.KLp + (long)l * a.Kp + k, 0.f);
-        }
-        wave_lds_sync();
-        float u3 = 0.f;
-#pragma unroll
-        for (int u = 0; u < KR; ++u) {
-          const int k = lane + 64 * u;
-          if (k < K) {
-            float w = 0.f;
-            for (int k2 = 0; k2 < K; ++k2) w += s_TT[k2 * K + k] * aw[k2];     // TT symmetric: row k2, column k
-            u3 += av[u] * w;
-          }
-        }
-        u1 = wave_sum(u1); u2 = wave_sum(u2); u3 = wave_sum(u3);
-        Sx += gv * (float)a.C * u1;
-        Sxx += 2.f * gv * u2 + gv * gv * u3;
-      }
-      float mu = 0.f, r = 1.f;
-      if (a.ln_before) {
-        mu = Sx / (float)a.C;
-        const float var = Sxx / (float)a.C - mu * mu;
-        r = rsqrtf(fmaxf(var, 0.f) + a.ln_eps);
-      }
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        if (dd < DD) {
-          const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
-          float zr = Z[t * a.DZ + col];
-          if (l >= 0) {
-            float acc = 0.f;
-            for (int k = 0; k < K; ++k) acc += aw[k] * s_TW[k * DD + dd];
-            zr += gv * acc;
-          }
-          const float z = a.ln_before ? r * (zr - mu * wsum[col]) + dconst[col] : zr;
-          Z[t * a.DZ + col] = z;
-          csum[u] += z; csq[u] += z * z;
-        }
-      }
-      if (lane == 0) { rmu[t * a.E + e] = r; rmu[(long)a.NT * a.E + t * a.E + e] = mu; }
-    }
-    // block-level column partials of this expert's columns
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < DR; ++u) {
-      const int dd = lane + 64 * u;
-      if (dd < DD) { s_red[(wave * 2 + 0) * DD + dd] = csum[u]; s_red[(wave * 2 + 1) * DD + dd] = csq[u]; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * DD; i += 256) {
-      const int which = i / DD, dd = i % DD;
-      const float v = s_red[(0 * 2 + which) * DD + dd] + s_red[(1 * 2 + which) * DD + dd] +
-                      s_red[(2 * 2 + which) * DD + dd] + s_red[(3 * 2 + which) * DD + dd];
-      const int col = (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
-      colpart[((long)blk * 4 + which) * a.DZ + col] = v;
-    }
-  }
-}
-
-static void tok_grid(const Dims& d, dim3* grid) { *grid = dim3((unsigned)(d.nblk_tok / d.S), (unsigned)d.S); }
-
-int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
-  ProfScope ps_("k_pre_small", 0.0, 0.0, st);
-  const Dims& d = pl.d;
-  PreArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
-  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.K = d.K; a.Kp = d.Kp; a.El = d.El; a.KLT = d.KLT; a.KLp = d.KLp; a.DD = d.DD; a.DZ = d.DZ;
-  a.dgp = d.dgp; a.g = d.g; a.NT = d.NT; a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
-  const size_t sh = (size_t)(d.K * d.K + d.K * d.DD + d.K + 4 * d.K + 8 * d.DD) * sizeof(float);
-  dim3 grid; tok_grid(d, &grid);
-  if (sh > 65536) {
-    static bool done[2] = {false, false};
-    if (!done[d.bf16]) {
-      hipError_t e = d.bf16 ? hipFuncSetAttribute((const void*)kk_pre_small<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                            : hipFuncSetAttribute((const void*)kk_pre_small<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) { set_last_error("pre_small: LDS attribute: %s", hipGetErrorString(e)); return ERR_LAUNCH; }
-      done[d.bf16] = true;
-    }
-  }
-  if (sh > 160 * 1024) { set_last_error("pre_small: K=%d, DD=%d need %zu B of LDS", d.K, d.DD, sh); return ERR_UNSUPPORTED; }
-  DISPATCH_T(d.bf16, kk_pre_small, grid, dim3(256), sh, st, a, (float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2),
-             (const float*)(saved + pl.o_sx), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW),
-             (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst),
-             (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu), (float*)(scratch + pl.o_colpart));
-  AVMOE_CHECK_LAUNCH("pre_small");
-  return OK;
-}
+// (PRE_SMALL / POST_SMALL live in tile_kernels.hip: 16-token MFMA tiles)
 
 // ---------------------------------------------------------------------------------------------
 // BN1 finalize: column partials -> batch mean / biased var -> (mean, rstd, scale, shift); running
@@ -877,115 +715,6 @@ int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   hipLaunchKernelGGL(kk_gq, dim3(d.g * d.E), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2), (float*)(saved + pl.o_Gq),
                      (float*)(saved + pl.o_uvh));
   AVMOE_CHECK_LAUNCH("post_prep");
-  return OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// POST_SMALL: LayerNorm-post statistics from the d-space quadratic form, gate * prob, and the row of
-// Apost for the single output GEMM.   net_trans_v3.py:430-434,485-486
-// ---------------------------------------------------------------------------------------------
-struct PostArgs {
-  P16 gate; int relu_of_e[MAX_E];
-  int S, N, C, E, DD, DZ, dgp, g, KPp, NT, ln_post, use_gate;
-  float ln_eps;
-};
-template <typename T>
-__global__ void __launch_bounds__(256) kk_post_small(PostArgs a, const float* Z, const float* bn1, const float* Gq, const float* uvh,
-                                                     const float* probs, void* Apost_, float* rpmup) {
-  T* Apost = (T*)Apost_;
-  extern __shared__ float sm[];
-  const int DD = a.DD, dgp = a.dgp;
-  float* s_G = sm;                         // g * dgp * dgp
-  float* s_us = s_G + a.g * dgp * dgp;     // DD
-  float* s_vh = s_us + DD;                 // DD
-  float* s_sc = s_vh + DD;                 // DD
-  float* s_sh = s_sc + DD;                 // DD
-  float* s_z = s_sh + DD;                  // 4 * DD
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (a.N + gridDim.x - 1) / gridDim.x;
-  const int n_beg = blockIdx.x * per, n_end = min(a.N, n_beg + per);
-  constexpr int DR = 4;
-  for (int e = 0; e < a.E; ++e) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < a.g * dgp * dgp; i += 256) {
-      const int gi = i / (dgp * dgp);
-      s_G[i] = Gq[((long)(gi * a.E + e)) * dgp * dgp + (i % (dgp * dgp))];
-    }
-    float H1 = 0.f, H2 = 0.f;
-    for (int gi = 0; gi < a.g; ++gi) { H1 += uvh[2 * a.DZ + gi * a.E + e]; H2 += uvh[2 * a.DZ + a.g * a.E + gi * a.E + e]; }
-    for (int dd = threadIdx.x; dd < DD; dd += 256) {
-      const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
-      s_us[dd] = uvh[col]; s_vh[dd] = uvh[a.DZ + col];
-      s_sc[dd] = bn1[2 * a.DZ + col]; s_sh[dd] = bn1[3 * a.DZ + col];
-    }
-    __syncthreads();
-    const bool relu = a.relu_of_e[e];
-    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
-    const float q = probs[(long)s * a.E + e] * gate;
-    for (int n = n_beg + wave; n < n_end; n += 4) {
-      const long t = (long)s * a.N + n;
-      float zv[DR];
-      float* zs = s_z + wave * DD;
-      wave_lds_sync();
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        zv[u] = 0.f;
-        if (dd < DD) {
-          const int col = (dd / dgp) * a.E * dgp + e * dgp + (dd % dgp);
-          float y = Z[t * a.DZ + col] * s_sc[dd] + s_sh[dd];
-          if (relu) y = fmaxf(y, 0.f);
-          zv[u] = y; zs[dd] = y;
-        }
-      }
-      wave_lds_sync();
-      float rp = 1.f, mup = 0.f;
-      if (a.ln_post) {
-        float so = 0.f, soo = 0.f;
-#pragma unroll
-        for (int u = 0; u < DR; ++u) {
-          const int dd = lane + 64 * u;
-          if (dd < DD) {
-            const int gi = dd / dgp, jp = dd % dgp;
-            const float* Gg = s_G + gi * dgp * dgp;
-            float w = 0.f;
-            for (int l2 = 0; l2 < dgp; ++l2) w += Gg[l2 * dgp + jp] * zs[gi * dgp + l2];   // G symmetric
-            so += zv[u] * s_us[dd];
-            soo += zv[u] * (w + 2.f * s_vh[dd]);
-          }
-        }
-        so = wave_sum(so) + H1; soo = wave_sum(soo) + H2;
-        mup = so / (float)a.C;
-        const float varp = soo / (float)a.C - mup * mup;
-        rp = rsqrtf(fmaxf(varp, 0.f) + a.ln_eps);
-      }
-      const float qr = q * rp;
-#pragma unroll
-      for (int u = 0; u < DR; ++u) {
-        const int dd = lane + 64 * u;
-        if (dd < DD) stT<T>(Apost, (t * a.g + dd / dgp) * a.KPp + e * dgp + (dd % dgp), qr * zv[u]);
-      }
-      if (lane < a.g) {
-        const long base = (t * a.g + lane) * a.KPp + a.E * dgp + 3 * e;
-        stT<T>(Apost, base + 0, qr); stT<T>(Apost, base + 1, -qr * mup); stT<T>(Apost, base + 2, q);
-      }
-      if (lane == 0) { rpmup[t * a.E + e] = rp; rpmup[(long)a.NT * a.E + t * a.E + e] = mup; }
-    }
-  }
-}
-int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
-  ProfScope ps_("k_post_small", 0.0, 0.0, st);
-  const Dims& d = pl.d;
-  PostArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.S = d.S; a.N = d.N; a.C = d.C; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.g = d.g; a.KPp = d.KPp; a.NT = d.NT;
-  a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
-  const size_t sh = (size_t)(d.g * d.dgp * d.dgp + 8 * d.DD) * sizeof(float);
-  dim3 grid; tok_grid(d, &grid);
-  DISPATCH_T(d.bf16, kk_post_small, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
-             (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
-  AVMOE_CHECK_LAUNCH("post_small");
   return OK;
 }
 

@@ -42,6 +42,12 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
               hipStream_t st);
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
                     const avmoe_moe_ptrs& grads, hipStream_t st);
+int k_post_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
+                              const avmoe_moe_ptrs& grads, hipStream_t st);
+int k_mid_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
+                       hipStream_t st);
+int k_pre_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
+                             const avmoe_moe_ptrs& grads, hipStream_t st);
 int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                  const float* lb_grad, hipStream_t st);
 int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, void* out_t, int grp,

@@ -1,0 +1,900 @@
+// Bottleneck-space kernels, tiled for CDNA4: one wavefront owns a tile of 16 tokens of one frame and every
+// per-token mat-vec (hop-2 softmax x K x K / K x d matrices, d x d quadratic forms, BN2-moment terms) is a
+// 16 x n x k product on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32), with the per-frame matrices staged
+// once per block in LDS.  Arithmetic and names: oracle/algebra_ref.py (PRE_SMALL, MID, POST_SMALL and their backward).
+//
+// Register layouts inside a wave (lane l, r = l & 15, q = l >> 4):
+//   "C layout"  the MFMA result: lane holds rows (tokens) 4q+e, e = 0..3, of column 16*ct + r
+//   A operand   read from a per-wave LDS tile  At[16][lda]:  At[r][4*kk + q]        (lda  = 2 mod 32: conflict-free)
+//   B operand   read from a per-block LDS matrix Bs[k][ldb]: Bs[4*kk + q][col0 + r] (ldb  = 16 mod 32: conflict-free)
+// Row reductions over columns = in-lane over column tiles, then xor-shuffles 1,2,4,8 inside the 16-lane group.
+// Column sums over tokens (BatchNorm etc.) = xor-shuffles 16,32, then a per-wave LDS accumulator, flushed per block
+// into colpart[blk][slot][col] (summed over blocks by kk_reduce_colpart: no float atomics, reproducible).
+#include "kernels.h"
+#include "device_utils.h"
+#include "prof.h"
+#include <algorithm>
+
+namespace avmoe {
+
+#define DISPATCH_T(bf16, KERN, grid, block, shmem, st, ...)                                   \
+  do {                                                                                        \
+    if (bf16) hipLaunchKernelGGL((KERN<__bf16>), grid, block, shmem, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERN<float>), grid, block, shmem, st, __VA_ARGS__);              \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename T> __device__ __forceinline__ float rndT(float v);
+template <> __device__ __forceinline__ float rndT<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rndT<__bf16>(float v) { return bf2f(f2bf(v)); }
+
+// sum over the 16 lanes that share q (all columns of a C-layout row)
+__device__ __forceinline__ float rsum16(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+// sum over the 4 lanes that share r (A-layout token spread over q, or the 4 row-quads of one column)
+__device__ __forceinline__ float qsum4(float v) {
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float qmax4(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// 16 x 16 tile of  At (16 x 4*k4) . Bs (4*k4 x ..)  at columns col0..col0+15
+__device__ __forceinline__ f32x4 tile_mm(const float* At, int lda, const float* Bs, int ldb, int k4, int col0, int r, int q) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* ap = At + r * lda + q;
+  const float* bp = Bs + q * ldb + col0 + r;
+  for (int kk = 0; kk < k4; ++kk) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[4 * kk * ldb], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+static inline int pad_lda(int k) { return (int)round_up(k, 32) + 2; }    // = 2 (mod 32)
+static inline int pad_ldb(int n) { return (int)round_up(n, 32) + 16; }   // = 16 (mod 32)
+static void tile_grid(const Dims& d, dim3* grid, int* per) {
+  const int bps = d.nblk_tok / d.S;
+  *per = (int)round_up(cdiv(d.N, bps), 16);
+  *grid = dim3((unsigned)bps, (unsigned)d.S);
+}
+static int set_lds(const void* fn, size_t bytes, const char* what) {
+  if (bytes <= 65536) return OK;
+  if (bytes > 160 * 1024) { set_last_error("%s needs %zu B of LDS (num_tk / bottleneck too large)", what, bytes); return ERR_UNSUPPORTED; }
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_last_error("%s: LDS attribute: %s", what, hipGetErrorString(e)); return ERR_LAUNCH; }
+  return OK;
+}
+
+struct TileDims {
+  int S, N, C, E, K, Kp, El, KL, KLT, KLp, DD, DZ, dgp, g, KPp, NT, per;
+  int k4;        // ceil(K / 4): contraction steps over the latent index
+  int lda_k;     // leading dim of per-wave K-wide tiles
+  int ldb_k;     // leading dim of LDS matrices with K columns
+  int lda_d;     // leading dim of per-wave DD-wide tiles
+  int ldb_d;     // leading dim of LDS matrices with DD columns
+  int ldb_g;     // leading dim of LDS matrices with dgp columns
+};
+static TileDims make_td(const Dims& d, int per) {
+  TileDims t;
+  t.S = d.S; t.N = d.N; t.C = d.C; t.E = d.E; t.K = d.K; t.Kp = d.Kp; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp;
+  t.DD = d.DD; t.DZ = d.DZ; t.dgp = d.dgp; t.g = d.g; t.KPp = d.KPp; t.NT = d.NT; t.per = per;
+  t.k4 = cdiv(d.K, 4);
+  t.lda_k = pad_lda(4 * t.k4); t.ldb_k = pad_ldb(4 * t.k4);
+  t.lda_d = pad_lda(d.DD); t.ldb_d = pad_ldb(d.DD); t.ldb_g = pad_ldb(d.dgp);
+  return t;
+}
+__device__ __forceinline__ int colmap(const TileDims& a, int e, int dd) {
+  return (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
+}
+// flush per-wave column accumulators (LDS, [waves][nslot][width]) of expert e into colpart
+__device__ __forceinline__ void flush_colacc(const TileDims& a, float* s_col, int nslot, int e, float* colpart, int blk, int slot0) {
+  const int nw = blockDim.x >> 6;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nslot * a.DD; i += blockDim.x) {
+    const int which = i / a.DD, dd = i % a.DD;
+    float v = 0.f;
+    for (int w = 0; w < nw; ++w) { float* p = s_col + (w * nslot + which) * a.DD + dd; v += *p; *p = 0.f; }
+    colpart[((long)blk * 4 + slot0 + which) * a.DZ + colmap(a, e, dd)] = v;
+  }
+  __syncthreads();
+}
+// block sum of per-wave scalars: every wave passes v[0..3] (valid in all lanes after wave_sum); out4[i] written for mask bits
+__device__ __forceinline__ void flush_scal4(float* s_sc, float v0, float v1, float v2, float v3, float* out4, unsigned mask) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) { s_sc[wave * 4 + 0] = v0; s_sc[wave * 4 + 1] = v1; s_sc[wave * 4 + 2] = v2; s_sc[wave * 4 + 3] = v3; }
+  __syncthreads();
+  if (threadIdx.x < 4 && ((mask >> threadIdx.x) & 1u)) {
+    float acc = 0.f;
+    for (int w = 0; w < nw; ++w) acc += s_sc[w * 4 + threadIdx.x];
+    out4[threadIdx.x] = acc;
+  }
+}
+
+// =====================================================================================================
+// PRE_SMALL forward   (net_trans_v3.py:385-395)
+// =====================================================================================================
+struct PreTArgs { P16 glat; int lat_of_e[MAX_E]; TileDims t; int ln_before; float ln_eps; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* Z, const float* L2, const float* sxs, const float* TT,
+                                                    const float* TW, const float* Tsum, const float* wsum, const float* dconst,
+                                                    void* aout_, float* rmu, float* colpart) {
+  T* aout = (T*)aout_;
+  const TileDims& t = a.t;
+  extern __shared__ float sm[];
+  const int K = t.K, DD = t.DD, K4 = 4 * t.k4;
+  float* s_TT = sm;                               // [K4][ldb_k]
+  float* s_TW = s_TT + K4 * t.ldb_k;              // [K4][ldb_d]
+  float* s_tb = s_TW + K4 * t.ldb_d;              // [K4]
+  float* s_a = s_tb + K4;                         // 4 waves x [16][lda_k]
+  float* s_rv = s_a + 4 * 16 * t.lda_k;           // 4 waves x [3][16]   A-layout -> C-layout scalars
+  float* s_col = s_rv + 4 * 48;                   // 4 waves x [2][DD]
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  float* At = s_a + wave * 16 * t.lda_k;
+  float* rv = s_rv + wave * 48;
+  float* mycol = s_col + wave * 2 * DD;
+  for (int i = threadIdx.x; i < 4 * 2 * DD; i += 256) s_col[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * 16 * t.lda_k; i += 256) s_a[i] = 0.f;      // columns >= 4*k4 stay zero
+
+  for (int e = 0; e < t.E; ++e) {
+    const int l = a.lat_of_e[e];
+    float gv = 0.f;
+    __syncthreads();
+    if (l >= 0) {
+      gv = a.glat.p[e][0];
+      const float* tt = TT + ((long)s * t.El + l) * K * K;
+      for (int i = threadIdx.x; i < K4 * t.ldb_k; i += 256) {
+        const int k = i / t.ldb_k, c = i % t.ldb_k;
+        s_TT[i] = (k < K && c < K) ? tt[k * K + c] : 0.f;
+      }
+      for (int i = threadIdx.x; i < K4 * t.ldb_d; i += 256) {
+        const int k = i / t.ldb_d, dd = i % t.ldb_d;
+        s_TW[i] = (k < K && dd < DD) ? TW[((long)s * t.KLT + (long)l * t.Kp + k) * t.DZ + colmap(t, e, dd)] : 0.f;
+      }
+      for (int i = threadIdx.x; i < K4; i += 256) s_tb[i] = i < K ? Tsum[(long)s * t.KLT + (long)l * t.Kp + i] / (float)t.C : 0.f;
+    }
+    __syncthreads();
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const long t0 = (long)s * t.N + n0;
+      float Sx[4], Sxx[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int n = n0 + 4 * q + x;
+        Sx[x] = n < t.N ? sxs[t0 + 4 * q + x] : 0.f;
+        Sxx[x] = n < t.N ? sxs[t.NT + t0 + 4 * q + x] : 1.f;
+      }
+      if (l >= 0) {
+        // ---- softmax of the hop-2 logits, token r spread over the 4 lanes q (k = 4*kk + q) ----
+        const bool rowok = (n0 + r) < t.N;
+        const float* l2 = L2 + (t0 + r) * t.KLp + (long)l * t.Kp;
+        float mx = -INFINITY;
+        for (int kk = 0; kk < t.k4; ++kk) { const int k = 4 * kk + q; if (rowok && k < K) mx = fmaxf(mx, l2[k]); }
+        mx = qmax4(mx);
+        float sum = 0.f;
+        for (int kk = 0; kk < t.k4; ++kk) { const int k = 4 * kk + q; if (rowok && k < K) sum += __expf(l2[k] - mx); }
+        sum = qsum4(sum);
+        const float inv = rowok ? 1.f / sum : 0.f;
+        float u1 = 0.f, u2 = 0.f;
+        wsync();
+        for (int kk = 0; kk < t.k4; ++kk) {
+          const int k = 4 * kk + q;
+          float av = 0.f;
+          if (rowok && k < K) {
+            const float lv = l2[k];
+            av = rndT<T>(__expf(lv - mx) * inv);
+            u1 += av * s_tb[k]; u2 += av * lv;
+          }
+          At[r * t.lda_k + k] = av;
+          if (rowok && k < t.Kp) stT<T>(aout, (t0 + r) * t.KLp + (long)l * t.Kp + k, av);
+        }
+        if (rowok) for (int k = K4 + q; k < t.Kp; k += 4) stT<T>(aout, (t0 + r) * t.KLp + (long)l * t.Kp + k, 0.f);
+        u1 = qsum4(u1); u2 = qsum4(u2);
+        if (q == 0) { rv[r] = u1; rv[16 + r] = u2; }
+        wsync();
+        // ---- u3 = a^T (T T^T) a  through the matrix pipe ----
+        float u3[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct * 16 < K; ++ct) {
+          const f32x4 w = tile_mm(At, t.lda_k, s_TT, t.ldb_k, t.k4, ct * 16, r, q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) u3[x] += w[x] * At[(4 * q + x) * t.lda_k + ct * 16 + r];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          u3[x] = rsum16(u3[x]);
+          Sx[x] += gv * (float)t.C * rv[4 * q + x];
+          Sxx[x] += 2.f * gv * rv[16 + 4 * q + x] + gv * gv * u3[x];
+        }
+      }
+      float mu[4], rr[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        mu[x] = 0.f; rr[x] = 1.f;
+        if (a.ln_before) {
+          mu[x] = Sx[x] / (float)t.C;
+          rr[x] = rsqrtf(fmaxf(Sxx[x] / (float)t.C - mu[x] * mu[x], 0.f) + a.ln_eps);
+        }
+      }
+      // ---- LN-folded down projection, column tile by column tile ----
+      for (int ct = 0; ct * 16 < DD; ++ct) {
+        const int dd = ct * 16 + r;
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        if (l >= 0) p = tile_mm(At, t.lda_k, s_TW, t.ldb_d, t.k4, ct * 16, r, q);
+        float c0 = 0.f, c1 = 0.f;
+        if (dd < DD) {
+          const int col = colmap(t, e, dd);
+          const float ws = wsum[col], dc = dconst[col];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            if (n0 + 4 * q + x < t.N) {
+              const long zi = (t0 + 4 * q + x) * t.DZ + col;
+              const float zr = Z[zi] + gv * p[x];
+              const float z = a.ln_before ? rr[x] * (zr - mu[x] * ws) + dc : zr;
+              Z[zi] = z;
+              c0 += z; c1 += z * z;
+            }
+          }
+        }
+        c0 = qsum4(c0); c1 = qsum4(c1);
+        if (q == 0 && dd < DD) { mycol[dd] += c0; mycol[DD + dd] += c1; }
+      }
+      if (r == 0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          if (n0 + 4 * q + x < t.N) { rmu[(t0 + 4 * q + x) * t.E + e] = rr[x]; rmu[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] = mu[x]; }
+      }
+    }
+    flush_colacc(t, s_col, 2, e, colpart, blk, 0);
+  }
+}
+
+int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_pre_small", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  dim3 grid; int per; tile_grid(d, &grid, &per);
+  PreTArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.t = make_td(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
+  const TileDims& t = a.t;
+  const int K4 = 4 * t.k4;
+  const size_t sh = (size_t)(K4 * t.ldb_k + K4 * t.ldb_d + K4 + 4 * 16 * t.lda_k + 4 * 48 + 4 * 2 * t.DD) * sizeof(float);
+  AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_pre_small<__bf16> : (const void*)kt_pre_small<float>, sh, "pre_small"));
+  DISPATCH_T(d.bf16, kt_pre_small, grid, dim3(256), sh, st, a, (float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2),
+             (const float*)(saved + pl.o_sx), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW),
+             (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst),
+             (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu), (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("pre_small");
+  return OK;
+}
+
+// =====================================================================================================
+// POST_SMALL forward  (net_trans_v3.py:430-434,485-486)
+// =====================================================================================================
+struct PostTArgs { P16 gate; int relu_of_e[MAX_E]; TileDims t; int ln_post, use_gate; float ln_eps; };
+
+// z' tile of expert e: C-layout values written to the per-wave LDS tile Zt[16][lda_d] (rows = tokens)
+__device__ __forceinline__ void load_zp_tile(const TileDims& t, int e, bool relu, const float* Z, const float* s_sc, const float* s_sh,
+                                             long t0, int n0, float* Zt, int r, int q) {
+  for (int ct = 0; ct * 16 < t.DD; ++ct) {
+    const int dd = ct * 16 + r;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      float y = 0.f;
+      if (dd < t.DD && n0 + 4 * q + x < t.N) {
+        y = Z[(t0 + 4 * q + x) * t.DZ + colmap(t, e, dd)] * s_sc[dd] + s_sh[dd];
+        if (relu) y = fmaxf(y, 0.f);
+      }
+      Zt[(4 * q + x) * t.lda_d + dd] = y;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* Z, const float* bn1, const float* Gq, const float* uvh,
+                                                     const float* probs, void* Apost_, float* rpmup) {
+  T* Apost = (T*)Apost_;
+  const TileDims& t = a.t;
+  extern __shared__ float sm[];
+  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4;
+  float* s_G = sm;                                // [g][4*g4][ldb_g]
+  float* s_us = s_G + t.g * 4 * g4 * t.ldb_g;     // DD
+  float* s_vh = s_us + DD;
+  float* s_sc = s_vh + DD;
+  float* s_sh = s_sc + DD;
+  float* s_z = s_sh + DD;                         // 4 waves x [16][lda_d]
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  float* Zt = s_z + wave * 16 * t.lda_d;
+  for (int e = 0; e < t.E; ++e) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < t.g * 4 * g4 * t.ldb_g; i += 256) {
+      const int gi = i / (4 * g4 * t.ldb_g), rem = i % (4 * g4 * t.ldb_g), k = rem / t.ldb_g, c = rem % t.ldb_g;
+      s_G[i] = (k < dgp && c < dgp) ? Gq[((long)(gi * t.E + e)) * dgp * dgp + k * dgp + c] : 0.f;
+    }
+    float H1 = 0.f, H2 = 0.f;
+    for (int gi = 0; gi < t.g; ++gi) { H1 += uvh[2 * t.DZ + gi * t.E + e]; H2 += uvh[2 * t.DZ + t.g * t.E + gi * t.E + e]; }
+    for (int dd = threadIdx.x; dd < DD; dd += 256) {
+      const int col = colmap(t, e, dd);
+      s_us[dd] = uvh[col]; s_vh[dd] = uvh[t.DZ + col]; s_sc[dd] = bn1[2 * t.DZ + col]; s_sh[dd] = bn1[3 * t.DZ + col];
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float qv = probs[(long)s * t.E + e] * gate;
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const long t0 = (long)s * t.N + n0;
+      wsync();
+      load_zp_tile(t, e, relu, Z, s_sc, s_sh, t0, n0, Zt, r, q);
+      wsync();
+      float rp[4] = {1.f, 1.f, 1.f, 1.f}, mup[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.ln_post) {
+        float so[4] = {0.f, 0.f, 0.f, 0.f}, soo[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int gi = 0; gi < t.g; ++gi)
+          for (int ct = 0; ct * 16 < dgp; ++ct) {
+            const f32x4 w = tile_mm(Zt + gi * dgp, t.lda_d, s_G + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
+            const int jp = ct * 16 + r, dd = gi * dgp + jp;
+            if (jp < dgp) {
+#pragma unroll
+              for (int x = 0; x < 4; ++x) {
+                const float zv = Zt[(4 * q + x) * t.lda_d + dd];
+                so[x] += zv * s_us[dd];
+                soo[x] += zv * (w[x] + 2.f * s_vh[dd]);
+              }
+            }
+          }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float So = rsum16(so[x]) + H1, Soo = rsum16(soo[x]) + H2;
+          mup[x] = So / (float)t.C;
+          rp[x] = rsqrtf(fmaxf(Soo / (float)t.C - mup[x] * mup[x], 0.f) + a.ln_eps);
+        }
+      }
+      for (int ct = 0; ct * 16 < DD; ++ct) {
+        const int dd = ct * 16 + r;
+        if (dd < DD) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            if (n0 + 4 * q + x < t.N)
+              stT<T>(Apost, ((t0 + 4 * q + x) * t.g + dd / dgp) * t.KPp + e * dgp + (dd % dgp), qv * rp[x] * Zt[(4 * q + x) * t.lda_d + dd]);
+        }
+      }
+      if (r < t.g) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          if (n0 + 4 * q + x < t.N) {
+            const long base = ((t0 + 4 * q + x) * t.g + r) * t.KPp + t.E * dgp + 3 * e;
+            stT<T>(Apost, base + 0, qv * rp[x]); stT<T>(Apost, base + 1, -qv * rp[x] * mup[x]); stT<T>(Apost, base + 2, qv);
+          }
+      }
+      if (r == 0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          if (n0 + 4 * q + x < t.N) { rpmup[(t0 + 4 * q + x) * t.E + e] = rp[x]; rpmup[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] = mup[x]; }
+      }
+    }
+  }
+}
+
+int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_post_small", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  dim3 grid; int per; tile_grid(d, &grid, &per);
+  PostTArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.t = make_td(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
+  const TileDims& t = a.t;
+  const int g4 = cdiv(t.dgp, 4);
+  const size_t sh = (size_t)(t.g * 4 * g4 * t.ldb_g + 4 * t.DD + 4 * 16 * t.lda_d) * sizeof(float);
+  AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_post_small<__bf16> : (const void*)kt_post_small<float>, sh, "post_small"));
+  DISPATCH_T(d.bf16, kt_post_small, grid, dim3(256), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
+             (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
+  AVMOE_CHECK_LAUNCH("post_small");
+  return OK;
+}
+
+}  // namespace avmoe
+
+namespace avmoe {
+
+// =====================================================================================================
+// POST_SMALL backward
+// =====================================================================================================
+struct PostBTArgs { P16 gate; int relu_of_e[MAX_E]; TileDims t; int ln_post, use_gate; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const float* Z, const float* bn1, const float* Gq,
+                                                         const float* uvh, const float* probs, const float* rpmup, const float* dAp,
+                                                         float* dzp, void* Zp_, void* Zw_, float* colpart, float* blkscal) {
+  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_;
+  const TileDims& t = a.t;
+  extern __shared__ float sm[];
+  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4, nw = blockDim.x >> 6;
+  float* s_G = sm;
+  float* s_us = s_G + t.g * 4 * g4 * t.ldb_g;
+  float* s_vh = s_us + DD;
+  float* s_sc = s_vh + DD;
+  float* s_sh = s_sc + DD;
+  float* s_z = s_sh + DD;                         // nw x [16][lda_d]
+  float* s_col = s_z + nw * 16 * t.lda_d;         // nw x [2][DD]
+  float* s_scal = s_col + nw * 2 * DD;            // nw x 4
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  float* Zt = s_z + wave * 16 * t.lda_d;
+  float* mycol = s_col + wave * 2 * DD;
+  for (int i = threadIdx.x; i < nw * 2 * DD; i += blockDim.x) s_col[i] = 0.f;
+  for (int e = 0; e < t.E; ++e) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < t.g * 4 * g4 * t.ldb_g; i += blockDim.x) {
+      const int gi = i / (4 * g4 * t.ldb_g), rem = i % (4 * g4 * t.ldb_g), k = rem / t.ldb_g, c = rem % t.ldb_g;
+      s_G[i] = (k < dgp && c < dgp) ? Gq[((long)(gi * t.E + e)) * dgp * dgp + k * dgp + c] : 0.f;
+    }
+    for (int dd = threadIdx.x; dd < DD; dd += blockDim.x) {
+      const int col = colmap(t, e, dd);
+      s_us[dd] = uvh[col]; s_vh[dd] = uvh[t.DZ + col]; s_sc[dd] = bn1[2 * t.DZ + col]; s_sh[dd] = bn1[3 * t.DZ + col];
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float qv = probs[(long)s * t.E + e] * gate;
+    float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 16 * nw) {
+      const long t0 = (long)s * t.N + n0;
+      wsync();
+      load_zp_tile(t, e, relu, Z, s_sc, s_sh, t0, n0, Zt, r, q);
+      wsync();
+      bool ok[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) ok[x] = n0 + 4 * q + x < t.N;
+      float zz[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct * 16 < DD; ++ct) {
+        const int dd = ct * 16 + r;
+        if (dd < DD) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            if (ok[x]) zz[x] += dAp[((t0 + 4 * q + x) * t.g + dd / dgp) * t.KPp + e * dgp + (dd % dgp)] * Zt[(4 * q + x) * t.lda_d + dd];
+        }
+      }
+      float rp[4], mup[4], dSo[4], dSoo[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        zz[x] = rsum16(zz[x]);
+        rp[x] = 1.f; mup[x] = 0.f; dSo[x] = 0.f; dSoo[x] = 0.f;
+        if (ok[x]) {
+          float da1 = 0.f, da2 = 0.f, da3 = 0.f;
+          for (int gi = 0; gi < t.g; ++gi) {
+            const float* p = dAp + ((t0 + 4 * q + x) * t.g + gi) * t.KPp + t.E * dgp + 3 * e;
+            da1 += p[0]; da2 += p[1]; da3 += p[2];
+          }
+          rp[x] = rpmup[(t0 + 4 * q + x) * t.E + e]; mup[x] = rpmup[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e];
+          const float dq = rp[x] * zz[x] + rp[x] * da1 - rp[x] * mup[x] * da2 + da3;
+          if (a.ln_post) {
+            const float drp = qv * zz[x] + qv * da1 - qv * mup[x] * da2;
+            float dmup = -qv * rp[x] * da2;
+            const float dvarp = drp * (-0.5f) * rp[x] * rp[x] * rp[x];
+            dSoo[x] = dvarp / (float)t.C;
+            dmup -= 2.f * mup[x] * dvarp;
+            dSo[x] = dmup / (float)t.C;
+          }
+          if (r == 0) { sdq += dq; sdSo += dSo[x]; sdSoo += dSoo[x]; }
+        }
+      }
+      for (int gi = 0; gi < t.g; ++gi)
+        for (int ct = 0; ct * 16 < dgp; ++ct) {
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if (a.ln_post) w = tile_mm(Zt + gi * dgp, t.lda_d, s_G + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
+          const int jp = ct * 16 + r, dd = gi * dgp + jp;
+          float c0 = 0.f, c1 = 0.f;
+          if (jp < dgp) {
+            const int col = colmap(t, e, dd);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              if (ok[x]) {
+                const float zv = Zt[(4 * q + x) * t.lda_d + dd];
+                const float dAz = dAp[((t0 + 4 * q + x) * t.g + gi) * t.KPp + e * dgp + jp];
+                float dz = qv * rp[x] * dAz;
+                if (a.ln_post) {
+                  dz += dSo[x] * s_us[dd] + dSoo[x] * (2.f * w[x] + 2.f * s_vh[dd]);
+                  c0 += dSo[x] * zv; c1 += dSoo[x] * zv;
+                }
+                const long zi = (t0 + 4 * q + x) * t.DZ + col;
+                dzp[zi] = dz;
+                stT<T>(Zp, zi, zv);
+                stT<T>(Zw, zi, dSoo[x] * zv);
+              }
+          }
+          c0 = qsum4(c0); c1 = qsum4(c1);
+          if (q == 0 && jp < dgp) { mycol[dd] += c0; mycol[DD + dd] += c1; }
+        }
+    }
+    flush_colacc(t, s_col, 2, e, colpart, blk, 0);
+    flush_scal4(s_scal, wave_sum(sdq), wave_sum(sdSo), wave_sum(sdSoo), 0.f, blkscal + ((long)blk * t.E + e) * 4, 0x7u);
+  }
+}
+
+// =====================================================================================================
+// MID backward
+// =====================================================================================================
+struct MidBTArgs { int relu_of_e[MAX_E]; TileDims t; int moments; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* Z, const float* bn1, const float* dsm, const float* sdSzz,
+                                                  float* dzp, float* colpart) {
+  const TileDims& t = a.t;
+  extern __shared__ float sm[];
+  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4, nw = blockDim.x >> 6;
+  float* s_S = sm;                                // [g][4*g4][ldb_g]
+  float* s_bn = s_S + t.g * 4 * g4 * t.ldb_g;     // [5][DD]: mean, rstd, sc, sh, dmz/NT
+  float* s_z = s_bn + 5 * DD;
+  float* s_col = s_z + nw * 16 * t.lda_d;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  float* Zt = s_z + wave * 16 * t.lda_d;
+  float* mycol = s_col + wave * 2 * DD;
+  for (int i = threadIdx.x; i < nw * 2 * DD; i += blockDim.x) s_col[i] = 0.f;
+  for (int e = 0; e < t.E; ++e) {
+    __syncthreads();
+    if (a.moments)
+      for (int i = threadIdx.x; i < t.g * 4 * g4 * t.ldb_g; i += blockDim.x) {
+        const int gi = i / (4 * g4 * t.ldb_g), rem = i % (4 * g4 * t.ldb_g), k = rem / t.ldb_g, c = rem % t.ldb_g;
+        s_S[i] = (k < dgp && c < dgp) ? sdSzz[((long)(gi * t.E + e)) * dgp * dgp + k * dgp + c] : 0.f;
+      }
+    for (int dd = threadIdx.x; dd < DD; dd += blockDim.x) {
+      const int col = colmap(t, e, dd);
+      s_bn[dd] = bn1[col]; s_bn[DD + dd] = bn1[t.DZ + col]; s_bn[2 * DD + dd] = bn1[2 * t.DZ + col];
+      s_bn[3 * DD + dd] = bn1[3 * t.DZ + col]; s_bn[4 * DD + dd] = a.moments ? dsm[2 * t.DZ + col] : 0.f;
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 16 * nw) {
+      const long t0 = (long)s * t.N + n0;
+      wsync();
+      load_zp_tile(t, e, relu, Z, s_bn + 2 * DD, s_bn + 3 * DD, t0, n0, Zt, r, q);
+      wsync();
+      for (int gi = 0; gi < t.g; ++gi)
+        for (int ct = 0; ct * 16 < dgp; ++ct) {
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if (a.moments) w = tile_mm(Zt + gi * dgp, t.lda_d, s_S + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
+          const int jp = ct * 16 + r, dd = gi * dgp + jp;
+          float c0 = 0.f, c1 = 0.f;
+          if (jp < dgp) {
+            const int col = colmap(t, e, dd);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              if (n0 + 4 * q + x < t.N) {
+                const long zi = (t0 + 4 * q + x) * t.DZ + col;
+                const float z = Z[zi];
+                const float zh = (z - s_bn[dd]) * s_bn[DD + dd];
+                const float y = z * s_bn[2 * DD + dd] + s_bn[3 * DD + dd];
+                const float dz = dzp[zi] + s_bn[4 * DD + dd] + w[x];
+                const float dy = (relu && y <= 0.f) ? 0.f : dz;
+                dzp[zi] = dy;
+                c0 += dy; c1 += dy * zh;
+              }
+          }
+          c0 = qsum4(c0); c1 = qsum4(c1);
+          if (q == 0 && jp < dgp) { mycol[dd] += c0; mycol[DD + dd] += c1; }
+        }
+    }
+    flush_colacc(t, s_col, 2, e, colpart, blk, 2);
+  }
+}
+
+// =====================================================================================================
+// PRE_SMALL backward
+// =====================================================================================================
+struct PreBTArgs { P16 glat; int lat_of_e[MAX_E]; TileDims t; int ln_before, use_bn, bn_train, dd4; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float* Z, const float* L2, const float* TT, const float* TW,
+                                                        const float* Tsum, const float* wsum, const float* dconst, const void* ain_,
+                                                        const float* rmu, const float* bn1, const float* dsm, const float* dy_in,
+                                                        void* dZx_, void* dL2x_, void* aw_, void* ag_, float* dsxs, float* rs2x,
+                                                        float* colpart, float* blkscal, float* dtbp) {
+  const T* ain = (const T*)ain_;
+  T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
+  const TileDims& t = a.t;
+  extern __shared__ float sm[];
+  const int K = t.K, DD = t.DD, K4 = 4 * t.k4, D4 = 4 * a.dd4, nw = blockDim.x >> 6;
+  float* s_TT = sm;                               // [K4][ldb_k]
+  float* s_TW = s_TT + K4 * t.ldb_k;              // [K4][ldb_d]   B of a . TW       (contraction k)
+  float* s_TWt = s_TW + K4 * t.ldb_d;             // [D4][ldb_k]   B of dzraw . TW^T (contraction dd)
+  float* s_tb = s_TWt + D4 * t.ldb_k;             // [K4]
+  float* s_bn = s_tb + K4;                        // [7][DD]: mean, rstd, sc, mdy, mdyz, wsum, dconst
+  float* s_a = s_bn + 7 * DD;                     // nw x [16][lda_k]   a tile
+  float* s_da = s_a + nw * 16 * t.lda_k;          // nw x [16][lda_k]   da tile
+  float* s_dz = s_da + nw * 16 * t.lda_k;         // nw x [16][lda_d]   dzraw tile
+  float* s_rv = s_dz + nw * 16 * t.lda_d;         // nw x 32
+  float* s_col = s_rv + nw * 32;                  // nw x [2][DD]
+  float* s_kcol = s_col + nw * 2 * DD;            // nw x [K4]
+  float* s_scal = s_kcol + nw * K4;               // nw x 4
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  float* At = s_a + wave * 16 * t.lda_k;
+  float* Da = s_da + wave * 16 * t.lda_k;
+  float* Dt = s_dz + wave * 16 * t.lda_d;
+  float* rv = s_rv + wave * 32;
+  float* mycol = s_col + wave * 2 * DD;
+  float* mykcol = s_kcol + wave * K4;
+  for (int i = threadIdx.x; i < nw * 2 * DD; i += blockDim.x) s_col[i] = 0.f;
+  for (int i = threadIdx.x; i < nw * K4; i += blockDim.x) s_kcol[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * nw * 16 * t.lda_k; i += blockDim.x) s_a[i] = 0.f;       // a and da tiles
+  for (int i = threadIdx.x; i < nw * 16 * t.lda_d; i += blockDim.x) s_dz[i] = 0.f;
+
+  for (int e = 0; e < t.E; ++e) {
+    const int l = a.lat_of_e[e];
+    float gv = 0.f;
+    __syncthreads();
+    if (l >= 0) {
+      gv = a.glat.p[e][0];
+      const float* tt = TT + ((long)s * t.El + l) * K * K;
+      for (int i = threadIdx.x; i < K4 * t.ldb_k; i += blockDim.x) {
+        const int k = i / t.ldb_k, c = i % t.ldb_k;
+        s_TT[i] = (k < K && c < K) ? tt[k * K + c] : 0.f;
+      }
+      for (int i = threadIdx.x; i < K4 * t.ldb_d; i += blockDim.x) {
+        const int k = i / t.ldb_d, dd = i % t.ldb_d;
+        s_TW[i] = (k < K && dd < DD) ? TW[((long)s * t.KLT + (long)l * t.Kp + k) * t.DZ + colmap(t, e, dd)] : 0.f;
+      }
+      for (int i = threadIdx.x; i < D4 * t.ldb_k; i += blockDim.x) {
+        const int dd = i / t.ldb_k, k = i % t.ldb_k;
+        s_TWt[i] = (k < K && dd < DD) ? TW[((long)s * t.KLT + (long)l * t.Kp + k) * t.DZ + colmap(t, e, dd)] : 0.f;
+      }
+      for (int i = threadIdx.x; i < K4; i += blockDim.x) s_tb[i] = i < K ? Tsum[(long)s * t.KLT + (long)l * t.Kp + i] / (float)t.C : 0.f;
+    }
+    for (int dd = threadIdx.x; dd < DD; dd += blockDim.x) {
+      const int col = colmap(t, e, dd);
+      s_bn[dd] = bn1[col]; s_bn[DD + dd] = bn1[t.DZ + col]; s_bn[2 * DD + dd] = bn1[2 * t.DZ + col];
+      s_bn[3 * DD + dd] = a.bn_train ? dsm[3 * t.DZ + col] : 0.f; s_bn[4 * DD + dd] = a.bn_train ? dsm[4 * t.DZ + col] : 0.f;
+      s_bn[5 * DD + dd] = wsum[col]; s_bn[6 * DD + dd] = dconst[col];
+    }
+    __syncthreads();
+    float sdg = 0.f;
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 16 * nw) {
+      const long t0 = (long)s * t.N + n0;
+      bool ok[4];
+      float rr[4], mu[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        ok[x] = n0 + 4 * q + x < t.N;
+        rr[x] = (a.ln_before && ok[x]) ? rmu[(t0 + 4 * q + x) * t.E + e] : 1.f;
+        mu[x] = (a.ln_before && ok[x]) ? rmu[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] : 0.f;
+      }
+      // ---- BN1 input gradient, folded-LayerNorm sums, dzraw tile ----
+      float s_dr[4] = {0.f, 0.f, 0.f, 0.f}, s_dmu[4] = {0.f, 0.f, 0.f, 0.f};
+      wsync();
+      for (int ct = 0; ct * 16 < DD; ++ct) {
+        const int dd = ct * 16 + r;
+        float c0 = 0.f, c1 = 0.f;
+        if (dd < DD) {
+          const int col = colmap(t, e, dd);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            float dzr = 0.f;
+            if (ok[x]) {
+              const long zi = (t0 + 4 * q + x) * t.DZ + col;
+              const float z = Z[zi];
+              float dz = dy_in[zi];
+              if (a.use_bn) {
+                if (a.bn_train) dz = s_bn[2 * DD + dd] * (dz - s_bn[3 * DD + dd] - (z - s_bn[dd]) * s_bn[DD + dd] * s_bn[4 * DD + dd]);
+                else dz = s_bn[2 * DD + dd] * dz;
+              }
+              if (a.ln_before) {
+                const float zc = (z - s_bn[6 * DD + dd]) / rr[x];
+                c0 += dz; c1 += -rr[x] * mu[x] * dz;
+                s_dr[x] += dz * zc; s_dmu[x] += dz * s_bn[5 * DD + dd];
+                dzr = rr[x] * dz;
+              } else dzr = dz;
+              stT<T>(dZx, zi, dzr);
+            }
+            Dt[(4 * q + x) * t.lda_d + dd] = dzr;
+          }
+        }
+        c0 = qsum4(c0); c1 = qsum4(c1);
+        if (q == 0 && dd < DD) { mycol[dd] += c0; mycol[DD + dd] += c1; }
+      }
+      float dSx[4], dSxx[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        dSx[x] = 0.f; dSxx[x] = 0.f;
+        if (a.ln_before) {
+          const float sdr = rsum16(s_dr[x]), sdm = rsum16(s_dmu[x]);
+          float dmu = -rr[x] * sdm;
+          const float dvar = sdr * (-0.5f) * rr[x] * rr[x] * rr[x];
+          dSxx[x] = dvar / (float)t.C;
+          dmu -= 2.f * mu[x] * dvar;
+          dSx[x] = dmu / (float)t.C;
+        }
+        if (r == 0 && ok[x]) {
+          const long ti = t0 + 4 * q + x;
+          if (e == 0) { dsxs[ti] = dSx[x]; dsxs[t.NT + ti] = dSxx[x]; }
+          else { dsxs[ti] += dSx[x]; dsxs[t.NT + ti] += dSxx[x]; }
+        }
+      }
+      if (l >= 0) {
+        // ---- a tile (A operand + C layout source), u1, u2 ----
+        const bool rowok = (n0 + r) < t.N;
+        const long arow = (t0 + r) * t.KLp + (long)l * t.Kp;
+        float u1 = 0.f, u2 = 0.f;
+        for (int kk = 0; kk < t.k4; ++kk) {
+          const int k = 4 * kk + q;
+          float av = 0.f;
+          if (rowok && k < K) { av = ldT<T>(ain, arow + k); u1 += av * s_tb[k]; u2 += av * L2[arow + k]; }
+          At[r * t.lda_k + k] = av;
+        }
+        u1 = qsum4(u1); u2 = qsum4(u2);
+        if (q == 0) { rv[r] = u1; rv[16 + r] = u2; }
+        wsync();
+        float u3[4] = {0.f, 0.f, 0.f, 0.f}, dgr[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct * 16 < DD; ++ct) {                       // dzraw . (a TW)
+          const f32x4 p = tile_mm(At, t.lda_k, s_TW, t.ldb_d, t.k4, ct * 16, r, q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) dgr[x] += p[x] * Dt[(4 * q + x) * t.lda_d + ct * 16 + r];
+        }
+        float du1[4], du2[4], du3[4], sada[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { du1[x] = dSx[x] * gv * (float)t.C; du2[x] = 2.f * gv * dSxx[x]; du3[x] = gv * gv * dSxx[x]; }
+        for (int ct = 0; ct * 16 < K; ++ct) {                        // da tile
+          const f32x4 ta = tile_mm(At, t.lda_k, s_TT, t.ldb_k, t.k4, ct * 16, r, q);
+          const f32x4 twd = tile_mm(Dt, t.lda_d, s_TWt, t.ldb_k, a.dd4, ct * 16, r, q);
+          const int k = ct * 16 + r;
+          float ck = 0.f;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float ac = At[(4 * q + x) * t.lda_k + k];
+            u3[x] += ta[x] * ac;
+            float da = 0.f;
+            if (k < K && ok[x]) {
+              da = gv * twd[x] + du1[x] * s_tb[k] + du2[x] * L2[(t0 + 4 * q + x) * t.KLp + (long)l * t.Kp + k] + 2.f * du3[x] * ta[x];
+              sada[x] += ac * da;
+              ck += du1[x] * ac;
+            }
+            Da[(4 * q + x) * t.lda_k + k] = da;
+          }
+          ck = qsum4(ck);
+          if (q == 0 && k < K) mykcol[k] += ck;
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          sada[x] = rsum16(sada[x]);
+          u3[x] = rsum16(u3[x]); dgr[x] = rsum16(dgr[x]);
+          if (r == 0 && ok[x]) sdg += dSx[x] * (float)t.C * rv[4 * q + x] + dSxx[x] * (2.f * rv[16 + 4 * q + x] + 2.f * gv * u3[x]) + dgr[x];
+        }
+        wsync();
+        for (int ct = 0; ct * 16 < t.Kp; ++ct) {
+          const int k = ct * 16 + r;
+          if (k < t.Kp) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              if (ok[x]) {
+                const long o = (t0 + 4 * q + x) * t.KLp + (long)l * t.Kp + k;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+                if (k < K) {
+                  const float ac = At[(4 * q + x) * t.lda_k + k], da = Da[(4 * q + x) * t.lda_k + k];
+                  v0 = du2[x] * ac + ac * (da - sada[x]); v1 = du3[x] * ac; v2 = gv * ac;
+                }
+                stT<T>(dL2x, o, v0); stT<T>(aw_o, o, v1); stT<T>(ag_o, o, v2);
+              }
+          }
+        }
+      }
+      if (e == t.E - 1 && r == 0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          if (ok[x]) {
+            const long ti = t0 + 4 * q + x;
+            stT<T>(dL2x, ti * t.KLp + t.KL, dsxs[ti]);
+            stT<T>(dL2x, ti * t.KLp + t.KL + 1, 1.f);
+            rs2x[ti] = 2.f * dsxs[t.NT + ti];
+          }
+      }
+    }
+    flush_colacc(t, s_col, 2, e, colpart, blk, 0);
+    flush_scal4(s_scal, 0.f, 0.f, 0.f, wave_sum(sdg), blkscal + ((long)blk * t.E + e) * 4, 0x8u);
+    if (l >= 0) {
+      __syncthreads();
+      for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) { v += s_kcol[w * K4 + k]; s_kcol[w * K4 + k] = 0.f; }
+        dtbp[(long)blk * t.KL + (long)l * t.Kp + k] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace avmoe
+
+namespace avmoe {
+
+// waves per block: as many (4, 2, 1) as the LDS budget allows
+static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes) {
+  for (int nw = 4; nw >= 1; nw >>= 1) {
+    *bytes = (fixed_floats + nw * per_wave_floats) * sizeof(float);
+    if (*bytes <= 160 * 1024) return nw;
+  }
+  return 0;
+}
+
+int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  ProfScope ps_("k_post_small_bwd", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  dim3 grid; int per; tile_grid(d, &grid, &per);
+  PostBTArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.t = make_td(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  const TileDims& t = a.t;
+  const int g4 = cdiv(t.dgp, 4);
+  size_t sh;
+  const int nw = pick_waves((size_t)t.g * 4 * g4 * t.ldb_g + 4 * t.DD, (size_t)16 * t.lda_d + 2 * t.DD + 4, &sh);
+  if (!nw) { set_last_error("post_small_bwd: LDS budget"); return ERR_UNSUPPORTED; }
+  AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_post_small_bwd<__bf16> : (const void*)kt_post_small_bwd<float>, sh, "post_small_bwd"));
+  DISPATCH_T(d.bf16, kt_post_small_bwd, grid, dim3(64 * nw), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
+             (const float*)(saved + pl.o_rpmup), (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp),
+             (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
+  AVMOE_CHECK_LAUNCH("post_small_bwd");
+  return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+}
+
+int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  ProfScope ps_("k_mid_bwd", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  dim3 grid; int per; tile_grid(d, &grid, &per);
+  MidBTArgs a;
+  for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
+  a.t = make_td(d, per); a.moments = d.use_bn && d.training;
+  const TileDims& t = a.t;
+  const int g4 = cdiv(t.dgp, 4);
+  size_t sh;
+  const int nw = pick_waves((size_t)t.g * 4 * g4 * t.ldb_g + 5 * t.DD, (size_t)16 * t.lda_d + 2 * t.DD, &sh);
+  if (!nw) { set_last_error("mid_bwd: LDS budget"); return ERR_UNSUPPORTED; }
+  AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_mid_bwd<__bf16> : (const void*)kt_mid_bwd<float>, sh, "mid_bwd"));
+  DISPATCH_T(d.bf16, kt_mid_bwd, grid, dim3(64 * nw), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+             (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (float*)(scratch + pl.o_dzp),
+             (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("mid_bwd");
+  return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
+}
+
+int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  ProfScope ps_("k_pre_small_bwd", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  dim3 grid; int per; tile_grid(d, &grid, &per);
+  PreBTArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.t = make_td(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training; a.dd4 = cdiv(d.DD, 4);
+  const TileDims& t = a.t;
+  const int K4 = 4 * t.k4, D4 = 4 * a.dd4;
+  size_t sh;
+  const int nw = pick_waves((size_t)K4 * t.ldb_k + (size_t)K4 * t.ldb_d + (size_t)D4 * t.ldb_k + K4 + 7 * t.DD,
+                            (size_t)2 * 16 * t.lda_k + 16 * t.lda_d + 32 + 2 * t.DD + K4 + 4, &sh);
+  if (!nw) { set_last_error("pre_small_bwd: K=%d, bottleneck %d exceed the LDS budget", d.K, d.DD); return ERR_UNSUPPORTED; }
+  AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_pre_small_bwd<__bf16> : (const void*)kt_pre_small_bwd<float>, sh, "pre_small_bwd"));
+  DISPATCH_T(d.bf16, kt_pre_small_bwd, grid, dim3(64 * nw), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2),
+             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
+             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a),
+             (const float*)(saved + pl.o_rmu), (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm),
+             (const float*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw),
+             (void*)(scratch + pl.o_ag), (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x),
+             (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
+  AVMOE_CHECK_LAUNCH("pre_small_bwd");
+  return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+}
+
+}  // namespace avmoe
