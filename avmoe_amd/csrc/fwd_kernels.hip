@@ -41,32 +41,38 @@ int k_fill_f32(float* p, long n, float v, hipStream_t st) {
   return OK;
 }
 
-// Sum the per-block column partials colpart[nblk][4][DZ] over blocks: grid (ceil(DZ/64), nslots), 1024 threads;
-// wave w adds the blocks b = w (mod 16) for its 64 columns (coalesced 256-B rows, independent loads), then the
-// 16 waves are combined in double through LDS.  out[slot][col].
-__global__ void __launch_bounds__(1024) kk_reduce_colpart(const float* colpart, int nblk, int DZ, float* out) {
+// Deterministic column sums  out[slot][c] = scale * sum_r in[slot*slot_in + r*row_stride + c]:
+// grid (ceil(ncol/64), nslot), 1024 threads; wave w adds the rows r = w (mod 16) of its 64 columns (coalesced,
+// independent loads), then the 16 waves are combined in double through LDS.  No float atomics anywhere.
+__global__ void __launch_bounds__(1024) kk_colsum_f32(const float* in, long R, int ncol, long row_stride, long slot_in, float* out,
+                                                      long slot_out, float scale) {
   __shared__ double red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane, slot = blockIdx.y;
+  const int col = blockIdx.x * 64 + lane;
+  const float* p = in + (long)blockIdx.y * slot_in;
   float acc = 0.f;
-  if (col < DZ)
-    for (int b = wave; b < nblk; b += 16) acc += colpart[((long)b * 4 + slot) * DZ + col];
+  if (col < ncol)
+    for (long r = wave; r < R; r += 16) acc += p[r * row_stride + col];
   red[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0 && col < DZ) {
+  if (wave == 0 && col < ncol) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += red[w][lane];
-    out[(long)slot * DZ + col] = (float)s;
+    out[(long)blockIdx.y * slot_out + col] = (float)(s * scale);
   }
+}
+int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out, float scale,
+                 hipStream_t st) {
+  if (ncol <= 0 || nslot <= 0) return OK;
+  hipLaunchKernelGGL(kk_colsum_f32, dim3(cdiv(ncol, 64), nslot), dim3(1024), 0, st, in, R, ncol, row_stride, slot_in, out, slot_out, scale);
+  AVMOE_CHECK_LAUNCH("colsum_f32");
+  return OK;
 }
 int k_reduce_colpart(const Plan& pl, char* scratch, int slot0, int nslots, hipStream_t st) {
   const Dims& d = pl.d;
-  hipLaunchKernelGGL(kk_reduce_colpart, dim3(cdiv(d.DZ, 64), nslots), dim3(1024), 0, st,
-                     (const float*)(scratch + pl.o_colpart) + (long)slot0 * d.DZ, d.nblk_tok, d.DZ,
-                     (float*)(scratch + pl.o_colsum) + (long)slot0 * d.DZ);
-  AVMOE_CHECK_LAUNCH("reduce_colpart");
-  return OK;
+  return k_colsum_f32((const float*)(scratch + pl.o_colpart) + (long)slot0 * d.DZ, d.nblk_tok, d.DZ, 4L * d.DZ, nslots, d.DZ,
+                      (float*)(scratch + pl.o_colsum) + (long)slot0 * d.DZ, d.DZ, 1.f, st);
 }
 
 template <typename T>
@@ -111,11 +117,9 @@ __global__ void kk_prep_remap(const float* Wc, const float* bc, const float* Wf,
   }
 }
 
-// rw[c] = sum_y WfT[c][y] (T-rounded weights, so the folded bias matches the GEMM operands);
-// wbar[m] = mean_n Wc[n][m]; scal[0] = mean(bc)
+// rw[c] = sum_y WfT[c][y] (T-rounded weights, so the folded bias matches the GEMM operands); one wave per row
 template <typename T>
-__global__ void kk_prep_remap2(const void* WfT_, const float* Wc, const float* bc, float* rw, float* wbar, float* scal,
-                               int N, int M, int Mb, int C, int Cy) {
+__global__ void kk_prep_remap2(const void* WfT_, float* rw, int C, int Cy) {
   const T* WfT = (const T*)WfT_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
@@ -123,17 +127,6 @@ __global__ void kk_prep_remap2(const void* WfT_, const float* Wc, const float* b
     for (int y = lane; y < Cy; y += 64) s += ldT<T>(WfT, (long)c * Cy + y);
     s = wave_sum(s);
     if (lane == 0) rw[c] = s;
-  }
-  for (int m = blockIdx.x * 256 + threadIdx.x; m < Mb; m += gridDim.x * 256) {
-    float s = 0.f;
-    if (m < M) for (int n = 0; n < N; ++n) s += Wc[(long)n * M + m];
-    wbar[m] = m < M ? s / (float)N : 0.f;
-  }
-  if (blockIdx.x == 0 && wave == 0) {
-    float s = 0.f;
-    for (int n = lane; n < N; n += 64) s += bc[n];
-    s = wave_sum(s);
-    if (lane == 0) scal[0] = s / (float)N;
   }
 }
 
@@ -144,8 +137,13 @@ int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, 
   const long tot = (long)d.N * d.Mk + (long)(d.M + 1) * d.Np + (long)d.C * d.Cy;
   DISPATCH_T(d.bf16, kk_prep_remap, dim3(grid1d(tot)), dim3(256), 0, st, Wc, bc, Wf, (void*)(saved + pl.o_WcK),
              (void*)(saved + pl.o_WcT), (void*)(saved + pl.o_WfT), d.N, d.M, d.Mk, d.Np, d.C, d.Cy);
-  DISPATCH_T(d.bf16, kk_prep_remap2, dim3(64), dim3(256), 0, st, (const void*)(saved + pl.o_WfT), Wc, bc,
-             (float*)(saved + pl.o_rw), (float*)(saved + pl.o_wbar), (float*)(saved + pl.o_scal), d.N, d.M, d.Mb, d.C, d.Cy);
+  DISPATCH_T(d.bf16, kk_prep_remap2, dim3(cdiv(d.C, 4)), dim3(256), 0, st, (const void*)(saved + pl.o_WfT), (float*)(saved + pl.o_rw), d.C, d.Cy);
+  {   // wbar[m] = mean_n Wc[n][m] (padding zero) ; scal[0] = mean(bc)
+    hipError_t e__ = hipMemsetAsync(saved + pl.o_wbar, 0, (size_t)d.Mb * 4, st);
+    if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; }
+    AVMOE_TRY(k_colsum_f32(Wc, d.N, d.M, d.M, 1, 0, (float*)(saved + pl.o_wbar), 0, 1.f / (float)d.N, st));
+    AVMOE_TRY(k_colsum_f32(bc, d.N, 1, 1, 1, 0, (float*)(saved + pl.o_scal), 0, 1.f / (float)d.N, st));
+  }
   AVMOE_CHECK_LAUNCH("prep_remap");
   return OK;
 }
@@ -599,123 +597,6 @@ int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   return OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// POST_PREP (weight space): BN2 statistics of o = Wu z' from the d-space moments, folded output
-// weights Bpost, and the d-space Gram / sums the LayerNorm-post statistics need.
-// net_trans_v3.py:401-403,430-434
-// ---------------------------------------------------------------------------------------------
-struct PostPrepArgs {
-  P16 up, w2, b2, lpw, lpb; W16 rm, rv;
-  int E, g, dg, dgp, Cg, C, KPp, NT, use_bn, training, ln_post;
-  float eps, momentum;
-};
-// thread per (e, c): mo, rs2, k2, h2
-__global__ void kk_bn2_stats(PostPrepArgs a, const float* mz, const float* Szz, float* bn2) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.E * a.C) return;
-  const int e = idx / a.C, c = idx % a.C, i = c / a.Cg;
-  float mo = 0.f, rs2 = 1.f, k2 = 1.f, h2 = 0.f;
-  if (a.use_bn) {
-    float v2;
-    if (a.training) {
-      const float* wu = a.up.p[e] + (long)c * a.dg;
-      const int cb = i * a.E + e;
-      const float* m = mz + (long)cb * a.dgp;
-      const float* S = Szz + (long)cb * a.dgp * a.dgp;
-      double dmo = 0.0, eo2 = 0.0;
-      for (int j = 0; j < a.dg; ++j) {
-        dmo += (double)wu[j] * m[j];
-        double row = 0.0;
-        for (int l = 0; l < a.dg; ++l) row += (double)S[j * a.dgp + l] * wu[l];
-        eo2 += (double)wu[j] * row;
-      }
-      mo = (float)dmo;
-      const double v = fmax(eo2 - dmo * dmo, 0.0);
-      v2 = (float)v;
-      const double unb = a.NT > 1 ? v * ((double)a.NT / (a.NT - 1)) : v;
-      a.rm.p[e][c] = (1.f - a.momentum) * a.rm.p[e][c] + a.momentum * mo;
-      a.rv.p[e][c] = (1.f - a.momentum) * a.rv.p[e][c] + a.momentum * (float)unb;
-    } else { mo = a.rm.p[e][c]; v2 = a.rv.p[e][c]; }
-    rs2 = rsqrtf(v2 + a.eps);
-    k2 = a.w2.p[e][c] * rs2;
-    h2 = a.b2.p[e][c] - mo * k2;
-  }
-  const long EC = (long)a.E * a.C;
-  bn2[idx] = mo; bn2[EC + idx] = rs2; bn2[2 * EC + idx] = k2; bn2[3 * EC + idx] = h2;
-}
-// thread per (c, k'): Bpost[c][k']
-template <typename T>
-__global__ void kk_build_bpost(PostPrepArgs a, const float* bn2, void* Bpost_) {
-  T* Bpost = (T*)Bpost_;
-  const long total = (long)a.C * a.KPp;
-  const long EC = (long)a.E * a.C;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx / a.KPp), kp = (int)(idx % a.KPp);
-    float v = 0.f;
-    if (kp < a.E * a.dgp) {
-      const int e = kp / a.dgp, jp = kp % a.dgp;
-      if (jp < a.dg) {
-        const float gp = a.ln_post ? a.lpw.p[e][c] : 1.f;
-        v = gp * a.up.p[e][(long)c * a.dg + jp] * bn2[2 * EC + (long)e * a.C + c];
-      }
-    } else if (kp < a.E * a.dgp + 3 * a.E) {
-      const int r = kp - a.E * a.dgp, e = r / 3, w = r % 3;
-      const float gp = a.ln_post ? a.lpw.p[e][c] : 1.f;
-      const float bp = a.ln_post ? a.lpb.p[e][c] : 0.f;
-      const float h2 = bn2[3 * EC + (long)e * a.C + c];
-      v = w == 0 ? gp * h2 : (w == 1 ? gp : bp);
-    }
-    stT<T>(Bpost, idx, v);
-  }
-}
-// block per (i, e): G = Wh^T Wh, usum, vh, H1, H2 partial (per group)
-__global__ void __launch_bounds__(256) kk_gq(PostPrepArgs a, const float* bn2, float* Gq, float* uvh) {
-  const int cb = blockIdx.x, i = cb / a.E, e = cb % a.E;
-  const long EC = (long)a.E * a.C;
-  const float* k2 = bn2 + 2 * EC + (long)e * a.C + (long)i * a.Cg;
-  const float* h2 = bn2 + 3 * EC + (long)e * a.C + (long)i * a.Cg;
-  const float* wu = a.up.p[e] + (long)i * a.Cg * a.dg;
-  const int DZ = a.g * a.E * a.dgp;
-  for (int pr = threadIdx.x; pr < a.dgp * a.dgp; pr += 256) {
-    const int j = pr / a.dgp, l = pr % a.dgp;
-    float acc = 0.f;
-    if (j < a.dg && l < a.dg)
-      for (int c = 0; c < a.Cg; ++c) { const float k = k2[c]; acc += (wu[(long)c * a.dg + j] * k) * (wu[(long)c * a.dg + l] * k); }
-    Gq[(long)cb * a.dgp * a.dgp + pr] = acc;
-  }
-  for (int j = threadIdx.x; j < a.dgp; j += 256) {
-    float us = 0.f, vh = 0.f;
-    if (j < a.dg) for (int c = 0; c < a.Cg; ++c) { const float wh = wu[(long)c * a.dg + j] * k2[c]; us += wh; vh += wh * h2[c]; }
-    uvh[(long)cb * a.dgp + j] = us;
-    uvh[DZ + (long)cb * a.dgp + j] = vh;
-  }
-  if (threadIdx.x == 0) {
-    float H1 = 0.f, H2 = 0.f;
-    for (int c = 0; c < a.Cg; ++c) { H1 += h2[c]; H2 += h2[c] * h2[c]; }
-    uvh[2 * DZ + cb] = H1;                       // [i][e] partials; consumers add the groups
-    uvh[2 * DZ + a.g * a.E + cb] = H2;
-  }
-}
-static void fill_postprep(const Dims& d, const avmoe_moe_ptrs& prm, PostPrepArgs* a) {
-  for (int e = 0; e < MAX_E; ++e) {
-    a->up.p[e] = prm.e[e].up_w; a->w2.p[e] = prm.e[e].bn2_w; a->b2.p[e] = prm.e[e].bn2_b;
-    a->lpw.p[e] = prm.e[e].lnp_w; a->lpb.p[e] = prm.e[e].lnp_b; a->rm.p[e] = prm.e[e].bn2_rm; a->rv.p[e] = prm.e[e].bn2_rv;
-  }
-  a->E = d.E; a->g = d.g; a->dg = d.dg; a->dgp = d.dgp; a->Cg = d.Cg; a->C = d.C; a->KPp = d.KPp; a->NT = d.NT;
-  a->use_bn = d.use_bn; a->training = d.training; a->ln_post = d.ln_post; a->eps = d.bn_eps; a->momentum = d.bn_momentum;
-}
-int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
-  ProfScope ps_("k_post_prep", 0.0, 0.0, st);
-  const Dims& d = pl.d;
-  PostPrepArgs a; fill_postprep(d, prm, &a);
-  hipLaunchKernelGGL(kk_bn2_stats, dim3(cdiv((long)d.E * d.C, 256)), dim3(256), 0, st, a, (const float*)(saved + pl.o_mz),
-                     (const float*)(saved + pl.o_Szz), (float*)(saved + pl.o_bn2));
-  DISPATCH_T(d.bf16, kk_build_bpost, dim3(grid1d((long)d.C * d.KPp)), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2),
-             (void*)(saved + pl.o_Bpost));
-  hipLaunchKernelGGL(kk_gq, dim3(d.g * d.E), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2), (float*)(saved + pl.o_Gq),
-                     (float*)(saved + pl.o_uvh));
-  AVMOE_CHECK_LAUNCH("post_prep");
-  return OK;
-}
+// (POST_PREP lives in weight_kernels.hip)
 
 }  // namespace avmoe

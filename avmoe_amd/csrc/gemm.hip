@@ -20,7 +20,7 @@
 #include "common.h"
 #include "prof.h"
 #include <algorithm>
-#include <typeinfo>
+#include <cstdlib>
 
 namespace avmoe {
 
@@ -431,12 +431,19 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];
   if (!name[0]) snprintf(name, sizeof(name), "%s_%s_%d", names[AMN][BMN], sizeof(T) == 2 ? "bf16" : "f32", BM);
+  static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
+  const char* pname = name;
+  if (shapes && prof_enabled()) {            // debug only: one family per distinct call shape (leaks the small strings)
+    char* nm = (char*)malloc(96);
+    snprintf(nm, 96, "%s M%d N%d K%d b%d ks%d", name, d.M, d.N, d.K, d.nbatch, d.ksplit);
+    pname = nm;
+  }
   const double nb = (double)d.nbatch;
   const double esz = sizeof(T), osz = d.ksplit > 1 ? 4.0 : (d.out_bf16 ? 2.0 : 4.0);
   // algorithmic bytes: every operand element once (broadcast operands counted once), C written once (+ read if accumulating)
   const double abytes = ((d.sA1 == 0 && d.sA2 == 0 ? 1.0 : nb) * d.M * (double)d.K + (d.sB1 == 0 && d.sB2 == 0 ? 1.0 : nb) * d.N * (double)d.K) * esz +
                         nb * d.M * (double)d.N * osz * (d.accumulate ? 2.0 : 1.0) + (d.D ? nb * d.M * (double)d.N * esz : 0.0);
-  ProfScope ps(name, abytes, 2.0 * nb * d.M * (double)d.N * d.K, stream);
+  ProfScope ps(pname, abytes, 2.0 * nb * d.M * (double)d.N * d.K, stream);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, d);
   AVMOE_CHECK_LAUNCH("gemm_kernel");
   return OK;

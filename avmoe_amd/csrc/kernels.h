@@ -60,6 +60,8 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
 int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st);
 
 // generic helpers
+int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out,
+                 float scale, hipStream_t st);
 int k_reduce_colpart(const Plan& pl, char* scratch, int slot0, int nslots, hipStream_t st);   // colpart -> colsum
 int k_fill_f32(float* p, long n, float v, hipStream_t st);
 int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, void* dst, long ld_dst, hipStream_t st);

@@ -95,6 +95,7 @@ struct Dims {
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
   X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
   X(colsum, 1, 4, (size_t)4 * d.DZ)                 /* colpart summed over blocks     */       \
+  X(gpart, 1, 4, (size_t)8 * d.g * d.E * (d.dgp * d.dgp + 2 * d.dgp + 2))  /* Gram partials */ \
   X(rowpart, 1, 4, (size_t)512 * (d.C > d.Cy ? d.C : d.Cy) * 2)  /* chunked row reductions */   \
   X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \
   /* ---- backward only ---- */                                                                \

@@ -9,7 +9,7 @@
 namespace avmoe {
 
 namespace {
-struct Rec { const char* name; double bytes, flops; hipEvent_t e0, e1; };
+struct Rec { std::string name; double bytes, flops; hipEvent_t e0, e1; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
