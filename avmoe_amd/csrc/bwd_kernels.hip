@@ -3,6 +3,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include "prof.h"
+#include "gemm.h"
 #include <algorithm>
 
 namespace avmoe {
@@ -167,10 +168,9 @@ __global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const fl
                                                        int KL, int C, int N) {
   __shared__ float s_dl[MAX_E], s_d2[32], s_d1[128], s_pm[MAX_E];
   const int s = blockIdx.x;
-  float* dlog = rbw + (long)s * a.E;
-  float* dh2 = rbw + (long)a.S * a.E + (long)s * 32;
-  float* dh1 = rbw + (long)a.S * (a.E + 32) + (long)s * 128;
-  float* drin = rbw + (long)a.S * (a.E + 32 + 128) + (long)s * a.C2;
+  float* dh1 = rbw + (long)s * 128;
+  float* dh2 = rbw + (long)a.S * (128 + a.C2) + (long)s * 32;
+  float* dlog = rbw + (long)a.S * (128 + a.C2 + 32) + (long)s * a.E;
   if (threadIdx.x < a.E) {                       // column means of p for the LB loss
     float acc = 0.f;
     for (int ss = 0; ss < a.S; ++ss) acc += probs[(long)ss * a.E + threadIdx.x];
@@ -201,12 +201,15 @@ __global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const fl
     s_d1[threadIdx.x] = v; dh1[threadIdx.x] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.C2; i += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < 128; ++j) acc += s_d1[j] * a.W1[(long)j * a.C2 + i];
-    drin[i] = acc;
-    if (bf16) ((unsigned short*)drinT_)[(long)s * a.C2 + i] = f2bf(acc); else ((float*)drinT_)[(long)s * a.C2 + i] = acc;
-    if (i < C) {                                   // dm1 / N  into the extra row of Text[s]
+}
+// drin (engine GEMM output) -> T copy for the GEMMs that consume dm2, and dm1 / N into the extra row of Text[s]
+__global__ void kk_router_bwd_c(const float* drin, void* drinT_, int bf16, void* Text_, int S, int C2, int KLT, int KL, int C, int N) {
+  const long total = (long)S * C2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int s = (int)(idx / C2), i = (int)(idx % C2);
+    const float acc = drin[idx];
+    if (bf16) ((unsigned short*)drinT_)[idx] = f2bf(acc); else ((float*)drinT_)[idx] = acc;
+    if (i < C) {
       const long o = ((long)s * KLT + KL + 1) * C + i;
       const float v = acc / (float)N;
       if (bf16) ((unsigned short*)Text_)[o] = f2bf(v); else ((float*)Text_)[o] = v;
@@ -216,16 +219,14 @@ __global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const fl
 // weight gradients: thread per weight element, loop over frames
 __global__ void kk_router_bwd_b(int S, int E, int C2, const float* rbw, const float* rin, const float* rh1, const float* rh2,
                                 float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
-  const float* dlog = rbw;
-  const float* dh2 = rbw + (long)S * E;
-  const float* dh1 = rbw + (long)S * (E + 32);
+  const float* dh1 = rbw;
+  const float* dh2 = rbw + (long)S * (128 + C2);
+  const float* dlog = rbw + (long)S * (128 + C2 + 32);
   const long n1 = 128L * C2, n2 = 32 * 128, n3 = (long)E * 32, nb = 128 + 32 + E;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + nb; i += (long)gridDim.x * 256) {
+  for (long i = n1 + (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + nb; i += (long)gridDim.x * 256) {
     float acc = 0.f;
     if (i < n1) {
-      const int j = (int)(i / C2), c = (int)(i % C2);
-      for (int s = 0; s < S; ++s) acc += dh1[(long)s * 128 + j] * rin[(long)s * C2 + c];
-      if (gW1) gW1[i] = acc;
+      continue;                                    // dW1 = dh1^T rin is an engine GEMM (k_router_bwd)
     } else if (i < n1 + n2) {
       const long k = i - n1; const int j = (int)(k / 128), c = (int)(k % 128);
       for (int s = 0; s < S; ++s) acc += dh2[(long)s * 32 + j] * rh1[(long)s * 128 + c];
@@ -251,8 +252,27 @@ int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
                      (const float*)(scratch + pl.o_dp), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
                      (float*)(scratch + pl.o_rbw), (void*)(scratch + pl.o_drinT), d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL,
                      d.C, d.N);
+  float* rbw = (float*)(scratch + pl.o_rbw);
+  float* dh1 = rbw;
+  float* drin = rbw + (long)d.S * 128;
+  {   // drin = dh1 W1   (fp32 engine GEMM)
+    GemmArgs g;
+    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
+    g.A = dh1; g.B = prm.r0_w; g.C = drin;
+    g.M = d.S; g.N = 2 * d.C; g.K = 128; g.lda = 128; g.b_layout = MN_MAJOR; g.ldb = 2L * d.C; g.sCi = 2L * d.C;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  hipLaunchKernelGGL(kk_router_bwd_c, dim3(grid1db((long)d.S * 2 * d.C)), dim3(256), 0, st, (const float*)drin, (void*)(scratch + pl.o_drinT),
+                     d.bf16, (void*)(saved + pl.o_Text), d.S, 2 * d.C, d.KLT, d.KL, d.C, d.N);
+  if (grads.r0_w) {   // dW1 = dh1^T rin
+    GemmArgs g;
+    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
+    g.A = dh1; g.B = saved + pl.o_rin; g.C = grads.r0_w;
+    g.M = 128; g.N = 2 * d.C; g.K = d.S; g.a_layout = g.b_layout = MN_MAJOR; g.lda = 128; g.ldb = 2L * d.C; g.sCi = 2L * d.C;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
   const long tot = 128L * 2 * d.C + 32 * 128 + (long)d.E * 32 + 160 + d.E;
-  hipLaunchKernelGGL(kk_router_bwd_b, dim3(grid1db(tot)), dim3(256), 0, st, d.S, d.E, 2 * d.C, (const float*)(scratch + pl.o_rbw),
+  hipLaunchKernelGGL(kk_router_bwd_b, dim3(grid1db(32 * 128 + (long)d.E * 32 + 160 + d.E)), dim3(256), 0, st, d.S, d.E, 2 * d.C, (const float*)(scratch + pl.o_rbw),
                      (const float*)(saved + pl.o_rin), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
                      grads.r0_w, grads.r0_b, grads.r2_w, grads.r2_b, grads.r4_w, grads.r4_b);
   AVMOE_CHECK_LAUNCH("router_bwd");
@@ -457,7 +477,7 @@ __global__ void kk_down_bwd(DownBwdArgs a, const float* dWt, const float* dsm) {
 // ---- host wrappers for the glue ---------------------------------------------------------------
 int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   const Dims& d = pl.d;
-  const float* drin = (const float*)(scratch + pl.o_rbw) + (long)d.S * (d.E + 32 + 128);
+  const float* drin = (const float*)(scratch + pl.o_rbw) + (long)d.S * 128;
   const long rows = (long)d.S * (d.Kcyb + d.Kcx);
   DISPATCH_T(d.bf16, kk_finish_dT, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st,
              (const float*)(scratch + pl.o_dT), (const float*)(scratch + pl.o_dtbar), drin, (const float*)(saved + pl.o_rw),

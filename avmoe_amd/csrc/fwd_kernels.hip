@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include "prof.h"
+#include "gemm.h"
 #include <algorithm>
 
 namespace avmoe {
@@ -254,6 +255,71 @@ int k_rowstats(int bf16, const void* X, long rows, int C, float* out, hipStream_
   return OK;
 }
 
+// One pass over X: per-token sum / sum of squares (LayerNorm) AND per-block column partial sums (router mean).
+// grid (nchunk, S); wave per row, lanes own 16-byte column vectors.  xpart[s][chunk][C].
+template <typename T>
+__global__ void __launch_bounds__(256) kk_xstats(const void* X_, int N, int C, int rows_per_blk, float* sx, long NT, float* xpart) {
+  const T* X = (const T*)X_;
+  constexpr int EPV = 16 / sizeof(T);
+  constexpr int NV = 6;                                 // C <= 64 * NV * EPV
+  __shared__ float s_col[4][64 * NV * 8 > 3072 ? 3072 : 64 * NV * 8];
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = blockIdx.x * rows_per_blk, n1 = min(N, n0 + rows_per_blk);
+  const int nvec = C / EPV;
+  float cacc[NV][EPV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) cacc[v][e] = 0.f;
+  for (int n = n0 + wave; n < n1; n += 4) {
+    const long row = (long)s * N + n;
+    const uint4* p = (const uint4*)(X + row * C);
+    float rs = 0.f, rss = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int iv = lane + 64 * v;
+      if (iv < nvec) {
+        const uint4 w = p[iv];
+        const unsigned int ww[4] = {w.x, w.y, w.z, w.w};
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float x = __uint_as_float(ww[e]); rs += x; rss += x * x; cacc[v][e] += x; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = bf2f((unsigned short)(ww[e] & 0xFFFFu)), x1 = bf2f((unsigned short)(ww[e] >> 16));
+            rs += x0 + x1; rss += x0 * x0 + x1 * x1; cacc[v][2 * e] += x0; cacc[v][2 * e + 1] += x1;
+          }
+        }
+      }
+    }
+    rs = wave_sum(rs); rss = wave_sum(rss);
+    if (lane == 0) { sx[row] = rs; sx[NT + row] = rss; }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int iv = lane + 64 * v;
+    if (iv < nvec)
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) s_col[wave][iv * EPV + e] = cacc[v][e];
+  }
+  __syncthreads();
+  float* out = xpart + ((long)s * gridDim.x + blockIdx.x) * C;
+  for (int c = threadIdx.x; c < C; c += 256) out[c] = s_col[0][c] + s_col[1][c] + s_col[2][c] + s_col[3][c];
+}
+int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st) {
+  ProfScope ps_("k_xstats", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  const int epv = 16 / d.esz;
+  if (d.C > 64 * 6 * epv || d.C > 3072) { set_last_error("xstats: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
+  const int nchunk = d.xchunks, rpb = cdiv(d.N, nchunk);
+  DISPATCH_T(d.bf16, kk_xstats, dim3(nchunk, d.S), dim3(256), 0, st, X, d.N, d.C, rpb, (float*)(saved + pl.o_sx), (long)d.NT,
+             (float*)(scratch + pl.o_xpart));
+  AVMOE_CHECK_LAUNCH("xstats");
+  return k_colsum_f32((const float*)(scratch + pl.o_xpart), nchunk, d.C, d.C, d.S, (long)nchunk * d.C, (float*)(saved + pl.o_rin),
+                      2L * d.C, 1.f / (float)d.N, st);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) kk_colmean(const void* X_, int N, int C, float* out, long out_ld) {
   const T* X = (const T*)X_;
@@ -423,37 +489,29 @@ struct RouterArgs {
   const float *W1, *b1, *W2, *b2, *W3, *b3, *noise;
   int C2, E, S;
 };
-__global__ void __launch_bounds__(256) kk_router(RouterArgs a, const float* rin, float* rh1, float* rh2, float* probs,
-                                                 float* probs_out, int64_t* idx_out) {
-  extern __shared__ float sm[];
-  float* s_in = sm;                 // C2
-  float* s_h1 = sm + a.C2;          // 128
-  float* s_h2 = s_h1 + 128;         // 32
-  float* s_lg = s_h2 + 32;          // E
-  const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < a.C2; i += 256) s_in[i] = rin[(long)s * a.C2 + i];
+__global__ void __launch_bounds__(128) kk_router_tail(RouterArgs a, float* rh1, float* rh2, float* probs, float* probs_out,
+                                                      int64_t* idx_out) {
+  __shared__ float s_h1[128], s_h2[32], s_lg[MAX_E];
+  const int s = blockIdx.x, t = threadIdx.x;
+  {   // rh1 holds rin . W1^T (engine GEMM); add bias, ReLU, keep the activation for the backward
+    const float h = fmaxf(rh1[(long)s * 128 + t] + a.b1[t], 0.f);
+    s_h1[t] = h; rh1[(long)s * 128 + t] = h;
+  }
   __syncthreads();
-  for (int j = wave; j < 128; j += 4) {
+  if (t < 32) {
     float acc = 0.f;
-    for (int i = lane; i < a.C2; i += 64) acc += a.W1[(long)j * a.C2 + i] * s_in[i];
-    acc = wave_sum(acc);
-    if (lane == 0) { const float h = fmaxf(acc + a.b1[j], 0.f); s_h1[j] = h; rh1[(long)s * 128 + j] = h; }
+    for (int i = 0; i < 128; ++i) acc += a.W2[t * 128 + i] * s_h1[i];
+    const float h = fmaxf(acc + a.b2[t], 0.f);
+    s_h2[t] = h; rh2[(long)s * 32 + t] = h;
   }
   __syncthreads();
-  for (int j = wave; j < 32; j += 4) {
+  if (t < a.E) {
     float acc = 0.f;
-    for (int i = lane; i < 128; i += 64) acc += a.W2[j * 128 + i] * s_h1[i];
-    acc = wave_sum(acc);
-    if (lane == 0) { const float h = fmaxf(acc + a.b2[j], 0.f); s_h2[j] = h; rh2[(long)s * 32 + j] = h; }
+    for (int i = 0; i < 32; ++i) acc += a.W3[t * 32 + i] * s_h2[i];
+    s_lg[t] = acc + a.b3[t] + (a.noise ? a.noise[(long)s * a.E + t] : 0.f);
   }
   __syncthreads();
-  for (int j = wave; j < a.E; j += 4) {
-    float acc = lane < 32 ? a.W3[j * 32 + lane] * s_h2[lane] : 0.f;
-    acc = wave_sum(acc);
-    if (lane == 0) s_lg[j] = acc + a.b3[j] + (a.noise ? a.noise[(long)s * a.E + j] : 0.f);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  if (t == 0) {
     float mx = s_lg[0];
     for (int e = 1; e < a.E; ++e) mx = fmaxf(mx, s_lg[e]);
     float sum = 0.f;
@@ -488,9 +546,15 @@ int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float
     set_last_error("moe: router parameters missing"); return ERR_BAD_ARG;
   }
   RouterArgs a{prm.r0_w, prm.r0_b, prm.r2_w, prm.r2_b, prm.r4_w, prm.r4_b, noise, 2 * d.C, d.E, d.S};
-  const size_t sh = (size_t)(2 * d.C + 128 + 32 + d.E) * sizeof(float);
-  hipLaunchKernelGGL(kk_router, dim3(d.S), dim3(256), sh, st, a, (const float*)(saved + pl.o_rin),
-                     (float*)(saved + pl.o_rh1), (float*)(saved + pl.o_rh2), (float*)(saved + pl.o_probs), probs_out, idx_out);
+  {   // layer 1 on the matrix pipe in exact fp32 whatever the activation dtype (bit-stable argmax): rh1 = rin W1^T
+    GemmArgs g;
+    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
+    g.A = saved + pl.o_rin; g.B = prm.r0_w; g.C = saved + pl.o_rh1;
+    g.M = d.S; g.N = 128; g.K = 2 * d.C; g.lda = 2L * d.C; g.ldb = 2L * d.C; g.sCi = 128;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  hipLaunchKernelGGL(kk_router_tail, dim3(d.S), dim3(128), 0, st, a, (float*)(saved + pl.o_rh1), (float*)(saved + pl.o_rh2),
+                     (float*)(saved + pl.o_probs), probs_out, idx_out);
   AVMOE_CHECK_LAUNCH("router");
   if (lb_out) {
     if (d.lb_loss) hipLaunchKernelGGL(kk_lb_loss, dim3(1), dim3(256), 0, st, (const float*)(saved + pl.o_probs), d.S, d.E, lb_out);

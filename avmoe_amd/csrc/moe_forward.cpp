@@ -29,8 +29,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   AVMOE_TRY(k_prep_remap(pl, sv, prm.conv_w, prm.conv_b, prm.fc_w, st));
   AVMOE_TRY(k_prep_experts(pl, sv, prm, st));
   // ---- token statistics of X: row sums (LayerNorm), column means (router) ---------------------
-  AVMOE_TRY(k_rowstats(d.bf16, X, d.NT, d.C, (float*)(sv + pl.o_sx), st));
-  AVMOE_TRY(k_colmean(d.bf16, X, d.S, d.N, d.C, (float*)(sv + pl.o_rin), 2L * d.C, st));
+  AVMOE_TRY(k_xstats(pl, X, sv, sc, st));
 
   // ---- hop 1, cross-modal experts: latent tokens read the (never materialised) remapped Y -----
   if (d.Kcy > 0) {

@@ -93,6 +93,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
   int bps = std::max(1, std::min(cdiv(d.N, 64), cdiv(2048, d.S)));
   d.nblk_tok = bps * d.S;
+  d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 
   size_t off[2] = {0, 0};
   int n = 0;

@@ -41,6 +41,7 @@ struct Dims {
   int src_of_lat[MAX_E]; // 0 = Y (cross-modal), 1 = X (v2)
   int relu_of_e[MAX_E];
   int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
+  int xchunks;    // row chunks per frame of the fused X statistics pass
 };
 
 // name, region (0 saved / 1 scratch), element bytes expr (4 or d.esz), element count expr
@@ -95,6 +96,7 @@ struct Dims {
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
   X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
   X(colsum, 1, 4, (size_t)4 * d.DZ)                 /* colpart summed over blocks     */       \
+  X(xpart, 1, 4, (size_t)d.S * d.xchunks * d.C)     /* column partials of X           */       \
   X(gpart, 1, 4, (size_t)8 * d.g * d.E * (d.dgp * d.dgp + 2 * d.dgp + 2))  /* Gram partials */ \
   X(rowpart, 1, 4, (size_t)512 * (d.C > d.Cy ? d.C : d.Cy) * 2)  /* chunked row reductions */   \
   X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \
