@@ -121,7 +121,7 @@ int k_mid_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_m
 // ---------------------------------------------------------------------------------------------
 // PRE_SMALL backward: BN1 input gradient, folded-LayerNorm statistics, hop-2 softmax.
 // ---------------------------------------------------------------------------------------------
-struct PreFinArgs { W16 gglat; int lat_of_e[MAX_E]; int S, E, DZ, KL, nblk, bps; };
+struct PreFinArgs { W16 gglat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int S, E, DZ, KL, nblk, bps; };
 __global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const float* colpart, const float* blkscal,
                                                            const float* dtbp, float* dsm, float* dtbar) {
   for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {   // block-summed (k_reduce_colpart)
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const f
   if (blockIdx.x == 0) {
     __shared__ float red[4];
     for (int e = 0; e < a.E; ++e) {
-      if (a.lat_of_e[e] < 0) continue;
+      if (a.lat_of_e[e] < 0 && !a.nxn_of_e[e]) continue;
       float acc = 0.f;
       for (int b = threadIdx.x; b < a.nblk; b += 256) acc += blkscal[((long)b * a.E + e) * 4 + 3];
       acc = block_sum256(acc, red);
@@ -148,7 +148,7 @@ int k_pre_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const a
                              hipStream_t st) {
   const Dims& d = pl.d;
   PreFinArgs f;
-  for (int e = 0; e < MAX_E; ++e) { f.gglat.p[e] = grads.e[e].gate_lat; f.lat_of_e[e] = d.lat_of_e[e]; }
+  for (int e = 0; e < MAX_E; ++e) { f.gglat.p[e] = grads.e[e].gate_lat; f.lat_of_e[e] = d.lat_of_e[e]; f.nxn_of_e[e] = d.nxn_of_e[e]; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.KL = d.KL; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S;
   AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
   hipLaunchKernelGGL(kk_pre_bwd_finalize, dim3(std::max(1, cdiv(std::max((long)d.DZ, (long)d.S * d.KL), 256))), dim3(256), 0, st, f,
@@ -472,6 +472,54 @@ __global__ void kk_down_bwd(DownBwdArgs a, const float* dWt, const float* dsm) {
       if (a.glnbb.p[e]) a.glnbb.p[e][gi * a.Cg + c] = dbb;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// AVVP N x N block helpers
+// ---------------------------------------------------------------------------------------------
+// per token: sum xr, sum xr^2, x . xr    (one wave per row)
+template <typename T>
+__global__ void __launch_bounds__(256) kk_xrstats(const void* X_, const void* R_, long rows, int C, float* out) {
+  const T* X = (const T*)X_; const T* R = (const T*)R_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float x = ldT<T>(X, row * C + c), v = ldT<T>(R, row * C + c);
+      s0 += v; s1 += v * v; s2 += x * v;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { out[row] = s0; out[rows + row] = s1; out[2 * rows + row] = s2; }
+  }
+}
+int k_xrstats(const Plan& pl, const void* X, char* saved, hipStream_t st) {
+  ProfScope ps_("k_xrstats", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  DISPATCH_T(d.bf16, kk_xrstats, dim3((unsigned)std::min<long>((d.NT + 3) / 4, 8192)), dim3(256), 0, st, X, (const void*)(saved + pl.o_xr),
+             (long)d.NT, d.C, (float*)(saved + pl.o_sxr));
+  AVMOE_CHECK_LAUNCH("xrstats");
+  return OK;
+}
+// dxr[t][c] += dsr2[t] * X[t][c] + dsr0[t] ;  dX[t][c] += dsr2[t] * xr[t][c]
+template <typename T>
+__global__ void kk_nxn_axpy(const void* X_, const void* R_, const float* dsr, long NT, int C, void* dxr_, void* dX_) {
+  const T* X = (const T*)X_; const T* R = (const T*)R_;
+  T* dxr = (T*)dxr_; T* dX = (T*)dX_;
+  const long total = NT * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long t = i / C;
+    const float d0 = dsr[t], d2 = dsr[2 * NT + t];
+    stT<T>(dxr, i, ldT<T>(dxr, i) + d2 * ldT<T>(X, i) + d0);
+    stT<T>(dX, i, ldT<T>(dX, i) + d2 * ldT<T>(R, i));
+  }
+}
+int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, hipStream_t st) {
+  ProfScope ps_("k_nxn_axpy", 0.0, 0.0, st);
+  const Dims& d = pl.d;
+  DISPATCH_T(d.bf16, kk_nxn_axpy, dim3(grid1db((long)d.NT * d.C, 16384)), dim3(256), 0, st, X, (const void*)(saved + pl.o_xr),
+             (const float*)(scratch + pl.o_dsr), (long)d.NT, d.C, (void*)(scratch + pl.o_dxr), dX);
+  AVMOE_CHECK_LAUNCH("nxn_axpy");
+  return OK;
 }
 
 // ---- host wrappers for the glue ---------------------------------------------------------------

@@ -60,6 +60,8 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
                     hipStream_t st);
 int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st);
 
+int k_xrstats(const Plan& pl, const void* X, char* saved, hipStream_t st);
+int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, hipStream_t st);
 // generic helpers
 int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out,
                  float scale, hipStream_t st);

@@ -55,6 +55,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_router_bwd(pl, sv, sc, prm, grads, lb_grad, st));
   // ---- phase 4: folded LayerNorm / hop-2 softmax ---------------------------------------------------
   MEMSET0(sc + pl.o_dtbp, (size_t)d.nblk_tok * (d.KL ? d.KL : 1) * 4);
+  if (d.nxn) MEMSET0(sc + pl.o_dZR, (size_t)d.NT * d.DZ * esz);
   AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));
   const char* dZx = sc + pl.o_Zw;
 
@@ -73,6 +74,41 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.M = d.N; g.N = d.C; g.K = d.KLT; g.lda = d.KLp; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S;
     g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.KLT * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
     AVMOE_TRY(run(g, false));
+  }
+  if (d.nxn) {   // ---- AVVP N x N block: back through ZR = xr Wt^T, the three row sums and xr = att^T X --------------------
+    {                                                      // dxr = dZR Wt + (2 g^2 dSxx) xr
+      GemmArgs g = base();
+      g.A = sc + pl.o_dZR; g.B = sv + pl.o_Wt; g.C = sc + pl.o_dxr;
+      g.M = d.NT; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb2 = d.g;
+      g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.C; g.sC2 = d.Cg; g.out_dtype = dt;
+      g.row_scale = (const float*)(sc + pl.o_dsr) + d.NT; g.D = sv + pl.o_xr; g.sDi = d.C; g.sD2 = d.Cg;
+      AVMOE_TRY(run(g, false));
+    }
+    AVMOE_TRY(k_nxn_axpy(pl, X, sv, sc, dX, st));            // dxr += dsr2 X + dsr0 ; dX += dsr2 xr
+    {                                                      // d att[s] = X[s] dxr[s]^T
+      GemmArgs g = base();
+      g.A = X; g.B = sc + pl.o_dxr; g.C = sc + pl.o_attS;
+      g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.sA1 = g.sB1 = (long)d.N * d.C;
+      g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
+      AVMOE_TRY(run(g, false));
+    }
+    {                                                      // dX[s] += att[s] dxr[s]
+      GemmArgs g = base();
+      g.A = sv + pl.o_att; g.B = sc + pl.o_dxr; g.C = dX;
+      g.M = d.N; g.N = d.C; g.K = d.N; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S;
+      g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
+    AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_att, (const float*)(sc + pl.o_attS), (long)d.S * d.N, d.N, d.Np, sc + pl.o_dSc,
+                                 nullptr, 1, 1, st));
+    for (int tr = 0; tr < 2; ++tr) {                       // dX[s] += dSc[s] X[s]  and  dSc[s]^T X[s]
+      GemmArgs g = base();
+      g.A = sc + pl.o_dSc; g.B = X; g.C = dX;
+      g.M = d.N; g.N = d.C; g.K = d.N; g.a_layout = tr ? MN_MAJOR : K_MAJOR; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C;
+      g.nb1 = d.S; g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
+      g.accumulate = 1;
+      AVMOE_TRY(run(g, false));
+    }
   }
   MEMSET0(sc + pl.o_dTW, (size_t)d.S * d.KLT * d.DZ * esz);
   for (int l = 0; l < d.El; ++l) {                         // dTW[s][slot l] = gate * a^T dzraw  (own expert's columns)
@@ -94,6 +130,11 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     if (d.El > 0) {
       GemmArgs h = g;
       h.A = sc + pl.o_dTW; h.B = sv + pl.o_Text; h.K = d.S * d.KLT; h.accumulate = 1; h.ksplit = 1;
+      AVMOE_TRY(run(h, true));
+    }
+    if (d.nxn) {                                           // + dZR^T xr
+      GemmArgs h = g;
+      h.A = sc + pl.o_dZR; h.B = sv + pl.o_xr; h.accumulate = 1; h.ksplit = 1;
       AVMOE_TRY(run(h, true));
     }
   }

@@ -133,6 +133,27 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     g.sA1 = (long)d.N * d.C; g.sB1 = (long)d.KLT * d.C; g.sCi = d.KLp; g.sC1 = (long)d.N * d.KLp;
     AVMOE_TRY(launch_gemm(g, st));
   }
+  // ---- AVVP unimodal N x N block (mgn.py:132-139): xr = softmax_rows(X X^T)^T X, shared by the unimodal experts;
+  //      their input x + gate_av * xr enters the LN-folded projection through ZR = xr Wt^T and three row sums ----
+  if (d.nxn) {
+    {                                                      // scores[s] = X[s] X[s]^T
+      GemmArgs g = base();
+      g.A = X; g.B = X; g.C = sc + pl.o_attS;
+      g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.sA1 = g.sB1 = (long)d.N * d.C;
+      g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_attS), (long)d.S * d.N, d.N, d.Np, sv + pl.o_att, d.Np, 1, 1, 1, 1, st));
+    {                                                      // xr[s] = att[s]^T X[s]
+      GemmArgs g = base();
+      g.A = sv + pl.o_att; g.B = X; g.C = sv + pl.o_xr;
+      g.M = d.N; g.N = d.C; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.C; g.nb1 = d.S;
+      g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+    AVMOE_TRY(k_xrstats(pl, X, sv, st));
+    AVMOE_TRY(down_gemm(sv + pl.o_xr, d.NT, sv + pl.o_ZR));
+  }
   // ---- bottleneck space --------------------------------------------------------------------------
   AVMOE_TRY(k_pre_small(pl, sv, sc, prm, st));
   AVMOE_TRY(k_bn1_finalize(pl, sv, sc, prm, st));

@@ -44,10 +44,6 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
     set_last_error("moe: C/groups (%d) and Cy (%d) must be multiples of 8 (16-byte rows)", d.C / d.g, d.Cy);
     return ERR_UNSUPPORTED;
   }
-  if (d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN) {
-    set_last_error("moe: the AVVP N x N unimodal attention block is not built yet");
-    return ERR_UNSUPPORTED;
-  }
   const bool v2 = d.self_attn == AVMOE_SELF_ATTN_LATENT_V2;
   if ((d.E_m > 0 || v2) && (d.K <= 0 || d.K > 128)) {
     set_last_error("moe: num_tk K=%d outside 1..128", d.K);
@@ -65,6 +61,8 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   for (int e = 0; e < d.E; ++e) {
     const bool multimodal = e < d.E_m;
     d.relu_of_e[e] = multimodal;
+    d.nxn_of_e[e] = (!multimodal && (d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN)) ? 1 : 0;
+    if (d.nxn_of_e[e]) d.nxn = 1;
     d.lat_of_e[e] = -1;
     if (multimodal || v2) {
       d.lat_of_e[e] = d.El;

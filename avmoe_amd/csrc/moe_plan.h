@@ -40,6 +40,8 @@ struct Dims {
   int e_of_lat[MAX_E];
   int src_of_lat[MAX_E]; // 0 = Y (cross-modal), 1 = X (v2)
   int relu_of_e[MAX_E];
+  int nxn_of_e[MAX_E];   // AVVP unimodal expert: input is X + gate_av * (softmax(X X^T)^T X)  (mgn.py:132-139)
+  int nxn;               // any such expert
   int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
   int xchunks;    // row chunks per frame of the fused X statistics pass
 };
@@ -89,6 +91,16 @@ struct Dims {
   X(Gq, 0, 4, (size_t)d.g * d.E * d.dgp * d.dgp)    /* Wh^T Wh per (i,e)              */       \
   X(uvh, 0, 4, (size_t)2 * d.DZ + 2 * d.g * d.E)    /* usum, vh, H1[i][e], H2[i][e]   */       \
   X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
+  /* ---- AVVP N x N block (only sized when present) ---- */                                     \
+  X(att, 0, d.esz, d.nxn ? (size_t)d.S * d.N * d.Np : 1)        /* softmax_rows(X X^T)            */  \
+  X(xr, 0, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)               /* att^T X                        */  \
+  X(sxr, 0, 4, d.nxn ? (size_t)3 * d.NT : 1)                    /* sum xr, sum xr^2, x . xr       */  \
+  X(ZR, 0, 4, d.nxn ? (size_t)d.NT * d.DZ : 1)                  /* xr through Wt                  */  \
+  X(attS, 1, 4, d.nxn ? (size_t)d.S * d.N * d.Np : 1)           /* scores ; d att in the backward */  \
+  X(dZR, 1, d.esz, d.nxn ? (size_t)d.NT * d.DZ : 1)                                                    \
+  X(dsr, 1, 4, d.nxn ? (size_t)3 * d.NT : 1)                                                           \
+  X(dxr, 1, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)                                                     \
+  X(dSc, 1, d.esz, d.nxn ? (size_t)d.S * d.N * d.Np : 1)                                               \
   /* ---- transient ---- */                                                                    \
   X(L1, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)    /* L1 ; dA1 in bwd */  \
   X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \
@@ -151,7 +163,7 @@ struct Plan {
 #undef X
   size_t saved_bytes, scratch_bytes;
   int nbuf;
-  BufInfo info[96];
+  BufInfo info[128];
 };
 
 // Validates the descriptor and fills the plan.  Returns 0 or a negative status.

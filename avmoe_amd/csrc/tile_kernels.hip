@@ -124,7 +124,7 @@ __device__ __forceinline__ void flush_scal4(float* s_sc, float v0, float v1, flo
 // =====================================================================================================
 // PRE_SMALL forward   (net_trans_v3.py:385-395)
 // =====================================================================================================
-struct PreTArgs { P16 glat; int lat_of_e[MAX_E]; TileDims t; int ln_before; float ln_eps; };
+struct PreTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; TileDims t; int ln_before; float ln_eps; const float* ZR; const float* sxr; };
 
 template <typename T>
 __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* Z, const float* L2, const float* sxs, const float* TT,
@@ -151,8 +151,10 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* Z, const 
 
   for (int e = 0; e < t.E; ++e) {
     const int l = a.lat_of_e[e];
+    const bool nxn = a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
+    if (nxn) gv = a.glat.p[e][0];
     if (l >= 0) {
       gv = a.glat.p[e][0];
       const float* tt = TT + ((long)s * t.El + l) * K * K;
@@ -175,6 +177,11 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* Z, const 
         const int n = n0 + 4 * q + x;
         Sx[x] = n < t.N ? sxs[t0 + 4 * q + x] : 0.f;
         Sxx[x] = n < t.N ? sxs[t.NT + t0 + 4 * q + x] : 1.f;
+        if (nxn && n < t.N) {        // x' = x + g xr : sums of x' from the sums of x, xr and x . xr   (mgn.py:132-139)
+          const long ti = t0 + 4 * q + x;
+          Sx[x] += gv * a.sxr[ti];
+          Sxx[x] += 2.f * gv * a.sxr[2L * t.NT + ti] + gv * gv * a.sxr[(long)t.NT + ti];
+        }
       }
       if (l >= 0) {
         // ---- softmax of the hop-2 logits, token r spread over the 4 lanes q (k = 4*kk + q) ----
@@ -240,7 +247,7 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* Z, const 
           for (int x = 0; x < 4; ++x) {
             if (n0 + 4 * q + x < t.N) {
               const long zi = (t0 + 4 * q + x) * t.DZ + col;
-              const float zr = Z[zi] + gv * p[x];
+              const float zr = Z[zi] + gv * (nxn ? a.ZR[zi] : p[x]);
               const float z = a.ln_before ? rr[x] * (zr - mu[x] * ws) + dc : zr;
               Z[zi] = z;
               c0 += z; c1 += z * z;
@@ -265,8 +272,11 @@ int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   const Dims& d = pl.d;
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e]; }
   a.t = make_td(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
+  a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
+  for (int e = 0; e < d.E; ++e)
+    if (d.nxn_of_e[e] && !prm.e[e].gate_lat) { set_last_error("moe: expert %d lacks gate_av", e); return ERR_BAD_ARG; }
   const TileDims& t = a.t;
   const int K4 = 4 * t.k4;
   const size_t sh = (size_t)(K4 * t.ldb_k + K4 * t.ldb_d + K4 + 4 * 16 * t.lda_k + 4 * 48 + 4 * 2 * t.DD) * sizeof(float);
@@ -597,7 +607,8 @@ __global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* Z, c
 // =====================================================================================================
 // PRE_SMALL backward
 // =====================================================================================================
-struct PreBTArgs { P16 glat; int lat_of_e[MAX_E]; TileDims t; int ln_before, use_bn, bn_train, dd4; };
+struct PreBTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; TileDims t; int ln_before, use_bn, bn_train, dd4, first_nxn;
+                   const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
 template <typename T>
 __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float* Z, const float* L2, const float* TT, const float* TW,
@@ -638,8 +649,10 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
 
   for (int e = 0; e < t.E; ++e) {
     const int l = a.lat_of_e[e];
+    const bool nxn = a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
+    if (nxn) gv = a.glat.p[e][0];
     if (l >= 0) {
       gv = a.glat.p[e][0];
       const float* tt = TT + ((long)s * t.El + l) * K * K;
@@ -676,7 +689,7 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
         mu[x] = (a.ln_before && ok[x]) ? rmu[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] : 0.f;
       }
       // ---- BN1 input gradient, folded-LayerNorm sums, dzraw tile ----
-      float s_dr[4] = {0.f, 0.f, 0.f, 0.f}, s_dmu[4] = {0.f, 0.f, 0.f, 0.f};
+      float s_dr[4] = {0.f, 0.f, 0.f, 0.f}, s_dmu[4] = {0.f, 0.f, 0.f, 0.f}, s_zr[4] = {0.f, 0.f, 0.f, 0.f};
       wsync();
       for (int ct = 0; ct * 16 < DD; ++ct) {
         const int dd = ct * 16 + r;
@@ -701,6 +714,7 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
                 dzr = rr[x] * dz;
               } else dzr = dz;
               stT<T>(dZx, zi, dzr);
+              if (nxn) { stT<T>((T*)a.dZR, zi, gv * dzr); s_zr[x] += dzr * a.ZR[zi]; }
             }
             Dt[(4 * q + x) * t.lda_d + dd] = dzr;
           }
@@ -724,6 +738,16 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
           const long ti = t0 + 4 * q + x;
           if (e == 0) { dsxs[ti] = dSx[x]; dsxs[t.NT + ti] = dSxx[x]; }
           else { dsxs[ti] += dSx[x]; dsxs[t.NT + ti] += dSxx[x]; }
+        }
+        if (nxn) {                   // x' = x + g xr : statistics gradients to (sum xr, sum xr^2, x . xr) and to the gate
+          const float zr = rsum16(s_zr[x]);
+          if (r == 0 && ok[x]) {
+            const long ti = t0 + 4 * q + x;
+            const float v0 = gv * dSx[x], v1 = 2.f * gv * gv * dSxx[x], v2 = 2.f * gv * dSxx[x];
+            if (e == a.first_nxn) { a.dsr[ti] = v0; a.dsr[(long)t.NT + ti] = v1; a.dsr[2L * t.NT + ti] = v2; }
+            else { a.dsr[ti] += v0; a.dsr[(long)t.NT + ti] += v1; a.dsr[2L * t.NT + ti] += v2; }
+            sdg += dSx[x] * a.sxr[ti] + dSxx[x] * (2.f * a.sxr[2L * t.NT + ti] + 2.f * gv * a.sxr[(long)t.NT + ti]) + zr;
+          }
         }
       }
       if (l >= 0) {
@@ -877,7 +901,13 @@ int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   const Dims& d = pl.d;
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreBTArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.first_nxn = -1;
+  for (int e = 0; e < MAX_E; ++e) {
+    a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e];
+    if (e < d.E && d.nxn_of_e[e] && a.first_nxn < 0) a.first_nxn = e;
+  }
+  a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
+  a.dZR = (void*)(scratch + pl.o_dZR); a.dsr = (float*)(scratch + pl.o_dsr);
   a.t = make_td(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training; a.dd4 = cdiv(d.DD, 4);
   const TileDims& t = a.t;
   const int K4 = 4 * t.k4, D4 = 4 * a.dd4;

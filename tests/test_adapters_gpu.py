@@ -9,7 +9,7 @@ from tests.test_adapters_api import build_module
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["ave_train", "ave_eval", "avqa_train", "avs_train_nonoise", "avs_v2_train", "ave_noln_nogate"])
+@pytest.mark.parametrize("name", ["ave_train", "ave_eval", "avqa_train", "avvp_train", "avs_train_nonoise", "avs_v2_train", "ave_noln_nogate"])
 def test_module_forward_backward_matches_reference_vectors(name):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
@@ -24,11 +24,17 @@ def test_module_forward_backward_matches_reference_vectors(name):
         out, idx, probs, lb = m(xin, yin, is_training=False)
         assert probs.shape == (X.shape[0], 1, cfg.E)
         assert torch.allclose(probs.reshape(-1, cfg.E).cpu(), t["probs"], atol=1e-5)
+    elif meta["which"] == "avvp":
+        out, lb = m(xin, yin)
+        idx = None
+        assert abs(float(lb) - float(t["lb"])) < 1e-4 * max(1.0, abs(float(t["lb"])))
     else:
         out, idx = m(xin, yin)
         lb = 0.0
-    assert out.shape == xin.shape and idx.shape == (X.shape[0], 1) and idx.dtype == torch.int64
-    assert torch.equal(idx.reshape(-1).cpu(), t["idx"])
+    assert out.shape == xin.shape
+    if idx is not None:
+        assert idx.shape == (X.shape[0], 1) and idx.dtype == torch.int64
+        assert torch.equal(idx.reshape(-1).cpu(), t["idx"])
     out_tm = out.squeeze(-1).permute(0, 2, 1)
     assert out_tm.is_contiguous()                      # the caller's residual add needs no copy
     assert float((out_tm.cpu() - t["out"]).abs().max() / t["out"].abs().max()) < 1e-3

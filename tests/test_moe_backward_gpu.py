@@ -7,7 +7,7 @@ from tests.golden_util import golden_names, load_golden, split_params, grad_erro
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [n for n in golden_names() if not n.startswith("avvp")]
+SUPPORTED = golden_names()          # every task variant, incl. the AVVP N x N unimodal block
 
 
 def _report(errs, rtol, floor_frac=1e-3):

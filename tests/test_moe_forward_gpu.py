@@ -8,7 +8,7 @@ from tests.golden_util import golden_names, load_golden, split_params
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [n for n in golden_names() if not n.startswith("avvp")]
+SUPPORTED = golden_names()          # every task variant, incl. the AVVP N x N unimodal block
 
 
 @pytest.mark.parametrize("name", SUPPORTED)
