@@ -50,6 +50,13 @@ struct GemmArgs {
   int ksplit = 1;
   float* slabs = nullptr;
   int tile = 0;                         // 0 = auto, 64 or 128 = force block tile
+  // optional second K segment, accumulated into the same tile before the epilogue:
+  //   C += alpha * A2[b][i][k2] * B2[b][j][k2]   with A2 K_MAJOR (lda2), B2 MN_MAJOR (ldb2), own batch strides.
+  // Fuses e.g. dX = dZx Wt + [dL2|dsx|1] [T;1;dm1/N] so the (NT, C) result is written once.
+  const void* A2 = nullptr;
+  const void* B2 = nullptr;
+  int K2 = 0;
+  long lda2 = 0, ldb2 = 0, s2A1 = 0, s2A2 = 0, s2B1 = 0, s2B2 = 0;
 };
 
 // Returns 0 on success, negative avmoe status otherwise (message through set_last_error).

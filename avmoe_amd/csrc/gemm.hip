@@ -35,6 +35,7 @@ struct DevArgs {
   int M, N, K, nb2, ksplit, kper, nbatch, tiles_n;
   long lda, ldb, sA1, sA2, sB1, sB2, sCi, sCj, sC1, sC2, sRS1, sRS2, sDi, sD1, sD2;
   float alpha; int accumulate, out_bf16, vec_c, vec_d;
+  const char* A2; const char* B2; int K2; long lda2, ldb2, s2A1, s2A2, s2B1, s2B2;
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
@@ -60,34 +61,28 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int valid) {
   return v;
 }
 
-template <typename T, int BM, int BN, bool AMN, bool BMN>
-__global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
+// One K segment of the block's tile: 2-stage LDS pipeline over [kbeg, kend), accumulating into acc.
+// Ends on a barrier, so a following segment (or the epilogue) may reuse the LDS buffer.
+template <typename T, int BM, int BN, bool AMN, bool BMN, int TM, int TN>
+__device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const char* Bb, long lda, long ldb, int M, int N, int m0,
+                                             int n0, int kbeg, int kend, f32x4 (&acc)[TM][TN]) {
   constexpr int ESZ = sizeof(T);
   constexpr int BK = 128 / ESZ;      // K elements per stage
   constexpr int EPC = 16 / ESZ;      // elements per 16-byte chunk
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int A_ROWB = AMN ? BM * ESZ + 16 : 144;
   constexpr int A_BYTES = (AMN ? BK : BM) * A_ROWB;
   constexpr int B_ROWB = BMN ? BN * ESZ + 16 : 144;
   constexpr int B_BYTES = (BMN ? BK : BN) * B_ROWB;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int A_CPR = BM * ESZ / 16, B_CPR = BN * ESZ / 16;   // chunks per LDS row (MN_MAJOR)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
-  const int split = blockIdx.y % p.ksplit, b = blockIdx.y / p.ksplit;
-  const int b1 = b / p.nb2, b2 = b % p.nb2;
-  const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2) * ESZ;
-  const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2) * ESZ;
-  const int kbeg = split * p.kper;
-  const int kend = min(p.K, kbeg + p.kper);
   const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  struct { int M, N; long lda, ldb; } p{M, N, lda, ldb};
 
   u32x4 ra[BM / 32], rb[BN / 32];
-
   auto gload = [&](int kt) {
     const int k0 = kbeg + kt * BK;
 #pragma unroll
@@ -146,12 +141,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
       else *(u32x4*)(sB + (c / B_CPR) * B_ROWB + (c % B_CPR) * 16) = rb[i];
     }
   };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int buf) {
     const char* sA = smem + buf * STAGE;
@@ -238,6 +227,38 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
     compute(kt & 1);
     if (kt + 1 < nkt) lstore((kt + 1) & 1);
     __syncthreads();
+  }
+
+}
+
+template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2>
+__global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
+  constexpr int ESZ = sizeof(T);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+  const int split = blockIdx.y % p.ksplit, b = blockIdx.y / p.ksplit;
+  const int b1 = b / p.nb2, b2 = b % p.nb2;
+  const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2) * ESZ;
+  const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2) * ESZ;
+  const int kbeg = split * p.kper;
+  const int kend = min(p.K, kbeg + p.kper);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gemm_segment<T, BM, BN, AMN, BMN, TM, TN>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend, acc);
+  if constexpr (SEG2) {     // second K segment: A2 K-major, B2 MN-major, own batch strides (C += A2 . B2^T)
+    const char* A2 = p.A2 + ((long)b1 * p.s2A1 + (long)b2 * p.s2A2) * ESZ;
+    const char* B2 = p.B2 + ((long)b1 * p.s2B1 + (long)b2 * p.s2B2) * ESZ;
+    gemm_segment<T, BM, BN, false, true, TM, TN>(smem, A2, B2, p.lda2, p.ldb2, p.M, p.N, m0, n0, 0, p.K2, acc);
   }
 
   // ---- epilogue through LDS ----
@@ -405,17 +426,19 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, bool AMN, bool BMN>
+template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2 = false>
 static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   constexpr int ESZ = sizeof(T);
   constexpr int BK = 128 / ESZ;
   constexpr int A_BYTES = (AMN ? BK : BM) * (AMN ? BM * ESZ + 16 : 144);
   constexpr int B_BYTES = (BMN ? BK : BN) * (BMN ? BN * ESZ + 16 : 144);
-  constexpr int STAGES = 2 * (A_BYTES + B_BYTES);
+  constexpr int A2_BYTES = BM * 144, B2_BYTES = BK * (BN * ESZ + 16);
+  constexpr int S1 = 2 * (A_BYTES + B_BYTES), S2 = SEG2 ? 2 * (A2_BYTES + B2_BYTES) : 0;
+  constexpr int STAGES = S1 > S2 ? S1 : S2;
   constexpr int EPI = BM * (BN + 4) * 4;
   constexpr int LDS = STAGES > EPI ? STAGES : EPI;
   static bool attr_done = false;
-  auto kern = gemm_kernel<T, BM, BN, AMN, BMN>;
+  auto kern = gemm_kernel<T, BM, BN, AMN, BMN, SEG2>;
   if (!attr_done) {
     if (LDS > 65536) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -430,7 +453,7 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];
-  if (!name[0]) snprintf(name, sizeof(name), "%s_%s_%d", names[AMN][BMN], sizeof(T) == 2 ? "bf16" : "f32", BM);
+  if (!name[0]) snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : "f32", BM);
   static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
   const char* pname = name;
   if (shapes && prof_enabled()) {            // debug only: one family per distinct call shape (leaks the small strings)
@@ -441,9 +464,10 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   const double nb = (double)d.nbatch;
   const double esz = sizeof(T), osz = d.ksplit > 1 ? 4.0 : (d.out_bf16 ? 2.0 : 4.0);
   // algorithmic bytes: every operand element once (broadcast operands counted once), C written once (+ read if accumulating)
-  const double abytes = ((d.sA1 == 0 && d.sA2 == 0 ? 1.0 : nb) * d.M * (double)d.K + (d.sB1 == 0 && d.sB2 == 0 ? 1.0 : nb) * d.N * (double)d.K) * esz +
+  const double abytes = ((d.sA1 == 0 && d.sA2 == 0 ? 1.0 : nb) * d.M * (double)d.K + (d.sB1 == 0 && d.sB2 == 0 ? 1.0 : nb) * d.N * (double)d.K +
+                         (SEG2 ? nb * (d.M + d.N) * (double)d.K2 : 0.0)) * esz +
                         nb * d.M * (double)d.N * osz * (d.accumulate ? 2.0 : 1.0) + (d.D ? nb * d.M * (double)d.N * esz : 0.0);
-  ProfScope ps(pname, abytes, 2.0 * nb * d.M * (double)d.N * d.K, stream);
+  ProfScope ps(pname, abytes, 2.0 * nb * d.M * (double)d.N * (d.K + (SEG2 ? d.K2 : 0)), stream);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, d);
   AVMOE_CHECK_LAUNCH("gemm_kernel");
   return OK;
@@ -452,6 +476,12 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
 template <typename T, int BM, int BN>
 static int launch_layout(const GemmArgs& a, const DevArgs& d, int bz, hipStream_t s) {
   const bool amn = a.a_layout == MN_MAJOR, bmn = a.b_layout == MN_MAJOR;
+  if (a.A2) {
+    if (!amn && bmn) return launch_inst<T, BM, BN, false, true, true>(d, bz, s);
+    if (amn && bmn) return launch_inst<T, BM, BN, true, true, true>(d, bz, s);
+    set_last_error("gemm: second K segment is built for B MN-major first segments only");
+    return ERR_UNSUPPORTED;
+  }
   if (!amn && !bmn) return launch_inst<T, BM, BN, false, false>(d, bz, s);
   if (!amn && bmn) return launch_inst<T, BM, BN, false, true>(d, bz, s);
   if (amn && !bmn) return launch_inst<T, BM, BN, true, false>(d, bz, s);
@@ -492,6 +522,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.sCi = a.sCi; d.sCj = a.sCj; d.sC1 = a.sC1; d.sC2 = a.sC2;
   d.sRS1 = a.sRS1; d.sRS2 = a.sRS2; d.sDi = a.sDi; d.sD1 = a.sD1; d.sD2 = a.sD2;
   d.alpha = a.alpha; d.accumulate = a.accumulate; d.out_bf16 = a.out_dtype == GEMM_BF16;
+  d.A2 = (const char*)a.A2; d.B2 = (const char*)a.B2; d.K2 = a.K2; d.lda2 = a.lda2; d.ldb2 = a.ldb2;
+  d.s2A1 = a.s2A1; d.s2A2 = a.s2A2; d.s2B1 = a.s2B1; d.s2B2 = a.s2B2;
+  if ((a.A2 != nullptr) != (a.B2 != nullptr) || (a.A2 && (a.ksplit > 1 || !aligned16(a.A2) || !aligned16(a.B2) || !mult16(a.lda2) || !mult16(a.ldb2) ||
+                                                  !mult16(a.s2A1) || !mult16(a.s2A2) || !mult16(a.s2B1) || !mult16(a.s2B2)))) {
+    set_last_error("gemm: bad second K segment (pair of pointers, no split-K, 16-byte aligned strides)");
+    return ERR_BAD_ARG;
+  }
   const int osz = d.out_bf16 ? 2 : 4;
   const int vecb = 4 * osz;    // bytes of a 4-element output vector
   d.vec_c = (a.sCj == 1) && (((uintptr_t)a.C) % vecb == 0) && ((a.sCi * osz) % vecb == 0) &&

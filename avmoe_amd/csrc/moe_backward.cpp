@@ -60,19 +60,15 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   const char* dZx = sc + pl.o_Zw;
 
   // ---- phase 5: GEMMs against X --------------------------------------------------------------------
-  {                                                        // dX = dZx Wt + 2 dSxx X
+  {   // dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + 2 dSxx X[s]   -- one pass: two K segments + row-scale epilogue
     GemmArgs g = base();
     g.A = dZx; g.B = sv + pl.o_Wt; g.C = dX;
-    g.M = d.NT; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb2 = d.g;
-    g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.C; g.sC2 = d.Cg; g.out_dtype = dt;
-    g.row_scale = (const float*)(sc + pl.o_rs2x); g.D = X; g.sDi = d.C; g.sD2 = d.Cg;
-    AVMOE_TRY(run(g, false));
-  }
-  {                                                        // dX += [dL2 | dsx | 1] [T ; 1 ; dm1/N]
-    GemmArgs g = base();
-    g.A = sc + pl.o_dL2x; g.B = sv + pl.o_Text; g.C = dX;
-    g.M = d.N; g.N = d.C; g.K = d.KLT; g.lda = d.KLp; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S;
-    g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.KLT * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
+    g.M = d.N; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
+    g.sA1 = (long)d.N * d.DZ; g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg;
+    g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.sC2 = d.Cg; g.out_dtype = dt;
+    g.row_scale = (const float*)(sc + pl.o_rs2x); g.sRS1 = d.N; g.D = X; g.sDi = d.C; g.sD1 = (long)d.N * d.C; g.sD2 = d.Cg;
+    g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
+    g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
     AVMOE_TRY(run(g, false));
   }
   if (d.nxn) {   // ---- AVVP N x N block: back through ZR = xr Wt^T, the three row sums and xr = att^T X --------------------
@@ -194,13 +190,6 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.sA1 = (long)d.Kcyb * d.Cy; g.sB1 = (long)d.M * d.Cy; g.sCi = d.Mb; g.sC1 = (long)d.Kcyb * d.Mb;
     AVMOE_TRY(run(g, false));
   }
-  {                                                        // dY[s] = [Bm ; wbar][s]^T dV[s]
-    GemmArgs g = base();
-    g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
-    g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
-    g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
-    AVMOE_TRY(run(g, false));
-  }
   AVMOE_TRY(k_prep_dBm(pl, sc, st));
   MEMSET0(sc + pl.o_dWcK, (size_t)d.N * d.Mk * 4);
   MEMSET0(sc + pl.o_dqp, ((size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb) * 4);
@@ -244,11 +233,12 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       AVMOE_TRY(run(g, true));
     }
     AVMOE_TRY(k_cast(d.bf16, (const float*)(sc + pl.o_dQ), d.Kcy, d.Cy, d.Cy, sc + pl.o_dQT, d.Cy, st));
-    {                                                      // dY[s] += dR[s]^T Q
+    {   // dY[s] = [Bm ; wbar][s]^T dV[s] + dR[s]^T Q   -- one pass over dY (two K segments)
       GemmArgs g = base();
-      g.A = sc + pl.o_dRT; g.B = sv + pl.o_Qx; g.C = dY;
-      g.M = d.M; g.N = d.Cy; g.K = d.Kcy; g.lda = d.Kcyp; g.b_layout = MN_MAJOR; g.ldb = d.Cy; g.nb1 = d.S;
-      g.sA1 = (long)d.M * d.Kcyp; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt; g.accumulate = 1;
+      g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
+      g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
+      g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
+      g.A2 = sc + pl.o_dRT; g.B2 = sv + pl.o_Qx; g.K2 = d.Kcy; g.lda2 = d.Kcyp; g.ldb2 = d.Cy; g.s2A1 = (long)d.M * d.Kcyp;
       AVMOE_TRY(run(g, false));
     }
     {                                                      // dT0[y slots] += dQ Wf^T
@@ -264,6 +254,13 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.accumulate = 1;
       AVMOE_TRY(run(g, false));
     }
+  }
+  if (d.Kcy == 0) {                                        // no cross-modal expert: dY[s] = wbar (x) d ybar[s]
+    GemmArgs g = base();
+    g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
+    g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
+    g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
+    AVMOE_TRY(run(g, false));
   }
   // ---- phase 6b: latent self attention on X (AVS v2) ----------------------------------------------
   if (d.Kcx > 0) {
