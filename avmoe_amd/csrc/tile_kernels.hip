@@ -14,6 +14,7 @@
 #include "device_utils.h"
 #include "prof.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace avmoe {
 
@@ -83,6 +84,8 @@ struct TileDims {
   int lda_d;     // leading dim of per-wave DD-wide tiles
   int ldb_d;     // leading dim of LDS matrices with DD columns
   int ldb_g;     // leading dim of LDS matrices with dgp columns
+  int lg_pr;     // log2(DD / 4) if a power of two, else -1   (float4 per slab row)
+  int lg_sw;     // log2(dgp / 4) if a power of two, else -1  (float4 per group segment)
 };
 static TileDims make_td(const Dims& d, int per) {
   TileDims t;
@@ -91,9 +94,12 @@ static TileDims make_td(const Dims& d, int per) {
   t.k4 = cdiv(d.K, 4);
   t.lda_k = pad_lda(4 * t.k4); t.ldb_k = pad_ldb(4 * t.k4);
   t.lda_d = pad_lda(d.DD); t.ldb_d = pad_ldb(d.DD); t.ldb_g = pad_ldb(d.dgp);
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  t.lg_pr = lg(d.DD / 4); t.lg_sw = lg(d.dgp / 4);
   return t;
 }
 __device__ __forceinline__ int colmap(const TileDims& a, int e, int dd) {
+  if (a.lg_sw >= 0) { const int sh = a.lg_sw + 2; return ((dd >> sh) * a.E + e) * a.dgp + (dd & (a.dgp - 1)); }
   return (dd / a.dgp) * a.E * a.dgp + e * a.dgp + (dd % a.dgp);
 }
 // flush per-wave column accumulators (LDS, [waves][nslot][width]) of expert e into colpart
@@ -121,15 +127,127 @@ __device__ __forceinline__ void flush_scal4(float* s_sc, float v0, float v1, flo
   }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Slab I/O: the 16 x DD block of one expert inside a row-major array whose rows hold [group][expert][dgp]
+// (element (row, gi, jp) at base[row*row_stride + gi*grp_stride + col0 + jp]).  The whole wave moves it with
+// 16-byte accesses, MAXV of them in flight per lane, through the per-wave LDS tile [16][ld] -- so the compute
+// phases never wait on global memory inside their loops.
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_index(const TileDims& t, int idx, int& row, int& gi, int& c4) {
+  const int per_row = t.DD >> 2, segw = t.dgp >> 2;
+  int rem;
+  if (t.lg_pr >= 0) { row = idx >> t.lg_pr; rem = idx & (per_row - 1); } else { row = idx / per_row; rem = idx - row * per_row; }
+  if (t.lg_sw >= 0) { gi = rem >> t.lg_sw; c4 = rem & (segw - 1); } else { gi = rem / segw; c4 = rem - gi * segw; }
+}
+template <int MAXV, typename F>
+__device__ __forceinline__ void slab_load(const float* __restrict__ base, long row_stride, long grp_stride, int col0, const TileDims& t,
+                                          int nvalid, float* dst, int ld, int lane, F&& xform) {
+  const int total = 16 * (t.DD >> 2);
+  for (int i0 = 0; i0 < total; i0 += 64 * MAXV) {
+    float4 v[MAXV];
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      const int idx = i0 + u * 64 + lane;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < total) {
+        int row, gi, c4; slab_index(t, idx, row, gi, c4);
+        if (row < nvalid) v[u] = *(const float4*)(base + row * row_stride + gi * grp_stride + col0 + 4 * c4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      const int idx = i0 + u * 64 + lane;
+      if (idx < total) {
+        int row, gi, c4; slab_index(t, idx, row, gi, c4);
+        const int dd = gi * t.dgp + 4 * c4;
+        float2* d2 = (float2*)(dst + row * ld + dd);
+        d2[0] = make_float2(xform(dd, v[u].x), xform(dd + 1, v[u].y));
+        d2[1] = make_float2(xform(dd + 2, v[u].z), xform(dd + 3, v[u].w));
+      }
+    }
+  }
+}
+// Register-staged variant for software pipelining (slabs with at most 64*MAXV float4, i.e. DD <= 16*MAXV):
+// slab_fetch issues the loads of a (future) tile, slab_commit writes them to the LDS tile one iteration later.
+template <int MAXV>
+__device__ __forceinline__ void slab_fetch(const float* __restrict__ base, long row_stride, long grp_stride, int col0, const TileDims& t,
+                                           int nvalid, int lane, float4 (&v)[MAXV]) {
+  const int total = 16 * (t.DD >> 2);
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int idx = u * 64 + lane;
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total) {
+      int row, gi, c4; slab_index(t, idx, row, gi, c4);
+      if (row < nvalid) v[u] = *(const float4*)(base + row * row_stride + gi * grp_stride + col0 + 4 * c4);
+    }
+  }
+}
+template <int MAXV, typename F>
+__device__ __forceinline__ void slab_commit(const float4 (&v)[MAXV], const TileDims& t, float* dst, int ld, int lane, F&& xform) {
+  const int total = 16 * (t.DD >> 2);
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int idx = u * 64 + lane;
+    if (idx < total) {
+      int row, gi, c4; slab_index(t, idx, row, gi, c4);
+      const int dd = gi * t.dgp + 4 * c4;
+      float2* d2 = (float2*)(dst + row * ld + dd);
+      d2[0] = make_float2(xform(dd, v[u].x), xform(dd + 1, v[u].y));
+      d2[1] = make_float2(xform(dd + 2, v[u].z), xform(dd + 3, v[u].w));
+    }
+  }
+}
+// fp32 slab store: value(row, dd) = src[row*ld + dd] * rowscale(row)
+template <typename F>
+__device__ __forceinline__ void slab_store_f32(float* __restrict__ base, long row_stride, long grp_stride, int col0, const TileDims& t,
+                                               int nvalid, const float* src, int ld, int lane, F&& rowscale) {
+  const int total = 16 * (t.DD >> 2);
+  for (int idx = lane; idx < total; idx += 64) {
+    int row, gi, c4; slab_index(t, idx, row, gi, c4);
+    if (row < nvalid) {
+      const int dd = gi * t.dgp + 4 * c4;
+      const float sc = rowscale(row);
+      const float2* s2 = (const float2*)(src + row * ld + dd);
+      const float2 a = s2[0], b = s2[1];
+      *(float4*)(base + row * row_stride + gi * grp_stride + col0 + 4 * c4) = make_float4(a.x * sc, a.y * sc, b.x * sc, b.y * sc);
+    }
+  }
+}
+// T-typed slab store (bf16: 8 bytes per lane)
+template <typename T, typename F>
+__device__ __forceinline__ void slab_store_T(void* __restrict__ base_, long elem0, long row_stride, long grp_stride, int col0,
+                                             const TileDims& t, int nvalid, const float* src, int ld, int lane, F&& rowscale) {
+  const int total = 16 * (t.DD >> 2);
+  for (int idx = lane; idx < total; idx += 64) {
+    int row, gi, c4; slab_index(t, idx, row, gi, c4);
+    if (row < nvalid) {
+      const int dd = gi * t.dgp + 4 * c4;
+      const float sc = rowscale(row);
+      const float2* s2 = (const float2*)(src + row * ld + dd);
+      const float2 a = s2[0], b = s2[1];
+      const long o = elem0 + row * row_stride + gi * grp_stride + col0 + 4 * c4;
+      if constexpr (sizeof(T) == 4) {
+        *(float4*)((float*)base_ + o) = make_float4(a.x * sc, a.y * sc, b.x * sc, b.y * sc);
+      } else {
+        uint2 pk;
+        pk.x = (unsigned)f2bf(a.x * sc) | ((unsigned)f2bf(a.y * sc) << 16);
+        pk.y = (unsigned)f2bf(b.x * sc) | ((unsigned)f2bf(b.y * sc) << 16);
+        *(uint2*)((unsigned short*)base_ + o) = pk;
+      }
+    }
+  }
+}
+
 // =====================================================================================================
 // PRE_SMALL forward   (net_trans_v3.py:385-395)
 // =====================================================================================================
 struct PreTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; TileDims t; int ln_before; float ln_eps; const float* ZR; const float* sxr; };
 
 template <typename T>
-__global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* Z, const float* L2, const float* sxs, const float* TT,
-                                                    const float* TW, const float* Tsum, const float* wsum, const float* dconst,
-                                                    void* aout_, float* rmu, float* colpart) {
+__global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ sxs, const float* __restrict__ TT,
+                                                    const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum, const float* __restrict__ dconst,
+                                                    void* __restrict__ aout_, float* __restrict__ rmu, float* __restrict__ colpart) {
   T* aout = (T*)aout_;
   const TileDims& t = a.t;
   extern __shared__ float sm[];
@@ -312,8 +430,8 @@ __device__ __forceinline__ void load_zp_tile(const TileDims& t, int e, bool relu
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* Z, const float* bn1, const float* Gq, const float* uvh,
-                                                     const float* probs, void* Apost_, float* rpmup) {
+__global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq, const float* __restrict__ uvh,
+                                                     const float* __restrict__ probs, void* __restrict__ Apost_, float* __restrict__ rpmup) {
   T* Apost = (T*)Apost_;
   const TileDims& t = a.t;
   extern __shared__ float sm[];
@@ -424,28 +542,34 @@ namespace avmoe {
 // =====================================================================================================
 struct PostBTArgs { P16 gate; int relu_of_e[MAX_E]; TileDims t; int ln_post, use_gate; };
 
-template <typename T>
-__global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const float* Z, const float* bn1, const float* Gq,
-                                                         const float* uvh, const float* probs, const float* rpmup, const float* dAp,
-                                                         float* dzp, void* Zp_, void* Zw_, float* colpart, float* blkscal) {
-  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_;
+template <typename T, bool PF>
+__global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const float* __restrict__ Z, const float* __restrict__ bn1,
+                                                         const float* __restrict__ Gq, const float* __restrict__ uvh,
+                                                         const float* __restrict__ probs, const float* __restrict__ rpmup,
+                                                         const float* __restrict__ dAp, float* __restrict__ dzp, void* __restrict__ Zp_,
+                                                         void* __restrict__ Zw_, float* __restrict__ colpart, float* __restrict__ blkscal) {
   const TileDims& t = a.t;
   extern __shared__ float sm[];
-  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4, nw = blockDim.x >> 6;
+  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4, nw = blockDim.x >> 6, ld = t.lda_d;
   float* s_G = sm;
   float* s_us = s_G + t.g * 4 * g4 * t.ldb_g;
   float* s_vh = s_us + DD;
   float* s_sc = s_vh + DD;
   float* s_sh = s_sc + DD;
-  float* s_z = s_sh + DD;                         // nw x [16][lda_d]
-  float* s_col = s_z + nw * 16 * t.lda_d;         // nw x [2][DD]
+  float* s_til = s_sh + DD;                       // nw x 3 x [16][ld] : z', dAz, dz'
+  float* s_row = s_til + nw * 3 * 16 * ld;        // nw x [6][16]      : da1, da2, da3, rp, mup, dSoo
+  float* s_col = s_row + nw * 96;                 // nw x [2][DD]
   float* s_scal = s_col + nw * 2 * DD;            // nw x 4
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  float* Zt = s_z + wave * 16 * t.lda_d;
+  float* Zt = s_til + wave * 3 * 16 * ld;
+  float* Dt = Zt + 16 * ld;
+  float* Ot = Dt + 16 * ld;
+  float* rw = s_row + wave * 96;
   float* mycol = s_col + wave * 2 * DD;
   for (int i = threadIdx.x; i < nw * 2 * DD; i += blockDim.x) s_col[i] = 0.f;
+  for (int i = threadIdx.x; i < nw * 3 * 16 * ld; i += blockDim.x) s_til[i] = 0.f;
   for (int e = 0; e < t.E; ++e) {
     __syncthreads();
     for (int i = threadIdx.x; i < t.g * 4 * g4 * t.ldb_g; i += blockDim.x) {
@@ -461,74 +585,108 @@ __global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const flo
     const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
     const float qv = probs[(long)s * t.E + e] * gate;
     float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
+    // software pipeline (PF): the loads of tile i+1 are in flight while tile i is computed and stored
+    float4 pz[4], pd[4];
+    float pr[5] = {0.f, 0.f, 0.f, 1.f, 0.f};
+    auto fetch = [&](int n0) {
+      const long t0 = (long)s * t.N + n0;
+      const int nvalid = min(16, t.N - n0);
+      slab_fetch<4>(Z + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, lane, pz);
+      slab_fetch<4>(dAp + t0 * t.g * t.KPp, (long)t.g * t.KPp, t.KPp, e * dgp, t, nvalid, lane, pd);
+      pr[0] = pr[1] = pr[2] = 0.f; pr[3] = 1.f; pr[4] = 0.f;
+      if (lane < nvalid) {
+        for (int gi = 0; gi < t.g; ++gi) {
+          const float* p = dAp + ((t0 + lane) * t.g + gi) * t.KPp + t.E * dgp + 3 * e;
+          pr[0] += p[0]; pr[1] += p[1]; pr[2] += p[2];
+        }
+        pr[3] = rpmup[(t0 + lane) * t.E + e]; pr[4] = rpmup[(long)t.NT * t.E + (t0 + lane) * t.E + e];
+      }
+    };
+    if (PF && n_beg + 16 * wave < n_end) fetch(n_beg + 16 * wave);
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 16 * nw) {
       const long t0 = (long)s * t.N + n0;
+      const int nvalid = min(16, t.N - n0);
       wsync();
-      load_zp_tile(t, e, relu, Z, s_sc, s_sh, t0, n0, Zt, r, q);
+      // ---- phase A: everything this tile needs, in coalesced 16-byte loads ----
+      auto zx = [&](int dd, float z) { const float y = z * s_sc[dd] + s_sh[dd]; return relu ? fmaxf(y, 0.f) : y; };
+      if constexpr (PF) {
+        slab_commit<4>(pz, t, Zt, ld, lane, zx);
+        slab_commit<4>(pd, t, Dt, ld, lane, [](int, float v) { return v; });
+        if (lane < 16) { rw[lane] = pr[0]; rw[16 + lane] = pr[1]; rw[32 + lane] = pr[2]; rw[48 + lane] = pr[3]; rw[64 + lane] = pr[4]; }
+        if (n0 + 16 * nw < n_end) fetch(n0 + 16 * nw);
+      } else {
+        slab_load<4>(Z + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Zt, ld, lane, zx);
+        slab_load<4>(dAp + t0 * t.g * t.KPp, (long)t.g * t.KPp, t.KPp, e * dgp, t, nvalid, Dt, ld, lane, [](int, float v) { return v; });
+        if (lane < 16) {
+          float d1 = 0.f, d2 = 0.f, d3 = 0.f, rpv = 1.f, mupv = 0.f;
+          if (lane < nvalid) {
+            for (int gi = 0; gi < t.g; ++gi) {
+              const float* p = dAp + ((t0 + lane) * t.g + gi) * t.KPp + t.E * dgp + 3 * e;
+              d1 += p[0]; d2 += p[1]; d3 += p[2];
+            }
+            rpv = rpmup[(t0 + lane) * t.E + e]; mupv = rpmup[(long)t.NT * t.E + (t0 + lane) * t.E + e];
+          }
+          rw[lane] = d1; rw[16 + lane] = d2; rw[32 + lane] = d3; rw[48 + lane] = rpv; rw[64 + lane] = mupv;
+        }
+      }
       wsync();
-      bool ok[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) ok[x] = n0 + 4 * q + x < t.N;
+      // ---- phase B: bottleneck-space arithmetic from LDS ----
       float zz[4] = {0.f, 0.f, 0.f, 0.f};
       for (int ct = 0; ct * 16 < DD; ++ct) {
         const int dd = ct * 16 + r;
         if (dd < DD) {
 #pragma unroll
-          for (int x = 0; x < 4; ++x)
-            if (ok[x]) zz[x] += dAp[((t0 + 4 * q + x) * t.g + dd / dgp) * t.KPp + e * dgp + (dd % dgp)] * Zt[(4 * q + x) * t.lda_d + dd];
+          for (int x = 0; x < 4; ++x) zz[x] += Dt[(4 * q + x) * ld + dd] * Zt[(4 * q + x) * ld + dd];
         }
       }
-      float rp[4], mup[4], dSo[4], dSoo[4];
+      float rp[4], dSo[4], dSoo[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
+        const int row = 4 * q + x;
         zz[x] = rsum16(zz[x]);
-        rp[x] = 1.f; mup[x] = 0.f; dSo[x] = 0.f; dSoo[x] = 0.f;
-        if (ok[x]) {
-          float da1 = 0.f, da2 = 0.f, da3 = 0.f;
-          for (int gi = 0; gi < t.g; ++gi) {
-            const float* p = dAp + ((t0 + 4 * q + x) * t.g + gi) * t.KPp + t.E * dgp + 3 * e;
-            da1 += p[0]; da2 += p[1]; da3 += p[2];
-          }
-          rp[x] = rpmup[(t0 + 4 * q + x) * t.E + e]; mup[x] = rpmup[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e];
-          const float dq = rp[x] * zz[x] + rp[x] * da1 - rp[x] * mup[x] * da2 + da3;
+        rp[x] = rw[48 + row];
+        const float mup = rw[64 + row], da1 = rw[row], da2 = rw[16 + row], da3 = rw[32 + row];
+        dSo[x] = 0.f; dSoo[x] = 0.f;
+        if (row < nvalid) {
+          const float dq = rp[x] * zz[x] + rp[x] * da1 - rp[x] * mup * da2 + da3;
           if (a.ln_post) {
-            const float drp = qv * zz[x] + qv * da1 - qv * mup[x] * da2;
+            const float drp = qv * zz[x] + qv * da1 - qv * mup * da2;
             float dmup = -qv * rp[x] * da2;
             const float dvarp = drp * (-0.5f) * rp[x] * rp[x] * rp[x];
             dSoo[x] = dvarp / (float)t.C;
-            dmup -= 2.f * mup[x] * dvarp;
+            dmup -= 2.f * mup * dvarp;
             dSo[x] = dmup / (float)t.C;
           }
-          if (r == 0) { sdq += dq; sdSo += dSo[x]; sdSoo += dSoo[x]; }
-        }
+          if (r == 0) { sdq += dq; sdSo += dSo[x]; sdSoo += dSoo[x]; rw[80 + row] = dSoo[x]; }
+        } else if (r == 0) rw[80 + row] = 0.f;
       }
       for (int gi = 0; gi < t.g; ++gi)
         for (int ct = 0; ct * 16 < dgp; ++ct) {
           f32x4 w = {0.f, 0.f, 0.f, 0.f};
-          if (a.ln_post) w = tile_mm(Zt + gi * dgp, t.lda_d, s_G + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
+          if (a.ln_post) w = tile_mm(Zt + gi * dgp, ld, s_G + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
           const int jp = ct * 16 + r, dd = gi * dgp + jp;
           float c0 = 0.f, c1 = 0.f;
           if (jp < dgp) {
-            const int col = colmap(t, e, dd);
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-              if (ok[x]) {
-                const float zv = Zt[(4 * q + x) * t.lda_d + dd];
-                const float dAz = dAp[((t0 + 4 * q + x) * t.g + gi) * t.KPp + e * dgp + jp];
-                float dz = qv * rp[x] * dAz;
-                if (a.ln_post) {
-                  dz += dSo[x] * s_us[dd] + dSoo[x] * (2.f * w[x] + 2.f * s_vh[dd]);
-                  c0 += dSo[x] * zv; c1 += dSoo[x] * zv;
-                }
-                const long zi = (t0 + 4 * q + x) * t.DZ + col;
-                dzp[zi] = dz;
-                stT<T>(Zp, zi, zv);
-                stT<T>(Zw, zi, dSoo[x] * zv);
+            for (int x = 0; x < 4; ++x) {
+              const int row = 4 * q + x;
+              const float zv = Zt[row * ld + dd];
+              float dz = qv * rp[x] * Dt[row * ld + dd];
+              if (a.ln_post) {
+                dz += dSo[x] * s_us[dd] + dSoo[x] * (2.f * w[x] + 2.f * s_vh[dd]);
+                c0 += dSo[x] * zv; c1 += dSoo[x] * zv;
               }
+              Ot[row * ld + dd] = dz;
+            }
           }
           c0 = qsum4(c0); c1 = qsum4(c1);
           if (q == 0 && jp < dgp) { mycol[dd] += c0; mycol[DD + dd] += c1; }
         }
+      wsync();
+      // ---- phase C: coalesced stores ----
+      slab_store_f32(dzp + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Ot, ld, lane, [](int) { return 1.f; });
+      slab_store_T<T>(Zp_, t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Zt, ld, lane, [](int) { return 1.f; });
+      slab_store_T<T>(Zw_, t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Zt, ld, lane, [&](int row) { return rw[80 + row]; });
     }
     flush_colacc(t, s_col, 2, e, colpart, blk, 0);
     flush_scal4(s_scal, wave_sum(sdq), wave_sum(sdSo), wave_sum(sdSoo), 0.f, blkscal + ((long)blk * t.E + e) * 4, 0x7u);
@@ -538,24 +696,28 @@ __global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const flo
 // =====================================================================================================
 // MID backward
 // =====================================================================================================
-struct MidBTArgs { int relu_of_e[MAX_E]; TileDims t; int moments; };
+struct MidBTArgs { int relu_of_e[MAX_E]; TileDims t; int moments; int dbg; };
 
 template <typename T>
-__global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* Z, const float* bn1, const float* dsm, const float* sdSzz,
-                                                  float* dzp, float* colpart) {
+__global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* __restrict__ Z, const float* __restrict__ bn1,
+                                                  const float* __restrict__ dsm, const float* __restrict__ sdSzz, float* __restrict__ dzp,
+                                                  float* __restrict__ colpart) {
   const TileDims& t = a.t;
   extern __shared__ float sm[];
-  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4, nw = blockDim.x >> 6;
+  const int DD = t.DD, dgp = t.dgp, g4 = (dgp + 3) / 4, nw = blockDim.x >> 6, ld = t.lda_d;
   float* s_S = sm;                                // [g][4*g4][ldb_g]
   float* s_bn = s_S + t.g * 4 * g4 * t.ldb_g;     // [5][DD]: mean, rstd, sc, sh, dmz/NT
-  float* s_z = s_bn + 5 * DD;
-  float* s_col = s_z + nw * 16 * t.lda_d;
+  float* s_til = s_bn + 5 * DD;                   // nw x 3 x [16][ld] : raw z, z', dz' -> dy
+  float* s_col = s_til + nw * 3 * 16 * ld;        // nw x [2][DD]
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  float* Zt = s_z + wave * 16 * t.lda_d;
+  float* Zr = s_til + wave * 3 * 16 * ld;
+  float* Zt = Zr + 16 * ld;
+  float* Dt = Zt + 16 * ld;
   float* mycol = s_col + wave * 2 * DD;
   for (int i = threadIdx.x; i < nw * 2 * DD; i += blockDim.x) s_col[i] = 0.f;
+  for (int i = threadIdx.x; i < nw * 3 * 16 * ld; i += blockDim.x) s_til[i] = 0.f;
   for (int e = 0; e < t.E; ++e) {
     __syncthreads();
     if (a.moments)
@@ -572,33 +734,51 @@ __global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* Z, c
     const bool relu = a.relu_of_e[e];
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 16 * nw) {
       const long t0 = (long)s * t.N + n0;
+      const int nvalid = min(16, t.N - n0);
       wsync();
-      load_zp_tile(t, e, relu, Z, s_bn + 2 * DD, s_bn + 3 * DD, t0, n0, Zt, r, q);
+      slab_load<4>(Z + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Zr, ld, lane, [](int, float v) { return v; });
+      slab_load<4>(dzp + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Dt, ld, lane, [](int, float v) { return v; });
       wsync();
+      if (a.dbg & 1) goto store_phase;       // debug: I/O only
+      if (a.moments) {                       // z' tile (A operand of the BN2-moment term)
+        for (int ct = 0; ct * 16 < DD; ++ct) {
+          const int dd = ct * 16 + r;
+          if (dd < DD) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const float y = Zr[(4 * q + x) * ld + dd] * s_bn[2 * DD + dd] + s_bn[3 * DD + dd];
+              Zt[(4 * q + x) * ld + dd] = relu ? fmaxf(y, 0.f) : y;
+            }
+          }
+        }
+        wsync();
+      }
       for (int gi = 0; gi < t.g; ++gi)
         for (int ct = 0; ct * 16 < dgp; ++ct) {
           f32x4 w = {0.f, 0.f, 0.f, 0.f};
-          if (a.moments) w = tile_mm(Zt + gi * dgp, t.lda_d, s_S + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
+          if (a.moments) w = tile_mm(Zt + gi * dgp, ld, s_S + gi * 4 * g4 * t.ldb_g, t.ldb_g, g4, ct * 16, r, q);
           const int jp = ct * 16 + r, dd = gi * dgp + jp;
           float c0 = 0.f, c1 = 0.f;
           if (jp < dgp) {
-            const int col = colmap(t, e, dd);
+            const float mean = s_bn[dd], rstd = s_bn[DD + dd], sc = s_bn[2 * DD + dd], sh = s_bn[3 * DD + dd], dm = s_bn[4 * DD + dd];
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-              if (n0 + 4 * q + x < t.N) {
-                const long zi = (t0 + 4 * q + x) * t.DZ + col;
-                const float z = Z[zi];
-                const float zh = (z - s_bn[dd]) * s_bn[DD + dd];
-                const float y = z * s_bn[2 * DD + dd] + s_bn[3 * DD + dd];
-                const float dz = dzp[zi] + s_bn[4 * DD + dd] + w[x];
-                const float dy = (relu && y <= 0.f) ? 0.f : dz;
-                dzp[zi] = dy;
-                c0 += dy; c1 += dy * zh;
-              }
+            for (int x = 0; x < 4; ++x) {
+              const int row = 4 * q + x;
+              const float z = Zr[row * ld + dd];
+              const float zh = (z - mean) * rstd;
+              const float y = z * sc + sh;
+              const float dz = Dt[row * ld + dd] + dm + w[x];
+              const float dy = (row >= nvalid || (relu && y <= 0.f)) ? 0.f : dz;
+              Dt[row * ld + dd] = dy;
+              c0 += dy; c1 += dy * zh;
+            }
           }
           c0 = qsum4(c0); c1 = qsum4(c1);
           if (q == 0 && jp < dgp) { mycol[dd] += c0; mycol[DD + dd] += c1; }
         }
+    store_phase:
+      wsync();
+      if (!(a.dbg & 2)) slab_store_f32(dzp + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Dt, ld, lane, [](int) { return 1.f; });
     }
     flush_colacc(t, s_col, 2, e, colpart, blk, 2);
   }
@@ -611,11 +791,11 @@ struct PreBTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; TileDims 
                    const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
 template <typename T>
-__global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float* Z, const float* L2, const float* TT, const float* TW,
-                                                        const float* Tsum, const float* wsum, const float* dconst, const void* ain_,
-                                                        const float* rmu, const float* bn1, const float* dsm, const float* dy_in,
-                                                        void* dZx_, void* dL2x_, void* aw_, void* ag_, float* dsxs, float* rs2x,
-                                                        float* colpart, float* blkscal, float* dtbp) {
+__global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ TT, const float* __restrict__ TW,
+                                                        const float* __restrict__ Tsum, const float* __restrict__ wsum, const float* __restrict__ dconst, const void* __restrict__ ain_,
+                                                        const float* __restrict__ rmu, const float* __restrict__ bn1, const float* __restrict__ dsm, const float* __restrict__ dy_in,
+                                                        void* __restrict__ dZx_, void* __restrict__ dL2x_, void* __restrict__ aw_, void* __restrict__ ag_, float* __restrict__ dsxs, float* __restrict__ rs2x,
+                                                        float* __restrict__ colpart, float* __restrict__ blkscal, float* __restrict__ dtbp) {
   const T* ain = (const T*)ain_;
   T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
   const TileDims& t = a.t;
@@ -865,13 +1045,21 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   const TileDims& t = a.t;
   const int g4 = cdiv(t.dgp, 4);
   size_t sh;
-  const int nw = pick_waves((size_t)t.g * 4 * g4 * t.ldb_g + 4 * t.DD, (size_t)16 * t.lda_d + 2 * t.DD + 4, &sh);
+  const int nw = pick_waves((size_t)t.g * 4 * g4 * t.ldb_g + 4 * t.DD, (size_t)3 * 16 * t.lda_d + 96 + 2 * t.DD + 4, &sh);
   if (!nw) { set_last_error("post_small_bwd: LDS budget"); return ERR_UNSUPPORTED; }
-  AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_post_small_bwd<__bf16> : (const void*)kt_post_small_bwd<float>, sh, "post_small_bwd"));
-  DISPATCH_T(d.bf16, kt_post_small_bwd, grid, dim3(64 * nw), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-             (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs),
-             (const float*)(saved + pl.o_rpmup), (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp),
-             (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
+  const bool pf = d.DD <= 64;
+#define KPSB(TT_, PF_) kt_post_small_bwd<TT_, PF_>
+  const void* fn = d.bf16 ? (pf ? (const void*)KPSB(__bf16, true) : (const void*)KPSB(__bf16, false))
+                          : (pf ? (const void*)KPSB(float, true) : (const void*)KPSB(float, false));
+  AVMOE_TRY(set_lds(fn, sh, "post_small_bwd"));
+#define LAUNCH_PSB(TT_, PF_) hipLaunchKernelGGL((KPSB(TT_, PF_)), grid, dim3(64 * nw), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), \
+                     (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), \
+                     (const float*)(saved + pl.o_rpmup), (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp), \
+                     (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal))
+  if (d.bf16) { if (pf) LAUNCH_PSB(__bf16, true); else LAUNCH_PSB(__bf16, false); }
+  else { if (pf) LAUNCH_PSB(float, true); else LAUNCH_PSB(float, false); }
+#undef LAUNCH_PSB
+#undef KPSB
   AVMOE_CHECK_LAUNCH("post_small_bwd");
   return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
 }
@@ -883,10 +1071,11 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
   MidBTArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_td(d, per); a.moments = d.use_bn && d.training;
+  a.dbg = getenv("AVMOE_DBG_MID") ? atoi(getenv("AVMOE_DBG_MID")) : 0;
   const TileDims& t = a.t;
   const int g4 = cdiv(t.dgp, 4);
   size_t sh;
-  const int nw = pick_waves((size_t)t.g * 4 * g4 * t.ldb_g + 5 * t.DD, (size_t)16 * t.lda_d + 2 * t.DD, &sh);
+  const int nw = pick_waves((size_t)t.g * 4 * g4 * t.ldb_g + 5 * t.DD, (size_t)3 * 16 * t.lda_d + 2 * t.DD, &sh);
   if (!nw) { set_last_error("mid_bwd: LDS budget"); return ERR_UNSUPPORTED; }
   AVMOE_TRY(set_lds(d.bf16 ? (const void*)kt_mid_bwd<__bf16> : (const void*)kt_mid_bwd<float>, sh, "mid_bwd"));
   DISPATCH_T(d.bf16, kt_mid_bwd, grid, dim3(64 * nw), sh, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),

@@ -211,7 +211,7 @@ def main():
                         path_algorithmic_gbs=round(algorithmic_bytes_per_clip_pair(c, esz) * value / world / 1e9, 1),
                         path_reference_tflops=round(reference_flops_per_clip_pair(c) * value / world / 1e12, 1),
                         families=sorted([dict(name=r["name"], calls=r["calls"] // nprof, ms_per_step=round(r["total_ms"] / nprof, 4))
-                                         for r in rep], key=lambda r: -r["ms_per_step"])[:8])
+                                         for r in rep], key=lambda r: -r["ms_per_step"])[:12])
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
