@@ -62,6 +62,13 @@ int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const a
 
 int k_xrstats(const Plan& pl, const void* X, char* saved, hipStream_t st);
 int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, hipStream_t st);
+// register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
+bool tile_fast_ok(const Dims& d);
+int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
+int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 // generic helpers
 int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out,
                  float scale, hipStream_t st);

@@ -89,7 +89,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Mb = (int)round_up(d.M + 1, 8);
   d.Np = (int)round_up(d.N, 8);
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
-  int bps = std::max(1, std::min(cdiv(d.N, 64), cdiv(2048, d.S)));
+  int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(1024, d.S))));
   d.nblk_tok = bps * d.S;
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 

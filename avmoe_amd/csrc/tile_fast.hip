@@ -1,0 +1,798 @@
+// Bottleneck-space kernels, register-resident form for the shape every ViT-B/16 / HTS-AT site of the reference has:
+// bottleneck 64 in 2 conv groups (reduction 12 of 768 channels), 32 latent tokens (net_trans_v3.py:296-487).
+// Same arithmetic as the run-time-shaped kernels of tile_kernels.hip (names: oracle/algebra_ref.py), different data path:
+//
+//   * a wavefront owns 16 tokens; lane (r = lane & 15, q = lane >> 4) holds, for token r, the bottleneck entries
+//     dd = 16 c + 4 q + x  (c = 0..3 chunk, x = 0..3)  of the current expert -- exactly one 16-byte global access per chunk,
+//     so Z-space tensors go HBM <-> registers directly, no LDS staging;
+//   * every per-token mat-vec  W[tok][n] = sum_k P[tok][k] M[k][n]  is computed TRANSPOSED on the fp32 matrix pipe:
+//     A operand = M^T (lane supplies M[k(step,q)][16 ct + r], from LDS), B operand = P^T (lane supplies its own register
+//     P[r][k(step,q)]), and D^T leaves W[tok r][16 ct + 4 q + x] in the same lane layout -- so chains of mat-vecs and
+//     elementwise work never leave the register file;
+//   * sums over the bottleneck index = in-lane + 2 cross-row shuffles; sums over tokens (BatchNorm statistics) are carried
+//     in per-lane accumulators over the whole expert pass and folded once at its end (no float atomics: reproducible).
+#include "kernels.h"
+#include "device_utils.h"
+#include "prof.h"
+#include <algorithm>
+
+namespace avmoe {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int FDD = 64;     // bottleneck width of one expert (2 groups x 32)
+constexpr int FDG = 32;     // per group
+constexpr int FK = 32;      // latent tokens
+constexpr int LD32 = 36;    // leading dim of LDS matrices with 32 columns   (4*ld = 16 mod 32: conflict-free A-operand reads)
+constexpr int LD64 = 68;    // ... with 64 columns
+
+struct FastDims { int S, N, C, El, KL, KLT, KLp, KPp, NT, per; };
+
+__device__ __forceinline__ float qsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float qmax4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+__device__ __forceinline__ float rsum16(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+// an integer the optimiser cannot see through (always 0): added to LDS offsets inside the tile loops so that the per-expert
+// constants are re-read from LDS each tile instead of being hoisted into (and spilled from) registers
+__device__ __forceinline__ int opaque0() { int v = 0; asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <typename T> __device__ __forceinline__ float rndT(float v);
+template <> __device__ __forceinline__ float rndT<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rndT<__bf16>(float v) { return bf2f(f2bf(v)); }
+template <typename T> __device__ __forceinline__ float4 ldT4(const T* p);
+template <> __device__ __forceinline__ float4 ldT4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 ldT4<__bf16>(const __bf16* p) {
+  const uint2 u = *(const uint2*)p;
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void stT4(T* p, float4 v);
+template <> __device__ __forceinline__ void stT4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void stT4<__bf16>(__bf16* p, float4 v) {
+  uint2 u;
+  u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+  u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+  *(uint2*)p = u;
+}
+__device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
+__device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
+
+// column offset of chunk c (dd = 16 c + 4 q ..) of expert e inside a Z-space row [group][expert][32]
+template <int E> __device__ __forceinline__ int zcol(int c, int e, int q) { return (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q; }
+
+// W[tok r][16 ct + 4 q + x] = sum over NJ chunks of  P[r][16 j + 4 q' + x'] * M[16 j + 4 q' + x'][16 ct + r-column]
+// Ms: LDS matrix [k][ld] already offset to its first row / column block; p[j]: this lane's chunk registers.
+template <int NJ>
+__device__ __forceinline__ f32x4 mmT(const float* Ms, int ld, int col0, const float4* p, int r, int q) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* mp = Ms + (4 * q) * ld + col0 + r;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[(16 * j + x) * ld], at(p[j], x), acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// fold per-lane token-slot accumulators (acc[c][x] for dd = 16 c + 4 q + x) over the 16 token slots and the waves of the
+// block, then write colpart[blk][slot][colmap(e, dd)]
+template <int E>
+__device__ __forceinline__ void flush_cols(float4 (&acc)[4], float* s_col /* [4 waves][64] */, float* colpart, int blk, int slot, int e) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float v = rsum16(at(acc[c], x));
+      if (r == 0) s_col[wave * FDD + 16 * c + 4 * q + x] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < FDD) {
+    const int dd = threadIdx.x;
+    const float v = s_col[dd] + s_col[FDD + dd] + s_col[2 * FDD + dd] + s_col[3 * FDD + dd];
+    colpart[((long)blk * 4 + slot) * (E * FDD) + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)] = v;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ float block_scalar(float v, float* s4) {   // sum of per-wave values (already wave-uniform)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) s4[wave] = v;
+  __syncthreads();
+  return s4[0] + s4[1] + s4[2] + s4[3];
+}
+__device__ __forceinline__ float wsum_q0(float v, int q) {   // sum over the 16 lanes with q == 0 of v (others contribute 0)
+  return wave_sum(q == 0 ? v : 0.f);
+}
+
+// =====================================================================================================
+// MID backward      (BN2-moment terms + BN1/ReLU mask; algebra_ref.py MID backward)
+// =====================================================================================================
+struct FMidArgs { int relu_of_e[MAX_E]; FastDims t; int moments; };
+
+template <int E>
+__global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ dsm,
+                                                  const float* __restrict__ sdSzz, float* __restrict__ dzp, float* __restrict__ colpart) {
+  constexpr int DZ = E * FDD;
+  __shared__ float s_S[2 * FDG * LD32];
+  __shared__ float s_bn[5 * FDD];
+  __shared__ float s_col[4 * FDD];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    if (a.moments)
+      for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
+        const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
+        s_S[(gi * FDG + k) * LD32 + c] = sdSzz[(long)(gi * E + e) * FDG * FDG + k * FDG + c];
+      }
+    if (threadIdx.x < FDD) {
+      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
+      s_bn[3 * FDD + dd] = bn1[3 * DZ + col]; s_bn[4 * FDD + dd] = a.moments ? dsm[2 * DZ + col] : 0.f;
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    float4 cs0[4], cs1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long row = ((long)s * t.N + n0 + r) * DZ;
+      float4 z[4], dz[4], zp[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        z[c] = ok ? ld4(Z + row + zcol<E>(c, e, q)) : zero4();
+        dz[c] = ok ? ld4(dzp + row + zcol<E>(c, e, q)) : zero4();
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float y = at(z[c], x) * at(sc, x) + at(sh, x);
+          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gi = c >> 1, ct = c & 1;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (a.moments) w = mmT<2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+        const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), dm = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
+        float4 dy;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float zv = at(z[c], x);
+          const float zh = (zv - at(mean, x)) * at(rstd, x);
+          const float d = at(dz[c], x) + at(dm, x) + w[x];
+          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : d;
+          at(dy, x) = v;
+          at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
+        }
+        if (ok) *(float4*)(dzp + row + zcol<E>(c, e, q)) = dy;
+      }
+    }
+    flush_cols<E>(cs0, s_col, colpart, blk, 2, e);
+    flush_cols<E>(cs1, s_col, colpart, blk, 3, e);
+  }
+}
+
+// =====================================================================================================
+// POST_SMALL forward  (net_trans_v3.py:430-434,485-486)
+// =====================================================================================================
+struct FPostArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; float ln_eps; };
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
+                                                     const float* __restrict__ uvh, const float* __restrict__ probs, void* __restrict__ Apost_,
+                                                     float* __restrict__ rpmup) {
+  constexpr int DZ = E * FDD;
+  T* Apost = (T*)Apost_;
+  __shared__ float s_G[2 * FDG * LD32];
+  __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
+      const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
+      s_G[(gi * FDG + k) * LD32 + c] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];
+    }
+    if (threadIdx.x < FDD) {
+      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_c[dd] = uvh[col]; s_c[FDD + dd] = uvh[DZ + col]; s_c[2 * FDD + dd] = bn1[2 * DZ + col]; s_c[3 * FDD + dd] = bn1[3 * DZ + col];
+    }
+    float H1 = 0.f, H2 = 0.f;
+    for (int gi = 0; gi < 2; ++gi) { H1 += uvh[2 * DZ + gi * E + e]; H2 += uvh[2 * DZ + 2 * E + gi * E + e]; }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float qv = probs[(long)s * E + e] * gate;
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long tok = (long)s * t.N + n0 + r;
+      float4 zp[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 z = ok ? ld4(Z + tok * DZ + zcol<E>(c, e, q)) : zero4();
+        const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float y = at(z, x) * at(sc, x) + at(sh, x);
+          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+        }
+      }
+      float rp = 1.f, mup = 0.f;
+      if (a.ln_post) {
+        float so = 0.f, soo = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gi = c >> 1, ct = c & 1;
+          const f32x4 w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+          const float4 us = ld4(s_c + oz + 16 * c + 4 * q), vh = ld4(s_c + oz + FDD + 16 * c + 4 * q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float zv = at(zp[c], x);
+            so += zv * at(us, x);
+            soo += zv * (w[x] + 2.f * at(vh, x));
+          }
+        }
+        const float So = qsum4(so) + H1, Soo = qsum4(soo) + H2;
+        mup = So / (float)t.C;
+        rp = rsqrtf(fmaxf(Soo / (float)t.C - mup * mup, 0.f) + a.ln_eps);
+      }
+      if (ok) {
+        const float sc = qv * rp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 v = make_float4(sc * zp[c].x, sc * zp[c].y, sc * zp[c].z, sc * zp[c].w);
+          stT4<T>(Apost + (tok * 2 + (c >> 1)) * t.KPp + e * FDG + (c & 1) * 16 + 4 * q, v);
+        }
+        if (q < 2) {
+          const long base = (tok * 2 + q) * t.KPp + E * FDG + 3 * e;
+          stT<T>(Apost, base + 0, qv * rp); stT<T>(Apost, base + 1, -qv * rp * mup); stT<T>(Apost, base + 2, qv);
+        }
+        if (q == 2) { rpmup[tok * E + e] = rp; rpmup[(long)t.NT * E + tok * E + e] = mup; }
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// POST_SMALL backward
+// =====================================================================================================
+struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; };
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256, 3) kf_post_small_bwd(FPostBArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
+                                                         const float* __restrict__ uvh, const float* __restrict__ probs, const float* __restrict__ rpmup,
+                                                         const float* __restrict__ dAp, float* __restrict__ dzp, void* __restrict__ Zp_, void* __restrict__ Zw_,
+                                                         float* __restrict__ colpart, float* __restrict__ blkscal) {
+  constexpr int DZ = E * FDD;
+  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_;
+  __shared__ float s_G[2 * FDG * LD32];
+  __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
+  __shared__ float s_col[4 * FDD];
+  __shared__ float s_sc[4];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
+      const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
+      s_G[(gi * FDG + k) * LD32 + c] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];
+    }
+    if (threadIdx.x < FDD) {
+      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_c[dd] = uvh[col]; s_c[FDD + dd] = uvh[DZ + col]; s_c[2 * FDD + dd] = bn1[2 * DZ + col]; s_c[3 * FDD + dd] = bn1[3 * DZ + col];
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float qv = probs[(long)s * E + e] * gate;
+    float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
+    float4 cs0[4], cs1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long tok = (long)s * t.N + n0 + r;
+      float4 zp[4], d[4];
+      float da1 = 0.f, da2 = 0.f, da3 = 0.f, rp = 1.f, mup = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 z = ok ? ld4(Z + tok * DZ + zcol<E>(c, e, q)) : zero4();
+        d[c] = ok ? ld4(dAp + (tok * 2 + (c >> 1)) * t.KPp + e * FDG + (c & 1) * 16 + 4 * q) : zero4();
+        const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float y = at(z, x) * at(sc, x) + at(sh, x);
+          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const float* p = dAp + (tok * 2 + gi) * t.KPp + E * FDG + 3 * e;
+          da1 += p[0]; da2 += p[1]; da3 += p[2];
+        }
+        rp = rpmup[tok * E + e]; mup = rpmup[(long)t.NT * E + tok * E + e];
+      }
+      float zz = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) zz += at(d[c], x) * at(zp[c], x);
+      zz = qsum4(zz);
+      float dSo = 0.f, dSoo = 0.f;
+      if (ok) {
+        const float dq = rp * zz + rp * da1 - rp * mup * da2 + da3;
+        if (a.ln_post) {
+          const float drp = qv * zz + qv * da1 - qv * mup * da2;
+          float dmup = -qv * rp * da2;
+          const float dvarp = drp * (-0.5f) * rp * rp * rp;
+          dSoo = dvarp / (float)t.C;
+          dmup -= 2.f * mup * dvarp;
+          dSo = dmup / (float)t.C;
+        }
+        if (q == 0) { sdq += dq; sdSo += dSo; sdSoo += dSoo; }
+      }
+      const float k1 = qv * rp;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gi = c >> 1, ct = c & 1;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (a.ln_post) w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+        const float4 us = ld4(s_c + oz + 16 * c + 4 * q), vh = ld4(s_c + oz + FDD + 16 * c + 4 * q);
+        float4 o, zw;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float zv = at(zp[c], x);
+          float dzv = k1 * at(d[c], x);
+          if (a.ln_post) {
+            dzv += dSo * at(us, x) + dSoo * (2.f * w[x] + 2.f * at(vh, x));
+            at(cs0[c], x) += dSo * zv; at(cs1[c], x) += dSoo * zv;
+          }
+          at(o, x) = dzv; at(zw, x) = dSoo * zv;
+        }
+        if (ok) {
+          const long off = tok * DZ + zcol<E>(c, e, q);
+          *(float4*)(dzp + off) = o;
+          stT4<T>(Zp + off, zp[c]);
+          stT4<T>(Zw + off, zw);
+        }
+      }
+    }
+    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
+    flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
+    const float v0 = block_scalar(wave_sum(sdq), s_sc), v1 = block_scalar(wave_sum(sdSo), s_sc), v2 = block_scalar(wave_sum(sdSoo), s_sc);
+    if (threadIdx.x == 0) { float* o = blkscal + ((long)blk * E + e) * 4; o[0] = v0; o[1] = v1; o[2] = v2; }
+  }
+}
+
+// =====================================================================================================
+// PRE_SMALL forward   (net_trans_v3.py:385-395)
+// =====================================================================================================
+struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before; float ln_eps; };
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ sxs,
+                                                    const float* __restrict__ TT, const float* __restrict__ TW, const float* __restrict__ Tsum,
+                                                    const float* __restrict__ wsum, const float* __restrict__ dconst, void* __restrict__ aout_,
+                                                    float* __restrict__ rmu, float* __restrict__ colpart) {
+  constexpr int DZ = E * FDD;
+  T* aout = (T*)aout_;
+  __shared__ float s_TT[FK * LD32];
+  __shared__ float s_TW[FK * LD64];
+  __shared__ float s_tb[FK];
+  __shared__ float s_c[2 * FDD];      // wsum, dconst
+  __shared__ float s_col[4 * FDD];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = 0; e < E; ++e) {
+    const int l = a.lat_of_e[e];
+    float gv = 0.f;
+    __syncthreads();
+    if (l >= 0) {
+      gv = a.glat.p[e][0];
+      const float* tt = TT + ((long)s * t.El + l) * FK * FK;
+      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i >> 5) * LD32 + (i & 31)] = tt[i];
+      for (int i = threadIdx.x; i < FK * FDD; i += 256) {
+        const int k = i >> 6, dd = i & 63;
+        s_TW[k * LD64 + dd] = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
+      }
+      if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
+    }
+    if (threadIdx.x < FDD) {
+      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_c[dd] = wsum[col]; s_c[FDD + dd] = dconst[col];
+    }
+    __syncthreads();
+    float4 cs0[4], cs1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long tok = (long)s * t.N + n0 + r;
+      float Sx = ok ? sxs[tok] : 0.f, Sxx = ok ? sxs[t.NT + tok] : 1.f;
+      float4 z[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) z[c] = ok ? ld4(Z + tok * DZ + zcol<E>(c, e, q)) : zero4();
+      float4 av[2] = {zero4(), zero4()};
+      if (l >= 0) {
+        const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+        float4 lg[2];
+        lg[0] = ok ? ld4(L2 + lo) : zero4();
+        lg[1] = ok ? ld4(L2 + lo + 16) : zero4();
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) mx = fmaxf(mx, at(lg[j], x));
+        mx = qmax4(mx);
+        float sum = 0.f;
+        float4 ex[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { at(ex[j], x) = __expf(at(lg[j], x) - mx); sum += at(ex[j], x); }
+        sum = qsum4(sum);
+        const float inv = ok ? 1.f / sum : 0.f;
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float4 tb = ld4(s_tb + oz + 16 * j + 4 * q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float v = rndT<T>(at(ex[j], x) * inv);
+            at(av[j], x) = v;
+            u1 += v * at(tb, x); u2 += v * at(lg[j], x);
+          }
+          if (ok) stT4<T>(aout + lo + 16 * j, av[j]);
+        }
+        u1 = qsum4(u1); u2 = qsum4(u2);
+        float u3 = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 w = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) u3 += w[x] * at(av[ct], x);
+        }
+        u3 = qsum4(u3);
+        Sx += gv * (float)t.C * u1;
+        Sxx += 2.f * gv * u2 + gv * gv * u3;
+      }
+      float mu = 0.f, rr = 1.f;
+      if (a.ln_before) {
+        mu = Sx / (float)t.C;
+        rr = rsqrtf(fmaxf(Sxx / (float)t.C - mu * mu, 0.f) + a.ln_eps);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        if (l >= 0) p = mmT<2>(s_TW + oz, LD64, 16 * c, av, r, q);
+        const float4 ws = ld4(s_c + oz + 16 * c + 4 * q), dc = ld4(s_c + oz + FDD + 16 * c + 4 * q);
+        float4 o;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float zr = at(z[c], x) + gv * p[x];
+          const float zv = a.ln_before ? rr * (zr - mu * at(ws, x)) + at(dc, x) : zr;
+          at(o, x) = zv;
+          if (ok) { at(cs0[c], x) += zv; at(cs1[c], x) += zv * zv; }
+        }
+        if (ok) *(float4*)(Z + tok * DZ + zcol<E>(c, e, q)) = o;
+      }
+      if (ok && q == 0) { rmu[tok * E + e] = rr; rmu[(long)t.NT * E + tok * E + e] = mu; }
+    }
+    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
+    flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
+  }
+}
+
+// =====================================================================================================
+// PRE_SMALL backward
+// =====================================================================================================
+struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before, use_bn, bn_train; };
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ TT,
+                                                        const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
+                                                        const float* __restrict__ dconst, const void* __restrict__ ain_, const float* __restrict__ rmu,
+                                                        const float* __restrict__ bn1, const float* __restrict__ dsm, const float* __restrict__ dy_in,
+                                                        void* __restrict__ dZx_, void* __restrict__ dL2x_, void* __restrict__ aw_, void* __restrict__ ag_,
+                                                        float* __restrict__ dsxs, float* __restrict__ rs2x, float* __restrict__ colpart,
+                                                        float* __restrict__ blkscal, float* __restrict__ dtbp) {
+  constexpr int DZ = E * FDD;
+  const T* ain = (const T*)ain_;
+  T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
+  __shared__ float s_TT[FK * LD32];
+  __shared__ float s_TW[FK * LD64];     // [k][dd]
+  __shared__ float s_TWt[FDD * LD32];   // [dd][k]
+  __shared__ float s_tb[FK];
+  __shared__ float s_bn[7 * FDD];       // mean, rstd, sc, mdy, mdyz, wsum, dconst
+  __shared__ float s_col[4 * FDD];
+  __shared__ float s_sc[4];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = 0; e < E; ++e) {
+    const int l = a.lat_of_e[e];
+    float gv = 0.f;
+    __syncthreads();
+    if (l >= 0) {
+      gv = a.glat.p[e][0];
+      const float* tt = TT + ((long)s * t.El + l) * FK * FK;
+      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i >> 5) * LD32 + (i & 31)] = tt[i];
+      for (int i = threadIdx.x; i < FK * FDD; i += 256) {
+        const int k = i >> 6, dd = i & 63;
+        const float v = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
+        s_TW[k * LD64 + dd] = v;
+        s_TWt[dd * LD32 + k] = v;
+      }
+      if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
+    }
+    if (threadIdx.x < FDD) {
+      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
+      s_bn[3 * FDD + dd] = a.bn_train ? dsm[3 * DZ + col] : 0.f; s_bn[4 * FDD + dd] = a.bn_train ? dsm[4 * DZ + col] : 0.f;
+      s_bn[5 * FDD + dd] = wsum[col]; s_bn[6 * FDD + dd] = dconst[col];
+    }
+    __syncthreads();
+    float sdg = 0.f;
+    float4 cs0[4], cs1[4], ck[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    ck[0] = zero4(); ck[1] = zero4();
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long tok = (long)s * t.N + n0 + r;
+      const float rr = (a.ln_before && ok) ? rmu[tok * E + e] : 1.f;
+      const float mu = (a.ln_before && ok) ? rmu[(long)t.NT * E + tok * E + e] : 0.f;
+      const float irr = 1.f / rr;
+      // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
+      float4 dzr[4];
+      float s_dr = 0.f, s_dmu = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long off = tok * DZ + zcol<E>(c, e, q);
+        const float4 z = ok ? ld4(Z + off) : zero4();
+        const float4 dyv = ok ? ld4(dy_in + off) : zero4();
+        const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q);
+        const float4 mdy = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q), mdyz = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
+        const float4 ws = ld4(s_bn + oz + 5 * FDD + 16 * c + 4 * q), dc = ld4(s_bn + oz + 6 * FDD + 16 * c + 4 * q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          float v = 0.f;
+          if (ok) {
+            const float zv = at(z, x);
+            float dz = at(dyv, x);
+            if (a.use_bn) {
+              if (a.bn_train) dz = at(sc, x) * (dz - at(mdy, x) - (zv - at(mean, x)) * at(rstd, x) * at(mdyz, x));
+              else dz = at(sc, x) * dz;
+            }
+            if (a.ln_before) {
+              const float zc = (zv - at(dc, x)) * irr;
+              at(cs0[c], x) += dz; at(cs1[c], x) += -rr * mu * dz;
+              s_dr += dz * zc; s_dmu += dz * at(ws, x);
+              v = rr * dz;
+            } else v = dz;
+          }
+          at(dzr[c], x) = v;
+        }
+        if (ok) stT4<T>(dZx + off, dzr[c]);
+      }
+      float dSx = 0.f, dSxx = 0.f;
+      if (a.ln_before) {
+        const float sdr = qsum4(s_dr), sdm = qsum4(s_dmu);
+        float dmu = -rr * sdm;
+        const float dvar = sdr * (-0.5f) * rr * rr * rr;
+        dSxx = dvar / (float)t.C;
+        dmu -= 2.f * mu * dvar;
+        dSx = dmu / (float)t.C;
+      }
+      float accx = dSx, accxx = dSxx;
+      if (ok && q == 0) {
+        if (e != 0) { accx += dsxs[tok]; accxx += dsxs[t.NT + tok]; }
+        dsxs[tok] = accx; dsxs[t.NT + tok] = accxx;
+      }
+      if (l >= 0) {
+        const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+        float4 av[2], lg[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          av[j] = ok ? ldT4<T>(ain + lo + 16 * j) : zero4();
+          lg[j] = ok ? ld4(L2 + lo + 16 * j) : zero4();
+        }
+        float u1 = 0.f, u2 = 0.f;
+        float4 tb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          tb[j] = ld4(s_tb + oz + 16 * j + 4 * q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { u1 += at(av[j], x) * at(tb[j], x); u2 += at(av[j], x) * at(lg[j], x); }
+        }
+        u1 = qsum4(u1); u2 = qsum4(u2);
+        float dgr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
+          const f32x4 p = mmT<2>(s_TW + oz, LD64, 16 * c, av, r, q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
+        }
+        dgr = qsum4(dgr);
+        const float du1 = dSx * gv * (float)t.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
+        float u3 = 0.f, sada = 0.f;
+        float4 da[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
+          const f32x4 twd = mmT<4>(s_TWt + oz, LD32, 16 * ct, dzr, r, q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float ac = at(av[ct], x);
+            u3 += ta[x] * ac;
+            float d = 0.f;
+            if (ok) {
+              d = gv * twd[x] + du1 * at(tb[ct], x) + du2 * at(lg[ct], x) + 2.f * du3 * ta[x];
+              sada += ac * d;
+              at(ck[ct], x) += du1 * ac;
+            }
+            at(da[ct], x) = d;
+          }
+        }
+        u3 = qsum4(u3); sada = qsum4(sada);
+        if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float4 v0, v1, v2;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const float ac = at(av[j], x);
+              at(v0, x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1, x) = du3 * ac; at(v2, x) = gv * ac;
+            }
+            stT4<T>(dL2x + lo + 16 * j, v0); stT4<T>(aw_o + lo + 16 * j, v1); stT4<T>(ag_o + lo + 16 * j, v2);
+          }
+        }
+      }
+      if (e == E - 1 && ok && q == 0) {
+        stT<T>(dL2x, tok * t.KLp + t.KL, accx);
+        stT<T>(dL2x, tok * t.KLp + t.KL + 1, 1.f);
+        rs2x[tok] = 2.f * accxx;
+      }
+    }
+    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
+    flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
+    const float vg = block_scalar(wave_sum(sdg), s_sc);
+    if (threadIdx.x == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;
+    if (l >= 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float v = rsum16(at(ck[j], x));
+          if (r == 0) s_col[wave * FDD + 16 * j + 4 * q + x] = v;
+        }
+      __syncthreads();
+      if (threadIdx.x < FK) {
+        const int k = threadIdx.x;
+        dtbp[(long)blk * t.KL + (long)l * FK + k] = s_col[k] + s_col[FDD + k] + s_col[2 * FDD + k] + s_col[3 * FDD + k];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+FastDims make_fd(const Dims& d, int per) {
+  FastDims t;
+  t.S = d.S; t.N = d.N; t.C = d.C; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp; t.KPp = d.KPp; t.NT = d.NT; t.per = per;
+  return t;
+}
+void fast_grid(const Dims& d, dim3* grid, int* per) {
+  const int bps = d.nblk_tok / d.S;
+  *per = (int)round_up(cdiv(d.N, bps), 16);
+  *grid = dim3((unsigned)bps, (unsigned)d.S);
+}
+
+}  // namespace
+
+// The register-resident kernels cover exactly: bottleneck 64 in 2 groups, 32 latent tokens, 4 experts, no N x N block.
+bool tile_fast_ok(const Dims& d) {
+  return d.DD == FDD && d.dgp == FDG && d.g == 2 && d.K == FK && d.Kp == FK && d.E == 4 && !d.nxn;
+}
+
+#define LAUNCH_TE(bf16, KERN, ...)                                                                     \
+  do {                                                                                                 \
+    if (bf16) hipLaunchKernelGGL((KERN<__bf16, 4>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+    else hipLaunchKernelGGL((KERN<float, 4>), grid, dim3(256), 0, st, __VA_ARGS__);                    \
+  } while (0)
+
+int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FPreArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.t = make_fd(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
+  LAUNCH_TE(d.bf16, kf_pre_small, a, (float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
+            (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
+            (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu),
+            (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("pre_small (64/32)");
+  return OK;
+}
+
+int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FPostArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
+  LAUNCH_TE(d.bf16, kf_post_small, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
+            (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
+  AVMOE_CHECK_LAUNCH("post_small (64/32)");
+  return OK;
+}
+
+int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FPostBArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  LAUNCH_TE(d.bf16, kf_post_small_bwd, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
+            (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),
+            (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),
+            (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
+  AVMOE_CHECK_LAUNCH("post_small_bwd (64/32)");
+  return OK;
+}
+
+int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  const Dims& d = pl.d;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FMidArgs a;
+  for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
+  a.t = make_fd(d, per); a.moments = d.use_bn && d.training;
+  hipLaunchKernelGGL((kf_mid_bwd<4>), grid, dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+                     (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (float*)(scratch + pl.o_dzp),
+                     (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("mid_bwd (64/32)");
+  return OK;
+}
+
+int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FPreBArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.t = make_fd(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
+  LAUNCH_TE(d.bf16, kf_pre_small_bwd, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
+            (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum),
+            (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a), (const float*)(saved + pl.o_rmu),
+            (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_dzp),
+            (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw), (void*)(scratch + pl.o_ag),
+            (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x), (float*)(scratch + pl.o_colpart),
+            (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
+  AVMOE_CHECK_LAUNCH("pre_small_bwd (64/32)");
+  return OK;
+}
+
+}  // namespace avmoe

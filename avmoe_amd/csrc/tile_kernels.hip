@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   ProfScope ps_("k_pre_small", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e]; }
@@ -518,6 +519,7 @@ __global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* _
 int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   ProfScope ps_("k_post_small", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  if (tile_fast_ok(d)) return kf_post_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
@@ -696,7 +698,7 @@ __global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const flo
 // =====================================================================================================
 // MID backward
 // =====================================================================================================
-struct MidBTArgs { int relu_of_e[MAX_E]; TileDims t; int moments; int dbg; };
+struct MidBTArgs { int relu_of_e[MAX_E]; TileDims t; int moments; };
 
 template <typename T>
 __global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* __restrict__ Z, const float* __restrict__ bn1,
@@ -739,7 +741,6 @@ __global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* __re
       slab_load<4>(Z + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Zr, ld, lane, [](int, float v) { return v; });
       slab_load<4>(dzp + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Dt, ld, lane, [](int, float v) { return v; });
       wsync();
-      if (a.dbg & 1) goto store_phase;       // debug: I/O only
       if (a.moments) {                       // z' tile (A operand of the BN2-moment term)
         for (int ct = 0; ct * 16 < DD; ++ct) {
           const int dd = ct * 16 + r;
@@ -776,9 +777,8 @@ __global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* __re
           c0 = qsum4(c0); c1 = qsum4(c1);
           if (q == 0 && jp < dgp) { mycol[dd] += c0; mycol[DD + dd] += c1; }
         }
-    store_phase:
       wsync();
-      if (!(a.dbg & 2)) slab_store_f32(dzp + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Dt, ld, lane, [](int) { return 1.f; });
+      slab_store_f32(dzp + t0 * t.DZ, t.DZ, (long)t.E * dgp, e * dgp, t, nvalid, Dt, ld, lane, [](int) { return 1.f; });
     }
     flush_colacc(t, s_col, 2, e, colpart, blk, 2);
   }
@@ -1038,6 +1038,10 @@ static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   ProfScope ps_("k_post_small_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  if (tile_fast_ok(d)) {
+    AVMOE_TRY(kf_post_small_bwd(pl, saved, scratch, prm, st));
+    return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostBTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
@@ -1067,11 +1071,14 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
 int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   ProfScope ps_("k_mid_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  if (tile_fast_ok(d)) {
+    AVMOE_TRY(kf_mid_bwd(pl, saved, scratch, st));
+    return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
   dim3 grid; int per; tile_grid(d, &grid, &per);
   MidBTArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_td(d, per); a.moments = d.use_bn && d.training;
-  a.dbg = getenv("AVMOE_DBG_MID") ? atoi(getenv("AVMOE_DBG_MID")) : 0;
   const TileDims& t = a.t;
   const int g4 = cdiv(t.dgp, 4);
   size_t sh;
@@ -1088,6 +1095,10 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   ProfScope ps_("k_pre_small_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  if (tile_fast_ok(d)) {
+    AVMOE_TRY(kf_pre_small_bwd(pl, saved, scratch, prm, st));
+    return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreBTArgs a;
   a.first_nxn = -1;
