@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libavmoe_hip.so")
+LIB_PATH = os.environ.get("AVMOE_LIB", os.path.join(_HERE, "lib", "libavmoe_hip.so"))   # AVMOE_LIB: A/B builds (dev)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avmoe.h")
 
 F32, BF16 = 0, 1

@@ -240,8 +240,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
-  const int split = blockIdx.y % p.ksplit, b = blockIdx.y / p.ksplit;
+  // XCD-aware tile order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2),
+  // so workgroup w is given the logical tile  start(w % 8) + w / 8  -- the N-tiles of one M-tile (which share their A rows)
+  // and neighbouring M-tiles then run on the same XCD at about the same time.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7u, idx = lin >> 3, base = total >> 3, rem = total & 7u;
+    const unsigned logical = xcd * base + min(xcd, rem) + idx;
+    bx = (int)(logical % gridDim.x); by = (int)(logical / gridDim.x);
+  }
+  const int m0 = (bx / p.tiles_n) * BM, n0 = (bx % p.tiles_n) * BN;
+  const int split = by % p.ksplit, b = by / p.ksplit;
   const int b1 = b / p.nb2, b2 = b % p.nb2;
   const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2) * ESZ;
   const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2) * ESZ;
