@@ -62,6 +62,10 @@ struct GemmArgs {
 // Returns 0 on success, negative avmoe status otherwise (message through set_last_error).
 int launch_gemm(const GemmArgs& args, hipStream_t stream);
 
+// Streaming (B-stationary, persistent) kernel for token-streaming shapes; 0 = launched, 1 = shape not covered, < 0 error.
+// launch_gemm tries it first.
+int launch_gemm_stream(const GemmArgs& args, hipStream_t stream);
+
 // Bytes of fp32 slab workspace a split-K launch of `args` needs (0 when ksplit <= 1).
 size_t gemm_slab_bytes(const GemmArgs& args);
 

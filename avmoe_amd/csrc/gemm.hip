@@ -539,6 +539,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     set_last_error("gemm: bad second K segment (pair of pointers, no split-K, 16-byte aligned strides)");
     return ERR_BAD_ARG;
   }
+  {
+    static const bool nostream = getenv("AVMOE_GEMM_NOSTREAM") != nullptr;     // dev switch: A/B against the tiled engine
+    if (!nostream) {
+      const int s = launch_gemm_stream(a, stream);
+      if (s <= 0) return s;
+    }
+  }
   const int osz = d.out_bf16 ? 2 : 4;
   const int vecb = 4 * osz;    // bytes of a 4-element output vector
   d.vec_c = (a.sCj == 1) && (((uintptr_t)a.C) % vecb == 0) && ((a.sCi * osz) % vecb == 0) &&

@@ -1,0 +1,248 @@
+// Streaming form of the engine GEMM for the products that run over ALL tokens against a small shared matrix:
+//
+//   C[b2][m][n] = alpha * sum_k A[b2][m][k] B[b2][n][k]  (+ row_scale[m] * D[b2][m][n])      M ~ 10^5..10^6,  N, K <= 384
+//
+// (the grouped down projection, the fused output GEMM and dApost = dOut Bpost of the adapter site).  The tiled engine in
+// gemm.hip runs these at a fraction of HBM speed because a block's load, MFMA and store phases do not overlap and B is
+// re-staged through LDS for every tile.  Here B never moves again after the prologue:
+//
+//   * persistent blocks; wave w keeps the MFMA fragments of ITS TPW 16-column tiles of B in registers for the whole kernel
+//     (B stationary), so the LDS only carries the streamed A rows;
+//   * A row tiles (BM rows x K) go global -> registers -> LDS, two buffers, the loads of tile i+1 in flight during the
+//     MFMAs and stores of tile i: one barrier per tile;
+//   * products are computed transposed (A operand = B fragment, B operand = A fragment): lane (r, q) ends up with
+//     C[row r][4 q .. 4 q + 3] of each tile -- 8 / 16 contiguous bytes per lane, stored straight from registers.
+#include "gemm.h"
+#include "common.h"
+#include "prof.h"
+#include <algorithm>
+
+namespace avmoe {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct StreamArgs {
+  const char* A; const char* B; char* C; const char* D; const float* rs;
+  int M, N, K, tiles_m;
+  long lda, ldb, ldc, ldd, sA2, sB2, sC2, sD2, sRS2;
+  float alpha; int b_mn, out_bf16;
+};
+
+__device__ __forceinline__ float bfbits(unsigned int h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ unsigned int f2bfbits(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ u32x4 mask_tail8(u32x4 v, int valid) {     // keep the first `valid` (< 8) bf16 of a 16-byte chunk
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (2 * e >= valid) v[e] = 0u;
+    else if (2 * e + 1 >= valid) v[e] &= 0xFFFFu;
+  }
+  return v;
+}
+
+template <int KS, int TPW, int NW, int BM>
+__global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p) {
+  constexpr int NT = NW * 64, MT = BM / 16;
+  constexpr int RB = KS * 64 + 16;             // LDS bytes per A row (odd multiple of 16: conflict-free 16-byte fragment reads)
+  constexpr int STG = BM * RB;
+  constexpr int CPR = KS * 4, TOT = BM * CPR, NLD = (TOT + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int g = blockIdx.y;
+  const char* Ab = p.A + (long)g * p.sA2 * 2;
+  const char* Bb = p.B + (long)g * p.sB2 * 2;
+  const int osz = p.out_bf16 ? 2 : 4;
+  char* Cb = p.C + (long)g * p.sC2 * osz;
+  const char* Db = p.D ? p.D + (long)g * p.sD2 * 2 : nullptr;
+  const float* rsb = p.rs ? p.rs + (long)g * p.sRS2 : nullptr;
+
+  // ---- B fragments of this wave's column tiles: registers for the whole kernel ----
+  bf16x8 bfr[TPW][KS];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int n = wave * TPW * 16 + (r >> 2) * (4 * TPW) + 4 * t + (r & 3);   // row i = r of tile t <-> column n (see stores)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k0 = 32 * ks + 8 * q;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (n < p.N && k0 < p.K) {
+        if (!p.b_mn) {
+          v = *(const u32x4*)(Bb + ((long)n * p.ldb + k0) * 2);
+          if (k0 + 8 > p.K) v = mask_tail8(v, p.K - k0);
+        } else {
+          const unsigned short* bp = (const unsigned short*)Bb + (long)k0 * p.ldb + n;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned int h = (k0 + j < p.K) ? (unsigned int)bp[(long)j * p.ldb] : 0u;
+            v[j >> 1] |= (j & 1) ? (h << 16) : h;
+          }
+        }
+      }
+      bfr[t][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  u32x4 ra[NLD];
+  auto gload = [&](int tile) {
+    const int m0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * NT;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (c < TOT) {
+        const int row = c / CPR, k = (c % CPR) * 8, gm = m0 + row;
+        if (gm < p.M && k < p.K) {
+          v = *(const u32x4*)(Ab + ((long)gm * p.lda + k) * 2);
+          if (k + 8 > p.K) v = mask_tail8(v, p.K - k);
+        }
+      }
+      ra[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * NT;
+      if (c < TOT) *(u32x4*)(smem + buf * STG + (c / CPR) * RB + (c % CPR) * 16) = ra[i];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.tiles_m) { gload(tile); lstore(0); }
+  __syncthreads();
+  for (int it = 0; tile < p.tiles_m; ++it, tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < p.tiles_m) gload(nxt);
+    const char* sA = smem + (it & 1) * STG;
+    const int m0 = tile * BM;
+    // optional epilogue operand: all of this tile's D fragments are requested before the MFMAs start
+    // lane (r, q) owns C[m0 + 16 mt + r][nw0 + 4 TPW q .. + 4 TPW): tile t supplies elements 4 t .. 4 t + 3 of that run
+    const int nl = wave * TPW * 16 + 4 * TPW * q;
+    u32x2 dv[MT][TPW];
+    float rsv[MT];
+    if (Db) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 16 * mt + r;
+        rsv[mt] = (m < p.M) ? rsb[m] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          dv[mt][t] = u32x2{0u, 0u};
+          if (m < p.M && nl + 4 * t < p.N) dv[mt][t] = *(const u32x2*)(Db + ((long)m * p.ldd + nl + 4 * t) * 2);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 acc[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + ks * 64 + q * 16);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][ks], af, acc[t], 0, 0, 0);
+      }
+      const int m = m0 + 16 * mt + r;
+      if (m < p.M) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] *= p.alpha;
+          if (Db) {
+            acc[t][0] += rsv[mt] * bfbits(dv[mt][t][0] & 0xFFFFu); acc[t][1] += rsv[mt] * bfbits(dv[mt][t][0] >> 16);
+            acc[t][2] += rsv[mt] * bfbits(dv[mt][t][1] & 0xFFFFu); acc[t][3] += rsv[mt] * bfbits(dv[mt][t][1] >> 16);
+          }
+        }
+        char* cp = Cb + ((long)m * p.ldc + nl) * osz;
+        if (p.out_bf16) {
+          auto pk = [&](int t, int e) { return f2bfbits(acc[t][e]) | (f2bfbits(acc[t][e + 1]) << 16); };
+          if constexpr (TPW % 2 == 0) {                      // runs of 8 elements: 16-byte stores (N % 4 == 0)
+#pragma unroll
+            for (int t = 0; t < TPW; t += 2) {
+              if (nl + 4 * t + 4 < p.N) *(u32x4*)(cp + 8 * t) = u32x4{pk(t, 0), pk(t, 2), pk(t + 1, 0), pk(t + 1, 2)};
+              else if (nl + 4 * t < p.N) *(u32x2*)(cp + 8 * t) = u32x2{pk(t, 0), pk(t, 2)};
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+              if (nl + 4 * t < p.N) *(u32x2*)(cp + 8 * t) = u32x2{pk(t, 0), pk(t, 2)};
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            if (nl + 4 * t < p.N) *(f32x4*)(cp + 16 * t) = acc[t];
+        }
+      }
+    }
+    if (nxt < p.tiles_m) lstore((it + 1) & 1);
+    __syncthreads();
+  }
+}
+
+template <int KS, int TPW, int NW, int BM>
+int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
+  constexpr int LDS = 2 * BM * (KS * 64 + 16);
+  auto kern = gemm_stream_kernel<KS, TPW, NW, BM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (LDS > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) { set_last_error("gemm_stream: LDS attribute: %s", hipGetErrorString(e)); return ERR_LAUNCH; }
+    }
+    attr_done = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_last_error("gemm_stream: device query"); return ERR_LAUNCH; }
+    cus = prop.multiProcessorCount;
+  }
+  int gx = std::max(1, cus * per_cu / nb2);
+  gx = std::min(gx, s.tiles_m);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nb2), dim3(NW * 64), LDS, st, s);
+  AVMOE_CHECK_LAUNCH("gemm_stream");
+  return OK;
+}
+
+}  // namespace
+
+// Returns OK when the product was launched, 1 when this shape is not one the streaming kernel is built for (the caller
+// then uses the tiled engine), negative on error.
+int launch_gemm_stream(const GemmArgs& a, hipStream_t st) {
+  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.nb1 != 1 || a.ksplit > 1 || a.accumulate || a.sCj != 1 || a.A2 ||
+      a.M < 8192 || a.K > 384 || a.N > 384)
+    return 1;
+  const int osz = a.out_dtype == GEMM_BF16 ? 2 : 4;
+  if (((uintptr_t)a.C % 16) || (a.sCi * osz) % 16 || (a.sC2 * osz) % 16 || (a.N % 4)) return 1;
+  if (a.D && (a.row_scale == nullptr || ((uintptr_t)a.D % 8) || (a.sDi * 2) % 8 || (a.sD2 * 2) % 8)) return 1;
+  if (a.b_layout == K_MAJOR && (((uintptr_t)a.B % 16) || (a.ldb * 2) % 16 || (a.sB2 * 2) % 16)) return 1;
+  StreamArgs s;
+  s.A = (const char*)a.A; s.B = (const char*)a.B; s.C = (char*)a.C; s.D = (const char*)a.D; s.rs = a.row_scale;
+  s.M = a.M; s.N = a.N; s.K = a.K;
+  s.lda = a.lda; s.ldb = a.ldb; s.ldc = a.sCi; s.ldd = a.sDi; s.sA2 = a.sA2; s.sB2 = a.sB2; s.sC2 = a.sC2; s.sD2 = a.sD2; s.sRS2 = a.sRS2;
+  s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
+  const int ks = cdiv(a.K, 32), tiles = cdiv(a.N, 16);
+  const double nb = a.nb2;
+  const double abytes = (nb * a.M * (double)a.K + nb * a.N * (double)a.K) * 2.0 + nb * a.M * (double)a.N * osz + (a.D ? nb * a.M * (double)a.N * 2.0 : 0.0);
+  const double flops = 2.0 * nb * a.M * (double)a.N * a.K;
+// (K steps of 32, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X (scripts/stream_sweep.py):
+// many waves per block and ONE block per CU win for the write-heavy shapes
+#define STREAM_CASE(KS_, TPW_, NW_, BM_, PERCU_, NAME)                              \
+  if (ks <= KS_ && tiles <= TPW_ * NW_) {                                           \
+    s.tiles_m = cdiv(a.M, BM_);                                                     \
+    ProfScope ps(NAME, abytes, flops, st);                                          \
+    return launch_inst<KS_, TPW_, NW_, BM_>(s, a.nb2, PERCU_, st);                  \
+  }
+  STREAM_CASE(5, 2, 12, 64, 1, "gemm_stream_k160_n384")     // output GEMM: K = 4*32 + 12, N = 384 per group
+  STREAM_CASE(12, 2, 4, 32, 2, "gemm_stream_k384_n128")     // grouped down projection
+  STREAM_CASE(12, 1, 9, 32, 1, "gemm_stream_k384_n144")     // dApost = dOut Bpost (N = 140)
+#undef STREAM_CASE
+  return 1;
+}
+
+}  // namespace avmoe

@@ -201,3 +201,22 @@ def test_gemm_throughput_report(capsys):
                         f"{by / ms / 1e6:8.1f} GB/s")
     with capsys.disabled():
         print("\n[gemm throughput]\n" + "\n".join(rows))
+
+
+@pytest.mark.parametrize("case", [
+    dict(M=8200, N=384, K=140, b_mn=False, nb2=2, out_bf16=True),                   # output GEMM class (K tail 12, bf16 C)
+    dict(M=9001, N=128, K=384, b_mn=False, nb2=2),                                  # grouped down projection class
+    dict(M=8197, N=140, K=384, b_mn=True, nb2=2),                                   # dApost class (B MN-major, N tail)
+    dict(M=8300, N=100, K=70, b_mn=True, nb2=1, epilogue=True, out_bf16=True),      # row-scale * D epilogue
+    dict(M=8193, N=12, K=8, b_mn=False, nb2=3, epilogue=True),                      # tiny N / K
+])
+def test_streaming_kernel_shapes(case):
+    """M >= 8192 with N, K <= 384 and K-major bf16 A is served by the B-stationary streaming kernel (gemm_stream.hip);
+    the ragged M / N / K tails, both B layouts, both output types and the epilogue are checked against fp64."""
+    case = dict(case)
+    out_bf16 = case.get("out_bf16", False)
+    got, ref = _run_gemm(case.pop("M"), case.pop("N"), case.pop("K"), 1, False, case.pop("b_mn"), seed=13, **case)
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < (2e-2 if out_bf16 else 1e-4), float(err)
+    ints, ref = _run_gemm(8200, 144, 96, 1, False, True, nb2=2, exact_ints=True, seed=3)
+    assert torch.equal(ints, ref)
