@@ -27,9 +27,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct StreamArgs {
-  const char* A; const char* B; char* C; const char* D; const float* rs;
-  int M, N, K, tiles_m;
-  long lda, ldb, ldc, ldd, sA2, sB2, sC2, sD2, sRS2;
+  const char* A; const char* B; const char* A2; const char* B2; char* C; const char* D; const float* rs;
+  int Mper, nsamp, N, K, K2, tps, ntiles, contig;          // tps: row tiles per sample ; ntiles = nsamp * tps
+  long lda, ldb, lda2, ldb2, ldc, ldd;
+  long sA1, sA2, sB2, s2A1, s2A2, s2B1, s2B2, sC1, sC2, sD1, sD2, sRS1, sRS2;   // batch strides (elements): 1 = sample, 2 = group
   float alpha; int b_mn, out_bf16;
 };
 
@@ -44,27 +45,39 @@ __device__ __forceinline__ u32x4 mask_tail8(u32x4 v, int valid) {     // keep th
   return v;
 }
 
-template <int KS, int TPW, int NW, int BM>
+// One 8-element fragment of an MN-major matrix ([k][n], leading dim ld): elements k0 .. k0+7 of column n
+__device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, int n, int k0, int K) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  const unsigned short* bp = base + (long)k0 * ld + n;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned int h = (k0 + j < K) ? (unsigned int)bp[(long)j * ld] : 0u;
+    v[j >> 1] |= (j & 1) ? (h << 16) : h;
+  }
+  return v;
+}
+
+// KS / KS2: 32-wide K steps of the first / second segment (KS2 = 0: none).  The second segment's B2 is per sample
+// (MN-major) and is re-read into registers whenever the block moves on to the next sample.
+template <int KS, int KS2, int TPW, int NW, int BM>
 __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p) {
-  constexpr int NT = NW * 64, MT = BM / 16;
-  constexpr int RB = KS * 64 + 16;             // LDS bytes per A row (odd multiple of 16: conflict-free 16-byte fragment reads)
+  constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
+  constexpr int RB = KSA * 64 + 16;            // LDS bytes per A row (odd multiple of 16: conflict-free 16-byte fragment reads)
   constexpr int STG = BM * RB;
-  constexpr int CPR = KS * 4, TOT = BM * CPR, NLD = (TOT + NT - 1) / NT;
+  constexpr int CPR = KSA * 4, TOT = BM * CPR, NLD = (TOT + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int g = blockIdx.y;
-  const char* Ab = p.A + (long)g * p.sA2 * 2;
-  const char* Bb = p.B + (long)g * p.sB2 * 2;
   const int osz = p.out_bf16 ? 2 : 4;
-  char* Cb = p.C + (long)g * p.sC2 * osz;
-  const char* Db = p.D ? p.D + (long)g * p.sD2 * 2 : nullptr;
-  const float* rsb = p.rs ? p.rs + (long)g * p.sRS2 : nullptr;
+  const char* Bb = p.B + (long)g * p.sB2 * 2;
 
   // ---- B fragments of this wave's column tiles: registers for the whole kernel ----
+  // row i = r of tile t  <->  column nrow(t) ; lane (r, q) then owns the output run  nl .. nl + 4 TPW  (see the stores)
+  const int nw0 = wave * TPW * 16;
   bf16x8 bfr[TPW][KS];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int n = wave * TPW * 16 + (r >> 2) * (4 * TPW) + 4 * t + (r & 3);   // row i = r of tile t <-> column n (see stores)
+    const int n = nw0 + (r >> 2) * (4 * TPW) + 4 * t + (r & 3);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k0 = 32 * ks + 8 * q;
@@ -74,30 +87,40 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
           v = *(const u32x4*)(Bb + ((long)n * p.ldb + k0) * 2);
           if (k0 + 8 > p.K) v = mask_tail8(v, p.K - k0);
         } else {
-          const unsigned short* bp = (const unsigned short*)Bb + (long)k0 * p.ldb + n;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const unsigned int h = (k0 + j < p.K) ? (unsigned int)bp[(long)j * p.ldb] : 0u;
-            v[j >> 1] |= (j & 1) ? (h << 16) : h;
-          }
+          v = frag_mn((const unsigned short*)Bb, p.ldb, n, k0, p.K);
         }
       }
       bfr[t][ks] = __builtin_bit_cast(bf16x8, v);
     }
   }
+  bf16x8 bfr2[TPW][KS2 > 0 ? KS2 : 1];
+  int cur_s = -1;
 
   u32x4 ra[NLD];
   auto gload = [&](int tile) {
-    const int m0 = tile * BM;
+    const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
+    const char* A1 = p.A + ((long)s * p.sA1 + (long)g * p.sA2) * 2;
+    const char* A2 = KS2 > 0 ? p.A2 + ((long)s * p.s2A1 + (long)g * p.s2A2) * 2 : nullptr;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (c < TOT) {
-        const int row = c / CPR, k = (c % CPR) * 8, gm = m0 + row;
-        if (gm < p.M && k < p.K) {
-          v = *(const u32x4*)(Ab + ((long)gm * p.lda + k) * 2);
-          if (k + 8 > p.K) v = mask_tail8(v, p.K - k);
+        const int row = c / CPR, cc = c % CPR, gm = m0 + row;
+        if (gm < p.Mper) {
+          if (cc < KS * 4) {
+            const int k = cc * 8;
+            if (k < p.K) {
+              v = *(const u32x4*)(A1 + ((long)gm * p.lda + k) * 2);
+              if (k + 8 > p.K) v = mask_tail8(v, p.K - k);
+            }
+          } else if (KS2 > 0) {
+            const int k = (cc - KS * 4) * 8;
+            if (k < p.K2) {
+              v = *(const u32x4*)(A2 + ((long)gm * p.lda2 + k) * 2);
+              if (k + 8 > p.K2) v = mask_tail8(v, p.K2 - k);
+            }
+          }
         }
       }
       ra[i] = v;
@@ -111,28 +134,52 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < p.tiles_m) { gload(tile); lstore(0); }
+  // tiles of this block: interleaved over the blocks, or one contiguous range (few sample changes when B2 is per sample)
+  int tile, t_end, step;
+  if (p.contig) {
+    tile = (int)((long)p.ntiles * blockIdx.x / gridDim.x); t_end = (int)((long)p.ntiles * (blockIdx.x + 1) / gridDim.x); step = 1;
+  } else {
+    tile = blockIdx.x; t_end = p.ntiles; step = gridDim.x;
+  }
+  if (tile < t_end) { gload(tile); lstore(0); }
   __syncthreads();
-  for (int it = 0; tile < p.tiles_m; ++it, tile += gridDim.x) {
-    const int nxt = tile + gridDim.x;
-    if (nxt < p.tiles_m) gload(nxt);
+  for (int it = 0; tile < t_end; ++it, tile += step) {
+    const int nxt = tile + step;
+    if (nxt < t_end) gload(nxt);
     const char* sA = smem + (it & 1) * STG;
-    const int m0 = tile * BM;
+    const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
+    if (KS2 > 0 && s != cur_s) {
+      cur_s = s;
+      const unsigned short* B2 = (const unsigned short*)p.B2 + (long)s * p.s2B1 + (long)g * p.s2B2;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int n = nw0 + (r >> 2) * (4 * TPW) + 4 * t + (r & 3);
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          const int k0 = 32 * ks + 8 * q;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (n < p.N && k0 < p.K2) v = frag_mn(B2, p.ldb2, n, k0, p.K2);
+          bfr2[t][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+    }
+    char* Cb = p.C + ((long)s * p.sC1 + (long)g * p.sC2) * osz;
+    const char* Db = p.D ? p.D + ((long)s * p.sD1 + (long)g * p.sD2) * 2 : nullptr;
+    const float* rsb = p.rs ? p.rs + (long)s * p.sRS1 + (long)g * p.sRS2 : nullptr;
+    // lane (r, q) owns C[m0 + 16 mt + r][nl .. nl + 4 TPW): tile t supplies elements 4 t .. 4 t + 3 of that run
+    const int nl = nw0 + 4 * TPW * q;
     // optional epilogue operand: all of this tile's D fragments are requested before the MFMAs start
-    // lane (r, q) owns C[m0 + 16 mt + r][nw0 + 4 TPW q .. + 4 TPW): tile t supplies elements 4 t .. 4 t + 3 of that run
-    const int nl = wave * TPW * 16 + 4 * TPW * q;
     u32x2 dv[MT][TPW];
     float rsv[MT];
     if (Db) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + r;
-        rsv[mt] = (m < p.M) ? rsb[m] : 0.f;
+        rsv[mt] = (m < p.Mper) ? rsb[m] : 0.f;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
           dv[mt][t] = u32x2{0u, 0u};
-          if (m < p.M && nl + 4 * t < p.N) dv[mt][t] = *(const u32x2*)(Db + ((long)m * p.ldd + nl + 4 * t) * 2);
+          if (m < p.Mper && nl + 4 * t < p.N) dv[mt][t] = *(const u32x2*)(Db + ((long)m * p.ldd + nl + 4 * t) * 2);
         }
       }
     }
@@ -147,8 +194,16 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][ks], af, acc[t], 0, 0, 0);
       }
+      if constexpr (KS2 > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + (KS + ks) * 64 + q * 16);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr2[t][ks], af, acc[t], 0, 0, 0);
+        }
+      }
       const int m = m0 + 16 * mt + r;
-      if (m < p.M) {
+      if (m < p.Mper) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
 #pragma unroll
@@ -179,15 +234,15 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
         }
       }
     }
-    if (nxt < p.tiles_m) lstore((it + 1) & 1);
+    if (nxt < t_end) lstore((it + 1) & 1);
     __syncthreads();
   }
 }
 
-template <int KS, int TPW, int NW, int BM>
+template <int KS, int KS2, int TPW, int NW, int BM>
 int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
-  constexpr int LDS = 2 * BM * (KS * 64 + 16);
-  auto kern = gemm_stream_kernel<KS, TPW, NW, BM>;
+  constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM>;
   static bool attr_done = false;
   if (!attr_done) {
     if (LDS > 65536) {
@@ -203,7 +258,7 @@ int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
     cus = prop.multiProcessorCount;
   }
   int gx = std::max(1, cus * per_cu / nb2);
-  gx = std::min(gx, s.tiles_m);
+  gx = std::min(gx, s.ntiles);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nb2), dim3(NW * 64), LDS, st, s);
   AVMOE_CHECK_LAUNCH("gemm_stream");
   return OK;
@@ -214,33 +269,41 @@ int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
 // Returns OK when the product was launched, 1 when this shape is not one the streaming kernel is built for (the caller
 // then uses the tiled engine), negative on error.
 int launch_gemm_stream(const GemmArgs& a, hipStream_t st) {
-  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.nb1 != 1 || a.ksplit > 1 || a.accumulate || a.sCj != 1 || a.A2 ||
-      a.M < 8192 || a.K > 384 || a.N > 384)
+  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.ksplit > 1 || a.accumulate || a.sCj != 1 || (long)a.M * a.nb1 < 512 ||
+      a.K > 384 || a.N > 384 || (a.nb1 > 1 && (a.sB1 != 0 || a.M < 64)))
     return 1;
+  if (a.A2 && (a.K2 > 96 || a.s2A1 == 0)) return 1;
   const int osz = a.out_dtype == GEMM_BF16 ? 2 : 4;
-  if (((uintptr_t)a.C % 16) || (a.sCi * osz) % 16 || (a.sC2 * osz) % 16 || (a.N % 4)) return 1;
-  if (a.D && (a.row_scale == nullptr || ((uintptr_t)a.D % 8) || (a.sDi * 2) % 8 || (a.sD2 * 2) % 8)) return 1;
+  if (((uintptr_t)a.C % 16) || (a.sCi * osz) % 16 || (a.sC1 * osz) % 16 || (a.sC2 * osz) % 16 || (a.N % 4)) return 1;
+  if (a.D && (a.row_scale == nullptr || ((uintptr_t)a.D % 8) || (a.sDi * 2) % 8 || (a.sD1 * 2) % 8 || (a.sD2 * 2) % 8)) return 1;
   if (a.b_layout == K_MAJOR && (((uintptr_t)a.B % 16) || (a.ldb * 2) % 16 || (a.sB2 * 2) % 16)) return 1;
   StreamArgs s;
-  s.A = (const char*)a.A; s.B = (const char*)a.B; s.C = (char*)a.C; s.D = (const char*)a.D; s.rs = a.row_scale;
-  s.M = a.M; s.N = a.N; s.K = a.K;
-  s.lda = a.lda; s.ldb = a.ldb; s.ldc = a.sCi; s.ldd = a.sDi; s.sA2 = a.sA2; s.sB2 = a.sB2; s.sC2 = a.sC2; s.sD2 = a.sD2; s.sRS2 = a.sRS2;
+  s.A = (const char*)a.A; s.B = (const char*)a.B; s.A2 = (const char*)a.A2; s.B2 = (const char*)a.B2; s.C = (char*)a.C;
+  s.D = (const char*)a.D; s.rs = a.row_scale;
+  s.Mper = a.M; s.nsamp = a.nb1; s.N = a.N; s.K = a.K; s.K2 = a.A2 ? a.K2 : 0;
+  s.lda = a.lda; s.ldb = a.ldb; s.lda2 = a.lda2; s.ldb2 = a.ldb2; s.ldc = a.sCi; s.ldd = a.sDi;
+  s.sA1 = a.sA1; s.sA2 = a.sA2; s.sB2 = a.sB2; s.s2A1 = a.s2A1; s.s2A2 = a.s2A2; s.s2B1 = a.s2B1; s.s2B2 = a.s2B2;
+  s.sC1 = a.sC1; s.sC2 = a.sC2; s.sD1 = a.sD1; s.sD2 = a.sD2; s.sRS1 = a.sRS1; s.sRS2 = a.sRS2;
   s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
-  const int ks = cdiv(a.K, 32), tiles = cdiv(a.N, 16);
-  const double nb = a.nb2;
-  const double abytes = (nb * a.M * (double)a.K + nb * a.N * (double)a.K) * 2.0 + nb * a.M * (double)a.N * osz + (a.D ? nb * a.M * (double)a.N * 2.0 : 0.0);
-  const double flops = 2.0 * nb * a.M * (double)a.N * a.K;
-// (K steps of 32, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X (scripts/stream_sweep.py):
-// many waves per block and ONE block per CU win for the write-heavy shapes
-#define STREAM_CASE(KS_, TPW_, NW_, BM_, PERCU_, NAME)                              \
-  if (ks <= KS_ && tiles <= TPW_ * NW_) {                                           \
-    s.tiles_m = cdiv(a.M, BM_);                                                     \
+  s.contig = a.A2 != nullptr;
+  const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);
+  const double nb = (double)a.nb1 * a.nb2;
+  const double abytes = (nb * a.M * (double)(a.K + s.K2) + (double)a.nb2 * a.N * (double)a.K + nb * a.N * (double)s.K2) * 2.0 +
+                        nb * a.M * (double)a.N * osz + (a.D ? nb * a.M * (double)a.N * 2.0 : 0.0);
+  const double flops = 2.0 * nb * a.M * (double)a.N * (a.K + s.K2);
+// (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
+// (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
+#define STREAM_CASE(COND, KS_, KS2_, TPW_, NW_, BM_, PERCU_, NAME)                  \
+  if ((COND) && ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {   \
+    s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                               \
     ProfScope ps(NAME, abytes, flops, st);                                          \
-    return launch_inst<KS_, TPW_, NW_, BM_>(s, a.nb2, PERCU_, st);                  \
+    return launch_inst<KS_, KS2_, TPW_, NW_, BM_>(s, a.nb2, PERCU_, st);            \
   }
-  STREAM_CASE(5, 2, 12, 64, 1, "gemm_stream_k160_n384")     // output GEMM: K = 4*32 + 12, N = 384 per group
-  STREAM_CASE(12, 2, 4, 32, 2, "gemm_stream_k384_n128")     // grouped down projection
-  STREAM_CASE(12, 1, 9, 32, 1, "gemm_stream_k384_n144")     // dApost = dOut Bpost (N = 140)
+  STREAM_CASE(true, 5, 0, 2, 12, 64, 1, "gemm_stream_k160_n384")          // output GEMM: K = 4*32 + 12, N = 384 per group
+  STREAM_CASE(true, 12, 0, 2, 4, 32, 2, "gemm_stream_k384_n128")          // grouped down projection
+  STREAM_CASE(true, 12, 0, 1, 9, 32, 1, "gemm_stream_k384_n144")          // dApost = dOut Bpost (N = 140)
+  STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, 1, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
+  STREAM_CASE(true, 4, 3, 2, 12, 32, 1, "gemm_stream_k128+96_n384r")      // ... ragged frames
 #undef STREAM_CASE
   return 1;
 }

@@ -16,7 +16,7 @@ CASES = {
     "fast_noln_nogate": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", ln_before=False,
                                       ln_post=False, use_gate=False), S=3),
     "fast_nobn": dict(cfg=dict(Cx=128, Nx=97, Cy=64, Ny=40, reduction=2, groups=2, K=32, variant="ave", use_bn=False), S=4),
-    "fast_avs_lb": dict(cfg=dict(Cx=128, Nx=260, Cy=128, Ny=33, reduction=2, groups=2, K=32, variant="avs", lb_loss=True), S=3),
+    "fast_avs_lb": dict(cfg=dict(Cx=128, Nx=256, Cy=128, Ny=33, reduction=2, groups=2, K=32, variant="avs", lb_loss=True), S=3),
     "fast_e3p1": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=3, E_s=1), S=2),
     "fast_e1p3": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=1, E_s=3), S=2),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
