@@ -58,6 +58,33 @@ template <> __device__ __forceinline__ void stT4<__bf16>(__bf16* p, float4 v) {
   u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
   *(uint2*)p = u;
 }
+// ---- 32-wide bf16 segments (one expert's 32 bottleneck entries of a group / one latent slot's 32 tokens) as ONE 16-byte access
+// per lane: lanes q and q^1 trade quads with v_permlane16_swap, so that lane q even holds entries 4q .. 4q+7 of the first
+// 16-chunk and lane q odd entries 4(q-1) .. 4(q-1)+7 of the second -- the four q lanes cover the 64-byte segment contiguously.
+// (fp32 tensors keep their two 16-byte accesses per lane.)  The swap is its own inverse: loads use it the other way round.
+__device__ __forceinline__ int seg_off8(int q) { return (q & 1) * 16 + (q >> 1) * 8; }
+template <typename T> __device__ __forceinline__ void st_seg(T* seg, const float4& c0, const float4& c1, int q);
+template <> __device__ __forceinline__ void st_seg<float>(float* seg, const float4& c0, const float4& c1, int q) {
+  *(float4*)(seg + 4 * q) = c0; *(float4*)(seg + 16 + 4 * q) = c1;
+}
+template <> __device__ __forceinline__ void st_seg<__bf16>(__bf16* seg, const float4& c0, const float4& c1, int q) {
+  const unsigned a0 = (unsigned)f2bf(c0.x) | ((unsigned)f2bf(c0.y) << 16), a1 = (unsigned)f2bf(c0.z) | ((unsigned)f2bf(c0.w) << 16);
+  const unsigned b0 = (unsigned)f2bf(c1.x) | ((unsigned)f2bf(c1.y) << 16), b1 = (unsigned)f2bf(c1.z) | ((unsigned)f2bf(c1.w) << 16);
+  const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+  *(uint4*)(seg + seg_off8(q)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+}
+template <typename T> __device__ __forceinline__ void ld_seg(const T* seg, float4& c0, float4& c1, int q);
+template <> __device__ __forceinline__ void ld_seg<float>(const float* seg, float4& c0, float4& c1, int q) {
+  c0 = *(const float4*)(seg + 4 * q); c1 = *(const float4*)(seg + 16 + 4 * q);
+}
+template <> __device__ __forceinline__ void ld_seg<__bf16>(const __bf16* seg, float4& c0, float4& c1, int q) {
+  const uint4 u = *(const uint4*)(seg + seg_off8(q));
+  const auto s0 = __builtin_amdgcn_permlane16_swap(u.x, u.z, false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(u.y, u.w, false, false);
+  c0 = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u), __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u));
+  c1 = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u));
+}
 __device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
 __device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
 
@@ -254,9 +281,10 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float
       if (ok) {
         const float sc = qv * rp;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 v = make_float4(sc * zp[c].x, sc * zp[c].y, sc * zp[c].z, sc * zp[c].w);
-          stT4<T>(Apost + (tok * 2 + (c >> 1)) * t.KPp + e * FDG + (c & 1) * 16 + 4 * q, v);
+        for (int gi = 0; gi < 2; ++gi) {
+          const float4 v0 = make_float4(sc * zp[2 * gi].x, sc * zp[2 * gi].y, sc * zp[2 * gi].z, sc * zp[2 * gi].w);
+          const float4 v1 = make_float4(sc * zp[2 * gi + 1].x, sc * zp[2 * gi + 1].y, sc * zp[2 * gi + 1].z, sc * zp[2 * gi + 1].w);
+          st_seg<T>(Apost + (tok * 2 + gi) * t.KPp + e * FDG, v0, v1, q);
         }
         if (q < 2) {
           const long base = (tok * 2 + q) * t.KPp + E * FDG + 3 * e;
@@ -357,7 +385,7 @@ __global__ void __launch_bounds__(256, 3) kf_post_small_bwd(FPostBArgs a, const 
         f32x4 w = {0.f, 0.f, 0.f, 0.f};
         if (a.ln_post) w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
         const float4 us = ld4(s_c + oz + 16 * c + 4 * q), vh = ld4(s_c + oz + FDD + 16 * c + 4 * q);
-        float4 o, zw;
+        float4 o;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const float zv = at(zp[c], x);
@@ -366,13 +394,18 @@ __global__ void __launch_bounds__(256, 3) kf_post_small_bwd(FPostBArgs a, const 
             dzv += dSo * at(us, x) + dSoo * (2.f * w[x] + 2.f * at(vh, x));
             at(cs0[c], x) += dSo * zv; at(cs1[c], x) += dSoo * zv;
           }
-          at(o, x) = dzv; at(zw, x) = dSoo * zv;
+          at(o, x) = dzv;
         }
-        if (ok) {
-          const long off = tok * DZ + zcol<E>(c, e, q);
-          *(float4*)(dzp + off) = o;
-          stT4<T>(Zp + off, zp[c]);
-          stT4<T>(Zw + off, zw);
+        if (ok) *(float4*)(dzp + tok * DZ + zcol<E>(c, e, q)) = o;
+      }
+      if (ok) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const long seg = tok * DZ + gi * (E * FDG) + e * FDG;
+          const float4& z0 = zp[2 * gi]; const float4& z1 = zp[2 * gi + 1];
+          st_seg<T>(Zp + seg, z0, z1, q);
+          st_seg<T>(Zw + seg, make_float4(dSoo * z0.x, dSoo * z0.y, dSoo * z0.z, dSoo * z0.w),
+                    make_float4(dSoo * z1.x, dSoo * z1.y, dSoo * z1.z, dSoo * z1.w), q);
         }
       }
     }
@@ -464,8 +497,8 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
             at(av[j], x) = v;
             u1 += v * at(tb, x); u2 += v * at(lg[j], x);
           }
-          if (ok) stT4<T>(aout + lo + 16 * j, av[j]);
         }
+        if (ok) st_seg<T>(aout + tok * t.KLp + (long)l * FK, av[0], av[1], q);
         u1 = qsum4(u1); u2 = qsum4(u2);
         float u3 = 0.f;
 #pragma unroll
@@ -597,7 +630,10 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const fl
           }
           at(dzr[c], x) = v;
         }
-        if (ok) stT4<T>(dZx + off, dzr[c]);
+      }
+      if (ok) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
       }
       float dSx = 0.f, dSxx = 0.f;
       if (a.ln_before) {
@@ -616,11 +652,10 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const fl
       if (l >= 0) {
         const long lo = tok * t.KLp + (long)l * FK + 4 * q;
         float4 av[2], lg[2];
+        av[0] = zero4(); av[1] = zero4();
+        if (ok) ld_seg<T>(ain + tok * t.KLp + (long)l * FK, av[0], av[1], q);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          av[j] = ok ? ldT4<T>(ain + lo + 16 * j) : zero4();
-          lg[j] = ok ? ld4(L2 + lo + 16 * j) : zero4();
-        }
+        for (int j = 0; j < 2; ++j) lg[j] = ok ? ld4(L2 + lo + 16 * j) : zero4();
         float u1 = 0.f, u2 = 0.f;
         float4 tb[2];
 #pragma unroll
@@ -661,16 +696,16 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const fl
         u3 = qsum4(u3); sada = qsum4(sada);
         if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
         if (ok) {
+          float4 v0[2], v1[2], v2[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            float4 v0, v1, v2;
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const float ac = at(av[j], x);
-              at(v0, x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1, x) = du3 * ac; at(v2, x) = gv * ac;
+              at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
             }
-            stT4<T>(dL2x + lo + 16 * j, v0); stT4<T>(aw_o + lo + 16 * j, v1); stT4<T>(ag_o + lo + 16 * j, v2);
-          }
+          const long so = tok * t.KLp + (long)l * FK;
+          st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
         }
       }
       if (e == E - 1 && ok && q == 0) {
