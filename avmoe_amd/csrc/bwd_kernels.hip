@@ -1,6 +1,7 @@
 // Backward bottleneck-space kernels.  Every formula is the one in oracle/algebra_ref.py::AlgebraRef.backward
 // (validated there against autograd); stage names match.  Full-width tensors are only touched by GEMMs.
 #include "kernels.h"
+#include "moe_run.h"
 #include "device_utils.h"
 #include "prof.h"
 #include "gemm.h"
@@ -217,31 +218,36 @@ __global__ void kk_router_bwd_c(const float* drin, void* drinT_, int bf16, void*
   }
 }
 // weight gradients: thread per weight element, loop over frames
-__global__ void kk_router_bwd_b(int S, int E, int C2, const float* rbw, const float* rin, const float* rh1, const float* rh2,
-                                float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
+__global__ void __launch_bounds__(256) kk_router_bwd_b(int S, int E, int C2, const float* rbw, const float* rin, const float* rh1, const float* rh2,
+                                                       float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
+  // dW1 = dh1^T rin is an engine GEMM (k_router_bwd); here the small layers: one output per lane, 4 frame streams per
+  // output, combined through LDS in a fixed order
+  __shared__ float red[4][64];
   const float* dh1 = rbw;
   const float* dh2 = rbw + (long)S * (128 + C2);
   const float* dlog = rbw + (long)S * (128 + C2 + 32);
-  const long n1 = 128L * C2, n2 = 32 * 128, n3 = (long)E * 32, nb = 128 + 32 + E;
-  for (long i = n1 + (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + nb; i += (long)gridDim.x * 256) {
-    float acc = 0.f;
-    if (i < n1) {
-      continue;                                    // dW1 = dh1^T rin is an engine GEMM (k_router_bwd)
-    } else if (i < n1 + n2) {
-      const long k = i - n1; const int j = (int)(k / 128), c = (int)(k % 128);
-      for (int s = 0; s < S; ++s) acc += dh2[(long)s * 32 + j] * rh1[(long)s * 128 + c];
-      if (gW2) gW2[k] = acc;
-    } else if (i < n1 + n2 + n3) {
-      const long k = i - n1 - n2; const int j = (int)(k / 32), c = (int)(k % 32);
-      for (int s = 0; s < S; ++s) acc += dlog[(long)s * E + j] * rh2[(long)s * 32 + c];
-      if (gW3) gW3[k] = acc;
-    } else {
-      const long k = i - n1 - n2 - n3;
-      if (k < 128) { for (int s = 0; s < S; ++s) acc += dh1[(long)s * 128 + k]; if (gb1) gb1[k] = acc; }
-      else if (k < 160) { for (int s = 0; s < S; ++s) acc += dh2[(long)s * 32 + (k - 128)]; if (gb2) gb2[k - 128] = acc; }
-      else { for (int s = 0; s < S; ++s) acc += dlog[(long)s * E + (k - 160)]; if (gb3) gb3[k - 160] = acc; }
-    }
+  const int n2 = 32 * 128, n3 = E * 32, nb = 128 + 32 + E;
+  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + l;
+  float acc = 0.f;
+  float* dst = nullptr;
+  if (i < n2) {
+    const int j = i / 128, c = i % 128;
+    for (int s = u; s < S; s += 4) acc += dh2[(long)s * 32 + j] * rh1[(long)s * 128 + c];
+    if (gW2) dst = gW2 + i;
+  } else if (i < n2 + n3) {
+    const int k = i - n2, j = k / 32, c = k % 32;
+    for (int s = u; s < S; s += 4) acc += dlog[(long)s * E + j] * rh2[(long)s * 32 + c];
+    if (gW3) dst = gW3 + k;
+  } else if (i < n2 + n3 + nb) {
+    const int k = i - n2 - n3;
+    if (k < 128) { for (int s = u; s < S; s += 4) acc += dh1[(long)s * 128 + k]; if (gb1) dst = gb1 + k; }
+    else if (k < 160) { for (int s = u; s < S; s += 4) acc += dh2[(long)s * 32 + (k - 128)]; if (gb2) dst = gb2 + (k - 128); }
+    else { for (int s = u; s < S; s += 4) acc += dlog[(long)s * E + (k - 160)]; if (gb3) dst = gb3 + (k - 160); }
   }
+  red[u][l] = acc;
+  __syncthreads();
+  if (u == 0 && dst) *dst = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                  const float* lb_grad, hipStream_t st) {
@@ -259,7 +265,7 @@ int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
     GemmArgs g;
     g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
     g.A = dh1; g.B = prm.r0_w; g.C = drin;
-    g.M = d.S; g.N = 2 * d.C; g.K = 128; g.lda = 128; g.b_layout = MN_MAJOR; g.ldb = 2L * d.C; g.sCi = 2L * d.C;
+    g.M = d.S; g.N = 2 * d.C; g.K = 128; g.lda = 128; g.b_layout = MN_MAJOR; g.ldb = 2L * d.C; g.sCi = 2L * d.C; g.tile = 64;
     AVMOE_TRY(launch_gemm(g, st));
   }
   hipLaunchKernelGGL(kk_router_bwd_c, dim3(grid1db((long)d.S * 2 * d.C)), dim3(256), 0, st, (const float*)drin, (void*)(scratch + pl.o_drinT),
@@ -269,10 +275,10 @@ int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
     g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
     g.A = dh1; g.B = saved + pl.o_rin; g.C = grads.r0_w;
     g.M = 128; g.N = 2 * d.C; g.K = d.S; g.a_layout = g.b_layout = MN_MAJOR; g.lda = 128; g.ldb = 2L * d.C; g.sCi = 2L * d.C;
+    g.tile = 64; g.slabs = (float*)(scratch + pl.o_slabs); g.ksplit = choose_ksplit(g, slab_floats(d));
     AVMOE_TRY(launch_gemm(g, st));
   }
-  const long tot = 128L * 2 * d.C + 32 * 128 + (long)d.E * 32 + 160 + d.E;
-  hipLaunchKernelGGL(kk_router_bwd_b, dim3(grid1db(32 * 128 + (long)d.E * 32 + 160 + d.E)), dim3(256), 0, st, d.S, d.E, 2 * d.C, (const float*)(scratch + pl.o_rbw),
+  hipLaunchKernelGGL(kk_router_bwd_b, dim3((unsigned)cdiv(32 * 128 + d.E * 32 + 160 + d.E, 64)), dim3(256), 0, st, d.S, d.E, 2 * d.C, (const float*)(scratch + pl.o_rbw),
                      (const float*)(saved + pl.o_rin), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
                      grads.r0_w, grads.r0_b, grads.r2_w, grads.r2_b, grads.r4_w, grads.r4_b);
   AVMOE_CHECK_LAUNCH("router_bwd");
@@ -342,15 +348,27 @@ __global__ void __launch_bounds__(256) kk_finish_dT(const float* dT, const float
     }
   }
 }
-// dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)      (thread per (kc, c); frames looped, coalesced over c)
-__global__ void kk_dT0(const float* dT, const float* dtbar, float* dT0, int S, int KL, int C) {
+// dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)   block = 64 columns x 4 frame streams (two loads in flight each),
+// combined through LDS in a fixed order
+__global__ void __launch_bounds__(256) kk_dT0(const float* dT, const float* dtbar, float* dT0, int S, int KL, int C) {
+  __shared__ float red[4][64];
   const long n1 = (long)KL * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += (long)gridDim.x * 256) {
+  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + l;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n1) {
     const int kc = (int)(i / C);
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] / (float)C;
-    dT0[i] = acc;
+    const float ic = 1.f / (float)C;
+    int s = u;
+    for (; s + 4 < S; s += 8) {
+      a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
+      a1 += dT[(long)(s + 4) * n1 + i] + dtbar[(long)(s + 4) * KL + kc] * ic;
+    }
+    for (; s < S; s += 4) a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
   }
+  red[u][l] = a0 + a1;
+  __syncthreads();
+  if (u == 0 && i < n1) dT0[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 // drw[c] = sum_r dTy[r][c] abx[r] ; dbf[c] = sum_r dTy[r][c]   over the S*Kcyb rows r, in two stages:
 // grid (ceil(C/256), nchunk) -> rowpart[chunk][2][C], then a sum over chunks.
@@ -371,30 +389,20 @@ __global__ void __launch_bounds__(256) kk_dTy_colsums_a(const void* dTy_, const 
   rowpart[((long)blockIdx.y * 2 + 0) * C + c] = drw;
   rowpart[((long)blockIdx.y * 2 + 1) * C + c] = dbf;
 }
-// dBmT = T([dBm | dabx | 0]) ; dwbar[m] = sum_s dBm[s][Kcy][m] ; dbcbar = sum_s dabx[s][Kcy]
+// dBmT = T([dBm | dabx | 0])   (one block per (frame, latent row));  dwbar[m] = sum_s dBm[s][Kcy][m] and
+// dbcbar = sum_s dabx[s][Kcy] are column sums over the frames (k_prep_dBm)
 template <typename T>
-__global__ void kk_prep_dBm(const float* dBm, const float* dabx, void* dBmT_, float* dvec, int S, int Kcy, int Kcyb, int M, int Mb,
-                            int C) {
+__global__ void __launch_bounds__(256) kk_prep_dBm(const float* dBm, const float* dabx, void* dBmT_, int Kcy, int Kcyb, int M, int Mb) {
   T* dBmT = (T*)dBmT_;
-  const long tot = (long)S * Kcyb * Mb;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot + Mb + 1; i += (long)gridDim.x * 256) {
-    if (i < tot) {
-      const int m = (int)(i % Mb);
-      const long row = i / Mb;
-      const int q = (int)(row % Kcyb);
-      float v = 0.f;
-      if (q < Kcy) v = m < M ? dBm[i] : (m == M ? dabx[row] : 0.f);
-      stT<T>(dBmT, i, v);
-    } else if (i < tot + Mb) {
-      const int m = (int)(i - tot);
-      float acc = 0.f;
-      if (m < M) for (int s = 0; s < S; ++s) acc += dBm[((long)s * Kcyb + Kcy) * Mb + m];
-      dvec[2 * C + m] = acc;
-    } else {
-      float acc = 0.f;
-      for (int s = 0; s < S; ++s) acc += dabx[(long)s * Kcyb + Kcy];
-      dvec[2 * C + Mb] = acc;
-    }
+  const long row = blockIdx.x;
+  const int q = (int)(row % Kcyb);
+  const float* src = dBm + row * Mb;
+  T* dst = dBmT + row * Mb;
+  const float ab = q < Kcy ? dabx[row] : 0.f;
+  for (int m = threadIdx.x; m < Mb; m += 256) {
+    float v = 0.f;
+    if (q < Kcy) v = m < M ? src[m] : (m == M ? ab : 0.f);
+    stT<T>(dst, m, v);
   }
 }
 // dqr[kc] = sum_{s,n} dL1 bc[n] ; dqb[kc] = sum_{s,n} dL1     (partials per (s,kc) row, then over s)
@@ -531,7 +539,7 @@ int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
              (const float*)(scratch + pl.o_dT), (const float*)(scratch + pl.o_dtbar), drin, (const float*)(saved + pl.o_rw),
              (void*)(scratch + pl.o_dTy), (void*)(scratch + pl.o_dTx), (float*)(scratch + pl.o_dabx), d.S, d.KL, d.Kcy, d.Kcyb, d.Kcx, d.C);
   if (d.KL > 0)
-    hipLaunchKernelGGL(kk_dT0, dim3(grid1db((long)d.KL * d.C, 8192)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
+    hipLaunchKernelGGL(kk_dT0, dim3((unsigned)cdiv((long)d.KL * d.C, 64)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
                        (const float*)(scratch + pl.o_dtbar), (float*)(scratch + pl.o_dT0), d.S, d.KL, d.C);
   {
     const long nrows = (long)d.S * d.Kcyb;
@@ -547,11 +555,16 @@ int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
 }
 int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
   const Dims& d = pl.d;
-  const long tot = (long)d.S * d.Kcyb * d.Mb + d.Mb + 1;
-  DISPATCH_T(d.bf16, kk_prep_dBm, dim3(grid1db(tot)), dim3(256), 0, st, (const float*)(scratch + pl.o_dBm),
-             (const float*)(scratch + pl.o_dabx), (void*)(scratch + pl.o_dBmT), (float*)(scratch + pl.o_dvec), d.S, d.Kcy, d.Kcyb, d.M,
-             d.Mb, d.C);
+  const float* dBm = (const float*)(scratch + pl.o_dBm);
+  const float* dabx = (const float*)(scratch + pl.o_dabx);
+  float* dvec = (float*)(scratch + pl.o_dvec);
+  DISPATCH_T(d.bf16, kk_prep_dBm, dim3((unsigned)(d.S * d.Kcyb)), dim3(256), 0, st, dBm, dabx, (void*)(scratch + pl.o_dBmT), d.Kcy, d.Kcyb,
+             d.M, d.Mb);
   AVMOE_CHECK_LAUNCH("prep_dBm");
+  // dwbar (row Kcy of every frame's dBm), zero in the padding m >= M ; dbcbar
+  AVMOE_TRY(k_fill_f32(dvec + 2 * d.C, d.Mb + 1, 0.f, st));
+  AVMOE_TRY(k_colsum_f32(dBm + (long)d.Kcy * d.Mb, d.S, d.M, (long)d.Kcyb * d.Mb, 1, 0, dvec + 2 * d.C, 0, 1.f, st));
+  AVMOE_TRY(k_colsum_f32(dabx + d.Kcy, d.S, 1, d.Kcyb, 1, 0, dvec + 2 * d.C + d.Mb, 0, 1.f, st));
   return OK;
 }
 int k_dqrqb(const Plan& pl, char* scratch, const float* bc, hipStream_t st) {

@@ -3,6 +3,7 @@
 //
 // Buffers of the operand type T (float | __bf16) are passed as void* and cast inside the kernel.
 #include "kernels.h"
+#include "moe_run.h"
 #include "device_utils.h"
 #include "prof.h"
 #include "gemm.h"
@@ -42,31 +43,40 @@ int k_fill_f32(float* p, long n, float v, hipStream_t st) {
   return OK;
 }
 
-// Deterministic column sums  out[slot][c] = scale * sum_r in[slot*slot_in + r*row_stride + c]:
-// grid (ceil(ncol/64), nslot), 1024 threads; wave w adds the rows r = w (mod 16) of its 64 columns (coalesced,
-// independent loads), then the 16 waves are combined in double through LDS.  No float atomics anywhere.
-__global__ void __launch_bounds__(1024) kk_colsum_f32(const float* in, long R, int ncol, long row_stride, long slot_in, float* out,
+// Deterministic column sums  out[slot][c] = scale * sum_r in[slot*slot_in + r*row_stride + c]   (no float atomics anywhere).
+// A block owns CW columns; its threads form NS = blockDim / CW row streams (stream k adds rows k, k + NS, ..., four
+// independent loads in flight), combined in double through LDS in a fixed order.  Many rows: CW = 16, 64 streams per block
+// (short serial chains, ncol/16 blocks); few rows: CW = 64, 4 streams.
+template <int CW, int NTHR>
+__global__ void __launch_bounds__(NTHR) kk_colsum_f32(const float* in, long R, int ncol, long row_stride, long slot_in, float* out,
                                                       long slot_out, float scale) {
-  __shared__ double red[16][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
-  const float* p = in + (long)blockIdx.y * slot_in;
-  float acc = 0.f;
-  if (col < ncol)
-    for (long r = wave; r < R; r += 16) acc += p[r * row_stride + col];
-  red[wave][lane] = acc;
+  constexpr int NS = NTHR / CW;
+  __shared__ double red[NS][CW];
+  const int c = threadIdx.x % CW, k = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + c;
+  const float* p = in + (long)blockIdx.y * slot_in + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < ncol) {
+    long r = k;
+    for (; r + 3L * NS < R; r += 4L * NS) {
+      a0 += p[r * row_stride]; a1 += p[(r + NS) * row_stride]; a2 += p[(r + 2L * NS) * row_stride]; a3 += p[(r + 3L * NS) * row_stride];
+    }
+    for (; r < R; r += NS) a0 += p[r * row_stride];
+  }
+  red[k][c] = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
   __syncthreads();
-  if (wave == 0 && col < ncol) {
+  if (k == 0 && col < ncol) {
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    for (int w = 0; w < NS; ++w) s += red[w][c];
     out[(long)blockIdx.y * slot_out + col] = (float)(s * scale);
   }
 }
 int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out, float scale,
                  hipStream_t st) {
   if (ncol <= 0 || nslot <= 0) return OK;
-  hipLaunchKernelGGL(kk_colsum_f32, dim3(cdiv(ncol, 64), nslot), dim3(1024), 0, st, in, R, ncol, row_stride, slot_in, out, slot_out, scale);
+  if (R >= 128) hipLaunchKernelGGL((kk_colsum_f32<16, 1024>), dim3(cdiv(ncol, 16), nslot), dim3(1024), 0, st, in, R, ncol, row_stride, slot_in, out, slot_out, scale);
+  else hipLaunchKernelGGL((kk_colsum_f32<64, 256>), dim3(cdiv(ncol, 64), nslot), dim3(256), 0, st, in, R, ncol, row_stride, slot_in, out, slot_out, scale);
   AVMOE_CHECK_LAUNCH("colsum_f32");
   return OK;
 }
@@ -256,14 +266,15 @@ int k_rowstats(int bf16, const void* X, long rows, int C, float* out, hipStream_
 }
 
 // One pass over X: per-token sum / sum of squares (LayerNorm) AND per-block column partial sums (router mean).
-// grid (nchunk, S); wave per row, lanes own 16-byte column vectors.  xpart[s][chunk][C].
+// grid (nchunk, S); 16 lanes per row (a wave reads 4 rows at once, every lane 16-byte vectors lane, lane+16, ..), two row
+// quartets in flight per wave; row reduction = 4 shuffles inside the 16-lane group.  xpart[s][chunk][C].
 template <typename T>
 __global__ void __launch_bounds__(256) kk_xstats(const void* X_, int N, int C, int rows_per_blk, float* sx, long NT, float* xpart) {
   const T* X = (const T*)X_;
   constexpr int EPV = 16 / sizeof(T);
-  constexpr int NV = 6;                                 // C <= 64 * NV * EPV
-  __shared__ float s_col[4][64 * NV * 8 > 3072 ? 3072 : 64 * NV * 8];
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NV = 96 / EPV;                          // C <= 16 * NV * EPV = 1536
+  __shared__ float s_col[4][1536];
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = lane & 15, grp = lane >> 4;
   const int n0 = blockIdx.x * rows_per_blk, n1 = min(N, n0 + rows_per_blk);
   const int nvec = C / EPV;
   float cacc[NV][EPV];
@@ -271,48 +282,62 @@ __global__ void __launch_bounds__(256) kk_xstats(const void* X_, int N, int C, i
   for (int v = 0; v < NV; ++v)
 #pragma unroll
     for (int e = 0; e < EPV; ++e) cacc[v][e] = 0.f;
-  for (int n = n0 + wave; n < n1; n += 4) {
-    const long row = (long)s * N + n;
-    const uint4* p = (const uint4*)(X + row * C);
-    float rs = 0.f, rss = 0.f;
+  for (int nb = n0 + 16 * wave; nb < n1; nb += 32 * 2) {
+    // two row quartets per iteration (rows nb + grp and nb + 4 + grp .. interleaved over the 4 waves in steps of 16)
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int iv = lane + 64 * v;
-      if (iv < nvec) {
-        const uint4 w = p[iv];
-        const unsigned int ww[4] = {w.x, w.y, w.z, w.w};
-        if constexpr (sizeof(T) == 4) {
+    for (int h = 0; h < 4; ++h) {
+      const int n = nb + 4 * h + grp;
+      const bool ok = n < n1;
+      const long row = (long)s * N + n;
+      const uint4* p = (const uint4*)(X + row * C);
+      float rs = 0.f, rss = 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float x = __uint_as_float(ww[e]); rs += x; rss += x * x; cacc[v][e] += x; }
-        } else {
+      for (int v = 0; v < NV; ++v) {
+        const int iv = l + 16 * v;
+        if (ok && iv < nvec) {
+          const uint4 w = p[iv];
+          const unsigned int ww[4] = {w.x, w.y, w.z, w.w};
+          if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x0 = bf2f((unsigned short)(ww[e] & 0xFFFFu)), x1 = bf2f((unsigned short)(ww[e] >> 16));
-            rs += x0 + x1; rss += x0 * x0 + x1 * x1; cacc[v][2 * e] += x0; cacc[v][2 * e + 1] += x1;
+            for (int e = 0; e < 4; ++e) { const float x = __uint_as_float(ww[e]); rs += x; rss += x * x; cacc[v][e] += x; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x0 = bf2f((unsigned short)(ww[e] & 0xFFFFu)), x1 = bf2f((unsigned short)(ww[e] >> 16));
+              rs += x0 + x1; rss += x0 * x0 + x1 * x1; cacc[v][2 * e] += x0; cacc[v][2 * e + 1] += x1;
+            }
           }
         }
       }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { rs += __shfl_xor(rs, o, 64); rss += __shfl_xor(rss, o, 64); }
+      if (l == 0 && ok) { sx[row] = rs; sx[NT + row] = rss; }
     }
-    rs = wave_sum(rs); rss = wave_sum(rss);
-    if (lane == 0) { sx[row] = rs; sx[NT + row] = rss; }
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int iv = lane + 64 * v;
+    const int iv = l + 16 * v;
     if (iv < nvec)
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) s_col[wave][iv * EPV + e] = cacc[v][e];
+      for (int e = 0; e < EPV; ++e) {
+        float c = cacc[v][e];
+        c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);        // the wave's 4 row groups
+        if (grp == 0) s_col[wave][iv * EPV + e] = c;
+      }
   }
   __syncthreads();
   float* out = xpart + ((long)s * gridDim.x + blockIdx.x) * C;
-  for (int c = threadIdx.x; c < C; c += 256) out[c] = s_col[0][c] + s_col[1][c] + s_col[2][c] + s_col[3][c];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    out[c] = s_col[0][c] + s_col[1][c] + s_col[2][c] + s_col[3][c];
+  }
 }
 int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st) {
   ProfScope ps_("k_xstats", 0.0, 0.0, st);
   const Dims& d = pl.d;
   const int epv = 16 / d.esz;
-  if (d.C > 64 * 6 * epv || d.C > 3072) { set_last_error("xstats: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
-  const int nchunk = d.xchunks, rpb = cdiv(d.N, nchunk);
+  if (d.C > 1536) { set_last_error("xstats: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
+  const int rpb = (int)round_up(cdiv(d.N, d.xchunks), 64);      // a block sweeps 64 rows per step (4 waves x 4 quartets x 4 rows)
+  const int nchunk = cdiv(d.N, rpb);                            // <= d.xchunks (xpart is sized by that)
   DISPATCH_T(d.bf16, kk_xstats, dim3(nchunk, d.S), dim3(256), 0, st, X, d.N, d.C, rpb, (float*)(saved + pl.o_sx), (long)d.NT,
              (float*)(scratch + pl.o_xpart));
   AVMOE_CHECK_LAUNCH("xstats");
@@ -442,28 +467,29 @@ struct FinishTArgs {
   int S, C, K, Kp, KL, KLT, Kcy, Kcyb, Kcx, Mb, M, src, lat0;
 };
 template <typename T>
-__global__ void kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, const float* rw, const float* bf,
-                            const float* scal, void* Text_, float* rin) {
+__global__ void __launch_bounds__(256) kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, const float* rw, const float* bf,
+                                                   const float* scal, void* Text_, float* rin) {
   const T* BmX = (const T*)BmX_;
   T* Text = (T*)Text_;
   const int rows = a.src == 0 ? a.Kcyb : a.Kcx;
-  const long total = (long)a.S * rows * a.C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % a.C);
-    const int kr = (int)((i / a.C) % rows);
-    const int s = (int)(i / ((long)a.C * rows));
-    const float tv = TV[i];
-    if (a.src == 0 && kr == a.Kcy) {
-      rin[(long)s * 2 * a.C + a.C + c] = tv + scal[0] * rw[c] + bf[c];
-      continue;
-    }
-    const int slot = a.lat0 + kr / a.Kp, k = kr % a.Kp;
-    float v = 0.f;                                   // padding rows of a slot stay exactly zero
-    if (k < a.K) {
-      v = a.tok.p[a.e_of_lat[slot]][(long)k * a.C + c] + tv;
-      if (a.src == 0) v += ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) * rw[c] + bf[c];
-    }
-    stT<T>(Text, ((long)s * a.KLT + (long)slot * a.Kp + k) * a.C + c, v);
+  const int s = blockIdx.x / rows, kr = blockIdx.x - s * rows;           // one block per (frame, latent row)
+  const float* tvr = TV + (long)blockIdx.x * a.C;
+  if (a.src == 0 && kr == a.Kcy) {
+    for (int c = threadIdx.x; c < a.C; c += 256) rin[(long)s * 2 * a.C + a.C + c] = tvr[c] + scal[0] * rw[c] + bf[c];
+    return;
+  }
+  const int slot = a.lat0 + kr / a.Kp, k = kr % a.Kp;
+  T* out = Text + ((long)s * a.KLT + (long)slot * a.Kp + k) * a.C;
+  if (k >= a.K) {                                    // padding rows of a slot stay exactly zero
+    for (int c = threadIdx.x; c < a.C; c += 256) stT<T>(out, c, 0.f);
+    return;
+  }
+  const float* tok = a.tok.p[a.e_of_lat[slot]] + (long)k * a.C;
+  const float ab = a.src == 0 ? ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) : 0.f;
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float v = tok[c] + tvr[c];
+    if (a.src == 0) v += ab * rw[c] + bf[c];
+    stT<T>(out, c, v);
   }
 }
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src, hipStream_t st) {
@@ -475,7 +501,8 @@ int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs&
   const int rows = src == 0 ? d.Kcyb : d.Kcx;
   if (rows <= 0) return OK;
   const long total = (long)d.S * rows * d.C;
-  DISPATCH_T(d.bf16, kk_finish_T, dim3(grid1d(total, 8192)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_TV),
+  (void)total;
+  DISPATCH_T(d.bf16, kk_finish_T, dim3((unsigned)(d.S * rows)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_TV),
              (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_rw), (const float*)prm.fc_b,
              (const float*)(saved + pl.o_scal), (void*)(saved + pl.o_Text), (float*)(saved + pl.o_rin));
   AVMOE_CHECK_LAUNCH("finish_T");
@@ -538,7 +565,7 @@ __global__ void __launch_bounds__(256) kk_lb_loss(const float* probs, int S, int
   }
   if (threadIdx.x == 0) *lb = total;
 }
-int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
+int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
              int64_t* idx_out, float* lb_out, hipStream_t st) {
   ProfScope ps_("k_router", 0.0, 0.0, st);
   const Dims& d = pl.d;
@@ -551,6 +578,7 @@ int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float
     g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
     g.A = saved + pl.o_rin; g.B = prm.r0_w; g.C = saved + pl.o_rh1;
     g.M = d.S; g.N = 128; g.K = 2 * d.C; g.lda = 2L * d.C; g.ldb = 2L * d.C; g.sCi = 128;
+    g.tile = 64; g.slabs = (float*)(scratch + pl.o_slabs); g.ksplit = choose_ksplit(g, slab_floats(d));   // few tiles, long K
     AVMOE_TRY(launch_gemm(g, st));
   }
   hipLaunchKernelGGL(kk_router_tail, dim3(d.S), dim3(128), 0, st, a, (float*)(saved + pl.o_rh1), (float*)(saved + pl.o_rh2),
@@ -652,8 +680,9 @@ int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   a.E = d.E; a.dgp = d.dgp; a.DZ = d.DZ; a.NT = d.NT;
   const int nblk = d.nblk_tok;
   const int rpb = cdiv(d.NT, nblk);
-  DISPATCH_T(d.bf16, kk_mid, dim3(nblk), dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-             (void*)(scratch + pl.o_Zp), (float*)(scratch + pl.o_colpart), rpb);
+  if (tile_fast_ok(d)) AVMOE_TRY(kf_mid(pl, saved, scratch, st));
+  else DISPATCH_T(d.bf16, kk_mid, dim3(nblk), dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+                  (void*)(scratch + pl.o_Zp), (float*)(scratch + pl.o_colpart), rpb);
   AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 1, st));
   hipLaunchKernelGGL(kk_colsum_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, (const float*)(scratch + pl.o_colsum),
                      d.DZ, 0, 1.f / (float)d.NT, (float*)(saved + pl.o_mz));

@@ -402,33 +402,53 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
 // split-K second pass: C = alpha * sum_s slab[s] (+ row_scale * D) (+ C)
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p) {
-  const long per = (long)p.M * p.N;
-  const long total = per * p.nbatch;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int b = (int)(idx / per);
-    const long rem = idx % per;
-    const int i = (int)(rem / p.N), j = (int)(rem % p.N);
-    float s = 0.f;
-    for (int sp = 0; sp < p.ksplit; ++sp) s += p.slabs[(long)sp * total + idx];
-    s *= p.alpha;
-    const int b1 = b / p.nb2, b2 = b % p.nb2;
-    if (p.D) {
-      const float rsv = p.rs ? p.rs[(long)b1 * p.sRS1 + (long)b2 * p.sRS2 + i] : 0.f;
-      const long off = (long)b1 * p.sD1 + (long)b2 * p.sD2 + (long)i * p.sDi + j;
-      float dv;
-      if constexpr (sizeof(T) == 2) dv = bf16_bits_to_f32(((const unsigned short*)p.D)[off]);
-      else dv = ((const float*)p.D)[off];
-      s += rsv * dv;
-    }
-    const long coff = (long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)i * p.sCi + (long)j * p.sCj;
-    if (p.out_bf16) {
-      unsigned short* c = (unsigned short*)p.C + coff;
-      if (p.accumulate) s += bf16_bits_to_f32(*c);
-      *c = f32_to_bf16_bits(s);
+  // one thread = VEC consecutive elements of a row (VEC = 4 when N % 4 == 0: 16-byte slab reads); 32-bit index math
+  const unsigned N = (unsigned)p.N, per = (unsigned)p.M * N, total = per * (unsigned)p.nbatch;
+  const unsigned VEC = (N % 4u == 0u) ? 4u : 1u;
+  const unsigned nvec = total / VEC;
+  for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < nvec; v += gridDim.x * 256u) {
+    const unsigned idx = v * VEC;
+    const unsigned b = idx / per, rem = idx - b * per;
+    const unsigned i = rem / N, j = rem - i * N;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* sl = p.slabs + idx;
+    if (VEC == 4u) {
+      int sp = 0;
+      for (; sp + 4 <= p.ksplit; sp += 4) {
+        const f32x4 a0 = *(const f32x4*)(sl + (size_t)sp * total), a1 = *(const f32x4*)(sl + (size_t)(sp + 1) * total);
+        const f32x4 a2 = *(const f32x4*)(sl + (size_t)(sp + 2) * total), a3 = *(const f32x4*)(sl + (size_t)(sp + 3) * total);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (a0[e] + a1[e]) + (a2[e] + a3[e]);
+      }
+      for (; sp < p.ksplit; ++sp) {
+        const f32x4 a0 = *(const f32x4*)(sl + (size_t)sp * total);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += a0[e];
+      }
     } else {
-      float* c = (float*)p.C + coff;
-      if (p.accumulate) s += *c;
-      *c = s;
+      for (int sp = 0; sp < p.ksplit; ++sp) s[0] += sl[(size_t)sp * total];
+    }
+    const int b1 = (int)b / p.nb2, b2 = (int)b % p.nb2;
+    const float rsv = (p.D && p.rs) ? p.rs[(long)b1 * p.sRS1 + (long)b2 * p.sRS2 + i] : 0.f;
+    for (unsigned e = 0; e < VEC; ++e) {
+      float x = s[e] * p.alpha;
+      if (p.D) {
+        const long off = (long)b1 * p.sD1 + (long)b2 * p.sD2 + (long)i * p.sDi + (j + e);
+        float dv;
+        if constexpr (sizeof(T) == 2) dv = bf16_bits_to_f32(((const unsigned short*)p.D)[off]);
+        else dv = ((const float*)p.D)[off];
+        x += rsv * dv;
+      }
+      const long coff = (long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)i * p.sCi + (long)(j + e) * p.sCj;
+      if (p.out_bf16) {
+        unsigned short* c = (unsigned short*)p.C + coff;
+        if (p.accumulate) x += bf16_bits_to_f32(*c);
+        *c = f32_to_bf16_bits(x);
+      } else {
+        float* c = (float*)p.C + coff;
+        if (p.accumulate) x += *c;
+        *c = x;
+      }
     }
   }
 }
@@ -575,7 +595,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (st != OK) return st;
   if (d.ksplit > 1) {
     const long total = (long)d.nbatch * a.M * a.N;
-    const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    if (total >= (1L << 31)) { set_last_error("gemm: split-K result too large"); return ERR_UNSUPPORTED; }
+    const long nvec = (a.N % 4 == 0) ? total / 4 : total;
+    const int blocks = (int)std::min<long>((nvec + 255) / 256, 4096);
     ProfScope ps("gemm_splitk_reduce", (double)total * 4.0 * (d.ksplit + 1), 0.0, stream);
     if (a.dtype == GEMM_BF16) hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3(blocks), dim3(256), 0, stream, d);
     else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d);

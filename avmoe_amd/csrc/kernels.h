@@ -25,7 +25,7 @@ int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, v
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src /*0 y, 1 x*/,
                hipStream_t st);
 // ---- forward: router --------------------------------------------------------------------------
-int k_router(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
+int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
              int64_t* idx_out, float* lb_out, hipStream_t st);
 // ---- forward: per token -----------------------------------------------------------------------
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
@@ -67,6 +67,7 @@ bool tile_fast_ok(const Dims& d);
 int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 // generic helpers

@@ -104,7 +104,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   }
 
   // ---- router -----------------------------------------------------------------------------------
-  AVMOE_TRY(k_router(pl, sv, prm, noise, probs_out, idx_out, lb_out, st));
+  AVMOE_TRY(k_router(pl, sv, sc, prm, noise, probs_out, idx_out, lb_out, st));
 
   // ---- per-sample K-space matrices of the latent tokens ------------------------------------------
   AVMOE_TRY(k_rowstats(d.bf16, sv + pl.o_Text, (long)d.S * d.KLT, d.C, (float*)(sv + pl.o_Tsum), st));

@@ -213,6 +213,68 @@ __global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __
 }
 
 // =====================================================================================================
+// MID forward: z' = act(BN1(z)) -> Zp (operand of the second-moment GEMM) + column sums of z'   (net_trans_v3.py:397-400)
+// =====================================================================================================
+struct FMidFArgs { int relu_of_e[MAX_E]; FastDims t; };
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, void* __restrict__ Zp_,
+                                                 float* __restrict__ colpart) {
+  constexpr int DZ = E * FDD;
+  T* Zp = (T*)Zp_;
+  __shared__ float s_c[2 * FDD];      // sc, sh
+  __shared__ float s_col[4 * FDD];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    if (threadIdx.x < FDD) {
+      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_c[dd] = bn1[2 * DZ + col]; s_c[FDD + dd] = bn1[3 * DZ + col];
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    float4 sc[4], sh[4], cs0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = ld4(s_c + 16 * c + 4 * q); sh[c] = ld4(s_c + FDD + 16 * c + 4 * q); cs0[c] = zero4(); }
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 128) {       // two tiles per step: 8 row loads in flight per lane
+      float4 z[2][4];
+      bool ok[2];
+      long tok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int n = n0 + 64 * u;
+        ok[u] = n < n_end && n + r < t.N;
+        tok[u] = (long)s * t.N + n + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) z[u][c] = ok[u] ? ld4(Z + tok[u] * DZ + zcol<E>(c, e, q)) : zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!ok[u]) continue;
+        float4 zp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            float y = at(z[u][c], x) * at(sc[c], x) + at(sh[c], x);
+            if (relu) y = fmaxf(y, 0.f);
+            y = rndT<T>(y);
+            at(zp[c], x) = y;
+            at(cs0[c], x) += y;
+          }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) st_seg<T>(Zp + tok[u] * DZ + gi * (E * FDG) + e * FDG, zp[2 * gi], zp[2 * gi + 1], q);
+      }
+    }
+    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
+  }
+}
+
+// =====================================================================================================
 // POST_SMALL forward  (net_trans_v3.py:430-434,485-486)
 // =====================================================================================================
 struct FPostArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; float ln_eps; };
@@ -771,6 +833,18 @@ int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu),
             (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("pre_small (64/32)");
+  return OK;
+}
+
+int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  const Dims& d = pl.d;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FMidFArgs a;
+  for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
+  a.t = make_fd(d, per);
+  LAUNCH_TE(d.bf16, kf_mid, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
+            (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("mid (64/32)");
   return OK;
 }
 
