@@ -77,6 +77,9 @@ class AdapterFunction(torch.autograd.Function):
                                  torch.cuda.current_stream(X.device).cuda_stream)
         capi.check(st, "avmoe_moe_forward")
         ctx.module, ctx.desc, ctx.names, ctx.saved_ws = module, desc, names, saved
+        sink = getattr(module, "_grad_sink", None)
+        if sink is not None and any(ctx.needs_input_grad[5:]):
+            sink.calls += 1                              # the site's bucket is complete after as many backward calls
         ctx.save_for_backward(X, Y, *params)
         ctx.mark_non_differentiable(probs, idx)
         return out, probs, idx, lb
@@ -89,8 +92,17 @@ class AdapterFunction(torch.autograd.Function):
         tensors = dict(zip(ctx.names, params))
         ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors()}, module.num_multimodal_experts,
                             module.num_singlemodal_experts)
-        grads = {k: (torch.empty_like(v) if ctx.needs_input_grad[5 + i] else None)
-                 for i, (k, v) in enumerate(tensors.items())}
+        # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
+        # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
+        # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
+        sink = getattr(module, "_grad_sink", None)
+        use_sink = sink is not None and all(ctx.needs_input_grad[5:]) and sink.matches(ctx.names, tensors)
+        if use_sink:
+            flat = sink.flat if sink.fresh else torch.empty_like(sink.flat)
+            grads = {k: flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
+        else:
+            grads = {k: (torch.empty_like(v) if ctx.needs_input_grad[5 + i] else None)
+                     for i, (k, v) in enumerate(tensors.items())}
         gptrs = cm.make_ptrs({k: v for k, v in grads.items() if v is not None}, module.num_multimodal_experts,
                              module.num_singlemodal_experts)
         d_out = d_out.to(X.dtype).contiguous()
@@ -103,6 +115,13 @@ class AdapterFunction(torch.autograd.Function):
                                   scratch.data_ptr(), dX.data_ptr(), dY.data_ptr(), C.byref(gptrs),
                                   torch.cuda.current_stream(X.device).cuda_stream)
         capi.check(st, "avmoe_moe_backward")
+        if use_sink:
+            if not sink.fresh:
+                sink.flat.add_(flat)                     # accumulation micro-step: one fused add for the whole site
+            sink.done()
+            return (None, dX, dY, None, None) + (None,) * len(ctx.names)
+        if sink is not None:
+            sink.calls -= 1
         return (None, dX, dY, None, None) + tuple(grads[k] for k in ctx.names)
 
 
@@ -207,6 +226,32 @@ class MoEAdapter(nn.Module):
     def _param_tensors(self):
         return {k: v for k, v in self.named_parameters()}
 
+    def grad_layout(self, align: int = 64):
+        """(names, offsets, total) of this site's parameter gradients inside one flat fp32 buffer (offsets in elements,
+        aligned) -- the layout a gradient sink must use (avmoe_amd.dp)."""
+        names, offs, off = [], [], 0
+        for k, v in self.named_parameters():
+            names.append(k); offs.append(off)
+            off += -(-v.numel() // align) * align
+        return tuple(names), tuple(offs), off
+
+    def _bump_batches_tracked(self):
+        """num_batches_tracked += 1 of every BatchNorm of the site in ONE kernel: the buffers are kept as views of one
+        int64 tensor (rebuilt whenever .to() / load_state_dict detached them)."""
+        mods = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        if not mods:
+            return
+        flat = getattr(self, "_nbt_flat", None)
+        ok = flat is not None and flat.numel() == len(mods) and all(
+            m.num_batches_tracked.device == flat.device and
+            m.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, m in enumerate(mods))
+        if not ok:
+            flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in mods])
+            for i, m in enumerate(mods):
+                m.num_batches_tracked = flat[i]
+            self._nbt_flat = flat
+        flat += 1
+
     def _buffer_tensors(self):
         return {k: v for k, v in self.named_buffers() if v.is_floating_point()}
 
@@ -219,9 +264,7 @@ class MoEAdapter(nn.Module):
         out, probs, idx, lb = AdapterFunction.apply(self, X, Y, noise, names, *P.values())
         if self.training and self.use_bn:
             with torch.no_grad():
-                for k, v in self.named_buffers():
-                    if k.endswith("num_batches_tracked"):
-                        v += 1
+                self._bump_batches_tracked()
         return out.permute(0, 2, 1).unsqueeze(-1), probs, idx, lb
 
     def forward(self, x, vis_token=None):

@@ -38,6 +38,38 @@ class _Bucket:
         self.work = None
 
 
+class _SiteSink:
+    """Hands a MoEAdapter site its slice of gradient memory: the site's backward writes all its parameter gradients there
+    (layout = site.grad_layout()) and calls done()."""
+
+    def __init__(self, site, bucket, reducer):
+        self.names, self.offsets, self.total = site.grad_layout()
+        self.bucket, self.reducer, self.fresh = bucket, reducer, True
+        self.flat = bucket.flat
+        self.calls = 0                                   # forward calls of the site still waiting for their backward
+
+    def matches(self, names, tensors) -> bool:
+        return tuple(names) == self.names and all(v.device == self.flat.device for v in tensors.values())
+
+    def done(self):
+        self.fresh = False
+        self.calls -= 1
+        if self.calls <= 0:
+            self.reducer._bucket_filled(self.bucket)
+
+
+class _SiteBucket:
+    def __init__(self, site):
+        names, offs, total = site.grad_layout()
+        ps = dict(site.named_parameters())
+        self.params = [ps[k] for k in names]
+        self.flat = torch.zeros(total, device=self.params[0].device, dtype=torch.float32)
+        for p, o in zip(self.params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self.pending = 1
+        self.work = None
+
+
 class AdapterGradReducer:
     """Bucketed, overlapped gradient all-reduce for the trainable parameters of adapter sites.
 
@@ -50,14 +82,29 @@ class AdapterGradReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
-                 process_group: Optional[dist.ProcessGroup] = None):
+                 process_group: Optional[dist.ProcessGroup] = None, sites=None):
+        """`sites`: MoEAdapter modules (GPU) whose backward should write its parameter gradients straight into a bucket
+        of this reducer (one bucket per site, no per-parameter accumulation kernels); their parameters may also be
+        listed in `params`, all other parameters are bucketed by size."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        ps = [p for p in params if p.requires_grad]
-        if not ps:
+        self.buckets: List[_Bucket] = []
+        self.sinks: List[_SiteSink] = []
+        owned = set()
+        for site in (sites or []):
+            sp = list(site.parameters())
+            if not sp or not all(p.requires_grad and p.dtype == torch.float32 for p in sp):
+                continue                                  # partly frozen site: plain autograd accumulation
+            b = _SiteBucket(site)
+            self.buckets.append(b)
+            sink = _SiteSink(site, b, self)
+            site._grad_sink = sink
+            self.sinks.append(sink)
+            owned.update(id(p) for p in sp)
+        ps = [p for p in params if p.requires_grad and id(p) not in owned]
+        if not ps and not self.buckets:
             raise ValueError("no trainable parameters")
         cap = int(bucket_mb * (1 << 20))
-        self.buckets: List[_Bucket] = []
         cur, cur_bytes = [], 0
         for p in reversed(ps):                       # backward produces gradients roughly in reverse order
             if cur and cur_bytes + p.numel() * 4 > cap:
@@ -70,9 +117,16 @@ class AdapterGradReducer:
         self._sync = True
         self._owner = {}
         for b in self.buckets:
+            if isinstance(b, _SiteBucket):
+                continue
             for p in b.params:
                 self._owner[p] = b
                 p.register_post_accumulate_grad_hook(self._hook)
+
+    def _bucket_filled(self, b):
+        b.pending = 0
+        if self._sync and self.world > 1:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p):
         b = self._owner[p]
@@ -92,8 +146,10 @@ class AdapterGradReducer:
     def begin(self, sync: bool = True):
         self._sync = sync
         for b in self.buckets:
-            b.pending = len(b.params)
+            b.pending = 1 if isinstance(b, _SiteBucket) else len(b.params)
             b.work = None
+        for s in self.sinks:
+            s.calls = 0
 
     def finish(self):
         if not self._sync or self.world == 1:
@@ -107,6 +163,8 @@ class AdapterGradReducer:
     def zero_grad(self):
         for b in self.buckets:
             b.flat.zero_()
+        for s in self.sinks:
+            s.fresh = True                               # the next backward of the site overwrites instead of adding
 
     def message_bytes(self) -> int:
         return sum(b.flat.numel() * 4 for b in self.buckets)

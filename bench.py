@@ -147,7 +147,7 @@ def main():
     S = c["B"] * c["T"]
     audio, visual = build_site(c, device)
     params = list(audio.parameters()) + list(visual.parameters())
-    reducer = AdapterGradReducer(params, bucket_mb=64.0)
+    reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=[audio, visual])
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     f_a = (0.3 * torch.randn(S, c["N_a"], c["C"], generator=g)).to(device, tdt).requires_grad_(True)

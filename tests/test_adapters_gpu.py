@@ -3,6 +3,7 @@ reference return tuples out, autograd through the HIP path, in-place BatchNorm b
 import pytest
 import torch
 
+from oracle import avmoe_oracle as O
 from tests.golden_util import load_golden, split_params, assert_grads_close
 from tests.test_adapters_api import build_module
 
@@ -68,3 +69,41 @@ def test_frozen_parameters_get_no_gradient_and_bf16_runs():
     out.float().sum().backward()
     for k, v in m.named_parameters():
         assert (v.grad is not None) == ("router" in k), k
+
+
+def test_gradient_sink_matches_autograd_accumulation():
+    """AdapterGradReducer(sites=[...]): the backward writes parameter gradients straight into the reducer's flat bucket
+    (param.grad are views of it) -- same numbers as plain autograd accumulation, also over two accumulation micro-steps,
+    and num_batches_tracked advances once per training forward for every BatchNorm."""
+    import copy
+    from avmoe_amd.dp import AdapterGradReducer
+    dev = torch.device("cuda:0")
+    cfg = O.AdapterConfig(Cx=64, Nx=50, Cy=48, Ny=20, reduction=4, groups=2, K=6)
+    ref = build_module("ave", cfg).to(dev).train()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k.endswith(("gate", "gate_av")):
+                p.fill_(0.4)
+    fused = copy.deepcopy(ref)
+    red = AdapterGradReducer(list(fused.parameters()), sites=[fused])
+    g = torch.Generator().manual_seed(5)
+    for micro in range(2):
+        X = torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev).requires_grad_(True)
+        Y = torch.randn(4, cfg.Cy, cfg.Ny, 1, generator=g).to(dev)
+        G = torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev)
+        Xf = X.detach().clone().requires_grad_(True)
+        ref(X, Y)[0].backward(G)
+        red.begin(sync=(micro == 1))
+        fused(Xf, Y)[0].backward(G)
+        red.finish()
+        assert torch.equal(X.grad, Xf.grad)
+    for (k, p), (_, q) in zip(ref.named_parameters(), fused.named_parameters()):
+        assert q.grad.data_ptr() >= red.buckets[0].flat.data_ptr()
+        scale = float(p.grad.abs().max()) + 1e-6
+        assert float((p.grad - q.grad).abs().max()) <= 1e-5 * scale, k
+    for (k, b), (_, c) in zip(ref.named_buffers(), fused.named_buffers()):
+        assert torch.equal(b, c), k
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == 2
+    red.zero_grad()
+    assert all(float(q.grad.abs().max()) == 0.0 for q in fused.parameters())
