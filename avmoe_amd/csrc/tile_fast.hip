@@ -30,8 +30,24 @@ constexpr int LD64 = 68;    // ... with 64 columns
 
 struct FastDims { int S, N, C, El, KL, KLT, KLp, KPp, NT, per; };
 
-__device__ __forceinline__ float qsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
-__device__ __forceinline__ float qmax4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+// reductions over the 4 lanes that hold one token (same r, q = 0..3): the gfx950 row swaps v_permlane16_swap (rows 0<->1,
+// 2<->3) and v_permlane32_swap (rows 0,1 <-> 2,3) -- plain VALU, no LDS crossbar round trip as with ds_bpermute
+__device__ __forceinline__ float qsum4(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned x = __float_as_uint(w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float qmax4(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned x = __float_as_uint(w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ float rsum16(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
@@ -91,16 +107,18 @@ __device__ __forceinline__ float at(const float4& v, int x) { return ((const flo
 // column offset of chunk c (dd = 16 c + 4 q ..) of expert e inside a Z-space row [group][expert][32]
 template <int E> __device__ __forceinline__ int zcol(int c, int e, int q) { return (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q; }
 
-// W[tok r][16 ct + 4 q + x] = sum over NJ chunks of  P[r][16 j + 4 q' + x'] * M[16 j + 4 q' + x'][16 ct + r-column]
-// Ms: LDS matrix [k][ld] already offset to its first row / column block; p[j]: this lane's chunk registers.
+// W[tok r][col0 + 4 q + x] = sum over NJ chunks of  P[r][16 j + 4 q' + x'] * M[16 j + 4 q' + x'][col0 + ...]
+// Mt: the matrix TRANSPOSED in LDS, Mt[n][k] (leading dim ld, a multiple of 4): the A operands of the four MFMA steps x' = 0..3
+// of a chunk are then one 16-byte read  Mt[col0 + r][16 j + 4 q .. + 3].   p[j]: this lane's chunk registers.
 template <int NJ>
-__device__ __forceinline__ f32x4 mmT(const float* Ms, int ld, int col0, const float4* p, int r, int q) {
+__device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float* mp = Ms + (4 * q) * ld + col0 + r;
+  const float* mp = Mt + (col0 + r) * ld + 4 * q;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
+    const float4 a = *(const float4*)(mp + 16 * j);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[(16 * j + x) * ld], at(p[j], x), acc, 0, 0, 0);
+    for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a, x), at(p[j], x), acc, 0, 0, 0);
   }
   return acc;
 }
@@ -157,7 +175,7 @@ __global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __
     if (a.moments)
       for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
         const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-        s_S[(gi * FDG + k) * LD32 + c] = sdSzz[(long)(gi * E + e) * FDG * FDG + k * FDG + c];
+        s_S[(gi * FDG + c) * LD32 + k] = sdSzz[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
       }
     if (threadIdx.x < FDD) {
       const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
@@ -294,7 +312,7 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
       const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-      s_G[(gi * FDG + k) * LD32 + c] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];
+      s_G[(gi * FDG + c) * LD32 + k] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
     }
     if (threadIdx.x < FDD) {
       const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
@@ -364,7 +382,7 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float
 struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_post_small_bwd(FPostBArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                          const float* __restrict__ uvh, const float* __restrict__ probs, const float* __restrict__ rpmup,
                                                          const float* __restrict__ dAp, float* __restrict__ dzp, void* __restrict__ Zp_, void* __restrict__ Zw_,
                                                          float* __restrict__ colpart, float* __restrict__ blkscal) {
@@ -382,7 +400,7 @@ __global__ void __launch_bounds__(256, 3) kf_post_small_bwd(FPostBArgs a, const 
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
       const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-      s_G[(gi * FDG + k) * LD32 + c] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];
+      s_G[(gi * FDG + c) * LD32 + k] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
     }
     if (threadIdx.x < FDD) {
       const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
@@ -491,7 +509,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
   constexpr int DZ = E * FDD;
   T* aout = (T*)aout_;
   __shared__ float s_TT[FK * LD32];
-  __shared__ float s_TW[FK * LD64];
+  __shared__ float s_TWt[FDD * LD32];   // [dd][k]: transposed TW slice (mmT)
   __shared__ float s_tb[FK];
   __shared__ float s_c[2 * FDD];      // wsum, dconst
   __shared__ float s_col[4 * FDD];
@@ -506,10 +524,10 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
     if (l >= 0) {
       gv = a.glat.p[e][0];
       const float* tt = TT + ((long)s * t.El + l) * FK * FK;
-      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i >> 5) * LD32 + (i & 31)] = tt[i];
+      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
       for (int i = threadIdx.x; i < FK * FDD; i += 256) {
         const int k = i >> 6, dd = i & 63;
-        s_TW[k * LD64 + dd] = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
+        s_TWt[dd * LD32 + k] = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
       }
       if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
     }
@@ -581,7 +599,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 p = {0.f, 0.f, 0.f, 0.f};
-        if (l >= 0) p = mmT<2>(s_TW + oz, LD64, 16 * c, av, r, q);
+        if (l >= 0) p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
         const float4 ws = ld4(s_c + oz + 16 * c + 4 * q), dc = ld4(s_c + oz + FDD + 16 * c + 4 * q);
         float4 o;
 #pragma unroll
@@ -606,7 +624,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
 struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before, use_bn, bn_train; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ TT,
+__global__ void __launch_bounds__(256, 2) kf_pre_small_bwd(FPreBArgs a, const float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ TT,
                                                         const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
                                                         const float* __restrict__ dconst, const void* __restrict__ ain_, const float* __restrict__ rmu,
                                                         const float* __restrict__ bn1, const float* __restrict__ dsm, const float* __restrict__ dy_in,
@@ -634,7 +652,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const fl
     if (l >= 0) {
       gv = a.glat.p[e][0];
       const float* tt = TT + ((long)s * t.El + l) * FK * FK;
-      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i >> 5) * LD32 + (i & 31)] = tt[i];
+      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
       for (int i = threadIdx.x; i < FK * FDD; i += 256) {
         const int k = i >> 6, dd = i & 63;
         const float v = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
@@ -730,7 +748,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const fl
         float dgr = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
-          const f32x4 p = mmT<2>(s_TW + oz, LD64, 16 * c, av, r, q);
+          const f32x4 p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
 #pragma unroll
           for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
         }
@@ -741,7 +759,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small_bwd(FPreBArgs a, const fl
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
-          const f32x4 twd = mmT<4>(s_TWt + oz, LD32, 16 * ct, dzr, r, q);
+          const f32x4 twd = mmT<4>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             const float ac = at(av[ct], x);
