@@ -116,16 +116,16 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     g.sCi = d.K; g.sC1 = (long)d.El * d.K * d.K; g.sC2 = (long)d.K * d.K;
     AVMOE_TRY(launch_gemm(g, st));
   }
-  auto down_gemm = [&](const void* rows, long nrows, void* dst) {      // rows (nrows, C) -> (nrows, DZ) through Wt
+  auto down_gemm = [&](const void* rows, long nrows, void* dst, int out_dt = GEMM_F32) {   // rows (nrows, C) -> (nrows, DZ) through Wt
     GemmArgs g = base();
-    g.A = rows; g.B = sv + pl.o_Wt; g.C = dst;
+    g.A = rows; g.B = sv + pl.o_Wt; g.C = dst; g.out_dtype = out_dt;
     g.M = (int)nrows; g.N = d.E * d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb2 = d.g;
     g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC2 = (long)d.E * d.dgp;
     return launch_gemm(g, st);
   };
   AVMOE_TRY(down_gemm(sv + pl.o_Text, (long)d.S * d.KLT, sv + pl.o_TW));   // TW (all latent rows x all experts)
   // ---- the X-side GEMMs ------------------------------------------------------------------------
-  AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z));                                // Zx = X Wt^T
+  AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z, d.zsz == 2 ? GEMM_BF16 : GEMM_F32));                                // Zx = X Wt^T
   if (d.KL > 0) {                                          // L2[s] = X[s] T[s]^T
     GemmArgs g = base();
     g.A = X; g.B = sv + pl.o_Text; g.C = sv + pl.o_L2;

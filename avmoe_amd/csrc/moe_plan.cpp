@@ -4,6 +4,8 @@
 
 namespace avmoe {
 
+bool tile_fast_ok(const Dims& d);   // tile_fast.hip
+
 size_t slab_floats(const Dims& d) {
   // worst split-K user: weight-gradient contractions over all tokens.  Sized generously:
   // ksplit_max * (largest small output), see moe_forward/backward for the actual launches.
@@ -91,6 +93,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
   int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(1024, d.S))));
   d.nblk_tok = bps * d.S;
+  d.zsz = tile_fast_ok(d) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident path
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 
   size_t off[2] = {0, 0};

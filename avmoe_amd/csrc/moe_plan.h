@@ -20,6 +20,7 @@ struct Dims {
   float bn_eps, ln_eps, bn_momentum;
   // derived
   int esz;        // bytes of an activation / operand element (T)
+  int zsz;        // bytes of a Z / dz' element: T on the register-resident path (tile_fast.hip), else fp32
   int NT;         // S * N tokens
   int dg, dgp;    // bottleneck per group, padded to 8
   int Cg;         // channels per group
@@ -78,7 +79,7 @@ struct Dims {
   X(probs, 0, 4, (size_t)d.S * d.E)                                                             \
   /* ---- per token ---- */                                                                    \
   X(sx, 0, 4, (size_t)2 * d.NT)                     /* row sum / sumsq of X           */       \
-  X(Z, 0, 4, (size_t)d.NT * d.DZ)                   /* Zx then z (in place)           */       \
+  X(Z, 0, d.zsz, (size_t)d.NT * d.DZ)                   /* Zx then z (in place)           */       \
   X(L2, 0, 4, (size_t)d.NT * d.KLp)                                                             \
   X(a, 0, d.esz, (size_t)d.NT * d.KLp)                                                          \
   X(rmu, 0, 4, (size_t)2 * d.NT * d.E)              /* r, mu  per (token, expert)     */       \
@@ -115,7 +116,7 @@ struct Dims {
   /* ---- backward only ---- */                                                                \
   X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)                                                      \
   X(dBp, 1, 4, (size_t)d.C * d.KPp)                                                             \
-  X(dzp, 1, 4, (size_t)d.NT * d.DZ)                 /* dz' -> dy (in place)           */       \
+  X(dzp, 1, d.zsz, (size_t)d.NT * d.DZ)                 /* dz' -> dy (in place)           */       \
   X(blkscal, 1, 4, (size_t)d.nblk_tok * d.E * 4)    /* per-block scalar partials      */       \
   X(dGq, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp)                                               \
   X(sdSzz, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp) /* 2 dSzz / NT                    */       \

@@ -101,6 +101,14 @@ template <> __device__ __forceinline__ void ld_seg<__bf16>(const __bf16* seg, fl
   c0 = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u), __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u));
   c1 = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u));
 }
+// one expert's 64 bottleneck entries of a Z-space row ([group][expert][32], element type T): chunks v[0..3]
+template <typename T, int E> __device__ __forceinline__ void ld_row(const T* row, int e, int q, float4 (&v)[4]) {
+  ld_seg<T>(row + e * FDG, v[0], v[1], q); ld_seg<T>(row + E * FDG + e * FDG, v[2], v[3], q);
+}
+template <typename T, int E> __device__ __forceinline__ void st_row(T* row, int e, int q, const float4 (&v)[4]) {
+  st_seg<T>(row + e * FDG, v[0], v[1], q); st_seg<T>(row + E * FDG + e * FDG, v[2], v[3], q);
+}
+__device__ __forceinline__ void zero_row(float4 (&v)[4]) { v[0] = v[1] = v[2] = v[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
 __device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
 
@@ -159,10 +167,11 @@ __device__ __forceinline__ float wsum_q0(float v, int q) {   // sum over the 16 
 // =====================================================================================================
 struct FMidArgs { int relu_of_e[MAX_E]; FastDims t; int moments; };
 
-template <int E>
-__global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ dsm,
-                                                  const float* __restrict__ sdSzz, float* __restrict__ dzp, float* __restrict__ colpart) {
+template <typename T, int E>
+__global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
+                                                  const float* __restrict__ sdSzz, void* __restrict__ dzp_, float* __restrict__ colpart) {
   constexpr int DZ = E * FDD;
+  const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
   __shared__ float s_S[2 * FDG * LD32];
   __shared__ float s_bn[5 * FDD];
   __shared__ float s_col[4 * FDD];
@@ -191,12 +200,9 @@ __global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long row = ((long)s * t.N + n0 + r) * DZ;
-      float4 z[4], dz[4], zp[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        z[c] = ok ? ld4(Z + row + zcol<E>(c, e, q)) : zero4();
-        dz[c] = ok ? ld4(dzp + row + zcol<E>(c, e, q)) : zero4();
-      }
+      float4 z[4], dz[4], zp[4], dyo[4];
+      zero_row(z); zero_row(dz);
+      if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
@@ -218,12 +224,13 @@ __global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __
           const float zv = at(z[c], x);
           const float zh = (zv - at(mean, x)) * at(rstd, x);
           const float d = at(dz[c], x) + at(dm, x) + w[x];
-          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : d;
+          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : rndT<T>(d);     // as stored: the BN1 sums see the same numbers
           at(dy, x) = v;
           at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
         }
-        if (ok) *(float4*)(dzp + row + zcol<E>(c, e, q)) = dy;
+        dyo[c] = dy;
       }
+      if (ok) st_row<T, E>(dzp + row, e, q, dyo);
     }
     flush_cols<E>(cs0, s_col, colpart, blk, 2, e);
     flush_cols<E>(cs1, s_col, colpart, blk, 3, e);
@@ -236,10 +243,10 @@ __global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const float* __
 struct FMidFArgs { int relu_of_e[MAX_E]; FastDims t; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, void* __restrict__ Zp_,
+__global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, void* __restrict__ Zp_,
                                                  float* __restrict__ colpart) {
   constexpr int DZ = E * FDD;
-  T* Zp = (T*)Zp_;
+  T* Zp = (T*)Zp_; const T* Z = (const T*)Z_;
   __shared__ float s_c[2 * FDD];      // sc, sh
   __shared__ float s_col[4 * FDD];
   const FastDims& t = a.t;
@@ -266,8 +273,8 @@ __global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const float* __res
         const int n = n0 + 64 * u;
         ok[u] = n < n_end && n + r < t.N;
         tok[u] = (long)s * t.N + n + r;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) z[u][c] = ok[u] ? ld4(Z + tok[u] * DZ + zcol<E>(c, e, q)) : zero4();
+        zero_row(z[u]);
+        if (ok[u]) ld_row<T, E>(Z + tok[u] * DZ, e, q, z[u]);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -298,11 +305,11 @@ __global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const float* __res
 struct FPostArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; float ln_eps; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                      const float* __restrict__ uvh, const float* __restrict__ probs, void* __restrict__ Apost_,
                                                      float* __restrict__ rpmup) {
   constexpr int DZ = E * FDD;
-  T* Apost = (T*)Apost_;
+  T* Apost = (T*)Apost_; const T* Z = (const T*)Z_;
   __shared__ float s_G[2 * FDG * LD32];
   __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
   const FastDims& t = a.t;
@@ -328,14 +335,15 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
-      float4 zp[4];
+      float4 zp[4], zraw[4];
+      zero_row(zraw);
+      if (ok) ld_row<T, E>(Z + tok * DZ, e, q, zraw);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 z = ok ? ld4(Z + tok * DZ + zcol<E>(c, e, q)) : zero4();
         const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-          const float y = at(z, x) * at(sc, x) + at(sh, x);
+          const float y = at(zraw[c], x) * at(sc, x) + at(sh, x);
           at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
         }
       }
@@ -382,12 +390,12 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const float
 struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const float* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                          const float* __restrict__ uvh, const float* __restrict__ probs, const float* __restrict__ rpmup,
-                                                         const float* __restrict__ dAp, float* __restrict__ dzp, void* __restrict__ Zp_, void* __restrict__ Zw_,
+                                                         const float* __restrict__ dAp, void* __restrict__ dzp_, void* __restrict__ Zp_, void* __restrict__ Zw_,
                                                          float* __restrict__ colpart, float* __restrict__ blkscal) {
   constexpr int DZ = E * FDD;
-  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_;
+  T* Zp = (T*)Zp_; T* Zw = (T*)Zw_; const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
   __shared__ float s_G[2 * FDG * LD32];
   __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
   __shared__ float s_col[4 * FDD];
@@ -418,11 +426,13 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
-      float4 zp[4], d[4];
+      float4 zp[4], d[4], zraw[4], dzo[4];
       float da1 = 0.f, da2 = 0.f, da3 = 0.f, rp = 1.f, mup = 0.f;
+      zero_row(zraw);
+      if (ok) ld_row<T, E>(Z + tok * DZ, e, q, zraw);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 z = ok ? ld4(Z + tok * DZ + zcol<E>(c, e, q)) : zero4();
+        const float4& z = zraw[c];
         d[c] = ok ? ld4(dAp + (tok * 2 + (c >> 1)) * t.KPp + e * FDG + (c & 1) * 16 + 4 * q) : zero4();
         const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
 #pragma unroll
@@ -476,9 +486,10 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
           }
           at(o, x) = dzv;
         }
-        if (ok) *(float4*)(dzp + tok * DZ + zcol<E>(c, e, q)) = o;
+        dzo[c] = o;
       }
       if (ok) {
+        st_row<T, E>(dzp + tok * DZ, e, q, dzo);
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
           const long seg = tok * DZ + gi * (E * FDG) + e * FDG;
@@ -502,12 +513,12 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
 struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before; float ln_eps; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ sxs,
+__global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
                                                     const float* __restrict__ TT, const float* __restrict__ TW, const float* __restrict__ Tsum,
                                                     const float* __restrict__ wsum, const float* __restrict__ dconst, void* __restrict__ aout_,
                                                     float* __restrict__ rmu, float* __restrict__ colpart) {
   constexpr int DZ = E * FDD;
-  T* aout = (T*)aout_;
+  T* aout = (T*)aout_; T* Z = (T*)Z_;
   __shared__ float s_TT[FK * LD32];
   __shared__ float s_TWt[FDD * LD32];   // [dd][k]: transposed TW slice (mmT)
   __shared__ float s_tb[FK];
@@ -544,9 +555,9 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
       float Sx = ok ? sxs[tok] : 0.f, Sxx = ok ? sxs[t.NT + tok] : 1.f;
-      float4 z[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) z[c] = ok ? ld4(Z + tok * DZ + zcol<E>(c, e, q)) : zero4();
+      float4 z[4], zo[4];
+      zero_row(z);
+      if (ok) ld_row<T, E>(Z + tok * DZ, e, q, z);
       float4 av[2] = {zero4(), zero4()};
       if (l >= 0) {
         const long lo = tok * t.KLp + (long)l * FK + 4 * q;
@@ -605,12 +616,13 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const float zr = at(z[c], x) + gv * p[x];
-          const float zv = a.ln_before ? rr * (zr - mu * at(ws, x)) + at(dc, x) : zr;
+          const float zv = rndT<T>(a.ln_before ? rr * (zr - mu * at(ws, x)) + at(dc, x) : zr);   // as stored: BN1 statistics of the stored z
           at(o, x) = zv;
           if (ok) { at(cs0[c], x) += zv; at(cs1[c], x) += zv * zv; }
         }
-        if (ok) *(float4*)(Z + tok * DZ + zcol<E>(c, e, q)) = o;
+        zo[c] = o;
       }
+      if (ok) st_row<T, E>(Z + tok * DZ, e, q, zo);
       if (ok && q == 0) { rmu[tok * E + e] = rr; rmu[(long)t.NT * E + tok * E + e] = mu; }
     }
     flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
@@ -624,15 +636,15 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, float* __rest
 struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before, use_bn, bn_train; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 2) kf_pre_small_bwd(FPreBArgs a, const float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ TT,
+__global__ void __launch_bounds__(256, 2) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ TT,
                                                         const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
                                                         const float* __restrict__ dconst, const void* __restrict__ ain_, const float* __restrict__ rmu,
-                                                        const float* __restrict__ bn1, const float* __restrict__ dsm, const float* __restrict__ dy_in,
+                                                        const float* __restrict__ bn1, const float* __restrict__ dsm, const void* __restrict__ dy_in_,
                                                         void* __restrict__ dZx_, void* __restrict__ dL2x_, void* __restrict__ aw_, void* __restrict__ ag_,
                                                         float* __restrict__ dsxs, float* __restrict__ rs2x, float* __restrict__ colpart,
                                                         float* __restrict__ blkscal, float* __restrict__ dtbp) {
   constexpr int DZ = E * FDD;
-  const T* ain = (const T*)ain_;
+  const T* ain = (const T*)ain_; const T* Z = (const T*)Z_; const T* dy_in = (const T*)dy_in_;
   T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
   __shared__ float s_TT[FK * LD32];
   __shared__ float s_TW[FK * LD64];     // [k][dd]
@@ -681,13 +693,14 @@ __global__ void __launch_bounds__(256, 2) kf_pre_small_bwd(FPreBArgs a, const fl
       const float mu = (a.ln_before && ok) ? rmu[(long)t.NT * E + tok * E + e] : 0.f;
       const float irr = 1.f / rr;
       // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
-      float4 dzr[4];
+      float4 dzr[4], zrow[4], dyrow[4];
       float s_dr = 0.f, s_dmu = 0.f;
+      zero_row(zrow); zero_row(dyrow);
+      if (ok) { ld_row<T, E>(Z + tok * DZ, e, q, zrow); ld_row<T, E>(dy_in + tok * DZ, e, q, dyrow); }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const long off = tok * DZ + zcol<E>(c, e, q);
-        const float4 z = ok ? ld4(Z + off) : zero4();
-        const float4 dyv = ok ? ld4(dy_in + off) : zero4();
+        const float4& z = zrow[c];
+        const float4& dyv = dyrow[c];
         const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q);
         const float4 mdy = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q), mdyz = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
         const float4 ws = ld4(s_bn + oz + 5 * FDD + 16 * c + 4 * q), dc = ld4(s_bn + oz + 6 * FDD + 16 * c + 4 * q);
@@ -846,7 +859,7 @@ int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   FPreArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
-  LAUNCH_TE(d.bf16, kf_pre_small, a, (float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
+  LAUNCH_TE(d.bf16, kf_pre_small, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu),
             (float*)(scratch + pl.o_colpart));
@@ -860,7 +873,7 @@ int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidFArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per);
-  LAUNCH_TE(d.bf16, kf_mid, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
+  LAUNCH_TE(d.bf16, kf_mid, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
             (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("mid (64/32)");
   return OK;
@@ -872,7 +885,7 @@ int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_pt
   FPostArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
-  LAUNCH_TE(d.bf16, kf_post_small, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
+  LAUNCH_TE(d.bf16, kf_post_small, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
   AVMOE_CHECK_LAUNCH("post_small (64/32)");
   return OK;
@@ -884,9 +897,9 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
   FPostBArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
-  LAUNCH_TE(d.bf16, kf_post_small_bwd, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
+  LAUNCH_TE(d.bf16, kf_post_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),
-            (const float*)(scratch + pl.o_dAp), (float*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),
+            (const float*)(scratch + pl.o_dAp), (void*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),
             (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
   AVMOE_CHECK_LAUNCH("post_small_bwd (64/32)");
   return OK;
@@ -898,9 +911,9 @@ int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per); a.moments = d.use_bn && d.training;
-  hipLaunchKernelGGL((kf_mid_bwd<4>), grid, dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-                     (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (float*)(scratch + pl.o_dzp),
-                     (float*)(scratch + pl.o_colpart));
+  LAUNCH_TE(d.bf16, kf_mid_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+            (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (void*)(scratch + pl.o_dzp),
+            (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("mid_bwd (64/32)");
   return OK;
 }
@@ -911,10 +924,10 @@ int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   FPreBArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
-  LAUNCH_TE(d.bf16, kf_pre_small_bwd, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
+  LAUNCH_TE(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
             (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum),
             (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a), (const float*)(saved + pl.o_rmu),
-            (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_dzp),
+            (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const void*)(scratch + pl.o_dzp),
             (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw), (void*)(scratch + pl.o_ag),
             (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x), (float*)(scratch + pl.o_colpart),
             (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
