@@ -59,12 +59,16 @@ __device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, in
 
 // KS / KS2: 32-wide K steps of the first / second segment (KS2 = 0: none).  The second segment's B2 is per sample
 // (MN-major) and is re-read into registers whenever the block moves on to the next sample.
-template <int KS, int KS2, int TPW, int NW, int BM>
+// A2MN: the second segment's A2 is MN-major ([k2][m], leading dim lda2): it is read along m and transposed into the
+// K-major LDS rows with 2-byte stores (its K2 is small), so the MFMA loop is the same.
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN>
 __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p) {
   constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
+  constexpr int CPR1 = A2MN ? KS * 4 : KSA * 4;           // 16-byte chunks per row that come from K-major sources
+  constexpr int TOT2 = A2MN ? KS2 * 32 * (BM / 8) : 0, NLD2 = A2MN ? (TOT2 + NT - 1) / NT : 1;
   constexpr int RB = KSA * 64 + 16;            // LDS bytes per A row (odd multiple of 16: conflict-free 16-byte fragment reads)
   constexpr int STG = BM * RB;
-  constexpr int CPR = KSA * 4, TOT = BM * CPR, NLD = (TOT + NT - 1) / NT;
+  constexpr int CPR = CPR1, TOT = BM * CPR, NLD = (TOT + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int g = blockIdx.y;
@@ -96,11 +100,26 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
   bf16x8 bfr2[TPW][KS2 > 0 ? KS2 : 1];
   int cur_s = -1;
 
-  u32x4 ra[NLD];
+  u32x4 ra[NLD], ra2[NLD2];
   auto gload = [&](int tile) {
     const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
     const char* A1 = p.A + ((long)s * p.sA1 + (long)g * p.sA2) * 2;
     const char* A2 = KS2 > 0 ? p.A2 + ((long)s * p.s2A1 + (long)g * p.s2A2) * 2 : nullptr;
+    if constexpr (A2MN) {
+#pragma unroll
+      for (int i = 0; i < NLD2; ++i) {
+        const int c = tid + i * NT;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (c < TOT2) {
+          const int k2 = c / (BM / 8), m = m0 + (c % (BM / 8)) * 8;
+          if (k2 < p.K2 && m < p.Mper) {
+            v = *(const u32x4*)(A2 + ((long)k2 * p.lda2 + m) * 2);
+            if (m + 8 > p.Mper) v = mask_tail8(v, p.Mper - m);
+          }
+        }
+        ra2[i] = v;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
@@ -114,7 +133,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
               v = *(const u32x4*)(A1 + ((long)gm * p.lda + k) * 2);
               if (k + 8 > p.K) v = mask_tail8(v, p.K - k);
             }
-          } else if (KS2 > 0) {
+          } else if (KS2 > 0 && !A2MN) {
             const int k = (cc - KS * 4) * 8;
             if (k < p.K2) {
               v = *(const u32x4*)(A2 + ((long)gm * p.lda2 + k) * 2);
@@ -131,6 +150,18 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
       if (c < TOT) *(u32x4*)(smem + buf * STG + (c / CPR) * RB + (c % CPR) * 16) = ra[i];
+    }
+    if constexpr (A2MN) {
+#pragma unroll
+      for (int i = 0; i < NLD2; ++i) {
+        const int c = tid + i * NT;
+        if (c < TOT2) {
+          const int k2 = c / (BM / 8), mr = (c % (BM / 8)) * 8;
+          unsigned short* dst = (unsigned short*)(smem + buf * STG + mr * RB + (KS * 32 + k2) * 2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dst[j * (RB / 2)] = (unsigned short)((ra2[i][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+        }
+      }
     }
   };
 
@@ -239,10 +270,10 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
   }
 }
 
-template <int KS, int KS2, int TPW, int NW, int BM>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN = false>
 int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
-  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM>;
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN>;
   static bool attr_done = false;
   if (!attr_done) {
     if (LDS > 65536) {
@@ -268,9 +299,19 @@ int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
 
 // Returns OK when the product was launched, 1 when this shape is not one the streaming kernel is built for (the caller
 // then uses the tiled engine), negative on error.
-int launch_gemm_stream(const GemmArgs& a, hipStream_t st) {
-  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.ksplit > 1 || a.accumulate || a.sCj != 1 || (long)a.M * a.nb1 < 512 ||
-      a.K > 384 || a.N > 384 || (a.nb1 > 1 && (a.sB1 != 0 || a.M < 64)))
+int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
+  GemmArgs a = a_in;
+  bool a2mn = false;
+  if (a.A2 && a.a_layout == MN_MAJOR && a.b_layout == MN_MAJOR && a.s2B1 == 0 && a.sB1 != 0) {
+    // [MN-major A, per-sample B] + [K-major A2, shared B2]  (dY = Bm^T dV + dR^T Q): the shared-B segment becomes the
+    // stationary first segment, the MN-major one the per-sample second segment
+    std::swap(a.A, a.A2); std::swap(a.B, a.B2); std::swap(a.K, a.K2); std::swap(a.lda, a.lda2); std::swap(a.ldb, a.ldb2);
+    std::swap(a.sA1, a.s2A1); std::swap(a.sA2, a.s2A2); std::swap(a.sB1, a.s2B1); std::swap(a.sB2, a.s2B2);
+    a.a_layout = K_MAJOR; a.b_layout = MN_MAJOR;
+    a2mn = true;
+  }
+  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.ksplit > 1 || a.accumulate || a.sCj != 1 || (long)a.M * a.nb1 < 256 ||
+      a.K > 384 || a.N > 768 || (a.nb1 > 1 && (a.sB1 != 0 || a.M < 64)))
     return 1;
   if (a.A2 && (a.K2 > 96 || a.s2A1 == 0)) return 1;
   const int osz = a.out_dtype == GEMM_BF16 ? 2 : 4;
@@ -293,17 +334,19 @@ int launch_gemm_stream(const GemmArgs& a, hipStream_t st) {
   const double flops = 2.0 * nb * a.M * (double)a.N * (a.K + s.K2);
 // (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
 // (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
-#define STREAM_CASE(COND, KS_, KS2_, TPW_, NW_, BM_, PERCU_, NAME)                  \
-  if ((COND) && ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {   \
+#define STREAM_CASE(COND, KS_, KS2_, TPW_, NW_, BM_, PERCU_, A2MN_, NAME)           \
+  if ((COND) && a2mn == A2MN_ && ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {   \
     s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                               \
     ProfScope ps(NAME, abytes, flops, st);                                          \
-    return launch_inst<KS_, KS2_, TPW_, NW_, BM_>(s, a.nb2, PERCU_, st);            \
+    return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_>(s, a.nb2, PERCU_, st);     \
   }
-  STREAM_CASE(true, 5, 0, 2, 12, 64, 1, "gemm_stream_k160_n384")          // output GEMM: K = 4*32 + 12, N = 384 per group
-  STREAM_CASE(true, 12, 0, 2, 4, 32, 2, "gemm_stream_k384_n128")          // grouped down projection
-  STREAM_CASE(true, 12, 0, 1, 9, 32, 1, "gemm_stream_k384_n144")          // dApost = dOut Bpost (N = 140)
-  STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, 1, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
-  STREAM_CASE(true, 4, 3, 2, 12, 32, 1, "gemm_stream_k128+96_n384r")      // ... ragged frames
+  STREAM_CASE(true, 5, 0, 2, 12, 64, 1, false, "gemm_stream_k160_n384")          // output GEMM: K = 4*32 + 12, N = 384 per group
+  STREAM_CASE(true, 12, 0, 2, 4, 32, 2, false, "gemm_stream_k384_n128")          // grouped down projection
+  STREAM_CASE(true, 12, 0, 1, 9, 32, 1, false, "gemm_stream_k384_n144")          // dApost = dOut Bpost (N = 140)
+  STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, 1, false, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
+  STREAM_CASE(true, 4, 3, 2, 12, 32, 1, false, "gemm_stream_k128+96_n384r")      // ... ragged frames
+  STREAM_CASE(a.M % 64 == 0, 2, 3, 4, 12, 64, 1, true, "gemm_stream_k64+96mn_n768")   // dY = dR^T Q + [Bm ; wbar]^T dV
+  STREAM_CASE(true, 2, 3, 4, 12, 32, 1, true, "gemm_stream_k64+96mn_n768r")      // ... ragged frames
 #undef STREAM_CASE
   return 1;
 }

@@ -211,7 +211,7 @@ def test_gemm_throughput_report(capsys):
     dict(M=8193, N=12, K=8, b_mn=False, nb2=3, epilogue=True),                      # tiny N / K
 ])
 def test_streaming_kernel_shapes(case):
-    """M >= 512 with N, K <= 384 and K-major bf16 A is served by the B-stationary streaming kernel (gemm_stream.hip);
+    """M >= 256 with N, K <= 384 and K-major bf16 A is served by the B-stationary streaming kernel (gemm_stream.hip);
     the ragged M / N / K tails, both B layouts, both output types and the epilogue are checked against fp64."""
     case = dict(case)
     out_bf16 = case.get("out_bf16", False)
