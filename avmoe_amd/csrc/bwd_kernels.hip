@@ -172,10 +172,18 @@ __global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const fl
   float* dh1 = rbw + (long)s * 128;
   float* dh2 = rbw + (long)a.S * (128 + a.C2) + (long)s * 32;
   float* dlog = rbw + (long)a.S * (128 + a.C2 + 32) + (long)s * a.E;
-  if (threadIdx.x < a.E) {                       // column means of p for the LB loss
+  if (a.lb_loss && a.lb_grad) {                  // column means of p for the LB loss: 256 / 16 frame streams per expert
+    __shared__ float s_part[16][MAX_E];
+    const int e = threadIdx.x % MAX_E, u = threadIdx.x / MAX_E;
     float acc = 0.f;
-    for (int ss = 0; ss < a.S; ++ss) acc += probs[(long)ss * a.E + threadIdx.x];
-    s_pm[threadIdx.x] = acc / (float)a.S;
+    if (e < a.E) for (int ss = u; ss < a.S; ss += 16) acc += probs[(long)ss * a.E + e];
+    s_part[u][e] = acc;
+    __syncthreads();
+    if (threadIdx.x < a.E) {
+      float t = 0.f;
+      for (int k = 0; k < 16; ++k) t += s_part[k][threadIdx.x];
+      s_pm[threadIdx.x] = t / (float)a.S;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -419,54 +427,65 @@ __global__ void __launch_bounds__(256) kk_dqrqb_part(const void* dL1_, const flo
 }
 // final assembly of the remap / token parameter gradients
 struct Hop1FinArgs { W16 gtok; int e_of_lat[MAX_E]; int S, N, M, Mk, Mb, C, Cy, K, Kp, KL, Kcy, Kcyb; };
+// drw[c] += sum_kc T0[kc][c] dqr[kc] ; dbf[c] += sum_kc T0[kc][c] dqb[kc]      (in place in dvec; thread per channel)
 template <typename T>
-__global__ void kk_hop1_finalize(Hop1FinArgs a, const float* dWcK, const float* dWf, const float* dvec, const float* dT0,
-                                 const float* dqp_fin, const void* T0T_, const float* rw, const float* bf, float* gWc, float* gbc,
-                                 float* gWf, float* gbf) {
+__global__ void __launch_bounds__(256) kk_hop1_vec(const void* T0T_, const float* dqp_fin, float* dvec, int C, int Kcy, int Kcyb) {
   const T* T0T = (const T*)T0T_;
-  const float* drw0 = dvec; const float* dbf0 = dvec + a.C; const float* dwbar = dvec + 2 * a.C;
-  const float dbcbar = dvec[2 * a.C + a.Mb];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* dqr = dqp_fin; const float* dqb = dqp_fin + Kcyb;
+  float a0 = 0.f, a1 = 0.f;
+  for (int kc = 0; kc < Kcy; ++kc) { const float t = ldT<T>(T0T, (long)kc * C + c); a0 += t * dqr[kc]; a1 += t * dqb[kc]; }
+  dvec[c] += a0; dvec[C + c] += a1;
+}
+// final assembly of the remap / token parameter gradients (pure elementwise; grid.y selects the tensor)
+template <typename T>
+__global__ void __launch_bounds__(256) kk_hop1_finalize(Hop1FinArgs a, const float* dWcK, const float* dWf, const float* dvec, const float* dT0,
+                                                        const float* dqp_fin, const float* rw, const float* bf, float* gWc, float* gbc,
+                                                        float* gWf, float* gbf) {
+  const float* drw = dvec; const float* dbf = dvec + a.C; const float* dwbar = dvec + 2 * a.C;
   const float* dqr = dqp_fin; const float* dqb = dqp_fin + a.Kcyb;
-  const long n1 = (long)a.N * a.M, n2 = a.N, n3 = (long)a.C * a.Cy, n4 = a.C, n5 = (long)a.KL * a.C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + n4 + n5; i += (long)gridDim.x * 256) {
-    if (i < n1) {
-      const int n = (int)(i / a.M), m = (int)(i % a.M);
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.y == 0) {                             // conv_adapter weight (N x M) and bias
+    if (i < (unsigned)a.N * a.M) {
+      const unsigned n = i / a.M, m = i - n * a.M;
       if (gWc) gWc[i] = dWcK[(long)n * a.Mk + m] + dwbar[m] / (float)a.N;
-    } else if (i < n1 + n2) {
-      const int n = (int)(i - n1);
-      if (gbc) gbc[n] = dWcK[(long)n * a.Mk + a.M] + dbcbar / (float)a.N;
-    } else if (i < n1 + n2 + n3) {
-      const long k = i - n1 - n2;
-      const int c = (int)(k / a.Cy);
-      float drw = drw0[c];
-      for (int kc = 0; kc < a.Kcy; ++kc) drw += ldT<T>(T0T, (long)kc * a.C + c) * dqr[kc];
-      if (gWf) gWf[k] = dWf[k] + drw;                  // rw = Wf 1  =>  every column of row c gets drw[c]
-    } else if (i < n1 + n2 + n3 + n4) {
-      const int c = (int)(i - n1 - n2 - n3);
-      float v = dbf0[c];
-      for (int kc = 0; kc < a.Kcy; ++kc) v += ldT<T>(T0T, (long)kc * a.C + c) * dqb[kc];
-      if (gbf) gbf[c] = v;
-    } else {
-      const long k = i - n1 - n2 - n3 - n4;
-      const int kc = (int)(k / a.C), c = (int)(k % a.C);
-      float v = dT0[k];
-      if (kc < a.Kcy) v += dqr[kc] * rw[c] + dqb[kc] * bf[c];
+    } else if (i < (unsigned)a.N * a.M + a.N) {
+      const unsigned n = i - (unsigned)a.N * a.M;
+      if (gbc) gbc[n] = dWcK[(long)n * a.Mk + a.M] + dvec[2 * a.C + a.Mb] / (float)a.N;
+    }
+  } else if (blockIdx.y == 1) {                      // fc weight (C x Cy) and bias:  rw = Wf 1  =>  every column of row c gets drw[c]
+    if (i < (unsigned)a.C * a.Cy) {
+      const unsigned c = i / a.Cy;
+      if (gWf) gWf[i] = dWf[i] + drw[c];
+    } else if (i < (unsigned)a.C * a.Cy + a.C) {
+      const unsigned c = i - (unsigned)a.C * a.Cy;
+      if (gbf) gbf[c] = dbf[c];
+    }
+  } else {                                           // latent tokens
+    if (i < (unsigned)a.KL * a.C) {
+      const unsigned kc = i / a.C, c = i - kc * a.C;
+      float v = dT0[i];
+      if ((int)kc < a.Kcy) v += dqr[kc] * rw[c] + dqb[kc] * bf[c];
       float* gt = a.gtok.p[a.e_of_lat[kc / a.Kp]];
-      if (gt && (kc % a.Kp) < a.K) gt[(long)(kc % a.Kp) * a.C + c] = v;
+      if (gt && (int)(kc % a.Kp) < a.K) gt[(long)(kc % a.Kp) * a.C + c] = v;
     }
   }
 }
 
 // down projection / ln_before gradients from dWt (+ dwsum, ddconst)
 struct DownBwdArgs { P16 down, lnbw, lnbb; W16 gdown, glnbw, glnbb; int E, g, dg, dgp, Cg, DZ, ln_before; };
-__global__ void kk_down_bwd(DownBwdArgs a, const float* dWt, const float* dsm) {
-  const long tot = (long)a.E * a.g * a.Cg;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % a.Cg), gi = (int)((i / a.Cg) % a.g), e = (int)(i / ((long)a.Cg * a.g));
-    const float gb = a.ln_before ? a.lnbw.p[e][gi * a.Cg + c] : 1.f;
-    const float bb = a.ln_before ? a.lnbb.p[e][gi * a.Cg + c] : 0.f;
-    float dgb = 0.f, dbb = 0.f;
-    for (int jp = 0; jp < a.dg; ++jp) {
+__global__ void __launch_bounds__(256) kk_down_bwd(DownBwdArgs a, const float* dWt, const float* dsm) {
+  // block = 64 channels x 4 bottleneck-row streams of one (expert, group); the two LayerNorm sums are combined through LDS
+  __shared__ float red[2][4][64];
+  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l, gi = blockIdx.y % a.g, e = blockIdx.y / a.g;
+  const bool on = c < a.Cg;
+  const float gb = (a.ln_before && on) ? a.lnbw.p[e][gi * a.Cg + c] : 1.f;
+  const float bb = (a.ln_before && on) ? a.lnbb.p[e][gi * a.Cg + c] : 0.f;
+  float dgb = 0.f, dbb = 0.f;
+  if (on)
+    for (int jp = u; jp < a.dg; jp += 4) {
       const int row = (gi * a.E + e) * a.dgp + jp;
       float dwt = dWt[(long)row * a.Cg + c];
       float ddc = 0.f;
@@ -475,10 +494,11 @@ __global__ void kk_down_bwd(DownBwdArgs a, const float* dWt, const float* dsm) {
       if (a.gdown.p[e]) a.gdown.p[e][(long)(gi * a.dg + jp) * a.Cg + c] = dwt * gb + ddc * bb;
       dgb += dwt * wd; dbb += ddc * wd;
     }
-    if (a.ln_before) {
-      if (a.glnbw.p[e]) a.glnbw.p[e][gi * a.Cg + c] = dgb;
-      if (a.glnbb.p[e]) a.glnbb.p[e][gi * a.Cg + c] = dbb;
-    }
+  red[0][u][l] = dgb; red[1][u][l] = dbb;
+  __syncthreads();
+  if (u == 0 && on && a.ln_before) {
+    if (a.glnbw.p[e]) a.glnbw.p[e][gi * a.Cg + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+    if (a.glnbb.p[e]) a.glnbb.p[e][gi * a.Cg + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
   }
 }
 
@@ -584,12 +604,15 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   Hop1FinArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gtok.p[e] = grads.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e]; }
   a.S = d.S; a.N = d.N; a.M = d.M; a.Mk = d.Mk; a.Mb = d.Mb; a.C = d.C; a.Cy = d.Cy; a.K = d.K; a.Kp = d.Kp; a.KL = d.KL; a.Kcy = d.Kcy; a.Kcyb = d.Kcyb;
-  const long tot = (long)d.N * d.M + d.N + (long)d.C * d.Cy + d.C + (long)d.KL * d.C;
+  const long big = std::max(std::max((long)d.N * d.M + d.N, (long)d.C * d.Cy + d.C), (long)d.KL * d.C);
+  if (big >= (1L << 31)) { set_last_error("hop1_finalize: parameter tensor too large"); return ERR_UNSUPPORTED; }
   const float* dqp_fin = (const float*)(scratch + pl.o_dqp) + 2L * d.S * d.Kcyb;
-  DISPATCH_T(d.bf16, kk_hop1_finalize, dim3(grid1db(tot)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWcK),
+  if (d.Kcy > 0)
+    DISPATCH_T(d.bf16, kk_hop1_vec, dim3(cdiv(d.C, 256)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T), dqp_fin, (float*)(scratch + pl.o_dvec),
+               d.C, d.Kcy, d.Kcyb);
+  DISPATCH_T(d.bf16, kk_hop1_finalize, dim3((unsigned)cdiv(big, 256), 3), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWcK),
              (const float*)(scratch + pl.o_dWf), (const float*)(scratch + pl.o_dvec), (const float*)(scratch + pl.o_dT0), dqp_fin,
-             (const void*)(saved + pl.o_T0T), (const float*)(saved + pl.o_rw), (const float*)prm.fc_b, grads.conv_w, grads.conv_b,
-             grads.fc_w, grads.fc_b);
+             (const float*)(saved + pl.o_rw), (const float*)prm.fc_b, grads.conv_w, grads.conv_b, grads.fc_w, grads.fc_b);
   AVMOE_CHECK_LAUNCH("hop1_finalize");
   return OK;
 }
@@ -602,7 +625,7 @@ int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const a
     a.gdown.p[e] = grads.e[e].down_w; a.glnbw.p[e] = grads.e[e].lnb_w; a.glnbb.p[e] = grads.e[e].lnb_b;
   }
   a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.DZ = d.DZ; a.ln_before = d.ln_before;
-  hipLaunchKernelGGL(kk_down_bwd, dim3(grid1db((long)d.E * d.g * d.Cg)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWt),
+  hipLaunchKernelGGL(kk_down_bwd, dim3((unsigned)cdiv(d.Cg, 64), (unsigned)(d.E * d.g)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWt),
                      (const float*)(scratch + pl.o_dsm));
   AVMOE_CHECK_LAUNCH("down_bwd");
   return OK;
