@@ -19,7 +19,6 @@ namespace avmoe {
 
 static inline unsigned grid1dw(long n, int cap = 4096) { return (unsigned)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
 
-constexpr int WCH = 128;     // channels per block
 constexpr int GCS = 8;       // channel chunks of the Gram kernels
 
 struct WArgs {
@@ -40,51 +39,60 @@ static void fill_w(const Dims& d, const avmoe_moe_ptrs& prm, const avmoe_moe_ptr
 }
 
 // ---------------------------------------------------------------------------------------------
-// BN2 statistics: mo[c] = Wu[c,:] . mz ; E[o^2][c] = Wu[c,:] Szz Wu[c,:]^T    grid (g*E, ceil(Cg/WCH))
+// BN2 statistics: mo[c] = Wu[c,:] . mz ; E[o^2][c] = Wu[c,:] Szz Wu[c,:]^T    grid (g*E, ceil(Cg/8))
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WCH) kw_bn2_stats(WArgs a, const float* mz, const float* Szz, float* bn2) {
+// block = BS_CH channels x 32 bottleneck lanes: lane jl owns rows j = jl, jl + 32, .. of Szz Wu[c,:]^T; the two sums are
+// folded over the lanes in double
+constexpr int BS_CH = 8;
+__global__ void __launch_bounds__(256) kw_bn2_stats(WArgs a, const float* mz, const float* Szz, float* bn2) {
   extern __shared__ float sm[];
-  const int dg = a.dg, dgp = a.dgp, ldw = dg + 1;
-  float* s_S = sm;                     // dgp*dgp
-  float* s_m = s_S + dgp * dgp;        // dgp
-  float* s_w = s_m + dgp;              // WCH x ldw
+  const int dg = a.dg, dgp = a.dgp, ldm = dgp + 1;
+  float* s_S = sm;                     // dgp x ldm
+  float* s_m = s_S + dgp * ldm;        // dgp
+  float* s_w = s_m + dgp;              // BS_CH x dgp
   const int cb = blockIdx.x, i = cb / a.E, e = cb % a.E;
-  const int cl = blockIdx.y * WCH + threadIdx.x;            // channel inside the group
+  const int jl = threadIdx.x & 31, cc = threadIdx.x >> 5;
+  const int cl = blockIdx.y * BS_CH + cc;                   // channel inside the group
   const bool on = cl < a.Cg;
-  const int c = i * a.Cg + cl;
+  const int c = i * a.Cg + (on ? cl : 0);
   const bool stats = a.use_bn && a.training;
   if (stats) {
-    for (int k = threadIdx.x; k < dgp * dgp; k += WCH) s_S[k] = Szz[(long)cb * dgp * dgp + k];
-    for (int k = threadIdx.x; k < dgp; k += WCH) s_m[k] = mz[(long)cb * dgp + k];
-    if (on) for (int j = 0; j < dg; ++j) s_w[threadIdx.x * ldw + j] = a.up.p[e][(long)c * dg + j];
+    for (int k = threadIdx.x; k < dgp * dgp; k += 256) { const int r = k / dgp; s_S[r * ldm + (k - r * dgp)] = Szz[(long)cb * dgp * dgp + k]; }
+    for (int k = threadIdx.x; k < dgp; k += 256) s_m[k] = mz[(long)cb * dgp + k];
+    for (int j = jl; j < dgp; j += 32) s_w[cc * dgp + j] = (on && j < dg) ? a.up.p[e][(long)c * dg + j] : 0.f;
   }
   __syncthreads();
-  if (!on) return;
   float mo = 0.f, rs2 = 1.f, k2 = 1.f, h2 = 0.f;
   if (a.use_bn) {
     float v2;
     if (a.training) {
-      const float* wu = s_w + threadIdx.x * ldw;
+      const float* wu = s_w + cc * dgp;
       double dmo = 0.0, eo2 = 0.0;
-      for (int j = 0; j < dg; ++j) {
+      for (int j = jl; j < dg; j += 32) {
         dmo += (double)wu[j] * s_m[j];
         float row = 0.f;
-        for (int l = 0; l < dg; ++l) row += s_S[j * dgp + l] * wu[l];
+        for (int l = 0; l < dg; ++l) row += s_S[j * ldm + l] * wu[l];
         eo2 += (double)wu[j] * row;
       }
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) { dmo += __shfl_xor(dmo, o, 64); eo2 += __shfl_xor(eo2, o, 64); }
       mo = (float)dmo;
       const double v = fmax(eo2 - dmo * dmo, 0.0);
       v2 = (float)v;
       const double unb = a.NT > 1 ? v * ((double)a.NT / (a.NT - 1)) : v;
-      a.rm.p[e][c] = (1.f - a.momentum) * a.rm.p[e][c] + a.momentum * mo;
-      a.rv.p[e][c] = (1.f - a.momentum) * a.rv.p[e][c] + a.momentum * (float)unb;
+      if (on && jl == 0) {
+        a.rm.p[e][c] = (1.f - a.momentum) * a.rm.p[e][c] + a.momentum * mo;
+        a.rv.p[e][c] = (1.f - a.momentum) * a.rv.p[e][c] + a.momentum * (float)unb;
+      }
     } else { mo = a.rm.p[e][c]; v2 = a.rv.p[e][c]; }
     rs2 = rsqrtf(v2 + a.eps);
     k2 = a.w2.p[e][c] * rs2;
     h2 = a.b2.p[e][c] - mo * k2;
   }
-  const long EC = (long)a.E * a.C, idx = (long)e * a.C + c;
-  bn2[idx] = mo; bn2[EC + idx] = rs2; bn2[2 * EC + idx] = k2; bn2[3 * EC + idx] = h2;
+  if (on && jl == 0) {
+    const long EC = (long)a.E * a.C, idx = (long)e * a.C + c;
+    bn2[idx] = mo; bn2[EC + idx] = rs2; bn2[2 * EC + idx] = k2; bn2[3 * EC + idx] = h2;
+  }
 }
 
 // thread per (c, k'): Bpost[c][k']
@@ -205,8 +213,9 @@ int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   ProfScope ps_("k_post_prep", 0.0, 0.0, st);
   const Dims& d = pl.d;
   WArgs a; fill_w(d, prm, nullptr, &a);
-  const size_t sh = (size_t)(d.dgp * d.dgp + d.dgp + WCH * (d.dg + 1)) * sizeof(float);
-  hipLaunchKernelGGL(kw_bn2_stats, dim3(d.g * d.E, cdiv(d.Cg, WCH)), dim3(WCH), sh, st, a, (const float*)(saved + pl.o_mz),
+  const size_t sh = (size_t)(d.dgp * (d.dgp + 1) + d.dgp + BS_CH * d.dgp) * sizeof(float);
+  if (sh > 65536) { set_last_error("post_prep: bottleneck per group %d needs %zu B of LDS", d.dg, sh); return ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(kw_bn2_stats, dim3(d.g * d.E, cdiv(d.Cg, BS_CH)), dim3(256), sh, st, a, (const float*)(saved + pl.o_mz),
                      (const float*)(saved + pl.o_Szz), (float*)(saved + pl.o_bn2));
   DISPATCH_T(d.bf16, kw_build_bpost, dim3(grid1dw((long)d.C * d.KPp)), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2),
              (void*)(saved + pl.o_Bpost));
@@ -218,82 +227,98 @@ int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
 // ---------------------------------------------------------------------------------------------
 // POST_PREP backward, per channel: dBpost, dG, dusum, dvh, dH  ->  up_sampler / bn2 / ln_post gradients and
 // (dmo, dv2) per channel; then the channel contraction (kw_gram mode 1) gives dmz / NT and 2 dSzz / NT.
-// grid (g*E, ceil(Cg/WCH))
+// grid (g*E, ceil(Cg/8))
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WCH) kw_post_prep_bwd(WArgs a, const float* bn2, const float* dBp, const float* dGq, const float* dsm,
+// block = PB_CH channels x 32 bottleneck lanes of one (group, expert): lane jl owns rows j = jl, jl + 32, .. of the d x d
+// contractions (LDS matrices padded to an odd leading dim), the per-channel sums are folded with 5 shuffles
+constexpr int PB_CH = 8, PB_JMAX = 4;      // bottleneck per group <= 32 * PB_JMAX
+__global__ void __launch_bounds__(256) kw_post_prep_bwd(WArgs a, const float* bn2, const float* dBp, const float* dGq, const float* dsm,
                                                         const float* mz, const float* Szz, float* dmodv) {
   extern __shared__ float sm[];
-  const int dg = a.dg, dgp = a.dgp, ldw = dg + 1;
-  float* s_dG = sm;                      // dgp*dgp
-  float* s_S = s_dG + dgp * dgp;         // dgp*dgp
-  float* s_v = s_S + dgp * dgp;          // 3*dgp : dusum, dvh, mz
-  float* s_w = s_v + 3 * dgp;            // WCH x ldw
+  const int dg = a.dg, dgp = a.dgp, ldm = dgp + 1;
+  float* s_dG = sm;                      // dgp x ldm
+  float* s_S = s_dG + dgp * ldm;         // dgp x ldm
+  float* s_v = s_S + dgp * ldm;          // 3*dgp : dusum, dvh, mz
+  float* s_w = s_v + 3 * dgp;            // PB_CH x dgp
   const int cb = blockIdx.x, i = cb / a.E, e = cb % a.E;
-  const int cl = blockIdx.y * WCH + threadIdx.x;
+  const int jl = threadIdx.x & 31, cc = threadIdx.x >> 5;
+  const int cl = blockIdx.y * PB_CH + cc;
   const bool on = cl < a.Cg;
   const int c = i * a.Cg + cl;
   const bool stats = a.use_bn && a.training;
-  for (int k = threadIdx.x; k < dgp * dgp; k += WCH) {
-    s_dG[k] = a.ln_post ? dGq[(long)cb * dgp * dgp + k] : 0.f;
-    s_S[k] = stats ? Szz[(long)cb * dgp * dgp + k] : 0.f;
+  for (int k = threadIdx.x; k < dgp * dgp; k += 256) {
+    const int r = k / dgp, col = k - r * dgp;
+    s_dG[r * ldm + col] = a.ln_post ? dGq[(long)cb * dgp * dgp + k] : 0.f;
+    s_S[r * ldm + col] = stats ? Szz[(long)cb * dgp * dgp + k] : 0.f;
   }
-  for (int k = threadIdx.x; k < dgp; k += WCH) {
+  for (int k = threadIdx.x; k < dgp; k += 256) {
     s_v[k] = a.ln_post ? dsm[(long)cb * dgp + k] : 0.f;
     s_v[dgp + k] = a.ln_post ? dsm[a.DZ + (long)cb * dgp + k] : 0.f;
     s_v[2 * dgp + k] = stats ? mz[(long)cb * dgp + k] : 0.f;
   }
-  if (on) for (int j = 0; j < dg; ++j) s_w[threadIdx.x * ldw + j] = a.up.p[e][(long)c * dg + j];
+  for (int j = jl; j < dgp; j += 32) s_w[cc * dgp + j] = (on && j < dg) ? a.up.p[e][(long)c * dg + j] : 0.f;
   __syncthreads();
-  if (!on) return;
-  const long EC = (long)a.E * a.C, idx = (long)e * a.C + c;
+  const long EC = (long)a.E * a.C, idx = (long)e * a.C + (on ? c : 0);
   const float mo = bn2[idx], rs2 = bn2[EC + idx], k2 = bn2[2 * EC + idx], h2 = bn2[3 * EC + idx];
-  const float* wu = s_w + threadIdx.x * ldw;
-  const float gp = a.ln_post ? a.lpw.p[e][c] : 1.f;
-  const float* dBrow = dBp + (long)c * a.KPp;
+  const float* wu = s_w + cc * dgp;
+  const float gp = (a.ln_post && on) ? a.lpw.p[e][c] : 1.f;
+  const float* dBrow = dBp + (long)(on ? c : 0) * a.KPp;
   const float* dBmain = dBrow + e * dgp;
   const float dBh = dBrow[a.E * dgp + 3 * e + 0], dBg = dBrow[a.E * dgp + 3 * e + 1], dBb = dBrow[a.E * dgp + 3 * e + 2];
   float dH1 = 0.f, dH2 = 0.f;
   if (a.ln_post) { dH1 = dsm[8 * a.DZ + e]; dH2 = dsm[8 * a.DZ + a.E + e]; }
-  auto dWh_of = [&](int j) -> float {
-    float v = gp * dBmain[j];
-    if (a.ln_post) {
-      float acc = 0.f;
-      for (int l = 0; l < dg; ++l) acc += s_dG[j * dgp + l] * wu[l];
-      v += 2.f * k2 * acc + s_v[j] + s_v[dgp + j] * h2;
+  float dWh[PB_JMAX];
+  float dk2 = 0.f, dgp_acc = 0.f, dh2p = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < PB_JMAX; ++jj) {
+    const int j = jl + 32 * jj;
+    dWh[jj] = 0.f;
+    if (j < dg) {
+      float v = gp * dBmain[j];
+      if (a.ln_post) {
+        float acc = 0.f;
+        for (int l = 0; l < dg; ++l) acc += s_dG[j * ldm + l] * wu[l];
+        v += 2.f * k2 * acc + s_v[j] + s_v[dgp + j] * h2;
+      }
+      dWh[jj] = v;
+      dk2 += v * wu[j];
+      dgp_acc += dBmain[j] * (wu[j] * k2);
+      if (a.ln_post) dh2p += s_v[dgp + j] * (wu[j] * k2);
     }
-    return v;
-  };
-  float dk2 = 0.f, dgp_acc = 0.f, dh2 = gp * dBh;
-  for (int j = 0; j < dg; ++j) {
-    const float dWh = dWh_of(j);
-    dk2 += dWh * wu[j];
-    dgp_acc += dBmain[j] * (wu[j] * k2);
-    if (a.ln_post) dh2 += s_v[dgp + j] * (wu[j] * k2);
   }
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) { dk2 += __shfl_xor(dk2, o, 64); dgp_acc += __shfl_xor(dgp_acc, o, 64); dh2p += __shfl_xor(dh2p, o, 64); }
+  float dh2 = gp * dBh + dh2p;
   if (a.ln_post) {
     dh2 += dH1 + 2.f * h2 * dH2;
-    if (a.glpw.p[e]) a.glpw.p[e][c] = dgp_acc + dBh * h2 + dBg;
-    if (a.glpb.p[e]) a.glpb.p[e][c] = dBb;
+    if (on && jl == 0) {
+      if (a.glpw.p[e]) a.glpw.p[e][c] = dgp_acc + dBh * h2 + dBg;
+      if (a.glpb.p[e]) a.glpb.p[e][c] = dBb;
+    }
   }
   float dmo = 0.f, dv2 = 0.f;
   if (a.use_bn) {
-    if (a.gb2.p[e]) a.gb2.p[e][c] = dh2;
+    if (on && jl == 0 && a.gb2.p[e]) a.gb2.p[e][c] = dh2;
     dmo = -k2 * dh2;
     dk2 -= mo * dh2;
-    if (a.gw2.p[e]) a.gw2.p[e][c] = dk2 * rs2;
-    dv2 = dk2 * a.w2.p[e][c] * (-0.5f) * rs2 * rs2 * rs2;
+    if (on && jl == 0 && a.gw2.p[e]) a.gw2.p[e][c] = dk2 * rs2;
+    dv2 = dk2 * (on ? a.w2.p[e][c] : 0.f) * (-0.5f) * rs2 * rs2 * rs2;
     if (a.training) dmo -= 2.f * mo * dv2; else { dmo = 0.f; dv2 = 0.f; }
   }
-  dmodv[idx] = dmo; dmodv[EC + idx] = dv2;
-  float* gu = a.gup.p[e] ? a.gup.p[e] + (long)c * dg : nullptr;
-  for (int j = 0; j < dg; ++j) {
-    float v = dWh_of(j) * k2;
-    if (stats) {
-      float acc = 0.f;
-      for (int l = 0; l < dg; ++l) acc += s_S[j * dgp + l] * wu[l];
-      v += dmo * s_v[2 * dgp + j] + 2.f * dv2 * acc;
+  if (on && jl == 0) { dmodv[idx] = dmo; dmodv[EC + idx] = dv2; }
+  float* gu = (on && a.gup.p[e]) ? a.gup.p[e] + (long)c * dg : nullptr;
+#pragma unroll
+  for (int jj = 0; jj < PB_JMAX; ++jj) {
+    const int j = jl + 32 * jj;
+    if (j < dg) {
+      float v = dWh[jj] * k2;
+      if (stats) {
+        float acc = 0.f;
+        for (int l = 0; l < dg; ++l) acc += s_S[j * ldm + l] * wu[l];
+        v += dmo * s_v[2 * dgp + j] + 2.f * dv2 * acc;
+      }
+      if (gu) gu[j] = v;
     }
-    if (gu) gu[j] = v;
   }
 }
 
@@ -301,8 +326,10 @@ int k_post_prep_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   ProfScope ps_("k_post_prep_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   WArgs a; fill_w(d, prm, &grads, &a);
-  const size_t sh = (size_t)(2 * d.dgp * d.dgp + 3 * d.dgp + WCH * (d.dg + 1)) * sizeof(float);
-  hipLaunchKernelGGL(kw_post_prep_bwd, dim3(d.g * d.E, cdiv(d.Cg, WCH)), dim3(WCH), sh, st, a, (const float*)(saved + pl.o_bn2),
+  if (d.dg > 32 * PB_JMAX) { set_last_error("post_prep_bwd: bottleneck per group %d > %d", d.dg, 32 * PB_JMAX); return ERR_UNSUPPORTED; }
+  const size_t sh = (size_t)(2 * d.dgp * (d.dgp + 1) + 3 * d.dgp + PB_CH * d.dgp) * sizeof(float);
+  if (sh > 65536) { set_last_error("post_prep_bwd: bottleneck per group %d needs %zu B of LDS", d.dg, sh); return ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(kw_post_prep_bwd, dim3(d.g * d.E, cdiv(d.Cg, PB_CH)), dim3(256), sh, st, a, (const float*)(saved + pl.o_bn2),
                      (const float*)(scratch + pl.o_dBp), (const float*)(scratch + pl.o_dGq), (const float*)(scratch + pl.o_dsm),
                      (const float*)(saved + pl.o_mz), (const float*)(saved + pl.o_Szz), (float*)(scratch + pl.o_dmodv));
   AVMOE_CHECK_LAUNCH("post_prep_bwd");
