@@ -48,8 +48,16 @@ __device__ __forceinline__ float qmax4(float v) {
   const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
+// sum over the 16 lanes of a row (all tokens of the tile, fixed q): DPP adds -- quad swaps, then half-row and row mirrors
+// (after the quad steps every quad is uniform, so a mirror pairs the right partners)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float rsum16(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror
   return v;
 }
 // an integer the optimiser cannot see through (always 0): added to LDS offsets inside the tile loops so that the per-expert
@@ -108,6 +116,28 @@ template <typename T, int E> __device__ __forceinline__ void ld_row(const T* row
 template <typename T, int E> __device__ __forceinline__ void st_row(T* row, int e, int q, const float4 (&v)[4]) {
   st_seg<T>(row + e * FDG, v[0], v[1], q); st_seg<T>(row + E * FDG + e * FDG, v[2], v[3], q);
 }
+// the same row as RAW registers (bf16: 2 x 16 bytes): several tiles' loads are kept in flight in this form and only
+// unpacked (quad exchange + widen) when a tile is computed
+template <typename T> struct RawRow;
+template <> struct RawRow<float> { float4 v[4]; };
+template <> struct RawRow<__bf16> { uint4 v[2]; };
+template <int E> __device__ __forceinline__ void ldraw_row(const float* row, int e, int q, RawRow<float>& o) {
+  o.v[0] = *(const float4*)(row + e * FDG + 4 * q); o.v[1] = *(const float4*)(row + e * FDG + 16 + 4 * q);
+  o.v[2] = *(const float4*)(row + E * FDG + e * FDG + 4 * q); o.v[3] = *(const float4*)(row + E * FDG + e * FDG + 16 + 4 * q);
+}
+template <int E> __device__ __forceinline__ void ldraw_row(const __bf16* row, int e, int q, RawRow<__bf16>& o) {
+  o.v[0] = *(const uint4*)(row + e * FDG + seg_off8(q)); o.v[1] = *(const uint4*)(row + E * FDG + e * FDG + seg_off8(q));
+}
+__device__ __forceinline__ void zero_raw(RawRow<float>& o) { o.v[0] = o.v[1] = o.v[2] = o.v[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zero_raw(RawRow<__bf16>& o) { o.v[0] = o.v[1] = make_uint4(0u, 0u, 0u, 0u); }
+__device__ __forceinline__ void unpack_row(const RawRow<float>& i, float4 (&v)[4]) { v[0] = i.v[0]; v[1] = i.v[1]; v[2] = i.v[2]; v[3] = i.v[3]; }
+__device__ __forceinline__ void unpack_seg(const uint4& u, float4& c0, float4& c1) {
+  const auto s0 = __builtin_amdgcn_permlane16_swap(u.x, u.z, false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(u.y, u.w, false, false);
+  c0 = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u), __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u));
+  c1 = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u));
+}
+__device__ __forceinline__ void unpack_row(const RawRow<__bf16>& i, float4 (&v)[4]) { unpack_seg(i.v[0], v[0], v[1]); unpack_seg(i.v[1], v[2], v[3]); }
 __device__ __forceinline__ void zero_row(float4 (&v)[4]) { v[0] = v[1] = v[2] = v[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
 __device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
@@ -264,27 +294,29 @@ __global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const void* __rest
     float4 sc[4], sh[4], cs0[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { sc[c] = ld4(s_c + 16 * c + 4 * q); sh[c] = ld4(s_c + FDD + 16 * c + 4 * q); cs0[c] = zero4(); }
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 128) {       // two tiles per step: 8 row loads in flight per lane
-      float4 z[2][4];
-      bool ok[2];
-      long tok[2];
+    constexpr int UT = 4;                                            // tiles per step: all their row loads in flight together
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64 * UT) {
+      RawRow<T> z[UT];
+      bool ok[UT];
+      long tok[UT];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < UT; ++u) {
         const int n = n0 + 64 * u;
         ok[u] = n < n_end && n + r < t.N;
         tok[u] = (long)s * t.N + n + r;
-        zero_row(z[u]);
-        if (ok[u]) ld_row<T, E>(Z + tok[u] * DZ, e, q, z[u]);
+        zero_raw(z[u]);
+        if (ok[u]) ldraw_row<E>(Z + tok[u] * DZ, e, q, z[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < UT; ++u) {
         if (!ok[u]) continue;
-        float4 zp[4];
+        float4 zr[4], zp[4];
+        unpack_row(z[u], zr);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
-            float y = at(z[u][c], x) * at(sc[c], x) + at(sh[c], x);
+            float y = at(zr[c], x) * at(sc[c], x) + at(sh[c], x);
             if (relu) y = fmaxf(y, 0.f);
             y = rndT<T>(y);
             at(zp[c], x) = y;

@@ -10,7 +10,11 @@ def load(path):
     tot, cnt = defaultdict(float), defaultdict(int)
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            name = re.sub(r"\(.*", "", row["Kernel_Name"])
+            name = row["Kernel_Name"]
+            m = re.search(r"(kf_\w+?)I[DfL]|(gemm_stream_kernel<[^>]*>)|(k[kw]_\w+?)I[DfL]|(gemm_kernelI\w+?)EEv|avmoe::(\w+)", name)
+            if m:
+                name = next(g for g in m.groups() if g)
+            name = re.sub(r"\(.*", "", name)
             name = re.sub(r"^void ", "", name)
             tot[name] += float(row["Counter_Value"])
             cnt[name] += 1
