@@ -13,7 +13,8 @@ class MoeDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("S", "N", "C", "M", "Cy", "E_m", "E_s", "d", "groups", "K", "use_bn",
                                          "use_gate", "ln_before", "ln_post", "variant", "self_attn", "lb_loss",
                                          "dtype", "training")] + \
-               [(n, C.c_float) for n in ("bn_eps", "ln_eps", "bn_momentum")]
+               [(n, C.c_float) for n in ("bn_eps", "ln_eps", "bn_momentum")] + \
+               [(n, C.c_int32) for n in ("accumulate_dx", "accumulate_dy")]
 
 
 _EXPERT_FIELDS = ("gate", "my_tokens", "gate_lat", "down_w", "up_w", "bn1_w", "bn1_b", "bn2_w", "bn2_b",

@@ -39,90 +39,147 @@ def _scratch(dev: torch.device, nbytes: int) -> torch.Tensor:
     return buf
 
 
+def _site_forward(module, X, Y, noise, names, params):
+    """One avmoe_moe_forward call.  Returns (out, probs, idx, lb, state) with state = what the backward needs."""
+    if not (X.is_cuda and Y.is_cuda):
+        raise capi.AvmoeError("avmoe_amd runs on MI355X only: tensors must live on a GPU (no CPU fallback)")
+    if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
+        raise capi.AvmoeError(f"activations must both be float32 or bfloat16, got {X.dtype} / {Y.dtype}")
+    L = capi.lib()
+    X = X.contiguous()
+    Y = Y.contiguous()
+    S, N, Cc = X.shape
+    desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
+    tensors = dict(zip(names, params))
+    for k, v in tensors.items():
+        if v.dtype != torch.float32 or not v.is_contiguous() or v.device != X.device:
+            raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {X.device}")
+    bufs = module._buffer_tensors()
+    ptrs = cm.make_ptrs({**tensors, **bufs}, module.num_multimodal_experts, module.num_singlemodal_experts)
+    nsaved = L.avmoe_moe_saved_bytes(C.byref(desc))
+    if nsaved == 0:
+        raise capi.AvmoeError(L.avmoe_last_error().decode())
+    saved = torch.empty(nsaved, dtype=torch.uint8, device=X.device)
+    scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
+    out = torch.empty_like(X)
+    E = module.num_multimodal_experts + module.num_singlemodal_experts
+    probs = torch.empty(S, E, device=X.device, dtype=torch.float32)
+    idx = torch.empty(S, device=X.device, dtype=torch.int64)
+    lb = torch.zeros((), device=X.device, dtype=torch.float32)
+    if noise is not None:
+        noise = noise.to(torch.float32).contiguous()
+    st = L.avmoe_moe_forward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs),
+                             noise.data_ptr() if noise is not None else None, out.data_ptr(), probs.data_ptr(),
+                             idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+                             torch.cuda.current_stream(X.device).cuda_stream)
+    capi.check(st, "avmoe_moe_forward")
+    return out, probs, idx, lb, (desc, saved, X, Y)
+
+
+def _site_backward(module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False):
+    """One avmoe_moe_backward call writing (or, with acc_*, adding) the token gradients into dX / dY.  Returns the
+    parameter gradients in `names` order (None where not needed, or for all of them when a gradient sink took them)."""
+    L = capi.lib()
+    desc, saved, X, Y = state
+    tensors = dict(zip(names, params))
+    ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors()}, module.num_multimodal_experts,
+                        module.num_singlemodal_experts)
+    # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
+    # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
+    # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
+    sink = getattr(module, "_grad_sink", None)
+    use_sink = sink is not None and all(needs) and sink.matches(names, tensors)
+    if use_sink:
+        flat = sink.flat if sink.fresh else torch.empty_like(sink.flat)
+        grads = {k: flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
+    else:
+        grads = {k: (torch.empty_like(v) if needs[i] else None) for i, (k, v) in enumerate(tensors.items())}
+    gptrs = cm.make_ptrs({k: v for k, v in grads.items() if v is not None}, module.num_multimodal_experts,
+                         module.num_singlemodal_experts)
+    d_out = d_out.to(X.dtype).contiguous()
+    lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
+    scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
+    desc.accumulate_dx, desc.accumulate_dy = int(acc_dx), int(acc_dy)
+    st = L.avmoe_moe_backward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs), d_out.data_ptr(),
+                              lbg.data_ptr() if lbg is not None else None, saved.data_ptr(),
+                              scratch.data_ptr(), dX.data_ptr(), dY.data_ptr(), C.byref(gptrs),
+                              torch.cuda.current_stream(X.device).cuda_stream)
+    desc.accumulate_dx = desc.accumulate_dy = 0
+    capi.check(st, "avmoe_moe_backward")
+    if use_sink:
+        if not sink.fresh:
+            sink.flat.add_(flat)                     # accumulation micro-step: one fused add for the whole site
+        sink.done()
+        return (None,) * len(names)
+    if sink is not None:
+        sink.calls -= 1
+    return tuple(grads[k] for k in names)
+
+
 class AdapterFunction(torch.autograd.Function):
     """out, probs, lb = f(X, Y, noise, *params) on token-major X:(S,N,C), Y:(S,M,Cy)."""
 
     @staticmethod
     def forward(ctx, module, X, Y, noise, names, *params):
-        if not (X.is_cuda and Y.is_cuda):
-            raise capi.AvmoeError("avmoe_amd runs on MI355X only: tensors must live on a GPU (no CPU fallback)")
-        if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
-            raise capi.AvmoeError(f"activations must both be float32 or bfloat16, got {X.dtype} / {Y.dtype}")
-        L = capi.lib()
-        X = X.contiguous()
-        Y = Y.contiguous()
-        S, N, Cc = X.shape
-        desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
-        tensors = dict(zip(names, params))
-        for k, v in tensors.items():
-            if v.dtype != torch.float32 or not v.is_contiguous() or v.device != X.device:
-                raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {X.device}")
-        bufs = module._buffer_tensors()
-        ptrs = cm.make_ptrs({**tensors, **bufs}, module.num_multimodal_experts, module.num_singlemodal_experts)
-        nsaved = L.avmoe_moe_saved_bytes(C.byref(desc))
-        if nsaved == 0:
-            raise capi.AvmoeError(L.avmoe_last_error().decode())
-        saved = torch.empty(nsaved, dtype=torch.uint8, device=X.device)
-        scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
-        out = torch.empty_like(X)
-        E = module.num_multimodal_experts + module.num_singlemodal_experts
-        probs = torch.empty(S, E, device=X.device, dtype=torch.float32)
-        idx = torch.empty(S, device=X.device, dtype=torch.int64)
-        lb = torch.zeros((), device=X.device, dtype=torch.float32)
-        if noise is not None:
-            noise = noise.to(torch.float32).contiguous()
-        st = L.avmoe_moe_forward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs),
-                                 noise.data_ptr() if noise is not None else None, out.data_ptr(), probs.data_ptr(),
-                                 idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
-                                 torch.cuda.current_stream(X.device).cuda_stream)
-        capi.check(st, "avmoe_moe_forward")
-        ctx.module, ctx.desc, ctx.names, ctx.saved_ws = module, desc, names, saved
+        out, probs, idx, lb, state = _site_forward(module, X, Y, noise, names, params)
+        ctx.module, ctx.names, ctx.state = module, names, state[:2]
         sink = getattr(module, "_grad_sink", None)
         if sink is not None and any(ctx.needs_input_grad[5:]):
             sink.calls += 1                              # the site's bucket is complete after as many backward calls
-        ctx.save_for_backward(X, Y, *params)
+        ctx.save_for_backward(state[2], state[3], *params)
         ctx.mark_non_differentiable(probs, idx)
         return out, probs, idx, lb
 
     @staticmethod
     def backward(ctx, d_out, _d_probs, _d_idx, d_lb):
-        L = capi.lib()
         X, Y, *params = ctx.saved_tensors
-        module, desc = ctx.module, ctx.desc
-        tensors = dict(zip(ctx.names, params))
-        ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors()}, module.num_multimodal_experts,
-                            module.num_singlemodal_experts)
-        # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
-        # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
-        # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
-        sink = getattr(module, "_grad_sink", None)
-        use_sink = sink is not None and all(ctx.needs_input_grad[5:]) and sink.matches(ctx.names, tensors)
-        if use_sink:
-            flat = sink.flat if sink.fresh else torch.empty_like(sink.flat)
-            grads = {k: flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
+        dX, dY = torch.empty_like(X), torch.empty_like(Y)
+        pg = _site_backward(ctx.module, (*ctx.state, X, Y), ctx.names, params, ctx.needs_input_grad[5:], d_out, d_lb, dX, dY)
+        return (None, dX, dY, None, None) + pg
+
+
+class _PairFunction(torch.autograd.Function):
+    """Both adapter sites of one backbone layer (net_trans_v3.py:695-698): site A adapts the tokens Xa with Xb as the other
+    modality, site B adapts Xb with Xa.  Each token tensor therefore receives two gradients (as X of one site and as Y of
+    the other); the second one is ADDED inside the GEMM epilogues (avmoe_moe_desc.accumulate_*), so no separate
+    accumulation pass over the token gradients runs."""
+
+    @staticmethod
+    def forward(ctx, site_a, site_b, Xa, Xb, names_a, names_b, *params):
+        na = len(names_a)
+        pa, pb = params[:na], params[na:]
+        out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa)
+        out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, st_a[3], st_a[2], None, names_b, pb)
+        ctx.sites, ctx.names, ctx.states = (site_a, site_b), (names_a, names_b), (st_a[:2], st_b[:2])
+        for site, needs in ((site_a, ctx.needs_input_grad[6:6 + na]), (site_b, ctx.needs_input_grad[6 + na:])):
+            sink = getattr(site, "_grad_sink", None)
+            if sink is not None and any(needs):
+                sink.calls += 1
+        ctx.save_for_backward(st_a[2], st_a[3], *params)
+        ctx.mark_non_differentiable(idx_a, idx_b)
+        return out_a, out_b, idx_a, idx_b
+
+    @staticmethod
+    def backward(ctx, d_a, d_b, _ia, _ib):
+        Xa, Xb, *params = ctx.saved_tensors
+        (site_a, site_b), (names_a, names_b) = ctx.sites, ctx.names
+        na = len(names_a)
+        gXa, gXb = torch.empty_like(Xa), torch.empty_like(Xb)
+        # both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The larger
+        # tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
+        # larger tensor runs second
+        first_b = Xa.numel() >= Xb.numel()
+        def run_a(acc):
+            return _site_backward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], ctx.needs_input_grad[6:6 + na], d_a,
+                                  None, gXa, gXb, acc_dx=acc, acc_dy=acc)              # dX -> gXa, dY -> gXb
+        def run_b(acc):
+            return _site_backward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], ctx.needs_input_grad[6 + na:], d_b,
+                                  None, gXb, gXa, acc_dx=acc, acc_dy=acc)              # dX -> gXb, dY -> gXa
+        if first_b:
+            pgb = run_b(False); pga = run_a(True)
         else:
-            grads = {k: (torch.empty_like(v) if ctx.needs_input_grad[5 + i] else None)
-                     for i, (k, v) in enumerate(tensors.items())}
-        gptrs = cm.make_ptrs({k: v for k, v in grads.items() if v is not None}, module.num_multimodal_experts,
-                             module.num_singlemodal_experts)
-        d_out = d_out.to(X.dtype).contiguous()
-        dX = torch.empty_like(X)
-        dY = torch.empty_like(Y)
-        lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
-        scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
-        st = L.avmoe_moe_backward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs), d_out.data_ptr(),
-                                  lbg.data_ptr() if lbg is not None else None, ctx.saved_ws.data_ptr(),
-                                  scratch.data_ptr(), dX.data_ptr(), dY.data_ptr(), C.byref(gptrs),
-                                  torch.cuda.current_stream(X.device).cuda_stream)
-        capi.check(st, "avmoe_moe_backward")
-        if use_sink:
-            if not sink.fresh:
-                sink.flat.add_(flat)                     # accumulation micro-step: one fused add for the whole site
-            sink.done()
-            return (None, dX, dY, None, None) + (None,) * len(ctx.names)
-        if sink is not None:
-            sink.calls -= 1
-        return (None, dX, dY, None, None) + tuple(grads[k] for k in ctx.names)
+            pga = run_a(False); pgb = run_b(True)
+        return (None, None, gXa, gXb, None, None) + pga + pgb
 
 
 class ExpertAdapter(nn.Module):
@@ -312,3 +369,33 @@ class MoEAdapterAVS(MoEAdapter):
             noise = torch.randn(x.shape[0], E, device=x.device, dtype=torch.float32) * 0.01
         out, probs, idx, lb = self._run(x, vis_token, noise)
         return out, idx.unsqueeze(-1), probs.unsqueeze(1), (lb if self.opt.use_load_balacing_loss == 1 else 0.)
+
+
+class AdapterPair(nn.Module):
+    """The two AVE / AVQA adapter sites of one backbone layer run as one autograd node:
+
+        pair = AdapterPair(audio_site, visual_site)            # two MoEAdapter / MoEAdapterAVQA modules (shared, not copied)
+        out_a, idx_a, out_v, idx_v = pair(f_a, f_v)            # == audio_site(f_a, f_v), visual_site(f_v, f_a)
+
+    Numerically identical to calling the two sites one after the other; in the backward the gradient each token tensor
+    receives from its second use is added inside the GEMM epilogues instead of by a separate accumulation kernel."""
+
+    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter):
+        super().__init__()
+        for m in (site_a, site_b):
+            if m.variant not in ("ave", "avqa"):
+                raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
+        self.site_a, self.site_b = site_a, site_b
+
+    def forward(self, x_a, x_b):
+        Xa = x_a.squeeze(-1).permute(0, 2, 1)
+        Xb = x_b.squeeze(-1).permute(0, 2, 1)
+        Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
+        out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, Xa, Xb, tuple(Pa.keys()), tuple(Pb.keys()),
+                                                         *Pa.values(), *Pb.values())
+        with torch.no_grad():
+            for m in (self.site_a, self.site_b):
+                if m.training and m.use_bn:
+                    m._bump_batches_tracked()
+        return (out_a.permute(0, 2, 1).unsqueeze(-1), idx_a.unsqueeze(-1),
+                out_b.permute(0, 2, 1).unsqueeze(-1), idx_b.unsqueeze(-1))

@@ -45,6 +45,22 @@ __device__ __forceinline__ u32x4 mask_tail8(u32x4 v, int valid) {     // keep th
   return v;
 }
 
+// A lane's run of 4 TPW bf16 output-row elements (columns nl ..): 16-byte loads where the run is 16-byte aligned (TPW even)
+template <int TPW>
+__device__ __forceinline__ void ld_run(const char* ptr, int nl, int N, u32x2 (&v)[TPW]) {
+  if constexpr (TPW % 2 == 0) {
+#pragma unroll
+    for (int t = 0; t < TPW; t += 2) {
+      if (nl + 4 * t + 4 < N) { const u32x4 w = *(const u32x4*)(ptr + 8 * t); v[t] = u32x2{w[0], w[1]}; v[t + 1] = u32x2{w[2], w[3]}; }
+      else if (nl + 4 * t < N) v[t] = *(const u32x2*)(ptr + 8 * t);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      if (nl + 4 * t < N) v[t] = *(const u32x2*)(ptr + 8 * t);
+  }
+}
+
 // One 8-element fragment of an MN-major matrix ([k][n], leading dim ld): elements k0 .. k0+7 of column n
 __device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, int n, int k0, int K) {
   u32x4 v = {0u, 0u, 0u, 0u};
@@ -61,7 +77,8 @@ __device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, in
 // (MN-major) and is re-read into registers whenever the block moves on to the next sample.
 // A2MN: the second segment's A2 is MN-major ([k2][m], leading dim lda2): it is read along m and transposed into the
 // K-major LDS rows with 2-byte stores (its K2 is small), so the MFMA loop is the same.
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN>
+// ACC: C += (bf16 C): the old values of a 16-row slab are requested one slab ahead of the MFMAs that need them.
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC>
 __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p) {
   constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
   constexpr int CPR1 = A2MN ? KS * 4 : KSA * 4;           // 16-byte chunks per row that come from K-major sources
@@ -200,23 +217,34 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
     // lane (r, q) owns C[m0 + 16 mt + r][nl .. nl + 4 TPW): tile t supplies elements 4 t .. 4 t + 3 of that run
     const int nl = nw0 + 4 * TPW * q;
     // optional epilogue operand: all of this tile's D fragments are requested before the MFMAs start
-    u32x2 dv[MT][TPW];
+    u32x2 dv[MT][TPW], cvn[ACC ? TPW : 1];
     float rsv[MT];
+    auto ldc = [&](int mt) {
+#pragma unroll
+      for (int t = 0; t < (ACC ? TPW : 1); ++t) cvn[t] = u32x2{0u, 0u};
+      if constexpr (ACC) {
+        const int m = m0 + 16 * mt + r;
+        if (m < p.Mper) ld_run<TPW>(Cb + ((long)m * p.ldc + nl) * 2, nl, p.N, cvn);
+      }
+    };
+    if constexpr (ACC) ldc(0);
     if (Db) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + r;
         rsv[mt] = (m < p.Mper) ? rsb[m] : 0.f;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          dv[mt][t] = u32x2{0u, 0u};
-          if (m < p.Mper && nl + 4 * t < p.N) dv[mt][t] = *(const u32x2*)(Db + ((long)m * p.ldd + nl + 4 * t) * 2);
-        }
+        for (int t = 0; t < TPW; ++t) dv[mt][t] = u32x2{0u, 0u};
+        if (m < p.Mper) ld_run<TPW>(Db + ((long)m * p.ldd + nl) * 2, nl, p.N, dv[mt]);
       }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       f32x4 acc[TPW];
+      u32x2 cvc[ACC ? TPW : 1];
+#pragma unroll
+      for (int t = 0; t < (ACC ? TPW : 1); ++t) cvc[t] = cvn[t];
+      if (ACC && mt + 1 < MT) ldc(mt + 1);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -242,6 +270,10 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
           if (Db) {
             acc[t][0] += rsv[mt] * bfbits(dv[mt][t][0] & 0xFFFFu); acc[t][1] += rsv[mt] * bfbits(dv[mt][t][0] >> 16);
             acc[t][2] += rsv[mt] * bfbits(dv[mt][t][1] & 0xFFFFu); acc[t][3] += rsv[mt] * bfbits(dv[mt][t][1] >> 16);
+          }
+          if constexpr (ACC) {
+            acc[t][0] += bfbits(cvc[t][0] & 0xFFFFu); acc[t][1] += bfbits(cvc[t][0] >> 16);
+            acc[t][2] += bfbits(cvc[t][1] & 0xFFFFu); acc[t][3] += bfbits(cvc[t][1] >> 16);
           }
         }
         char* cp = Cb + ((long)m * p.ldc + nl) * osz;
@@ -270,10 +302,10 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
   }
 }
 
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN = false>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC>
 int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
-  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN>;
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC>;
   static bool attr_done = false;
   if (!attr_done) {
     if (LDS > 65536) {
@@ -310,13 +342,13 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     a.a_layout = K_MAJOR; a.b_layout = MN_MAJOR;
     a2mn = true;
   }
-  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.ksplit > 1 || a.accumulate || a.sCj != 1 || (long)a.M * a.nb1 < 256 ||
+  if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.ksplit > 1 || (a.accumulate && a.out_dtype != GEMM_BF16) || a.sCj != 1 || (long)a.M * a.nb1 < 256 ||
       a.K > 384 || a.N > 768 || (a.nb1 > 1 && (a.sB1 != 0 || a.M < 64)))
     return 1;
   if (a.A2 && (a.K2 > 96 || a.s2A1 == 0)) return 1;
   const int osz = a.out_dtype == GEMM_BF16 ? 2 : 4;
   if (((uintptr_t)a.C % 16) || (a.sCi * osz) % 16 || (a.sC1 * osz) % 16 || (a.sC2 * osz) % 16 || (a.N % 4)) return 1;
-  if (a.D && (a.row_scale == nullptr || ((uintptr_t)a.D % 8) || (a.sDi * 2) % 8 || (a.sD1 * 2) % 8 || (a.sD2 * 2) % 8)) return 1;
+  if (a.D && (a.row_scale == nullptr || ((uintptr_t)a.D % 16) || (a.sDi * 2) % 16 || (a.sD1 * 2) % 16 || (a.sD2 * 2) % 16)) return 1;
   if (a.b_layout == K_MAJOR && (((uintptr_t)a.B % 16) || (a.ldb * 2) % 16 || (a.sB2 * 2) % 16)) return 1;
   StreamArgs s;
   s.A = (const char*)a.A; s.B = (const char*)a.B; s.A2 = (const char*)a.A2; s.B2 = (const char*)a.B2; s.C = (char*)a.C;
@@ -330,7 +362,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);
   const double nb = (double)a.nb1 * a.nb2;
   const double abytes = (nb * a.M * (double)(a.K + s.K2) + (double)a.nb2 * a.N * (double)a.K + nb * a.N * (double)s.K2) * 2.0 +
-                        nb * a.M * (double)a.N * osz + (a.D ? nb * a.M * (double)a.N * 2.0 : 0.0);
+                        nb * a.M * (double)a.N * osz * (a.accumulate ? 2.0 : 1.0) + (a.D ? nb * a.M * (double)a.N * 2.0 : 0.0);
   const double flops = 2.0 * nb * a.M * (double)a.N * (a.K + s.K2);
 // (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
 // (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
@@ -338,7 +370,10 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   if ((COND) && a2mn == A2MN_ && ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {   \
     s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                               \
     ProfScope ps(NAME, abytes, flops, st);                                          \
-    return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_>(s, a.nb2, PERCU_, st);     \
+    if constexpr (KS2_ > 0) {                                                       \
+      if (a.accumulate) return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, true>(s, a.nb2, PERCU_, st);   \
+    } else if (a.accumulate) return 1;                                              \
+    return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, false>(s, a.nb2, PERCU_, st);   \
   }
   STREAM_CASE(true, 5, 0, 2, 12, 64, 1, false, "gemm_stream_k160_n384")          // output GEMM: K = 4*32 + 12, N = 384 per group
   STREAM_CASE(true, 12, 0, 2, 4, 32, 2, false, "gemm_stream_k384_n128")          // grouped down projection

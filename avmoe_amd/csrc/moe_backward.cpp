@@ -69,6 +69,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.row_scale = (const float*)(sc + pl.o_rs2x); g.sRS1 = d.N; g.D = X; g.sDi = d.C; g.sD1 = (long)d.N * d.C; g.sD2 = d.Cg;
     g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
     g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
+    g.accumulate = d.acc_dx;
     AVMOE_TRY(run(g, false));
   }
   if (d.nxn) {   // ---- AVVP N x N block: back through ZR = xr Wt^T, the three row sums and xr = att^T X --------------------
@@ -239,6 +240,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
       g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
       g.A2 = sc + pl.o_dRT; g.B2 = sv + pl.o_Qx; g.K2 = d.Kcy; g.lda2 = d.Kcyp; g.ldb2 = d.Cy; g.s2A1 = (long)d.M * d.Kcyp;
+      g.accumulate = d.acc_dy;
       AVMOE_TRY(run(g, false));
     }
     {                                                      // dT0[y slots] += dQ Wf^T
@@ -260,6 +262,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
     g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
     g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
+    g.accumulate = d.acc_dy;
     AVMOE_TRY(run(g, false));
   }
   // ---- phase 6b: latent self attention on X (AVS v2) ----------------------------------------------

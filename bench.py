@@ -148,6 +148,8 @@ def main():
     audio, visual = build_site(c, device)
     params = list(audio.parameters()) + list(visual.parameters())
     reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=[audio, visual])
+    from avmoe_amd.adapters import AdapterPair
+    pair = AdapterPair(audio, visual)
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     f_a = (0.3 * torch.randn(S, c["N_a"], c["C"], generator=g)).to(device, tdt).requires_grad_(True)
@@ -159,8 +161,7 @@ def main():
     def step():
         reducer.begin(sync=True)
         xa, xv = f_a.permute(0, 2, 1).unsqueeze(-1), f_v.permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
-        out_a, _ = audio(xa, xv)                       # net_trans_v3.py:695
-        out_v, _ = visual(xv, xa)                      # net_trans_v3.py:697
+        out_a, _, out_v, _ = pair(xa, xv)              # net_trans_v3.py:695 and :697 as one autograd node
         torch.autograd.backward([out_a, out_v], [ga4, gv4])
         reducer.finish()
         f_a.grad = None

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 1
+#define AVMOE_ABI_VERSION 2
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -75,6 +75,10 @@ typedef struct avmoe_moe_desc {
   int32_t dtype;            /* activations */
   int32_t training;         /* 1: BatchNorm batch statistics + running-stat update ; 0: running stats */
   float bn_eps, ln_eps, bn_momentum;
+  /* backward only: add dX / dY to what the output buffers already hold instead of overwriting them -- lets a caller whose
+   * token tensor feeds several sites (the audio tokens are X of the audio site and Y of the visual site,
+   * net_trans_v3.py:695-698) collect the gradient in one buffer without a separate accumulation pass (ABI 2) */
+  int32_t accumulate_dx, accumulate_dy;
 } avmoe_moe_desc;
 
 typedef struct avmoe_expert_ptrs {        /* <list>.{j}.*  ; unused entries NULL                     */

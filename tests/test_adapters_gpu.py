@@ -107,3 +107,46 @@ def test_gradient_sink_matches_autograd_accumulation():
             assert int(b) == 2
     red.zero_grad()
     assert all(float(q.grad.abs().max()) == 0.0 for q in fused.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adapter_pair_equals_two_sites(dtype):
+    """AdapterPair(audio_site, visual_site) == the two MoEAdapter calls of net_trans_v3.py:695-698; the token gradients
+    (each tensor is X of one site and Y of the other) are accumulated inside the GEMM epilogues."""
+    from avmoe_amd.adapters import AdapterPair
+    dev = torch.device("cuda:0")
+    ca = O.AdapterConfig(Cx=64, Nx=272, Cy=48, Ny=80, reduction=4, groups=2, K=8)
+    cb = O.AdapterConfig(Cx=48, Nx=80, Cy=64, Ny=272, reduction=4, groups=2, K=8)
+    torch.manual_seed(3)
+    sa, sb = build_module("ave", ca).to(dev).train(), build_module("ave", cb).to(dev).train()
+    with torch.no_grad():
+        for m in (sa, sb):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.3)
+    g = torch.Generator().manual_seed(9)
+    fa = (0.5 * torch.randn(4, ca.Cx, ca.Nx, 1, generator=g)).to(dev, dtype)
+    fv = (0.5 * torch.randn(4, cb.Cx, cb.Nx, 1, generator=g)).to(dev, dtype)
+    ga = torch.randn(4, ca.Cx, ca.Nx, 1, generator=g).to(dev, dtype)
+    gv = torch.randn(4, cb.Cx, cb.Nx, 1, generator=g).to(dev, dtype)
+    bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in (sa, sb)]
+
+    def run(paired):
+        for m, bb in zip((sa, sb), bufs):
+            m.zero_grad()
+            m.load_state_dict({**m.state_dict(), **bb})
+        xa, xv = fa.clone().requires_grad_(True), fv.clone().requires_grad_(True)
+        if paired:
+            oa, ia, ov, iv = AdapterPair(sa, sb)(xa, xv)
+        else:
+            (oa, ia), (ov, iv) = sa(xa, xv), sb(xv, xa)
+        torch.autograd.backward([oa, ov], [ga, gv])
+        return oa.detach(), ov.detach(), ia, iv, xa.grad, xv.grad, [p.grad.clone() for m in (sa, sb) for p in m.parameters()]
+
+    ref, got = run(False), run(True)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3])
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    for r_, g_ in ((ref[4], got[4]), (ref[5], got[5])):
+        assert float((r_.float() - g_.float()).abs().max()) <= tol * float(r_.float().abs().max())
+    for r_, g_ in zip(ref[6], got[6]):
+        assert torch.equal(r_, g_)
