@@ -30,8 +30,8 @@ _SCRATCH: Dict[tuple, torch.Tensor] = {}
 
 
 def _scratch(dev: torch.device, nbytes: int) -> torch.Tensor:
-    """Per-device transient workspace, grown on demand and reused (all users are stream-ordered)."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(),)
+    """Transient workspace per (device, stream), grown on demand and reused (its users are ordered by that stream)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -145,13 +145,25 @@ class _PairFunction(torch.autograd.Function):
     accumulation pass over the token gradients runs."""
 
     @staticmethod
-    def forward(ctx, site_a, site_b, Xa, Xb, names_a, names_b, *params):
+    def forward(ctx, site_a, site_b, side, Xa, Xb, names_a, names_b, *params):
         na = len(names_a)
         pa, pb = params[:na], params[na:]
-        out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa)
-        out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, st_a[3], st_a[2], None, names_b, pb)
+        Xa, Xb = Xa.contiguous(), Xb.contiguous()
+        main = torch.cuda.current_stream(Xa.device)
+        if side is not None:                           # site B on the side stream, concurrently with site A
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb)
+            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa)
+            main.wait_stream(side)
+            for t_ in (out_b, idx_b, st_b[1]):
+                t_.record_stream(main)
+        else:
+            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa)
+            out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, st_a[3], st_a[2], None, names_b, pb)
+        ctx.side = side
         ctx.sites, ctx.names, ctx.states = (site_a, site_b), (names_a, names_b), (st_a[:2], st_b[:2])
-        for site, needs in ((site_a, ctx.needs_input_grad[6:6 + na]), (site_b, ctx.needs_input_grad[6 + na:])):
+        for site, needs in ((site_a, ctx.needs_input_grad[7:7 + na]), (site_b, ctx.needs_input_grad[7 + na:])):
             sink = getattr(site, "_grad_sink", None)
             if sink is not None and any(needs):
                 sink.calls += 1
@@ -165,21 +177,36 @@ class _PairFunction(torch.autograd.Function):
         (site_a, site_b), (names_a, names_b) = ctx.sites, ctx.names
         na = len(names_a)
         gXa, gXb = torch.empty_like(Xa), torch.empty_like(Xb)
+        needs_a, needs_b = ctx.needs_input_grad[7:7 + na], ctx.needs_input_grad[7 + na:]
+        if ctx.side is not None:
+            # the two backward passes run concurrently (own streams, own workspaces); each token tensor then gets its two
+            # gradients from separate buffers and one add
+            side, main = ctx.side, torch.cuda.current_stream(Xa.device)
+            gXa2, gXb2 = torch.empty_like(Xa), torch.empty_like(Xb)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pgb = _site_backward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb2, gXa2)
+            pga = _site_backward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb)
+            main.wait_stream(side)
+            for t_ in (gXa2, gXb2) + tuple(g_ for g_ in pgb if g_ is not None):
+                t_.record_stream(main)
+            gXa.add_(gXa2); gXb.add_(gXb2)
+            return (None, None, None, gXa, gXb, None, None) + pga + pgb
         # both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The larger
         # tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
         # larger tensor runs second
         first_b = Xa.numel() >= Xb.numel()
         def run_a(acc):
-            return _site_backward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], ctx.needs_input_grad[6:6 + na], d_a,
+            return _site_backward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a,
                                   None, gXa, gXb, acc_dx=acc, acc_dy=acc)              # dX -> gXa, dY -> gXb
         def run_b(acc):
-            return _site_backward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], ctx.needs_input_grad[6 + na:], d_b,
+            return _site_backward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b,
                                   None, gXb, gXa, acc_dx=acc, acc_dy=acc)              # dX -> gXb, dY -> gXa
         if first_b:
             pgb = run_b(False); pga = run_a(True)
         else:
             pga = run_a(False); pgb = run_b(True)
-        return (None, None, gXa, gXb, None, None) + pga + pgb
+        return (None, None, None, gXa, gXb, None, None) + pga + pgb
 
 
 class ExpertAdapter(nn.Module):
@@ -380,8 +407,12 @@ class AdapterPair(nn.Module):
     Numerically identical to calling the two sites one after the other; in the backward the gradient each token tensor
     receives from its second use is added inside the GEMM epilogues instead of by a separate accumulation kernel."""
 
-    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter):
+    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True):
+        """concurrent=True runs the two sites on two HIP streams (their kernels overlap; each token tensor's two gradients
+        are then summed by one add); False runs them back to back on the caller's stream and adds the second gradient inside
+        the GEMM epilogues instead."""
         super().__init__()
+        self.concurrent, self._side = bool(concurrent), None
         for m in (site_a, site_b):
             if m.variant not in ("ave", "avqa"):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
@@ -391,8 +422,10 @@ class AdapterPair(nn.Module):
         Xa = x_a.squeeze(-1).permute(0, 2, 1)
         Xb = x_b.squeeze(-1).permute(0, 2, 1)
         Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
-        out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, Xa, Xb, tuple(Pa.keys()), tuple(Pb.keys()),
-                                                         *Pa.values(), *Pb.values())
+        if self.concurrent and self._side is None:
+            self._side = torch.cuda.Stream(device=x_a.device)
+        out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, self._side if self.concurrent else None, Xa, Xb,
+                                                         tuple(Pa.keys()), tuple(Pb.keys()), *Pa.values(), *Pb.values())
         with torch.no_grad():
             for m in (self.site_a, self.site_b):
                 if m.training and m.use_bn:

@@ -385,9 +385,19 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
   }
 }
 
+
+// Algorithmic bytes of the bottleneck-space passes (every element each pass has to read or write, once; zsz / esz are the
+// element sizes of the Z-space and T-typed tensors) -- the numerators of their HBM rooflines.
+static double bytes_pre_small(const Dims& d) { return (double)d.NT * (2.0 * d.DZ * d.zsz + (d.KL ? (double)d.KL * (4 + d.esz) : 0.0) + 8.0 + 8.0 * d.E); }
+static double bytes_post_small(const Dims& d) { return (double)d.NT * ((double)d.DZ * d.zsz + (double)d.g * d.KPp * d.esz + 8.0 * d.E); }
+static double bytes_post_small_bwd(const Dims& d) { return (double)d.NT * ((double)d.DZ * (2.0 * d.zsz + 2.0 * d.esz) + (double)d.g * d.KPp * 4.0 + 8.0 * d.E); }
+static double bytes_mid_bwd(const Dims& d) { return (double)d.NT * (3.0 * d.DZ * d.zsz); }
+static double bytes_pre_small_bwd(const Dims& d) {
+  return (double)d.NT * ((double)d.DZ * (2.0 * d.zsz + d.esz) + (d.KL ? (double)d.KL * (4 + 4 * d.esz) : 0.0) + 8.0 * d.E + 12.0);
+}
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
-  ProfScope ps_("k_pre_small", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  ProfScope ps_("k_pre_small", bytes_pre_small(d), 0.0, st);
   if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
@@ -517,8 +527,8 @@ __global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* _
 }
 
 int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
-  ProfScope ps_("k_post_small", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  ProfScope ps_("k_post_small", bytes_post_small(d), 0.0, st);
   if (tile_fast_ok(d)) return kf_post_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostTArgs a;
@@ -1036,8 +1046,8 @@ static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes
 }
 
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
-  ProfScope ps_("k_post_small_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  ProfScope ps_("k_post_small_bwd", bytes_post_small_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_post_small_bwd(pl, saved, scratch, prm, st));
     return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
@@ -1069,8 +1079,8 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
 }
 
 int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
-  ProfScope ps_("k_mid_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  ProfScope ps_("k_mid_bwd", bytes_mid_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_mid_bwd(pl, saved, scratch, st));
     return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
@@ -1093,8 +1103,8 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 }
 
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
-  ProfScope ps_("k_pre_small_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
+  ProfScope ps_("k_pre_small_bwd", bytes_pre_small_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_pre_small_bwd(pl, saved, scratch, prm, st));
     return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);

@@ -211,8 +211,15 @@ def main():
                         kernel_tflops=round(tfs, 1), kernel_mfma_frac=round(tfs / MFMA_PEAK_TF[args.dtype], 4),
                         path_algorithmic_gbs=round(algorithmic_bytes_per_clip_pair(c, esz) * value / world / 1e9, 1),
                         path_reference_tflops=round(reference_flops_per_clip_pair(c) * value / world / 1e12, 1),
-                        families=sorted([dict(name=r["name"], calls=r["calls"] // nprof, ms_per_step=round(r["total_ms"] / nprof, 4))
-                                         for r in rep], key=lambda r: -r["ms_per_step"])[:12])
+                        families=sorted([dict(name=r["name"], calls=r["calls"] // nprof, ms_per_step=round(r["total_ms"] / nprof, 4),
+                                              gbs=round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1))
+                                         for r in rep], key=lambda r: -r["ms_per_step"])[:14])
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(tj):       # HBM bytes per launch of the dominant family, from the committed rocprofv3 --pmc passes
+            with open(tj) as fh:
+                t = json.load(fh).get(dom["name"])
+            if t:
+                roofline["traffic"] = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:

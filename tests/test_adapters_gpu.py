@@ -109,8 +109,9 @@ def test_gradient_sink_matches_autograd_accumulation():
     assert all(float(q.grad.abs().max()) == 0.0 for q in fused.parameters())
 
 
+@pytest.mark.parametrize("concurrent", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_adapter_pair_equals_two_sites(dtype):
+def test_adapter_pair_equals_two_sites(dtype, concurrent):
     """AdapterPair(audio_site, visual_site) == the two MoEAdapter calls of net_trans_v3.py:695-698; the token gradients
     (each tensor is X of one site and Y of the other) are accumulated inside the GEMM epilogues."""
     from avmoe_amd.adapters import AdapterPair
@@ -137,7 +138,7 @@ def test_adapter_pair_equals_two_sites(dtype):
             m.load_state_dict({**m.state_dict(), **bb})
         xa, xv = fa.clone().requires_grad_(True), fv.clone().requires_grad_(True)
         if paired:
-            oa, ia, ov, iv = AdapterPair(sa, sb)(xa, xv)
+            oa, ia, ov, iv = AdapterPair(sa, sb, concurrent=concurrent)(xa, xv)
         else:
             (oa, ia), (ov, iv) = sa(xa, xv), sb(xv, xa)
         torch.autograd.backward([oa, ov], [ga, gv])
