@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--batch", type=int, default=CFG2["B"], help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off"],
+                    help="how the two sites of the layer are run: AdapterPair on two streams / on one stream / two separate calls")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -149,7 +151,7 @@ def main():
     params = list(audio.parameters()) + list(visual.parameters())
     reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=[audio, visual])
     from avmoe_amd.adapters import AdapterPair
-    pair = AdapterPair(audio, visual)
+    pair = AdapterPair(audio, visual, concurrent=(args.pair == "concurrent"))
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     f_a = (0.3 * torch.randn(S, c["N_a"], c["C"], generator=g)).to(device, tdt).requires_grad_(True)
@@ -161,7 +163,11 @@ def main():
     def step():
         reducer.begin(sync=True)
         xa, xv = f_a.permute(0, 2, 1).unsqueeze(-1), f_v.permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
-        out_a, _, out_v, _ = pair(xa, xv)              # net_trans_v3.py:695 and :697 as one autograd node
+        if args.pair == "off":
+            out_a, _ = audio(xa, xv)                   # net_trans_v3.py:695
+            out_v, _ = visual(xv, xa)                  # net_trans_v3.py:697
+        else:
+            out_a, _, out_v, _ = pair(xa, xv)          # the same two calls as one autograd node (AdapterPair)
         torch.autograd.backward([out_a, out_v], [ga4, gv4])
         reducer.finish()
         f_a.grad = None
