@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256) kk_xstats(const void* X_, int N, int C, i
 }
 int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_xstats", (double)d.NT * ((double)d.C * d.esz + 8.0), 0.0, st);
+  ProfScope ps_("k_xstats", (long)d.NT, (double)d.NT * ((double)d.C * d.esz + 8.0), 0.0, st);
   const int epv = 16 / d.esz;
   if (d.C > 1536) { set_last_error("xstats: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
   const int rpb = (int)round_up(cdiv(d.N, d.xchunks), 64);      // a block sweeps 64 rows per step (4 waves x 4 quartets x 4 rows)
@@ -674,7 +674,7 @@ __global__ void kk_colsum_finalize(const float* colsum, int DZ, int slot, float 
 }
 int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_mid", (double)d.NT * d.DZ * (double)(d.zsz + d.esz), 0.0, st);
+  ProfScope ps_("k_mid", (long)d.NT, (double)d.NT * d.DZ * (double)(d.zsz + d.esz), 0.0, st);
   MidArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.E = d.E; a.dgp = d.dgp; a.DZ = d.DZ; a.NT = d.NT;

@@ -369,7 +369,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #define STREAM_CASE(COND, KS_, KS2_, TPW_, NW_, BM_, PERCU_, A2MN_, NAME)           \
   if ((COND) && a2mn == A2MN_ && ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {   \
     s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                               \
-    ProfScope ps(NAME, abytes, flops, st);                                          \
+    ProfScope ps(NAME, (long)a.M * a.nb1, abytes, flops, st);                       \
     if constexpr (KS2_ > 0) {                                                       \
       if (a.accumulate) return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, true>(s, a.nb2, PERCU_, st);   \
     } else if (a.accumulate) return 1;                                              \

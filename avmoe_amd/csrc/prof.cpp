@@ -1,5 +1,6 @@
 #include "prof.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -39,6 +40,16 @@ void prof_begin(const char* name, double bytes, double flops, hipStream_t st) {
   g_cur = Rec{name, bytes, flops, get_event(), get_event()};
   (void)hipEventRecord(g_cur.e0, st);
   g_open = true;
+}
+bool prof_shapes() {
+  static const bool on = getenv("AVMOE_PROF_SHAPES") != nullptr;
+  return on;
+}
+void prof_begin_tagged(const char* name, long tag, double bytes, double flops, hipStream_t st) {
+  if (!prof_shapes()) { prof_begin(name, bytes, flops, st); return; }
+  char buf[96];
+  snprintf(buf, sizeof(buf), "%s NT%ld", name, tag);
+  prof_begin(buf, bytes, flops, st);
 }
 void prof_end(hipStream_t st) {
   std::lock_guard<std::mutex> l(g_mu);

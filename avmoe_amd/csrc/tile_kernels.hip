@@ -397,7 +397,7 @@ static double bytes_pre_small_bwd(const Dims& d) {
 }
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_pre_small", bytes_pre_small(d), 0.0, st);
+  ProfScope ps_("k_pre_small", (long)d.NT, bytes_pre_small(d), 0.0, st);
   if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* _
 
 int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_post_small", bytes_post_small(d), 0.0, st);
+  ProfScope ps_("k_post_small", (long)d.NT, bytes_post_small(d), 0.0, st);
   if (tile_fast_ok(d)) return kf_post_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostTArgs a;
@@ -1047,7 +1047,7 @@ static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes
 
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_post_small_bwd", bytes_post_small_bwd(d), 0.0, st);
+  ProfScope ps_("k_post_small_bwd", (long)d.NT, bytes_post_small_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_post_small_bwd(pl, saved, scratch, prm, st));
     return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
@@ -1080,7 +1080,7 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
 
 int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_mid_bwd", bytes_mid_bwd(d), 0.0, st);
+  ProfScope ps_("k_mid_bwd", (long)d.NT, bytes_mid_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_mid_bwd(pl, saved, scratch, st));
     return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
@@ -1104,7 +1104,7 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_pre_small_bwd", bytes_pre_small_bwd(d), 0.0, st);
+  ProfScope ps_("k_pre_small_bwd", (long)d.NT, bytes_pre_small_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_pre_small_bwd(pl, saved, scratch, prm, st));
     return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
