@@ -232,9 +232,9 @@ def main():
         tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
         if os.path.isfile(tj):       # HBM bytes per launch of the dominant family, from the committed rocprofv3 --pmc passes
             with open(tj) as fh:
-                t = json.load(fh).get(dom["name"])
-            if t:
-                roofline["traffic"] = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
+                t = json.load(fh).get(dom["name"].split(" NT")[0].split(" M")[0])
+            if t:      # the dominant launch is the audio-side (largest) one of its family
+                roofline["traffic"] = t["read_bytes_largest_launch"] + t["write_bytes_largest_launch"]
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:

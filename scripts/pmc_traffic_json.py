@@ -1,6 +1,12 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of one bench run -> per-launch HBM bytes per profiler family
 (the names bench.py's roofline uses).   python scripts/pmc_traffic_json.py <fetch_csv> <write_csv> > profiles/r01_pmc_traffic.json
-FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 B: MI355X_MICROARCH.md, HBM section); both counters are in KB."""
+Both counters are in KB.  FETCH_SIZE is doubled for kernels that read with whole-line (16 B per lane, lane-contiguous)
+requests: gfx950 tallies a 128-byte read request at 64 B (MI355X_MICROARCH.md, HBM section).  The register-resident
+bottleneck-space kernels (k_pre_small .. k_mid_bwd) read 64-byte row segments -- one 64-byte request each -- and are NOT
+doubled: calibrated on k_mid / k_mid_bwd, whose only reads are Z (and dz') at a known byte count (undoubled FETCH_SIZE
+= 1.00x / 1.00x of it; doubled it would claim 2x)."""
+
+HALF_LINE_READERS = ("k_pre_small", "k_post_small", "k_post_small_bwd", "k_mid", "k_mid_bwd", "k_pre_small_bwd")
 import csv
 import json
 import re
@@ -27,29 +33,37 @@ def family(sym: str):
         return "k_xstats"
     m = re.search(r"gemm_stream_kernel<([^>]*)>", sym)
     if m:
-        return "gemm_stream<" + m.group(1).replace(" ", "") + ">"
+        a = [x.strip() for x in m.group(1).split(",")]
+        return STREAM.get(tuple(a[:6]), "gemm_stream<" + ",".join(a) + ">")
     return None
 
 
+STREAM = {("5", "0", "2", "12", "64", "false"): "gemm_stream_k160_n384", ("12", "0", "2", "4", "32", "false"): "gemm_stream_k384_n128",
+          ("12", "0", "1", "9", "32", "false"): "gemm_stream_k384_n144", ("4", "3", "2", "12", "64", "false"): "gemm_stream_k128+96_n384",
+          ("4", "3", "2", "12", "32", "false"): "gemm_stream_k128+96_n384r", ("2", "3", "4", "12", "64", "true"): "gemm_stream_k64+96mn_n768",
+          ("2", "3", "4", "12", "32", "true"): "gemm_stream_k64+96mn_n768r"}
+
+
 def load(path, scale):
-    tot, cnt = defaultdict(float), defaultdict(int)
+    """per family: mean and LARGEST per-launch bytes (the largest launch is the audio-side site of cfg-2)"""
+    vals = defaultdict(list)
     with open(path) as fh:
         for row in csv.DictReader(fh):
             f = family(row["Kernel_Name"])
             if f:
-                tot[f] += float(row["Counter_Value"]) * 1024.0 * scale
-                cnt[f] += 1
-    return tot, cnt
+                vals[f].append(float(row["Counter_Value"]) * 1024.0 * (1.0 if (scale == 2.0 and f in HALF_LINE_READERS) else scale))
+    return vals
 
 
 def main():
-    rd, rc = load(sys.argv[1], 2.0)
-    wr, wc = load(sys.argv[2], 1.0)
+    rd = load(sys.argv[1], 2.0)
+    wr = load(sys.argv[2], 1.0)
     out = {}
     for f in sorted(set(rd) | set(wr)):
-        n = max(rc.get(f, 0), wc.get(f, 0), 1)
-        out[f] = {"launches_profiled": n, "read_bytes_per_launch": round(rd.get(f, 0.0) / max(rc.get(f, 1), 1)),
-                  "write_bytes_per_launch": round(wr.get(f, 0.0) / max(wc.get(f, 1), 1))}
+        r, w = rd.get(f, [0.0]), wr.get(f, [0.0])
+        out[f] = {"launches_profiled": max(len(r), len(w)), "read_bytes_per_launch": round(sum(r) / len(r)),
+                  "write_bytes_per_launch": round(sum(w) / len(w)), "read_bytes_largest_launch": round(max(r)),
+                  "write_bytes_largest_launch": round(max(w))}
     json.dump(out, sys.stdout, indent=1)
 
 
