@@ -1,0 +1,160 @@
+// Second-moment (Gram) matrices of the bottleneck activations z' over ALL tokens, for the shape of tile_fast.hip
+// (bottleneck 64 in 2 groups, 4 experts, bf16 activations):
+//
+//   G[cb][j][l] = scale * sum_t w[e][t] * Zp[t][col(cb) + j] * Zp[t][col(cb) + l]      cb = group * E + e,  32 x 32 each
+//
+//   forward  (net_trans_v3.py:397-400 folded, algebra_ref.py "Szz"):  w = 1, scale = 1 / NT      -> BatchNorm-2 statistics
+//   backward (algebra_ref.py "dG"):                                    w = dSoo (LayerNorm-post variance gradient per token)
+//
+// One streaming pass over Zp (each row read once, whole 512-byte rows), instead of the 8 batched 32 x 32 token
+// contractions of the generic engine that each pull their 64-byte column slice out of every row.  Token tiles go
+// global -> registers -> LDS (two buffers); a wave owns two (group, expert) pairs and reads its operand fragments with the
+// transposing LDS read ds_read_b64_tr_b16 (tokens are the contraction index); the same fragment serves as A and as B
+// operand of v_mfma_f32_16x16x32_bf16 (the weighted form scales the A copy).  Per-block partial sums are written to
+// `part` and summed over the blocks by the deterministic column-sum kernel (no float atomics).
+#include "kernels.h"
+#include "device_utils.h"
+#include "prof.h"
+#include <algorithm>
+
+namespace avmoe {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int GE = 4, GG = 2, GD = 32, GDZ = GE * GG * GD;      // experts, groups, bottleneck per group, row width (256)
+constexpr int GT = 64;                                          // tokens per tile
+constexpr int G_ROWB = GDZ * 2 + 16;                            // LDS bytes per token row
+constexpr int G_TILE = GT * G_ROWB;
+
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restrict__ Zp, const float* __restrict__ w /* [E][NT] */,
+                                                 float* __restrict__ part, long NT, int tiles_per_blk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_w = (float*)(smem + 2 * G_TILE);                     // [2 buffers][E][GT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const long tile0 = (long)blockIdx.x * tiles_per_blk;
+  const long ntiles = (NT + GT - 1) / GT;
+  const long tile1 = min(ntiles, tile0 + (long)tiles_per_blk);
+
+  f32x4 acc[2][2][2];                                            // [pair of this wave][row tile][column tile]
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[8];                                                   // 64 rows x 32 chunks of 16 B / 256 threads
+  float rw = 0.f;
+  auto gload = [&](long tile) {
+    const long t0 = tile * GT;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 5, cc = c & 31;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t0 + row < NT) v = *(const u32x4*)(Zp + (t0 + row) * GDZ + cc * 8);
+      ra[i] = v;
+    }
+    if constexpr (WEIGHTED) {
+      const int e = tid >> 6, tl = tid & 63;                     // 4 experts x 64 tokens
+      rw = (t0 + tl < NT) ? w[(long)e * NT + t0 + tl] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* s = smem + buf * G_TILE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i;
+      *(u32x4*)(s + (c >> 5) * G_ROWB + (c & 31) * 16) = ra[i];
+    }
+    if constexpr (WEIGHTED) s_w[buf * GE * GT + tid] = rw;
+  };
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+  if (tile0 < tile1) { gload(tile0); lstore(0); }
+  __syncthreads();
+  for (long tile = tile0; tile < tile1; ++tile) {
+    const int buf = (int)((tile - tile0) & 1);
+    if (tile + 1 < tile1) gload(tile + 1);
+    const char* s = smem + buf * G_TILE;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int cb = 2 * wave + p, gi = cb / GE, e = cb % GE;
+      const int col0 = gi * (GE * GD) + e * GD;
+#pragma unroll
+      for (int ks = 0; ks < GT / 32; ++ks) {
+        bf16x8 f[2], fa[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {                        // fragment of columns col0 + 16 ct .., tokens 32 ks + 8 q .. + 7
+          const char* ad = s + (ks * 32 + 8 * q + (r >> 2)) * G_ROWB + (col0 + 16 * ct + 4 * (r & 3)) * 2;
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad));
+          const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + 4 * G_ROWB));
+          const s16x8 v = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+          f[ct] = __builtin_bit_cast(bf16x8, v);
+          fa[ct] = f[ct];
+          if constexpr (WEIGHTED) {                              // element i of the fragment <-> token 32 ks + 8 q + i
+            const float* wp = s_w + buf * GE * GT + e * GT + ks * 32 + 8 * q;
+            s16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (short)f2bf(bf2f((unsigned short)v[i]) * wp[i]);
+            fa[ct] = __builtin_bit_cast(bf16x8, o);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) acc[p][it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], f[jt], acc[p][it][jt], 0, 0, 0);
+      }
+    }
+    if (tile + 1 < tile1) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // C layout: lane (r, q) holds rows 4 q + x, column r of each 16 x 16 tile
+  float* out = part + (long)blockIdx.x * (GG * GE * GD * GD);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int cb = 2 * wave + p;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) out[(long)cb * GD * GD + (16 * it + 4 * q + x) * GD + 16 * jt + r] = acc[p][it][jt][x];
+  }
+}
+
+}  // namespace
+
+// G (g*E matrices of dgp x dgp, the layout of Szz / dGq) from Zp (NT, DZ) bf16; w = nullptr: unweighted.  Only for the
+// register-resident shape (tile_fast_ok) in bf16.
+int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st) {
+  const Dims& d = pl.d;
+  ProfScope ps_("k_gram64", (long)d.NT, (double)d.NT * (d.DZ * 2.0 + (w ? 4.0 * d.E : 0.0)), 2.0 * d.NT * (double)d.g * d.E * d.dgp * d.dgp, st);
+  if (!tile_fast_ok(d) || !d.bf16) { set_last_error("gram64: shape not covered"); return ERR_UNSUPPORTED; }
+  const long ntiles = cdiv((long)d.NT, GT);
+  const int nblk = (int)std::min<long>(GRAM_BLOCKS, ntiles);
+  const int tpb = (int)cdiv(ntiles, (long)nblk);
+  const size_t sh = 2 * G_TILE + 2 * GE * GT * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)kg_gram64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kg_gram64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      set_last_error("gram64: LDS attribute"); return ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const int used = (int)cdiv(ntiles, (long)tpb);
+  if (w) hipLaunchKernelGGL((kg_gram64<true>), dim3(used), dim3(256), sh, st, (const unsigned short*)Zp, w, part, (long)d.NT, tpb);
+  else hipLaunchKernelGGL((kg_gram64<false>), dim3(used), dim3(256), sh, st, (const unsigned short*)Zp, w, part, (long)d.NT, tpb);
+  AVMOE_CHECK_LAUNCH("gram64");
+  const int ncol = d.g * d.E * d.dgp * d.dgp;
+  return k_colsum_f32(part, used, ncol, ncol, 1, 0, out, 0, scale, st);
+}
+
+}  // namespace avmoe

@@ -158,7 +158,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   AVMOE_TRY(k_pre_small(pl, sv, sc, prm, st));
   AVMOE_TRY(k_bn1_finalize(pl, sv, sc, prm, st));
   AVMOE_TRY(k_mid(pl, sv, sc, st));
-  if (d.use_bn && d.training) {                            // Szz[i][e] = Zp^T Zp / NT   (token contraction)
+  if (d.use_bn && d.training && d.gram64) {                // Szz[i][e] = Zp^T Zp / NT : one streaming pass over z'
+    AVMOE_TRY(k_gram64(pl, sv + pl.o_ZpS, nullptr, 1.f / (float)d.NT, (float*)(sc + pl.o_gpartT), (float*)(sv + pl.o_Szz), st));
+  } else if (d.use_bn && d.training) {                     // ... as 8 batched token contractions of the engine
     GemmArgs g = base();
     g.A = sc + pl.o_Zp; g.B = sc + pl.o_Zp; g.C = sv + pl.o_Szz;
     g.M = d.dgp; g.N = d.dgp; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = g.ldb = d.DZ;

@@ -95,6 +95,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(1024, d.S))));
   d.nblk_tok = bps * d.S;
   d.zsz = tile_fast_ok(d) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident path
+  d.gram64 = tile_fast_ok(d) && d.bf16;
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 
   size_t off[2] = {0, 0};

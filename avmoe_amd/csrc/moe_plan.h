@@ -12,6 +12,7 @@
 namespace avmoe {
 
 constexpr int MAX_E = AVMOE_MAX_EXPERTS;
+constexpr int GRAM_BLOCKS = 256;   // blocks (= partial sums) of the streaming Gram kernel
 
 struct Dims {
   // raw
@@ -22,6 +23,7 @@ struct Dims {
   // derived
   int esz;        // bytes of an activation / operand element (T)
   int zsz;        // bytes of a Z / dz' element: T on the register-resident path (tile_fast.hip), else fp32
+  int gram64;     // register-resident shape in bf16: z' is kept forward -> backward and the d x d Grams come from gram.hip
   int NT;         // S * N tokens
   int dg, dgp;    // bottleneck per group, padded to 8
   int Cg;         // channels per group
@@ -107,6 +109,9 @@ struct Dims {
   X(L1, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)    /* L1 ; dA1 in bwd */  \
   X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \
   X(Zp, 1, d.esz, (size_t)d.NT * d.DZ)              /* z'                              */       \
+  X(ZpS, 0, d.esz, d.gram64 ? (size_t)d.NT * d.DZ : 1)   /* z' kept for the backward (gram64)  */    \
+  X(dSooT, 1, 4, d.gram64 ? (size_t)d.E * d.NT : 1)      /* dSoo per (expert, token)            */    \
+  X(gpartT, 1, 4, d.gram64 ? (size_t)GRAM_BLOCKS * d.g * d.E * d.dgp * d.dgp : 1)  /* Gram partials */ \
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
   X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
   X(colsum, 1, 4, (size_t)4 * d.DZ)                 /* colpart summed over blocks     */       \

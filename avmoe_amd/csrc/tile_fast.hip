@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const void*
 // =====================================================================================================
 // POST_SMALL backward
 // =====================================================================================================
-struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; };
+struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; const void* ZpS; float* dSooT; };   // ZpS / dSooT: gram64 mode
 
 template <typename T, int E>
 __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
@@ -461,7 +461,8 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
       float4 zp[4], d[4], zraw[4], dzo[4];
       float da1 = 0.f, da2 = 0.f, da3 = 0.f, rp = 1.f, mup = 0.f;
       zero_row(zraw);
-      if (ok) ld_row<T, E>(Z + tok * DZ, e, q, zraw);
+      const bool saved_zp = a.ZpS != nullptr;                 // gram64 mode: z' was kept by the forward
+      if (ok) ld_row<T, E>((saved_zp ? (const T*)a.ZpS : Z) + tok * DZ, e, q, zraw);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4& z = zraw[c];
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const float y = at(z, x) * at(sc, x) + at(sh, x);
-          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+          at(zp[c], x) = saved_zp ? at(z, x) : (relu ? fmaxf(y, 0.f) : y);
         }
       }
       if (ok) {
@@ -522,8 +523,9 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
       }
       if (ok) {
         st_row<T, E>(dzp + tok * DZ, e, q, dzo);
+        if (a.dSooT && q == 0) a.dSooT[(long)e * t.NT + tok] = dSoo;
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
+        for (int gi = 0; gi < 2 && a.dSooT == nullptr; ++gi) {
           const long seg = tok * DZ + gi * (E * FDG) + e * FDG;
           const float4& z0 = zp[2 * gi]; const float4& z1 = zp[2 * gi + 1];
           st_seg<T>(Zp + seg, z0, z1, q);
@@ -905,7 +907,7 @@ int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidFArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per);
-  LAUNCH_TE(d.bf16, kf_mid, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
+  LAUNCH_TE(d.bf16, kf_mid, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), d.gram64 ? (void*)(saved + pl.o_ZpS) : (void*)(scratch + pl.o_Zp),
             (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("mid (64/32)");
   return OK;
@@ -929,6 +931,8 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
   FPostBArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  a.ZpS = d.gram64 ? (const void*)(saved + pl.o_ZpS) : nullptr;
+  a.dSooT = d.gram64 ? (float*)(scratch + pl.o_dSooT) : nullptr;
   LAUNCH_TE(d.bf16, kf_post_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),
             (const float*)(scratch + pl.o_dAp), (void*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),

@@ -390,7 +390,11 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
 // element sizes of the Z-space and T-typed tensors) -- the numerators of their HBM rooflines.
 static double bytes_pre_small(const Dims& d) { return (double)d.NT * (2.0 * d.DZ * d.zsz + (d.KL ? (double)d.KL * (4 + d.esz) : 0.0) + 8.0 + 8.0 * d.E); }
 static double bytes_post_small(const Dims& d) { return (double)d.NT * ((double)d.DZ * d.zsz + (double)d.g * d.KPp * d.esz + 8.0 * d.E); }
-static double bytes_post_small_bwd(const Dims& d) { return (double)d.NT * ((double)d.DZ * (2.0 * d.zsz + 2.0 * d.esz) + (double)d.g * d.KPp * 4.0 + 8.0 * d.E); }
+static double bytes_post_small_bwd(const Dims& d) {
+  const double zspace = d.gram64 ? (double)d.DZ * (d.esz + d.zsz) + 4.0 * d.E       // read the saved z', write dz' and dSoo
+                                 : (double)d.DZ * (2.0 * d.zsz + 2.0 * d.esz);      // read Z, write dz', z', dSoo z'
+  return (double)d.NT * (zspace + (double)d.g * d.KPp * 4.0 + 8.0 * d.E);
+}
 static double bytes_mid_bwd(const Dims& d) { return (double)d.NT * (3.0 * d.DZ * d.zsz); }
 static double bytes_pre_small_bwd(const Dims& d) {
   return (double)d.NT * ((double)d.DZ * (2.0 * d.zsz + d.esz) + (d.KL ? (double)d.KL * (4 + 4 * d.esz) : 0.0) + 8.0 * d.E + 12.0);
