@@ -46,6 +46,8 @@ TOP_KEY_TO_FIELD = {
 
 
 def declare(L):
+    L.avmoe_router_forward.restype = C.c_int
+    L.avmoe_router_forward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.POINTER(MoePtrs)] + [C.c_void_p] * 7
     L.avmoe_moe_saved_bytes.restype = C.c_size_t
     L.avmoe_moe_saved_bytes.argtypes = [C.POINTER(MoeDesc)]
     L.avmoe_moe_scratch_bytes.restype = C.c_size_t

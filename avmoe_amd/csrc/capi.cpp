@@ -66,6 +66,18 @@ int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y,
   return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream);
 }
 
+int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avmoe_moe_ptrs* params, const float* noise,
+                         float* probs, int64_t* idx, float* lb, void* saved, void* scratch, void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!rin || !params || !saved || !scratch) { set_last_error("avmoe_router_forward: null pointer"); return ERR_BAD_ARG; }
+  const size_t bytes = (size_t)pl.d.S * 2 * pl.d.C * sizeof(float);
+  if (hipMemcpyAsync((char*)saved + pl.o_rin, rin, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_last_error("avmoe_router_forward: copy of rin failed"); return ERR_LAUNCH;
+  }
+  return k_router(pl, (char*)saved, (char*)scratch, *params, noise, probs, idx, lb, (hipStream_t)stream);
+}
+
 int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region, size_t* offset,
                           size_t* bytes) {
   Plan pl;

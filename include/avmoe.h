@@ -112,6 +112,16 @@ int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y,
                        const void* dOut, const float* lb_grad, void* saved, void* scratch,
                        void* dX, void* dY, const avmoe_moe_ptrs* grads, void* stream);
 
+/* Sub-op (tests / partial adoption): the router alone -- Sequential(Linear(2C,128), ReLU, Linear(128,32), ReLU,
+ * Linear(32,E)) + optional logit noise + softmax + first-max argmax  (net_trans_v3.py:460-466,477-479).
+ * rin (S, 2C) f32 = [mean over tokens of x | mean over tokens of the remapped other modality]; same workspaces as the
+ * site calls (rin is copied into `saved`; a following avmoe_moe_backward on it is not meaningful).  probs (S,E) f32,
+ * idx (S) int64, lb (1 float, written only when desc.lb_loss) may each be NULL.
+ * (The remap and the experts have no stand-alone sub-op: in this library they are never materialised on their own --
+ *  DESIGN.md section 3 -- their intermediates are reachable through avmoe_moe_buffer_info.)                       */
+int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avmoe_moe_ptrs* params, const float* noise,
+                         float* probs, int64_t* idx, float* lb, void* saved, void* scratch, void* stream);
+
 /* Workspace introspection for tests: buffer `index` -> name / region (0 saved, 1 scratch) / offset / bytes.
  * Returns 0, or AVMOE_ERR_BAD_ARG when index is past the last buffer.                                 */
 int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region,

@@ -48,3 +48,29 @@ def test_forward_bf16_close_to_reference_vectors(name):
     err = float((out - t["out"]).abs().max() / t["out"].abs().max())
     assert err < 4e-2, err
     assert torch.equal(run.idx.cpu(), t["idx"])
+
+
+@pytest.mark.parametrize("name", ["ave_train", "avs_train_noise", "avvp_train"])
+def test_router_subop_matches_reference_vectors(name):
+    """avmoe_router_forward (the router alone through the C ABI) on the means the full forward computed: probabilities within
+    1e-5 of the reference vectors, first-max argmax bit-exact, LB loss where the variant has one."""
+    import ctypes as C
+    from avmoe_amd import _capi as capi
+    from tests.moe_gpu_util import MoeRun
+    meta, cfg, t = load_golden(name)
+    P, B = split_params(t)
+    noise = t.get("noise")
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=bool(meta["module_train"]), noise=noise).forward()
+    rin = run.buf("rin").to(run.dev).contiguous()                    # (S, 2C): [mean_n x | mean_n remap(y)]
+    probs = torch.empty_like(run.probs)
+    idx = torch.empty_like(run.idx)
+    lb = torch.zeros(1, device=run.dev)
+    st = run.L.avmoe_router_forward(C.byref(run.desc), rin.data_ptr(), C.byref(run.ptrs),
+                                    run.noise.data_ptr() if run.noise is not None else None, probs.data_ptr(), idx.data_ptr(),
+                                    lb.data_ptr(), run.saved.data_ptr(), run.scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    capi.check(st, "avmoe_router_forward")
+    torch.cuda.synchronize()
+    assert torch.allclose(probs.cpu(), t["probs"], atol=1e-5)
+    assert torch.equal(idx.cpu(), t["idx"].reshape(-1))
+    if cfg.lb_loss:
+        assert abs(float(lb) - float(t["lb"])) < 1e-4 * max(1.0, abs(float(t["lb"])))
