@@ -1,0 +1,78 @@
+// Training-loop pieces either side of the adapter path: a fused Adam step over one flat parameter
+// bucket (the reference's optimizer is torch.optim.Adam over the adapter parameters, AVE/main_trans_v3.py:322) and a
+// device-side expert-activation histogram (the reference loops over idx.tolist() on the host, main_trans_v3.py:183-207).
+#include "../../include/avmoe.h"
+#include "common.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+
+namespace avmoe {
+
+// torch.optim.Adam semantics (no amsgrad, L2 weight decay added to the gradient), one thread per 4 elements
+__global__ void __launch_bounds__(256) kk_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                               float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  if (i0 + 3 < n) {
+    float4 pp = *(float4*)(p + i0), mm = *(float4*)(m + i0), vv = *(float4*)(v + i0);
+    const float4 gg = *(const float4*)(g + i0);
+    float* P = (float*)&pp; float* M = (float*)&mm; float* V = (float*)&vv; const float* G = (const float*)&gg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = G[k] * gscale + wd * P[k];
+      M[k] = b1 * M[k] + (1.f - b1) * gr;
+      V[k] = b2 * V[k] + (1.f - b2) * gr * gr;
+      P[k] -= (lr / bc1) * M[k] / (sqrtf(V[k]) / bc2_sqrt + eps);
+    }
+    *(float4*)(p + i0) = pp; *(float4*)(m + i0) = mm; *(float4*)(v + i0) = vv;
+  } else {
+    for (long i = i0; i < n; ++i) {
+      const float gr = g[i] * gscale + wd * p[i];
+      m[i] = b1 * m[i] + (1.f - b1) * gr;
+      v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+      p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+    }
+  }
+}
+
+// counts[idx[s]] += 1 (integer atomics: exact and order-independent)
+__global__ void kk_expert_hist(const int64_t* __restrict__ idx, long S, int E, long long* __restrict__ counts) {
+  for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < S; s += (long)gridDim.x * 256) {
+    const int64_t e = idx[s];
+    if (e >= 0 && e < E) atomicAdd((unsigned long long*)(counts + e), 1ull);
+  }
+}
+
+}  // namespace avmoe
+
+using namespace avmoe;
+
+extern "C" {
+
+int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) { set_last_error("avmoe_adam_step: bad argument"); return ERR_BAD_ARG; }
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) != 0) {
+    set_last_error("avmoe_adam_step: buffers must be 16-byte aligned"); return ERR_ALIGNMENT;
+  }
+  if (n == 0) return OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const long nblk = (n + 1023) / 1024;
+  hipLaunchKernelGGL(kk_adam, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2,
+                     eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  AVMOE_CHECK_LAUNCH("adam_step");
+  return OK;
+}
+
+int avmoe_expert_histogram(const int64_t* idx, int64_t S, int32_t E, int64_t* counts, void* stream) {
+  if (!idx || !counts || S < 0 || E < 1) { set_last_error("avmoe_expert_histogram: bad argument"); return ERR_BAD_ARG; }
+  if (S == 0) return OK;
+  const unsigned nblk = (unsigned)std::min<long>((S + 255) / 256, 1024);
+  hipLaunchKernelGGL(kk_expert_hist, dim3(nblk), dim3(256), 0, (hipStream_t)stream, idx, (long)S, (int)E, (long long*)counts);
+  AVMOE_CHECK_LAUNCH("expert_histogram");
+  return OK;
+}
+
+}  // extern "C"

@@ -128,6 +128,16 @@ int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char*
                           size_t* offset, size_t* bytes);
 
 
+/* ---- either side of the path on the training loop ---------------------------------------
+ * avmoe_adam_step: one torch.optim.Adam step (no amsgrad; L2 weight_decay added to the gradient) over a FLAT fp32
+ * parameter bucket -- replaces optimizer.step() over the adapter parameters (AVE/main_trans_v3.py:322).  `step` is the
+ * 1-based step count (bias correction), grad_scale multiplies the gradient first (1/accum_itr, 1/world ...).
+ * avmoe_expert_histogram: counts[e] += #{s : idx[s] == e} on the device (int64 counts, exact) -- replaces the host loop
+ * over idx.tolist() that fills the expert-activation tables (AVE/main_trans_v3.py:183-207).                          */
+int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+int avmoe_expert_histogram(const int64_t* idx, int64_t S, int32_t E, int64_t* counts, void* stream);
+
 /* ---- optional per-launch timing (HIP events on the launch stream; off by default; process-wide) --------
  * avmoe_prof_report writes a JSON array of {"name","calls","total_ms","alg_bytes","flops"} per kernel family
  * into buf (NUL-terminated, truncated to cap) and returns the full length.  Used by bench.py for the roofline. */

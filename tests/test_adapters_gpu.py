@@ -151,3 +151,49 @@ def test_adapter_pair_equals_two_sites(dtype, concurrent):
         assert float((r_.float() - g_.float()).abs().max()) <= tol * float(r_.float().abs().max())
     for r_, g_ in zip(ref[6], got[6]):
         assert torch.equal(r_, g_)
+
+
+def test_flat_adam_matches_torch_adam_and_histogram_matches_bincount():
+    """avmoe_amd.train.FlatAdam (one HIP kernel per flat bucket) against torch.optim.Adam over three steps of the same
+    gradients, with weight decay and StepLR-style decay; ExpertActivationCounter against torch.bincount."""
+    import copy
+    from avmoe_amd.dp import AdapterGradReducer
+    from avmoe_amd.train import FlatAdam, ExpertActivationCounter
+    dev = torch.device("cuda:0")
+    cfg = O.AdapterConfig(Cx=64, Nx=50, Cy=48, Ny=20, reduction=4, groups=2, K=6)
+    ref = build_module("ave", cfg).to(dev).train()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k.endswith(("gate", "gate_av")):
+                p.fill_(0.4)
+    fused = copy.deepcopy(ref)
+    topt = torch.optim.Adam(ref.parameters(), lr=3e-3, weight_decay=1e-2)
+    sched = torch.optim.lr_scheduler.StepLR(topt, step_size=2, gamma=0.5)
+    red = AdapterGradReducer(list(fused.parameters()), sites=[fused])
+    fopt = FlatAdam(red, lr=3e-3, weight_decay=1e-2, step_size=2, gamma=0.5)
+    g = torch.Generator().manual_seed(2)
+    for epoch in range(3):
+        X = torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev)
+        Y = torch.randn(4, cfg.Cy, cfg.Ny, 1, generator=g).to(dev)
+        G = torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev)
+        topt.zero_grad()
+        ref(X, Y)[0].backward(G)
+        red.begin(sync=True)
+        fused(X, Y)[0].backward(G)                      # fills the flat bucket through the gradient sink
+        red.finish()
+        with torch.no_grad():                           # both optimizers see bit-identical gradients: the comparison is
+            for p, q in zip(ref.parameters(), fused.parameters()):      # about the update arithmetic only
+                q.grad.copy_(p.grad)
+        topt.step(); sched.step()
+        fopt.step(); fopt.epoch_end(); red.zero_grad()
+        with torch.no_grad():
+            for (k, p), (_, q) in zip(ref.named_parameters(), fused.named_parameters()):
+                # |update| <= lr; where sqrt(v) ~ eps the two fp32 evaluation orders differ by a small fraction of it
+                assert float((p - q).abs().max()) <= 1e-6 * float(p.abs().max()) + 2e-3 * 3e-3, (epoch, k)
+                q.copy_(p)
+    cnt = ExpertActivationCounter(["audio_p1", "video_p1"], num_layers=3, num_experts=4, device=dev)
+    idx = torch.randint(0, 4, (37, 1), generator=g).to(dev)
+    cnt.update("video_p1", 2, idx); cnt.update("video_p1", 2, idx); cnt.update("audio_p1", 0, idx[:5])
+    tabs = cnt.numpy()
+    assert (tabs["video_p1"][2] == 2 * torch.bincount(idx.reshape(-1).cpu(), minlength=4).numpy()).all()
+    assert tabs["audio_p1"][0].sum() == 5 and tabs["audio_p1"][1:].sum() == 0 and tabs["video_p1"][:2].sum() == 0
