@@ -40,6 +40,7 @@ def lib():
     if not os.path.isfile(LIB_PATH):
         raise AvmoeError(f"{LIB_PATH} is missing: build it with `python -m avmoe_amd.build` "
                          "(the adapter path has no fallback)")
+    import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch has loaded (one runtime per process)
     L = C.CDLL(LIB_PATH)
     L.avmoe_abi_version.restype = C.c_int
     L.avmoe_last_error.restype = C.c_char_p
