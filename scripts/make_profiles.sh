@@ -11,7 +11,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -- python3
 cd $R
 cp $O/kt/*/*kernel_stats.csv $O/kernel_stats_default.csv
 cp $O/kts/*/*kernel_stats.csv $O/kernel_stats_serial.csv
-tail -1 $O/kts.log > $O/bench_line_serial.json
+grep -h "^{\"metric\"" $O/kts.log | tail -1 > $O/bench_line_serial.json
 python3 scripts/pmc_traffic_json.py $O/f/*/*counter_collection.csv $O/w/*/*counter_collection.csv > $O/pmc_traffic.json
 python3 scripts/pmc_summary.py $O/f/*/*counter_collection.csv $O/w/*/*counter_collection.csv 3 > $O/pmc_traffic.txt
 tail -1 $O/kt.log | cut -c1-300
