@@ -1,0 +1,100 @@
+"""World-size-2 data-parallel step on ONE MI355X (two processes share cuda:0, gloo carries the exchange): the real HIP
+adapter path with AdapterPair on two streams, the gradient sink (backward writes parameter gradients straight into the
+reducer's flat buckets) and the bucket all-reduce launched from inside the backward.  After finish(), every rank must hold
+the average of the per-rank gradients -- checked against single-process runs of both ranks' inputs.  (RCCL itself needs
+one GPU per rank; the reducer logic, ordering and stream handling are identical.)"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(dev):
+    sys.path.insert(0, ROOT)
+    from oracle import avmoe_oracle as O
+    from tests.test_adapters_api import build_module
+    ca = O.AdapterConfig(Cx=128, Nx=96, Cy=64, Ny=48, reduction=2, groups=2, K=32)      # register-resident shape
+    cb = O.AdapterConfig(Cx=64, Nx=48, Cy=128, Ny=96, reduction=4, groups=2, K=8)
+    torch.manual_seed(0)                                                                # identical parameters on every rank
+    sa, sb = build_module("ave", ca).to(dev).train(), build_module("ave", cb).to(dev).train()
+    with torch.no_grad():
+        for m in (sa, sb):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.4)
+    return ca, cb, sa, sb
+
+
+def _inputs(ca, cb, rank, dev, dtype):
+    g = torch.Generator().manual_seed(100 + rank)
+    fa = (0.5 * torch.randn(3, ca.Cx, ca.Nx, 1, generator=g)).to(dev, dtype)
+    fv = (0.5 * torch.randn(3, cb.Cx, cb.Nx, 1, generator=g)).to(dev, dtype)
+    ga = torch.randn(3, ca.Cx, ca.Nx, 1, generator=g).to(dev, dtype)
+    gv = torch.randn(3, cb.Cx, cb.Nx, 1, generator=g).to(dev, dtype)
+    return fa, fv, ga, gv
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        ca, cb, sa, sb = _build(dev)
+        from avmoe_amd.adapters import AdapterPair
+        from avmoe_amd.dp import AdapterGradReducer
+        dtype = torch.bfloat16
+        # reference: the gradients of BOTH ranks' inputs computed locally without any reducer, averaged
+        expect = None
+        bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in (sa, sb)]
+        for r in range(world):
+            for m, bb in zip((sa, sb), bufs):
+                m.zero_grad(); m.load_state_dict({**m.state_dict(), **bb})
+            fa, fv, ga, gv = _inputs(ca, cb, r, dev, dtype)
+            oa, _ = sa(fa, fv); ov, _ = sb(fv, fa)
+            torch.autograd.backward([oa, ov], [ga, gv])
+            gr = [p.grad.clone() for m in (sa, sb) for p in m.parameters()]
+            expect = gr if expect is None else [a + b for a, b in zip(expect, gr)]
+        expect = [e / world for e in expect]
+        for m, bb in zip((sa, sb), bufs):
+            m.zero_grad(set_to_none=True); m.load_state_dict({**m.state_dict(), **bb})
+        # the data-parallel step of this rank
+        params = list(sa.parameters()) + list(sb.parameters())
+        red = AdapterGradReducer(params, sites=[sa, sb])
+        pair = AdapterPair(sa, sb, concurrent=True)
+        fa, fv, ga, gv = _inputs(ca, cb, rank, dev, dtype)
+        red.begin(sync=True)
+        oa, _, ov, _ = pair(fa, fv)
+        torch.autograd.backward([oa, ov], [ga, gv])
+        red.finish()
+        torch.cuda.synchronize()
+        ok = len(red.sinks) == 2
+        gmax = max(float(e.abs().max()) for e in expect)
+        for p, e in zip(params, expect):
+            ok &= float((p.grad - e).abs().max()) <= 1e-5 * max(float(e.abs().max()), 1e-3 * gmax)
+            ok &= any(b.flat.data_ptr() <= p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4 for b in red.buckets)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_step_world2_on_one_gpu():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
