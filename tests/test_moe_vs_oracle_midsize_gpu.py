@@ -19,6 +19,12 @@ CASES = {
     "fast_avs_lb": dict(cfg=dict(Cx=128, Nx=256, Cy=128, Ny=33, reduction=2, groups=2, K=32, variant="avs", lb_loss=True), S=3),
     "fast_e3p1": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=3, E_s=1), S=2),
     "fast_e1p3": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=1, E_s=3), S=2),
+    # BASELINE.json configs[0] (cfg-1): the Swin-B x HTS-AT adapter sites the AVE model really has (stages 0 and 2,
+    # reduction 8, 2+2 experts, 32 latent tokens), two frames
+    "cfg1_stage0_audio_side": dict(cfg=dict(Cx=96, Nx=4096, Cy=128, Ny=2304, reduction=8, groups=2, K=32, variant="ave"), S=2),
+    "cfg1_stage0_visual_side": dict(cfg=dict(Cx=128, Nx=2304, Cy=96, Ny=4096, reduction=8, groups=2, K=32, variant="ave"), S=2),
+    "cfg1_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=512, Ny=144, reduction=8, groups=2, K=32, variant="ave"), S=2),
+    "cfg1_stage2_visual_side": dict(cfg=dict(Cx=512, Nx=144, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="ave"), S=2),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
 }
