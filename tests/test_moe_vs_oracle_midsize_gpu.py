@@ -25,6 +25,15 @@ CASES = {
     "cfg1_stage0_visual_side": dict(cfg=dict(Cx=128, Nx=2304, Cy=96, Ny=4096, reduction=8, groups=2, K=32, variant="ave"), S=2),
     "cfg1_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=512, Ny=144, reduction=8, groups=2, K=32, variant="ave"), S=2),
     "cfg1_stage2_visual_side": dict(cfg=dict(Cx=512, Nx=144, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="ave"), S=2),
+    # cfg-3 (AVVP, Swin-L x HTS-AT stage 2: N x N self attention in the unimodal experts, load-balancing loss)
+    "cfg3_avvp_stage2_visual_side": dict(cfg=dict(Cx=768, Nx=144, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
+    "cfg3_avvp_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=768, Ny=144, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
+    # cfg-4 (AVQA: 1 + 2 experts, 2 latent tokens, 4 groups; Swin-L stages 0 and 2)
+    "cfg4_avqa_stage2_visual_side": dict(cfg=dict(Cx=768, Nx=144, Cy=384, Ny=256, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    "cfg4_avqa_stage0_audio_side": dict(cfg=dict(Cx=96, Nx=4096, Cy=192, Ny=2304, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    # cfg-5 (AVS: 4 + 4 experts, bottleneck 128, latent self attention v2, 5 frames; PVT-v2-b5 stage 3 x HTS-AT)
+    "cfg5_avs_stage3_visual_side": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_avs_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=320, Ny=196, reduction=3, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
 }
