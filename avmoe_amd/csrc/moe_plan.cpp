@@ -1,3 +1,5 @@
+#include <cstdlib>
+#include <cstdio>
 #include "moe_plan.h"
 #include <algorithm>
 #include <cstring>
@@ -93,6 +95,10 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Np = (int)round_up(d.N, 8);
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
   int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(1024, d.S))));
+  if (const char* ev = getenv("AVMOE_BPS")) {     // development: "<bps for N >= 512>,<bps for N < 512>"
+    int a = 0, b = 0;
+    if (sscanf(ev, "%d,%d", &a, &b) == 2) bps = std::max(1, d.N >= 512 ? a : b);
+  }
   d.nblk_tok = bps * d.S;
   d.zsz = tile_fast_ok(d) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident path
   d.gram64 = tile_fast_ok(d) && d.bf16;

@@ -16,6 +16,26 @@
 #include "prof.h"
 #include <algorithm>
 
+// waves per SIMD each kernel is compiled for (register budget = 512 / value); measured best on MI355X
+#ifndef LB_MIDB
+#define LB_MIDB 3
+#endif
+#ifndef LB_MID
+#define LB_MID 4
+#endif
+#ifndef LB_POST
+#define LB_POST 5
+#endif
+#ifndef LB_POSTB
+#define LB_POSTB 2
+#endif
+#ifndef LB_PRE
+#define LB_PRE 3
+#endif
+#ifndef LB_PREB
+#define LB_PREB 2
+#endif
+
 namespace avmoe {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -198,7 +218,7 @@ __device__ __forceinline__ float wsum_q0(float v, int q) {   // sum over the 16 
 struct FMidArgs { int relu_of_e[MAX_E]; FastDims t; int moments; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
+__global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
                                                   const float* __restrict__ sdSzz, void* __restrict__ dzp_, float* __restrict__ colpart) {
   constexpr int DZ = E * FDD;
   const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
@@ -273,7 +293,7 @@ __global__ void __launch_bounds__(256, 3) kf_mid_bwd(FMidArgs a, const void* __r
 struct FMidFArgs { int relu_of_e[MAX_E]; FastDims t; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, void* __restrict__ Zp_,
+__global__ void __launch_bounds__(256, LB_MID) kf_mid(FMidFArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, void* __restrict__ Zp_,
                                                  float* __restrict__ colpart) {
   constexpr int DZ = E * FDD;
   T* Zp = (T*)Zp_; const T* Z = (const T*)Z_;
@@ -337,7 +357,7 @@ __global__ void __launch_bounds__(256, 4) kf_mid(FMidFArgs a, const void* __rest
 struct FPostArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; float ln_eps; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                      const float* __restrict__ uvh, const float* __restrict__ probs, void* __restrict__ Apost_,
                                                      float* __restrict__ rpmup) {
   constexpr int DZ = E * FDD;
@@ -422,7 +442,7 @@ __global__ void __launch_bounds__(256, 3) kf_post_small(FPostArgs a, const void*
 struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; const void* ZpS; float* dSooT; };   // ZpS / dSooT: gram64 mode
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                          const float* __restrict__ uvh, const float* __restrict__ probs, const float* __restrict__ rpmup,
                                                          const float* __restrict__ dAp, void* __restrict__ dzp_, void* __restrict__ Zp_, void* __restrict__ Zw_,
                                                          float* __restrict__ colpart, float* __restrict__ blkscal) {
@@ -547,7 +567,7 @@ __global__ void __launch_bounds__(256, 2) kf_post_small_bwd(FPostBArgs a, const 
 struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before; float ln_eps; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
+__global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
                                                     const float* __restrict__ TT, const float* __restrict__ TW, const float* __restrict__ Tsum,
                                                     const float* __restrict__ wsum, const float* __restrict__ dconst, void* __restrict__ aout_,
                                                     float* __restrict__ rmu, float* __restrict__ colpart) {
@@ -670,7 +690,7 @@ __global__ void __launch_bounds__(256, 3) kf_pre_small(FPreArgs a, void* __restr
 struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before, use_bn, bn_train; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, 2) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ TT,
+__global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ TT,
                                                         const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
                                                         const float* __restrict__ dconst, const void* __restrict__ ain_, const float* __restrict__ rmu,
                                                         const float* __restrict__ bn1, const float* __restrict__ dsm, const void* __restrict__ dy_in_,

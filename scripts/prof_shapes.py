@@ -28,7 +28,7 @@ torch.cuda.synchronize(); L.avmoe_prof_enable(0)
 rep = sorted(capi.prof_report(), key=lambda r: -r["total_ms"])
 tot = sum(r["total_ms"] for r in rep) / n
 print(f"total {tot:.3f} ms/step")
-for r in rep[:45]:
+for r in rep[:90]:
     ms = r["total_ms"] / r["calls"]
     gbs = r["alg_bytes"] / r["calls"] / ms / 1e6 if r["alg_bytes"] else 0
     tf = r["flops"] / r["calls"] / ms / 1e9 if r["flops"] else 0

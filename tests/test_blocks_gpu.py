@@ -1,0 +1,103 @@
+"""DualBackboneLoop (avmoe_amd/blocks.py) with real HIP adapter sites on stand-in backbone stages: outputs, expert indices and
+all gradients equal the site-by-site schedule of AVE/nets/net_trans_v3.py:673-727 run with the same modules."""
+import pytest
+import torch
+from torch import nn
+
+from oracle import avmoe_oracle as O
+from tests.test_adapters_gpu import build_module
+from tests.test_blocks import Stage, restated_loop
+
+pytestmark = pytest.mark.gpu
+
+
+class VisBlock(nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.norm1, self.norm2 = nn.LayerNorm(C), nn.LayerNorm(C)
+        self.mlp = nn.Sequential(nn.Linear(C, 2 * C), nn.GELU(), nn.Linear(2 * C, C))
+        self.mix = nn.Linear(C, C)
+        self.drop_path1, self.drop_path2 = nn.Identity(), nn.Identity()
+    def _attn(self, x): return self.mix(x.roll(1, dims=1))
+
+
+class AudBlock(nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.fc = nn.Linear(C, C)
+    def forward(self, x): return x + 0.5 * torch.tanh(self.fc(x)), None
+
+
+class Merge(nn.Module):
+    """stand-in for patch merging: 4 neighbouring tokens -> one token with twice the channels"""
+    def __init__(self, C):
+        super().__init__()
+        self.red = nn.Linear(4 * C, 2 * C)
+    def forward(self, x):
+        S, N, C = x.shape
+        return self.red(x.reshape(S, N // 4, 4 * C))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loop_equals_site_by_site(dtype):
+    from avmoe_amd.blocks import DualBackboneLoop
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    S, Cv, Nv, Ca, Na = 3, 64, 144, 48, 256
+    dims = [(Cv, Nv, Ca, Na), (2 * Cv, Nv // 4, 2 * Ca, Na // 4)]
+    sv = [Stage(nn.ModuleList([VisBlock(c), VisBlock(c)]).to(dev, dtype), Merge(c).to(dev, dtype)) for c, _, _, _ in dims]
+    sa = [Stage(nn.ModuleList([AudBlock(c), AudBlock(c)]).to(dev, dtype), Merge(c).to(dev, dtype)) for _, _, c, _ in dims]
+    sites = {k: [] for k in ("a1", "v1", "a2", "v2")}
+    for cv, nv, ca, na in dims:
+        for _ in range(2):                                   # two adapted blocks per stage
+            for pos in ("1", "2"):
+                a = build_module("ave", O.AdapterConfig(Cx=ca, Nx=na, Cy=cv, Ny=nv, reduction=4, groups=2, K=8)).to(dev).train()
+                v = build_module("ave", O.AdapterConfig(Cx=cv, Nx=nv, Cy=ca, Ny=na, reduction=4, groups=2, K=8)).to(dev).train()
+                with torch.no_grad():
+                    for m in (a, v):
+                        for k, p in m.named_parameters():
+                            if k.endswith(("gate", "gate_av")):
+                                p.fill_(0.3)
+                sites["a" + pos].append(a); sites["v" + pos].append(v)
+    all_sites = [m for k in sites for m in sites[k]]
+    backbone = [p for st in sv + sa for p in list(st.blocks.parameters()) + list(st.downsample.parameters())]
+    bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in all_sites]
+    g = torch.Generator().manual_seed(1)
+    f_v0 = (0.5 * torch.randn(S, Nv, Cv, generator=g)).to(dev, dtype)
+    f_a0 = (0.5 * torch.randn(S, Na, Ca, generator=g)).to(dev, dtype)
+    g_v = torch.randn(S, Nv // 16, 4 * Cv, generator=g).to(dev, dtype)
+    g_a = torch.randn(S, Na // 16, 4 * Ca, generator=g).to(dev, dtype)
+
+    def run(fused):
+        for m, bb in zip(all_sites, bufs):
+            m.zero_grad(); m.load_state_dict({**m.state_dict(), **bb})
+        for p in backbone: p.grad = None
+        f_v, f_a = f_v0.clone().requires_grad_(True), f_a0.clone().requires_grad_(True)
+        if fused:
+            loop = DualBackboneLoop(sites["a1"], sites["v1"], sites["a2"], sites["v2"], num_skip=1)
+            ov, oa, rec = loop(sv, sa, f_v, f_a)
+            rec = rec.to_dict()
+        else:
+            ov, oa, rec = restated_loop(sv, sa, f_v, f_a, sites, 1, True, True)
+        torch.autograd.backward([ov, oa], [g_v, g_a])
+        return (ov.detach(), oa.detach(), rec, f_v.grad, f_a.grad, [p.grad.clone() for m in all_sites for p in m.parameters()],
+                [p.grad.clone() for p in backbone])
+
+    ref, got = run(False), run(True)
+    assert got[2] == ref[2] and len(got[2]["audio"]["p1"]) == 4 and len(got[2]["video"]["p2"]) == 4
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    gscale = max(float(a.float().abs().max()) for a in ref[5])      # gradients that are analytically zero (a bias in front of a
+    def close(a, b, what, floor=0.0):                                # BatchNorm) are rounding noise: judge them on the global scale
+        scale = max(float(a.float().abs().max()), floor) + 1e-12
+        err = float((a.float() - b.float()).abs().max())
+        assert err <= tol * scale, (what, err, scale)
+    close(ref[0], got[0], "f_v"); close(ref[1], got[1], "f_a")
+    close(ref[3], got[3], "d f_v"); close(ref[4], got[4], "d f_a")
+    if dtype == torch.float32:
+        for k, (a, b) in enumerate(zip(ref[5], got[5])): close(a, b, f"site param {k}", 1e-2 * gscale)
+        for k, (a, b) in enumerate(zip(ref[6], got[6])): close(a, b, f"backbone param {k}", 1e-2 * gscale)
+    else:       # bf16 activations through four adapted blocks: sums with heavy cancellation (the scalar gates) move by several
+        for grp in (5, 6):      # percent with the order of two bf16 additions, so compare the gradient as one vector
+            a = torch.cat([x.float().reshape(-1) for x in ref[grp]]); b = torch.cat([x.float().reshape(-1) for x in got[grp]])
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+            assert cos > 0.999, (grp, cos)
