@@ -35,6 +35,7 @@ struct DevArgs {
   int M, N, K, nb2, ksplit, kper, nbatch, tiles_n;
   long lda, ldb, sA1, sA2, sB1, sB2, sCi, sCj, sC1, sC2, sRS1, sRS2, sDi, sD1, sD2;
   float alpha; int accumulate, out_bf16, vec_c, vec_d;
+  int fold_rps, fold_valid;      // batch folded into M: rows per sample / stored rows per sample (0 = no fold)
   const char* A2; const char* B2; int K2; long lda2, ldb2, s2A1, s2A2, s2B1, s2B2;
 };
 
@@ -324,9 +325,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
       const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
       const int gi = m0 + i, gj = n0 + j;
       if (gi >= p.M || gj >= p.N) continue;
+      long crow = (long)gi * p.sCi;
+      if (p.fold_rps) {                                   // row gi of the folded GEMM = row ri of sample sidx; gap rows are not stored
+        const int sidx = gi / p.fold_rps, ri = gi - sidx * p.fold_rps;
+        if (ri >= p.fold_valid) continue;
+        crow = (long)sidx * p.sC1 + (long)ri * p.sCi;
+      }
       f32x4 v = *(const f32x4*)&Cs[i * CLD + j];
       const float rsv = rsb ? rsb[gi] : 0.f;
-      char* cp = Cb + ((long)gi * p.sCi + gj) * osz;
+      char* cp = Cb + (crow + gj) * osz;
       const bool full = (gj + 3 < p.N);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
@@ -389,10 +396,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (gi + e < p.M) {
+          char* ce = cp + e * osz;
+          if (p.fold_rps) {
+            const int sidx = (gi + e) / p.fold_rps, ri = (gi + e) - sidx * p.fold_rps;
+            if (ri >= p.fold_valid) continue;
+            ce = Cb + ((long)sidx * p.sC1 + (long)gj * p.sCj + ri) * osz;
+          }
           float x = p.alpha * Cs[(i + e) * CLD + j];
           if (Db) x += (rsb ? rsb[gi + e] : 0.f) * load_d((long)(gi + e) * p.sDi + gj);
-          if (p.accumulate) x += load_out(cp + e * osz);
-          store_out(cp + e * osz, x);
+          if (p.accumulate) x += load_out(ce);
+          store_out(ce, x);
         }
       }
     }
@@ -566,6 +579,22 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       if (s <= 0) return s;
     }
   }
+  // Batch fold: per-sample row blocks of A (K-major, regularly spaced) against ONE shared B are the rows of a single tall
+  // GEMM -- used when the per-sample M would leave a quarter or more of its tile rows empty (65 rows on a 128-row tile, 8
+  // latent rows on a 64-row tile).  Rows of the gaps between the samples' blocks are computed and not stored.
+  d.fold_rps = d.fold_valid = 0;
+  {
+    static const bool nofold = getenv("AVMOE_GEMM_NOFOLD") != nullptr;      // dev switch
+    if (!nofold && a.nb1 > 1 && a.nb2 == 1 && a.a_layout == K_MAJOR && a.sB1 == 0 && d.ksplit == 1 && !a.A2 && !a.D && a.lda > 0 &&
+        a.sA1 > 0 && a.sA1 % a.lda == 0) {
+      const long rps = a.sA1 / a.lda, rows = (long)(a.nb1 - 1) * rps + a.M;
+      const int t0 = a.tile ? a.tile : ((a.M > 64 && a.N > 64) ? 128 : 64);      // tile of the unfolded launch
+      const bool wasteful = round_up(a.M, t0) * 4 >= (long)a.M * 5;             // >= 25 % of its tile rows are padding (measured:
+      if (wasteful && rps >= a.M && (rps - a.M) * 8 <= a.M && rows < (1L << 30)) {   // folding full tiles gains nothing)
+        d.fold_rps = (int)rps; d.fold_valid = a.M; d.M = (int)rows; d.nbatch = 1; d.sA1 = 0;
+      }
+    }
+  }
   const int osz = d.out_bf16 ? 2 : 4;
   const int vecb = 4 * osz;    // bytes of a 4-element output vector
   d.vec_c = (a.sCj == 1) && (((uintptr_t)a.C) % vecb == 0) && ((a.sCi * osz) % vecb == 0) &&
@@ -576,7 +605,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.kper = d.ksplit > 1 ? (int)round_up(cdiv(a.K, d.ksplit), bk) : (a.K > 0 ? (int)round_up(a.K, bk) : bk);
 
   int tile = a.tile;
-  if (tile == 0) tile = (a.M > 64 && a.N > 64) ? 128 : 64;
+  if (tile == 0 || d.fold_rps) tile = (d.M > 64 && a.N > 64) ? 128 : 64;
   const int bz = d.nbatch * d.ksplit;
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
   int st;

@@ -220,3 +220,47 @@ def test_streaming_kernel_shapes(case):
     assert err < (2e-2 if out_bf16 else 1e-4), float(err)
     ints, ref = _run_gemm(8200, 144, 96, 1, False, True, nb2=2, exact_ints=True, seed=3)
     assert torch.equal(ints, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("M,rps,c_transposed", [(64, 65, False), (65, 65, False), (64, 65, True), (32, 33, True), (48, 48, False), (40, 41, False), (8, 9, False)])
+def test_batch_fold_shared_b(dtype, M, rps, c_transposed):
+    """Per-sample row blocks of A against ONE shared B run as a single tall GEMM (gemm.hip "batch fold", the latent x
+    token-remap products of moe_forward.cpp / moe_backward.cpp): the rows between the blocks hold NaN and must neither leak
+    into the result nor be stored -- C's gap rows keep their sentinel."""
+    from avmoe_amd import _capi as capi
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 + M + rps)
+    tdt = torch.bfloat16 if dtype == capi.BF16 else torch.float32
+    nb, N, K = 7, 197, 100
+    Kp = 104
+    A = torch.full((nb, rps, Kp), float("nan"), dtype=tdt)
+    A[:, :M, :] = 0
+    A[:, :M, :K] = torch.randn(nb, M, K, generator=g).to(tdt)
+    Bm = torch.full((N, Kp), 7.0, dtype=tdt)
+    Bm[:, :K] = torch.randn(N, K, generator=g).to(tdt)
+    ref = 0.5 * torch.matmul(A[:, :M, :K].double(), Bm[:, :K].double().t())            # (nb, M, N)
+    Nld, Mld = 200, 72
+    Cd = torch.full((nb, Nld, Mld) if c_transposed else (nb, rps, Nld), -5.0, dtype=torch.float32)
+    Ad, Bd, Cd = A.to(dev), Bm.to(dev), Cd.to(dev)
+    d = capi.GemmDesc()
+    d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb, 1
+    d.dtype, d.out_dtype, d.a_layout, d.b_layout = dtype, capi.F32, 0, 0
+    d.accumulate, d.ksplit, d.tile, d.alpha = 0, 1, 0, 0.5
+    d.lda, d.ldb, d.sA1, d.sA2, d.sB1, d.sB2 = Kp, Kp, rps * Kp, 0, 0, 0
+    if c_transposed:
+        d.sCi, d.sCj, d.sC1 = 1, Mld, Nld * Mld
+    else:
+        d.sCi, d.sCj, d.sC1 = Nld, 1, rps * Nld
+    st = L.avmoe_gemm(C.byref(d), Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), None, None, None, torch.cuda.current_stream().cuda_stream)
+    capi.check(st, "avmoe_gemm")
+    torch.cuda.synchronize()
+    got = Cd.double().cpu()
+    if c_transposed:
+        val, rest = got[:, :N, :M].transpose(1, 2), torch.cat([got[:, N:, :].reshape(-1), got[:, :N, M:].reshape(-1)])
+    else:
+        val, rest = got[:, :M, :N], torch.cat([got[:, M:, :].reshape(-1), got[:, :M, N:].reshape(-1)])
+    assert torch.isfinite(val).all()
+    assert float((val - ref).abs().max()) <= _tol(dtype) * float(ref.abs().max())
+    assert bool((rest == -5.0).all())
