@@ -413,34 +413,49 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
 }
 
 // split-K second pass: C = alpha * sum_s slab[s] (+ row_scale * D) (+ C)
+// A wave covers 64 / P consecutive output vectors; the slabs of one vector are shared by P lanes (lane = part * (64 / P) + vector,
+// part p sums slabs p, p + P, ...) and the P partial sums are combined by a fixed xor-shuffle tree -- a deterministic order.
+// With one thread per vector (P = 1) a long split of a small matrix keeps a hundred workgroups busy with 64 dependent loads each.
 template <typename T>
-__global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p) {
-  // one thread = VEC consecutive elements of a row (VEC = 4 when N % 4 == 0: 16-byte slab reads); 32-bit index math
+__global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p, int lgP) {
   const unsigned N = (unsigned)p.N, per = (unsigned)p.M * N, total = per * (unsigned)p.nbatch;
   const unsigned VEC = (N % 4u == 0u) ? 4u : 1u;
   const unsigned nvec = total / VEC;
-  for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < nvec; v += gridDim.x * 256u) {
-    const unsigned idx = v * VEC;
-    const unsigned b = idx / per, rem = idx - b * per;
-    const unsigned i = rem / N, j = rem - i * N;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned P = 1u << lgP, V = 64u >> lgP;           // parts per vector, vectors per wave
+  const unsigned part = lane / V, vl = lane % V;
+  const unsigned nwv = (nvec + V - 1) / V;                 // wave-sized groups of vectors
+  for (unsigned w = blockIdx.x * 4u + wave; w < nwv; w += gridDim.x * 4u) {
+    const unsigned v = w * V + vl;
+    const bool live = v < nvec;
+    const unsigned idx = live ? v * VEC : 0u;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float* sl = p.slabs + idx;
-    if (VEC == 4u) {
-      int sp = 0;
-      for (; sp + 4 <= p.ksplit; sp += 4) {
-        const f32x4 a0 = *(const f32x4*)(sl + (size_t)sp * total), a1 = *(const f32x4*)(sl + (size_t)(sp + 1) * total);
-        const f32x4 a2 = *(const f32x4*)(sl + (size_t)(sp + 2) * total), a3 = *(const f32x4*)(sl + (size_t)(sp + 3) * total);
+    if (live) {
+      if (VEC == 4u) {
+        int sp = (int)part;
+        for (; sp + 3 * (int)P < p.ksplit; sp += 4 * (int)P) {
+          const f32x4 a0 = *(const f32x4*)(sl + (size_t)sp * total), a1 = *(const f32x4*)(sl + (size_t)(sp + P) * total);
+          const f32x4 a2 = *(const f32x4*)(sl + (size_t)(sp + 2 * P) * total), a3 = *(const f32x4*)(sl + (size_t)(sp + 3 * P) * total);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += (a0[e] + a1[e]) + (a2[e] + a3[e]);
-      }
-      for (; sp < p.ksplit; ++sp) {
-        const f32x4 a0 = *(const f32x4*)(sl + (size_t)sp * total);
+          for (int e = 0; e < 4; ++e) s[e] += (a0[e] + a1[e]) + (a2[e] + a3[e]);
+        }
+        for (; sp < p.ksplit; sp += (int)P) {
+          const f32x4 a0 = *(const f32x4*)(sl + (size_t)sp * total);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += a0[e];
+          for (int e = 0; e < 4; ++e) s[e] += a0[e];
+        }
+      } else {
+        for (int sp = (int)part; sp < p.ksplit; sp += (int)P) s[0] += sl[(size_t)sp * total];
       }
-    } else {
-      for (int sp = 0; sp < p.ksplit; ++sp) s[0] += sl[(size_t)sp * total];
     }
+    for (unsigned off = V; off < 64u; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += __shfl_xor(s[e], (int)off, 64);
+    }
+    if (!live || part != 0u) continue;
+    const unsigned b = idx / per, rem = idx - b * per;
+    const unsigned i = rem / N, j = rem - i * N;
     const int b1 = (int)b / p.nb2, b2 = (int)b % p.nb2;
     const float rsv = (p.D && p.rs) ? p.rs[(long)b1 * p.sRS1 + (long)b2 * p.sRS2 + i] : 0.f;
     for (unsigned e = 0; e < VEC; ++e) {
@@ -626,10 +641,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     const long total = (long)d.nbatch * a.M * a.N;
     if (total >= (1L << 31)) { set_last_error("gemm: split-K result too large"); return ERR_UNSUPPORTED; }
     const long nvec = (a.N % 4 == 0) ? total / 4 : total;
-    const int blocks = (int)std::min<long>((nvec + 255) / 256, 4096);
+    int lgP = 0;                                             // lanes per output vector: enough threads for ~2 waves per SIMD
+    while (lgP < 4 && (2 << lgP) <= d.ksplit && (nvec << lgP) < 131072) ++lgP;
+    const long nwv = (nvec + (64 >> lgP) - 1) / (64 >> lgP);
+    const int blocks = (int)std::min<long>((nwv + 3) / 4, 4096);
     ProfScope ps("gemm_splitk_reduce", (double)total * 4.0 * (d.ksplit + 1), 0.0, stream);
-    if (a.dtype == GEMM_BF16) hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3(blocks), dim3(256), 0, stream, d);
-    else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d);
+    if (a.dtype == GEMM_BF16) hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3(blocks), dim3(256), 0, stream, d, lgP);
+    else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d, lgP);
     AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
   }
   return OK;

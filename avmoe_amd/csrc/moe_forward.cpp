@@ -1,6 +1,7 @@
 // Forward orchestration of one MoEAdapter site: a fixed sequence of engine GEMMs and bottleneck-space
 // kernels on the caller's stream (no allocation, no host sync: capturable in a hipGraph).
 // Stage names follow oracle/algebra_ref.py::AlgebraRef.forward.
+#include <cstdlib>
 #include "moe_run.h"
 
 namespace avmoe {
@@ -9,7 +10,8 @@ int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap) {
   const int tile = (g.tile ? g.tile : ((g.M > 64 && g.N > 64) ? 128 : 64));
   const long tiles = (long)cdiv(g.M, tile) * cdiv(g.N, tile) * g.nb1 * g.nb2;
   const int bk = g.dtype == GEMM_BF16 ? 64 : 32;
-  long ks = std::max<long>(1, 768 / std::max<long>(tiles, 1));
+  static const long target = getenv("AVMOE_KS_TARGET") ? atol(getenv("AVMOE_KS_TARGET")) : 768;     // workgroups wanted (dev override)
+  long ks = std::max<long>(1, target / std::max<long>(tiles, 1));
   ks = std::min<long>(ks, std::max<long>(1, g.K / (4 * bk)));
   ks = std::min<long>(ks, 64);
   const size_t per = (size_t)g.nb1 * g.nb2 * g.M * g.N;
