@@ -51,7 +51,10 @@ class AdapterConfig:
     ln_before: bool = True       # opt.is_before_layernorm
     ln_post: bool = True         # opt.is_post_layernorm
     variant: str = "ave"         # ave | avqa | avvp | avs
-    self_attn: str = "none"      # none | v2 (AVS latent self attention) | nxn (AVVP, implied by variant)
+    self_attn: str = "none"      # none | v2 (AVS latent self attention) | v1 (AVS MultiheadAttention across frames) |
+                                 # nxn (AVVP, implied by variant)
+    mha_heads: int = 4           # PVT_AVSModel_v2.py:138
+    mha_dropout: float = 0.2     # PVT_AVSModel_v2.py:139 (on the attention weights, training only)
     lb_loss: bool = False        # opt.use_load_balacing_loss
     bn_eps: float = 1e-5
     ln_eps: float = 1e-5
@@ -71,7 +74,7 @@ class AdapterConfig:
                [f"singlemodal_experts.{j}" for j in range(self.E_s)]
 
     def uni_has_attn(self) -> bool:
-        return self.variant == "avvp" or self.self_attn in ("v2", "nxn")
+        return self.variant == "avvp" or self.self_attn in ("v1", "v2", "nxn")
 
     def to_dict(self):
         return asdict(self)
@@ -103,6 +106,11 @@ def param_shapes(cfg: AdapterConfig) -> Dict[str, tuple]:
             elif cfg.self_attn == "v2":
                 sh[f"{pre}.my_tokens"] = (cfg.K, C)  # PVT_AVSModel_v2.py:144-145
                 sh[f"{pre}.gate_self"] = (1,)
+            elif cfg.self_attn == "v1":              # nn.MultiheadAttention(C, 4, dropout=.2), PVT_AVSModel_v2.py:141-142
+                sh[f"{pre}.self_attention.in_proj_weight"] = (3 * C, C)
+                sh[f"{pre}.self_attention.in_proj_bias"] = (3 * C,)
+                sh[f"{pre}.self_attention.out_proj.weight"] = (C, C)
+                sh[f"{pre}.self_attention.out_proj.bias"] = (C,)
         sh[f"{pre}.down_sampler.weight"] = (d, C // g, 1, 1)
         sh[f"{pre}.up_sampler.weight"] = (C, d // g, 1, 1)
         if cfg.use_bn:
@@ -144,6 +152,8 @@ def init_params(cfg: AdapterConfig, seed: int = 0, dtype=torch.float32, randomiz
                 if randomize else torch.zeros(shp, dtype=dtype)
         elif leaf == "my_tokens":
             v = torch.rand(shp, generator=gen, dtype=torch.float64).to(dtype)      # torch.rand init
+        elif leaf in ("in_proj_weight", "in_proj_bias"):
+            v = uni(shp, 1.0 / math.sqrt(cfg.Cx)) if (randomize or leaf == "in_proj_weight") else torch.zeros(shp, dtype=dtype)
         elif mod in ("bn1", "bn2", "ln_before", "ln_post"):
             if randomize:
                 v = torch.rand(shp, generator=gen, dtype=torch.float64).add(0.5).to(dtype) \
@@ -212,7 +222,23 @@ def latent_attention(X, src, tokens):
     return A2 @ T                                                    # :388      (S,N,C)
 
 
-def expert_forward(P, B, pre, X, Yf, cfg: AdapterConfig, multimodal, training, new_buffers):
+def frames_mha(X, Win, bin_, Wout, bout, heads, keep=None):
+    """nn.MultiheadAttention(C, heads, dropout) called with batch_first=False on (S, N, C) (PVT_AVSModel_v2.py:212-214): the
+    SEQUENCE axis is the frames S, the batch axis the tokens N.  torch.nn.functional.multi_head_attention_forward with
+    need_weights=True: q scaled by 1/sqrt(C/heads), softmax over the key frames, dropout on the attention weights, out_proj.
+    keep: (N * heads, S, S) multiplier (0 or 1/(1-p)) standing for that dropout, or None (eval / p = 0)."""
+    S, N, C = X.shape
+    dh = C // heads
+    q, k, v = (X @ Win.t() + bin_).split(C, dim=-1)                               # (S, N, C) each
+    hd = lambda t: t.reshape(S, N * heads, dh).transpose(0, 1)                    # (N * heads, S, dh)
+    att = F.softmax((hd(q) * (1.0 / math.sqrt(dh))) @ hd(k).transpose(1, 2), dim=-1)   # (N * heads, S, S)
+    if keep is not None:
+        att = att * keep
+    o = (att @ hd(v)).transpose(0, 1).reshape(S, N, C)
+    return o @ Wout.t() + bout
+
+
+def expert_forward(P, B, pre, X, Yf, cfg: AdapterConfig, multimodal, training, new_buffers, mha_keep=None):
     """ExpertAdapter.forward, token-major (net_trans_v3.py:376-435)."""
     if multimodal:
         X = X + P[f"{pre}.gate_av"] * latent_attention(X, Yf, P[f"{pre}.my_tokens"])   # :390
@@ -221,6 +247,10 @@ def expert_forward(P, B, pre, X, Yf, cfg: AdapterConfig, multimodal, training, n
         X = X + P[f"{pre}.gate_av"] * (att.transpose(1, 2) @ X)      # mgn.py:137-139  x_cn @ att
     elif cfg.self_attn == "v2":
         X = X + P[f"{pre}.gate_self"] * latent_attention(X, X, P[f"{pre}.my_tokens"])  # S4 :215-227
+    elif cfg.self_attn == "v1":                                      # S4 :210-214 -- REPLACES x
+        X = frames_mha(X, P[f"{pre}.self_attention.in_proj_weight"], P[f"{pre}.self_attention.in_proj_bias"],
+                       P[f"{pre}.self_attention.out_proj.weight"], P[f"{pre}.self_attention.out_proj.bias"], cfg.mha_heads,
+                       None if mha_keep is None else mha_keep.get(pre))
     elif cfg.self_attn not in ("none",):
         raise NotImplementedError(f"self_attn={cfg.self_attn}")
     if cfg.ln_before:
@@ -251,12 +281,13 @@ def load_balancing_loss(probs):
     return -(torch.log(pbar)).sum()
 
 
-def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, update_buffers=True):
+def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, update_buffers=True, mha_keep=None):
     """MoEAdapter.forward (net_trans_v3.py:468-487) on token-major X:(S,Nx,Cx), Y:(S,Ny,Cy).
 
     Returns dict(out (S,Nx,Cx), probs (S,E), idx (S,) int64, lb (0-d), Yf, new_buffers).
     `noise` (S,E) is the AVS logit noise already scaled by 0.01 (PVT_AVSModel_v2.py:294-296);
-    pass None for no noise."""
+    pass None for no noise.  `mha_keep`: {expert prefix: (N * heads, S, S) dropout multiplier} for self_attn == "v1" in training
+    mode (the reference draws it from the global RNG); None = no dropout."""
     Wc = P["conv_adapter.weight"][:, :, 0, 0]
     Yt = torch.einsum("nm,smc->snc", Wc, Y) + P["conv_adapter.bias"][None, :, None]    # :469
     Yf = Yt @ P["fc.weight"].t() + P["fc.bias"]                                          # :470
@@ -271,7 +302,7 @@ def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, updat
     new_buffers = {} if (training and update_buffers and cfg.use_bn) else None
     out = torch.zeros_like(X)
     for j, pre in enumerate(cfg.expert_prefixes()):                                      # :482
-        o = expert_forward(P, B, pre, X, Yf, cfg, j < cfg.E_m, training, new_buffers)
+        o = expert_forward(P, B, pre, X, Yf, cfg, j < cfg.E_m, training, new_buffers, mha_keep)
         out = out + probs[:, j].reshape(-1, 1, 1) * o                                    # :485-486
     lb = load_balancing_loss(probs) if cfg.lb_loss else torch.zeros((), dtype=X.dtype)
     if new_buffers is not None:
@@ -282,13 +313,13 @@ def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, updat
 
 
 def moe_forward_backward(P, B, X, Y, cfg: AdapterConfig, grad_out, training=True, noise=None,
-                         lb_weight: float = 0.0):
+                         lb_weight: float = 0.0, mha_keep=None):
     """Forward + autograd backward.  Loss = <out, grad_out> + lb_weight * lb.
     Returns (fwd dict, grads dict with 'X', 'Y' and one entry per parameter key)."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     Xg = X.detach().clone().requires_grad_(True)
     Yg = Y.detach().clone().requires_grad_(True)
-    fwd = moe_forward(Pg, B, Xg, Yg, cfg, training=training, noise=noise)
+    fwd = moe_forward(Pg, B, Xg, Yg, cfg, training=training, noise=noise, mha_keep=mha_keep)
     loss = (fwd["out"] * grad_out).sum()
     if cfg.lb_loss and lb_weight != 0.0:
         loss = loss + lb_weight * fwd["lb"]

@@ -112,11 +112,33 @@ def _import_variant(which):
 def _opt(cfg: AdapterConfig):
     return NS(num_conv_group=cfg.groups, is_before_layernorm=int(cfg.ln_before),
               is_post_layernorm=int(cfg.ln_post),
-              is_self_attention=int(cfg.self_attn == "v2"), self_attention_version="v2",
+              is_self_attention=int(cfg.self_attn in ("v1", "v2")),
+              self_attention_version=cfg.self_attn if cfg.self_attn in ("v1", "v2") else "v2",
               num_multimodal_experts=cfg.E_m, num_singlemodal_experts=cfg.E_s,
               use_load_balacing_loss=int(cfg.lb_loss),
               Adapter_downsample=cfg.reduction, is_bn=int(cfg.use_bn), is_gate=int(cfg.use_gate),
               num_tokens=cfg.K)
+
+
+class _RecordDropout:
+    """Records, in call order, the multiplier (0 or 1/(1-p)) every torch.nn.functional.dropout call of the reference forward
+    applied -- the "v1" experts' MultiheadAttention drops attention weights with the global RNG in training mode.  The
+    fixture stores the multipliers as data so that the oracle and the HIP path replay exactly that draw."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.orig, self.keeps = F, F.dropout, []
+
+        def rec(input, p=0.5, training=True, inplace=False):
+            out = self.orig(input, p=p, training=training, inplace=False)
+            if training and p > 0.0:
+                self.keeps.append(torch.where(out == 0, torch.zeros_like(out), torch.full_like(out, 1.0 / (1.0 - p))).detach())
+            return out
+        F.dropout = rec
+        return self
+
+    def __exit__(self, *a):
+        self.F.dropout = self.orig
 
 
 def _build_reference(which, cfg: AdapterConfig):
@@ -164,7 +186,8 @@ def make_case(name, which, cfg: AdapterConfig, S, module_train=True, is_training
             torch.manual_seed(noise_seed)
             noise = (torch.randn(S, 1, cfg.E) * 0.01).reshape(S, cfg.E)
             torch.manual_seed(noise_seed)
-        out, idx, probs, lb = ref(xin, yin, is_training=flag)
+        with _RecordDropout() as drops:
+            out, idx, probs, lb = ref(xin, yin, is_training=flag)
     elif which == "avvp":
         out, lb = ref(xin, yin)
         idx, probs = None, None
@@ -203,6 +226,13 @@ def make_case(name, which, cfg: AdapterConfig, S, module_train=True, is_training
     }
     if noise is not None:
         arrays["noise"] = noise.numpy()
+    if cfg.self_attn == "v1" and module_train:          # one draw per unimodal expert, in expert order (PVT_AVSModel_v2.py:306-308)
+        uni = cfg.expert_prefixes()[cfg.E_m:]
+        assert len(drops.keeps) == len(uni), (len(drops.keeps), len(uni))
+        for pre, kp in zip(uni, drops.keeps):
+            assert tuple(kp.shape) == (cfg.Nx * cfg.mha_heads, S, S), kp.shape
+            assert float((kp == 0).float().mean()) > 0.05      # softmax weights are never exactly 0: zeros are drops
+            arrays[f"mha_keep.{pre}"] = kp.numpy()
     for k, v in ref.named_parameters():
         arrays[f"param.{k}"] = P[k].numpy()
         arrays[f"grad.{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
@@ -246,6 +276,11 @@ def main():
               is_training_flag=True, noise_seed=777, lb_weight=0.01, seed=11)
     make_case("avs_v2_train", "avs", A(**small, variant="avs", self_attn="v2", lb_loss=True), S,
               is_training_flag=False, lb_weight=0.01, seed=12)
+    v1 = dict(Cx=64, Nx=24, Cy=48, Ny=40, reduction=4, groups=2, K=8)
+    make_case("avs_v1_train", "avs", A(**v1, variant="avs", self_attn="v1", lb_loss=True), 5,
+              is_training_flag=False, lb_weight=0.01, seed=16)
+    make_case("avs_v1_eval", "avs", A(**v1, variant="avs", self_attn="v1", E_m=1, E_s=1), 5, module_train=False,
+              is_training_flag=False, seed=17)
     make_case("avs_ms3_eval", "avs_ms3", A(**small, variant="avs", lb_loss=False), S, module_train=False,
               is_training_flag=False, seed=13)
     make_case("avs_k87_train", "avs", A(Cx=96, Nx=40, Cy=64, Ny=56, reduction=8, groups=2, K=87,

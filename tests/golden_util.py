@@ -37,6 +37,12 @@ def split_params(t):
     return P, B
 
 
+def mha_keep_of(t):
+    """{expert prefix: dropout multiplier} recorded from the reference's "v1" MultiheadAttention draw, or None."""
+    d = {k[len("mha_keep."):]: v for k, v in t.items() if k.startswith("mha_keep.")}
+    return d or None
+
+
 def grad_errors(grads, t, keys=None):
     """Per-key error of `grads` against the fixture's `grad.<key>` entries.
 

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import avmoe_oracle as O
-from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close
+from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close, mha_keep_of
 
 NAMES = golden_names()
 
@@ -20,7 +20,7 @@ def test_oracle_matches_reference_vectors(name):
     training = bool(meta["module_train"])
     noise = t.get("noise")
     fwd, grads = O.moe_forward_backward(P, B, t["X"], t["Y"], cfg, t["grad_out"], training=training,
-                                        noise=noise, lb_weight=meta["lb_weight"])
+                                        noise=noise, lb_weight=meta["lb_weight"], mha_keep=mha_keep_of(t))
     assert torch.equal(fwd["idx"], t["idx"]), "router argmax must be bit-exact"
     assert _rel(fwd["out"], t["out"]) < 2e-5
     assert _rel(fwd["probs"], t["probs"]) < 1e-5
