@@ -6,7 +6,7 @@ from typing import Dict, List, Optional
 
 MAX_EXPERTS = 16
 VARIANT = {"ave": 0, "avqa": 0, "avvp": 1, "avs": 2}
-SELF_ATTN = {"none": 0, "v2": 1, "nxn": 2}
+SELF_ATTN = {"none": 0, "v2": 1, "nxn": 2, "v1": 3}
 
 
 class MoeDesc(C.Structure):
@@ -18,7 +18,8 @@ class MoeDesc(C.Structure):
 
 
 _EXPERT_FIELDS = ("gate", "my_tokens", "gate_lat", "down_w", "up_w", "bn1_w", "bn1_b", "bn2_w", "bn2_b",
-                  "lnb_w", "lnb_b", "lnp_w", "lnp_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv")
+                  "lnb_w", "lnb_b", "lnp_w", "lnp_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv",
+                  "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "sa_keep")
 _TOP_FIELDS = ("conv_w", "conv_b", "fc_w", "fc_b", "r0_w", "r0_b", "r2_w", "r2_b", "r4_w", "r4_b")
 
 
@@ -30,6 +31,8 @@ class MoePtrs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _TOP_FIELDS] + [("e", ExpertPtrs * MAX_EXPERTS)]
 
 
+SA_KEEP = "self_attention.__keep__"
+
 # state_dict leaf (relative to the expert prefix) -> ExpertPtrs field
 EXPERT_KEY_TO_FIELD = {
     "gate": "gate", "my_tokens": "my_tokens", "gate_av": "gate_lat", "gate_self": "gate_lat",
@@ -37,6 +40,9 @@ EXPERT_KEY_TO_FIELD = {
     "bn1.weight": "bn1_w", "bn1.bias": "bn1_b", "bn2.weight": "bn2_w", "bn2.bias": "bn2_b",
     "ln_before.weight": "lnb_w", "ln_before.bias": "lnb_b", "ln_post.weight": "lnp_w", "ln_post.bias": "lnp_b",
     "bn1.running_mean": "bn1_rm", "bn1.running_var": "bn1_rv", "bn2.running_mean": "bn2_rm", "bn2.running_var": "bn2_rv",
+    "self_attention.in_proj_weight": "sa_in_w", "self_attention.in_proj_bias": "sa_in_b",
+    "self_attention.out_proj.weight": "sa_out_w", "self_attention.out_proj.bias": "sa_out_b",
+    SA_KEEP: "sa_keep",            # not a state_dict entry: the dropout multiplier of one call (include/avmoe.h)
 }
 TOP_KEY_TO_FIELD = {
     "conv_adapter.weight": "conv_w", "conv_adapter.bias": "conv_b", "fc.weight": "fc_w", "fc.bias": "fc_b",

@@ -55,7 +55,8 @@ def _site_forward(module, X, Y, noise, names, params):
         if v.dtype != torch.float32 or not v.is_contiguous() or v.device != X.device:
             raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {X.device}")
     bufs = module._buffer_tensors()
-    ptrs = cm.make_ptrs({**tensors, **bufs}, module.num_multimodal_experts, module.num_singlemodal_experts)
+    keep = module._attention_keep(S, N, X.device)
+    ptrs = cm.make_ptrs({**tensors, **bufs, **keep}, module.num_multimodal_experts, module.num_singlemodal_experts)
     nsaved = L.avmoe_moe_saved_bytes(C.byref(desc))
     if nsaved == 0:
         raise capi.AvmoeError(L.avmoe_last_error().decode())
@@ -73,16 +74,16 @@ def _site_forward(module, X, Y, noise, names, params):
                              idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
                              torch.cuda.current_stream(X.device).cuda_stream)
     capi.check(st, "avmoe_moe_forward")
-    return out, probs, idx, lb, (desc, saved, X, Y)
+    return out, probs, idx, lb, ((desc, keep), saved, X, Y)
 
 
 def _site_backward(module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False):
     """One avmoe_moe_backward call writing (or, with acc_*, adding) the token gradients into dX / dY.  Returns the
     parameter gradients in `names` order (None where not needed, or for all of them when a gradient sink took them)."""
     L = capi.lib()
-    desc, saved, X, Y = state
+    (desc, keep), saved, X, Y = state
     tensors = dict(zip(names, params))
-    ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors()}, module.num_multimodal_experts,
+    ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors(), **keep}, module.num_multimodal_experts,
                         module.num_singlemodal_experts)
     # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
     # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
@@ -229,16 +230,16 @@ class ExpertAdapter(nn.Module):
             self.gate_av = nn.Parameter(torch.zeros(1))
         elif variant == "avvp":
             self.gate_av = nn.Parameter(torch.zeros(1))                       # mgn.py:83
-        elif variant == "avs" and getattr(opt, "is_self_attention", 0):
-            ver = getattr(opt, "self_attention_version", "v1")
-            if ver == "v2":                                                   # PVT_AVSModel_v2.py:143-145
-                self.my_tokens = nn.Parameter(torch.rand((num_tk, input_dim)))
-                self.gate_self = nn.Parameter(torch.zeros(1))
-            else:
-                raise NotImplementedError("self_attention_version 'v1' (nn.MultiheadAttention across frames, "
-                                          "PVT_AVSModel_v2.py:141-142,211-214) is not built")
+        elif variant == "avs" and getattr(opt, "is_self_attention", 0) and \
+                getattr(opt, "self_attention_version", "v1") == "v2":         # PVT_AVSModel_v2.py:143-145
+            self.my_tokens = nn.Parameter(torch.rand((num_tk, input_dim)))
+            self.gate_self = nn.Parameter(torch.zeros(1))
         elif getattr(opt, "is_self_attention", 0):
-            raise NotImplementedError("opt.is_self_attention=1 (nn.MultiheadAttention, net_trans_v3.py:346-347) is not built")
+            # AVS self_attention_version "v1" (its default, PVT_AVSModel_v2.py:141-142) and the AVE / AVQA is_self_attention
+            # switch (net_trans_v3.py:342-343): the unimodal expert's input is replaced by MultiheadAttention(x, x, x) over the
+            # FRAMES.  Parameter container only (in_proj_weight, in_proj_bias, out_proj.*); csrc/mha_frames.hip does the work.
+            self.num_head, self.head_dropout = 4, 0.2
+            self.self_attention = nn.MultiheadAttention(input_dim, num_heads=self.num_head, dropout=self.head_dropout)
         self.down_sampler = nn.Conv2d(input_dim, self.down_sample_size, 1, groups=g, bias=False)
         self.up_sampler = nn.Conv2d(self.down_sample_size, output_dim, 1, groups=g, bias=False)
         if use_bn:
@@ -284,7 +285,26 @@ class MoEAdapter(nn.Module):
         if self.variant == "avs" and getattr(self.opt, "is_self_attention", 0) and \
                 getattr(self.opt, "self_attention_version", "v1") == "v2":
             return "v2"
+        if getattr(self.opt, "is_self_attention", 0) and self.num_singlemodal_experts > 0:
+            return "v1"
         return "none"
+
+    def _attention_keep(self, S, N, device):
+        """{key: (N * heads, S, S) f32} dropout multipliers (0 or 1 / (1 - p)) of the "v1" experts' attention weights for one
+        training-mode call -- the draw nn.MultiheadAttention makes with the global RNG (one per unimodal expert, in expert
+        order); {} in eval mode.  `self.attention_keep` (same keys) overrides the draw: tests replay a recorded one."""
+        if self._self_attn() != "v1" or not self.training:
+            return {}
+        forced = getattr(self, "attention_keep", None)
+        out = {}
+        for j, ex in enumerate(self.singlemodal_experts):
+            key = f"singlemodal_experts.{j}.{cm.SA_KEEP}"
+            p = ex.self_attention.dropout
+            if forced is not None:
+                out[key] = forced[key].to(device=device, dtype=torch.float32).contiguous()
+            elif p > 0.0:
+                out[key] = (torch.rand(N * ex.self_attention.num_heads, S, S, device=device) >= p).float().mul_(1.0 / (1.0 - p))
+        return out
 
     def _desc(self, S, N, M, bf16):
         d = cm.MoeDesc()

@@ -520,32 +520,35 @@ __global__ void __launch_bounds__(256) kk_xrstats(const void* X_, const void* R_
     if (lane == 0) { out[row] = s0; out[rows + row] = s1; out[2 * rows + row] = s2; }
   }
 }
-int k_xrstats(const Plan& pl, const void* X, char* saved, hipStream_t st) {
+int k_xrstats(const Plan& pl, const void* X, char* saved, int slot, hipStream_t st) {
   ProfScope ps_("k_xrstats", 0.0, 0.0, st);
   const Dims& d = pl.d;
-  DISPATCH_T(d.bf16, kk_xrstats, dim3((unsigned)std::min<long>((d.NT + 3) / 4, 8192)), dim3(256), 0, st, X, (const void*)(saved + pl.o_xr),
-             (long)d.NT, d.C, (float*)(saved + pl.o_sxr));
+  DISPATCH_T(d.bf16, kk_xrstats, dim3((unsigned)std::min<long>((d.NT + 3) / 4, 8192)), dim3(256), 0, st, X,
+             (const void*)(saved + pl.o_xr + (size_t)slot * d.NT * d.C * d.esz), (long)d.NT, d.C, (float*)(saved + pl.o_sxr) + (size_t)slot * 3 * d.NT);
   AVMOE_CHECK_LAUNCH("xrstats");
   return OK;
 }
-// dxr[t][c] += dsr2[t] * X[t][c] + dsr0[t] ;  dX[t][c] += dsr2[t] * xr[t][c]
+// dxr[t][c] += dsr2[t] * X[t][c] + dsr0[t] ;  dX[t][c] += dsr2[t] * xr[t][c]  (- dxr[t][c] when xr = f(X) - X REPLACES the
+// input: the direct route of that expert's input gradient is then not a route at all -- AVS "v1")
 template <typename T>
-__global__ void kk_nxn_axpy(const void* X_, const void* R_, const float* dsr, long NT, int C, void* dxr_, void* dX_) {
+__global__ void kk_nxn_axpy(const void* X_, const void* R_, const float* dsr, long NT, int C, void* dxr_, void* dX_, int replaces) {
   const T* X = (const T*)X_; const T* R = (const T*)R_;
   T* dxr = (T*)dxr_; T* dX = (T*)dX_;
   const long total = NT * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long t = i / C;
     const float d0 = dsr[t], d2 = dsr[2 * NT + t];
-    stT<T>(dxr, i, ldT<T>(dxr, i) + d2 * ldT<T>(X, i) + d0);
-    stT<T>(dX, i, ldT<T>(dX, i) + d2 * ldT<T>(R, i));
+    const float g = roundTb<T>(ldT<T>(dxr, i) + d2 * ldT<T>(X, i) + d0);
+    stT<T>(dxr, i, g);
+    stT<T>(dX, i, ldT<T>(dX, i) + d2 * ldT<T>(R, i) - (replaces ? g : 0.f));
   }
 }
-int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, hipStream_t st) {
+int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, int slot, int replaces, hipStream_t st) {
   ProfScope ps_("k_nxn_axpy", 0.0, 0.0, st);
   const Dims& d = pl.d;
-  DISPATCH_T(d.bf16, kk_nxn_axpy, dim3(grid1db((long)d.NT * d.C, 16384)), dim3(256), 0, st, X, (const void*)(saved + pl.o_xr),
-             (const float*)(scratch + pl.o_dsr), (long)d.NT, d.C, (void*)(scratch + pl.o_dxr), dX);
+  DISPATCH_T(d.bf16, kk_nxn_axpy, dim3(grid1db((long)d.NT * d.C, 16384)), dim3(256), 0, st, X,
+             (const void*)(saved + pl.o_xr + (size_t)slot * d.NT * d.C * d.esz), (const float*)(scratch + pl.o_dsr) + (size_t)slot * 3 * d.NT,
+             (long)d.NT, d.C, (void*)(scratch + pl.o_dxr), dX, replaces);
   AVMOE_CHECK_LAUNCH("nxn_axpy");
   return OK;
 }

@@ -12,9 +12,12 @@ namespace avmoe {
     if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; } \
   } while (0)
 
-int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, const float* lb_grad,
+avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* sv);   // moe_forward.cpp
+
+int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const void* dOut, const float* lb_grad,
                  char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
+  const avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
@@ -74,7 +77,23 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.accumulate = d.acc_dx;
     AVMOE_TRY(run(g, false));
   }
-  if (d.nxn) {   // ---- AVVP N x N block: back through ZR = xr Wt^T, the three row sums and xr = att^T X --------------------
+  if (d.mha) {   // ---- AVS "v1": per expert back through ZR = xr Wt_e^T, the row sums and xr = MHA_e(X) - X -------------------
+    for (int e = 0; e < d.E; ++e) {
+      if (!d.nxn_of_e[e]) continue;
+      const int slot = d.xr_of_e[e];
+      {                                                    // dxr = dZR[:, expert e] Wt_e + (2 dSxx) xr
+        GemmArgs g = base();
+        g.A = sc + pl.o_dZR + (size_t)e * d.dgp * esz; g.B = sv + pl.o_Wt + (size_t)e * d.dgp * d.Cg * esz; g.C = sc + pl.o_dxr;
+        g.M = d.NT; g.N = d.Cg; g.K = d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb2 = d.g;
+        g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.C; g.sC2 = d.Cg; g.out_dtype = dt;
+        g.row_scale = (const float*)(sc + pl.o_dsr) + (size_t)slot * 3 * d.NT + d.NT;
+        g.D = sv + pl.o_xr + (size_t)slot * d.NT * d.C * esz; g.sDi = d.C; g.sD2 = d.Cg;
+        AVMOE_TRY(run(g, false));
+      }
+      AVMOE_TRY(k_nxn_axpy(pl, X, sv, sc, dX, slot, 1, st));   // dxr += dsr2 X + dsr0 ; dX += dsr2 xr - dxr (input replaced)
+      AVMOE_TRY(mha_frames_backward(pl, X, prm.e[e], grads.e[e], slot, sc + pl.o_dxr, sv, sc, slabs, slab_cap, dX, st));
+    }
+  } else if (d.nxn) {   // ---- AVVP N x N block: back through ZR = xr Wt^T, the three row sums and xr = att^T X --------------------
     {                                                      // dxr = dZR Wt + (2 g^2 dSxx) xr
       GemmArgs g = base();
       g.A = sc + pl.o_dZR; g.B = sv + pl.o_Wt; g.C = sc + pl.o_dxr;
@@ -83,7 +102,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.row_scale = (const float*)(sc + pl.o_dsr) + d.NT; g.D = sv + pl.o_xr; g.sDi = d.C; g.sD2 = d.Cg;
       AVMOE_TRY(run(g, false));
     }
-    AVMOE_TRY(k_nxn_axpy(pl, X, sv, sc, dX, st));            // dxr += dsr2 X + dsr0 ; dX += dsr2 xr
+    AVMOE_TRY(k_nxn_axpy(pl, X, sv, sc, dX, 0, 0, st));      // dxr += dsr2 X + dsr0 ; dX += dsr2 xr
     {                                                      // d att[s] = X[s] dxr[s]^T
       GemmArgs g = base();
       g.A = X; g.B = sc + pl.o_dxr; g.C = sc + pl.o_attS;
@@ -131,7 +150,15 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       h.A = sc + pl.o_dTW; h.B = sv + pl.o_Text; h.K = d.S * d.KLT; h.accumulate = 1; h.ksplit = 1;
       AVMOE_TRY(run(h, true));
     }
-    if (d.nxn) {                                           // + dZR^T xr
+    if (d.mha) {                                           // + dZR[:, expert e]^T xr_e
+      for (int e = 0; e < d.E; ++e) {
+        if (!d.nxn_of_e[e]) continue;
+        GemmArgs h = g;
+        h.A = sc + pl.o_dZR + (size_t)e * d.dgp * esz; h.B = sv + pl.o_xr + (size_t)d.xr_of_e[e] * d.NT * d.C * esz;
+        h.C = sc + pl.o_dWt + (size_t)e * d.dgp * d.Cg * 4; h.M = d.dgp; h.accumulate = 1; h.ksplit = 1;
+        AVMOE_TRY(run(h, true));
+      }
+    } else if (d.nxn) {                                    // + dZR^T xr
       GemmArgs h = g;
       h.A = sc + pl.o_dZR; h.B = sv + pl.o_xr; h.accumulate = 1; h.ksplit = 1;
       AVMOE_TRY(run(h, true));

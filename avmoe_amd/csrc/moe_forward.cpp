@@ -19,9 +19,20 @@ int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap) {
   return (int)ks;
 }
 
-int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const float* noise, void* out,
+// The "v1" experts run through the x + gate * xr code of the AVVP ones with gate 1: a device constant stands in for gate_av.
+avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* sv) {
+  avmoe_moe_ptrs p = prm;
+  if (pl.d.mha)
+    for (int e = 0; e < pl.d.E; ++e)
+      if (pl.d.nxn_of_e[e]) p.e[e].gate_lat = (float*)(sv + pl.o_scal) + 1;
+  return p;
+}
+
+int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const float* noise, void* out,
                 float* probs_out, int64_t* idx_out, float* lb_out, char* sv, char* sc, hipStream_t st) {
   const Dims& d = pl.d;
+  const avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
+  if (d.mha) AVMOE_TRY(k_fill_f32((float*)(sv + pl.o_scal) + 1, 1, 1.f, st));
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
@@ -137,7 +148,20 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   }
   // ---- AVVP unimodal N x N block (mgn.py:132-139): xr = softmax_rows(X X^T)^T X, shared by the unimodal experts;
   //      their input x + gate_av * xr enters the LN-folded projection through ZR = xr Wt^T and three row sums ----
-  if (d.nxn) {
+  if (d.mha) {                                             // AVS "v1": one xr = MHA_e(X) - X per unimodal expert, through that expert's Wt rows
+    for (int e = 0; e < d.E; ++e) {
+      if (!d.nxn_of_e[e]) continue;
+      const int slot = d.xr_of_e[e];
+      AVMOE_TRY(mha_frames_forward(pl, X, prm.e[e], slot, sv, sc, st));
+      AVMOE_TRY(k_xrstats(pl, X, sv, slot, st));
+      GemmArgs g = base();                                 // ZR[:, expert e] = xr Wt_e^T
+      g.A = sv + pl.o_xr + (size_t)slot * d.NT * d.C * d.esz; g.B = sv + pl.o_Wt + (size_t)e * d.dgp * d.Cg * d.esz;
+      g.C = sv + pl.o_ZR + (size_t)e * d.dgp * 4;
+      g.M = d.NT; g.N = d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb2 = d.g;
+      g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC2 = (long)d.E * d.dgp;
+      AVMOE_TRY(launch_gemm(g, st));
+    }
+  } else if (d.nxn) {
     {                                                      // scores[s] = X[s] X[s]^T
       GemmArgs g = base();
       g.A = X; g.B = X; g.C = sc + pl.o_attS;
@@ -153,7 +177,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
       AVMOE_TRY(launch_gemm(g, st));
     }
-    AVMOE_TRY(k_xrstats(pl, X, sv, st));
+    AVMOE_TRY(k_xrstats(pl, X, sv, 0, st));
     AVMOE_TRY(down_gemm(sv + pl.o_xr, d.NT, sv + pl.o_ZR));
   }
   // ---- bottleneck space --------------------------------------------------------------------------

@@ -16,7 +16,8 @@ size_t slab_floats(const Dims& d) {
   const size_t out3 = (size_t)d.g * d.E * d.dgp * d.Cg;               // dWt
   const size_t out4 = (size_t)d.N * d.Mk + (size_t)d.C * d.Cy;        // dWc, dWf
   const size_t out5 = (size_t)(d.KL ? d.KL : 1) * (d.Cy > d.C ? d.Cy : d.C);
-  size_t m = std::max(std::max(out1, out2), std::max(std::max(out3, out4), out5));
+  const size_t out6 = d.mha ? (size_t)3 * d.C * d.C : 0;              // d in_proj_weight
+  size_t m = std::max(std::max(std::max(out1, out2), std::max(std::max(out3, out4), out5)), out6);
   return m * 64 + 1024;
 }
 
@@ -63,11 +64,21 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.DZ = d.E * d.DD;
   if (d.DD > 256) { set_last_error("moe: padded bottleneck %d > 256", d.DD); return ERR_UNSUPPORTED; }
   d.El = 0;
+  const bool v1 = d.self_attn == AVMOE_SELF_ATTN_MHA_V1;
+  if (v1) {
+    d.H = 4; d.dh = d.C / d.H; d.Sp = (int)round_up(d.S, 8);           // PVT_AVSModel_v2.py:138
+    if (d.C % d.H || d.dh % 8) { set_last_error("moe: self attention v1 needs C / 4 heads to be a multiple of 8 (C=%d)", d.C); return ERR_UNSUPPORTED; }
+  }
   for (int e = 0; e < d.E; ++e) {
     const bool multimodal = e < d.E_m;
     d.relu_of_e[e] = multimodal;
-    d.nxn_of_e[e] = (!multimodal && (d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN)) ? 1 : 0;
-    if (d.nxn_of_e[e]) d.nxn = 1;
+    d.nxn_of_e[e] = (!multimodal && (d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN || v1)) ? 1 : 0;
+    d.xr_of_e[e] = -1;
+    if (d.nxn_of_e[e]) {
+      d.nxn = 1;
+      if (v1) { d.mha = 1; d.xr_of_e[e] = d.nxr++; }
+      else { d.xr_of_e[e] = 0; d.nxr = 1; }
+    }
     d.lat_of_e[e] = -1;
     if (multimodal || v2) {
       d.lat_of_e[e] = d.El;

@@ -46,6 +46,13 @@ struct Dims {
   int relu_of_e[MAX_E];
   int nxn_of_e[MAX_E];   // AVVP unimodal expert: input is X + gate_av * (softmax(X X^T)^T X)  (mgn.py:132-139)
   int nxn;               // any such expert
+  // The unimodal input x + gate * xr of those experts: AVVP shares one xr (slot 0); the AVS "v1" experts (input REPLACED by
+  // MultiheadAttention(x) across the frames, PVT_AVSModel_v2.py:210-214) run through the same code with
+  // xr = MHA_e(x) - x, gate 1 and one xr slot per expert.
+  int nxr;               // xr slots
+  int xr_of_e[MAX_E];    // slot of expert e or -1
+  int mha;               // "v1" experts present
+  int H, dh, Sp;         // heads, head width, frames padded to 8
   int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
   int xchunks;    // row chunks per frame of the fused X statistics pass
 };
@@ -97,14 +104,26 @@ struct Dims {
   X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
   /* ---- AVVP N x N block (only sized when present) ---- */                                     \
   X(att, 0, d.esz, d.nxn ? (size_t)d.S * d.N * d.Np : 1)        /* softmax_rows(X X^T)            */  \
-  X(xr, 0, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)               /* att^T X                        */  \
-  X(sxr, 0, 4, d.nxn ? (size_t)3 * d.NT : 1)                    /* sum xr, sum xr^2, x . xr       */  \
+  X(xr, 0, d.esz, d.nxn ? (size_t)d.nxr * d.NT * d.C : 1)       /* att^T X  |  MHA_e(X) - X per slot */  \
+  X(sxr, 0, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)            /* sum xr, sum xr^2, x . xr  per slot */  \
   X(ZR, 0, 4, d.nxn ? (size_t)d.NT * d.DZ : 1)                  /* xr through Wt                  */  \
   X(attS, 1, 4, d.nxn ? (size_t)d.S * d.N * d.Np : 1)           /* scores ; d att in the backward */  \
   X(dZR, 1, d.esz, d.nxn ? (size_t)d.NT * d.DZ : 1)                                                    \
-  X(dsr, 1, 4, d.nxn ? (size_t)3 * d.NT : 1)                                                           \
+  X(dsr, 1, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)                                                   \
   X(dxr, 1, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)                                                     \
   X(dSc, 1, d.esz, d.nxn ? (size_t)d.S * d.N * d.Np : 1)                                               \
+  /* ---- AVS "v1" MultiheadAttention across the frames, per slot (only sized when present) ---- */ \
+  X(mWin, 0, d.esz, d.mha ? (size_t)d.nxr * 3 * d.C * d.C : 1)      /* in_proj_weight in T              */  \
+  X(mWout, 0, d.esz, d.mha ? (size_t)d.nxr * d.C * d.C : 1)         /* out_proj.weight in T             */  \
+  X(mQKV, 0, d.esz, d.mha ? (size_t)d.nxr * d.NT * 3 * d.C : 1)     /* [s][n][q | k | v]                */  \
+  X(mP, 0, d.esz, d.mha ? (size_t)d.nxr * d.N * d.H * d.S * d.Sp : 1)   /* softmax  [n][h][s][s']         */  \
+  X(mPd, 0, d.esz, d.mha ? (size_t)d.nxr * d.N * d.H * d.S * d.Sp : 1)  /* after dropout                  */  \
+  X(mO, 0, d.esz, d.mha ? (size_t)d.nxr * d.NT * d.C : 1)           /* heads concatenated, before out_proj */ \
+  X(mSc, 1, 4, d.mha ? (size_t)d.N * d.H * d.S * d.Sp : 1)          /* scores ; d Pd in the backward    */  \
+  X(mdO, 1, d.esz, d.mha ? (size_t)d.NT * d.C : 1)                                                         \
+  X(mdS, 1, d.esz, d.mha ? (size_t)d.N * d.H * d.S * d.Sp : 1)                                             \
+  X(mdQKV, 1, d.esz, d.mha ? (size_t)d.NT * 3 * d.C : 1)                                                   \
+  X(mdW, 1, 4, d.mha ? (size_t)3 * d.C * d.C + 4 * d.C : 1)         /* sink for parameter gradients nobody asked for */ \
   /* ---- transient ---- */                                                                    \
   X(L1, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)    /* L1 ; dA1 in bwd */  \
   X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \
@@ -170,7 +189,7 @@ struct Plan {
 #undef X
   size_t saved_bytes, scratch_bytes;
   int nbuf;
-  BufInfo info[128];
+  BufInfo info[160];
 };
 
 // Validates the descriptor and fills the plan.  Returns 0 or a negative status.

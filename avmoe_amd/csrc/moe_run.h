@@ -9,6 +9,11 @@ namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap);
 
+// AVS "v1" unimodal expert: xr slot = MultiheadAttention_e(X) - X across the frames, and its backward (mha_frames.hip)
+int mha_frames_forward(const Plan& pl, const void* X, const avmoe_expert_ptrs& ep, int slot, char* saved, char* scratch, hipStream_t st);
+int mha_frames_backward(const Plan& pl, const void* X, const avmoe_expert_ptrs& ep, const avmoe_expert_ptrs& eg, int slot, const void* dxr,
+                        char* saved, char* scratch, float* slabs, size_t slab_cap, void* dX, hipStream_t st);
+
 int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const float* noise, void* out,
                 float* probs_out, int64_t* idx_out, float* lb_out, char* saved, char* scratch, hipStream_t st);
 

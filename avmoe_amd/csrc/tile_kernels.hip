@@ -242,7 +242,7 @@ __device__ __forceinline__ void slab_store_T(void* __restrict__ base_, long elem
 // =====================================================================================================
 // PRE_SMALL forward   (net_trans_v3.py:385-395)
 // =====================================================================================================
-struct PreTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; TileDims t; int ln_before; float ln_eps; const float* ZR; const float* sxr; };
+struct PreTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; long sxr_off[MAX_E]; TileDims t; int ln_before; float ln_eps; const float* ZR; const float* sxr; };
 
 template <typename T>
 __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restrict__ Z, const float* __restrict__ L2, const float* __restrict__ sxs, const float* __restrict__ TT,
@@ -297,8 +297,9 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
         Sxx[x] = n < t.N ? sxs[t.NT + t0 + 4 * q + x] : 1.f;
         if (nxn && n < t.N) {        // x' = x + g xr : sums of x' from the sums of x, xr and x . xr   (mgn.py:132-139)
           const long ti = t0 + 4 * q + x;
-          Sx[x] += gv * a.sxr[ti];
-          Sxx[x] += 2.f * gv * a.sxr[2L * t.NT + ti] + gv * gv * a.sxr[(long)t.NT + ti];
+          const float* sxr = a.sxr + a.sxr_off[e];              // this expert's xr slot
+          Sx[x] += gv * sxr[ti];
+          Sxx[x] += 2.f * gv * sxr[2L * t.NT + ti] + gv * gv * sxr[(long)t.NT + ti];
         }
       }
       if (l >= 0) {
@@ -405,7 +406,10 @@ int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e]; }
+  for (int e = 0; e < MAX_E; ++e) {
+    a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e];
+    a.sxr_off[e] = (e < d.E && d.xr_of_e[e] > 0) ? (long)d.xr_of_e[e] * 3 * d.NT : 0;
+  }
   a.t = make_td(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   for (int e = 0; e < d.E; ++e)
@@ -801,7 +805,7 @@ __global__ void __launch_bounds__(256) kt_mid_bwd(MidBTArgs a, const float* __re
 // =====================================================================================================
 // PRE_SMALL backward
 // =====================================================================================================
-struct PreBTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; TileDims t; int ln_before, use_bn, bn_train, dd4, first_nxn;
+struct PreBTArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int first_of_slot[MAX_E]; long sxr_off[MAX_E]; TileDims t; int ln_before, use_bn, bn_train, dd4;
                    const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
 template <typename T>
@@ -938,9 +942,11 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
           if (r == 0 && ok[x]) {
             const long ti = t0 + 4 * q + x;
             const float v0 = gv * dSx[x], v1 = 2.f * gv * gv * dSxx[x], v2 = 2.f * gv * dSxx[x];
-            if (e == a.first_nxn) { a.dsr[ti] = v0; a.dsr[(long)t.NT + ti] = v1; a.dsr[2L * t.NT + ti] = v2; }
-            else { a.dsr[ti] += v0; a.dsr[(long)t.NT + ti] += v1; a.dsr[2L * t.NT + ti] += v2; }
-            sdg += dSx[x] * a.sxr[ti] + dSxx[x] * (2.f * a.sxr[2L * t.NT + ti] + 2.f * gv * a.sxr[(long)t.NT + ti]) + zr;
+            float* dsr = a.dsr + a.sxr_off[e];                  // this expert's xr slot (shared by the AVVP experts)
+            const float* sxr = a.sxr + a.sxr_off[e];
+            if (a.first_of_slot[e]) { dsr[ti] = v0; dsr[(long)t.NT + ti] = v1; dsr[2L * t.NT + ti] = v2; }
+            else { dsr[ti] += v0; dsr[(long)t.NT + ti] += v1; dsr[2L * t.NT + ti] += v2; }
+            sdg += dSx[x] * sxr[ti] + dSxx[x] * (2.f * sxr[2L * t.NT + ti] + 2.f * gv * sxr[(long)t.NT + ti]) + zr;
           }
         }
       }
@@ -1115,10 +1121,17 @@ int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   }
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreBTArgs a;
-  a.first_nxn = -1;
-  for (int e = 0; e < MAX_E; ++e) {
-    a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e];
-    if (e < d.E && d.nxn_of_e[e] && a.first_nxn < 0) a.first_nxn = e;
+  {
+    bool seen[MAX_E] = {};
+    for (int e = 0; e < MAX_E; ++e) {
+      a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = d.nxn_of_e[e];
+      a.first_of_slot[e] = 0; a.sxr_off[e] = 0;
+      if (e < d.E && d.nxn_of_e[e]) {
+        const int slot = d.xr_of_e[e];
+        a.sxr_off[e] = (long)slot * 3 * d.NT;
+        a.first_of_slot[e] = !seen[slot]; seen[slot] = true;
+      }
+    }
   }
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.dZR = (void*)(scratch + pl.o_dZR); a.dsr = (float*)(scratch + pl.o_dsr);

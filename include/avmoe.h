@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 2
+#define AVMOE_ABI_VERSION 3
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -63,7 +63,8 @@ int avmoe_gemm(const avmoe_gemm_desc* desc, const void* A, const void* B, void* 
  * Parameters / buffers / their gradients are fp32, one pointer per reference state_dict entry.      */
 #define AVMOE_MAX_EXPERTS 16
 enum { AVMOE_VARIANT_AVE = 0, AVMOE_VARIANT_AVVP = 1, AVMOE_VARIANT_AVS = 2 };   /* AVQA == AVE math */
-enum { AVMOE_SELF_ATTN_NONE = 0, AVMOE_SELF_ATTN_LATENT_V2 = 1, AVMOE_SELF_ATTN_NXN = 2 };
+enum { AVMOE_SELF_ATTN_NONE = 0, AVMOE_SELF_ATTN_LATENT_V2 = 1, AVMOE_SELF_ATTN_NXN = 2,
+       AVMOE_SELF_ATTN_MHA_V1 = 3 };   /* AVS self_attention_version "v1": nn.MultiheadAttention(C, 4) across the FRAMES (ABI 3) */
 
 typedef struct avmoe_moe_desc {
   int32_t S, N, C;          /* this modality: frames, tokens, channels  (C = input_dim = linear_out) */
@@ -87,6 +88,11 @@ typedef struct avmoe_expert_ptrs {        /* <list>.{j}.*  ; unused entries NULL
   float *bn1_w, *bn1_b, *bn2_w, *bn2_b;
   float *lnb_w, *lnb_b, *lnp_w, *lnp_b;   /* ln_before.* ; ln_post.*                                  */
   float *bn1_rm, *bn1_rv, *bn2_rm, *bn2_rv; /* running_mean / running_var (updated in place in training) */
+  /* ABI 3 -- AVS unimodal expert with self_attention_version "v1" (PVT_AVSModel_v2.py:141-142,210-214):
+   * self_attention.{in_proj_weight (3C, C), in_proj_bias (3C), out_proj.weight (C, C), out_proj.bias (C)} and, in `params`
+   * only, sa_keep: the dropout multiplier of the attention weights, (N * 4, S, S) f32 holding 0 or 1 / (1 - p), or NULL for
+   * no dropout (eval).  The caller draws it (the reference uses the global RNG) and keeps it alive until the backward.  */
+  float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b, *sa_keep;
 } avmoe_expert_ptrs;
 
 typedef struct avmoe_moe_ptrs {

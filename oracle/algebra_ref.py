@@ -24,6 +24,7 @@ Facts used (all exact in real arithmetic):
 """
 from __future__ import annotations
 
+import math
 import torch
 import torch.nn.functional as F
 
@@ -47,6 +48,7 @@ class _Expert:
         self.multimodal = j < cfg.E_m
         self.relu = self.multimodal                       # net_trans_v3.py:400 vs :416-422
         self.nxn = (not self.multimodal) and cfg.variant == "avvp"
+        self.mha = (not self.multimodal) and cfg.self_attn == "v1"     # input replaced by MultiheadAttention across the frames
         if self.multimodal:
             self.latent, self.gname = "y", "gate_av"
         elif cfg.self_attn == "v2":
@@ -61,7 +63,7 @@ class AlgebraRef:
         self.experts = [_Expert(cfg, j) for j in range(cfg.E)]
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, X, Y, training=True, noise=None):
+    def forward(self, X, Y, training=True, noise=None, mha_keep=None):
         cfg, P, B = self.cfg, self.P, self.B
         C, N, Cy, M, g, d, K = cfg.Cx, cfg.Nx, cfg.Cy, cfg.Ny, cfg.groups, cfg.d, cfg.K
         dg, Cg = d // g, C // g
@@ -103,6 +105,22 @@ class AlgebraRef:
                 xr = att.transpose(1, 2) @ X
                 Xe = X + P[f"{pre}.gate_av"] * xr
                 e.update(att=att, xr=xr)
+            # ---- AVS "v1" (PVT_AVSModel_v2.py:210-214): xr = MHA(X) - X over the FRAMES, then as above with gate 1
+            #      (csrc/mha_frames.hip: the same products, per (token, head) on strided views) ----
+            if ex.mha:
+                H = cfg.mha_heads
+                dh = C // H
+                Win, bin_ = P[f"{pre}.self_attention.in_proj_weight"], P[f"{pre}.self_attention.in_proj_bias"]
+                Wout, bout = P[f"{pre}.self_attention.out_proj.weight"], P[f"{pre}.self_attention.out_proj.bias"]
+                qkv = (X @ Win.t() + bin_).reshape(S, N, 3, H, dh)                 # [s][n][q|k|v][h][j]
+                q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (S, N, H, dh)
+                Pm = F.softmax(torch.einsum("snhj,tnhj->nhst", q, k) / math.sqrt(dh), -1)      # (N, H, S, S')
+                keep = None if (mha_keep is None or not training) else mha_keep[pre].reshape(N, H, S, S).to(Pm.dtype)
+                Pd = Pm if keep is None else Pm * keep
+                Oh = torch.einsum("nhst,tnhj->snhj", Pd, v).reshape(S, N, C)
+                xr = Oh @ Wout.t() + bout - X
+                Xe = X + xr
+                e.update(mha=dict(q=q, k=k, v=v, P=Pm, Pd=Pd, keep=keep, O=Oh, Win=Win, Wout=Wout), xr=xr)
             e["Xe"] = Xe
             # ---- hop 1: latent tokens summarise the (never materialised) remapped other modality ----
             if ex.latent == "y":
@@ -401,6 +419,25 @@ class AlgebraRef:
                 dX = dX + dXe + att @ dxr
                 dSc = _softmax_bwd(att, datt)
                 dX = dX + dSc @ X + dSc.transpose(1, 2) @ X
+            elif ex.mha:               # xr = MHA(X) - X replaced the input: X only acts through MHA (the direct route cancels)
+                m = e["mha"]
+                H = cfg.mha_heads
+                dh = C // H
+                S_, N_ = X.shape[0], X.shape[1]
+                dxr = dXe
+                G_[f"{pre}.self_attention.out_proj.bias"] += dxr.sum((0, 1))
+                G_[f"{pre}.self_attention.out_proj.weight"] += torch.einsum("sno,sni->oi", dxr, m["O"])
+                dO = (dxr @ m["Wout"]).reshape(S_, N_, H, dh)
+                dPd = torch.einsum("snhj,tnhj->nhst", dO, m["v"])
+                dv = torch.einsum("nhst,snhj->tnhj", m["Pd"], dO)
+                dP = dPd if m["keep"] is None else dPd * m["keep"]
+                dS = _softmax_bwd(m["P"], dP) / math.sqrt(dh)
+                dq = torch.einsum("nhst,tnhj->snhj", dS, m["k"])
+                dk = torch.einsum("nhst,snhj->tnhj", dS, m["q"])
+                dqkv = torch.stack([dq, dk, dv], dim=2).reshape(S_, N_, 3 * C)
+                G_[f"{pre}.self_attention.in_proj_bias"] += dqkv.sum((0, 1))
+                G_[f"{pre}.self_attention.in_proj_weight"] += torch.einsum("snj,snc->jc", dqkv, X)
+                dX = dX + dqkv @ m["Win"]
             else:
                 dX = dX + dXe
             # ---- phase 6: hop-1 backward ----

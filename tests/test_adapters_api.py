@@ -11,7 +11,8 @@ from tests.golden_util import load_golden, split_params
 
 def _opt(cfg):
     return NS(num_conv_group=cfg.groups, is_before_layernorm=int(cfg.ln_before), is_post_layernorm=int(cfg.ln_post),
-              is_self_attention=int(cfg.self_attn == "v2"), self_attention_version="v2",
+              is_self_attention=int(cfg.self_attn in ("v1", "v2")),
+              self_attention_version=cfg.self_attn if cfg.self_attn in ("v1", "v2") else "v2",
               num_multimodal_experts=cfg.E_m, num_singlemodal_experts=cfg.E_s,
               use_load_balacing_loss=int(cfg.lb_loss), Adapter_downsample=cfg.reduction, is_bn=int(cfg.use_bn),
               is_gate=int(cfg.use_gate), num_tokens=cfg.K)
@@ -33,7 +34,8 @@ def build_module(which, cfg):
 
 
 @pytest.mark.parametrize("name", ["ave_train", "ave_nobn", "ave_noln_nogate", "avqa_train", "avvp_train",
-                                  "avs_train_noise", "avs_v2_train", "avs_ms3_eval", "avs_k87_train"])
+                                  "avs_train_noise", "avs_v2_train", "avs_ms3_eval", "avs_k87_train", "avs_v1_train",
+                                  "avs_v1_eval"])
 def test_state_dict_matches_reference_checkpoint_layout(name):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
@@ -66,9 +68,9 @@ def test_no_cpu_fallback_and_unbuilt_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         adapters.ExpertAdapter(96, 96, "basic", opt=_opt(cfg))
     o = _opt(cfg)
-    o.is_self_attention, o.self_attention_version = 1, "v1"
-    with pytest.raises(NotImplementedError):
-        adapters.ExpertAdapter(96, 96, "bottleneck", 8, o, is_multimodal=False, variant="avs")
+    o.is_self_attention, o.self_attention_version = 1, "v1"       # AVS default version: nn.MultiheadAttention parameters
+    e = adapters.ExpertAdapter(96, 96, "bottleneck", 8, o, is_multimodal=False, variant="avs")
+    assert e.self_attention.in_proj_weight.shape == (288, 96) and e.self_attention.out_proj.weight.shape == (96, 96)
 
 
 def test_library_exports_every_declared_symbol():
@@ -76,7 +78,7 @@ def test_library_exports_every_declared_symbol():
     L = _capi.lib()
     for sym in _capi.exported_symbols():
         assert hasattr(L, sym), sym
-    assert L.avmoe_abi_version() == 2
+    assert L.avmoe_abi_version() == 3
 
 
 def test_descriptor_validation_without_a_gpu():

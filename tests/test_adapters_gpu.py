@@ -4,13 +4,14 @@ import pytest
 import torch
 
 from oracle import avmoe_oracle as O
-from tests.golden_util import load_golden, split_params, assert_grads_close
+from tests.golden_util import load_golden, split_params, assert_grads_close, mha_keep_of
 from tests.test_adapters_api import build_module
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["ave_train", "ave_eval", "avqa_train", "avvp_train", "avs_train_nonoise", "avs_v2_train", "ave_noln_nogate"])
+@pytest.mark.parametrize("name", ["ave_train", "ave_eval", "avqa_train", "avvp_train", "avs_train_nonoise", "avs_v2_train", "ave_noln_nogate",
+                                  "avs_v1_train", "avs_v1_eval"])
 def test_module_forward_backward_matches_reference_vectors(name):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
@@ -18,6 +19,9 @@ def test_module_forward_backward_matches_reference_vectors(name):
     m = build_module(meta["which"], cfg).to(dev)
     m.load_state_dict({**P, **B}, strict=True)
     m.train(bool(meta["module_train"]))
+    if mha_keep_of(t) is not None:          # "v1": replay the dropout draw recorded from the reference's MultiheadAttention
+        from avmoe_amd._capi_moe import SA_KEEP
+        m.attention_keep = {f"{pre}.{SA_KEEP}": v for pre, v in mha_keep_of(t).items()}
     X = t["X"].to(dev).requires_grad_(True)
     Y = t["Y"].to(dev).requires_grad_(True)
     xin, yin = X.permute(0, 2, 1).unsqueeze(-1), Y.permute(0, 2, 1).unsqueeze(-1)

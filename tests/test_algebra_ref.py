@@ -6,7 +6,7 @@ import torch
 
 from oracle import avmoe_oracle as O
 from oracle.algebra_ref import AlgebraRef
-from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close
+from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close, mha_keep_of
 
 NAMES = golden_names()
 
@@ -18,9 +18,9 @@ def test_factorisation_equals_direct_restatement_fp64(name):
     training = bool(meta["module_train"])
     noise = t.get("noise")
     fwd, grads = O.moe_forward_backward(P, B, t["X"], t["Y"], cfg, t["grad_out"], training=training,
-                                        noise=noise, lb_weight=meta["lb_weight"])
+                                        noise=noise, lb_weight=meta["lb_weight"], mha_keep=mha_keep_of(t))
     A = AlgebraRef(cfg, P, B)
-    r = A.forward(t["X"], t["Y"], training=training, noise=noise)
+    r = A.forward(t["X"], t["Y"], training=training, noise=noise, mha_keep=mha_keep_of(t))
     assert torch.equal(r["idx"], fwd["idx"])
     assert float((r["out"] - fwd["out"]).abs().max()) < 1e-10 * max(1.0, float(fwd["out"].abs().max()))
     assert float((r["probs"] - fwd["probs"]).abs().max()) < 1e-12
