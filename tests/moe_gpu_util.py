@@ -23,7 +23,7 @@ def make_desc(cfg, S, bf16, training):
 class MoeRun:
     """One forward (+ optional backward) of the HIP path on cuda:0."""
 
-    def __init__(self, cfg, P, B, X, Y, bf16=False, training=True, noise=None):
+    def __init__(self, cfg, P, B, X, Y, bf16=False, training=True, noise=None, mha_keep=None):
         self.L = capi.lib()
         self.cfg, self.bf16, self.training = cfg, bf16, training
         dev = torch.device("cuda:0")
@@ -50,7 +50,9 @@ class MoeRun:
         self.probs = torch.empty(S, cfg.E, device=dev, dtype=torch.float32)
         self.idx = torch.empty(S, device=dev, dtype=torch.int64)
         self.lb = torch.zeros(1, device=dev, dtype=torch.float32)
-        self.ptrs = cm.make_ptrs({**self.params, **self.buffers}, cfg.E_m, cfg.E_s)
+        # "v1" experts: dropout multipliers of the attention weights, {expert prefix: (N * heads, S, S)} (include/avmoe.h sa_keep)
+        self.keep = {f"{pre}.{cm.SA_KEEP}": v.detach().to(dev, torch.float32).contiguous() for pre, v in (mha_keep or {}).items()}
+        self.ptrs = cm.make_ptrs({**self.params, **self.buffers, **self.keep}, cfg.E_m, cfg.E_s)
 
     def forward(self):
         st = self.L.avmoe_moe_forward(C.byref(self.desc), self.X.data_ptr(), self.Y.data_ptr(), C.byref(self.ptrs),

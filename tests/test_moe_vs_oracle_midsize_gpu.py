@@ -34,9 +34,22 @@ CASES = {
     # cfg-5 (AVS: 4 + 4 experts, bottleneck 128, latent self attention v2, 5 frames; PVT-v2-b5 stage 3 x HTS-AT)
     "cfg5_avs_stage3_visual_side": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
     "cfg5_avs_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=320, Ny=196, reduction=3, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
+    # AVS self_attention_version "v1" (the S4 training script's default): MultiheadAttention across the frames, PVT-v2 stage shapes
+    # (C 64 / 320, N 3136 / 196), 5 frames x 2 clips, 1 + 1 experts as in train_v2.sh and 2 + 2
+    "avs_v1_stage0": dict(cfg=dict(Cx=64, Nx=3136, Cy=96, Ny=1024, reduction=8, groups=2, K=32, variant="avs", self_attn="v1", E_m=1, E_s=1, lb_loss=True), S=10, keep=True),
+    "avs_v1_stage2": dict(cfg=dict(Cx=320, Nx=196, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="avs", self_attn="v1", lb_loss=True), S=10, keep=True),
+    "avs_v1_eval": dict(cfg=dict(Cx=128, Nx=77, Cy=96, Ny=50, reduction=4, groups=2, K=8, variant="avs", self_attn="v1", E_m=1, E_s=2), S=7, training=False),
+    "ave_selfattn": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", self_attn="v1"), S=6, keep=True),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
 }
+
+
+def _draw_keep(cfg, S, gen):
+    """A dropout draw for the "v1" experts' attention weights: {expert prefix: (N * heads, S, S) of 0 | 1 / (1 - p)}."""
+    p = cfg.mha_dropout
+    return {pre: (torch.rand(cfg.Nx * cfg.mha_heads, S, S, generator=gen) >= p).float() / (1.0 - p)
+            for pre in cfg.expert_prefixes()[cfg.E_m:]}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -51,8 +64,9 @@ def test_midsize_matches_oracle_fp32(name):
     Y = 0.3 * torch.randn(S, cfg.Ny, cfg.Cy, generator=g)
     G = torch.randn(S, cfg.Nx, cfg.Cx, generator=g)
     lbw = 0.01 if cfg.lb_loss else 0.0
-    fwd, grads = O.moe_forward_backward(P, B, X, Y, cfg, G, training=training, lb_weight=lbw)
-    run = MoeRun(cfg, P, B, X, Y, bf16=False, training=training).forward()
+    keep = _draw_keep(cfg, S, g) if case.get("keep") else None
+    fwd, grads = O.moe_forward_backward(P, B, X, Y, cfg, G, training=training, lb_weight=lbw, mha_keep=keep)
+    run = MoeRun(cfg, P, B, X, Y, bf16=False, training=training, mha_keep=keep).forward()
     out = run.out.float().cpu()
     assert torch.equal(run.idx.cpu(), fwd["idx"])
     assert float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()) < 1e-3
@@ -64,7 +78,7 @@ def test_midsize_matches_oracle_fp32(name):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1"])
+@pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2"])
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path on the register-resident shape (bf16 Z / dz' storage, streaming GEMMs, streaming Gram)
     against the fp32 oracle: outputs within 4e-2, gradients norm-wise 6 % (token tensors) / 12 % (parameters; analytically
@@ -81,8 +95,9 @@ def test_midsize_bf16_close_to_oracle(name):
     G = torch.randn(S, cfg.Nx, cfg.Cx, generator=g)
     lbw = 0.01 if cfg.lb_loss else 0.0
     Xb, Yb, Gb = X.bfloat16().float(), Y.bfloat16().float(), G.bfloat16().float()          # the oracle sees the rounded inputs
-    fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw)
-    run = MoeRun(cfg, P, B, X, Y, bf16=True, training=True).forward()
+    keep = _draw_keep(cfg, S, g) if case.get("keep") else None
+    fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw, mha_keep=keep)
+    run = MoeRun(cfg, P, B, X, Y, bf16=True, training=True, mha_keep=keep).forward()
     assert torch.equal(run.idx.cpu(), fwd["idx"])
     out = run.out.float().cpu()
     assert float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()) < 4e-2
