@@ -32,7 +32,7 @@ def _digest():
     files.append(os.path.join(os.path.dirname(HERE), "include", "avmoe.h"))
     for p in files:
         if os.path.isfile(p):
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())      # not the absolute path: the GPU box has the repo elsewhere
             with open(p, "rb") as fh:
                 h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -85,7 +85,7 @@ def test_loop_equals_site_by_site(dtype):
 
     ref, got = run(False), run(True)
     assert got[2] == ref[2] and len(got[2]["audio"]["p1"]) == 4 and len(got[2]["video"]["p2"]) == 4
-    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
     gscale = max(float(a.float().abs().max()) for a in ref[5])      # gradients that are analytically zero (a bias in front of a
     def close(a, b, what, floor=0.0):                                # BatchNorm) are rounding noise: judge them on the global scale
         scale = max(float(a.float().abs().max()), floor) + 1e-12

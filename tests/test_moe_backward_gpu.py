@@ -3,7 +3,7 @@ parameter against the vectors captured from the reference (fp32, 1e-3) and at bf
 import pytest
 import torch
 
-from tests.golden_util import golden_names, load_golden, split_params, grad_errors
+from tests.golden_util import golden_names, load_golden, split_params, grad_errors, mha_keep_of
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ def test_backward_fp32_matches_reference_vectors(name, capsys):
     from tests.moe_gpu_util import MoeRun
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
-    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=bool(meta["module_train"]), noise=t.get("noise")).forward()
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=bool(meta["module_train"]), noise=t.get("noise"), mha_keep=mha_keep_of(t)).forward()
     g = run.backward(t["grad_out"], lb_weight=meta["lb_weight"])
     errs = grad_errors(g, t)
     bad = _report(errs, 1e-3)
@@ -43,7 +43,7 @@ def test_backward_bf16_close_to_reference_vectors(name):
     from tests.moe_gpu_util import MoeRun
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
-    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=True, training=bool(meta["module_train"]), noise=t.get("noise")).forward()
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=True, training=bool(meta["module_train"]), noise=t.get("noise"), mha_keep=mha_keep_of(t)).forward()
     g = run.backward(t["grad_out"], lb_weight=meta["lb_weight"])
     refn = {k: float(t[f"grad.{k}"].norm()) for k in g}
     gmax = max(v for k, v in refn.items() if k not in ("X", "Y"))

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle.algebra_ref import AlgebraRef
-from tests.golden_util import golden_names, load_golden, split_params
+from tests.golden_util import golden_names, load_golden, split_params, mha_keep_of
 
 pytestmark = pytest.mark.gpu
 
@@ -17,13 +17,13 @@ def test_forward_fp32_matches_reference_vectors(name, capsys):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
     training = bool(meta["module_train"])
-    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=training, noise=t.get("noise")).forward()
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=training, noise=t.get("noise"), mha_keep=mha_keep_of(t)).forward()
     out = run.out.float().cpu()
     err = float((out - t["out"]).abs().max() / t["out"].abs().max())
     ok = err < 1e-3 and torch.equal(run.idx.cpu(), t["idx"])
     if not ok:
         A = AlgebraRef(cfg, P, B)
-        A.forward(t["X"], t["Y"], training=training, noise=t.get("noise"))
+        A.forward(t["X"], t["Y"], training=training, noise=t.get("noise"), mha_keep=mha_keep_of(t))
         with capsys.disabled():
             print(f"\n[{name}] out rel err {err:.3e}")
             compare_forward_intermediates(run, A)
@@ -43,7 +43,7 @@ def test_forward_bf16_close_to_reference_vectors(name):
     from tests.moe_gpu_util import MoeRun
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
-    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=True, training=bool(meta["module_train"]), noise=t.get("noise")).forward()
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=True, training=bool(meta["module_train"]), noise=t.get("noise"), mha_keep=mha_keep_of(t)).forward()
     out = run.out.float().cpu()
     err = float((out - t["out"]).abs().max() / t["out"].abs().max())
     assert err < 4e-2, err
@@ -60,7 +60,7 @@ def test_router_subop_matches_reference_vectors(name):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
     noise = t.get("noise")
-    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=bool(meta["module_train"]), noise=noise).forward()
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=bool(meta["module_train"]), noise=noise, mha_keep=mha_keep_of(t)).forward()
     rin = run.buf("rin").to(run.dev).contiguous()                    # (S, 2C): [mean_n x | mean_n remap(y)]
     probs = torch.empty_like(run.probs)
     idx = torch.empty_like(run.idx)
