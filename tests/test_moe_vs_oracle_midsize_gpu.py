@@ -40,6 +40,13 @@ CASES = {
     "avs_v1_stage2": dict(cfg=dict(Cx=320, Nx=196, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="avs", self_attn="v1", lb_loss=True), S=10, keep=True),
     "avs_v1_eval": dict(cfg=dict(Cx=128, Nx=77, Cy=96, Ny=50, reduction=4, groups=2, K=8, variant="avs", self_attn="v1", E_m=1, E_s=2), S=7, training=False),
     "ave_selfattn": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", self_attn="v1"), S=6, keep=True),
+    # edges: no cross-modal expert at all, a single frame (BatchNorm over one frame's tokens), fewer tokens than one tile, one
+    # expert in total (router softmax over one logit), eval on the register-resident shape
+    "only_unimodal": dict(cfg=dict(Cx=96, Nx=70, Cy=64, Ny=30, reduction=4, groups=2, K=8, variant="ave", E_m=0, E_s=2), S=3),
+    "single_frame": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave"), S=1),
+    "tiny_tokens": dict(cfg=dict(Cx=64, Nx=3, Cy=32, Ny=2, reduction=4, groups=2, K=4, variant="ave"), S=5),
+    "one_expert": dict(cfg=dict(Cx=64, Nx=40, Cy=32, Ny=20, reduction=4, groups=2, K=4, variant="avs", E_m=1, E_s=0, lb_loss=True), S=4),
+    "fast_eval": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave"), S=4, training=False),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
 }
