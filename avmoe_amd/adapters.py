@@ -39,8 +39,10 @@ def _scratch(dev: torch.device, nbytes: int) -> torch.Tensor:
     return buf
 
 
-def _site_forward(module, X, Y, noise, names, params):
-    """One avmoe_moe_forward call.  Returns (out, probs, idx, lb, state) with state = what the backward needs."""
+def _site_forward(module, X, Y, noise, names, params, add_to=None):
+    """One avmoe_moe_forward call.  Returns (out, probs, idx, lb, state) with state = what the backward needs.
+    add_to: a contiguous tensor like X that receives `+= adapter(X, Y)` in place (avmoe_moe_desc.accumulate_out) and is
+    returned as `out`."""
     if not (X.is_cuda and Y.is_cuda):
         raise capi.AvmoeError("avmoe_amd runs on MI355X only: tensors must live on a GPU (no CPU fallback)")
     if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
@@ -62,7 +64,12 @@ def _site_forward(module, X, Y, noise, names, params):
         raise capi.AvmoeError(L.avmoe_last_error().decode())
     saved = torch.empty(nsaved, dtype=torch.uint8, device=X.device)
     scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
-    out = torch.empty_like(X)
+    if add_to is not None:
+        if add_to.shape != X.shape or add_to.dtype != X.dtype or not add_to.is_contiguous() or add_to.device != X.device:
+            raise capi.AvmoeError("add_to must be a contiguous tensor with the shape, dtype and device of the tokens")
+        out, desc.accumulate_out = add_to, 1
+    else:
+        out = torch.empty_like(X)
     E = module.num_multimodal_experts + module.num_singlemodal_experts
     probs = torch.empty(S, E, device=X.device, dtype=torch.float32)
     idx = torch.empty(S, device=X.device, dtype=torch.int64)
@@ -73,6 +80,7 @@ def _site_forward(module, X, Y, noise, names, params):
                              noise.data_ptr() if noise is not None else None, out.data_ptr(), probs.data_ptr(),
                              idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
                              torch.cuda.current_stream(X.device).cuda_stream)
+    desc.accumulate_out = 0
     capi.check(st, "avmoe_moe_forward")
     return out, probs, idx, lb, ((desc, keep), saved, X, Y)
 
@@ -146,7 +154,8 @@ class _PairFunction(torch.autograd.Function):
     accumulation pass over the token gradients runs."""
 
     @staticmethod
-    def forward(ctx, site_a, site_b, side, Xa, Xb, names_a, names_b, *params):
+    def forward(ctx, site_a, site_b, side, Xa, Xb, base_a, base_b, names_a, names_b, *params):
+        """base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs)."""
         na = len(names_a)
         pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
@@ -154,17 +163,21 @@ class _PairFunction(torch.autograd.Function):
         if side is not None:                           # site B on the side stream, concurrently with site A
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb)
-            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa)
+                out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb, add_to=base_b)
+            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
             main.wait_stream(side)
             for t_ in (out_b, idx_b, st_b[1]):
                 t_.record_stream(main)
         else:
-            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa)
-            out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, st_a[3], st_a[2], None, names_b, pb)
+            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
+            out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, st_a[3], st_a[2], None, names_b, pb, add_to=base_b)
+        dirty = [t for t in (base_a, base_b) if t is not None]
+        if dirty:
+            ctx.mark_dirty(*dirty)
+        ctx.has_base = (base_a is not None, base_b is not None)
         ctx.side = side
         ctx.sites, ctx.names, ctx.states = (site_a, site_b), (names_a, names_b), (st_a[:2], st_b[:2])
-        for site, needs in ((site_a, ctx.needs_input_grad[7:7 + na]), (site_b, ctx.needs_input_grad[7 + na:])):
+        for site, needs in ((site_a, ctx.needs_input_grad[9:9 + na]), (site_b, ctx.needs_input_grad[9 + na:])):
             sink = getattr(site, "_grad_sink", None)
             if sink is not None and any(needs):
                 sink.calls += 1
@@ -178,7 +191,9 @@ class _PairFunction(torch.autograd.Function):
         (site_a, site_b), (names_a, names_b) = ctx.sites, ctx.names
         na = len(names_a)
         gXa, gXb = torch.empty_like(Xa), torch.empty_like(Xb)
-        needs_a, needs_b = ctx.needs_input_grad[7:7 + na], ctx.needs_input_grad[7 + na:]
+        needs_a, needs_b = ctx.needs_input_grad[9:9 + na], ctx.needs_input_grad[9 + na:]
+        gba = d_a if ctx.has_base[0] else None            # out = base + adapter(...): the residual stream passes the gradient on
+        gbb = d_b if ctx.has_base[1] else None
         if ctx.side is not None:
             # the two backward passes run concurrently (own streams, own workspaces); each token tensor then gets its two
             # gradients from separate buffers and one add
@@ -192,7 +207,7 @@ class _PairFunction(torch.autograd.Function):
             for t_ in (gXa2, gXb2) + tuple(g_ for g_ in pgb if g_ is not None):
                 t_.record_stream(main)
             gXa.add_(gXa2); gXb.add_(gXb2)
-            return (None, None, None, gXa, gXb, None, None) + pga + pgb
+            return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
         # both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The larger
         # tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
         # larger tensor runs second
@@ -207,7 +222,7 @@ class _PairFunction(torch.autograd.Function):
             pgb = run_b(False); pga = run_a(True)
         else:
             pga = run_a(False); pgb = run_b(True)
-        return (None, None, None, gXa, gXb, None, None) + pga + pgb
+        return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
 
 
 class ExpertAdapter(nn.Module):
@@ -438,14 +453,19 @@ class AdapterPair(nn.Module):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
         self.site_a, self.site_b = site_a, site_b
 
-    def forward(self, x_a, x_b):
+    def forward(self, x_a, x_b, add_to=(None, None)):
+        """add_to = (base_a, base_b): token-major (S, N, C) residual streams (or None) that receive `+= adapter output` IN PLACE
+        inside the output GEMM and are returned (in the (S, C, N, 1) view) instead of the bare adapter outputs -- the
+        `f = f + f_res` of net_trans_v3.py:709,712 without a separate pass.  Only hand in tensors nobody else needs at their
+        old value (e.g. the fresh result of `x + attention(x)`)."""
         Xa = x_a.squeeze(-1).permute(0, 2, 1)
         Xb = x_b.squeeze(-1).permute(0, 2, 1)
         Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
         if self.concurrent and self._side is None:
             self._side = torch.cuda.Stream(device=x_a.device)
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, self._side if self.concurrent else None, Xa, Xb,
-                                                         tuple(Pa.keys()), tuple(Pb.keys()), *Pa.values(), *Pb.values())
+                                                         add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
+                                                         *Pa.values(), *Pb.values())
         with torch.no_grad():
             for m in (self.site_a, self.site_b):
                 if m.training and m.use_bn:

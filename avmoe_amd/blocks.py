@@ -11,7 +11,8 @@ Reference: AVE/nets/net_trans_v3.py:669-730 (`MMIL_Net.forward_vit`; AVQA twin n
 
 calls `idx.squeeze().tolist()` after every site (a host sync each) and appends the lists to `adapter_index_dict`.
 
-Here the two sites of a position run as ONE `AdapterPair` node (two HIP streams, second-use gradients folded), the expert
+Here the two sites of a position run as ONE `AdapterPair` node (two HIP streams, second-use gradients folded), the adapter
+residuals are added to the residual streams inside the adapters' output GEMMs where that is safe (`fuse_residual`), the expert
 indices stay on the device until `AdapterIndexRecord.to_dict()` is called (one sync per forward instead of 4 per block),
 and everything else -- which blocks get adapters, `num_skip`, the 18-vs-6 block alignment of stage 3, downsampling -- follows
 the reference.  The backbone blocks themselves are out of scope: any object with the timm Swin-V2
@@ -92,8 +93,9 @@ class DualBackboneLoop(nn.Module):
 
     def __init__(self, audio_p1: Optional[Sequence[nn.Module]], vis_p1: Optional[Sequence[nn.Module]],
                  audio_p2: Optional[Sequence[nn.Module]], vis_p2: Optional[Sequence[nn.Module]], num_skip: int = 1,
-                 concurrent: bool = True):
+                 concurrent: bool = True, fuse_residual: bool = True):
         super().__init__()
+        self.fuse_residual = bool(fuse_residual)
         if (audio_p1 is None) != (vis_p1 is None) or (audio_p2 is None) != (vis_p2 is None):
             raise ValueError("a position has adapters for both modalities or for neither")
         self.num_skip, self.concurrent = int(num_skip), bool(concurrent)
@@ -113,11 +115,28 @@ class DualBackboneLoop(nn.Module):
                 pairs.append(_SequentialPair(a, v))
         return pairs          # a plain list: the sites stay registered in the model only (no duplicate state_dict keys)
 
-    def _adapt(self, pairs, i, f_a, f_v, record, pos):
-        res_a, idx_a, res_v, idx_v = pairs[i](_to_site(f_a), _to_site(f_v))
+    def _adapt(self, pairs, i, f_a, f_v, record, pos, base_a=None, base_v=None):
+        """Runs the two sites of one position on (f_a, f_v).  base_*: the residual streams AFTER the backbone half-block; where
+        the pair can add into them in place (AdapterPair, and the stream is a fresh sum nobody else reads) the returned
+        tensor is the updated stream, otherwise stream + adapter residual is formed here."""
+        pair = pairs[i]
+        fuse = self.fuse_residual and isinstance(pair, AdapterPair) and base_a is not None
+        # in place only into a fresh sum: not one of the adapters' own inputs (saved for their backward), and produced by an
+        # addition (whose backward does not read its result)
+        ok = lambda t: fuse and t.is_contiguous() and t.dtype == f_a.dtype and t.is_cuda and \
+            t.data_ptr() not in (f_a.data_ptr(), f_v.data_ptr()) and \
+            (not t.requires_grad or type(t.grad_fn).__name__.startswith("AddBackward"))
+        in_a, in_v = (base_a if ok(base_a) else None), (base_v if ok(base_v) else None)
+        if in_a is not None or in_v is not None:
+            out_a, idx_a, out_v, idx_v = pair(_to_site(f_a), _to_site(f_v), add_to=(in_a, in_v))
+        else:
+            out_a, idx_a, out_v, idx_v = pair(_to_site(f_a), _to_site(f_v))
         record.append("audio", pos, idx_a)
         record.append("video", pos, idx_v)
-        return _from_site(res_a), _from_site(res_v)
+        out_a, out_v = _from_site(out_a), _from_site(out_v)
+        if base_a is None:
+            return out_a, out_v                           # bare residuals
+        return (out_a if in_a is not None else base_a + out_a), (out_v if in_v is not None else base_v + out_v)
 
     def forward(self, vis_layers, aud_layers, f_v: torch.Tensor, f_a: torch.Tensor):
         record = AdapterIndexRecord()
@@ -133,23 +152,24 @@ class DualBackboneLoop(nn.Module):
                     f_a, _ = blk_a(f_a)
                     f_v = f_v + blk.drop_path2(blk.norm2(blk.mlp(f_v)))
                     continue
+                # The adapters of a position see the streams BEFORE the backbone half-block and their residuals are added AFTER
+                # it; the half-blocks do not depend on the adapters, so they run first and the adapter outputs are added into
+                # their results inside the output GEMMs (same values as the reference's order of statements).
                 if self.p1 is not None:
                     if i >= len(self.p1):
                         raise IndexError("more adapted blocks than position-1 adapter sites")
-                    res_a, res_v = self._adapt(self.p1, i, f_a, f_v, record, "p1")
-                    f_v = f_v + blk.drop_path1(blk.norm1(blk._attn(f_v)))
-                    f_v = f_v + res_v
-                f_a, _ = blk_a(f_a)
-                if self.p1 is not None:
-                    f_a = f_a + res_a
+                    base_v = f_v + blk.drop_path1(blk.norm1(blk._attn(f_v)))
+                    base_a, _ = blk_a(f_a)
+                    f_a, f_v = self._adapt(self.p1, i, f_a, f_v, record, "p1", base_a, base_v)
+                else:
+                    f_a, _ = blk_a(f_a)                   # (the reference skips the visual attention half without p1 adapters)
                 if self.p2 is not None:
                     if i >= len(self.p2):
                         raise IndexError("more adapted blocks than position-2 adapter sites")
-                    res_a, res_v = self._adapt(self.p2, i, f_a, f_v, record, "p2")
-                f_v = f_v + blk.drop_path2(blk.norm2(blk.mlp(f_v)))
-                if self.p2 is not None:
-                    f_v = f_v + res_v
-                    f_a = f_a + res_a
+                    base_v = f_v + blk.drop_path2(blk.norm2(blk.mlp(f_v)))
+                    f_a, f_v = self._adapt(self.p2, i, f_a, f_v, record, "p2", f_a, base_v)
+                else:
+                    f_v = f_v + blk.drop_path2(blk.norm2(blk.mlp(f_v)))
                 i += 1
             f_v = vl.downsample(f_v)                                                         # :725-727
             if getattr(al, "downsample", None) is not None:

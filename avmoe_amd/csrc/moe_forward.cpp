@@ -202,6 +202,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     g.A = sv + pl.o_Apost; g.B = sv + pl.o_Bpost; g.C = out;
     g.M = d.NT; g.N = d.Cg; g.K = d.KP; g.lda = (long)d.g * d.KPp; g.ldb = d.KPp; g.nb2 = d.g;
     g.sA2 = d.KPp; g.sB2 = (long)d.Cg * d.KPp; g.sCi = d.C; g.sC2 = d.Cg; g.out_dtype = dt;
+    g.accumulate = d.acc_out;
     AVMOE_TRY(launch_gemm(g, st));
   }
   return OK;

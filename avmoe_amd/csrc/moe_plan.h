@@ -19,6 +19,7 @@ struct Dims {
   int S, N, C, M, Cy, E, E_m, E_s, g, d, K;
   int use_bn, use_gate, ln_before, ln_post, variant, self_attn, lb_loss, training, bf16;
   int acc_dx, acc_dy;   // backward: accumulate into dX / dY
+  int acc_out;          // forward: accumulate into out
   float bn_eps, ln_eps, bn_momentum;
   // derived
   int esz;        // bytes of an activation / operand element (T)

@@ -80,6 +80,9 @@ typedef struct avmoe_moe_desc {
    * token tensor feeds several sites (the audio tokens are X of the audio site and Y of the visual site,
    * net_trans_v3.py:695-698) collect the gradient in one buffer without a separate accumulation pass (ABI 2) */
   int32_t accumulate_dx, accumulate_dy;
+  /* forward only (ABI 3): out += adapter(X, Y) instead of out = ... -- the caller's residual stream (x + attention(x), then
+   * "+ adapter residual", net_trans_v3.py:706-709) takes the adapter's contribution inside the output GEMM's epilogue */
+  int32_t accumulate_out;
 } avmoe_moe_desc;
 
 typedef struct avmoe_expert_ptrs {        /* <list>.{j}.*  ; unused entries NULL                     */

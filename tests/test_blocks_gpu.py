@@ -38,8 +38,9 @@ class Merge(nn.Module):
         return self.red(x.reshape(S, N // 4, 4 * C))
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_loop_equals_site_by_site(dtype):
+def test_loop_equals_site_by_site(dtype, fuse):
     from avmoe_amd.blocks import DualBackboneLoop
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
@@ -74,7 +75,7 @@ def test_loop_equals_site_by_site(dtype):
         for p in backbone: p.grad = None
         f_v, f_a = f_v0.clone().requires_grad_(True), f_a0.clone().requires_grad_(True)
         if fused:
-            loop = DualBackboneLoop(sites["a1"], sites["v1"], sites["a2"], sites["v2"], num_skip=1)
+            loop = DualBackboneLoop(sites["a1"], sites["v1"], sites["a2"], sites["v2"], num_skip=1, fuse_residual=fuse)
             ov, oa, rec = loop(sv, sa, f_v, f_a)
             rec = rec.to_dict()
         else:
@@ -85,11 +86,15 @@ def test_loop_equals_site_by_site(dtype):
 
     ref, got = run(False), run(True)
     assert got[2] == ref[2] and len(got[2]["audio"]["p1"]) == 4 and len(got[2]["video"]["p2"]) == 4
-    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    tol = 1e-4 if dtype == torch.float32 else 5e-2      # bf16: four adapted blocks deep, the fused add rounds once instead of twice
     gscale = max(float(a.float().abs().max()) for a in ref[5])      # gradients that are analytically zero (a bias in front of a
     def close(a, b, what, floor=0.0):                                # BatchNorm) are rounding noise: judge them on the global scale
-        scale = max(float(a.float().abs().max()), floor) + 1e-12
-        err = float((a.float() - b.float()).abs().max())
+        if dtype == torch.float32:
+            scale = max(float(a.float().abs().max()), floor) + 1e-12
+            err = float((a.float() - b.float()).abs().max())
+        else:                                                        # bf16, four adapted blocks deep: norm-wise
+            scale = float(a.float().norm()) + 1e-12
+            err = float((a.float() - b.float()).norm())
         assert err <= tol * scale, (what, err, scale)
     close(ref[0], got[0], "f_v"); close(ref[1], got[1], "f_a")
     close(ref[3], got[3], "d f_v"); close(ref[4], got[4], "d f_a")
@@ -100,4 +105,55 @@ def test_loop_equals_site_by_site(dtype):
         for grp in (5, 6):      # percent with the order of two bf16 additions, so compare the gradient as one vector
             a = torch.cat([x.float().reshape(-1) for x in ref[grp]]); b = torch.cat([x.float().reshape(-1) for x in got[grp]])
             cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-            assert cos > 0.999, (grp, cos)
+            assert cos > 0.995, (grp, cos)
+
+
+@pytest.mark.parametrize("concurrent", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pair_adds_into_residual_streams(dtype, concurrent):
+    """AdapterPair(..., add_to=(base_a, base_v)): base += adapter output inside the output GEMM (avmoe_moe_desc.accumulate_out)
+    == base + pair(...) ; the gradient reaches the base tensors unchanged and the adapters as before."""
+    from avmoe_amd.adapters import AdapterPair
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    ca = O.AdapterConfig(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32)      # streaming output GEMM (bf16)
+    cv = O.AdapterConfig(Cx=64, Nx=50, Cy=128, Ny=150, reduction=4, groups=2, K=8)
+    a, v = build_module("ave", ca).to(dev).train(), build_module("ave", cv).to(dev).train()
+    with torch.no_grad():
+        for m in (a, v):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.3)
+    bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in (a, v)]
+    g = torch.Generator().manual_seed(4)
+    S = 4
+    mk = lambda n, c: (0.5 * torch.randn(S, n, c, generator=g)).to(dev, dtype)
+    fa0, fv0, ra0, rv0, ga, gv = mk(150, 128), mk(50, 64), mk(150, 128), mk(50, 64), mk(150, 128), mk(50, 64)
+    pair = AdapterPair(a, v, concurrent=concurrent)
+    site = lambda t: t.permute(0, 2, 1).unsqueeze(-1)
+
+    def run(fused):
+        for m, bb in zip((a, v), bufs):
+            m.zero_grad(); m.load_state_dict({**m.state_dict(), **bb})
+        fa, fv, ra, rv = (t.clone().requires_grad_(True) for t in (fa0, fv0, ra0, rv0))
+        base_a, base_v = ra + 1.0, rv * 1.0 + 0.5                 # fresh sums (AddBackward)
+        if fused:
+            oa, ia, ov, iv = pair(site(fa), site(fv), add_to=(base_a, base_v))
+            oa, ov = oa.squeeze(-1).permute(0, 2, 1), ov.squeeze(-1).permute(0, 2, 1)
+            assert oa.data_ptr() == base_a.data_ptr() and ov.data_ptr() == base_v.data_ptr()      # in place
+        else:
+            ra_, ia, rv_, iv = pair(site(fa), site(fv))
+            oa, ov = base_a + ra_.squeeze(-1).permute(0, 2, 1), base_v + rv_.squeeze(-1).permute(0, 2, 1)
+        torch.autograd.backward([oa, ov], [ga, gv])
+        return [oa.detach(), ov.detach(), ia, iv, fa.grad, fv.grad, ra.grad, rv.grad] + [p.grad.clone() for m in (a, v) for p in m.parameters()]
+
+    ref, got = run(False), run(True)
+    assert torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for k, (r_, g_) in enumerate(zip(ref, got)):
+        if k in (2, 3):
+            continue
+        if k >= 4:                       # gradients do not depend on where the output was added
+            assert torch.equal(r_, g_), k
+        else:
+            assert float((r_.float() - g_.float()).abs().max()) <= tol * float(r_.float().abs().max()), k
