@@ -69,13 +69,22 @@ def algorithmic_bytes_per_clip_pair(c, esz):
     return 5.0 * c["T"] * (c["N_a"] + c["N_v"]) * c["C"] * esz
 
 
+def reference_flops_forward(Cx, Nx, Cy, Ny, S, E_m, E_s, d, g, K):
+    """Algorithmic FLOPs of one MoEAdapter forward in the reference's formulation (multiply-add = 2): token
+    remap + fc, router, the four latent-attention products per cross-modal expert, grouped down + up, mixture."""
+    E = E_m + E_s
+    f = 2.0 * S * Nx * Ny * Cy + 2.0 * S * Nx * Cy * Cx
+    f += 2.0 * S * (2 * Cx * 128 + 128 * 32 + 32 * E)
+    f += E_m * 8.0 * S * K * Cx * Nx
+    f += E * 4.0 * S * Nx * Cx * d / g
+    f += 2.0 * S * E * Cx * Nx
+    return f
+
+
 def reference_flops_per_clip_pair(c):
-    from oracle.avmoe_oracle import AdapterConfig, reference_flops_forward
-    a = AdapterConfig(Cx=c["C"], Nx=c["N_a"], Cy=c["C"], Ny=c["N_v"], E_m=c["E_m"], E_s=c["E_s"], reduction=c["reduction"],
-                      groups=c["groups"], K=c["K"])
-    v = AdapterConfig(Cx=c["C"], Nx=c["N_v"], Cy=c["C"], Ny=c["N_a"], E_m=c["E_m"], E_s=c["E_s"], reduction=c["reduction"],
-                      groups=c["groups"], K=c["K"])
-    return 3.0 * (reference_flops_forward(a, c["T"]) + reference_flops_forward(v, c["T"]))
+    kw = dict(S=c["T"], E_m=c["E_m"], E_s=c["E_s"], d=c["C"] // c["reduction"], g=c["groups"], K=c["K"])
+    return 3.0 * (reference_flops_forward(c["C"], c["N_a"], c["C"], c["N_v"], **kw) +
+                  reference_flops_forward(c["C"], c["N_v"], c["C"], c["N_a"], **kw))
 
 
 def cpu_baseline(c, budget_s=25.0):

@@ -1,7 +1,7 @@
 """Development: capture avmoe_moe_forward + avmoe_moe_backward (C ABI, one stream, caller-owned workspaces) into a HIP graph and
 replay it.  python scripts/graph_capture_cabi.py"""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import avmoe_oracle as O
 from tests.moe_gpu_util import MoeRun

@@ -1,7 +1,7 @@
 """Development: fwd + bwd time of one site through the C ABI for a few AVS configurations (v1 / v2 / none).
 python scripts/time_case.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import avmoe_oracle as O
 from tests.moe_gpu_util import MoeRun
