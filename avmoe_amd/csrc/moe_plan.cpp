@@ -105,7 +105,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Mb = (int)round_up(d.M + 1, 8);
   d.Np = (int)round_up(d.N, 8);
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
-  int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(1024, d.S))));
+  int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(256, d.S))));     // (A/B on the concurrent cfg-2 step)
   if (const char* ev = getenv("AVMOE_BPS")) {     // development: "<bps for N >= 512>,<bps for N < 512>"
     int a = 0, b = 0;
     if (sscanf(ev, "%d,%d", &a, &b) == 2) bps = std::max(1, d.N >= 512 ? a : b);
