@@ -27,6 +27,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     return launch_gemm(g, st);
   };
   const size_t esz = d.esz;
+  // the accumulators that start from zero (dtbp, dTW, dWcK, dqp, dRT) are adjacent in the plan: one memset instead of five
+  MEMSET0(sc + pl.o_dtbp, (pl.o_dRT - pl.o_dtbp) + (size_t)d.S * d.M * d.Kcyp * esz);
 
   // ---- phase 1: dApost = dOut Bpost ; dBpost = dOut^T Apost -------------------------------------
   {
@@ -59,7 +61,6 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_mid_bwd(pl, sv, sc, prm, grads, st));
   AVMOE_TRY(k_router_bwd(pl, sv, sc, prm, grads, lb_grad, st));
   // ---- phase 4: folded LayerNorm / hop-2 softmax ---------------------------------------------------
-  MEMSET0(sc + pl.o_dtbp, (size_t)d.nblk_tok * (d.KL ? d.KL : 1) * 4);
   if (d.nxn) MEMSET0(sc + pl.o_dZR, (size_t)d.NT * d.DZ * esz);
   AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));
   const char* dZx = sc + pl.o_Zw;
@@ -128,7 +129,6 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       AVMOE_TRY(run(g, false));
     }
   }
-  MEMSET0(sc + pl.o_dTW, (size_t)d.S * d.KLT * d.DZ * esz);
   for (int l = 0; l < d.El; ++l) {                         // dTW[s][slot l] = gate * a^T dzraw  (own expert's columns)
     const int e = d.e_of_lat[l];
     GemmArgs g = base();
@@ -221,8 +221,6 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(run(g, false));
   }
   AVMOE_TRY(k_prep_dBm(pl, sc, st));
-  MEMSET0(sc + pl.o_dWcK, (size_t)d.N * d.Mk * 4);
-  MEMSET0(sc + pl.o_dqp, ((size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb) * 4);
   if (d.Kcy > 0) {
     {                                                      // dA1[s] = [dBm | dab][s] [Wc | bc]^T
       GemmArgs g = base();
@@ -240,7 +238,6 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     }
     AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_A1y, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcyb, d.N, d.Np,
                                  sc + pl.o_dL1, nullptr, 1, 1, st));
-    MEMSET0(sc + pl.o_dRT, (size_t)d.S * d.M * d.Kcyp * esz);
     {                                                      // dR[s]^T = (dL1[s] Wc)^T   stored [m][kc]
       GemmArgs g = base();
       g.A = sc + pl.o_dL1; g.B = sv + pl.o_WcT; g.C = sc + pl.o_dRT;

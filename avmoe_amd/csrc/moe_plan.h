@@ -140,6 +140,12 @@ struct Dims {
   X(rowpart, 1, 4, (size_t)512 * (d.C > d.Cy ? d.C : d.Cy) * 2)  /* chunked row reductions */   \
   X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \
   /* ---- backward only ---- */                                                                \
+  /* zero-initialised accumulators: ONE memset at the start of the backward covers [dtbp, dRT] -- keep them adjacent */ \
+  X(dtbp, 1, 4, (size_t)d.nblk_tok * (d.KL ? d.KL : 1))                                         \
+  X(dTW, 1, d.esz, (size_t)d.S * d.KLT * d.DZ)                                                  \
+  X(dWcK, 1, 4, (size_t)d.N * d.Mk)                                                             \
+  X(dqp, 1, 4, (size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb)                                           \
+  X(dRT, 1, d.esz, (size_t)d.S * d.M * d.Kcyp)                                                  \
   X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)                                                      \
   X(dBp, 1, 4, (size_t)d.C * d.KPp)                                                             \
   X(dzp, 1, d.zsz, (size_t)d.NT * d.DZ)                 /* dz' -> dy (in place)           */       \
@@ -156,9 +162,7 @@ struct Dims {
   X(dL2x, 1, d.esz, (size_t)d.NT * d.KLp)           /* [dL2 | dsx | 1]                */       \
   X(aw, 1, d.esz, (size_t)d.NT * d.KLp)             /* du3 * a                        */       \
   X(ag, 1, d.esz, (size_t)d.NT * d.KLp)             /* gate_lat * a                   */       \
-  X(dtbp, 1, 4, (size_t)d.nblk_tok * (d.KL ? d.KL : 1))                                         \
   X(dtbar, 1, 4, (size_t)d.S * (d.KL ? d.KL : 1))                                               \
-  X(dTW, 1, d.esz, (size_t)d.S * d.KLT * d.DZ)                                                  \
   X(dTT, 1, d.esz, (size_t)d.S * (d.El ? d.El : 1) * d.K * d.Kp)                                \
   X(dWt, 1, 4, (size_t)d.g * d.E * d.dgp * d.Cg)                                                \
   X(dT, 1, 4, (size_t)d.S * (d.KL ? d.KL : 1) * d.C)                                            \
@@ -171,11 +175,8 @@ struct Dims {
   X(dBmT, 1, d.esz, (size_t)d.S * d.Kcyb * d.Mb)                                                \
   X(dL1, 1, d.esz, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)                      \
   X(dL1xT, 1, d.esz, (size_t)d.NT * d.Kcxp)                                                     \
-  X(dRT, 1, d.esz, (size_t)d.S * d.M * d.Kcyp)                                                  \
   X(dQ, 1, 4, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                               \
   X(dQT, 1, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                          \
-  X(dqp, 1, 4, (size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb)                                           \
-  X(dWcK, 1, 4, (size_t)d.N * d.Mk)                                                             \
   X(dWf, 1, 4, (size_t)d.C * d.Cy)                                                              \
   X(dvec, 1, 4, (size_t)2 * d.C + d.Mb + 64)        /* drw, dbf, dwbar, dbcbar        */
 
