@@ -364,6 +364,24 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   const double abytes = (nb * a.M * (double)(a.K + s.K2) + (double)a.nb2 * a.N * (double)a.K + nb * a.N * (double)s.K2) * 2.0 +
                         nb * a.M * (double)a.N * osz * (a.accumulate ? 2.0 : 1.0) + (a.D ? nb * a.M * (double)a.N * 2.0 : 0.0);
   const double flops = 2.0 * nb * a.M * (double)a.N * (a.K + s.K2);
+#ifndef SC_OUT_BM
+#define SC_OUT_BM 64
+#endif
+#ifndef SC_OUT_PC
+#define SC_OUT_PC 1
+#endif
+#ifndef SC_DOWN_PC
+#define SC_DOWN_PC 2
+#endif
+#ifndef SC_DAP_PC
+#define SC_DAP_PC 2
+#endif
+#ifndef SC_DX_PC
+#define SC_DX_PC 1
+#endif
+#ifndef SC_DY_PC
+#define SC_DY_PC 1
+#endif
 // (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
 // (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
 #define STREAM_CASE(COND, KS_, KS2_, TPW_, NW_, BM_, PERCU_, A2MN_, ACCOK_, NAME)   \
@@ -375,12 +393,12 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     } else if (a.accumulate) return 1;                                              \
     return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, false>(s, a.nb2, PERCU_, st);   \
   }
-  STREAM_CASE(true, 5, 0, 2, 12, 64, 1, false, true, "gemm_stream_k160_n384")    // output GEMM: K = 4*32 + 12, N = 384 per group (+= for accumulate_out)
-  STREAM_CASE(true, 12, 0, 2, 4, 32, 2, false, false, "gemm_stream_k384_n128")   // grouped down projection
-  STREAM_CASE(true, 12, 0, 1, 9, 32, 1, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
-  STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, 1, false, true, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
+  STREAM_CASE(true, 5, 0, 2, 12, SC_OUT_BM, SC_OUT_PC, false, true, "gemm_stream_k160_n384")    // output GEMM: K = 4*32 + 12, N = 384 per group (+= for accumulate_out)
+  STREAM_CASE(true, 12, 0, 2, 4, 32, SC_DOWN_PC, false, false, "gemm_stream_k384_n128")   // grouped down projection
+  STREAM_CASE(true, 12, 0, 1, 9, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
+  STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, SC_DX_PC, false, true, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
   STREAM_CASE(true, 4, 3, 2, 12, 32, 1, false, true, "gemm_stream_k128+96_n384r")      // ... ragged frames
-  STREAM_CASE(a.M % 64 == 0, 2, 3, 4, 12, 64, 1, true, true, "gemm_stream_k64+96mn_n768")   // dY = dR^T Q + [Bm ; wbar]^T dV
+  STREAM_CASE(a.M % 64 == 0, 2, 3, 4, 12, 64, SC_DY_PC, true, true, "gemm_stream_k64+96mn_n768")   // dY = dR^T Q + [Bm ; wbar]^T dV
   STREAM_CASE(true, 2, 3, 4, 12, 32, 1, true, true, "gemm_stream_k64+96mn_n768r")      // ... ragged frames
 #undef STREAM_CASE
   return 1;
