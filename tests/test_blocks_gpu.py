@@ -157,3 +157,29 @@ def test_pair_adds_into_residual_streams(dtype, concurrent):
             assert torch.equal(r_, g_), k
         else:
             assert float((r_.float() - g_.float()).abs().max()) <= tol * float(r_.float().abs().max()), k
+
+
+def test_loop_inference_no_grad():
+    """eval() + torch.no_grad(): the loop (fused residuals, two streams) gives the site-by-site result and leaves no autograd state."""
+    from avmoe_amd.blocks import DualBackboneLoop
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    S, Cv, Nv, Ca, Na = 2, 64, 144, 48, 256
+    sv = [Stage(nn.ModuleList([VisBlock(Cv)]).to(dev).eval(), nn.Identity())]
+    sa = [Stage(nn.ModuleList([AudBlock(Ca)]).to(dev).eval(), None)]
+    sites = {}
+    for key, (cx, nx, cy, ny) in {"a1": (Ca, Na, Cv, Nv), "v1": (Cv, Nv, Ca, Na), "a2": (Ca, Na, Cv, Nv), "v2": (Cv, Nv, Ca, Na)}.items():
+        m = build_module("ave", O.AdapterConfig(Cx=cx, Nx=nx, Cy=cy, Ny=ny, reduction=4, groups=2, K=8)).to(dev).eval()
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.3)
+        sites[key] = [m]
+    g = torch.Generator().manual_seed(1)
+    f_v, f_a = (0.5 * torch.randn(S, Nv, Cv, generator=g)).to(dev), (0.5 * torch.randn(S, Na, Ca, generator=g)).to(dev)
+    with torch.no_grad():
+        ov, oa, rec = DualBackboneLoop(sites["a1"], sites["v1"], sites["a2"], sites["v2"])(sv, sa, f_v, f_a)
+        ev, ea, erec = restated_loop(sv, sa, f_v, f_a, sites, 1, True, True)
+    assert not ov.requires_grad and not oa.requires_grad
+    assert rec.to_dict() == erec
+    assert float((ov - ev).abs().max()) <= 1e-5 * float(ev.abs().max()) and float((oa - ea).abs().max()) <= 1e-5 * float(ea.abs().max())
