@@ -54,6 +54,8 @@ TOP_KEY_TO_FIELD = {
 def declare(L):
     L.avmoe_adam_step.restype = C.c_int
     L.avmoe_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float, C.c_void_p]
+    L.avmoe_router_topk.restype = C.c_int
+    L.avmoe_router_topk.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.avmoe_expert_histogram.restype = C.c_int
     L.avmoe_expert_histogram.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.avmoe_router_forward.restype = C.c_int

@@ -49,6 +49,20 @@ __global__ void kk_expert_hist(const int64_t* __restrict__ idx, long S, int E, l
 
 using namespace avmoe;
 
+// idx[s][j] = expert with the j-th largest probability of frame s; equal probabilities keep the lower expert index first, so
+// column 0 is exactly the forward's first-max argmax (net_trans_v3.py:479).  One thread per frame, E <= 16: selection by rank.
+__global__ void __launch_bounds__(256) kk_router_topk(const float* __restrict__ probs, long S, int E, int k, long long* __restrict__ idx) {
+  for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < S; s += (long)gridDim.x * 256) {
+    float p[AVMOE_MAX_EXPERTS];
+    for (int e = 0; e < E; ++e) p[e] = probs[s * E + e];
+    for (int e = 0; e < E; ++e) {
+      int rank = 0;                                    // experts that come before e
+      for (int f = 0; f < E; ++f) rank += (p[f] > p[e]) || (p[f] == p[e] && f < e);
+      if (rank < k) idx[s * k + rank] = e;
+    }
+  }
+}
+
 extern "C" {
 
 int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
@@ -63,6 +77,15 @@ int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
   hipLaunchKernelGGL(kk_adam, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2,
                      eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
   AVMOE_CHECK_LAUNCH("adam_step");
+  return OK;
+}
+
+int avmoe_router_topk(const float* probs, int64_t S, int32_t E, int32_t k, int64_t* idx, void* stream) {
+  if (!probs || !idx || S < 0 || E < 1 || E > AVMOE_MAX_EXPERTS || k < 1 || k > E) { set_last_error("avmoe_router_topk: bad argument"); return ERR_BAD_ARG; }
+  if (S == 0) return OK;
+  hipLaunchKernelGGL(kk_router_topk, dim3((unsigned)std::min<long>((S + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, probs, (long)S,
+                     (int)E, (int)k, (long long*)idx);
+  AVMOE_CHECK_LAUNCH("router_topk");
   return OK;
 }
 

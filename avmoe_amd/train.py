@@ -114,6 +114,19 @@ class ExpertActivationCounter:
         return {n: c[i] for i, n in enumerate(self.names)}
 
 
+def topk_experts(probs: torch.Tensor, k: int) -> torch.Tensor:
+    """(S, k) int64: the k most probable experts per frame, most probable first, ties in expert order (column 0 == the `idx`
+    the sites return).  Extension for statistics (BASELINE config 3); the mixture stays dense as in the reference."""
+    if not probs.is_cuda:
+        raise capi.AvmoeError("topk_experts runs on the GPU (no CPU fallback)")
+    p = probs.reshape(-1, probs.shape[-1]).to(torch.float32).contiguous()
+    out = torch.empty(p.shape[0], k, dtype=torch.int64, device=p.device)
+    st = capi.lib().avmoe_router_topk(p.data_ptr(), C.c_int64(p.shape[0]), C.c_int32(p.shape[1]), C.c_int32(k), out.data_ptr(),
+                                      torch.cuda.current_stream(p.device).cuda_stream)
+    capi.check(st, "avmoe_router_topk")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def adapter_state_dict(model: torch.nn.Module, substrings=("adapter",)) -> Dict[str, torch.Tensor]:
     """The adapter / router entries of model.state_dict() (keys containing 'adapter': `*_adapter_blocks_p{1,2}.*`)."""

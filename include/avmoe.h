@@ -146,6 +146,10 @@ int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char*
 int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 int avmoe_expert_histogram(const int64_t* idx, int64_t S, int32_t E, int64_t* counts, void* stream);
+/* Extension (no reference counterpart; BASELINE config 3 "router top-k=2"): idx (S, k) int64 = the k most probable experts of
+ * every frame from probs (S, E) f32, most probable first, equal probabilities in expert order -- column 0 is the forward's
+ * first-max argmax.  The mixture itself stays dense (net_trans_v3.py:482-486).                                          */
+int avmoe_router_topk(const float* probs, int64_t S, int32_t E, int32_t k, int64_t* idx, void* stream);
 
 /* ---- optional per-launch timing (HIP events on the launch stream; off by default; process-wide) --------
  * avmoe_prof_report writes a JSON array of {"name","calls","total_ms","alg_bytes","flops"} per kernel family

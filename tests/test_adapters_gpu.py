@@ -201,3 +201,25 @@ def test_flat_adam_matches_torch_adam_and_histogram_matches_bincount():
     tabs = cnt.numpy()
     assert (tabs["video_p1"][2] == 2 * torch.bincount(idx.reshape(-1).cpu(), minlength=4).numpy()).all()
     assert tabs["audio_p1"][0].sum() == 5 and tabs["audio_p1"][1:].sum() == 0 and tabs["video_p1"][:2].sum() == 0
+
+
+def test_router_topk_matches_stable_sort_and_argmax():
+    """avmoe_router_topk (extension, BASELINE config 3 "top-k=2"): the k most probable experts per frame, ties in expert order;
+    column 0 is the site's own first-max argmax -- on real AVVP probabilities and on rows with exact ties."""
+    from avmoe_amd.train import topk_experts
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    probs = torch.softmax(torch.randn(1000, 4, generator=g), -1)
+    probs[::7] = 0.25                                   # exact four-way ties
+    probs[1::7, 1] = probs[1::7, 0]                     # two-way ties
+    for k in (1, 2, 4):
+        got = topk_experts(probs.to(dev), k).cpu()
+        ref = torch.sort(probs, dim=-1, descending=True, stable=True).indices[:, :k]
+        assert torch.equal(got, ref)
+    assert torch.equal(topk_experts(probs.to(dev), 1).cpu().reshape(-1), torch.argmax(probs, -1))
+    meta, cfg, t = load_golden("avvp_train")            # the module's probabilities -> top-2
+    P, B = split_params(t)
+    from tests.moe_gpu_util import MoeRun
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], training=True).forward()
+    top2 = topk_experts(run.probs, 2).cpu()
+    assert torch.equal(top2[:, 0], t["idx"]) and torch.equal(top2, torch.sort(t["probs"], dim=-1, descending=True, stable=True).indices[:, :2])
