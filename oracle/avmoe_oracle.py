@@ -8,7 +8,8 @@ the backward) of what the reference's two hot-path modules compute:
     (AVQA twin      AVQA/net_grd_avst/net_avst_v2.py:215-399  -- identical arithmetic)
     (AVVP variant   AVVP/nets/mgn.py:39-224                   -- N x N unimodal attention, LB loss)
     (AVS variant    AVS/avs_scripts/avs_s4/model/PVT_AVSModel_v2.py:90-318 -- logit noise,
-                    probs + LB loss returned, optional latent "v2" self attention)
+                    probs + LB loss returned, optional self attention of the unimodal experts:
+                    "v2" latent tokens on X, "v1" nn.MultiheadAttention across the frames)
 
 It is NOT the product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import it, and only as the checker / the timed CPU baseline.  The product path lives in
