@@ -620,7 +620,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.kper = d.ksplit > 1 ? (int)round_up(cdiv(a.K, d.ksplit), bk) : (a.K > 0 ? (int)round_up(a.K, bk) : bk);
 
   int tile = a.tile;
-  if (tile == 0 || d.fold_rps) tile = (d.M > 64 && a.N > 64) ? 128 : 64;
+  if (tile == 0 || d.fold_rps) tile = (d.M > 64 && a.N > 64) ? 128 : ((d.M <= 32 && a.N <= 32) ? 32 : 64);
   const int bz = d.nbatch * d.ksplit;
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
   int st;
@@ -632,6 +632,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     d.tiles_n = cdiv(a.N, 64);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 64, 64>(a, d, bz, stream)
                               : launch_layout<float, 64, 64>(a, d, bz, stream);
+  } else if (tile == 32) {                                   // small per-batch problems (K x K latent matrices, S x S frame attention)
+    d.tiles_n = cdiv(a.N, 32);
+    st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 32, 32>(a, d, bz, stream)
+                              : launch_layout<float, 32, 32>(a, d, bz, stream);
   } else {
     set_last_error("gemm: tile %d not built", tile);
     return ERR_UNSUPPORTED;

@@ -66,18 +66,28 @@ __global__ void km_finish(void* xr_, const float* bout, const void* X_, long row
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
     stT<T>(xr, i, ldT<T>(xr, i) + bout[i % C] - ldT<T>(X, i));
 }
-// out[c] = sum_t rows[t][c] : one block per 64 columns, 4 waves over the rows (deterministic)
+// part[chunk][c] = sum over the rows of the chunk of rows[t][c]   (grid: column blocks x row chunks; summed over the chunks by
+// k_colsum_f32 -- deterministic, no atomics)
 template <typename T>
-__global__ void __launch_bounds__(256) km_colsum(const void* rows_, long rows, int cols, float* out) {
+__global__ void __launch_bounds__(256) km_colsum_part(const void* rows_, long rows, int cols, int rows_per_chunk, float* part) {
   const T* p = (const T*)rows_;
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  const long t0 = (long)blockIdx.y * rows_per_chunk, t1 = t0 + rows_per_chunk < rows ? t0 + rows_per_chunk : rows;
   float acc = 0.f;
   if (c < cols)
-    for (long t = wave; t < rows; t += 4) acc += ldT<T>(p, t * cols + c);
+    for (long t = t0 + wave; t < t1; t += 4) acc += ldT<T>(p, t * cols + c);
   red[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+int colsum_rows(int bf16, const void* rows, long nrows, int cols, float* part /* >= 256 * cols floats */, float* out, hipStream_t st) {
+  const int chunks = (int)std::max<long>(1, std::min<long>(256, nrows / 64));
+  const int rpc = (int)((nrows + chunks - 1) / chunks);
+  DISPATCH_T(bf16, km_colsum_part, dim3(cdiv(cols, 64), chunks), dim3(256), 0, st, rows, nrows, cols, rpc, part);
+  AVMOE_CHECK_LAUNCH("mha colsum");
+  return k_colsum_f32(part, chunks, cols, cols, 1, 0, out, 0, 1.f, st);
 }
 
 struct Slot {
@@ -173,8 +183,8 @@ int mha_frames_backward(const Plan& pl, const void* X, const avmoe_expert_ptrs& 
     if (split) g.ksplit = choose_ksplit(g, slab_cap);
     return launch_gemm(g, st);
   };
-  DISPATCH_T(d.bf16, km_colsum, dim3(cdiv(d.C, 64)), dim3(256), 0, st, dxr, (long)d.NT, d.C, dbout);
-  AVMOE_CHECK_LAUNCH("mha colsum");
+  float* part = (float*)(sc + pl.o_mpart);
+  AVMOE_TRY(colsum_rows(d.bf16, dxr, (long)d.NT, d.C, part, dbout, st));
   {                                                        // d Wout = dxr^T O
     GemmArgs g = base();
     g.A = dxr; g.B = b.O(); g.C = dWout; g.out_dtype = GEMM_F32;
@@ -219,8 +229,7 @@ int mha_frames_backward(const Plan& pl, const void* X, const avmoe_expert_ptrs& 
     mat_view_a(g, d); head_view_b(g, d, 3 * d.C); head_view_c(g, d, 3 * d.C);
     AVMOE_TRY(run(g, false));
   }
-  DISPATCH_T(d.bf16, km_colsum, dim3(cdiv(3 * d.C, 64)), dim3(256), 0, st, (const void*)dQKV, (long)d.NT, 3 * d.C, dbin);
-  AVMOE_CHECK_LAUNCH("mha colsum");
+  AVMOE_TRY(colsum_rows(d.bf16, dQKV, (long)d.NT, 3 * d.C, part, dbin, st));
   {                                                        // d Win = dQKV^T X
     GemmArgs g = base();
     g.A = dQKV; g.B = X; g.C = dWin; g.out_dtype = GEMM_F32;

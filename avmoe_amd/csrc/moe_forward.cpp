@@ -7,7 +7,7 @@
 namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap) {
-  const int tile = (g.tile ? g.tile : ((g.M > 64 && g.N > 64) ? 128 : 64));
+  const int tile = (g.tile ? g.tile : ((g.M > 64 && g.N > 64) ? 128 : ((g.M <= 32 && g.N <= 32) ? 32 : 64)));
   const long tiles = (long)cdiv(g.M, tile) * cdiv(g.N, tile) * g.nb1 * g.nb2;
   const int bk = g.dtype == GEMM_BF16 ? 64 : 32;
   static const long target = getenv("AVMOE_KS_TARGET") ? atol(getenv("AVMOE_KS_TARGET")) : 512;     // workgroups wanted (dev override)

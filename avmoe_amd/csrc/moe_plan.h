@@ -125,6 +125,7 @@ struct Dims {
   X(mdS, 1, d.esz, d.mha ? (size_t)d.N * d.H * d.S * d.Sp : 1)                                             \
   X(mdQKV, 1, d.esz, d.mha ? (size_t)d.NT * 3 * d.C : 1)                                                   \
   X(mdW, 1, 4, d.mha ? (size_t)3 * d.C * d.C + 4 * d.C : 1)         /* sink for parameter gradients nobody asked for */ \
+  X(mpart, 1, 4, d.mha ? (size_t)256 * 3 * d.C : 1)                 /* row-chunk partial sums of the bias gradients  */ \
   /* ---- transient ---- */                                                                    \
   X(L1, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)    /* L1 ; dA1 in bwd */  \
   X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \

@@ -105,7 +105,7 @@ LAYOUTS = list(itertools.product([False, True], [False, True]))
 def test_exact_integer_tiles_asymmetric(dtype, a_mn, b_mn):
     """Small-integer operands: every product and partial sum is exact, so any fragment-layout slip
     (row/col swap, k permutation mismatch between operands) shows up as a hard mismatch."""
-    for tile in (64, 128):
+    for tile in (32, 64, 128):
         got, ref = _run_gemm(80, 48, 96, dtype, a_mn, b_mn, tile=tile, exact_ints=True, seed=tile)
         assert torch.equal(got, ref), f"tile {tile}: max err {(got - ref).abs().max()}"
 
@@ -127,7 +127,7 @@ def test_batched_broadcast_and_two_level_batch(dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [32, 64, 128])
 def test_transposed_c_accumulate_epilogue(dtype, tile):
     got, ref = _run_gemm(150, 90, 72, dtype, False, False, nb1=2, tile=tile, c_transposed=True,
                          accumulate=True, seed=7)
@@ -264,3 +264,13 @@ def test_batch_fold_shared_b(dtype, M, rps, c_transposed):
     assert torch.isfinite(val).all()
     assert float((val - ref).abs().max()) <= _tol(dtype) * float(ref.abs().max())
     assert bool((rest == -5.0).all())
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+def test_small_batched_problems_take_the_32_tile(dtype, a_mn, b_mn):
+    """M, N <= 32 per batch entry (K x K latent matrices, S x S frame attention of the "v1" experts): the 32 x 32 tile, all
+    layouts, two-level batch, ragged extents, split-K."""
+    for (M, N, K, ks) in ((10, 10, 16, 1), (32, 32, 200, 1), (10, 16, 10, 1), (24, 31, 1000, 4)):
+        got, ref = _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=3, nb2=4, ksplit=ks, seed=M + N)
+        assert float((got - ref).abs().max()) <= _tol(dtype) * float(ref.abs().max()), (M, N, K, ks)
