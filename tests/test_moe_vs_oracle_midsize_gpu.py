@@ -85,7 +85,8 @@ def test_midsize_matches_oracle_fp32(name):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2"])
+@pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
+                                  "cfg1_stage0_visual_side"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path on the register-resident shape (bf16 Z / dz' storage, streaming GEMMs, streaming Gram)
     against the fp32 oracle: outputs within 4e-2, gradients norm-wise 6 % (token tensors) / 12 % (parameters; analytically
