@@ -34,7 +34,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   {
     GemmArgs g = base();
     g.A = dOut; g.B = sv + pl.o_Bpost; g.C = sc + pl.o_dAp;
-    g.M = d.NT; g.N = d.KP; g.K = d.Cg; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.KPp; g.nb2 = d.g;
+    // N = KP, or the padded KPp when KP is not a multiple of 4 (2 or 3 experts): Bpost's padding columns are zero, the streaming
+    // kernel wants whole 4-column vectors, and nobody reads the padding of dAp
+    g.M = d.NT; g.N = (d.KP % 4 == 0) ? d.KP : d.KPp; g.K = d.Cg; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.KPp; g.nb2 = d.g;
     g.sA2 = d.Cg; g.sB2 = (long)d.Cg * d.KPp; g.sCi = (long)d.g * d.KPp; g.sC2 = d.KPp;
     AVMOE_TRY(run(g, false));
   }

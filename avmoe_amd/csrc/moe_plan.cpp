@@ -60,12 +60,12 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.dg = d.d / d.g;
   d.dgp = (int)round_up(d.dg, 8);
   // A per-group bottleneck below 32 is padded to 32 when that makes the site the register-resident shape (2 groups, 32 latent
-  // tokens, 4 experts: tile_fast.hip): bf16 Z rows of 256 entries instead of fp32 rows of 4 * g * E * dgp bytes, and kernels
+  // tokens, 2 - 4 experts: tile_fast.hip): bf16 Z rows of 64 E entries instead of fp32 rows of 4 * g * E * dgp bytes, and kernels
   // that run 1.3-3x faster than the generic ones (HTS-AT / Swin-B sites at r = 8: bottleneck 48: -29 %, 32: -15 %, 24: -19 %,
   // 12 / 16: -4 % of the site step).  Padding columns are zero weights, as for every other padded width.
   {
     const bool attn_nxn = d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN || d.self_attn == AVMOE_SELF_ATTN_MHA_V1;
-    if (d.g == 2 && d.dg < 32 && d.K == 32 && d.E == 4 && !(attn_nxn && d.E_s > 0) && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
+    if (d.g == 2 && d.dg < 32 && d.K == 32 && d.E >= 2 && d.E <= 4 && !(attn_nxn && d.E_s > 0) && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
   }
   d.Cg = d.C / d.g;
   d.DD = d.g * d.dgp;
@@ -120,7 +120,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   }
   d.nblk_tok = bps * d.S;
   d.zsz = tile_fast_ok(d) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident path
-  d.gram64 = tile_fast_ok(d) && d.bf16;
+  d.gram64 = tile_fast_ok(d) && d.bf16 && d.E == 4;      // gram.hip is built for 4 experts
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 
   size_t off[2] = {0, 0};

@@ -896,15 +896,22 @@ void fast_grid(const Dims& d, dim3* grid, int* per) {
 
 }  // namespace
 
-// The register-resident kernels cover exactly: bottleneck 64 in 2 groups, 32 latent tokens, 4 experts, no N x N block.
+// The register-resident kernels cover exactly: bottleneck 64 in 2 groups, 32 latent tokens, 2 - 4 experts, no N x N block.
 bool tile_fast_ok(const Dims& d) {
-  return d.DD == FDD && d.dgp == FDG && d.g == 2 && d.K == FK && d.Kp == FK && d.E == 4 && !d.nxn;
+  return d.DD == FDD && d.dgp == FDG && d.g == 2 && d.K == FK && d.Kp == FK && d.E >= 2 && d.E <= 4 && !d.nxn;
 }
 
+#define LAUNCH_TE1(bf16, KERN, NE, ...)                                                                \
+  do {                                                                                                 \
+    if (bf16) hipLaunchKernelGGL((KERN<__bf16, NE>), grid, dim3(256), 0, st, __VA_ARGS__);             \
+    else hipLaunchKernelGGL((KERN<float, NE>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+  } while (0)
+// 4 experts: the cfg-2 configuration; 2 (1 + 1): what the reference's AVE / AVVP launchers ship (AVE/train.sh:7-8); 3: 1 + 2 / 2 + 1
 #define LAUNCH_TE(bf16, KERN, ...)                                                                     \
   do {                                                                                                 \
-    if (bf16) hipLaunchKernelGGL((KERN<__bf16, 4>), grid, dim3(256), 0, st, __VA_ARGS__);              \
-    else hipLaunchKernelGGL((KERN<float, 4>), grid, dim3(256), 0, st, __VA_ARGS__);                    \
+    if (d.E == 4) LAUNCH_TE1(bf16, KERN, 4, __VA_ARGS__);                                              \
+    else if (d.E == 2) LAUNCH_TE1(bf16, KERN, 2, __VA_ARGS__);                                         \
+    else LAUNCH_TE1(bf16, KERN, 3, __VA_ARGS__);                                                       \
   } while (0)
 
 int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {

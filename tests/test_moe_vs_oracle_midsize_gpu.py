@@ -50,6 +50,13 @@ CASES = {
     # register-resident shape with FOUR latent experts (AVS v2: the unimodal experts have latent tokens too) and with a padded bottleneck
     "fast_v2": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avs", self_attn="v2", lb_loss=True), S=3),
     "fast_v2_pad": dict(cfg=dict(Cx=96, Nx=70, Cy=64, Ny=50, reduction=4, groups=2, K=32, variant="avs", self_attn="v2"), S=3),
+    # 1 + 1 experts -- what the reference's AVE / AVVP launchers ship (AVE/train.sh:7-8: r = 8, 2 groups, 32 tokens) -- and 3 experts
+    # on the register-resident path; "ship" shapes: HTS-AT stage 2 x Swin-B stage 2 with r = 8 (bottlenecks 48 padded / 64)
+    "fast_e1p1": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=4),
+    "fast_e2p1": dict(cfg=dict(Cx=128, Nx=97, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=2, E_s=1), S=3),
+    "fast_e1p2": dict(cfg=dict(Cx=128, Nx=97, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avs", E_m=1, E_s=2, lb_loss=True), S=3),
+    "ship_stage2_audio": dict(cfg=dict(Cx=384, Nx=256, Cy=512, Ny=144, reduction=8, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=4),
+    "ship_stage2_visual": dict(cfg=dict(Cx=512, Nx=144, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=4),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
 }
@@ -89,7 +96,7 @@ def test_midsize_matches_oracle_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
-                                  "cfg1_stage0_visual_side", "fast_v2"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
+                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path on the register-resident shape (bf16 Z / dz' storage, streaming GEMMs, streaming Gram)
     against the fp32 oracle: outputs within 4e-2, gradients norm-wise 6 % (token tensors) / 12 % (parameters; analytically
