@@ -27,14 +27,19 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-constexpr int GE = 4, GG = 2, GD = 32, GDZ = GE * GG * GD;      // experts, groups, bottleneck per group, row width (256)
+constexpr int GG = 2, GD = 32;                                  // groups, bottleneck per group
 constexpr int GT = 64;                                          // tokens per tile
-constexpr int G_ROWB = GDZ * 2 + 16;                            // LDS bytes per token row
-constexpr int G_TILE = GT * G_ROWB;
 
-template <bool WEIGHTED>
+// GE experts (4: two (group, expert) pairs per wave; 2: one pair per wave)
+template <bool WEIGHTED, int GE>
 __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restrict__ Zp, const float* __restrict__ w /* [E][NT] */,
                                                  float* __restrict__ part, long NT, int tiles_per_blk) {
+  constexpr int GDZ = GE * GG * GD;                             // row width (256 / 128)
+  constexpr int G_ROWB = GDZ * 2 + 16;                          // LDS bytes per token row
+  constexpr int G_TILE = GT * G_ROWB;
+  constexpr int PPW = GG * GE / 4;                              // (group, expert) pairs per wave
+  constexpr int CPR = GDZ / 8;                                  // 16-byte chunks per row
+  constexpr int NLD = GT * CPR / 256;                           // chunks per thread and tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_w = (float*)(smem + 2 * G_TILE);                     // [2 buffers][E][GT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -42,38 +47,38 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
   const long ntiles = (NT + GT - 1) / GT;
   const long tile1 = min(ntiles, tile0 + (long)tiles_per_blk);
 
-  f32x4 acc[2][2][2];                                            // [pair of this wave][row tile][column tile]
+  f32x4 acc[PPW][2][2];                                          // [pair of this wave][row tile][column tile]
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < PPW; ++p)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[8];                                                   // 64 rows x 32 chunks of 16 B / 256 threads
+  u32x4 ra[NLD];                                                 // 64 rows x CPR chunks of 16 B / 256 threads
   float rw = 0.f;
   auto gload = [&](long tile) {
     const long t0 = tile * GT;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 256 * i, row = c >> 5, cc = c & 31;
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (t0 + row < NT) v = *(const u32x4*)(Zp + (t0 + row) * GDZ + cc * 8);
       ra[i] = v;
     }
     if constexpr (WEIGHTED) {
-      const int e = tid >> 6, tl = tid & 63;                     // 4 experts x 64 tokens
-      rw = (t0 + tl < NT) ? w[(long)e * NT + t0 + tl] : 0.f;
+      const int e = tid >> 6, tl = tid & 63;                     // experts x 64 tokens
+      rw = (e < GE && t0 + tl < NT) ? w[(long)e * NT + t0 + tl] : 0.f;
     }
   };
   auto lstore = [&](int buf) {
     char* s = smem + buf * G_TILE;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int c = tid + 256 * i;
-      *(u32x4*)(s + (c >> 5) * G_ROWB + (c & 31) * 16) = ra[i];
+      *(u32x4*)(s + (c / CPR) * G_ROWB + (c % CPR) * 16) = ra[i];
     }
-    if constexpr (WEIGHTED) s_w[buf * GE * GT + tid] = rw;
+    if constexpr (WEIGHTED) { if (tid < GE * GT) s_w[buf * GE * GT + tid] = rw; }
   };
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
@@ -84,8 +89,8 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
     if (tile + 1 < tile1) gload(tile + 1);
     const char* s = smem + buf * G_TILE;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int cb = 2 * wave + p, gi = cb / GE, e = cb % GE;
+    for (int p = 0; p < PPW; ++p) {
+      const int cb = PPW * wave + p, gi = cb / GE, e = cb % GE;
       const int col0 = gi * (GE * GD) + e * GD;
 #pragma unroll
       for (int ks = 0; ks < GT / 32; ++ks) {
@@ -118,8 +123,8 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
   // C layout: lane (r, q) holds rows 4 q + x, column r of each 16 x 16 tile
   float* out = part + (long)blockIdx.x * (GG * GE * GD * GD);
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int cb = 2 * wave + p;
+  for (int p = 0; p < PPW; ++p) {
+    const int cb = PPW * wave + p;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -136,22 +141,30 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
 int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st) {
   const Dims& d = pl.d;
   ProfScope ps_("k_gram64", (long)d.NT, (double)d.NT * (d.DZ * 2.0 + (w ? 4.0 * d.E : 0.0)), 2.0 * d.NT * (double)d.g * d.E * d.dgp * d.dgp, st);
-  if (!tile_fast_ok(d) || !d.bf16) { set_last_error("gram64: shape not covered"); return ERR_UNSUPPORTED; }
+  if (!tile_fast_ok(d) || !d.bf16 || (d.E != 4 && d.E != 2)) { set_last_error("gram64: shape not covered"); return ERR_UNSUPPORTED; }
   const long ntiles = cdiv((long)d.NT, GT);
   const int nblk = (int)std::min<long>(GRAM_BLOCKS, ntiles);
   const int tpb = (int)cdiv(ntiles, (long)nblk);
-  const size_t sh = 2 * G_TILE + 2 * GE * GT * sizeof(float);
+  const size_t sh = 2 * (size_t)GT * (d.DZ * 2 + 16) + 2 * (size_t)d.E * GT * sizeof(float);
+  const void* kerns[4] = {(const void*)kg_gram64<false, 4>, (const void*)kg_gram64<true, 4>, (const void*)kg_gram64<false, 2>,
+                          (const void*)kg_gram64<true, 2>};
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)kg_gram64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess ||
-        hipFuncSetAttribute((const void*)kg_gram64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
-      set_last_error("gram64: LDS attribute"); return ERR_LAUNCH;
-    }
+    for (const void* k : kerns)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * GT * (256 * 2 + 16) + 2 * 4 * GT * sizeof(float))) != hipSuccess) {
+        set_last_error("gram64: LDS attribute"); return ERR_LAUNCH;
+      }
     attr = true;
   }
   const int used = (int)cdiv(ntiles, (long)tpb);
-  if (w) hipLaunchKernelGGL((kg_gram64<true>), dim3(used), dim3(256), sh, st, (const unsigned short*)Zp, w, part, (long)d.NT, tpb);
-  else hipLaunchKernelGGL((kg_gram64<false>), dim3(used), dim3(256), sh, st, (const unsigned short*)Zp, w, part, (long)d.NT, tpb);
+  const unsigned short* zp = (const unsigned short*)Zp;
+  if (d.E == 4) {
+    if (w) hipLaunchKernelGGL((kg_gram64<true, 4>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
+    else hipLaunchKernelGGL((kg_gram64<false, 4>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
+  } else {
+    if (w) hipLaunchKernelGGL((kg_gram64<true, 2>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
+    else hipLaunchKernelGGL((kg_gram64<false, 2>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
+  }
   AVMOE_CHECK_LAUNCH("gram64");
   const int ncol = d.g * d.E * d.dgp * d.dgp;
   return k_colsum_f32(part, used, ncol, ncol, 1, 0, out, 0, scale, st);
