@@ -223,3 +223,49 @@ def test_router_topk_matches_stable_sort_and_argmax():
     run = MoeRun(cfg, P, B, t["X"], t["Y"], training=True).forward()
     top2 = topk_experts(run.probs, 2).cpu()
     assert torch.equal(top2[:, 0], t["idx"]) and torch.equal(top2, torch.sort(t["probs"], dim=-1, descending=True, stable=True).indices[:, :2])
+
+
+@pytest.mark.parametrize("concurrent", [False, True])
+def test_adapter_pair_with_frame_attention_experts(concurrent):
+    """AdapterPair over sites whose unimodal experts use MultiheadAttention across the frames (is_self_attention, "v1"): the
+    dropout draw of each site travels with its forward state to the backward, on either stream."""
+    from avmoe_amd.adapters import AdapterPair
+    from avmoe_amd._capi_moe import SA_KEEP
+    dev = torch.device("cuda:0")
+    S = 5
+    ca = O.AdapterConfig(Cx=64, Nx=40, Cy=96, Ny=24, reduction=4, groups=2, K=8, self_attn="v1")
+    cb = O.AdapterConfig(Cx=96, Nx=24, Cy=64, Ny=40, reduction=4, groups=2, K=8, self_attn="v1")
+    torch.manual_seed(3)
+    sa, sb = build_module("ave", ca).to(dev).train(), build_module("ave", cb).to(dev).train()
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for m, c in ((sa, ca), (sb, cb)):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.3)
+            m.attention_keep = {f"singlemodal_experts.{j}.{SA_KEEP}": (torch.rand(c.Nx * 4, S, S, generator=g) >= 0.2).float() / 0.8
+                                for j in range(c.E_s)}
+    fa = (0.5 * torch.randn(S, ca.Cx, ca.Nx, 1, generator=g)).to(dev)
+    fv = (0.5 * torch.randn(S, cb.Cx, cb.Nx, 1, generator=g)).to(dev)
+    ga, gv = torch.randn(S, ca.Cx, ca.Nx, 1, generator=g).to(dev), torch.randn(S, cb.Cx, cb.Nx, 1, generator=g).to(dev)
+    bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in (sa, sb)]
+
+    def run(paired):
+        for m, bb in zip((sa, sb), bufs):
+            m.zero_grad()
+            m.load_state_dict({**m.state_dict(), **bb})
+        xa, xv = fa.clone().requires_grad_(True), fv.clone().requires_grad_(True)
+        if paired:
+            oa, ia, ov, iv = AdapterPair(sa, sb, concurrent=concurrent)(xa, xv)
+        else:
+            (oa, ia), (ov, iv) = sa(xa, xv), sb(xv, xa)
+        torch.autograd.backward([oa, ov], [ga, gv])
+        return oa.detach(), ov.detach(), xa.grad, xv.grad, [p.grad.clone() for m in (sa, sb) for p in m.parameters()]
+
+    ref, got = run(False), run(True)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    for r_, g_ in ((ref[2], got[2]), (ref[3], got[3])):
+        assert float((r_ - g_).abs().max()) <= 1e-5 * float(r_.abs().max())
+    for r_, g_ in zip(ref[4], got[4]):
+        assert torch.equal(r_, g_)
+    assert any("self_attention.in_proj_weight" in k for k, _ in sa.named_parameters())
