@@ -120,7 +120,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   }
   d.nblk_tok = bps * d.S;
   d.zsz = tile_fast_ok(d) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident path
-  d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2);      // gram.hip is built for 2 and 4 experts
+  d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2) && !getenv("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 
   size_t off[2] = {0, 0};
