@@ -63,10 +63,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   // tokens, 2 - 4 experts: tile_fast.hip): bf16 Z rows of 64 E entries instead of fp32 rows of 4 * g * E * dgp bytes, and kernels
   // that run 1.3-3x faster than the generic ones (HTS-AT / Swin-B sites at r = 8: bottleneck 48: -29 %, 32: -15 %, 24: -19 %,
   // 12 / 16: -4 % of the site step).  Padding columns are zero weights, as for every other padded width.
-  {
-    const bool attn_nxn = d.variant == AVMOE_VARIANT_AVVP || d.self_attn == AVMOE_SELF_ATTN_NXN || d.self_attn == AVMOE_SELF_ATTN_MHA_V1;
-    if (d.g == 2 && d.dg < 32 && d.K == 32 && d.E >= 2 && d.E <= 4 && !(attn_nxn && d.E_s > 0) && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
-  }
+  if (d.g == 2 && d.dg < 32 && d.K == 32 && d.E >= 2 && d.E <= 4 && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
   d.Cg = d.C / d.g;
   d.DD = d.g * d.dgp;
   d.DZ = d.E * d.DD;

@@ -564,7 +564,8 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
 // =====================================================================================================
 // PRE_SMALL forward   (net_trans_v3.py:385-395)
 // =====================================================================================================
-struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before; float ln_eps; };
+struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; long sxr_off[MAX_E]; FastDims t; int ln_before; float ln_eps;
+                  const float* ZR; const float* sxr; };      // x + g xr experts (AVVP N x N block, frame attention): xr through Wt, row sums
 
 template <typename T, int E>
 __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
@@ -584,8 +585,10 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     const int l = a.lat_of_e[e];
+    const bool nxn = a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
+    if (nxn) gv = a.glat.p[e][0];
     if (l >= 0) {
       gv = a.glat.p[e][0];
       const float* tt = TT + ((long)s * t.El + l) * FK * FK;
@@ -656,6 +659,11 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
         Sx += gv * (float)t.C * u1;
         Sxx += 2.f * gv * u2 + gv * gv * u3;
       }
+      if (nxn && ok) {             // x' = x + g xr : sums of x' from the sums of x, xr and x . xr   (mgn.py:132-139)
+        const float* sxr = a.sxr + a.sxr_off[e];
+        Sx += gv * sxr[tok];
+        Sxx += 2.f * gv * sxr[2L * t.NT + tok] + gv * gv * sxr[(long)t.NT + tok];
+      }
       float mu = 0.f, rr = 1.f;
       if (a.ln_before) {
         mu = Sx / (float)t.C;
@@ -665,6 +673,10 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
       for (int c = 0; c < 4; ++c) {
         f32x4 p = {0.f, 0.f, 0.f, 0.f};
         if (l >= 0) p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
+        if (nxn && ok) {           // xr through Wt (fp32 rows in the Z layout)
+          const float4 zr4 = ld4(a.ZR + tok * DZ + (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q);
+          p = f32x4{zr4.x, zr4.y, zr4.z, zr4.w};
+        }
         const float4 ws = ld4(s_c + oz + 16 * c + 4 * q), dc = ld4(s_c + oz + FDD + 16 * c + 4 * q);
         float4 o;
 #pragma unroll
@@ -687,7 +699,8 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
 // =====================================================================================================
 // PRE_SMALL backward
 // =====================================================================================================
-struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before, use_bn, bn_train; };
+struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int first_of_slot[MAX_E]; long sxr_off[MAX_E]; FastDims t;
+                   int ln_before, use_bn, bn_train; const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
 template <typename T, int E>
 __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ TT,
@@ -713,8 +726,10 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     const int l = a.lat_of_e[e];
+    const bool nxn = a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
+    if (nxn) gv = a.glat.p[e][0];
     if (l >= 0) {
       gv = a.glat.p[e][0];
       const float* tt = TT + ((long)s * t.El + l) * FK * FK;
@@ -782,6 +797,25 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
       }
+      float szr = 0.f;
+      if (nxn) {                   // x' = x + g xr : d(xr Wt^T) = g dzraw, and dzraw . (xr Wt^T) for the gate
+        if (ok) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float4 zr4 = ld4(a.ZR + tok * DZ + (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) szr += at(dzr[c], x) * at(zr4, x);
+          }
+#pragma unroll
+          for (int gi = 0; gi < 2; ++gi) {
+            float4 g0, g1;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { at(g0, x) = gv * at(dzr[2 * gi], x); at(g1, x) = gv * at(dzr[2 * gi + 1], x); }
+            st_seg<T>((T*)a.dZR + tok * DZ + gi * (E * FDG) + e * FDG, g0, g1, q);
+          }
+        }
+        szr = qsum4(szr);
+      }
       float dSx = 0.f, dSxx = 0.f;
       if (a.ln_before) {
         const float sdr = qsum4(s_dr), sdm = qsum4(s_dmu);
@@ -795,6 +829,14 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
       if (ok && q == 0) {
         if (e != 0) { accx += dsxs[tok]; accxx += dsxs[t.NT + tok]; }
         dsxs[tok] = accx; dsxs[t.NT + tok] = accxx;
+      }
+      if (nxn && ok && q == 0) {   // statistics gradients to (sum xr, sum xr^2, x . xr) of this expert's xr slot, and to the gate
+        float* dsr = a.dsr + a.sxr_off[e];
+        const float* sxr = a.sxr + a.sxr_off[e];
+        const float v0 = gv * dSx, v1 = 2.f * gv * gv * dSxx, v2 = 2.f * gv * dSxx;
+        if (a.first_of_slot[e]) { dsr[tok] = v0; dsr[(long)t.NT + tok] = v1; dsr[2L * t.NT + tok] = v2; }
+        else { dsr[tok] += v0; dsr[(long)t.NT + tok] += v1; dsr[2L * t.NT + tok] += v2; }
+        sdg += dSx * sxr[tok] + dSxx * (2.f * sxr[2L * t.NT + tok] + 2.f * gv * sxr[(long)t.NT + tok]) + szr;
       }
       if (l >= 0) {
         const long lo = tok * t.KLp + (long)l * FK + 4 * q;
@@ -896,9 +938,9 @@ void fast_grid(const Dims& d, dim3* grid, int* per) {
 
 }  // namespace
 
-// The register-resident kernels cover exactly: bottleneck 64 in 2 groups, 32 latent tokens, 2 - 4 experts, no N x N block.
+// The register-resident kernels cover exactly: bottleneck 64 in 2 groups, 32 latent tokens, 2 - 4 experts (any variant).
 bool tile_fast_ok(const Dims& d) {
-  return d.DD == FDD && d.dgp == FDG && d.g == 2 && d.K == FK && d.Kp == FK && d.E >= 2 && d.E <= 4 && !d.nxn;
+  return d.DD == FDD && d.dgp == FDG && d.g == 2 && d.K == FK && d.Kp == FK && d.E >= 2 && d.E <= 4;
 }
 
 #define LAUNCH_TE1(bf16, KERN, NE, ...)                                                                \
@@ -918,7 +960,11 @@ int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   const Dims& d = pl.d;
   dim3 grid; int per; fast_grid(d, &grid, &per);
   FPreArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  for (int e = 0; e < MAX_E; ++e) {
+    a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; a.nxn_of_e[e] = e < d.E ? d.nxn_of_e[e] : 0;
+    a.sxr_off[e] = (e < d.E && d.xr_of_e[e] > 0) ? (long)d.xr_of_e[e] * 3 * d.NT : 0;
+  }
+  a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
   LAUNCH_TE(d.bf16, kf_pre_small, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
@@ -985,7 +1031,20 @@ int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   const Dims& d = pl.d;
   dim3 grid; int per; fast_grid(d, &grid, &per);
   FPreBArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  {
+    bool seen[MAX_E] = {};
+    for (int e = 0; e < MAX_E; ++e) {
+      a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e];
+      a.nxn_of_e[e] = 0; a.first_of_slot[e] = 0; a.sxr_off[e] = 0;
+      if (e < d.E && d.nxn_of_e[e]) {
+        const int slot = d.xr_of_e[e];
+        a.nxn_of_e[e] = 1; a.sxr_off[e] = (long)slot * 3 * d.NT;
+        a.first_of_slot[e] = !seen[slot]; seen[slot] = true;
+      }
+    }
+  }
+  a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
+  a.dZR = (void*)(scratch + pl.o_dZR); a.dsr = (float*)(scratch + pl.o_dsr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
   LAUNCH_TE(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
             (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum),

@@ -403,6 +403,8 @@ static double bytes_pre_small_bwd(const Dims& d) {
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   const Dims& d = pl.d;
   ProfScope ps_("k_pre_small", (long)d.NT, bytes_pre_small(d), 0.0, st);
+  for (int e = 0; e < d.E; ++e)
+    if (d.nxn_of_e[e] && !prm.e[e].gate_lat) { set_last_error("moe: expert %d lacks gate_av", e); return ERR_BAD_ARG; }
   if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
@@ -412,8 +414,6 @@ int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   }
   a.t = make_td(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
-  for (int e = 0; e < d.E; ++e)
-    if (d.nxn_of_e[e] && !prm.e[e].gate_lat) { set_last_error("moe: expert %d lacks gate_av", e); return ERR_BAD_ARG; }
   const TileDims& t = a.t;
   const int K4 = 4 * t.k4;
   const size_t sh = (size_t)(K4 * t.ldb_k + K4 * t.ldb_d + K4 + 4 * 16 * t.lda_k + 4 * 48 + 4 * 2 * t.DD) * sizeof(float);

@@ -57,6 +57,12 @@ CASES = {
     "fast_e1p2": dict(cfg=dict(Cx=128, Nx=97, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avs", E_m=1, E_s=2, lb_loss=True), S=3),
     "ship_stage2_audio": dict(cfg=dict(Cx=384, Nx=256, Cy=512, Ny=144, reduction=8, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=4),
     "ship_stage2_visual": dict(cfg=dict(Cx=512, Nx=144, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=4),
+    # the x + g xr experts on the register-resident path: AVVP (N x N block; 1 + 1 experts, r = 8, 32 tokens is what AVVP/train.sh ships)
+    # and frame attention ("v1")
+    "fast_avvp": dict(cfg=dict(Cx=128, Nx=150, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avvp", lb_loss=True), S=3),
+    "fast_avvp_e1p1_pad": dict(cfg=dict(Cx=384, Nx=97, Cy=192, Ny=50, reduction=8, groups=2, K=32, variant="avvp", E_m=1, E_s=1, lb_loss=True), S=4),
+    "fast_avvp_eval": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avvp", E_m=1, E_s=2), S=2, training=False),
+    "fast_v1": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avs", self_attn="v1", lb_loss=True), S=5, keep=True),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
 }
@@ -96,7 +102,7 @@ def test_midsize_matches_oracle_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
-                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
+                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio", "fast_avvp", "fast_avvp_e1p1_pad", "fast_v1"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path on the register-resident shape (bf16 Z / dz' storage, streaming GEMMs, streaming Gram)
     against the fp32 oracle: outputs within 4e-2, gradients norm-wise 6 % (token tensors) / 12 % (parameters; analytically
