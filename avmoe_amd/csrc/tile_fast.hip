@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
 struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; long sxr_off[MAX_E]; FastDims t; int ln_before; float ln_eps;
                   const float* ZR; const float* sxr; };      // x + g xr experts (AVVP N x N block, frame attention): xr through Wt, row sums
 
-template <typename T, int E>
+template <typename T, int E, bool XR>      // XR: the site has x + g xr experts (AVVP N x N block, frame attention)
 __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
                                                     const float* __restrict__ TT, const float* __restrict__ TW, const float* __restrict__ Tsum,
                                                     const float* __restrict__ wsum, const float* __restrict__ dconst, void* __restrict__ aout_,
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     const int l = a.lat_of_e[e];
-    const bool nxn = a.nxn_of_e[e] != 0;
+    const bool nxn = XR && a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
     if (nxn) gv = a.glat.p[e][0];
@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
 struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int first_of_slot[MAX_E]; long sxr_off[MAX_E]; FastDims t;
                    int ln_before, use_bn, bn_train; const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
-template <typename T, int E>
+template <typename T, int E, bool XR>
 __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ TT,
                                                         const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
                                                         const float* __restrict__ dconst, const void* __restrict__ ain_, const float* __restrict__ rmu,
@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     const int l = a.lat_of_e[e];
-    const bool nxn = a.nxn_of_e[e] != 0;
+    const bool nxn = XR && a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
     if (nxn) gv = a.glat.p[e][0];
@@ -956,6 +956,23 @@ bool tile_fast_ok(const Dims& d) {
     else LAUNCH_TE1(bf16, KERN, 3, __VA_ARGS__);                                                       \
   } while (0)
 
+#define LAUNCH_TEX1(bf16, KERN, NE, XR_, ...)                                                          \
+  do {                                                                                                 \
+    if (bf16) hipLaunchKernelGGL((KERN<__bf16, NE, XR_>), grid, dim3(256), 0, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERN<float, NE, XR_>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+  } while (0)
+#define LAUNCH_TEX2(bf16, KERN, XR_, ...)                                                              \
+  do {                                                                                                 \
+    if (d.E == 4) LAUNCH_TEX1(bf16, KERN, 4, XR_, __VA_ARGS__);                                        \
+    else if (d.E == 2) LAUNCH_TEX1(bf16, KERN, 2, XR_, __VA_ARGS__);                                   \
+    else LAUNCH_TEX1(bf16, KERN, 3, XR_, __VA_ARGS__);                                                 \
+  } while (0)
+#define LAUNCH_TEX(bf16, KERN, ...)                                                                    \
+  do {                                                                                                 \
+    if (d.nxn) LAUNCH_TEX2(bf16, KERN, true, __VA_ARGS__);                                             \
+    else LAUNCH_TEX2(bf16, KERN, false, __VA_ARGS__);                                                  \
+  } while (0)
+
 int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   const Dims& d = pl.d;
   dim3 grid; int per; fast_grid(d, &grid, &per);
@@ -966,7 +983,7 @@ int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   }
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
-  LAUNCH_TE(d.bf16, kf_pre_small, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
+  LAUNCH_TEX(d.bf16, kf_pre_small, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu),
             (float*)(scratch + pl.o_colpart));
@@ -1046,7 +1063,7 @@ int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.dZR = (void*)(scratch + pl.o_dZR); a.dsr = (float*)(scratch + pl.o_dsr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
-  LAUNCH_TE(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
+  LAUNCH_TEX(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
             (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum),
             (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a), (const float*)(saved + pl.o_rmu),
             (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const void*)(scratch + pl.o_dzp),
