@@ -43,8 +43,13 @@ class MoeRun:
         nscratch = self.L.avmoe_moe_scratch_bytes(C.byref(self.desc))
         if nsaved == 0:
             raise capi.AvmoeError(self.L.avmoe_last_error().decode())
-        self.saved = torch.zeros(nsaved, dtype=torch.uint8, device=dev)
-        self.scratch = torch.zeros(nscratch, dtype=torch.uint8, device=dev)
+        # workspaces exactly as large as the library asks for, followed by a guard band the kernels must never touch
+        self.GUARD = 4096
+        self._saved_all = torch.full((nsaved + self.GUARD,), 0xAB, dtype=torch.uint8, device=dev)
+        self._scratch_all = torch.full((nscratch + self.GUARD,), 0xAB, dtype=torch.uint8, device=dev)
+        self._saved_all[:nsaved] = 0
+        self._scratch_all[:nscratch] = 0
+        self.saved, self.scratch = self._saved_all[:nsaved], self._scratch_all[:nscratch]
         self.table = {n: (r, o, b) for (n, r, o, b) in cm.buffer_table(self.L, self.desc)}
         self.out = torch.empty_like(self.X)
         self.probs = torch.empty(S, cfg.E, device=dev, dtype=torch.float32)
@@ -81,6 +86,10 @@ class MoeRun:
         g = {k: v.cpu() for k, v in self.grads.items()}
         g["X"], g["Y"] = self.dX.float().cpu(), self.dY.float().cpu()
         return g
+
+    def guards_intact(self):
+        """True when no kernel wrote past the end of the saved / scratch workspace."""
+        return bool((self._saved_all[-self.GUARD:] == 0xAB).all()) and bool((self._scratch_all[-self.GUARD:] == 0xAB).all())
 
     def buf(self, name, dtype=None, shape=None):
         """Workspace buffer `name` as a CPU tensor (dtype: torch dtype of the elements)."""

@@ -72,6 +72,7 @@ def test_random_configuration_matches_oracle(seed):
     gmax = max(s for _, s in errs.values())
     bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax)}
     assert not bad, (cfg, bad)
+    assert run.guards_intact(), ("a kernel wrote past its workspace", cfg)
 
 
 @pytest.mark.parametrize("seed", SEEDS)
@@ -113,3 +114,4 @@ def test_random_configuration_bf16_close_to_oracle(seed):
         if err > tol * max(refn[k], 0.25 * gmax if k not in ("X", "Y") else refn[k]) + 1e-7:
             bad[k] = (err, refn[k])
     assert not bad, (cfg, bad)
+    assert run.guards_intact(), ("a kernel wrote past its workspace", cfg)

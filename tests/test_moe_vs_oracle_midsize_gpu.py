@@ -99,6 +99,7 @@ def test_midsize_matches_oracle_fp32(name):
     gmax = max(s for _, s in errs.values())
     bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax)}
     assert not bad, bad
+    assert run.guards_intact(), "a kernel wrote past its workspace"
 
 
 @pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
