@@ -142,11 +142,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the adapter path has no CPU fallback")
+    if os.environ.get("AVMOE_BENCH_BACKEND", "nccl") != "nccl":      # development: several ranks share the GPUs that exist
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("AVMOE_BENCH_BACKEND", "nccl")      # "gloo": development only (several ranks on one GPU)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from avmoe_amd import _capi as capi
@@ -170,8 +176,8 @@ def main():
     g_v = torch.randn(S, c["N_v"], c["C"], generator=g).to(device, tdt)
     ga4, gv4 = g_a.permute(0, 2, 1).unsqueeze(-1), g_v.permute(0, 2, 1).unsqueeze(-1)
 
-    def step():
-        reducer.begin(sync=True)
+    def step(sync=True):
+        reducer.begin(sync=sync)
         xa, xv = f_a.permute(0, 2, 1).unsqueeze(-1), f_v.permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
         if args.pair == "off":
             out_a, _ = audio(xa, xv)                   # net_trans_v3.py:695
@@ -210,14 +216,15 @@ def main():
         # back to back here (AdapterPair(concurrent=False)) so that every kernel is timed with the GPU to itself; the timed
         # region above overlaps them on two streams, which stretches each kernel's own duration.
         L = capi.lib()
+        # Rank 0 only: the steps of this pass must not enter a collective (sync=False = an accumulation micro-step).
         pair_timed, pair = pair, AdapterPair(audio, visual, concurrent=False)
         for _ in range(2):
-            step()
+            step(sync=False)
         L.avmoe_prof_reset()
         L.avmoe_prof_enable(1)
         nprof = 3
         for _ in range(nprof):
-            step()
+            step(sync=False)
         torch.cuda.synchronize()
         L.avmoe_prof_enable(0)
         pair = pair_timed

@@ -98,3 +98,21 @@ def test_data_parallel_step_world2_on_one_gpu():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_bench_two_ranks_finish_and_print_one_line():
+    """The driver's multi-GPU invocation of bench.py (torch.distributed.run, --gpus N): every rank must reach the end -- rank 0's
+    roofline pass may not enter a collective the other ranks never join -- and rank 0 prints exactly one JSON line.  Two ranks on
+    one GPU with gloo (AVMOE_BENCH_BACKEND, development switch); RCCL needs one GPU per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, AVMOE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["roofline"] is not None and d["cpu_baseline"] is None
+    assert d["config"]["grad_allreduce_bytes"] > 0
