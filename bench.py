@@ -271,6 +271,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                       # the other ranks wait for rank 0's profiling pass: clean teardown of the communicator
         dist.destroy_process_group()
 
 
