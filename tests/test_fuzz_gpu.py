@@ -44,6 +44,23 @@ import os
 SEEDS = range(int(os.environ.get("AVMOE_FUZZ_FROM", "0")), int(os.environ.get("AVMOE_FUZZ_TO", "48")))      # widen for a one-off sweep
 
 
+def relu_margin(P, B, X, Y, cfg, training, noise, keep):
+    """Smallest |pre-activation| in front of the cross-modal experts' ReLU in the oracle's forward: a value within rounding of 0
+    makes the mask -- and with it the gradients -- depend on the summation order (seen once in ~1000 random configurations)."""
+    mins, orig = [1.0], O.F.relu
+
+    def rec(x, inplace=False):
+        if x.dim() == 3 and x.shape[-1] == cfg.d:
+            mins.append(float(x.abs().min()))
+        return orig(x)
+    O.F.relu = rec
+    try:
+        O.moe_forward(P, B, X, Y, cfg, training=training, noise=noise, mha_keep=keep, update_buffers=False)
+    finally:
+        O.F.relu = orig
+    return min(mins)
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_configuration_matches_oracle(seed):
     from tests.moe_gpu_util import MoeRun
@@ -63,6 +80,8 @@ def test_random_configuration_matches_oracle(seed):
     top2 = torch.topk(fwd["probs"], min(2, cfg.E), dim=-1).values
     if cfg.E > 1 and float((top2[:, 0] - top2[:, -1]).min()) < 1e-4:
         pytest.skip("router margin below the fp32 noise of two different summation orders")
+    if relu_margin(P, B, X, Y, cfg, training, noise, keep) < 1e-5:
+        pytest.skip("a ReLU pre-activation within fp32 rounding of zero: the gradient is not defined to 1e-3 there")
     run = MoeRun(cfg, P, B, X, Y, bf16=False, training=training, noise=noise, mha_keep=keep).forward()
     assert torch.equal(run.idx.cpu(), fwd["idx"]), cfg
     scale = float(fwd["out"].abs().max())
@@ -70,7 +89,9 @@ def test_random_configuration_matches_oracle(seed):
     got = run.backward(G, lb_weight=lbw)
     errs = grad_errors(got, {f"grad.{k}": v for k, v in grads.items()})
     gmax = max(s for _, s in errs.values())
-    bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax)}
+    # (absolute floor 1e-4: gradients that are analytically zero -- a bias in front of a BatchNorm -- are sums of O(1) terms
+    #  cancelling to fp32 rounding on both sides)
+    bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax) and e > 1e-4}
     assert not bad, (cfg, bad)
     assert run.guards_intact(), ("a kernel wrote past its workspace", cfg)
 
