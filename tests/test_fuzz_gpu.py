@@ -1,6 +1,7 @@
 """Seeded random configurations (variants, expert counts, bottlenecks, groups, latent tokens, flags, ragged token counts) through
 the C ABI against the oracle in fp32 (1e-3, indices exact): catches interactions the hand-picked cases miss -- padded
 bottlenecks, the register-resident path with 2 / 3 / 4 experts, the batch fold, the 32-tile, the attention variants."""
+import os
 import random
 
 import pytest
@@ -33,14 +34,15 @@ def random_case(seed):
         self_attn = "v1"
     if self_attn == "v1" and ((Cx // 4) % 8 or E_s == 0):
         self_attn = "none"
-    cfg = O.AdapterConfig(Cx=Cx, Nx=rng.choice([5, 17, 40, 64, 97, 130]), Cy=8 * rng.randint(2, 12), Ny=rng.choice([3, 20, 50, 77]),
+    big = bool(os.environ.get("AVMOE_FUZZ_BIG"))          # one-off sweeps: token counts that span several blocks / streaming tiles
+    cfg = O.AdapterConfig(Cx=Cx, Nx=rng.choice([300, 333, 512, 640, 777, 1024] if big else [5, 17, 40, 64, 97, 130]),
+                          Cy=8 * rng.randint(2, 12), Ny=rng.choice([64, 150, 196, 300] if big else [3, 20, 50, 77]),
                           E_m=E_m, E_s=E_s, reduction=red, groups=g, K=K, variant=variant, self_attn=self_attn,
                           use_bn=rng.random() < 0.85, use_gate=rng.random() < 0.85, ln_before=rng.random() < 0.7,
                           ln_post=rng.random() < 0.8, lb_loss=variant in ("avvp", "avs") and rng.random() < 0.6)
-    return cfg, rng.choice([1, 2, 3, 5]), rng.random() < 0.8
+    return cfg, rng.choice([2, 4, 7] if big else [1, 2, 3, 5]), rng.random() < 0.8
 
 
-import os
 SEEDS = range(int(os.environ.get("AVMOE_FUZZ_FROM", "0")), int(os.environ.get("AVMOE_FUZZ_TO", "48")))      # widen for a one-off sweep
 
 
@@ -92,6 +94,8 @@ def test_random_configuration_matches_oracle(seed):
     # (absolute floor 1e-4: gradients that are analytically zero -- a bias in front of a BatchNorm -- are sums of O(1) terms
     #  cancelling to fp32 rounding on both sides)
     bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax) and e > 1e-4}
+    if training and cfg.use_bn and not cfg.ln_before:      # a channel shift in front of a train-mode BatchNorm: its gradient is exactly 0,
+        bad = {k: v for k, v in bad.items() if not k.endswith("self_attention.out_proj.bias")}      # both sides hold cancellation noise
     assert not bad, (cfg, bad)
     assert run.guards_intact(), ("a kernel wrote past its workspace", cfg)
 
