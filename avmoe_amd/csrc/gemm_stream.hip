@@ -379,6 +379,18 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #ifndef SC_DX_PC
 #define SC_DX_PC 1
 #endif
+#ifndef SC_ON_BM
+#define SC_ON_BM 32
+#endif
+#ifndef SC_ON_PC
+#define SC_ON_PC 6
+#endif
+#ifndef SC_DXN_PC
+#define SC_DXN_PC 4
+#endif
+#ifndef SC_DXN_BM
+#define SC_DXN_BM 32
+#endif
 #ifndef SC_DY_PC
 #define SC_DY_PC 1
 #endif
@@ -393,6 +405,12 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     } else if (a.accumulate) return 1;                                              \
     return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, false>(s, a.nb2, PERCU_, st);   \
   }
+  // narrow channel groups (C / g <= 64: the first stages of Swin / HTS-AT): long row tiles, few waves -- the wide configurations
+  // below leave most of their waves without a column tile there
+  STREAM_CASE(ks <= 2 && ks2 == 0, 2, 0, 2, 6, 128, 4, false, false, "gemm_stream_k64_n192")    // down projection / dApost from <= 64 channels per group
+  STREAM_CASE(tiles <= 4, 5, 0, 1, 4, SC_ON_BM, SC_ON_PC, false, true, "gemm_stream_k160_n64")               // output GEMM into <= 64 channels per group
+  STREAM_CASE(tiles <= 4 && a.M % SC_DXN_BM == 0, 4, 3, 1, 4, SC_DXN_BM, SC_DXN_PC, false, true, "gemm_stream_k128+96_n64")   // dX of such a site
+  STREAM_CASE(tiles <= 12 && a.M % 64 == 0, 2, 3, 1, 12, 64, 1, true, true, "gemm_stream_k64+96mn_n192")   // dY into <= 192 channels
   STREAM_CASE(true, 5, 0, 2, 12, SC_OUT_BM, SC_OUT_PC, false, true, "gemm_stream_k160_n384")    // output GEMM: K = 4*32 + 12, N = 384 per group (+= for accumulate_out)
   STREAM_CASE(true, 12, 0, 2, 4, 32, SC_DOWN_PC, false, false, "gemm_stream_k384_n128")   // grouped down projection
   STREAM_CASE(true, 12, 0, 1, 9, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)

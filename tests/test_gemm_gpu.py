@@ -274,3 +274,19 @@ def test_small_batched_problems_take_the_32_tile(dtype, a_mn, b_mn):
     for (M, N, K, ks) in ((10, 10, 16, 1), (32, 32, 200, 1), (10, 16, 10, 1), (24, 31, 1000, 4)):
         got, ref = _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=3, nb2=4, ksplit=ks, seed=M + N)
         assert float((got - ref).abs().max()) <= _tol(dtype) * float(ref.abs().max()), (M, N, K, ks)
+
+
+@pytest.mark.parametrize("case", [
+    dict(M=8200, N=48, K=140, b_mn=False, nb2=2, out_bf16=True),                    # output GEMM into 48 channels per group
+    dict(M=8200, N=64, K=70, b_mn=False, nb2=2, out_bf16=True, accumulate=True),    # ... accumulating (residual stream)
+    dict(M=9001, N=128, K=48, b_mn=False, nb2=2),                                   # down projection from 48 channels per group
+    dict(M=8197, N=140, K=64, b_mn=True, nb2=2),                                    # dApost from 64 channels per group
+    dict(M=8193, N=12, K=8, b_mn=True, nb2=3),                                      # tiny everything
+])
+def test_streaming_kernel_narrow_channel_groups(case):
+    """The narrow-group configurations of the streaming kernel (C / g <= 64: first Swin / HTS-AT stages) against fp64."""
+    case = dict(case)
+    out_bf16 = case.get("out_bf16", False)
+    got, ref = _run_gemm(case.pop("M"), case.pop("N"), case.pop("K"), 1, False, case.pop("b_mn"), seed=17, **case)
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < (2e-2 if out_bf16 else 1e-4), float(err)
