@@ -1046,13 +1046,21 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
 
 namespace avmoe {
 
-// waves per block: as many (4, 2, 1) as the LDS budget allows
+// waves per block (1 .. 4): the count that puts the most waves on a CU within its 160 KB of LDS -- e.g. 3 waves x 2 blocks
+// rather than 4 waves x 1 block when a 4-wave block needs more than half of it (bottlenecks above 64)
 static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes) {
-  for (int nw = 4; nw >= 1; nw >>= 1) {
-    *bytes = (fixed_floats + nw * per_wave_floats) * sizeof(float);
-    if (*bytes <= 160 * 1024) return nw;
+  static const bool old_rule = getenv("AVMOE_PICK_WAVES_POW2") != nullptr;      // dev switch
+  int best = 0, best_occ = 0;
+  for (int nw = 4; nw >= 1; --nw) {
+    if (old_rule && nw == 3) continue;
+    const size_t b = (fixed_floats + nw * per_wave_floats) * sizeof(float);
+    if (b > 160 * 1024) continue;
+    if (old_rule) { best = nw; break; }
+    const int occ = nw * (int)std::min<size_t>(8, (160 * 1024) / b);
+    if (occ > best_occ) { best_occ = occ; best = nw; }
   }
-  return 0;
+  if (best) *bytes = (fixed_floats + best * per_wave_floats) * sizeof(float);
+  return best;
 }
 
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
