@@ -285,6 +285,13 @@ def main():
               is_training_flag=False, seed=13)
     make_case("avs_k87_train", "avs", A(Cx=96, Nx=40, Cy=64, Ny=56, reduction=8, groups=2, K=87,
                                         variant="avs"), 3, is_training_flag=False, seed=14)
+    # the register-resident shape family on vectors from the reference: AVVP as shipped (1 + 1 experts, 32 tokens), frame attention,
+    # and the shipped AVE setting (1 + 1 experts, r = 8: bottleneck 24 zero-padded on the HIP side)
+    fast = dict(Cx=128, Nx=40, Cy=64, Ny=24, reduction=2, groups=2, K=32)
+    make_case("avvp_fast_train", "avvp", A(**fast, variant="avvp", E_m=1, E_s=1, lb_loss=True), 4, lb_weight=1.0, seed=31)
+    make_case("avs_v1_fast_train", "avs", A(**fast, variant="avs", self_attn="v1", E_m=2, E_s=2, lb_loss=True), 4,
+              is_training_flag=False, lb_weight=0.01, seed=32)
+    make_case("ave_ship_train", "ave", A(Cx=192, Nx=40, Cy=96, Ny=24, reduction=8, groups=2, K=32, variant="ave", E_m=1, E_s=1), 4, seed=33)
     # one wide case with the cfg-2 channel width / bottleneck (C=768, d=64, K=32), few tokens
     make_case("ave_wide_train", "ave", A(Cx=768, Nx=64, Cy=192, Ny=49, reduction=12, groups=2, K=32,
                                          variant="ave"), 2, seed=15)

@@ -35,7 +35,7 @@ def build_module(which, cfg):
 
 @pytest.mark.parametrize("name", ["ave_train", "ave_nobn", "ave_noln_nogate", "avqa_train", "avvp_train",
                                   "avs_train_noise", "avs_v2_train", "avs_ms3_eval", "avs_k87_train", "avs_v1_train",
-                                  "avs_v1_eval"])
+                                  "avs_v1_eval", "avvp_fast_train", "avs_v1_fast_train", "ave_ship_train"])
 def test_state_dict_matches_reference_checkpoint_layout(name):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)

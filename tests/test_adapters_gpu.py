@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", ["ave_train", "ave_eval", "avqa_train", "avvp_train", "avs_train_nonoise", "avs_v2_train", "ave_noln_nogate",
-                                  "avs_v1_train", "avs_v1_eval"])
+                                  "avs_v1_train", "avs_v1_eval", "avvp_fast_train", "avs_v1_fast_train", "ave_ship_train"])
 def test_module_forward_backward_matches_reference_vectors(name):
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
