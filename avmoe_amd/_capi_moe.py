@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 MAX_EXPERTS = 16
 VARIANT = {"ave": 0, "avqa": 0, "avvp": 1, "avs": 2}

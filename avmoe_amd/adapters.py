@@ -18,7 +18,7 @@ missing library or a non-GPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn
