@@ -25,17 +25,7 @@ template <> __device__ __forceinline__ float roundTb<float>(float v) { return v;
 template <> __device__ __forceinline__ float roundTb<__bf16>(float v) { return bf2f(f2bf(v)); }
 
 static inline unsigned grid1db(long n, int cap = 4096) { return (unsigned)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
-static void tok_grid_b(const Dims& d, dim3* grid) { *grid = dim3((unsigned)(d.nblk_tok / d.S), (unsigned)d.S); }
-static int lds_attr(const void* fn, size_t bytes, const char* what) {
-  if (bytes <= 65536) return OK;
-  if (bytes > 160 * 1024) { set_last_error("%s needs %zu B of LDS", what, bytes); return ERR_UNSUPPORTED; }
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) { set_last_error("%s: LDS attribute: %s", what, hipGetErrorString(e)); return ERR_LAUNCH; }
-  return OK;
-}
 
-constexpr int DR = 4;   // ceil(DD / 64) upper bound (DD <= 256)
-constexpr int KR = 2;   // ceil(K / 64) upper bound (K <= 128)
 
 // (the per-token backward kernels live in tile_kernels.hip; this file keeps their finalize / weight-space parts)
 

@@ -334,7 +334,6 @@ __global__ void __launch_bounds__(256) kk_xstats(const void* X_, int N, int C, i
 int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st) {
   const Dims& d = pl.d;
   ProfScope ps_("k_xstats", (long)d.NT, (double)d.NT * ((double)d.C * d.esz + 8.0), 0.0, st);
-  const int epv = 16 / d.esz;
   if (d.C > 1536) { set_last_error("xstats: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
   const int rpb = (int)round_up(cdiv(d.N, d.xchunks), 64);      // a block sweeps 64 rows per step (4 waves x 4 quartets x 4 rows)
   const int nchunk = cdiv(d.N, rpb);                            // <= d.xchunks (xpart is sized by that)
