@@ -88,20 +88,6 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 template <typename T> __device__ __forceinline__ float rndT(float v);
 template <> __device__ __forceinline__ float rndT<float>(float v) { return v; }
 template <> __device__ __forceinline__ float rndT<__bf16>(float v) { return bf2f(f2bf(v)); }
-template <typename T> __device__ __forceinline__ float4 ldT4(const T* p);
-template <> __device__ __forceinline__ float4 ldT4<float>(const float* p) { return *(const float4*)p; }
-template <> __device__ __forceinline__ float4 ldT4<__bf16>(const __bf16* p) {
-  const uint2 u = *(const uint2*)p;
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-}
-template <typename T> __device__ __forceinline__ void stT4(T* p, float4 v);
-template <> __device__ __forceinline__ void stT4<float>(float* p, float4 v) { *(float4*)p = v; }
-template <> __device__ __forceinline__ void stT4<__bf16>(__bf16* p, float4 v) {
-  uint2 u;
-  u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-  u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-  *(uint2*)p = u;
-}
 // ---- 32-wide bf16 segments (one expert's 32 bottleneck entries of a group / one latent slot's 32 tokens) as ONE 16-byte access
 // per lane: lanes q and q^1 trade quads with v_permlane16_swap, so that lane q even holds entries 4q .. 4q+7 of the first
 // 16-chunk and lane q odd entries 4(q-1) .. 4(q-1)+7 of the second -- the four q lanes cover the 64-byte segment contiguously.
@@ -207,9 +193,6 @@ __device__ __forceinline__ float block_scalar(float v, float* s4) {   // sum of 
   if (lane == 0) s4[wave] = v;
   __syncthreads();
   return s4[0] + s4[1] + s4[2] + s4[3];
-}
-__device__ __forceinline__ float wsum_q0(float v, int q) {   // sum over the 16 lanes with q == 0 of v (others contribute 0)
-  return wave_sum(q == 0 ? v : 0.f);
 }
 
 // =====================================================================================================
