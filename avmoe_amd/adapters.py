@@ -27,6 +27,25 @@ from . import _capi as capi
 from . import _capi_moe as cm
 
 _SCRATCH: Dict[tuple, torch.Tensor] = {}
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """THE side stream of a device: every AdapterPair shares it (pairs run one after another, so one second stream -- and one
+    second scratch workspace -- is all the concurrency there is to have)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def release_workspaces():
+    """Drops the cached transient workspaces (one per device and stream) -- e.g. after the largest site shape of a run has
+    changed.  Synchronises first: kernels still in flight may be using them."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _SCRATCH.clear()
 
 
 def _scratch(dev: torch.device, nbytes: int) -> torch.Tensor:
@@ -99,7 +118,7 @@ def _site_backward(module, state, names, params, needs, d_out, d_lb, dX, dY, acc
     sink = getattr(module, "_grad_sink", None)
     use_sink = sink is not None and all(needs) and sink.matches(names, tensors)
     if use_sink:
-        flat = sink.flat if sink.fresh else torch.empty_like(sink.flat)
+        flat = sink.flat if sink.fresh else torch.zeros_like(sink.flat)     # zeros: the alignment padding is added too
         grads = {k: flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
     else:
         grads = {k: (torch.empty_like(v) if needs[i] else None) for i, (k, v) in enumerate(tensors.items())}
@@ -433,6 +452,24 @@ class MoEAdapterAVS(MoEAdapter):
         return out, idx.unsqueeze(-1), probs.unsqueeze(1), (lb if self.opt.use_load_balacing_loss == 1 else 0.)
 
 
+def _storage_range(t: torch.Tensor):
+    lo = t.untyped_storage().data_ptr()
+    return lo, lo + t.untyped_storage().nbytes()
+
+
+def _safe_inplace(base: torch.Tensor, others) -> bool:
+    """May `base` be overwritten in place?  It has to own its storage (not a view of something else somebody may read)
+    and that storage must not overlap any of `others`."""
+    if base._base is not None or base.untyped_storage().nbytes() != base.numel() * base.element_size():
+        return False
+    lo, hi = _storage_range(base)
+    for o in others:
+        olo, ohi = _storage_range(o)
+        if lo < ohi and olo < hi:
+            return False
+    return True
+
+
 class AdapterPair(nn.Module):
     """The two AVE / AVQA adapter sites of one backbone layer run as one autograd node:
 
@@ -462,7 +499,10 @@ class AdapterPair(nn.Module):
         Xb = x_b.squeeze(-1).permute(0, 2, 1)
         Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
         if self.concurrent and self._side is None:
-            self._side = torch.cuda.Stream(device=x_a.device)
+            self._side = side_stream(x_a.device)
+        for base, X in zip(add_to, (Xa, Xb)):
+            if base is not None and not _safe_inplace(base, (Xa, Xb)):
+                raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, self._side if self.concurrent else None, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())

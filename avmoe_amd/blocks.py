@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 from torch import nn
 
-from .adapters import AdapterPair, MoEAdapter
+from .adapters import AdapterPair, MoEAdapter, _safe_inplace
 
 
 class AdapterIndexRecord:
@@ -123,8 +123,9 @@ class DualBackboneLoop(nn.Module):
         fuse = self.fuse_residual and isinstance(pair, AdapterPair) and base_a is not None
         # in place only into a fresh sum: not one of the adapters' own inputs (saved for their backward), and produced by an
         # addition (whose backward does not read its result)
+        # ... that owns its storage and does not overlap the adapters' inputs (adapters._safe_inplace); otherwise base + out
         ok = lambda t: fuse and t.is_contiguous() and t.dtype == f_a.dtype and t.is_cuda and \
-            t.data_ptr() not in (f_a.data_ptr(), f_v.data_ptr()) and \
+            _safe_inplace(t, (f_a, f_v)) and \
             (not t.requires_grad or type(t.grad_fn).__name__.startswith("AddBackward"))
         in_a, in_v = (base_a if ok(base_a) else None), (base_v if ok(base_v) else None)
         if in_a is not None or in_v is not None:

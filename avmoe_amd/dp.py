@@ -25,15 +25,20 @@ import torch
 import torch.distributed as dist
 
 
+ALIGN = 64        # elements: every parameter's slice of a flat bucket starts 256-byte aligned -- FlatAdam re-points param.data to
+                  # the same offsets and the GEMM engine wants 16-byte aligned operands (the rule of MoEAdapter.grad_layout)
+
+
 class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter], device, dtype):
         self.params = params
-        n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n, device=device, dtype=dtype)
-        off = 0
+        self.offsets, off = [], 0
         for p in params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            self.offsets.append(off)
+            off += -(-p.numel() // ALIGN) * ALIGN
+        self.flat = torch.zeros(off, device=device, dtype=dtype)
+        for p, o in zip(params, self.offsets):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
         self.pending = len(params)
         self.work = None
 
@@ -63,6 +68,7 @@ class _SiteBucket:
         names, offs, total = site.grad_layout()
         ps = dict(site.named_parameters())
         self.params = [ps[k] for k in names]
+        self.offsets = list(offs)
         self.flat = torch.zeros(total, device=self.params[0].device, dtype=torch.float32)
         for p, o in zip(self.params, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
@@ -132,13 +138,11 @@ class AdapterGradReducer:
         b = self._owner[p]
         # autograd may have replaced .grad (first accumulation into a None grad): keep the bucket view authoritative
         if p.grad.data_ptr() < b.flat.data_ptr() or p.grad.data_ptr() >= b.flat.data_ptr() + b.flat.numel() * 4:
-            off = 0
-            for q in b.params:
+            for q, off in zip(b.params, b.offsets):
                 if q is p:
                     b.flat[off:off + p.numel()].view_as(p).copy_(p.grad)
                     p.grad = b.flat[off:off + p.numel()].view_as(p)
                     break
-                off += q.numel()
         b.pending -= 1
         if b.pending == 0 and self._sync and self.world > 1:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -55,36 +55,65 @@ class FlatAdam:
     """
 
     def __init__(self, reducer, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 step_size: Optional[int] = None, gamma: float = 0.1, grad_scale: float = 1.0):
+                 step_size: Optional[int] = None, gamma: float = 0.1, grad_scale: float = 1.0, param_groups=None):
+        """param_groups: the list `select_trainable` returns ({"params": p, "lr": ...} per parameter, as handed to
+        torch.optim.Adam at AVE/main_trans_v3.py:313-322): each parameter is stepped with ITS group's learning rate (the
+        reference's `lr_mlp` for the classifier head vs `lr` for the adapters); parameters not listed use `lr`.  Inside a
+        bucket, neighbouring parameters with the same rate share one kernel launch (an adapter site is one range)."""
         self.reducer, self.lr0, self.betas, self.eps, self.wd = reducer, lr, betas, eps, weight_decay
         self.step_size, self.gamma, self.grad_scale = step_size, gamma, grad_scale
         self.t, self.epoch = 0, 0
         self.state = []
+        lr_of = {}
+        for grp in (param_groups or []):
+            ps = grp["params"]
+            for p in ([ps] if isinstance(ps, torch.Tensor) else ps):
+                lr_of[id(p)] = float(grp.get("lr", lr))
         for b in reducer.buckets:
             flat_g = b.flat
             if not flat_g.is_cuda:
                 raise capi.AvmoeError("FlatAdam updates GPU buckets (no CPU fallback)")
             flat_p = torch.zeros_like(flat_g)
+            spans = []                                   # (offset, end, lr) per parameter, in bucket order
             for p in b.params:                           # parameter offsets = offsets of their .grad views in the bucket
                 off = (p.grad.data_ptr() - flat_g.data_ptr()) // 4
                 view = flat_p[off:off + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-            self.state.append(dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_g), v=torch.zeros_like(flat_g)))
+                if view.data_ptr() % 16:
+                    raise capi.AvmoeError("FlatAdam: a re-pointed parameter is not 16-byte aligned (the GEMM engine needs "
+                                          "aligned operands); build the reducer with aligned buckets (avmoe_amd.dp)")
+                spans.append((off, off + p.numel(), lr_of.get(id(p), float(lr))))
+            spans.sort()
+            ranges = []                                  # merged [begin, end, lr0]: alignment padding rides with its left neighbour
+            for i, (o, e, r) in enumerate(spans):
+                end = spans[i + 1][0] if i + 1 < len(spans) else flat_g.numel()
+                if ranges and ranges[-1][2] == r:
+                    ranges[-1][1] = end
+                else:
+                    ranges.append([o if ranges else 0, end, r])
+            self.state.append(dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_g), v=torch.zeros_like(flat_g), ranges=ranges))
+
+    @property
+    def decay(self) -> float:
+        """StepLR factor of the current epoch (AVE/main_trans_v3.py:323)."""
+        return self.gamma ** (self.epoch // self.step_size) if self.step_size else 1.0
 
     @property
     def lr(self) -> float:
-        return self.lr0 * (self.gamma ** (self.epoch // self.step_size)) if self.step_size else self.lr0
+        return self.lr0 * self.decay
 
     def step(self):
         L = capi.lib()
         self.t += 1
         for s in self.state:
-            st = L.avmoe_adam_step(s["p"].data_ptr(), s["g"].data_ptr(), s["m"].data_ptr(), s["v"].data_ptr(),
-                                   C.c_int64(s["p"].numel()), C.c_float(self.lr), C.c_float(self.betas[0]),
-                                   C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(self.wd), C.c_int64(self.t),
-                                   C.c_float(self.grad_scale), torch.cuda.current_stream(s["p"].device).cuda_stream)
-            capi.check(st, "avmoe_adam_step")
+            for (o, e, r) in s["ranges"]:
+                st = L.avmoe_adam_step(s["p"].data_ptr() + 4 * o, s["g"].data_ptr() + 4 * o, s["m"].data_ptr() + 4 * o,
+                                       s["v"].data_ptr() + 4 * o, C.c_int64(e - o), C.c_float(r * self.decay),
+                                       C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                       C.c_float(self.wd), C.c_int64(self.t), C.c_float(self.grad_scale),
+                                       torch.cuda.current_stream(s["p"].device).cuda_stream)
+                capi.check(st, "avmoe_adam_step")
 
     def epoch_end(self):
         self.epoch += 1

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- clip-pairs/sec of the AVMoE adapter hot path (fwd+bwd) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f32] [--no-cpu-baseline] [--no-roofline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3|cfg4|cfg5] [--dtype bf16|f32] ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    (python bench.py --gpus N without a launcher starts that launcher itself, before any GPU call, and relays rank 0's line)
 
-Workload (BASELINE.json configs[1], "cfg-2"): synthetic token tensors f_a:(S=B*T, N_a=1024, C=768),
+Default workload (BASELINE.json configs[1], "cfg-2"): synthetic token tensors f_a:(S=B*T, N_a=1024, C=768),
 f_v:(S, N_v=196, C=768) with B=32 clips x T=10 frames PER GPU, one adapter site = the audio-side MoEAdapter
 (x=f_a, vis_token=f_v) + the visual-side MoEAdapter (x=f_v, vis_token=f_a)  [AVE net_trans_v3.py:695-698],
 4 experts (2 cross-modal + 2 unimodal), bottleneck 64 (reduction 12), 2 conv groups, 32 latent tokens,
@@ -12,52 +13,101 @@ BatchNorm (training mode) + both LayerNorms on, gates = 0.5, bf16 activations wi
 fp32 parameters.  One step = forward of both adapters + backward to both token tensors and every adapter /
 router parameter (+ the RCCL all-reduce of those parameter gradients when N > 1).  Inputs are resident in
 HBM before the timed region.  value = clips processed by all ranks / max-over-ranks time.
+--config cfg1|cfg3|cfg4|cfg5: the multi-site workloads of SURVEY 8(d) (every adapter site pair of the backbone table,
+positions p1 and p2; clip-pairs/s = clips through ALL of them per second).
 
 The JSON line also carries
-  roofline      the dominant kernel family (largest share of GPU time in a HIP-event profiling pass over the
-                same step): algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
+  roofline      PATH level: algorithmic bytes per clip-pair x clip-pairs/s vs the 8 TB/s HBM peak (`frac`), the
+                reference-formulation FLOPs vs the dense MFMA peak beside it (`mfma`), and the dominant kernel family of a
+                HIP-event profiling pass over the same step in the same execution mode as the timed region (`dominant_kernel`)
+  parity        max errors of this very build against oracle/avmoe_oracle.py at the benchmarked shapes with B = 2 clips
+                (fp32: outputs / gradients, router indices; bf16 the same against the oracle on bf16-rounded inputs)
+  value_f32     the same step in fp32 (the configuration held to the 1e-3 bar)
   cpu_baseline  oracle/avmoe_oracle.py (eager PyTorch, fp32) timed on this box's host cores on a bounded
                 sample of the same workload (same shapes, B=2 clips), rank 0 at N=1 only
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 from types import SimpleNamespace as NS
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG2 = dict(B=32, T=10, N_v=196, N_a=1024, C=768, E_m=2, E_s=2, reduction=12, groups=2, K=32)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
+ROUND = "r02"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
+
+# ---- workloads (SURVEY 8a-6 / 8d) --------------------------------------------------------------------------------
+# a site pair: (C_a, N_a, C_v, N_v, count) -- `count` identical pairs (block pairs of the stage x positions p1, p2)
+HTSAT = [(96, 4096), (192, 1024), (384, 256), (768, 64)]
+SWIN_B = [(128, 2304), (256, 576), (512, 144), (1024, 36)]
+SWIN_L = [(192, 2304), (384, 576), (768, 144), (1536, 36)]
+PVT_B5 = [(64, 3136), (128, 784), (320, 196), (512, 49)]
+DEPTH_PAIRS = (2, 2, 6, 2)       # adapted block pairs per stage (net_trans_v3.py:675-680)
+
+
+def _table(vis, stages, positions=2):
+    return [(HTSAT[i][0], HTSAT[i][1], vis[i][0], vis[i][1], DEPTH_PAIRS[i] * positions) for i in stages]
+
+
+CONFIGS = {
+    # BASELINE.json configs[1]: THE metric's configuration
+    "cfg2": dict(B=32, T=10, dtype="bf16", variant="ave", E_m=2, E_s=2, reduction=12, groups=2, K=32,
+                 pairs=[(768, 1024, 768, 196, 1)], what="one AVMoE adapter site (audio-side + visual-side MoEAdapter)"),
+    # configs[0]: AVE, batch 2, Swin-B x HTS-AT, all 12 block pairs x {p1, p2}, r = 8, fp32
+    "cfg1": dict(B=2, T=10, dtype="f32", variant="ave", E_m=2, E_s=2, reduction=8, groups=2, K=32,
+                 pairs=_table(SWIN_B, (0, 1, 2, 3)), what="AVE: Swin-B x HTS-AT, 12 block pairs x {p1,p2} = 24 site pairs"),
+    # configs[2]: AVVP (N x N unimodal attention, LB loss), batch 64, Swin-L x HTS-AT
+    "cfg3": dict(B=64, T=10, dtype="bf16", variant="avvp", E_m=2, E_s=2, reduction=8, groups=2, K=32,
+                 pairs=_table(SWIN_L, (0, 1, 2, 3)), what="AVVP: Swin-L x HTS-AT, 24 site pairs, N x N unimodal attention"),
+    # configs[3]: AVQA, 32 clips per GPU (256 over 8), Swin-L, 1 + 2 experts, 2 latent tokens, 4 groups
+    "cfg4": dict(B=32, T=10, dtype="bf16", variant="avqa", E_m=1, E_s=2, reduction=8, groups=4, K=2,
+                 pairs=_table(SWIN_L, (0, 1, 2, 3)), what="AVQA: Swin-L x HTS-AT, 24 site pairs, 1+2 experts, K=2, 4 groups"),
+    # configs[4]: AVS S4, PVT-v2-b5 x HTS-AT, 4 + 4 experts, bottleneck 128 at the C=512 stage (r = 4), T = 5, K = 87 (the AVS default)
+    "cfg5": dict(B=8, T=5, dtype="bf16", variant="avs", E_m=4, E_s=4, reduction=4, groups=2, K=87,
+                 pairs=[(HTSAT[i][0], HTSAT[i][1], PVT_B5[i][0], PVT_B5[i][1], 2) for i in range(4)],
+                 what="AVS S4: PVT-v2-b5 x HTS-AT, 8 site pairs, 4+4 experts, r=4 (bottleneck 128 at C=512), 87 latent tokens"),
+}
 
 
 def make_opt(c):
     return NS(num_conv_group=c["groups"], is_before_layernorm=1, is_post_layernorm=1, is_self_attention=0,
               self_attention_version="v1", num_multimodal_experts=c["E_m"], num_singlemodal_experts=c["E_s"],
-              use_load_balacing_loss=0)
+              use_load_balacing_loss=1 if c["variant"] in ("avvp", "avs") else 0,
+              Adapter_downsample=c["reduction"], is_bn=1, is_gate=1, num_tokens=c["K"])
 
 
-def build_site(c, device):
-    """The two MoEAdapters of one site, reference default init (seed 0), then gates <- 0.5."""
-    from avmoe_amd.adapters import MoEAdapter
-    torch.manual_seed(0)
-    opt = make_opt(c)
-    mk = lambda Nx, Ny: MoEAdapter(input_dim=c["C"], output_dim=c["C"], adapter_kind="bottleneck", dim_list=None,
-                                   layer_idx=0, reduction_factor=c["reduction"], opt=opt, use_bn=True, use_gate=True,
-                                   num_tk=c["K"], conv_dim_in=Ny, conv_dim_out=Nx, linear_in=c["C"], linear_out=c["C"])
-    audio, visual = mk(c["N_a"], c["N_v"]), mk(c["N_v"], c["N_a"])
+def new_site(c, Cx, Nx, Cy, Ny):
+    """One MoEAdapter of the configuration's task variant, built the way that task's model builds it."""
+    from avmoe_amd import adapters as A
+    common = dict(input_dim=Cx, output_dim=Cx, adapter_kind="bottleneck", dim_list=None, layer_idx=0, opt=make_opt(c),
+                  conv_dim_in=Ny, conv_dim_out=Nx, linear_in=Cy, linear_out=Cx)
+    if c["variant"] == "avvp":
+        return A.MoEAdapterAVVP(**common)
+    if c["variant"] == "avqa":
+        return A.MoEAdapterAVQA(reduction_factor=c["reduction"], use_bn=True, use_gate=True, **common)
+    cls = A.MoEAdapterAVS if c["variant"] == "avs" else A.MoEAdapter
+    return cls(reduction_factor=c["reduction"], use_bn=True, use_gate=True, num_tk=c["K"], **common)
+
+
+def build_pair(c, shape, device, seed=0):
+    """The two MoEAdapters of one site pair, reference default init (seed), then gates <- 0.5."""
+    import torch
+    C_a, N_a, C_v, N_v = shape
+    torch.manual_seed(seed)
+    audio, visual = new_site(c, C_a, N_a, C_v, N_v), new_site(c, C_v, N_v, C_a, N_a)
     for m in (audio, visual):
         with torch.no_grad():
             for k, p in m.named_parameters():
-                if k.endswith(("gate", "gate_av")):
+                if k.endswith(("gate", "gate_av", "gate_self")):
                     p.fill_(0.5)
         m.to(device).train()
     return audio, visual
@@ -65,31 +115,48 @@ def build_site(c, device):
 
 def algorithmic_bytes_per_clip_pair(c, esz):
     """ideal fusion reads f_a,f_v (fwd) + writes 2 residuals + reads 2 upstream grads + re-reads
-    f_a,f_v (bwd) + writes 2 input grads = 5 passes over both token tensors."""
-    return 5.0 * c["T"] * (c["N_a"] + c["N_v"]) * c["C"] * esz
+    f_a,f_v (bwd) + writes 2 input grads = 5 passes over both token tensors, per site pair."""
+    return sum(5.0 * c["T"] * (Na * Ca + Nv * Cv) * esz * cnt for Ca, Na, Cv, Nv, cnt in c["pairs"])
 
 
-def reference_flops_forward(Cx, Nx, Cy, Ny, S, E_m, E_s, d, g, K):
+def reference_flops_forward(Cx, Nx, Cy, Ny, S, E_m, E_s, d, g, K, nxn=False):
     """Algorithmic FLOPs of one MoEAdapter forward in the reference's formulation (multiply-add = 2): token
-    remap + fc, router, the four latent-attention products per cross-modal expert, grouped down + up, mixture."""
+    remap + fc, router, the four latent-attention products per cross-modal expert, grouped down + up, mixture
+    (+ the N x N block of the AVVP unimodal experts)."""
     E = E_m + E_s
     f = 2.0 * S * Nx * Ny * Cy + 2.0 * S * Nx * Cy * Cx
     f += 2.0 * S * (2 * Cx * 128 + 128 * 32 + 32 * E)
     f += E_m * 8.0 * S * K * Cx * Nx
     f += E * 4.0 * S * Nx * Cx * d / g
     f += 2.0 * S * E * Cx * Nx
+    if nxn:
+        f += E_s * 4.0 * S * Nx * Nx * Cx
     return f
 
 
 def reference_flops_per_clip_pair(c):
-    kw = dict(S=c["T"], E_m=c["E_m"], E_s=c["E_s"], d=c["C"] // c["reduction"], g=c["groups"], K=c["K"])
-    return 3.0 * (reference_flops_forward(c["C"], c["N_a"], c["C"], c["N_v"], **kw) +
-                  reference_flops_forward(c["C"], c["N_v"], c["C"], c["N_a"], **kw))
+    tot = 0.0
+    for Ca, Na, Cv, Nv, cnt in c["pairs"]:
+        kw = dict(S=c["T"], E_m=c["E_m"], E_s=c["E_s"], g=c["groups"], K=c["K"], nxn=c["variant"] == "avvp")
+        tot += cnt * 3.0 * (reference_flops_forward(Ca, Na, Cv, Nv, d=Ca // c["reduction"], **kw) +
+                            reference_flops_forward(Cv, Nv, Ca, Na, d=Cv // c["reduction"], **kw))
+    return tot
+
+
+# ---- CPU legs (rank 0, N = 1): the oracle as timed baseline AND as parity checker ------------------------------------
+def _oracle_cfgs(c, shape):
+    from oracle import avmoe_oracle as O
+    Ca, Na, Cv, Nv = shape
+    kw = dict(E_m=c["E_m"], E_s=c["E_s"], reduction=c["reduction"], groups=c["groups"], K=c["K"],
+              variant=c["variant"], lb_loss=c["variant"] in ("avvp", "avs"))
+    return O.AdapterConfig(Cx=Ca, Nx=Na, Cy=Cv, Ny=Nv, **kw), O.AdapterConfig(Cx=Cv, Nx=Nv, Cy=Ca, Ny=Na, **kw)
 
 
 def cpu_baseline(c, budget_s=15.0):
-    """Eager-PyTorch fp32 oracle on the host cores, same shapes at B=2 (S=20): 1 warm-up, then timed steps until ~budget_s of
-    CPU work (3 .. 8 of them); the median is reported."""
+    """Eager-PyTorch fp32 oracle on the host cores, same shapes at B=2: 1 warm-up, then timed steps until ~budget_s of
+    CPU work (3 .. 8 of them); the median is reported.  Returns (json object, the inputs / parameters / results of the last
+    step: parity_check compares the HIP path with them)."""
+    import torch
     from oracle import avmoe_oracle as O
     # eager PyTorch on many tiny bmm/softmax ops gets SLOWER past a few dozen threads (measured on the 256-thread
     # GPU host: 132 s/step with 256 threads); use at most 32 and report the number actually used
@@ -97,31 +164,115 @@ def cpu_baseline(c, budget_s=15.0):
     torch.set_num_threads(cores)
     Bc = 2
     S = Bc * c["T"]
-    mk = lambda Nx, Ny: O.AdapterConfig(Cx=c["C"], Nx=Nx, Cy=c["C"], Ny=Ny, E_m=c["E_m"], E_s=c["E_s"],
-                                        reduction=c["reduction"], groups=c["groups"], K=c["K"])
-    ca, cv = mk(c["N_a"], c["N_v"]), mk(c["N_v"], c["N_a"])
-    Pa, Ba = O.init_params(ca, seed=0)
-    Pv, Bv = O.init_params(cv, seed=1)
+    work = []
     g = torch.Generator().manual_seed(1234)
-    fa = 0.3 * torch.randn(S, c["N_a"], c["C"], generator=g)
-    fv = 0.3 * torch.randn(S, c["N_v"], c["C"], generator=g)
-    ga, gv = torch.randn(fa.shape, generator=g), torch.randn(fv.shape, generator=g)
+    for i, (Ca, Na, Cv, Nv, cnt) in enumerate(c["pairs"]):
+        ca, cv = _oracle_cfgs(c, (Ca, Na, Cv, Nv))
+        Pa, Ba = O.init_params(ca, seed=2 * i)
+        Pv, Bv = O.init_params(cv, seed=2 * i + 1)
+        fa = 0.3 * torch.randn(S, Na, Ca, generator=g)
+        fv = 0.3 * torch.randn(S, Nv, Cv, generator=g)
+        ga, gv = torch.randn(fa.shape, generator=g), torch.randn(fv.shape, generator=g)
+        work.append(dict(ca=ca, cv=cv, Pa=Pa, Ba=Ba, Pv=Pv, Bv=Bv, fa=fa, fv=fv, ga=ga, gv=gv, cnt=cnt))
+    lbw = 0.01 if c["variant"] in ("avvp", "avs") else 0.0
     times = []
     t_start = time.time()
     for it in range(9):
-        t0 = time.time()
-        O.moe_forward_backward(Pa, Ba, fa, fv, ca, ga, training=True)
-        O.moe_forward_backward(Pv, Bv, fv, fa, cv, gv, training=True)
-        dt = time.time() - t0
+        for w in work:      # the `cnt` site pairs of a stage have the same shapes: time one, scale
+            t0 = time.time()
+            w["ra"] = O.moe_forward_backward(w["Pa"], w["Ba"], w["fa"], w["fv"], w["ca"], w["ga"], training=True, lb_weight=lbw)
+            w["rv"] = O.moe_forward_backward(w["Pv"], w["Bv"], w["fv"], w["fa"], w["cv"], w["gv"], training=True, lb_weight=lbw)
+            w["dt"] = time.time() - t0
+        dt = sum(w["dt"] * w["cnt"] for w in work)
         if it > 0:
             times.append(dt)
         if time.time() - t_start > budget_s and len(times) >= 3:
             break
     med = statistics.median(times)
-    return dict(value=Bc / med, unit="clip-pairs/s", cores=cores, kind="port",
-                sample=f"oracle/avmoe_oracle.py eager PyTorch fp32, cfg-2 shapes at B={Bc} clips (S={S} frames), "
-                       f"{len(times)} timed fwd+bwd steps after 1 warm-up, median {med:.2f} s/step, "
-                       f"{torch.get_num_threads()} threads")
+    obj = dict(value=Bc / med, unit="clip-pairs/s", cores=cores, host_cores=os.cpu_count(), kind="port", dtype="f32", clips=Bc,
+               sample=f"oracle/avmoe_oracle.py eager PyTorch fp32, {c['name']} shapes at B={Bc} clips (S={S} frames), "
+                      f"{len(times)} timed fwd+bwd steps after 1 warm-up, median {med:.2f} s/step "
+                      f"(one site pair per distinct shape timed, x its multiplicity), {torch.get_num_threads()} of {os.cpu_count()} host threads; "
+                      f"the GPU value is {c['dtype']} at B={c['B']} clips")
+    return obj, (work, lbw)
+
+
+def parity_check(c, material, device):
+    """This build against the oracle at the benchmarked shapes, B = 2 clips, through the C ABI behind the module API.
+    fp32: max-abs error relative to the tensor's max (gradients: floor 1e-3 of the largest gradient), indices bit-exact.
+    bf16: against the oracle evaluated on the bf16-rounded inputs; outputs max-abs relative, gradients norm-wise relative
+    (worst over the tensors whose norm is at least 1e-3 of the largest gradient norm)."""
+    import torch
+    from oracle import avmoe_oracle as O
+    work, lbw = material
+    res = dict(clips=2, idx_equal=True, out_rel_f32=0.0, grad_rel_f32=0.0, out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None)
+
+    def hip(cfg, P, B, X, Y, G, bf16):
+        m = new_site(c, cfg.Cx, cfg.Nx, cfg.Cy, cfg.Ny)
+        m.load_state_dict({**P, **B})
+        m.to(device).train()
+        tdt = torch.bfloat16 if bf16 else torch.float32
+        Xd, Yd = X.to(device, tdt).requires_grad_(True), Y.to(device, tdt).requires_grad_(True)
+        x4, y4 = Xd.permute(0, 2, 1).unsqueeze(-1), Yd.permute(0, 2, 1).unsqueeze(-1)
+        lb = None
+        if c["variant"] == "avs":
+            out, idx, _p, lb = m(x4, y4, is_training=False)
+        elif c["variant"] == "avvp":
+            out, lb = m(x4, y4)
+            idx = None
+        else:
+            out, idx = m(x4, y4)
+        out_tm = out.squeeze(-1).permute(0, 2, 1)
+        loss = (out_tm.float() * G.to(device)).sum()
+        if torch.is_tensor(lb) and lbw:
+            loss = loss + lbw * lb
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.float().cpu() for k, p in m.named_parameters()}
+        grads["X"], grads["Y"] = Xd.grad.float().cpu(), Yd.grad.float().cpu()
+        return out_tm.detach().float().cpu(), (idx.reshape(-1).cpu() if idx is not None else None), grads
+
+    for w in work:
+        for cfg, P, B, X, Y, G, ref in ((w["ca"], w["Pa"], w["Ba"], w["fa"], w["fv"], w["ga"], w["ra"]),
+                                        (w["cv"], w["Pv"], w["Bv"], w["fv"], w["fa"], w["gv"], w["rv"])):
+            fwd, grads = ref
+            out, idx, got = hip(cfg, P, B, X, Y, G, False)
+            if idx is not None:
+                res["idx_equal"] = res["idx_equal"] and bool(torch.equal(idx, fwd["idx"]))
+            res["out_rel_f32"] = max(res["out_rel_f32"], float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()))
+            gmax = max(float(v.abs().max()) for v in grads.values())
+            for k, v in grads.items():
+                res["grad_rel_f32"] = max(res["grad_rel_f32"], float((got[k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax))
+            if c["dtype"] == "bf16":
+                Xb, Yb, Gb = X.bfloat16().float(), Y.bfloat16().float(), G.bfloat16().float()
+                fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw)
+                out, idx, got = hip(cfg, P, B, X, Y, Gb, True)
+                if idx is not None:
+                    res["idx_equal"] = res["idx_equal"] and bool(torch.equal(idx, fwd["idx"]))
+                res["out_rel_bf16"] = max(res["out_rel_bf16"] or 0.0, float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()))
+                nmax = max(float(v.norm()) for v in grads.values())
+                for k, v in grads.items():
+                    if float(v.norm()) >= 1e-3 * nmax:
+                        e = float((got[k] - v).norm() / v.norm())
+                        if e > (res["grad_relnorm_bf16"] or 0.0):
+                            res["grad_relnorm_bf16"], res["worst_bf16"] = e, k
+    for k in ("out_rel_f32", "grad_rel_f32", "out_rel_bf16", "grad_relnorm_bf16"):
+        if res[k] is not None:
+            res[k] = float(f"{res[k]:.3e}")
+    res["checked_against"] = "oracle/avmoe_oracle.py (pinned on the reference's vectors: tests/test_oracle_golden.py)"
+    return res
+
+
+# ---- launcher ------------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher environment: start `torch.distributed.run` with N ranks as a CHILD process -- before
+    this process has touched the GPU -- and relay its output (rank 0 prints the JSON line)."""
+    port = int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
 
 
 def main():
@@ -129,14 +280,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=CFG2["B"], help="clips per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="default: the configuration's own (cfg1: f32, else bf16)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the configuration's)")
+    ap.add_argument("--reps", type=int, default=3, help="timed repetitions of the K steps (value = the first; the others give the spread)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skips the fp32 re-run (value_f32)")
     ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off"],
-                    help="how the two sites of the layer are run: AdapterPair on two streams / on one stream / two separate calls")
+                    help="how the two sites of a layer are run: AdapterPair on two streams / on one stream / two separate calls")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
 
+    import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,125 +311,197 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from avmoe_amd import _capi as capi
     from avmoe_amd.dp import AdapterGradReducer
+    from avmoe_amd.adapters import AdapterPair
     os.environ.setdefault("AVMOE_PROF_SHAPES", "1")     # profiler families per kernel and launch shape (read at first launch)
     capi.lib()
-    c = dict(CFG2, B=args.batch)
-    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    esz = 2 if args.dtype == "bf16" else 4
+    c = dict(CONFIGS[args.config], name=args.config)
+    if args.batch:
+        c["B"] = args.batch
+    dtype = args.dtype or c["dtype"]
+    c["dtype"] = dtype
+    can_pair = c["variant"] in ("ave", "avqa")
+    pair_mode = args.pair if can_pair else "off"
     S = c["B"] * c["T"]
-    audio, visual = build_site(c, device)
-    params = list(audio.parameters()) + list(visual.parameters())
-    reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=[audio, visual])
-    from avmoe_amd.adapters import AdapterPair
-    pair = AdapterPair(audio, visual, concurrent=(args.pair == "concurrent"))
+    lbw = 0.01 if c["variant"] in ("avvp", "avs") else 0.0
 
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    f_a = (0.3 * torch.randn(S, c["N_a"], c["C"], generator=g)).to(device, tdt).requires_grad_(True)
-    f_v = (0.3 * torch.randn(S, c["N_v"], c["C"], generator=g)).to(device, tdt).requires_grad_(True)
-    g_a = torch.randn(S, c["N_a"], c["C"], generator=g).to(device, tdt)
-    g_v = torch.randn(S, c["N_v"], c["C"], generator=g).to(device, tdt)
-    ga4, gv4 = g_a.permute(0, 2, 1).unsqueeze(-1), g_v.permute(0, 2, 1).unsqueeze(-1)
+    def build_workload(tdt):
+        """modules + resident inputs of every distinct site-pair shape; the `cnt` pairs of a shape share the inputs, not the modules"""
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        work, sites = [], []
+        for i, (Ca, Na, Cv, Nv, cnt) in enumerate(c["pairs"]):
+            f_a = (0.3 * torch.randn(S, Na, Ca, generator=g)).to(device, tdt).requires_grad_(True)
+            f_v = (0.3 * torch.randn(S, Nv, Cv, generator=g)).to(device, tdt).requires_grad_(True)
+            g_a = torch.randn(S, Na, Ca, generator=g).to(device, tdt)
+            g_v = torch.randn(S, Nv, Cv, generator=g).to(device, tdt)
+            mods = []
+            for j in range(cnt):
+                a, v = build_pair(c, (Ca, Na, Cv, Nv), device, seed=100 * i + j)
+                mods.append((a, v, AdapterPair(a, v, concurrent=(pair_mode == "concurrent")) if can_pair else None))
+                sites += [a, v]
+            work.append(dict(f_a=f_a, f_v=f_v, ga4=g_a.permute(0, 2, 1).unsqueeze(-1), gv4=g_v.permute(0, 2, 1).unsqueeze(-1), mods=mods))
+        params = [p for m in sites for p in m.parameters()]
+        return work, AdapterGradReducer(params, bucket_mb=64.0, sites=sites)
 
-    def step(sync=True):
-        reducer.begin(sync=sync)
-        xa, xv = f_a.permute(0, 2, 1).unsqueeze(-1), f_v.permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
-        if args.pair == "off":
-            out_a, _ = audio(xa, xv)                   # net_trans_v3.py:695
-            out_v, _ = visual(xv, xa)                  # net_trans_v3.py:697
-        else:
-            out_a, _, out_v, _ = pair(xa, xv)          # the same two calls as one autograd node (AdapterPair)
-        torch.autograd.backward([out_a, out_v], [ga4, gv4])
-        reducer.finish()
-        f_a.grad = None
-        f_v.grad = None
-        reducer.zero_grad()
+    def make_step(work, reducer):
+        def step(sync=True):
+            reducer.begin(sync=sync)
+            for w in work:
+                xa, xv = w["f_a"].permute(0, 2, 1).unsqueeze(-1), w["f_v"].permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
+                for a, v, pr in w["mods"]:
+                    extra = []
+                    if pair_mode != "off" and pr is not None:
+                        out_a, _, out_v, _ = pr(xa, xv)          # net_trans_v3.py:695-698 as one autograd node (AdapterPair)
+                    elif c["variant"] == "avs":
+                        out_a, _, _, lb_a = a(xa, xv, is_training=True)
+                        out_v, _, _, lb_v = v(xv, xa, is_training=True)
+                        extra = [lbw * (lb_a + lb_v)]
+                    elif c["variant"] == "avvp":
+                        out_a, lb_a = a(xa, xv)
+                        out_v, lb_v = v(xv, xa)
+                        extra = [lb_a + lb_v]
+                    else:
+                        out_a, _ = a(xa, xv)                   # net_trans_v3.py:695
+                        out_v, _ = v(xv, xa)                   # net_trans_v3.py:697
+                    torch.autograd.backward([out_a, out_v] + extra, [w["ga4"], w["gv4"]] + [None] * len(extra))
+                w["f_a"].grad = None
+                w["f_v"].grad = None
+            reducer.finish()
+            reducer.zero_grad()
+        return step
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    esz = 2 if dtype == "bf16" else 4
+    work, reducer = build_workload(tdt)
+    msg_bytes = reducer.message_bytes()
+    step = make_step(work, reducer)
+    dt = timed(step, args.steps, args.warmup)                  # THE timed region: W warm-up steps, then exactly K steps
     ms_per_step = 1e3 * dt / args.steps
     value = c["B"] * world / (dt / args.steps)
+    rep_ms = [ms_per_step] + [1e3 * timed(step, args.steps, 0) / args.steps for _ in range(max(0, args.reps - 1))]
 
     roofline = None
-    if not args.no_roofline and rank == 0:
-        # Profiling pass (HIP events around every launch, one family per kernel AND launch shape).  The two sites are run
-        # back to back here (AdapterPair(concurrent=False)) so that every kernel is timed with the GPU to itself; the timed
-        # region above overlaps them on two streams, which stretches each kernel's own duration.
-        L = capi.lib()
-        # Rank 0 only: the steps of this pass must not enter a collective (sync=False = an accumulation micro-step).
-        pair_timed, pair = pair, AdapterPair(audio, visual, concurrent=False)
-        for _ in range(2):
-            step(sync=False)
-        L.avmoe_prof_reset()
-        L.avmoe_prof_enable(1)
-        nprof = 3
-        for _ in range(nprof):
-            step(sync=False)
-        torch.cuda.synchronize()
-        L.avmoe_prof_enable(0)
-        pair = pair_timed
-        rep = capi.prof_report()
-        L.avmoe_prof_reset()
-        tot_ms = sum(r["total_ms"] for r in rep)
-        dom = max(rep, key=lambda r: r["total_ms"])
-        avg_ms = dom["total_ms"] / dom["calls"]
-        gbs = dom["alg_bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9
-        tfs = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
-        roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                        traffic=None, kernel=dom["name"], launches_per_step=dom["calls"] // nprof,
-                        measured="sites serialised (kernel alone on the GPU); the timed region overlaps the two sites",
-                        avg_launch_us=round(avg_ms * 1e3, 2), share_of_gpu_time=round(dom["total_ms"] / tot_ms, 3),
-                        kernel_tflops=round(tfs, 1), kernel_mfma_frac=round(tfs / MFMA_PEAK_TF[args.dtype], 4),
-                        path_algorithmic_gbs=round(algorithmic_bytes_per_clip_pair(c, esz) * value / world / 1e9, 1),
-                        path_reference_tflops=round(reference_flops_per_clip_pair(c) * value / world / 1e12, 1),
-                        families=sorted([dict(name=r["name"], calls=r["calls"] // nprof, ms_per_step=round(r["total_ms"] / nprof, 4),
-                                              gbs=round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1))
-                                         for r in rep], key=lambda r: -r["ms_per_step"])[:14])
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(tj):       # HBM bytes per launch of the dominant family, from the committed rocprofv3 --pmc passes
-            with open(tj) as fh:
-                t = json.load(fh).get(dom["name"].split(" NT")[0].split(" M")[0])
-            if t:      # the dominant launch is the audio-side (largest) one of its family
-                roofline["traffic"] = t["read_bytes_largest_launch"] + t["write_bytes_largest_launch"]
+    if not args.no_roofline:
+        abytes, rflops = algorithmic_bytes_per_clip_pair(c, esz), reference_flops_per_clip_pair(c)
+        path_gbs = abytes * value / world / 1e9
+        path_tfs = rflops * value / world / 1e12
+        roofline = dict(bound="hbm", achieved=round(path_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(path_gbs / HBM_PEAK_GBS, 4), traffic=None,
+                        level="path (SURVEY 8d): algorithmic bytes per clip-pair x clip-pairs/s per GPU",
+                        algorithmic_bytes_per_clip_pair=round(abytes), algorithmic_bytes_per_step=round(abytes * c["B"]),
+                        mfma=dict(achieved=round(path_tfs, 1), peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s", frac=round(path_tfs / MFMA_PEAK_TF[dtype], 4),
+                                  reference_flops_per_clip_pair=round(rflops),
+                                  note="FLOPs of the reference's formulation (SURVEY 8d); the factorised path executes fewer"))
+        if rank == 0:
+            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape), same execution mode as the
+            # timed region.  Rank 0 only: its steps must not enter a collective (sync=False = an accumulation micro-step).
+            L = capi.lib()
+            for _ in range(2):
+                step(sync=False)
+            torch.cuda.synchronize()
+            L.avmoe_prof_reset()
+            L.avmoe_prof_enable(1)
+            nprof = 3
+            for _ in range(nprof):
+                step(sync=False)
+            torch.cuda.synchronize()
+            L.avmoe_prof_enable(0)
+            rep = capi.prof_report()
+            L.avmoe_prof_reset()
+            if os.environ.get("AVMOE_FAMILIES_OUT"):      # dev: every family of the profiling pass
+                with open(os.environ["AVMOE_FAMILIES_OUT"], "w") as fh:
+                    json.dump(sorted(rep, key=lambda r: -r["total_ms"]), fh, indent=0)
+            tot_ms = sum(r["total_ms"] for r in rep)
+            dom = max(rep, key=lambda r: r["total_ms"])
+            avg_ms = dom["total_ms"] / dom["calls"]
+            gbs = dom["alg_bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9
+            tfs = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
+            dk = dict(kernel=dom["name"], bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                      traffic=None, launches_per_step=dom["calls"] // nprof, avg_launch_us=round(avg_ms * 1e3, 2),
+                      share_of_gpu_time=round(dom["total_ms"] / tot_ms, 3), kernel_tflops=round(tfs, 1),
+                      measured=f"HIP events on the launch stream, --pair {pair_mode} (the mode of the timed region"
+                               + ("; the two sites' kernels overlap, which stretches each launch)" if pair_mode == "concurrent" else ")"))
+            tj = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic.json")
+            if os.path.isfile(tj) and args.config == "cfg2" and not args.batch and dtype == "bf16":
+                with open(tj) as fh:       # HBM bytes from THIS round's rocprofv3 --pmc passes (scripts/make_profiles.sh)
+                    tjd = json.load(fh)
+                t = tjd.get(dom["name"].split(" NT")[0].split(" M")[0])
+                if t:      # the dominant launch is the largest one of its family
+                    dk["traffic"] = t["read_bytes_largest_launch"] + t["write_bytes_largest_launch"]
+                    dk["traffic_source"] = f"profiles/{ROUND}_pmc_traffic.json"
+                if tjd.get("__total_bytes_per_step__"):
+                    roofline["traffic"] = tjd["__total_bytes_per_step__"]
+                    roofline["traffic_source"] = f"profiles/{ROUND}_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE over every kernel of one step"
+            roofline["dominant_kernel"] = dk
+            roofline["gpu_time_ms_per_step"] = round(tot_ms / nprof, 3)
+            roofline["kernel_families"] = len(rep)
+            roofline["families"] = sorted([dict(name=r["name"], calls=r["calls"] // nprof, ms_per_step=round(r["total_ms"] / nprof, 4),
+                                                gbs=round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1))
+                                           for r in rep], key=lambda r: -r["ms_per_step"])[:12]
 
-    cpu = None
+    del work, reducer, step
+    gc.collect()
+    torch.cuda.empty_cache()
+    value_f32 = None
+    if dtype == "bf16" and not args.no_f32:
+        work, reducer = build_workload(torch.float32)
+        step = make_step(work, reducer)
+        k32 = max(3, args.steps // 2)
+        dt32 = timed(step, k32, 2)
+        value_f32 = dict(value=round(c["B"] * world / (dt32 / k32), 2), unit="clip-pairs/s", ms_per_step=round(1e3 * dt32 / k32, 4), steps=k32,
+                         dtype="f32", note="fp32 activations on the exact-fp32 matrix pipe: the configuration held to the 1e-3 parity bar")
+        del work, reducer, step
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    cpu = parity = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(c)
+        cpu, material = cpu_baseline(c)
+        parity = parity_check(c, material, device)
 
     if rank == 0:
+        shapes = [dict(C_a=Ca, N_a=Na, C_v=Cv, N_v=Nv, site_pairs=cnt, bottleneck_a=Ca // c["reduction"], bottleneck_v=Cv // c["reduction"])
+                  for Ca, Na, Cv, Nv, cnt in c["pairs"]]
         line = {
             "metric": "clip-pairs/sec (adapter fwd+bwd, AVE-shape synthetic)", "value": round(value, 2),
             "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "cfg-2: one AVMoE adapter site (audio-side + visual-side MoEAdapter), fwd+bwd incl. "
-                                   "input and parameter grads", "clips_per_gpu": c["B"], "frames_per_clip": c["T"],
-                       "N_a": c["N_a"], "N_v": c["N_v"], "C": c["C"], "experts": "2 cross-modal + 2 unimodal",
-                       "bottleneck": c["C"] // c["reduction"], "latent_tokens": c["K"], "groups": c["groups"],
-                       "parallelism": f"dp{world}", "grad_allreduce_bytes": reducer.message_bytes() if world > 1 else 0},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{args.config}: {c['what']}, fwd+bwd incl. input and parameter grads", "variant": c["variant"],
+                       "clips_per_gpu": c["B"], "frames_per_clip": c["T"], "site_pairs": sum(p[4] for p in c["pairs"]), "shapes": shapes,
+                       "experts": f"{c['E_m']} cross-modal + {c['E_s']} unimodal", "reduction": c["reduction"], "latent_tokens": c["K"],
+                       "groups": c["groups"], "pair_mode": pair_mode, "parallelism": f"dp{world}",
+                       "grad_allreduce_bytes": msg_bytes if world > 1 else 0},
+            "repeat_ms_per_step": [round(x, 4) for x in rep_ms],
+            "spread_rel": round((max(rep_ms) - min(rep_ms)) / statistics.median(rep_ms), 4),
+            "roofline": roofline, "parity": parity, "value_f32": value_f32, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()                       # the other ranks wait for rank 0's profiling pass: clean teardown of the communicator
+        dist.barrier()                       # the other ranks wait for rank 0's extra passes: clean teardown of the communicator
         dist.destroy_process_group()
 
 

@@ -269,3 +269,66 @@ def test_adapter_pair_with_frame_attention_experts(concurrent):
     for r_, g_ in zip(ref[4], got[4]):
         assert torch.equal(r_, g_)
     assert any("self_attention.in_proj_weight" in k for k, _ in sa.named_parameters())
+
+
+def test_flat_adam_two_lr_groups_and_plain_buckets():
+    """(1) the reference's two Adam learning-rate groups (AVE/main_trans_v3.py:313-322: lr_mlp for 'mlp_class', lr for the
+    adapters; train.sh ships a factor of 100 between them) through select_trainable -> FlatAdam(param_groups=...) against
+    torch.optim.Adam with the same groups; (2) the reducer WITHOUT sites= on a 1 + 1 expert site (2-element router.4.bias and
+    1-element gates in front of GEMM operands): parameters re-pointed by FlatAdam stay 16-byte aligned and the next
+    forward / backward through the HIP path works (unaligned router.0.weight)."""
+    import copy
+    from avmoe_amd.dp import AdapterGradReducer
+    from avmoe_amd.train import FlatAdam, select_trainable
+    dev = torch.device("cuda:0")
+    cfg = O.AdapterConfig(Cx=64, Nx=50, Cy=48, Ny=20, reduction=4, groups=2, K=6, E_m=1, E_s=1)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.audio_moe_adapter_blocks_p1 = torch.nn.ModuleList([build_module("ave", cfg)])
+            self.mlp_class = torch.nn.Linear(cfg.Cx, 5)
+
+        def forward(self, X, Y):
+            out, _ = self.audio_moe_adapter_blocks_p1[0](X, Y)
+            return self.mlp_class(out.squeeze(-1).mean(-1))
+    torch.manual_seed(11)
+    ref = Net().to(dev).train()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k.endswith(("gate", "gate_av")):
+                p.fill_(0.4)
+    fused = copy.deepcopy(ref)
+    lr, lr_mlp = 5e-3, 5e-5
+    tg = select_trainable(ref, lr=lr, lr_mlp=lr_mlp)
+    topt = torch.optim.Adam([{"params": [g_["params"]], "lr": g_["lr"]} for g_ in tg if g_["params"].requires_grad])
+    fg = select_trainable(fused, lr=lr, lr_mlp=lr_mlp)
+    red = AdapterGradReducer([p for p in fused.parameters() if p.requires_grad])           # no sites=: plain size-capped buckets
+    fopt = FlatAdam(red, lr=lr, param_groups=fg)
+    for p in fused.parameters():
+        assert p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0
+    start = {k: p.detach().clone() for k, p in fused.named_parameters()}
+    g = torch.Generator().manual_seed(2)
+    for it in range(3):
+        X = torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev)
+        Y = torch.randn(4, cfg.Cy, cfg.Ny, 1, generator=g).to(dev)
+        G = torch.randn(4, 5, generator=g).to(dev)
+        topt.zero_grad()
+        ref(X, Y).backward(G)
+        red.begin(sync=True)
+        fused(X, Y).backward(G)                           # the HIP path reads the re-pointed (flat-buffer) parameters
+        red.finish()
+        with torch.no_grad():
+            for p, q in zip(ref.parameters(), fused.parameters()):
+                assert float((p.grad - q.grad).abs().max()) <= 1e-4 * float(p.grad.abs().max()) + 1e-7
+                q.grad.copy_(p.grad)
+        topt.step()
+        fopt.step(); red.zero_grad()
+        with torch.no_grad():
+            for (k, p), (_, q) in zip(ref.named_parameters(), fused.named_parameters()):
+                step_lr = lr_mlp if "mlp_class" in k else lr
+                assert float((p - q).abs().max()) <= 1e-6 * float(p.abs().max()) + 2e-3 * step_lr, (it, k)
+                q.copy_(p)
+    moved = {k: float((p.detach() - start[k]).abs().max()) for k, p in fused.named_parameters()}
+    assert max(v for k, v in moved.items() if "mlp_class" in k) <= 3.5 * lr_mlp          # |Adam update| <= ~lr per step
+    assert max(v for k, v in moved.items() if "mlp_class" not in k) > 10 * lr_mlp

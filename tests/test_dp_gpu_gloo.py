@@ -108,7 +108,7 @@ def test_bench_two_ranks_finish_and_print_one_line():
     import subprocess
     env = dict(os.environ, AVMOE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--reps", "1"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -116,3 +116,21 @@ def test_bench_two_ranks_finish_and_print_one_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["roofline"] is not None and d["cpu_baseline"] is None
     assert d["config"]["grad_allreduce_bytes"] > 0
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command with a larger N): bench.py starts
+    torch.distributed.run itself, as a child, before touching the GPU, and relays rank 0's single JSON line with n_gpus and the
+    all-reduce message size filled in (gloo stands in for RCCL: two ranks share the one GPU of the test box)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(AVMOE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--reps", "1", "--no-f32"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_allreduce_bytes"] > 0
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["mfma"]["frac"] > 0 and d["roofline"]["dominant_kernel"]["kernel"]

@@ -61,3 +61,14 @@ def test_adapter_only_checkpoint_roundtrip_and_prefix_strip():
     except KeyError:
         pass
     assert T.strip_prefix({"sed_model.layers.0.w": 1}) == {"layers.0.w": 1}
+
+
+def test_plain_bucket_offsets_are_aligned_and_flat_adam_ranges_cover_the_bucket():
+    """dp._Bucket pads every parameter to 64 elements (FlatAdam re-points param.data to the bucket offsets and the
+    GEMM engine needs 16-byte aligned operands); FlatAdam's per-learning-rate ranges tile the whole bucket in order."""
+    from avmoe_amd.dp import _Bucket
+    ps = [nn.Parameter(torch.zeros(n)) for n in (1, 2, 130, 64, 7)]
+    b = _Bucket(ps, torch.device("cpu"), torch.float32)
+    assert b.offsets == [0, 64, 128, 320, 384] and b.flat.numel() == 448
+    for p, o in zip(ps, b.offsets):
+        assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * o and p.grad.data_ptr() % 16 == 0
