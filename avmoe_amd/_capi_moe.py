@@ -54,6 +54,8 @@ TOP_KEY_TO_FIELD = {
 def declare(L):
     L.avmoe_adam_step.restype = C.c_int
     L.avmoe_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_float, C.c_void_p]
+    L.avmoe_add2.restype = C.c_int
+    L.avmoe_add2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     L.avmoe_router_topk.restype = C.c_int
     L.avmoe_router_topk.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.avmoe_expert_histogram.restype = C.c_int
@@ -71,6 +73,10 @@ def declare(L):
     L.avmoe_moe_backward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoePtrs),
                                      C.c_void_p]
+    L.avmoe_moe_backward_part.restype = C.c_int
+    L.avmoe_moe_backward_part.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoePtrs),
+                                          C.c_int32, C.c_void_p]
     L.avmoe_moe_buffer_info.restype = C.c_int
     L.avmoe_moe_buffer_info.argtypes = [C.POINTER(MoeDesc), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]

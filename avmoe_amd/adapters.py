@@ -104,44 +104,63 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None):
     return out, probs, idx, lb, ((desc, keep), saved, X, Y)
 
 
+class _SiteBackward:
+    """One site's backward through the C ABI, writing (or, with acc_*, adding) the token gradients into dX / dY.
+    run(0) = the whole of it; run(mask) = the sections of avmoe_moe_backward_part (1: touches neither dX nor dY, 2: every
+    writer of dX, 4: every writer of dY), in this order.  finish() returns the parameter gradients in `names` order (None where not needed,
+    or for all of them when a gradient sink took them)."""
+
+    def __init__(self, module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False):
+        self.L = capi.lib()
+        (desc, keep), self.saved, self.X, self.Y = state
+        self.desc, self.names, self.module = desc, names, module
+        tensors = dict(zip(names, params))
+        self.ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors(), **keep}, module.num_multimodal_experts,
+                                 module.num_singlemodal_experts)
+        # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
+        # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
+        # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
+        sink = self.sink = getattr(module, "_grad_sink", None)
+        self.use_sink = sink is not None and all(needs) and sink.matches(names, tensors)
+        if self.use_sink:
+            # zeros, not empty: on accumulation micro-steps the alignment padding is added to the bucket as well
+            self.flat = sink.flat if sink.fresh else torch.zeros_like(sink.flat)
+            self.grads = {k: self.flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
+        else:
+            self.grads = {k: (torch.empty_like(v) if needs[i] else None) for i, (k, v) in enumerate(tensors.items())}
+        self.gptrs = cm.make_ptrs({k: v for k, v in self.grads.items() if v is not None}, module.num_multimodal_experts,
+                                  module.num_singlemodal_experts)
+        self.d_out = d_out.to(self.X.dtype).contiguous()
+        self.lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
+        self.scratch = _scratch(self.X.device, self.L.avmoe_moe_scratch_bytes(C.byref(desc)))
+        self.dX, self.dY, self.acc = dX, dY, (int(acc_dx), int(acc_dy))
+
+    def run(self, parts=0):
+        d = self.desc
+        d.accumulate_dx, d.accumulate_dy = self.acc
+        st = self.L.avmoe_moe_backward_part(C.byref(d), self.X.data_ptr(), self.Y.data_ptr(), C.byref(self.ptrs), self.d_out.data_ptr(),
+                                            self.lbg.data_ptr() if self.lbg is not None else None, self.saved.data_ptr(),
+                                            self.scratch.data_ptr(), self.dX.data_ptr(), self.dY.data_ptr(), C.byref(self.gptrs),
+                                            int(parts), torch.cuda.current_stream(self.X.device).cuda_stream)
+        d.accumulate_dx = d.accumulate_dy = 0
+        capi.check(st, "avmoe_moe_backward")
+        return self
+
+    def finish(self):
+        sink = self.sink
+        if self.use_sink:
+            if not sink.fresh:
+                sink.flat.add_(self.flat)                # accumulation micro-step: one fused add for the whole site
+            sink.done()
+            return (None,) * len(self.names)
+        if sink is not None:
+            sink.calls -= 1
+        return tuple(self.grads[k] for k in self.names)
+
+
 def _site_backward(module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False):
-    """One avmoe_moe_backward call writing (or, with acc_*, adding) the token gradients into dX / dY.  Returns the
-    parameter gradients in `names` order (None where not needed, or for all of them when a gradient sink took them)."""
-    L = capi.lib()
-    (desc, keep), saved, X, Y = state
-    tensors = dict(zip(names, params))
-    ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors(), **keep}, module.num_multimodal_experts,
-                        module.num_singlemodal_experts)
-    # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
-    # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
-    # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
-    sink = getattr(module, "_grad_sink", None)
-    use_sink = sink is not None and all(needs) and sink.matches(names, tensors)
-    if use_sink:
-        flat = sink.flat if sink.fresh else torch.zeros_like(sink.flat)     # zeros: the alignment padding is added too
-        grads = {k: flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
-    else:
-        grads = {k: (torch.empty_like(v) if needs[i] else None) for i, (k, v) in enumerate(tensors.items())}
-    gptrs = cm.make_ptrs({k: v for k, v in grads.items() if v is not None}, module.num_multimodal_experts,
-                         module.num_singlemodal_experts)
-    d_out = d_out.to(X.dtype).contiguous()
-    lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
-    scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
-    desc.accumulate_dx, desc.accumulate_dy = int(acc_dx), int(acc_dy)
-    st = L.avmoe_moe_backward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs), d_out.data_ptr(),
-                              lbg.data_ptr() if lbg is not None else None, saved.data_ptr(),
-                              scratch.data_ptr(), dX.data_ptr(), dY.data_ptr(), C.byref(gptrs),
-                              torch.cuda.current_stream(X.device).cuda_stream)
-    desc.accumulate_dx = desc.accumulate_dy = 0
-    capi.check(st, "avmoe_moe_backward")
-    if use_sink:
-        if not sink.fresh:
-            sink.flat.add_(flat)                     # accumulation micro-step: one fused add for the whole site
-        sink.done()
-        return (None,) * len(names)
-    if sink is not None:
-        sink.calls -= 1
-    return tuple(grads[k] for k in names)
+    """The whole backward of one site in one call (see _SiteBackward)."""
+    return _SiteBackward(module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx, acc_dy).run(0).finish()
 
 
 class AdapterFunction(torch.autograd.Function):
@@ -174,6 +193,7 @@ class _PairFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, site_a, site_b, side, Xa, Xb, base_a, base_b, names_a, names_b, *params):
+        side, ctx.ordered = (side[0], side[1]) if isinstance(side, tuple) else (side, False)
         """base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs)."""
         na = len(names_a)
         pa, pb = params[:na], params[na:]
@@ -213,9 +233,9 @@ class _PairFunction(torch.autograd.Function):
         needs_a, needs_b = ctx.needs_input_grad[9:9 + na], ctx.needs_input_grad[9 + na:]
         gba = d_a if ctx.has_base[0] else None            # out = base + adapter(...): the residual stream passes the gradient on
         gbb = d_b if ctx.has_base[1] else None
-        if ctx.side is not None:
+        if ctx.side is not None and not ctx.ordered:
             # the two backward passes run concurrently (own streams, own workspaces); each token tensor then gets its two
-            # gradients from separate buffers and one add
+            # gradients from separate buffers and ONE fused add over both tensors (avmoe_add2)
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
             gXa2, gXb2 = torch.empty_like(Xa), torch.empty_like(Xb)
             side.wait_stream(main)
@@ -225,7 +245,34 @@ class _PairFunction(torch.autograd.Function):
             main.wait_stream(side)
             for t_ in (gXa2, gXb2) + tuple(g_ for g_ in pgb if g_ is not None):
                 t_.record_stream(main)
-            gXa.add_(gXa2); gXb.add_(gXb2)
+            capi.check(capi.lib().avmoe_add2(gXa.data_ptr(), gXa2.data_ptr(), gXa.numel(), gXb.data_ptr(), gXb2.data_ptr(), gXb.numel(),
+                                             capi.BF16 if gXa.dtype == torch.bfloat16 else capi.F32, main.cuda_stream), "avmoe_add2")
+            return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
+        if ctx.side is not None:
+            # Ordered variant (AdapterPair(ordered_accumulate=True)): ONE buffer per token tensor.  The site with the smaller X runs
+            # straight through on the side stream and OVERWRITES both buffers (its dX, its dY); the other site runs the sections
+            # that touch neither buffer (avmoe_moe_backward_part, 1), waits for the small site's event, and ADDS its dX / dY in the
+            # GEMM epilogues (sections 2 and 4).  Saves the add's 1.2 GB of traffic at cfg-2 but serialises the tail of the large
+            # site behind the small one: measured 3 % SLOWER than the default on MI355X, kept for memory-tight callers.
+            side, main = ctx.side, torch.cuda.current_stream(Xa.device)
+            a_big = Xa.numel() >= Xb.numel()
+            small = (site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa) if a_big else \
+                    (site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb)
+            big = (site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb) if a_big else \
+                  (site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cs = _SiteBackward(*small).run(0)
+                pg_small = cs.finish()
+                done = torch.cuda.Event()
+                done.record(side)
+            cb = _SiteBackward(*big, acc_dx=True, acc_dy=True).run(1)
+            main.wait_event(done)                       # both buffers hold the small site's gradients
+            pg_big = cb.run(6).finish()
+            for t_ in tuple(g_ for g_ in pg_small if g_ is not None) + (cs.d_out,):
+                t_.record_stream(main)
+            gXa.record_stream(side); gXb.record_stream(side)
+            pga, pgb = (pg_big, pg_small) if a_big else (pg_small, pg_big)
             return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
         # both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The larger
         # tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
@@ -479,12 +526,12 @@ class AdapterPair(nn.Module):
     Numerically identical to calling the two sites one after the other; in the backward the gradient each token tensor
     receives from its second use is added inside the GEMM epilogues instead of by a separate accumulation kernel."""
 
-    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True):
+    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True, ordered_accumulate: bool = False):
         """concurrent=True runs the two sites on two HIP streams (their kernels overlap; each token tensor's two gradients
         are then summed by one add); False runs them back to back on the caller's stream and adds the second gradient inside
         the GEMM epilogues instead."""
         super().__init__()
-        self.concurrent, self._side = bool(concurrent), None
+        self.concurrent, self._side, self.ordered_accumulate = bool(concurrent), None, bool(ordered_accumulate)
         for m in (site_a, site_b):
             if m.variant not in ("ave", "avqa"):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
@@ -503,7 +550,8 @@ class AdapterPair(nn.Module):
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
-        out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, self._side if self.concurrent else None, Xa, Xb,
+        side = ((self._side, True) if self.ordered_accumulate else self._side) if self.concurrent else None
+        out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())
         with torch.no_grad():

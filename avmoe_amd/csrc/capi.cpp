@@ -66,6 +66,17 @@ int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y,
   return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream);
 }
 
+int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
+                            const void* dOut, const float* lb_grad, void* saved, void* scratch, void* dX, void* dY,
+                            const avmoe_moe_ptrs* grads, int32_t parts, void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads || parts < 0 || parts > 7) {
+    set_last_error("avmoe_moe_backward_part: null pointer or parts not in 0..7"); return ERR_BAD_ARG;
+  }
+  return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream, parts);
+}
+
 int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avmoe_moe_ptrs* params, const float* noise,
                          float* probs, int64_t* idx, float* lb, void* saved, void* scratch, void* stream) {
   Plan pl;

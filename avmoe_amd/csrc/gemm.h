@@ -57,6 +57,12 @@ struct GemmArgs {
   const void* B2 = nullptr;
   int K2 = 0;
   long lda2 = 0, ldb2 = 0, s2A1 = 0, s2A2 = 0, s2B1 = 0, s2B2 = 0;
+  // optional split output (streaming kernel only; launch_gemm_stream returns 1 when it cannot honour it): columns >= nsplit
+  // (a multiple of 32) go, in fp32, to Cx[b2][i][j - nsplit] (row stride ldcx, group stride sCx2) instead of C -- lets the
+  // wide part of a product be stored in bf16 while a few columns that feed long fp32 sums keep full precision.
+  float* Cx = nullptr;
+  int nsplit = 0;
+  long ldcx = 0, sCx2 = 0;
 };
 
 // Returns 0 on success, negative avmoe status otherwise (message through set_last_error).

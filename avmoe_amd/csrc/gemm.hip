@@ -594,6 +594,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       if (s <= 0) return s;
     }
   }
+  if (a.Cx) { set_last_error("gemm: a split fp32 side output (Cx) is a feature of the streaming kernel only"); return ERR_UNSUPPORTED; }
   // Batch fold: per-sample row blocks of A (K-major, regularly spaced) against ONE shared B are the rows of a single tall
   // GEMM -- used when the per-sample M would leave a quarter or more of its tile rows empty (65 rows on a 128-row tile, 8
   // latent rows on a 64-row tile).  Rows of the gaps between the samples' blocks are computed and not stored.

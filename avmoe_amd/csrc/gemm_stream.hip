@@ -32,6 +32,7 @@ struct StreamArgs {
   long lda, ldb, lda2, ldb2, ldc, ldd;
   long sA1, sA2, sB2, s2A1, s2A2, s2B1, s2B2, sC1, sC2, sD1, sD2, sRS1, sRS2;   // batch strides (elements): 1 = sample, 2 = group
   float alpha; int b_mn, out_bf16;
+  float* Cx; int nsplit; long ldcx, sCx2;          // fp32 side output for the columns >= nsplit (GemmArgs::Cx)
 };
 
 __device__ __forceinline__ float bfbits(unsigned int h) { return __builtin_bit_cast(float, h << 16); }
@@ -277,7 +278,12 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
           }
         }
         char* cp = Cb + ((long)m * p.ldc + nl) * osz;
-        if (p.out_bf16) {
+        if (p.Cx && nl >= p.nsplit) {                        // this lane's run belongs to the fp32 side output
+          float* xp = p.Cx + (long)g * p.sCx2 + (long)m * p.ldcx + (nl - p.nsplit);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            if (nl + 4 * t < p.N) *(f32x4*)(xp + 4 * t) = acc[t];
+        } else if (p.out_bf16) {
           auto pk = [&](int t, int e) { return f2bfbits(acc[t][e]) | (f2bfbits(acc[t][e + 1]) << 16); };
           if constexpr (TPW % 2 == 0) {                      // runs of 8 elements: 16-byte stores (N % 4 == 0)
 #pragma unroll
@@ -346,6 +352,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
       a.K > 384 || a.N > 768 || (a.nb1 > 1 && (a.sB1 != 0 || a.M < 64)))
     return 1;
   if (a.A2 && (a.K2 > 96 || a.s2A1 == 0)) return 1;
+  if (a.Cx && (a.nb1 != 1 || a.accumulate || a.nsplit % 32 || ((uintptr_t)a.Cx % 16) || a.ldcx % 4 || a.sCx2 % 4)) return 1;
   const int osz = a.out_dtype == GEMM_BF16 ? 2 : 4;
   if (((uintptr_t)a.C % 16) || (a.sCi * osz) % 16 || (a.sC1 * osz) % 16 || (a.sC2 * osz) % 16 || (a.N % 4)) return 1;
   if (a.D && (a.row_scale == nullptr || ((uintptr_t)a.D % 16) || (a.sDi * 2) % 16 || (a.sD1 * 2) % 16 || (a.sD2 * 2) % 16)) return 1;
@@ -359,6 +366,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   s.sC1 = a.sC1; s.sC2 = a.sC2; s.sD1 = a.sD1; s.sD2 = a.sD2; s.sRS1 = a.sRS1; s.sRS2 = a.sRS2;
   s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
   s.contig = a.A2 != nullptr;
+  s.Cx = a.Cx; s.nsplit = a.nsplit; s.ldcx = a.ldcx; s.sCx2 = a.sCx2;
   const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);
   const double nb = (double)a.nb1 * a.nb2;
   const double abytes = (nb * a.M * (double)(a.K + s.K2) + (double)a.nb2 * a.N * (double)a.K + nb * a.N * (double)s.K2) * 2.0 +

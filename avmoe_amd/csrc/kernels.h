@@ -36,7 +36,7 @@ int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
 
 // ---- backward ---------------------------------------------------------------------------------
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
-                     const avmoe_moe_ptrs& grads, hipStream_t st);
+                     const avmoe_moe_ptrs& grads, hipStream_t st, int dap16 = 0);   // dap16: dApost = [T columns | fp32 dApx]
 int k_post_prep_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm,
                     const avmoe_moe_ptrs& grads, hipStream_t st);
 int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
@@ -66,7 +66,7 @@ int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* 
 bool tile_fast_ok(const Dims& d);
 int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
-int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st, int dap16 = 0);
 int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);

@@ -2,6 +2,7 @@
 // phase 1 the two GEMMs against dOut, phases 2-4 bottleneck / weight space, phase 5 GEMMs against X,
 // phase 6 the hop-1 (latent token) chain back to Y and the remap parameters.  Stream-ordered, no
 // allocation, no host sync.
+#include <cstdlib>
 #include "moe_run.h"
 
 namespace avmoe {
@@ -14,9 +15,17 @@ namespace avmoe {
 
 avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* sv);   // moe_forward.cpp
 
+// parts: bit mask of the sections to run, 0 = 7 = the whole backward:
+//   1  phases 1-4: the GEMMs against dOut and the bottleneck / weight space (touches neither dX nor dY)
+//   2  phase 5: the GEMMs against X -- every writer of dX
+//   4  phase 6: the hop-1 chain back to Y and the remap parameters -- every writer of dY
+// Sections are stream-ordered through `scratch`: a caller may put event records / waits between them (AdapterPair orders the
+// two sites' accumulations into the shared token gradients this way) but nothing that touches the workspaces.
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const void* dOut, const float* lb_grad,
-                 char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st) {
+                 char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st, int parts) {
   const Dims& d = pl.d;
+  if (parts == 0) parts = 7;
+  if (parts != 7 && d.Kcx > 0) { set_last_error("split backward: sites with latent self attention write dX in the last section"); return ERR_UNSUPPORTED; }
   const avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
@@ -27,10 +36,12 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     return launch_gemm(g, st);
   };
   const size_t esz = d.esz;
+  if (parts & 1) {   // =============================== section 1: phases 1 - 4 ===============================
   // the accumulators that start from zero (dtbp, dTW, dWcK, dqp, dRT) are adjacent in the plan: one memset instead of five
   MEMSET0(sc + pl.o_dtbp, (pl.o_dRT - pl.o_dtbp) + (size_t)d.S * d.M * d.Kcyp * esz);
 
   // ---- phase 1: dApost = dOut Bpost ; dBpost = dOut^T Apost -------------------------------------
+  int dap16 = 0;     // dApost stored as [E x 32 bottleneck columns in T | 3 E scalar columns in fp32 (dApx)]: the register-resident bf16 path
   {
     GemmArgs g = base();
     g.A = dOut; g.B = sv + pl.o_Bpost; g.C = sc + pl.o_dAp;
@@ -38,7 +49,14 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     // kernel wants whole 4-column vectors, and nobody reads the padding of dAp
     g.M = d.NT; g.N = (d.KP % 4 == 0) ? d.KP : d.KPp; g.K = d.Cg; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.KPp; g.nb2 = d.g;
     g.sA2 = d.Cg; g.sB2 = (long)d.Cg * d.KPp; g.sCi = (long)d.g * d.KPp; g.sC2 = d.KPp;
-    AVMOE_TRY(run(g, false));
+    if (d.zsz == 2 && !getenv("AVMOE_DAP_F32")) {          // bf16 main columns + fp32 scalar columns: 640 instead of 1152 bytes per token, written and re-read
+      GemmArgs h = g;
+      h.out_dtype = GEMM_BF16; h.Cx = (float*)(sc + pl.o_dApx); h.nsplit = d.E * d.dgp; h.ldcx = (long)d.g * 16; h.sCx2 = 16;
+      const int r = launch_gemm_stream(h, st);
+      if (r < 0) return r;
+      dap16 = r == 0;
+    }
+    if (!dap16) AVMOE_TRY(run(g, false));
   }
   {
     GemmArgs g = base();
@@ -48,7 +66,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(run(g, true));
   }
   // ---- phase 2: bottleneck space (LayerNorm-post statistics), then weight space ------------------
-  AVMOE_TRY(k_post_small_bwd(pl, sv, sc, prm, grads, st));
+  AVMOE_TRY(k_post_small_bwd(pl, sv, sc, prm, grads, st, dap16));
   if (d.ln_post && d.gram64) {                             // dG[i][e] = sum_t dSoo z' z'^T : one streaming pass over the saved z'
     AVMOE_TRY(k_gram64(pl, sv + pl.o_ZpS, (const float*)(sc + pl.o_dSooT), 1.f, (float*)(sc + pl.o_gpartT), (float*)(sc + pl.o_dGq), st));
   } else if (d.ln_post) {                                  // ... as batched engine GEMMs on Zw = dSoo z'
@@ -65,6 +83,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   // ---- phase 4: folded LayerNorm / hop-2 softmax ---------------------------------------------------
   if (d.nxn) MEMSET0(sc + pl.o_dZR, (size_t)d.NT * d.DZ * esz);
   AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));
+  }
+  if (parts & 2) {   // =============================== section 2: phase 5 ====================================
   const char* dZx = sc + pl.o_Zw;
 
   // ---- phase 5: GEMMs against X --------------------------------------------------------------------
@@ -201,6 +221,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   }
   AVMOE_TRY(k_finish_dT(pl, sv, sc, st));                  // + dtbar / C ; dTy (T, with the dm2 row) ; dTx ; dT0 ; drw, dbf
   AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
+  }
+  if (!(parts & 4)) return OK;   // ======================= section 3: phase 6 ====================================
 
   // ---- phase 6a: cross-modal hop-1 chain back to Y and the remap parameters -------------------------
   {                                                        // dV = dTy Wf   (row Kcy: d ybar)

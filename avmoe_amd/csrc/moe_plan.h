@@ -147,7 +147,8 @@ struct Dims {
   X(dWcK, 1, 4, (size_t)d.N * d.Mk)                                                             \
   X(dqp, 1, 4, (size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb)                                           \
   X(dRT, 1, d.esz, (size_t)d.S * d.M * d.Kcyp)                                                  \
-  X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)                                                      \
+  X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)          /* f32 ; T (+ dApx) on the register-resident bf16 path */ \
+  X(dApx, 1, 4, d.zsz == 2 ? (size_t)d.NT * d.g * 16 : 1)   /* the 3 E scalar columns of dApost per (token, group), fp32 */ \
   X(dBp, 1, 4, (size_t)d.C * d.KPp)                                                             \
   X(dzp, 1, d.zsz, (size_t)d.NT * d.DZ)                 /* dz' -> dy (in place)           */       \
   X(blkscal, 1, 4, (size_t)d.nblk_tok * d.E * 4)    /* per-block scalar partials      */       \

@@ -18,6 +18,6 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
                 float* probs_out, int64_t* idx_out, float* lb_out, char* saved, char* scratch, hipStream_t st);
 
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, const float* lb_grad,
-                 char* saved, char* scratch, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st);
+                 char* saved, char* scratch, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st, int parts = 0);
 
 }  // namespace avmoe

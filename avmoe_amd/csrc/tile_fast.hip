@@ -422,15 +422,18 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
 // =====================================================================================================
 // POST_SMALL backward
 // =====================================================================================================
-struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; const void* ZpS; float* dSooT; };   // ZpS / dSooT: gram64 mode
+struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; const void* ZpS; float* dSooT; const float* dApx; };   // ZpS / dSooT: gram64 mode
 
-template <typename T, int E>
+// D16: dApost arrives as T columns (the E x 32 bottleneck entries per group, row stride KPp) + an fp32 side array dApx
+// [token][group][16] with the 3 E scalar columns (the streaming GEMM's split output); otherwise one fp32 array.
+template <typename T, int E, bool D16>
 __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                          const float* __restrict__ uvh, const float* __restrict__ probs, const float* __restrict__ rpmup,
-                                                         const float* __restrict__ dAp, void* __restrict__ dzp_, void* __restrict__ Zp_, void* __restrict__ Zw_,
+                                                         const void* __restrict__ dAp_, void* __restrict__ dzp_, void* __restrict__ Zp_, void* __restrict__ Zw_,
                                                          float* __restrict__ colpart, float* __restrict__ blkscal) {
   constexpr int DZ = E * FDD;
   T* Zp = (T*)Zp_; T* Zw = (T*)Zw_; const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
+  const float* dAp = (const float*)dAp_; const T* dAp16 = (const T*)dAp_;
   __shared__ float s_G[2 * FDG * LD32];
   __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
   __shared__ float s_col[4 * FDD];
@@ -466,10 +469,14 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
       zero_row(zraw);
       const bool saved_zp = a.ZpS != nullptr;                 // gram64 mode: z' was kept by the forward
       if (ok) ld_row<T, E>((saved_zp ? (const T*)a.ZpS : Z) + tok * DZ, e, q, zraw);
+      if constexpr (D16) {
+        zero_row(d);
+        if (ok) { ld_seg<T>(dAp16 + (tok * 2) * t.KPp + e * FDG, d[0], d[1], q); ld_seg<T>(dAp16 + (tok * 2 + 1) * t.KPp + e * FDG, d[2], d[3], q); }
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4& z = zraw[c];
-        d[c] = ok ? ld4(dAp + (tok * 2 + (c >> 1)) * t.KPp + e * FDG + (c & 1) * 16 + 4 * q) : zero4();
+        if constexpr (!D16) d[c] = ok ? ld4(dAp + (tok * 2 + (c >> 1)) * t.KPp + e * FDG + (c & 1) * 16 + 4 * q) : zero4();
         const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
@@ -480,7 +487,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
       if (ok) {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-          const float* p = dAp + (tok * 2 + gi) * t.KPp + E * FDG + 3 * e;
+          const float* p = D16 ? a.dApx + (tok * 2 + gi) * 16 + 3 * e : dAp + (tok * 2 + gi) * t.KPp + E * FDG + 3 * e;
           da1 += p[0]; da2 += p[1]; da3 += p[2];
         }
         rp = rpmup[tok * E + e]; mup = rpmup[(long)t.NT * E + tok * E + e];
@@ -998,7 +1005,7 @@ int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_pt
   return OK;
 }
 
-int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st, int dap16) {
   const Dims& d = pl.d;
   dim3 grid; int per; fast_grid(d, &grid, &per);
   FPostBArgs a;
@@ -1006,10 +1013,15 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
   a.ZpS = d.gram64 ? (const void*)(saved + pl.o_ZpS) : nullptr;
   a.dSooT = d.gram64 ? (float*)(scratch + pl.o_dSooT) : nullptr;
-  LAUNCH_TE(d.bf16, kf_post_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
-            (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),
-            (const float*)(scratch + pl.o_dAp), (void*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),
-            (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
+  a.dApx = (const float*)(scratch + pl.o_dApx);
+  if (dap16 && !d.bf16) { set_last_error("post_small_bwd: split dApost is a bf16 form"); return ERR_BAD_ARG; }
+#define POSTB_ARGS a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),                       \
+            (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),                     \
+            (const void*)(scratch + pl.o_dAp), (void*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),       \
+            (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal)
+  if (dap16) LAUNCH_TEX2(true, kf_post_small_bwd, true, POSTB_ARGS);
+  else LAUNCH_TEX2(d.bf16, kf_post_small_bwd, false, POSTB_ARGS);
+#undef POSTB_ARGS
   AVMOE_CHECK_LAUNCH("post_small_bwd (64/32)");
   return OK;
 }

@@ -45,6 +45,37 @@ __global__ void kk_expert_hist(const int64_t* __restrict__ idx, long S, int E, l
   }
 }
 
+// dst1 += src1 ; dst2 += src2 in one launch (fp32 sums, rounded once): the two token tensors of a site pair each collect their
+// second gradient this way when the two sites ran on two streams.  16 bytes per lane; blocks [0, nb1) serve the first pair.
+template <typename T>
+__global__ void __launch_bounds__(256) kk_add2(T* __restrict__ d1, const T* __restrict__ s1, long n1, T* __restrict__ d2, const T* __restrict__ s2, long n2, int nb1) {
+  constexpr int V = 16 / sizeof(T);
+  const bool first = (int)blockIdx.x < nb1;
+  T* d = first ? d1 : d2; const T* s = first ? s1 : s2;
+  const long n = first ? n1 : n2, nblk = first ? nb1 : (long)gridDim.x - nb1, b = first ? blockIdx.x : blockIdx.x - nb1;
+  for (long i = (b * 256 + threadIdx.x) * V; i < n; i += nblk * 256 * V) {
+    if (i + V <= n) {
+      uint4 a = *(const uint4*)(d + i); const uint4 c = *(const uint4*)(s + i);
+      if constexpr (sizeof(T) == 4) {
+        float* A = (float*)&a; const float* C = (const float*)&c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A[k] += C[k];
+      } else {
+        unsigned* A = (unsigned*)&a; const unsigned* C = (const unsigned*)&c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = __builtin_bit_cast(float, A[k] << 16) + __builtin_bit_cast(float, C[k] << 16);
+          const float hi = __builtin_bit_cast(float, A[k] & 0xffff0000u) + __builtin_bit_cast(float, C[k] & 0xffff0000u);
+          A[k] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+        }
+      }
+      *(uint4*)(d + i) = a;
+    } else {
+      for (long j = i; j < n; ++j) d[j] = (T)((float)d[j] + (float)s[j]);
+    }
+  }
+}
+
 }  // namespace avmoe
 
 using namespace avmoe;
@@ -77,6 +108,22 @@ int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
   hipLaunchKernelGGL(kk_adam, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2,
                      eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
   AVMOE_CHECK_LAUNCH("adam_step");
+  return OK;
+}
+
+int avmoe_add2(void* dst1, const void* src1, int64_t n1, void* dst2, const void* src2, int64_t n2, int32_t dtype, void* stream) {
+  if ((n1 > 0 && (!dst1 || !src1)) || (n2 > 0 && (!dst2 || !src2)) || n1 < 0 || n2 < 0 || (dtype != AVMOE_F32 && dtype != AVMOE_BF16)) {
+    set_last_error("avmoe_add2: bad argument"); return ERR_BAD_ARG;
+  }
+  if ((((uintptr_t)dst1 | (uintptr_t)src1 | (uintptr_t)dst2 | (uintptr_t)src2) & 15u) != 0) { set_last_error("avmoe_add2: buffers must be 16-byte aligned"); return ERR_ALIGNMENT; }
+  if (n1 + n2 == 0) return OK;
+  const long per = 256L * 16 * 4;                       // bytes one block moves per sweep
+  const int esz = dtype == AVMOE_BF16 ? 2 : 4;
+  auto blocks = [&](long n) { return n == 0 ? 0L : std::max<long>(1, std::min<long>((n * esz + per - 1) / per, 2048)); };
+  const long nb1 = blocks(n1), nb2 = blocks(n2);
+  if (dtype == AVMOE_BF16) hipLaunchKernelGGL(kk_add2<__bf16>, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, (hipStream_t)stream, (__bf16*)dst1, (const __bf16*)src1, (long)n1, (__bf16*)dst2, (const __bf16*)src2, (long)n2, (int)nb1);
+  else hipLaunchKernelGGL(kk_add2<float>, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, (hipStream_t)stream, (float*)dst1, (const float*)src1, (long)n1, (float*)dst2, (const float*)src2, (long)n2, (int)nb1);
+  AVMOE_CHECK_LAUNCH("add2");
   return OK;
 }
 

@@ -205,7 +205,8 @@ def parity_check(c, material, device):
     import torch
     from oracle import avmoe_oracle as O
     work, lbw = material
-    res = dict(clips=2, idx_equal=True, out_rel_f32=0.0, grad_rel_f32=0.0, out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None)
+    res = dict(clips=2, idx_equal=True, out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None)
+    detail = [] if os.environ.get("AVMOE_PARITY_DETAIL") else None          # dev: per-tensor errors to stderr
 
     def hip(cfg, P, B, X, Y, G, bf16):
         m = new_site(c, cfg.Cx, cfg.Nx, cfg.Cy, cfg.Ny)
@@ -242,7 +243,11 @@ def parity_check(c, material, device):
             res["out_rel_f32"] = max(res["out_rel_f32"], float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()))
             gmax = max(float(v.abs().max()) for v in grads.values())
             for k, v in grads.items():
-                res["grad_rel_f32"] = max(res["grad_rel_f32"], float((got[k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax))
+                e = float((got[k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax)
+                if detail is not None:
+                    detail.append((f"{cfg.Cx}x{cfg.Nx}", k, e, float(v.abs().max()) / gmax))
+                if e > res["grad_rel_f32"]:
+                    res["grad_rel_f32"], res["worst_f32"] = e, f"{k} (C={cfg.Cx}, N={cfg.Nx})"
             if c["dtype"] == "bf16":
                 Xb, Yb, Gb = X.bfloat16().float(), Y.bfloat16().float(), G.bfloat16().float()
                 fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw)
@@ -259,6 +264,9 @@ def parity_check(c, material, device):
     for k in ("out_rel_f32", "grad_rel_f32", "out_rel_bf16", "grad_relnorm_bf16"):
         if res[k] is not None:
             res[k] = float(f"{res[k]:.3e}")
+    if detail:
+        for row in sorted(detail, key=lambda r: -r[2])[:25]:
+            print("parity f32 %-12s %-46s err %.3e  scale/gmax %.3e" % row, file=sys.stderr)
     res["checked_against"] = "oracle/avmoe_oracle.py (pinned on the reference's vectors: tests/test_oracle_golden.py)"
     return res
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 3
+#define AVMOE_ABI_VERSION 4
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -121,6 +121,19 @@ int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y,
                        const void* dOut, const float* lb_grad, void* saved, void* scratch,
                        void* dX, void* dY, const avmoe_moe_ptrs* grads, void* stream);
 
+/* ABI 4 -- the same backward in stream-ordered sections.  `parts` is a bit mask: 1 = the GEMMs against dOut and the bottleneck /
+ * weight space (touches neither dX nor dY), 2 = the GEMMs against X (every writer of dX), 4 = the chain back to Y and the remap
+ * parameters (every writer of dY); 0 or 7 = all of it (== avmoe_moe_backward).  Sections must be run in this order with the
+ * same arguments; between calls the caller may record / wait events on the stream but must leave `saved` and `scratch` alone.
+ * Purpose: a token tensor that feeds two sites (the audio tokens are X of the audio site and Y of the visual site,
+ * net_trans_v3.py:695-698) collects both gradients in ONE buffer while the two sites run on two streams -- the smaller site
+ * runs through and overwrites (its dY / dX), an event orders the larger site's sections 2 and 4 behind it, and that site adds
+ * its dX / dY in the GEMM epilogues (accumulate_dx / accumulate_dy).
+ * Not available (AVMOE_ERR_UNSUPPORTED) for sites with latent self attention (AVS v2), whose last section writes dX too.        */
+int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
+                            const void* dOut, const float* lb_grad, void* saved, void* scratch,
+                            void* dX, void* dY, const avmoe_moe_ptrs* grads, int32_t parts, void* stream);
+
 /* Sub-op (tests / partial adoption): the router alone -- Sequential(Linear(2C,128), ReLU, Linear(128,32), ReLU,
  * Linear(32,E)) + optional logit noise + softmax + first-max argmax  (net_trans_v3.py:460-466,477-479).
  * rin (S, 2C) f32 = [mean over tokens of x | mean over tokens of the remapped other modality]; same workspaces as the
@@ -146,6 +159,9 @@ int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char*
 int avmoe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 int avmoe_expert_histogram(const int64_t* idx, int64_t S, int32_t E, int64_t* counts, void* stream);
+/* ABI 4 -- dst1 += src1 and dst2 += src2 (n1 / n2 elements of `dtype`, 16-byte aligned) in ONE launch: how the two token tensors of a
+ * site pair (net_trans_v3.py:695-698) collect their second gradient when the two sites' backward passes ran on two streams.   */
+int avmoe_add2(void* dst1, const void* src1, int64_t n1, void* dst2, const void* src2, int64_t n2, int32_t dtype, void* stream);
 /* Extension (no reference counterpart; BASELINE config 3 "router top-k=2"): idx (S, k) int64 = the k most probable experts of
  * every frame from probs (S, E) f32, most probable first, equal probabilities in expert order -- column 0 is the forward's
  * first-max argmax.  The mixture itself stays dense (net_trans_v3.py:482-486).                                          */

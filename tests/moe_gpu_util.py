@@ -47,8 +47,12 @@ class MoeRun:
         self.GUARD = 4096
         self._saved_all = torch.full((nsaved + self.GUARD,), 0xAB, dtype=torch.uint8, device=dev)
         self._scratch_all = torch.full((nscratch + self.GUARD,), 0xAB, dtype=torch.uint8, device=dev)
-        self._saved_all[:nsaved] = 0
-        self._scratch_all[:nscratch] = 0
+        # the workspaces arrive UNINITIALISED in production (torch.empty in the facade): poison them (0xFF.. = NaN in fp32 and bf16)
+        # so that a kernel that relies on zeroed padding shows up as NaN here; AVMOE_TEST_ZERO_WS=1 restores zeroed workspaces
+        import os
+        poison = 0 if os.environ.get("AVMOE_TEST_ZERO_WS") else 0xFF
+        self._saved_all[:nsaved] = poison
+        self._scratch_all[:nscratch] = poison
         self.saved, self.scratch = self._saved_all[:nsaved], self._scratch_all[:nscratch]
         self.table = {n: (r, o, b) for (n, r, o, b) in cm.buffer_table(self.L, self.desc)}
         self.out = torch.empty_like(self.X)

@@ -133,4 +133,4 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_allreduce_bytes"] > 0
-    assert d["roofline"]["frac"] > 0 and d["roofline"]["mfma"]["frac"] > 0 and d["roofline"]["dominant_kernel"]["kernel"]
+    assert d["roofline"]["achieved"] > 0 and d["roofline"]["mfma"]["achieved"] > 0 and d["roofline"]["dominant_kernel"]["kernel"]

@@ -54,3 +54,42 @@ def test_backward_bf16_close_to_reference_vectors(name):
         if err > tol * max(refn[k], 0.25 * gmax if k not in ("X", "Y") else refn[k]):
             bad[k] = (err, refn[k])
     assert not bad, bad
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_backward_sections_equal_the_whole(bf16):
+    """avmoe_moe_backward_part with parts = 1, 2, 4 in turn == avmoe_moe_backward, bit for bit (ABI 4); a site with latent self
+    attention (its last section writes dX too) refuses the split."""
+    import ctypes as C
+    from avmoe_amd import _capi as capi
+    from avmoe_amd import _capi_moe as cm
+    from tests.moe_gpu_util import MoeRun
+    meta, cfg, t = load_golden("ave_wide_train")
+    P, B = split_params(t)
+    whole = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=bf16, training=True).forward()
+    g0 = whole.backward(t["grad_out"])
+    run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=bf16, training=True).forward()
+    run.dOut = t["grad_out"].to(run.dev, run.tdt).contiguous()
+    run.dX, run.dY = torch.empty_like(run.X), torch.empty_like(run.Y)
+    run.grads = {k: torch.full_like(v, float("nan")) for k, v in run.params.items()}
+    gptrs = cm.make_ptrs(run.grads, cfg.E_m, cfg.E_s)
+    lbw = torch.zeros(1, device=run.dev)
+    for parts in (1, 2, 4):
+        st = run.L.avmoe_moe_backward_part(C.byref(run.desc), run.X.data_ptr(), run.Y.data_ptr(), C.byref(run.ptrs), run.dOut.data_ptr(),
+                                           lbw.data_ptr(), run.saved.data_ptr(), run.scratch.data_ptr(), run.dX.data_ptr(), run.dY.data_ptr(),
+                                           C.byref(gptrs), parts, torch.cuda.current_stream().cuda_stream)
+        capi.check(st, "avmoe_moe_backward_part")
+    torch.cuda.synchronize()
+    assert torch.equal(run.dX.float().cpu(), g0["X"]) and torch.equal(run.dY.float().cpu(), g0["Y"])
+    for k, v in run.grads.items():
+        assert torch.equal(v.cpu(), g0[k]), k
+    meta, cfg, t = load_golden("avs_v2_train")
+    P, B = split_params(t)
+    r2 = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=bf16, training=True).forward()
+    r2.dOut = t["grad_out"].to(r2.dev, r2.tdt).contiguous()
+    r2.dX, r2.dY = torch.empty_like(r2.X), torch.empty_like(r2.Y)
+    gr = {k: torch.zeros_like(v) for k, v in r2.params.items()}
+    st = r2.L.avmoe_moe_backward_part(C.byref(r2.desc), r2.X.data_ptr(), r2.Y.data_ptr(), C.byref(r2.ptrs), r2.dOut.data_ptr(), lbw.data_ptr(),
+                                      r2.saved.data_ptr(), r2.scratch.data_ptr(), r2.dX.data_ptr(), r2.dY.data_ptr(),
+                                      C.byref(cm.make_ptrs(gr, cfg.E_m, cfg.E_s)), 1, torch.cuda.current_stream().cuda_stream)
+    assert st == -2                                       # AVMOE_ERR_UNSUPPORTED

@@ -31,6 +31,13 @@ CASES = {
     # cfg-4 (AVQA: 1 + 2 experts, 2 latent tokens, 4 groups; Swin-L stages 0 and 2)
     "cfg4_avqa_stage2_visual_side": dict(cfg=dict(Cx=768, Nx=144, Cy=384, Ny=256, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
     "cfg4_avqa_stage0_audio_side": dict(cfg=dict(Cx=96, Nx=4096, Cy=192, Ny=2304, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    "cfg4_avqa_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=768, Ny=144, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    "cfg4_avqa_stage2_audio_side_b2": dict(cfg=dict(Cx=384, Nx=256, Cy=768, Ny=144, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=20),
+    # cfg-1 stages 1 and 3 (skipped by the AVE launcher's num_skip = 2, present with num_skip = 1: SURVEY 8a-6)
+    "cfg1_stage1_audio_side": dict(cfg=dict(Cx=192, Nx=1024, Cy=256, Ny=576, reduction=8, groups=2, K=32, variant="ave"), S=2),
+    "cfg1_stage1_visual_side": dict(cfg=dict(Cx=256, Nx=576, Cy=192, Ny=1024, reduction=8, groups=2, K=32, variant="ave"), S=2),
+    "cfg1_stage3_audio_side": dict(cfg=dict(Cx=768, Nx=64, Cy=1024, Ny=36, reduction=8, groups=2, K=32, variant="ave"), S=4),
+    "cfg1_stage3_visual_side": dict(cfg=dict(Cx=1024, Nx=36, Cy=768, Ny=64, reduction=8, groups=2, K=32, variant="ave"), S=4),
     # cfg-5 (AVS: 4 + 4 experts, bottleneck 128, latent self attention v2, 5 frames; PVT-v2-b5 stage 3 x HTS-AT)
     "cfg5_avs_stage3_visual_side": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
     "cfg5_avs_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=320, Ny=196, reduction=3, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
