@@ -71,13 +71,11 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None):
     Y = Y.contiguous()
     S, N, Cc = X.shape
     desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
-    tensors = dict(zip(names, params))
-    for k, v in tensors.items():
+    for k, v in zip(names, params):
         if v.dtype != torch.float32 or not v.is_contiguous() or v.device != X.device:
             raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {X.device}")
-    bufs = module._buffer_tensors()
     keep = module._attention_keep(S, N, X.device)
-    ptrs = cm.make_ptrs({**tensors, **bufs, **keep}, module.num_multimodal_experts, module.num_singlemodal_experts)
+    ptrs = module._fill_ptrs(params, keep)
     nsaved = L.avmoe_moe_saved_bytes(C.byref(desc))
     if nsaved == 0:
         raise capi.AvmoeError(L.avmoe_last_error().decode())
@@ -115,21 +113,22 @@ class _SiteBackward:
         (desc, keep), self.saved, self.X, self.Y = state
         self.desc, self.names, self.module = desc, names, module
         tensors = dict(zip(names, params))
-        self.ptrs = cm.make_ptrs({**tensors, **module._buffer_tensors(), **keep}, module.num_multimodal_experts,
-                                 module.num_singlemodal_experts)
+        self.ptrs = module._fill_ptrs(params, keep)
         # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
         # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
         # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
         sink = self.sink = getattr(module, "_grad_sink", None)
         self.use_sink = sink is not None and all(needs) and sink.matches(names, tensors)
+        filler = module._site_cache()["fill_p"]
+        self.gptrs = cm.MoePtrs()
         if self.use_sink:
             # zeros, not empty: on accumulation micro-steps the alignment padding is added to the bucket as well
             self.flat = sink.flat if sink.fresh else torch.zeros_like(sink.flat)
-            self.grads = {k: self.flat[o:o + v.numel()].view_as(v) for (k, v), o in zip(tensors.items(), sink.offsets)}
+            self.grads = None                            # the kernels write at flat + offset: no per-parameter views needed
+            filler.fill(self.gptrs, None, base_ptr=self.flat.data_ptr(), offsets=sink.offsets)
         else:
             self.grads = {k: (torch.empty_like(v) if needs[i] else None) for i, (k, v) in enumerate(tensors.items())}
-        self.gptrs = cm.make_ptrs({k: v for k, v in self.grads.items() if v is not None}, module.num_multimodal_experts,
-                                  module.num_singlemodal_experts)
+            filler.fill(self.gptrs, [self.grads[k] for k in names])
         self.d_out = d_out.to(self.X.dtype).contiguous()
         self.lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
         self.scratch = _scratch(self.X.device, self.L.avmoe_moe_scratch_bytes(C.byref(desc)))
@@ -408,8 +407,51 @@ class MoEAdapter(nn.Module):
         d.ln_eps = experts[0].ln_before.eps if self.opt.is_before_layernorm else 1e-5
         return d
 
+    def _site_cache(self):
+        """Per-module bookkeeping that does not change from call to call (walking named_parameters / named_buffers and resolving
+        state_dict keys costs ~0.25 ms per call otherwise -- at the reference's batch of 2 clips that is most of a site's step):
+        parameter names / objects, where each float buffer lives, the key -> ABI-field resolution, the BatchNorm counters.
+        `refresh()` drops it (call after adding / replacing Parameters; .to(), load_state_dict and FlatAdam keep the objects)."""
+        c = self.__dict__.get("_avmoe_cache")
+        if c is None:
+            named = list(self.named_parameters())
+            names = tuple(k for k, _ in named)
+            params = [p for _, p in named]
+            bufs = []                                                  # (key, owner module, attribute)
+            for mod_name, mod in self.named_modules():
+                for attr, b in mod._buffers.items():
+                    if b is not None and b.is_floating_point():
+                        bufs.append(((mod_name + "." if mod_name else "") + attr, mod, attr))
+            E_m, E_s = self.num_multimodal_experts, self.num_singlemodal_experts
+            c = dict(names=names, params=params, bufs=bufs, fill_p=cm.PtrFiller(names, E_m, E_s),
+                     fill_b=cm.PtrFiller([k for k, _, _ in bufs], E_m, E_s),
+                     bn=[m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None])
+            self.__dict__["_avmoe_cache"] = c
+        return c
+
+    def refresh(self):
+        self.__dict__.pop("_avmoe_cache", None)
+
     def _param_tensors(self):
-        return {k: v for k, v in self.named_parameters()}
+        c = self._site_cache()
+        return dict(zip(c["names"], c["params"]))
+
+    def _fill_ptrs(self, params, keep=None):
+        """MoePtrs of this site's parameters (in _site_cache order), float buffers and -- for the "v1" experts -- dropout draws."""
+        c = self._site_cache()
+        P = cm.MoePtrs()
+        c["fill_p"].fill(P, params)
+        bufs = [m._buffers[a] for _, m, a in c["bufs"]]
+        for b in bufs:
+            if b.dtype != torch.float32 or not b.is_contiguous():
+                raise capi.AvmoeError("BatchNorm running statistics must be contiguous float32 tensors")
+        c["fill_b"].fill(P, bufs)
+        if keep:
+            P2 = cm.make_ptrs(keep, self.num_multimodal_experts, self.num_singlemodal_experts)
+            for j in range(self.num_multimodal_experts + self.num_singlemodal_experts):
+                if P2.e[j].sa_keep:
+                    P.e[j].sa_keep = P2.e[j].sa_keep
+        return P
 
     def grad_layout(self, align: int = 64):
         """(names, offsets, total) of this site's parameter gradients inside one flat fp32 buffer (offsets in elements,
@@ -423,18 +465,18 @@ class MoEAdapter(nn.Module):
     def _bump_batches_tracked(self):
         """num_batches_tracked += 1 of every BatchNorm of the site in ONE kernel: the buffers are kept as views of one
         int64 tensor (rebuilt whenever .to() / load_state_dict detached them)."""
-        mods = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        mods = self._site_cache()["bn"]
         if not mods:
             return
-        flat = getattr(self, "_nbt_flat", None)
+        flat = self.__dict__.get("_nbt_flat")
         ok = flat is not None and flat.numel() == len(mods) and all(
-            m.num_batches_tracked.device == flat.device and
-            m.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, m in enumerate(mods))
+            m._buffers["num_batches_tracked"].data_ptr() == flat.data_ptr() + 8 * i for i, m in enumerate(mods)) and \
+            mods[0]._buffers["num_batches_tracked"].device == flat.device
         if not ok:
             flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in mods])
             for i, m in enumerate(mods):
                 m.num_batches_tracked = flat[i]
-            self._nbt_flat = flat
+            self.__dict__["_nbt_flat"] = flat
         flat += 1
 
     def _buffer_tensors(self):

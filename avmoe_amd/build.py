@@ -46,9 +46,22 @@ def is_fresh() -> bool:
         return fh.read().strip() == _digest()
 
 
+def _obj_digest(src):
+    """source + every header / include file of csrc/ + the public header + the flags: what an object depends on"""
+    h = hashlib.sha256()
+    deps = [src] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "avmoe.h"))
+    for p in deps:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every .hip/.cpp under csrc/ into one shared library.  Objects are built in parallel
-    (one hipcc per translation unit) and then linked."""
+    (one hipcc per translation unit; an object whose source, headers and flags are unchanged is kept) and then linked."""
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and is_fresh():
         return LIB
@@ -57,16 +70,46 @@ def build(force: bool = False, verbose: bool = True) -> str:
     cflags = [f for f in FLAGS if f != "-shared"]
     procs = []
     objs = []
+    jobs = int(os.environ.get("AVMOE_BUILD_JOBS", str(max(1, min(8, os.cpu_count() or 1)))))
+    pending = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
+        dig, stamp = _obj_digest(src), obj + ".stamp"
+        if not force and os.path.isfile(obj) and os.path.isfile(stamp) and open(stamp).read().strip() == dig:
+            continue
+        pending.append((src, obj, stamp, dig))
+    pending.sort(key=lambda t: -os.path.getsize(t[0]) if not os.path.basename(t[0]).startswith("tile_gen") else -10 ** 9)   # longest first
+    running = []
+
+    def reap(block):
+        for item in list(running):
+            src, proc, stamp, dig = item
+            if block:
+                proc.wait()
+            if proc.poll() is None:
+                continue
+            running.remove(item)
+            if proc.returncode != 0:
+                for _s, pr, _a, _b in running:
+                    pr.wait()
+                raise RuntimeError(f"hipcc failed on {src}")
+            with open(stamp, "w") as fh:
+                fh.write(dig)
+            if block:
+                return
+    import time as _t
+    for src, obj, stamp, dig in pending:
+        while len(running) >= jobs:
+            reap(False)
+            if len(running) >= jobs:
+                _t.sleep(0.05)
         cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
         if verbose:
             print("[avmoe_amd.build]", " ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+        running.append((src, subprocess.Popen(cmd), stamp, dig))
+    while running:
+        reap(True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
         print("[avmoe_amd.build]", " ".join(cmd), flush=True)

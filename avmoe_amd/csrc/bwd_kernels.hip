@@ -533,6 +533,42 @@ __global__ void kk_nxn_axpy(const void* X_, const void* R_, const float* dsr, lo
     stT<T>(dX, i, ldT<T>(dX, i) + d2 * ldT<T>(R, i) - (replaces ? g : 0.f));
   }
 }
+__global__ void kk_merge_gather(W16 gdown, W16 gup, const float* __restrict__ gWd, const float* __restrict__ gWu, int E, int d, int C, int mg) {
+  const int dgt = d / mg, Cgt = C / mg;
+  const long per = (long)d * Cgt, total = (long)E * per;          // elements of one grouped weight: d * C / mg == C * d / mg
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int e = (int)(i / per);
+    const long r = i - (long)e * per;
+    if (gdown.p[e]) {                                      // (d, C / mg): row j reads its group's channel block
+      const int j = (int)(r / Cgt), cc = (int)(r % Cgt);
+      gdown.p[e][r] = gWd[((long)e * d + j) * C + (j / dgt) * Cgt + cc];
+    }
+    if (gup.p[e]) {                                        // (C, d / mg): row c reads its group's bottleneck block
+      const int c = (int)(r / dgt), jj = (int)(r % dgt);
+      gup.p[e][r] = gWu[((long)e * C + c) * d + (c / Cgt) * dgt + jj];
+    }
+  }
+}
+int k_merge_gather(const Plan& pl, char* scratch, const avmoe_moe_ptrs& grads, hipStream_t st) {
+  const Dims& d = pl.d;
+  W16 gd, gu;
+  for (int e = 0; e < MAX_E; ++e) { gd.p[e] = grads.e[e].down_w; gu.p[e] = grads.e[e].up_w; }
+  const long total = (long)d.E * d.d * (d.C / d.mg);
+  hipLaunchKernelGGL(kk_merge_gather, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, gd, gu,
+                     (const float*)(scratch + pl.o_gWd), (const float*)(scratch + pl.o_gWu), d.E, d.d, d.C, d.mg);
+  AVMOE_CHECK_LAUNCH("merge_gather");
+  return OK;
+}
+avmoe_moe_ptrs merged_grads(const Plan& pl, const avmoe_moe_ptrs& grads, char* scratch) {
+  avmoe_moe_ptrs p = grads;
+  const Dims& d = pl.d;
+  for (int e = 0; e < d.E; ++e) {        // the kernels write dense gradients here; k_merge_gather hands the diagonal blocks to the caller
+    if (grads.e[e].down_w) p.e[e].down_w = (float*)(scratch + pl.o_gWd) + (size_t)e * d.d * d.C;
+    if (grads.e[e].up_w) p.e[e].up_w = (float*)(scratch + pl.o_gWu) + (size_t)e * d.d * d.C;
+  }
+  return p;
+}
+
 int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, int slot, int replaces, hipStream_t st) {
   ProfScope ps_("k_nxn_axpy", 0.0, 0.0, st);
   const Dims& d = pl.d;

@@ -671,6 +671,45 @@ __global__ void kk_colsum_finalize(const float* colsum, int DZ, int slot, float 
   if (col >= DZ) return;
   out[col] = colsum[(long)slot * DZ + col] * scale;
 }
+// ---- merged groups -----------------------------------------------------------------------------------------------------------
+__global__ void kk_merge_expand(P16 down, P16 up, float* __restrict__ mWd, float* __restrict__ mWu, int E, int d, int C, int mg) {
+  const int dgt = d / mg, Cgt = C / mg;
+  const long per = (long)d * C, total = (long)E * per;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int e = (int)(i / per);
+    const long r = i - (long)e * per;
+    {                                                      // down: (d, C) from (d, C / mg)
+      const int j = (int)(r / C), c = (int)(r % C);
+      mWd[i] = (c / Cgt == j / dgt) ? down.p[e][(long)j * Cgt + c % Cgt] : 0.f;
+    }
+    {                                                      // up: (C, d) from (C, d / mg)
+      const int c = (int)(r / d), j = (int)(r % d);
+      mWu[i] = (j / dgt == c / Cgt) ? up.p[e][(long)c * dgt + j % dgt] : 0.f;
+    }
+  }
+}
+int k_merge_expand(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  P16 dn, up;
+  for (int e = 0; e < MAX_E; ++e) { dn.p[e] = prm.e[e].down_w; up.p[e] = prm.e[e].up_w; }
+  for (int e = 0; e < d.E; ++e)
+    if (!dn.p[e] || !up.p[e]) { set_last_error("moe: expert %d has no down/up weights", e); return ERR_BAD_ARG; }
+  const long total = (long)d.E * d.d * d.C;
+  hipLaunchKernelGGL(kk_merge_expand, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, dn, up,
+                     (float*)(saved + pl.o_mWd), (float*)(saved + pl.o_mWu), d.E, d.d, d.C, d.mg);
+  AVMOE_CHECK_LAUNCH("merge_expand");
+  return OK;
+}
+avmoe_moe_ptrs merged_params(const Plan& pl, const avmoe_moe_ptrs& prm, char* saved) {
+  avmoe_moe_ptrs p = prm;
+  const Dims& d = pl.d;
+  for (int e = 0; e < d.E; ++e) {
+    p.e[e].down_w = (float*)(saved + pl.o_mWd) + (size_t)e * d.d * d.C;
+    p.e[e].up_w = (float*)(saved + pl.o_mWu) + (size_t)e * d.d * d.C;
+  }
+  return p;
+}
+
 int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   const Dims& d = pl.d;
   ProfScope ps_("k_mid", (long)d.NT, (double)d.NT * d.DZ * (double)(d.zsz + d.esz), 0.0, st);
@@ -680,6 +719,7 @@ int k_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   const int nblk = d.nblk_tok;
   const int rpb = cdiv(d.NT, nblk);
   if (tile_fast_ok(d)) AVMOE_TRY(kf_mid(pl, saved, scratch, st));
+  else if (d.gen) AVMOE_TRY(kg_mid(pl, saved, scratch, st));
   else DISPATCH_T(d.bf16, kk_mid, dim3(nblk), dim3(256), 0, st, a, (const float*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
                   (void*)(scratch + pl.o_Zp), (float*)(scratch + pl.o_colpart), rpb);
   AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 1, st));

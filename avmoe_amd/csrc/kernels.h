@@ -13,6 +13,12 @@ struct W16 { float* p[MAX_E]; };
 // ---- forward: weight preparation -------------------------------------------------------------
 int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, const float* Wf, hipStream_t st);
 int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st);
+// merged groups (Dims::mg): block-diagonal dense copies of the grouped down_sampler / up_sampler weights, and the way back for
+// their gradients (only the diagonal blocks are parameters)
+int k_merge_expand(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st);
+int k_merge_gather(const Plan& pl, char* scratch, const avmoe_moe_ptrs& grads, hipStream_t st);
+avmoe_moe_ptrs merged_params(const Plan& pl, const avmoe_moe_ptrs& prm, char* saved);
+avmoe_moe_ptrs merged_grads(const Plan& pl, const avmoe_moe_ptrs& grads, char* scratch);
 // ---- forward: token statistics ---------------------------------------------------------------
 int k_rowstats(int bf16, const void* X, long rows, int C, float* out_sum_sq /* [2][rows] */, hipStream_t st);
 int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st);   // row sums + column means of X
@@ -70,6 +76,14 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
 int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+// register-resident kernels generalised over groups (1 / 2 / 4), per-group bottleneck (16 .. 96) and latent slots (16 / 32 / 96): tile_gen.hip
+bool tile_gen_ok(const Dims& d);
+int kg_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kg_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kg_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st, int dap16 = 0);
+int kg_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
+int kg_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
+int kg_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 // streaming Gram of z' for the register-resident shape in bf16 (gram.hip): out[g*E][dgp][dgp] = scale * sum_t w[e][t] z' z'^T
 int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st);
 // generic helpers

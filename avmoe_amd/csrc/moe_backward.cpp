@@ -22,11 +22,13 @@ avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* 
 // Sections are stream-ordered through `scratch`: a caller may put event records / waits between them (AdapterPair orders the
 // two sites' accumulations into the shared token gradients this way) but nothing that touches the workspaces.
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const void* dOut, const float* lb_grad,
-                 char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st, int parts) {
+                 char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads_in, hipStream_t st, int parts) {
   const Dims& d = pl.d;
   if (parts == 0) parts = 7;
   if (parts != 7 && d.Kcx > 0) { set_last_error("split backward: sites with latent self attention write dX in the last section"); return ERR_UNSUPPORTED; }
-  const avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
+  avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
+  avmoe_moe_ptrs grads = grads_in;
+  if (d.mg) { prm = merged_params(pl, prm, sv); grads = merged_grads(pl, grads_in, sc); }     // the forward left the dense copies in `saved`
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
@@ -51,7 +53,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.sA2 = d.Cg; g.sB2 = (long)d.Cg * d.KPp; g.sCi = (long)d.g * d.KPp; g.sC2 = d.KPp;
     if (d.zsz == 2 && !getenv("AVMOE_DAP_F32")) {          // bf16 main columns + fp32 scalar columns: 640 instead of 1152 bytes per token, written and re-read
       GemmArgs h = g;
-      h.out_dtype = GEMM_BF16; h.Cx = (float*)(sc + pl.o_dApx); h.nsplit = d.E * d.dgp; h.ldcx = (long)d.g * 16; h.sCx2 = 16;
+      h.out_dtype = GEMM_BF16; h.Cx = (float*)(sc + pl.o_dApx); h.nsplit = d.E * d.dgp; h.ldcx = (long)d.g * d.XW; h.sCx2 = d.XW;
       const int r = launch_gemm_stream(h, st);
       if (r < 0) return r;
       dap16 = r == 0;
@@ -126,29 +128,44 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       AVMOE_TRY(run(g, false));
     }
     AVMOE_TRY(k_nxn_axpy(pl, X, sv, sc, dX, 0, 0, st));      // dxr += dsr2 X + dsr0 ; dX += dsr2 xr
-    {                                                      // d att[s] = X[s] dxr[s]^T
-      GemmArgs g = base();
-      g.A = X; g.B = sc + pl.o_dxr; g.C = sc + pl.o_attS;
-      g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.sA1 = g.sB1 = (long)d.N * d.C;
-      g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
-      AVMOE_TRY(run(g, false));
-    }
-    {                                                      // dX[s] += att[s] dxr[s]
-      GemmArgs g = base();
-      g.A = sv + pl.o_att; g.B = sc + pl.o_dxr; g.C = dX;
-      g.M = d.N; g.N = d.C; g.K = d.N; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = d.S;
-      g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
-      AVMOE_TRY(run(g, false));
-    }
-    AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_att, (const float*)(sc + pl.o_attS), (long)d.S * d.N, d.N, d.Np, sc + pl.o_dSc,
-                                 nullptr, 1, 1, st));
-    for (int tr = 0; tr < 2; ++tr) {                       // dX[s] += dSc[s] X[s]  and  dSc[s]^T X[s]
-      GemmArgs g = base();
-      g.A = sc + pl.o_dSc; g.B = X; g.C = dX;
-      g.M = d.N; g.N = d.C; g.K = d.N; g.a_layout = tr ? MN_MAJOR : K_MAJOR; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C;
-      g.nb1 = d.S; g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
-      g.accumulate = 1;
-      AVMOE_TRY(run(g, false));
+    for (int s0 = 0; s0 < d.S; s0 += d.nxc) {              // d.nxc frames at a time (all of them when the forward kept att: moe_plan.cpp)
+      const int ns = std::min(d.nxc, d.S - s0);
+      const size_t xo = (size_t)s0 * d.N * d.C * esz;
+      const char* Xc = (const char*)X + xo;
+      const char* dxc = sc + pl.o_dxr + xo;
+      char* dXc = (char*)dX + xo;
+      if (d.nxc < d.S) {                                   // the forward ran in chunks too: scores and softmax of these frames again
+        GemmArgs g = base();
+        g.A = Xc; g.B = Xc; g.C = sc + pl.o_attS;
+        g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
+        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
+        AVMOE_TRY(run(g, false));
+        AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_attS), (long)ns * d.N, d.N, d.Np, sv + pl.o_att, d.Np, 1, 1, 1, 1, st));
+      }
+      {                                                    // d att[s] = X[s] dxr[s]^T
+        GemmArgs g = base();
+        g.A = Xc; g.B = dxc; g.C = sc + pl.o_attS;
+        g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
+        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
+        AVMOE_TRY(run(g, false));
+      }
+      {                                                    // dX[s] += att[s] dxr[s]
+        GemmArgs g = base();
+        g.A = sv + pl.o_att; g.B = dxc; g.C = dXc;
+        g.M = d.N; g.N = d.C; g.K = d.N; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = ns;
+        g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt; g.accumulate = 1;
+        AVMOE_TRY(run(g, true));
+      }
+      AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_att, (const float*)(sc + pl.o_attS), (long)ns * d.N, d.N, d.Np, sc + pl.o_dSc,
+                                   nullptr, 1, 1, st));
+      for (int tr = 0; tr < 2; ++tr) {                     // dX[s] += dSc[s] X[s]  and  dSc[s]^T X[s]
+        GemmArgs g = base();
+        g.A = sc + pl.o_dSc; g.B = Xc; g.C = dXc;
+        g.M = d.N; g.N = d.C; g.K = d.N; g.a_layout = tr ? MN_MAJOR : K_MAJOR; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C;
+        g.nb1 = ns; g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
+        g.accumulate = 1;
+        AVMOE_TRY(run(g, true));
+      }
     }
   }
   for (int l = 0; l < d.El; ++l) {                         // dTW[s][slot l] = gate * a^T dzraw  (own expert's columns)
@@ -221,6 +238,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   }
   AVMOE_TRY(k_finish_dT(pl, sv, sc, st));                  // + dtbar / C ; dTy (T, with the dm2 row) ; dTx ; dT0 ; drw, dbf
   AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
+  if (d.mg) AVMOE_TRY(k_merge_gather(pl, sc, grads_in, st));   // diagonal blocks of the dense weight gradients -> the caller's grouped ones
   }
   if (!(parts & 4)) return OK;   // ======================= section 3: phase 6 ====================================
 

@@ -31,8 +31,12 @@ avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* 
 int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const float* noise, void* out,
                 float* probs_out, int64_t* idx_out, float* lb_out, char* sv, char* sc, hipStream_t st) {
   const Dims& d = pl.d;
-  const avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
+  avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
   if (d.mha) AVMOE_TRY(k_fill_f32((float*)(sv + pl.o_scal) + 1, 1, 1.f, st));
+  if (d.mg) {                                              // merged groups: run on block-diagonal dense copies of the grouped weights
+    AVMOE_TRY(k_merge_expand(pl, sv, prm_in, st));
+    prm = merged_params(pl, prm, sv);
+  }
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
@@ -162,20 +166,25 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       AVMOE_TRY(launch_gemm(g, st));
     }
   } else if (d.nxn) {
-    {                                                      // scores[s] = X[s] X[s]^T
-      GemmArgs g = base();
-      g.A = X; g.B = X; g.C = sc + pl.o_attS;
-      g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S; g.sA1 = g.sB1 = (long)d.N * d.C;
-      g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
-      AVMOE_TRY(launch_gemm(g, st));
-    }
-    AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_attS), (long)d.S * d.N, d.N, d.Np, sv + pl.o_att, d.Np, 1, 1, 1, 1, st));
-    {                                                      // xr[s] = att[s]^T X[s]
-      GemmArgs g = base();
-      g.A = sv + pl.o_att; g.B = X; g.C = sv + pl.o_xr;
-      g.M = d.N; g.N = d.C; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.C; g.nb1 = d.S;
-      g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
-      AVMOE_TRY(launch_gemm(g, st));
+    for (int s0 = 0; s0 < d.S; s0 += d.nxc) {              // d.nxc frames at a time through one workspace (all of them when they fit: moe_plan.cpp)
+      const int ns = std::min(d.nxc, d.S - s0);
+      const char* Xc = (const char*)X + (size_t)s0 * d.N * d.C * d.esz;
+      {                                                    // scores[s] = X[s] X[s]^T
+        GemmArgs g = base();
+        g.A = Xc; g.B = Xc; g.C = sc + pl.o_attS;
+        g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
+        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
+        AVMOE_TRY(launch_gemm(g, st));
+      }
+      AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_attS), (long)ns * d.N, d.N, d.Np, sv + pl.o_att, d.Np, 1, 1, 1, 1, st));
+      {                                                    // xr[s] = att[s]^T X[s]
+        GemmArgs g = base();
+        g.A = sv + pl.o_att; g.B = Xc; g.C = sv + pl.o_xr + (size_t)s0 * d.N * d.C * d.esz;
+        g.M = d.N; g.N = d.C; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.C; g.nb1 = ns;
+        g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.out_dtype = dt;
+        g.ksplit = choose_ksplit(g, slab_cap);             // few frames x few column tiles: split the token contraction to fill the chip
+        AVMOE_TRY(launch_gemm(g, st));
+      }
     }
     AVMOE_TRY(k_xrstats(pl, X, sv, 0, st));
     AVMOE_TRY(down_gemm(sv + pl.o_xr, d.NT, sv + pl.o_ZR));

@@ -7,6 +7,7 @@
 namespace avmoe {
 
 bool tile_fast_ok(const Dims& d);   // tile_fast.hip
+bool tile_gen_ok(const Dims& d);    // tile_gen.hip
 
 size_t slab_floats(const Dims& d) {
   // worst split-K user: weight-gradient contractions over all tokens.  Sized generously:
@@ -57,17 +58,6 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   }
   d.esz = d.bf16 ? 2 : 4;
   d.NT = d.S * d.N;
-  d.dg = d.d / d.g;
-  d.dgp = (int)round_up(d.dg, 8);
-  // A per-group bottleneck below 32 is padded to 32 when that makes the site the register-resident shape (2 groups, 32 latent
-  // tokens, 2 - 4 experts: tile_fast.hip): bf16 Z rows of 64 E entries instead of fp32 rows of 4 * g * E * dgp bytes, and kernels
-  // that run 1.3-3x faster than the generic ones (HTS-AT / Swin-B sites at r = 8: bottleneck 48: -29 %, 32: -15 %, 24: -19 %,
-  // 12 / 16: -4 % of the site step).  Padding columns are zero weights, as for every other padded width.
-  if (d.g == 2 && d.dg < 32 && d.K == 32 && d.E >= 2 && d.E <= 4 && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
-  d.Cg = d.C / d.g;
-  d.DD = d.g * d.dgp;
-  d.DZ = d.E * d.DD;
-  if (d.DD > 256) { set_last_error("moe: padded bottleneck %d > 256", d.DD); return ERR_UNSUPPORTED; }
   d.El = 0;
   const bool v1 = d.self_attn == AVMOE_SELF_ATTN_MHA_V1;
   if (v1) {
@@ -95,7 +85,48 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Ey = d.E_m;
   d.Ex = d.El - d.Ey;
   if (d.El == 0) d.K = d.K > 0 ? d.K : 1;
-  d.Kp = (int)round_up(d.K, 8);
+  // ---- bottleneck layout ------------------------------------------------------------------------------------------------
+  static const bool no_gen = getenv("AVMOE_NO_GEN") != nullptr;          // development: without the generalised register-resident kernels
+  const int g_site = d.g;
+  // Merged groups.  A grouped 1x1 convolution is a dense one with a block-diagonal weight.  When the per-group bottleneck is tiny
+  // (AVQA: 4 groups, bottleneck 12 -> 3 per group) padding every GROUP to the 16-entry granule of the register-resident kernels
+  // multiplies the bottleneck-space traffic (4 x 16 = 64 entries for 12 real ones); the whole bottleneck padded once (16) is 4 x
+  // smaller.  Such sites run as ONE group on block-diagonal copies of down_sampler / up_sampler (zeros outside the blocks are
+  // exact, so every statistic and gradient is unchanged; gradients of the zero entries are discarded: moe_forward / moe_backward).
+  // Only where the ungrouped products still fit the streaming GEMMs (C <= 384), and not for the shapes tile_fast.hip serves.
+  bool try_merge = false;
+  {
+    const int merged = (int)round_up(d.d, 16), dg0 = d.d / g_site, grouped = g_site * (int)round_up(dg0, 16), ncg = merged / 16;
+    const bool fast_shape = g_site == 2 && dg0 > 16 && dg0 <= 32 && d.K == 32 && d.E >= 2 && d.E <= 4;
+    try_merge = !no_gen && !getenv("AVMOE_NO_MERGE") && g_site > 1 && d.C <= 384 && merged < grouped && (ncg <= 4 || ncg == 6) && !fast_shape;
+  }
+  for (int attempt = try_merge ? 0 : 1; attempt < 2; ++attempt) {
+    const bool merge = attempt == 0;
+    d.mg = merge ? g_site : 0; d.mdg = merge ? d.d / g_site : 0; d.g = merge ? 1 : g_site;
+    d.dg = d.d / d.g;
+    d.dgp = (int)round_up(d.dg, 8);
+    // A per-group bottleneck below 32 is padded to 32 when that makes the site the register-resident shape (2 groups, 32 latent
+    // tokens, 2 - 4 experts: tile_fast.hip): bf16 Z rows of 64 E entries instead of fp32 rows of 4 * g * E * dgp bytes, and kernels
+    // that run 1.3-3x faster than the generic ones (HTS-AT / Swin-B sites at r = 8: bottleneck 48: -29 %, 32: -15 %, 24: -19 %,
+    // 12 / 16: -4 % of the site step).  Padding columns are zero weights, as for every other padded width.
+    // (Per-group bottlenecks up to 16 stay at 16 entries and run on the generalised kernels of tile_gen.hip instead -- half the Z-space bytes.)
+    if (d.g == 2 && d.dg < 32 && (d.dg > 16 || no_gen) && d.K == 32 && d.E >= 2 && d.E <= 4 && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
+    d.Cg = d.C / d.g;
+    d.DD = d.g * d.dgp;
+    d.DZ = d.E * d.DD;
+    d.Kp = (int)round_up(d.K, 8);
+    // Generalised register-resident kernels (tile_gen.hip) for every other shape they are built for: bottleneck entries per group
+    // padded to a multiple of 16, latent-token slots to 16 / 32 / 96 (zero weights / masked slots, as for every padded width).
+    d.gen = 0;
+    if (!no_gen && !(d.g == 2 && d.dgp == 32 && d.K == 32 && d.E >= 2 && d.E <= 4)) {
+      Dims t = d;
+      t.dgp = (int)round_up(d.dg, 16);
+      if (d.El > 0) t.Kp = d.K <= 16 ? 16 : (d.K <= 32 ? 32 : (d.K <= 96 ? 96 : (int)round_up(d.K, 16)));
+      if (tile_gen_ok(t) && t.g * t.dgp <= 256) { d.dgp = t.dgp; d.Kp = t.Kp; d.DD = d.g * d.dgp; d.DZ = d.E * d.DD; d.gen = 1; }
+    }
+    if (!merge || d.gen) break;          // a merged site must land on the generalised kernels; otherwise plan it grouped
+  }
+  if (d.DD > 256) { set_last_error("moe: padded bottleneck %d > 256", d.DD); return ERR_UNSUPPORTED; }
   d.KL = d.El * d.Kp;          // latent rows per sample, each slot padded to Kp rows (pad rows are zero)
   d.KLT = d.KL + 2;
   d.KLp = (int)round_up(d.KL + 2, 8);
@@ -106,6 +137,17 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Kcxp = (int)round_up(d.Kcx > 0 ? d.Kcx : 1, 8);
   d.KP = d.E * d.dgp + 3 * d.E;
   d.KPp = (int)round_up(d.KP, 8);
+  d.XW = (int)round_up(d.KPp - d.E * d.dgp, 16);
+  // AVVP N x N block: scores / softmax / its gradient are (frames, N, N) tensors.  While all frames fit in a fraction of the
+  // 256 MiB Infinity Cache budget they are formed once and kept for the backward; beyond that the block runs a few frames at a
+  // time through one cache-sized workspace (forward AND backward, which then recomputes scores + softmax): no (S, N, N) tensor in
+  // HBM -- at AVVP stage 0 (N = 4096, 640 frames) that would be 21 GB (bf16) + 43 GB (fp32 scores) per site.
+  d.nxc = d.S;
+  if (d.nxn && !d.mha) {
+    const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (4 + 2 * (size_t)d.esz);
+    static const size_t keep_all = getenv("AVMOE_NXN_KEEP_MB") ? (size_t)atol(getenv("AVMOE_NXN_KEEP_MB")) << 20 : (size_t)256 << 20;
+    if ((size_t)d.S * per_frame > keep_all) d.nxc = (int)std::max<size_t>(1, std::min<size_t>((size_t)d.S, ((size_t)96 << 20) / per_frame));
+  }
   d.Mk = (int)round_up(d.M + 2, 8);
   d.Mb = (int)round_up(d.M + 1, 8);
   d.Np = (int)round_up(d.N, 8);
@@ -116,7 +158,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
     if (sscanf(ev, "%d,%d", &a, &b) == 2) bps = std::max(1, d.N >= 512 ? a : b);
   }
   d.nblk_tok = bps * d.S;
-  d.zsz = tile_fast_ok(d) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident path
+  d.zsz = (tile_fast_ok(d) || d.gen) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident paths
   d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2) && !getenv("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
 

@@ -24,6 +24,8 @@ struct Dims {
   // derived
   int esz;        // bytes of an activation / operand element (T)
   int zsz;        // bytes of a Z / dz' element: T on the register-resident path (tile_fast.hip), else fp32
+  int mg, mdg;    // merged groups: the site's real group count / per-group bottleneck when it is run as ONE group (0: not merged)
+  int gen;        // generalised register-resident kernels (tile_gen.hip): per-group bottleneck padded to 16 n, latent slots to 16 / 32 / 96
   int gram64;     // register-resident shape in bf16: z' is kept forward -> backward and the d x d Grams come from gram.hip
   int NT;         // S * N tokens
   int dg, dgp;    // bottleneck per group, padded to 8
@@ -38,6 +40,7 @@ struct Dims {
   int Kcx;        // Ex * Kp
   int Kp, Kcyp, Kcxp;  // K, Kcy, Kcx padded to 8 (row strides of dTT / dRT / dL1xT)
   int KP, KPp;    // post GEMM depth per group: E*dgp + 3E, padded to 8
+  int XW;         // width (floats) of a (token, group) row of dApx: the 3 E scalar columns of dApost, padded to 16
   int Mk;         // width of Rext / WcK : M + 2 (qr, qb / bc, 1 columns), padded to 8
   int Mb;         // width of Bm_ext: M + 1 (ab column), padded to 8
   int Np;         // N padded to 8
@@ -50,6 +53,7 @@ struct Dims {
   // The unimodal input x + gate * xr of those experts: AVVP shares one xr (slot 0); the AVS "v1" experts (input REPLACED by
   // MultiheadAttention(x) across the frames, PVT_AVSModel_v2.py:210-214) run through the same code with
   // xr = MHA_e(x) - x, gate 1 and one xr slot per expert.
+  int nxc;               // frames per chunk of the N x N block (== S: scores / softmax kept for the backward; < S: recomputed there)
   int nxr;               // xr slots
   int xr_of_e[MAX_E];    // slot of expert e or -1
   int mha;               // "v1" experts present
@@ -71,6 +75,8 @@ struct Dims {
   X(Wt, 0, d.esz, (size_t)d.g * d.E * d.dgp * d.Cg) /* [i][e][jp][c] = Wd*gamma_b     */       \
   X(wsum, 0, 4, (size_t)d.DZ)                                                                   \
   X(dconst, 0, 4, (size_t)d.DZ)                                                                 \
+  X(mWd, 0, 4, d.mg ? (size_t)d.E * d.d * d.C : 1)  /* merged groups: block-diagonal down_sampler (d, C) per expert */ \
+  X(mWu, 0, 4, d.mg ? (size_t)d.E * d.C * d.d : 1)  /* ... up_sampler (C, d) per expert                             */ \
   /* ---- hop 1 (cross-modal experts, source = remapped Y); Kcyb rows per sample ---- */       \
   X(Qx, 0, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)  /* T0 Wf                        */      \
   X(qrqb, 0, 4, (size_t)2 * (d.Kcy ? d.Kcy : 1))                                               \
@@ -104,15 +110,15 @@ struct Dims {
   X(uvh, 0, 4, (size_t)2 * d.DZ + 2 * d.g * d.E)    /* usum, vh, H1[i][e], H2[i][e]   */       \
   X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
   /* ---- AVVP N x N block (only sized when present) ---- */                                     \
-  X(att, 0, d.esz, d.nxn ? (size_t)d.S * d.N * d.Np : 1)        /* softmax_rows(X X^T)            */  \
+  X(att, 0, d.esz, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)   /* softmax_rows(X X^T), nxc frames */  \
   X(xr, 0, d.esz, d.nxn ? (size_t)d.nxr * d.NT * d.C : 1)       /* att^T X  |  MHA_e(X) - X per slot */  \
   X(sxr, 0, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)            /* sum xr, sum xr^2, x . xr  per slot */  \
   X(ZR, 0, 4, d.nxn ? (size_t)d.NT * d.DZ : 1)                  /* xr through Wt                  */  \
-  X(attS, 1, 4, d.nxn ? (size_t)d.S * d.N * d.Np : 1)           /* scores ; d att in the backward */  \
+  X(attS, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)      /* scores ; d att in the backward */  \
   X(dZR, 1, d.esz, d.nxn ? (size_t)d.NT * d.DZ : 1)                                                    \
   X(dsr, 1, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)                                                   \
   X(dxr, 1, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)                                                     \
-  X(dSc, 1, d.esz, d.nxn ? (size_t)d.S * d.N * d.Np : 1)                                               \
+  X(dSc, 1, d.esz, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)                                     \
   /* ---- AVS "v1" MultiheadAttention across the frames, per slot (only sized when present) ---- */ \
   X(mWin, 0, d.esz, d.mha ? (size_t)d.nxr * 3 * d.C * d.C : 1)      /* in_proj_weight in T              */  \
   X(mWout, 0, d.esz, d.mha ? (size_t)d.nxr * d.C * d.C : 1)         /* out_proj.weight in T             */  \
@@ -148,7 +154,7 @@ struct Dims {
   X(dqp, 1, 4, (size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb)                                           \
   X(dRT, 1, d.esz, (size_t)d.S * d.M * d.Kcyp)                                                  \
   X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)          /* f32 ; T (+ dApx) on the register-resident bf16 path */ \
-  X(dApx, 1, 4, d.zsz == 2 ? (size_t)d.NT * d.g * 16 : 1)   /* the 3 E scalar columns of dApost per (token, group), fp32 */ \
+  X(dApx, 1, 4, d.zsz == 2 ? (size_t)d.NT * d.g * d.XW : 1)   /* the 3 E scalar columns of dApost per (token, group), fp32 */ \
   X(dBp, 1, 4, (size_t)d.C * d.KPp)                                                             \
   X(dzp, 1, d.zsz, (size_t)d.NT * d.DZ)                 /* dz' -> dy (in place)           */       \
   X(blkscal, 1, 4, (size_t)d.nblk_tok * d.E * 4)    /* per-block scalar partials      */       \
@@ -180,7 +186,9 @@ struct Dims {
   X(dQ, 1, 4, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                               \
   X(dQT, 1, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                          \
   X(dWf, 1, 4, (size_t)d.C * d.Cy)                                                              \
-  X(dvec, 1, 4, (size_t)2 * d.C + d.Mb + 64)        /* drw, dbf, dwbar, dbcbar        */
+  X(dvec, 1, 4, (size_t)2 * d.C + d.Mb + 64)        /* drw, dbf, dwbar, dbcbar        */       \
+  X(gWd, 1, 4, d.mg ? (size_t)d.E * d.d * d.C : 1)  /* merged groups: gradients of the block-diagonal copies */ \
+  X(gWu, 1, 4, d.mg ? (size_t)d.E * d.C * d.d : 1)
 
 size_t slab_floats(const Dims& d);
 

@@ -1,0 +1,3 @@
+// Translation unit 5 of 5 of the generalised register-resident kernels (tile_gen.inc): split so that the instantiations build in parallel.
+#define GEN_PART 5
+#include "tile_gen.inc"

@@ -406,6 +406,7 @@ int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   for (int e = 0; e < d.E; ++e)
     if (d.nxn_of_e[e] && !prm.e[e].gate_lat) { set_last_error("moe: expert %d lacks gate_av", e); return ERR_BAD_ARG; }
   if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
+  if (d.gen) return kg_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
   for (int e = 0; e < MAX_E; ++e) {
@@ -538,6 +539,7 @@ int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   const Dims& d = pl.d;
   ProfScope ps_("k_post_small", (long)d.NT, bytes_post_small(d), 0.0, st);
   if (tile_fast_ok(d)) return kf_post_small(pl, saved, scratch, prm, st);
+  if (d.gen) return kg_post_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
@@ -1066,9 +1068,13 @@ static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st, int dap16) {
   const Dims& d = pl.d;
   ProfScope ps_("k_post_small_bwd", (long)d.NT, bytes_post_small_bwd(d) - (dap16 ? (double)d.NT * d.g * (d.E * d.dgp * 2.0 + (d.KPp - 16) * 4.0 - d.E * d.dgp * 2.0) : 0.0), 0.0, st);
-  if (dap16 && !tile_fast_ok(d)) { set_last_error("post_small_bwd: split dApost needs the register-resident path"); return ERR_BAD_ARG; }
+  if (dap16 && !tile_fast_ok(d) && !d.gen) { set_last_error("post_small_bwd: split dApost needs a register-resident path"); return ERR_BAD_ARG; }
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_post_small_bwd(pl, saved, scratch, prm, st, dap16));
+    return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
+  if (d.gen) {
+    AVMOE_TRY(kg_post_small_bwd(pl, saved, scratch, prm, st, dap16));
     return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
   }
   dim3 grid; int per; tile_grid(d, &grid, &per);
@@ -1104,6 +1110,10 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
     AVMOE_TRY(kf_mid_bwd(pl, saved, scratch, st));
     return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
   }
+  if (d.gen) {
+    AVMOE_TRY(kg_mid_bwd(pl, saved, scratch, st));
+    return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
   dim3 grid; int per; tile_grid(d, &grid, &per);
   MidBTArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
@@ -1126,6 +1136,10 @@ int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   ProfScope ps_("k_pre_small_bwd", (long)d.NT, bytes_pre_small_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
     AVMOE_TRY(kf_pre_small_bwd(pl, saved, scratch, prm, st));
+    return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
+  if (d.gen) {
+    AVMOE_TRY(kg_pre_small_bwd(pl, saved, scratch, prm, st));
     return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
   }
   dim3 grid; int per; tile_grid(d, &grid, &per);

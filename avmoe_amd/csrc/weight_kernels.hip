@@ -214,7 +214,10 @@ int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   const Dims& d = pl.d;
   WArgs a; fill_w(d, prm, nullptr, &a);
   const size_t sh = (size_t)(d.dgp * (d.dgp + 1) + d.dgp + BS_CH * d.dgp) * sizeof(float);
-  if (sh > 65536) { set_last_error("post_prep: bottleneck per group %d needs %zu B of LDS", d.dg, sh); return ERR_UNSUPPORTED; }
+  if (sh > 160 * 1024) { set_last_error("post_prep: bottleneck per group %d needs %zu B of LDS", d.dg, sh); return ERR_UNSUPPORTED; }
+  if (sh > 65536 && hipFuncSetAttribute((const void*)kw_bn2_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_last_error("post_prep: LDS attribute"); return ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(kw_bn2_stats, dim3(d.g * d.E, cdiv(d.Cg, BS_CH)), dim3(256), sh, st, a, (const float*)(saved + pl.o_mz),
                      (const float*)(saved + pl.o_Szz), (float*)(saved + pl.o_bn2));
   DISPATCH_T(d.bf16, kw_build_bpost, dim3(grid1dw((long)d.C * d.KPp)), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2),
@@ -328,7 +331,10 @@ int k_post_prep_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   WArgs a; fill_w(d, prm, &grads, &a);
   if (d.dg > 32 * PB_JMAX) { set_last_error("post_prep_bwd: bottleneck per group %d > %d", d.dg, 32 * PB_JMAX); return ERR_UNSUPPORTED; }
   const size_t sh = (size_t)(2 * d.dgp * (d.dgp + 1) + 3 * d.dgp + PB_CH * d.dgp) * sizeof(float);
-  if (sh > 65536) { set_last_error("post_prep_bwd: bottleneck per group %d needs %zu B of LDS", d.dg, sh); return ERR_UNSUPPORTED; }
+  if (sh > 160 * 1024) { set_last_error("post_prep_bwd: bottleneck per group %d needs %zu B of LDS", d.dg, sh); return ERR_UNSUPPORTED; }
+  if (sh > 65536 && hipFuncSetAttribute((const void*)kw_post_prep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_last_error("post_prep_bwd: LDS attribute"); return ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(kw_post_prep_bwd, dim3(d.g * d.E, cdiv(d.Cg, PB_CH)), dim3(256), sh, st, a, (const float*)(saved + pl.o_bn2),
                      (const float*)(scratch + pl.o_dBp), (const float*)(scratch + pl.o_dGq), (const float*)(scratch + pl.o_dsm),
                      (const float*)(saved + pl.o_mz), (const float*)(saved + pl.o_Szz), (float*)(scratch + pl.o_dmodv));

@@ -199,13 +199,16 @@ def cpu_baseline(c, budget_s=15.0):
 
 def parity_check(c, material, device):
     """This build against the oracle at the benchmarked shapes, B = 2 clips, through the C ABI behind the module API.
-    fp32: max-abs error relative to the tensor's max (gradients: floor 1e-3 of the largest gradient), indices bit-exact.
+    fp32: outputs max-abs relative to the tensor's max, indices bit-exact, gradients norm-wise per tensor (+ d X row by row).
     bf16: against the oracle evaluated on the bf16-rounded inputs; outputs max-abs relative, gradients norm-wise relative
     (worst over the tensors whose norm is at least 1e-3 of the largest gradient norm)."""
     import torch
     from oracle import avmoe_oracle as O
     work, lbw = material
-    res = dict(clips=2, idx_equal=True, out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None)
+    res = dict(clips=2, idx_equal=True, out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None,
+               measures="out_*: max-abs / max ; grad_rel_f32, grad_relnorm_bf16: norm-wise per tensor, worst tensor (floor 1e-3 of the largest gradient "
+                        "norm) ; dx_rows_above_1e-3: token rows of d X (fp32) whose max-abs error exceeds 1e-3 of max |d X| -- ReLU units within fp32 "
+                        "rounding of zero")
     detail = [] if os.environ.get("AVMOE_PARITY_DETAIL") else None          # dev: per-tensor errors to stderr
 
     def hip(cfg, P, B, X, Y, G, bf16):
@@ -241,13 +244,23 @@ def parity_check(c, material, device):
             if idx is not None:
                 res["idx_equal"] = res["idx_equal"] and bool(torch.equal(idx, fwd["idx"]))
             res["out_rel_f32"] = max(res["out_rel_f32"], float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()))
-            gmax = max(float(v.abs().max()) for v in grads.values())
+            # Gradients.  At these sizes (10^5 .. 10^6 ReLU units per cross-modal expert) a few pre-activations lie within fp32 rounding of
+            # zero in ANY draw; there the mask -- and with it that token's gradient row and ~1/sqrt(tokens) of every sum over tokens -- is
+            # decided by rounding, in the oracle as much as here (measured: one unit at |y| = 1.8e-9 moves d X by 12 % of its maximum in
+            # ONE of 5120 rows, fp32 oracle vs fp64 oracle; the parity tests skip such draws).  So: every tensor norm-wise, d X also row by
+            # row against the 1e-3 bar, with the number of rows that miss it.
+            nmax = max(float(v.norm()) for v in grads.values())
             for k, v in grads.items():
-                e = float((got[k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax)
+                e = float((got[k] - v).norm()) / max(float(v.norm()), 1e-3 * nmax)
                 if detail is not None:
-                    detail.append((f"{cfg.Cx}x{cfg.Nx}", k, e, float(v.abs().max()) / gmax))
+                    detail.append((f"{cfg.Cx}x{cfg.Nx}", k, e))
                 if e > res["grad_rel_f32"]:
                     res["grad_rel_f32"], res["worst_f32"] = e, f"{k} (C={cfg.Cx}, N={cfg.Nx})"
+            row_err = (got["X"] - grads["X"]).abs().amax(-1) / grads["X"].abs().max()
+            res["dx_rows"] = res.get("dx_rows", 0) + row_err.numel()
+            res["dx_rows_above_1e-3"] = res.get("dx_rows_above_1e-3", 0) + int((row_err > 1e-3).sum())
+            ok_rows = row_err[row_err <= 1e-3]
+            res["dx_row_maxabs_f32"] = max(res.get("dx_row_maxabs_f32", 0.0), float(ok_rows.max()) if ok_rows.numel() else 0.0)
             if c["dtype"] == "bf16":
                 Xb, Yb, Gb = X.bfloat16().float(), Y.bfloat16().float(), G.bfloat16().float()
                 fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw)
@@ -261,12 +274,12 @@ def parity_check(c, material, device):
                         e = float((got[k] - v).norm() / v.norm())
                         if e > (res["grad_relnorm_bf16"] or 0.0):
                             res["grad_relnorm_bf16"], res["worst_bf16"] = e, k
-    for k in ("out_rel_f32", "grad_rel_f32", "out_rel_bf16", "grad_relnorm_bf16"):
-        if res[k] is not None:
+    for k in ("out_rel_f32", "grad_rel_f32", "out_rel_bf16", "grad_relnorm_bf16", "dx_row_maxabs_f32"):
+        if res.get(k) is not None:
             res[k] = float(f"{res[k]:.3e}")
     if detail:
         for row in sorted(detail, key=lambda r: -r[2])[:25]:
-            print("parity f32 %-12s %-46s err %.3e  scale/gmax %.3e" % row, file=sys.stderr)
+            print("parity f32 %-12s %-46s err %.3e" % row[:3], file=sys.stderr)
     res["checked_against"] = "oracle/avmoe_oracle.py (pinned on the reference's vectors: tests/test_oracle_golden.py)"
     return res
 

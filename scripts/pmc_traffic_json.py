@@ -55,10 +55,26 @@ def load(path, scale):
     return vals
 
 
+def total_bytes(path, scale):
+    """every kernel of the run, family or not (whole-line readers doubled as in load())"""
+    tot = 0.0
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            f = family(row["Kernel_Name"])
+            tot += float(row["Counter_Value"]) * 1024.0 * (1.0 if (scale == 2.0 and f in HALF_LINE_READERS) else scale)
+    return tot
+
+
 def main():
+    """argv: <fetch_csv> <write_csv> [steps profiled]"""
     rd = load(sys.argv[1], 2.0)
     wr = load(sys.argv[2], 1.0)
+    steps = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     out = {}
+    if steps > 0:       # HBM-side bytes of ONE bench step over every kernel (bench.py: roofline.traffic)
+        out["__total_bytes_per_step__"] = round((total_bytes(sys.argv[1], 2.0) + total_bytes(sys.argv[2], 1.0)) / steps)
+        out["__read_bytes_per_step__"] = round(total_bytes(sys.argv[1], 2.0) / steps)
+        out["__write_bytes_per_step__"] = round(total_bytes(sys.argv[2], 1.0) / steps)
     for f in sorted(set(rd) | set(wr)):
         r, w = rd.get(f, [0.0]), wr.get(f, [0.0])
         out[f] = {"launches_profiled": max(len(r), len(w)), "read_bytes_per_launch": round(sum(r) / len(r)),

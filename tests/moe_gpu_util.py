@@ -114,12 +114,15 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
     d = run.desc
     T = run.tdt
     g, dg = cfg.groups, cfg.d // cfg.groups
-    dgp = -(-dg // 8) * 8
     E, K, N, Cc = cfg.E, cfg.K, cfg.Nx, cfg.Cx
+    # paddings as the library planned them (they depend on which kernel family serves the shape): read them off the buffer sizes
+    dgp = run.table["wsum"][2] // 4 // (E * g)          # wsum: DZ = E * g * dgp floats
     sv = A.sv
     lat = [j for j, ex in enumerate(A.experts) if ex.latent]
     El = len(lat)
-    Kp = -(-K // 8) * 8                     # latent slots are padded to Kp rows (padding rows are zero)
+    esz = 2 if run.bf16 else 4
+    KLT_ = run.table["Text"][2] // esz // (S * Cc)       # Text: S * KLT * C elements, KLT = El * Kp + 2
+    Kp = (KLT_ - 2) // El if El else -(-K // 8) * 8       # latent slots are padded to Kp rows (padding rows are zero)
     KL = El * Kp
     KLT, KLp = KL + 2, -(-(KL + 2) // 8) * 8
     DZ = E * g * dgp

@@ -86,7 +86,7 @@ def test_loop_equals_site_by_site(dtype, fuse):
 
     ref, got = run(False), run(True)
     assert got[2] == ref[2] and len(got[2]["audio"]["p1"]) == 4 and len(got[2]["video"]["p2"]) == 4
-    tol = 1e-4 if dtype == torch.float32 else 5e-2      # bf16: four adapted blocks deep, the fused add rounds once instead of twice
+    tol = 1e-4 if dtype == torch.float32 else 8e-2      # bf16 (activations AND bottleneck-space tensors), four adapted blocks deep; the fused add rounds once instead of twice
     gscale = max(float(a.float().abs().max()) for a in ref[5])      # gradients that are analytically zero (a bias in front of a
     def close(a, b, what, floor=0.0):                                # BatchNorm) are rounding noise: judge them on the global scale
         if dtype == torch.float32:
