@@ -16,6 +16,7 @@
 #include "common.h"
 #include "prof.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace avmoe {
 
@@ -421,6 +422,10 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   STREAM_CASE(tiles <= 12 && a.M % 64 == 0, 2, 3, 1, 12, 64, 1, true, true, "gemm_stream_k64+96mn_n192")   // dY into <= 192 channels
   STREAM_CASE(true, 5, 0, 2, 12, SC_OUT_BM, SC_OUT_PC, false, true, "gemm_stream_k160_n384")    // output GEMM: K = 4*32 + 12, N = 384 per group (+= for accumulate_out)
   STREAM_CASE(true, 12, 0, 2, 4, 32, SC_DOWN_PC, false, false, "gemm_stream_k384_n128")   // grouped down projection
+  {
+    static const bool tpw2 = getenv("AVMOE_DAP_TPW2") != nullptr;        // dev A/B: 5 waves x 2 column tiles instead of 9 x 1
+    if (tpw2) { STREAM_CASE(true, 12, 0, 2, 5, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n160") }
+  }
   STREAM_CASE(true, 12, 0, 1, 9, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
   STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, SC_DX_PC, false, true, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
   STREAM_CASE(true, 4, 3, 2, 12, 32, 1, false, true, "gemm_stream_k128+96_n384r")      // ... ragged frames

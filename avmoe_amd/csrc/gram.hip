@@ -31,9 +31,14 @@ constexpr int GG = 2, GD = 32;                                  // groups, bottl
 constexpr int GT = 64;                                          // tokens per tile
 
 // GE experts (4: two (group, expert) pairs per wave; 2: one pair per wave)
-template <bool WEIGHTED, int GE>
+// XF: the input is z (before BatchNorm-1); z' = act(sc z + sh), rounded to bf16, is formed on the way from global memory to LDS
+// (bn1: the [mean | rstd | scale | shift] rows of the plan, relu_mask: bit e = expert e has the ReLU) -- the forward then needs
+// neither the separate MID pass nor a stored copy of z'; with `colpart` the per-block column sums of z' are written as well
+// (BatchNorm-2's first moments).
+template <bool WEIGHTED, int GE, bool XF>
 __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restrict__ Zp, const float* __restrict__ w /* [E][NT] */,
-                                                 float* __restrict__ part, long NT, int tiles_per_blk) {
+                                                 float* __restrict__ part, long NT, int tiles_per_blk, const float* __restrict__ bn1,
+                                                 unsigned relu_mask, float* __restrict__ colpart) {
   constexpr int GDZ = GE * GG * GD;                             // row width (256 / 128)
   constexpr int G_ROWB = GDZ * 2 + 16;                          // LDS bytes per token row
   constexpr int G_TILE = GT * G_ROWB;
@@ -57,6 +62,16 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
 
   u32x4 ra[NLD];                                                 // 64 rows x CPR chunks of 16 B / 256 threads
   float rw = 0.f;
+  // XF: this thread always serves the same 8 columns (256 % CPR == 0): their scale / shift / activation stay in registers
+  float xsc[XF ? 8 : 1], xsh[XF ? 8 : 1], csum[XF ? 8 : 1];
+  bool xrelu = false;
+  long ld_t0 = 0;                                                // first token of the tile that sits in ra[]
+  if constexpr (XF) {
+    const int col0 = (tid % CPR) * 8;
+    xrelu = (relu_mask >> ((col0 / GD) % GE)) & 1u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xsc[j] = bn1[2 * GDZ + col0 + j]; xsh[j] = bn1[3 * GDZ + col0 + j]; csum[j] = 0.f; }
+  }
   auto gload = [&](long tile) {
     const long t0 = tile * GT;
 #pragma unroll
@@ -66,6 +81,7 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
       if (t0 + row < NT) v = *(const u32x4*)(Zp + (t0 + row) * GDZ + cc * 8);
       ra[i] = v;
     }
+    ld_t0 = t0;
     if constexpr (WEIGHTED) {
       const int e = tid >> 6, tl = tid & 63;                     // experts x 64 tokens
       rw = (e < GE && t0 + tl < NT) ? w[(long)e * NT + t0 + tl] : 0.f;
@@ -76,7 +92,21 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + 256 * i;
-      *(u32x4*)(s + (c / CPR) * G_ROWB + (c % CPR) * 16) = ra[i];
+      u32x4 v = ra[i];
+      if constexpr (XF) {                                        // z -> z' here, AFTER the MFMAs of the previous tile: the loads stay in flight behind them
+        if (ld_t0 + c / CPR < NT) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float y0 = bf2f((unsigned short)(v[j] & 0xffffu)) * xsc[2 * j] + xsh[2 * j];
+            float y1 = bf2f((unsigned short)(v[j] >> 16)) * xsc[2 * j + 1] + xsh[2 * j + 1];
+            if (xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+            const unsigned short b0 = f2bf(y0), b1 = f2bf(y1);
+            csum[2 * j] += bf2f(b0); csum[2 * j + 1] += bf2f(b1);
+            v[j] = (unsigned)b0 | ((unsigned)b1 << 16);
+          }
+        }
+      }
+      *(u32x4*)(s + (c / CPR) * G_ROWB + (c % CPR) * 16) = v;
     }
     if constexpr (WEIGHTED) { if (tid < GE * GT) s_w[buf * GE * GT + tid] = rw; }
   };
@@ -132,13 +162,29 @@ __global__ void __launch_bounds__(256) kg_gram64(const unsigned short* __restric
 #pragma unroll
         for (int x = 0; x < 4; ++x) out[(long)cb * GD * GD + (16 * it + 4 * q + x) * GD + 16 * jt + r] = acc[p][it][jt][x];
   }
+  if constexpr (XF) {
+    if (colpart) {                                               // column sums of z' of this block's tokens: 256 / CPR threads per column chunk
+      __syncthreads();
+      float* sc = (float*)smem;                                  // [256 / CPR][GDZ]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sc[(tid / CPR) * GDZ + (tid % CPR) * 8 + j] = csum[j];
+      __syncthreads();
+      for (int col = tid; col < GDZ; col += 256) {
+        float v = 0.f;
+        for (int k = 0; k < 256 / CPR; ++k) v += sc[k * GDZ + col];
+        colpart[(long)blockIdx.x * GDZ + col] = v;
+      }
+    }
+  }
 }
 
 }  // namespace
 
 // G (g*E matrices of dgp x dgp, the layout of Szz / dGq) from Zp (NT, DZ) bf16; w = nullptr: unweighted.  Only for the
-// register-resident shape (tile_fast_ok) in bf16.
-int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st) {
+// register-resident shape (tile_fast_ok) in bf16.  With `bn1` the input is z and z' = act(BN1(z)) is formed on the fly (XF above);
+// `mz` (DZ floats, needs `colpart`: GRAM_BLOCKS * DZ floats) then receives the column means of z'.
+int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st, const float* bn1,
+             float* colpart, float* mz) {
   const Dims& d = pl.d;
   ProfScope ps_("k_gram64", (long)d.NT, (double)d.NT * (d.DZ * 2.0 + (w ? 4.0 * d.E : 0.0)), 2.0 * d.NT * (double)d.g * d.E * d.dgp * d.dgp, st);
   if (!tile_fast_ok(d) || !d.bf16 || (d.E != 4 && d.E != 2)) { set_last_error("gram64: shape not covered"); return ERR_UNSUPPORTED; }
@@ -146,8 +192,9 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
   const int nblk = (int)std::min<long>(GRAM_BLOCKS, ntiles);
   const int tpb = (int)cdiv(ntiles, (long)nblk);
   const size_t sh = 2 * (size_t)GT * (d.DZ * 2 + 16) + 2 * (size_t)d.E * GT * sizeof(float);
-  const void* kerns[4] = {(const void*)kg_gram64<false, 4>, (const void*)kg_gram64<true, 4>, (const void*)kg_gram64<false, 2>,
-                          (const void*)kg_gram64<true, 2>};
+  const void* kerns[8] = {(const void*)kg_gram64<false, 4, false>, (const void*)kg_gram64<true, 4, false>, (const void*)kg_gram64<false, 2, false>,
+                          (const void*)kg_gram64<true, 2, false>, (const void*)kg_gram64<false, 4, true>, (const void*)kg_gram64<true, 4, true>,
+                          (const void*)kg_gram64<false, 2, true>, (const void*)kg_gram64<true, 2, true>};
   static bool attr = false;
   if (!attr) {
     for (const void* k : kerns)
@@ -158,14 +205,20 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
   }
   const int used = (int)cdiv(ntiles, (long)tpb);
   const unsigned short* zp = (const unsigned short*)Zp;
+  unsigned relu_mask = 0;
+  for (int e = 0; e < d.E; ++e) relu_mask |= d.relu_of_e[e] ? (1u << e) : 0u;
+  if (mz && !colpart) { set_last_error("gram64: column means need the per-block workspace"); return ERR_BAD_ARG; }
+#define GRAM_LAUNCH(WT, GE_, XF_) hipLaunchKernelGGL((kg_gram64<WT, GE_, XF_>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb, bn1, relu_mask, mz ? colpart : nullptr)
   if (d.E == 4) {
-    if (w) hipLaunchKernelGGL((kg_gram64<true, 4>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
-    else hipLaunchKernelGGL((kg_gram64<false, 4>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
+    if (bn1) { if (w) GRAM_LAUNCH(true, 4, true); else GRAM_LAUNCH(false, 4, true); }
+    else { if (w) GRAM_LAUNCH(true, 4, false); else GRAM_LAUNCH(false, 4, false); }
   } else {
-    if (w) hipLaunchKernelGGL((kg_gram64<true, 2>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
-    else hipLaunchKernelGGL((kg_gram64<false, 2>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb);
+    if (bn1) { if (w) GRAM_LAUNCH(true, 2, true); else GRAM_LAUNCH(false, 2, true); }
+    else { if (w) GRAM_LAUNCH(true, 2, false); else GRAM_LAUNCH(false, 2, false); }
   }
+#undef GRAM_LAUNCH
   AVMOE_CHECK_LAUNCH("gram64");
+  if (mz) AVMOE_TRY(k_colsum_f32(colpart, used, d.DZ, d.DZ, 1, 0, mz, 0, 1.f / (float)d.NT, st));
   const int ncol = d.g * d.E * d.dgp * d.dgp;
   return k_colsum_f32(part, used, ncol, ncol, 1, 0, out, 0, scale, st);
 }

@@ -85,7 +85,8 @@ int kg_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kg_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kg_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 // streaming Gram of z' for the register-resident shape in bf16 (gram.hip): out[g*E][dgp][dgp] = scale * sum_t w[e][t] z' z'^T
-int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st);
+int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float* part, float* out, hipStream_t st, const float* bn1 = nullptr,
+             float* colpart = nullptr, float* mz = nullptr);   // bn1: the input is z, z' = act(BN1(z)) on the fly; mz: column means of z' as well
 // generic helpers
 int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out,
                  float scale, hipStream_t st);

@@ -192,9 +192,12 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   // ---- bottleneck space --------------------------------------------------------------------------
   AVMOE_TRY(k_pre_small(pl, sv, sc, prm, st));
   AVMOE_TRY(k_bn1_finalize(pl, sv, sc, prm, st));
-  AVMOE_TRY(k_mid(pl, sv, sc, st));
-  if (d.use_bn && d.training && d.gram64) {                // Szz[i][e] = Zp^T Zp / NT : one streaming pass over z'
-    AVMOE_TRY(k_gram64(pl, sv + pl.o_ZpS, nullptr, 1.f / (float)d.NT, (float*)(sc + pl.o_gpartT), (float*)(sv + pl.o_Szz), st));
+  if (!d.gram64) AVMOE_TRY(k_mid(pl, sv, sc, st));
+  if (d.use_bn && d.training && d.gram64) {
+    // No MID pass and no stored z' on this path: ONE streaming pass over z forms z' = act(BN1(z)) on the way into LDS and leaves
+    // both BatchNorm-2 moments -- Szz[i][e] = z'^T z' / NT and the column means mz (every later kernel recomputes z' from z anyway)
+    AVMOE_TRY(k_gram64(pl, sv + pl.o_Z, nullptr, 1.f / (float)d.NT, (float*)(sc + pl.o_gpartT), (float*)(sv + pl.o_Szz), st,
+                       (const float*)(sv + pl.o_bn1), (float*)(sc + pl.o_gcolT), (float*)(sv + pl.o_mz)));
   } else if (d.use_bn && d.training) {                     // ... as 8 batched token contractions of the engine
     GemmArgs g = base();
     g.A = sc + pl.o_Zp; g.B = sc + pl.o_Zp; g.C = sv + pl.o_Szz;

@@ -136,7 +136,7 @@ struct Dims {
   X(L1, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.Np)    /* L1 ; dA1 in bwd */  \
   X(TV, 1, 4, (size_t)d.S * (d.Kcyb > d.Kcx ? d.Kcyb : d.Kcx) * d.C)                           \
   X(Zp, 1, d.esz, (size_t)d.NT * d.DZ)              /* z'                              */       \
-  X(ZpS, 0, d.esz, d.gram64 ? (size_t)d.NT * d.DZ : 1)   /* z' kept for the backward (gram64)  */    \
+  X(gcolT, 1, 4, d.gram64 ? (size_t)GRAM_BLOCKS * d.DZ : 1)   /* per-block column sums of z' (Gram kernel)   */    \
   X(dSooT, 1, 4, d.gram64 ? (size_t)d.E * d.NT : 1)      /* dSoo per (expert, token)            */    \
   X(gpartT, 1, 4, d.gram64 ? (size_t)GRAM_BLOCKS * d.g * d.E * d.dgp * d.dgp : 1)  /* Gram partials */ \
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \

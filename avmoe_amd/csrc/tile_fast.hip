@@ -987,7 +987,7 @@ int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidFArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per);
-  LAUNCH_TE(d.bf16, kf_mid, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), d.gram64 ? (void*)(saved + pl.o_ZpS) : (void*)(scratch + pl.o_Zp),
+  LAUNCH_TE(d.bf16, kf_mid, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
             (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("mid (64/32)");
   return OK;
@@ -1011,7 +1011,7 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
   FPostBArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
-  a.ZpS = d.gram64 ? (const void*)(saved + pl.o_ZpS) : nullptr;
+  a.ZpS = nullptr;          // z' is recomputed from z (no stored copy any more: the Gram kernel forms it on the fly too)
   a.dSooT = d.gram64 ? (float*)(scratch + pl.o_dSooT) : nullptr;
   a.dApx = (const float*)(scratch + pl.o_dApx);
   if (dap16 && !d.bf16) { set_last_error("post_small_bwd: split dApost is a bf16 form"); return ERR_BAD_ARG; }
