@@ -80,8 +80,13 @@ __device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, in
 // A2MN: the second segment's A2 is MN-major ([k2][m], leading dim lda2): it is read along m and transposed into the
 // K-major LDS rows with 2-byte stores (its K2 is small), so the MFMA loop is the same.
 // ACC: C += (bf16 C): the old values of a 16-row slab are requested one slab ahead of the MFMAs that need them.
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC>
-__global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p) {
+// PF2: TWO row tiles of loads in flight per block (two register stages in front of the two LDS buffers): a block's bytes in flight
+// -- what bounds an HBM stream once the arithmetic is hidden -- double for NLD more registers per stage.
+#ifndef SC_DAP_MINW
+#define SC_DAP_MINW 1        // 9-wave blocks (dApost): 5 here = two resident blocks per CU (<= 96 VGPRs, 4 spills): measured no gain
+#endif
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2>
+__global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_stream_kernel(const StreamArgs p) {
   constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
   constexpr int CPR1 = A2MN ? KS * 4 : KSA * 4;           // 16-byte chunks per row that come from K-major sources
   constexpr int TOT2 = A2MN ? KS2 * 32 * (BM / 8) : 0, NLD2 = A2MN ? (TOT2 + NT - 1) / NT : 1;
@@ -119,8 +124,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
   bf16x8 bfr2[TPW][KS2 > 0 ? KS2 : 1];
   int cur_s = -1;
 
-  u32x4 ra[NLD], ra2[NLD2];
-  auto gload = [&](int tile) {
+  u32x4 rs0[NLD], rs0b[NLD2], rs1[PF2 ? NLD : 1], rs1b[PF2 ? NLD2 : 1];
+  auto gload = [&](int tile, u32x4 (&ra)[NLD], u32x4 (&ra2)[NLD2]) {
     const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
     const char* A1 = p.A + ((long)s * p.sA1 + (long)g * p.sA2) * 2;
     const char* A2 = KS2 > 0 ? p.A2 + ((long)s * p.s2A1 + (long)g * p.s2A2) * 2 : nullptr;
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
       ra[i] = v;
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const u32x4 (&ra)[NLD], const u32x4 (&ra2)[NLD2]) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
@@ -191,11 +196,13 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
   } else {
     tile = blockIdx.x; t_end = p.ntiles; step = gridDim.x;
   }
-  if (tile < t_end) { gload(tile); lstore(0); }
+  if (tile < t_end) { gload(tile, rs0, rs0b); lstore(0, rs0, rs0b); }
   __syncthreads();
-  for (int it = 0; tile < t_end; ++it, tile += step) {
+  // one row tile: request the loads of tile `ld_tile` into one register stage, multiply the tile that sits in LDS buffer it & 1, move
+  // the stage that holds the NEXT tile into the other LDS buffer
+  auto body = [&](int it, int tile, u32x4 (&ldA)[NLD], u32x4 (&ldB)[NLD2], int ld_tile, const u32x4 (&stA)[NLD], const u32x4 (&stB)[NLD2]) {
     const int nxt = tile + step;
-    if (nxt < t_end) gload(nxt);
+    if (ld_tile < t_end) gload(ld_tile, ldA, ldB);
     const char* sA = smem + (it & 1) * STG;
     const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
     if (KS2 > 0 && s != cur_s) {
@@ -304,15 +311,25 @@ __global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(const StreamArgs p
         }
       }
     }
-    if (nxt < t_end) lstore((it + 1) & 1);
+    if (nxt < t_end) lstore((it + 1) & 1, stA, stB);
     __syncthreads();
+  };
+  if constexpr (!PF2) {
+    for (int it = 0; tile < t_end; ++it, tile += step) body(it, tile, rs0, rs0b, tile + step, rs0, rs0b);
+  } else {
+    if (tile + step < t_end) gload(tile + step, rs0, rs0b);          // stage 0: the next tile, already in flight
+    for (int it = 0; tile < t_end;) {
+      body(it, tile, rs1, rs1b, tile + 2 * step, rs0, rs0b); ++it; tile += step;
+      if (tile >= t_end) break;
+      body(it, tile, rs0, rs0b, tile + 2 * step, rs1, rs1b); ++it; tile += step;
+    }
   }
 }
 
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC>
-int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2>
+int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
-  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC>;
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2>;
   static bool attr_done = false;
   if (!attr_done) {
     if (LDS > 65536) {
@@ -332,6 +349,19 @@ int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nb2), dim3(NW * 64), LDS, st, s);
   AVMOE_CHECK_LAUNCH("gemm_stream");
   return OK;
+}
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC>
+int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
+  // PF2 (two row tiles of loads in flight per block) is a development switch, AVMOE_STREAM_PF2=1: measured on MI355X it changes
+  // no configuration by more than +-3 % (same-box A/B of the cfg-2 step: 6.51 vs 6.50 ms) -- these kernels are not short of
+  // bytes in flight; the 9-wave dApost configuration is held back by residency (105 VGPRs x 9 waves: one block per CU).
+  // (Not built for the MN-major second segment: those kernels sit at their register limit already and would spill.)
+  static const bool pf2 = getenv("AVMOE_STREAM_PF2") != nullptr;
+  if constexpr (A2MN) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false>(s, nb2, per_cu, st);
+  else {
+    if (pf2) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, true>(s, nb2, per_cu, st);
+    return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false>(s, nb2, per_cu, st);
+  }
 }
 
 }  // namespace
@@ -422,10 +452,6 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   STREAM_CASE(tiles <= 12 && a.M % 64 == 0, 2, 3, 1, 12, 64, 1, true, true, "gemm_stream_k64+96mn_n192")   // dY into <= 192 channels
   STREAM_CASE(true, 5, 0, 2, 12, SC_OUT_BM, SC_OUT_PC, false, true, "gemm_stream_k160_n384")    // output GEMM: K = 4*32 + 12, N = 384 per group (+= for accumulate_out)
   STREAM_CASE(true, 12, 0, 2, 4, 32, SC_DOWN_PC, false, false, "gemm_stream_k384_n128")   // grouped down projection
-  {
-    static const bool tpw2 = getenv("AVMOE_DAP_TPW2") != nullptr;        // dev A/B: 5 waves x 2 column tiles instead of 9 x 1
-    if (tpw2) { STREAM_CASE(true, 12, 0, 2, 5, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n160") }
-  }
   STREAM_CASE(true, 12, 0, 1, 9, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
   STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, SC_DX_PC, false, true, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
   STREAM_CASE(true, 4, 3, 2, 12, 32, 1, false, true, "gemm_stream_k128+96_n384r")      // ... ragged frames

@@ -145,8 +145,9 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.nxc = d.S;
   if (d.nxn && !d.mha) {
     const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (4 + 2 * (size_t)d.esz);
-    static const size_t keep_all = getenv("AVMOE_NXN_KEEP_MB") ? (size_t)atol(getenv("AVMOE_NXN_KEEP_MB")) << 20 : (size_t)256 << 20;
+    const size_t keep_all = (size_t)256 << 20;
     if ((size_t)d.S * per_frame > keep_all) d.nxc = (int)std::max<size_t>(1, std::min<size_t>((size_t)d.S, ((size_t)96 << 20) / per_frame));
+    if (const char* ev = getenv("AVMOE_NXN_CHUNK")) d.nxc = std::max(1, std::min(d.S, atoi(ev)));     // tests: force the chunked path on small shapes
   }
   d.Mk = (int)round_up(d.M + 2, 8);
   d.Mb = (int)round_up(d.M + 1, 8);

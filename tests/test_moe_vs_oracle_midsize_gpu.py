@@ -143,3 +143,36 @@ def test_midsize_bf16_close_to_oracle(name):
         if err > tol * max(refn[k], 0.25 * gmax if k not in ("X", "Y") else refn[k]):
             bad[k] = (err, refn[k])
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
+    """The AVVP N x N block run a few frames at a time through one workspace, scores and softmax recomputed in the backward (what
+    the plan does by itself once the (frames, N, N) tensors outgrow the Infinity Cache: stage 0, N = 4096 / 2304) == the same site
+    with everything kept -- bit for bit in fp32 (same kernels on the same rows), and within 1e-3 of the oracle."""
+    from tests.moe_gpu_util import MoeRun
+    case = CASES[name]
+    cfg = O.AdapterConfig(**case["cfg"])
+    S = case["S"]
+    P, B = O.init_params(cfg, seed=21)
+    g = torch.Generator().manual_seed(77)
+    X = 0.3 * torch.randn(S, cfg.Nx, cfg.Cx, generator=g)
+    Y = 0.3 * torch.randn(S, cfg.Ny, cfg.Cy, generator=g)
+    G = torch.randn(S, cfg.Nx, cfg.Cx, generator=g)
+    lbw = 0.01 if cfg.lb_loss else 0.0
+    whole = MoeRun(cfg, P, B, X, Y, bf16=bf16, training=True).forward()
+    g0 = whole.backward(G, lb_weight=lbw)
+    monkeypatch.setenv("AVMOE_NXN_CHUNK", str(chunk))
+    run = MoeRun(cfg, P, B, X, Y, bf16=bf16, training=True).forward()
+    assert run.table["att"][2] < whole.table["att"][2]                  # the (frames, N, N) workspace shrank
+    g1 = run.backward(G, lb_weight=lbw)
+    monkeypatch.delenv("AVMOE_NXN_CHUNK")
+    assert torch.equal(run.out, whole.out) and torch.equal(run.idx, whole.idx)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    if not bf16:
+        fwd, grads = O.moe_forward_backward(P, B, X, Y, cfg, G, training=True, lb_weight=lbw)
+        gmax = max(float(v.abs().max()) for v in grads.values())
+        bad = {k: float((g1[k] - v).abs().max()) for k, v in grads.items() if float((g1[k] - v).abs().max()) > 1e-3 * max(float(v.abs().max()), 1e-3 * gmax)}
+        assert not bad, bad
