@@ -39,14 +39,16 @@ def test_forward_fp32_matches_reference_vectors(name, capsys):
 
 @pytest.mark.parametrize("name", ["ave_train", "ave_wide_train", "avs_v2_train"])
 def test_forward_bf16_close_to_reference_vectors(name):
-    """bf16 I/O + fp32 accumulate: compared with the fp32 reference output at bf16-level tolerance."""
+    """bf16 I/O + fp32 accumulate against the fp32 reference output (which saw the unrounded inputs): within 1.5e-2, max-abs relative
+    (measured 4e-3 .. 9e-3 on these vectors; the bf16 bar of the parity tests proper is 1e-2 against the oracle on rounded inputs)."""
     from tests.moe_gpu_util import MoeRun
     meta, cfg, t = load_golden(name)
     P, B = split_params(t)
     run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=True, training=bool(meta["module_train"]), noise=t.get("noise"), mha_keep=mha_keep_of(t)).forward()
     out = run.out.float().cpu()
     err = float((out - t["out"]).abs().max() / t["out"].abs().max())
-    assert err < 4e-2, err
+    print(f"[{name}] bf16 forward max-abs relative error {err:.3e}")
+    assert err < 1.5e-2, err
     assert torch.equal(run.idx.cpu(), t["idx"])
 
 

@@ -112,11 +112,12 @@ def test_midsize_matches_oracle_fp32(name):
 @pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
                                   "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio", "fast_avvp", "fast_avvp_e1p1_pad", "fast_v1"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
 def test_midsize_bf16_close_to_oracle(name):
-    """The bf16 production path on the register-resident shape (bf16 Z / dz' storage, streaming GEMMs, streaming Gram)
-    against the fp32 oracle: outputs within 4e-2, gradients norm-wise 6 % (token tensors) / 12 % (parameters; analytically
-    small ones are held to a fraction of the largest parameter-gradient norm) -- the tolerances of the reference-vector
-    bf16 tests (tests/test_moe_backward_gpu.py)."""
+    """The bf16 production path (bf16 activations AND bottleneck-space tensors, streaming GEMMs, streaming Gram) against the fp32 oracle
+    on the bf16-rounded inputs: router indices bit-exact, outputs within 1e-2 (max-abs relative; 4e-2 for the frame-attention
+    experts, whose softmax over a handful of frames amplifies operand rounding: measured 2.8e-2), every gradient norm-wise within
+    max(1 %, 2 x the error of the reference formulation itself under bf16 autocast) -- tests/golden_util.py::bf16_budget_violations."""
     from tests.moe_gpu_util import MoeRun
+    from tests.golden_util import bf16_budget_violations
     case = CASES[name]
     cfg = O.AdapterConfig(**case["cfg"])
     S = case["S"]
@@ -132,18 +133,13 @@ def test_midsize_bf16_close_to_oracle(name):
     run = MoeRun(cfg, P, B, X, Y, bf16=True, training=True, mha_keep=keep).forward()
     assert torch.equal(run.idx.cpu(), fwd["idx"])
     out = run.out.float().cpu()
-    assert float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()) < 4e-2
+    assert float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()) < (4e-2 if cfg.self_attn == "v1" else 1e-2)
     got = run.backward(G, lb_weight=lbw)
-    refn = {k: float(v.norm()) for k, v in grads.items()}
-    gmax = max(v for k, v in refn.items() if k not in ("X", "Y"))
-    bad = {}
-    for k, v in got.items():
-        err = float((v.float().cpu() - grads[k]).norm())
-        tol = 0.06 if k in ("X", "Y") else 0.12
-        if err > tol * max(refn[k], 0.25 * gmax if k not in ("X", "Y") else refn[k]):
-            bad[k] = (err, refn[k])
+    # frame attention ("v1"): QKV / scores / P V / out-proj all run on bf16 operands here, eager autocast keeps the softmax chain in
+    # fp32 -- measured 2.5 - 3 x the eager error on the router and BatchNorm-2 gradients (1.2 - 2.7 %): factor 4 and a 3 % floor there
+    kw = dict(factor=4.0, floor=3e-2) if cfg.self_attn == "v1" else {}
+    bad = bf16_budget_violations(O, cfg, P, B, Xb, Yb, Gb, got, grads, lb_weight=lbw, mha_keep=keep, **kw)
     assert not bad, bad
-
 
 @pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2)])
 @pytest.mark.parametrize("bf16", [False, True])
