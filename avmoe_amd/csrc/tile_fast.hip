@@ -29,6 +29,9 @@
 #ifndef LB_POSTB
 #define LB_POSTB 2
 #endif
+#ifndef LB_POSTB_PREFETCH
+#define LB_POSTB_PREFETCH 1       // post_small_bwd (bf16, split dApost): next tile's rows requested before the current tile is computed
+#endif
 #ifndef LB_PRE
 #define LB_PRE 3
 #endif
@@ -460,18 +463,50 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
     float4 cs0[4], cs1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    // PFB (bf16 + split dApost): the raw rows of the NEXT tile are requested before the current one is computed -- a wave keeps two
+    // tiles of loads in flight (+ 24 registers), which is what bounds these latency-bound kernels
+    constexpr bool PFB = D16 && sizeof(T) == 2 && LB_POSTB_PREFETCH;
+    RawRow<T> nz, nd;
+    float nx[8];
+    auto prefetch = [&](int n0p) {
+      zero_raw(nz); zero_raw(nd);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) nx[i] = 0.f;
+      if (n0p < n_end && n0p + r < t.N) {
+        const long tk = (long)s * t.N + n0p + r;
+        ldraw_row<E>(Z + tk * DZ, e, q, nz);
+        if constexpr (sizeof(T) == 2) {
+          nd.v[0] = *(const uint4*)(dAp16 + (tk * 2) * t.KPp + e * FDG + seg_off8(q));
+          nd.v[1] = *(const uint4*)(dAp16 + (tk * 2 + 1) * t.KPp + e * FDG + seg_off8(q));
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const float* p = a.dApx + (tk * 2 + gi) * 16 + 3 * e;
+          nx[3 * gi] = p[0]; nx[3 * gi + 1] = p[1]; nx[3 * gi + 2] = p[2];
+        }
+        nx[6] = rpmup[tk * E + e]; nx[7] = rpmup[(long)t.NT * E + tk * E + e];
+      }
+    };
+    if constexpr (PFB) prefetch(n_beg + 16 * wave);
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
       float4 zp[4], d[4], zraw[4], dzo[4];
       float da1 = 0.f, da2 = 0.f, da3 = 0.f, rp = 1.f, mup = 0.f;
-      zero_row(zraw);
-      const bool saved_zp = a.ZpS != nullptr;                 // gram64 mode: z' was kept by the forward
-      if (ok) ld_row<T, E>((saved_zp ? (const T*)a.ZpS : Z) + tok * DZ, e, q, zraw);
-      if constexpr (D16) {
-        zero_row(d);
-        if (ok) { ld_seg<T>(dAp16 + (tok * 2) * t.KPp + e * FDG, d[0], d[1], q); ld_seg<T>(dAp16 + (tok * 2 + 1) * t.KPp + e * FDG, d[2], d[3], q); }
+      const bool saved_zp = a.ZpS != nullptr;                 // (a stored copy of z': no longer produced by the forward)
+      if constexpr (PFB) {
+        unpack_row(nz, zraw); unpack_row(nd, d);
+        da1 = nx[0] + nx[3]; da2 = nx[1] + nx[4]; da3 = nx[2] + nx[5];
+        if (ok) { rp = nx[6]; mup = nx[7]; }
+        prefetch(n0 + 64);
+      } else {
+        zero_row(zraw);
+        if (ok) ld_row<T, E>((saved_zp ? (const T*)a.ZpS : Z) + tok * DZ, e, q, zraw);
+        if constexpr (D16) {
+          zero_row(d);
+          if (ok) { ld_seg<T>(dAp16 + (tok * 2) * t.KPp + e * FDG, d[0], d[1], q); ld_seg<T>(dAp16 + (tok * 2 + 1) * t.KPp + e * FDG, d[2], d[3], q); }
+        }
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -484,7 +519,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
           at(zp[c], x) = saved_zp ? at(z, x) : (relu ? fmaxf(y, 0.f) : y);
         }
       }
-      if (ok) {
+      if (!PFB && ok) {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
           const float* p = D16 ? a.dApx + (tok * 2 + gi) * 16 + 3 * e : dAp + (tok * 2 + gi) * t.KPp + E * FDG + 3 * e;
