@@ -17,6 +17,7 @@
 #include "prof.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 
 namespace avmoe {
 
@@ -82,12 +83,24 @@ __device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, in
 // ACC: C += (bf16 C): the old values of a 16-row slab are requested one slab ahead of the MFMAs that need them.
 // PF2: TWO row tiles of loads in flight per block (two register stages in front of the two LDS buffers): a block's bytes in flight
 // -- what bounds an HBM stream once the arithmetic is hidden -- double for NLD more registers per stage.
+// slabs of a row tile whose stores are issued after the next tile has been moved into the LDS (see the loop body)
+constexpr int stream_hold(int KS, int KS2, int TPW, int NW, int MT, bool ACC) {
+  if (ACC) return 0;
+  const int est = TPW * (KS + KS2) * 4 + MT * TPW * 6 + 80;          // B fragments + held accumulators + D operands + the rest
+  if (NW >= 9) return est <= 168 ? MT : 1;                          // 9 / 12 waves: three per SIMD
+  if (NW == 4 && KS == 12) return MT;                               // the down projection: two 4-wave blocks per CU, 256 registers
+  return 1;                                                         // several small blocks per CU: residency first
+}
+#ifndef STREAM_DISSECT
+#define STREAM_DISSECT 0         // development builds: 1 = no stores, 2 = no MFMAs, 3 = no row-tile loads (scripts/stream_dissect.sh)
+#endif
 #ifndef SC_DAP_MINW
 #define SC_DAP_MINW 1        // 9-wave blocks (dApost): 5 here = two resident blocks per CU (<= 96 VGPRs, 4 spills): measured no gain
 #endif
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2>
-__global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_stream_kernel(const StreamArgs p) {
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW>
+__global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const StreamArgs p) {
   constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
+  constexpr int HOLD = stream_hold(KS, KS2, TPW, NW, BM / 16, ACC);
   constexpr int CPR1 = A2MN ? KS * 4 : KSA * 4;           // 16-byte chunks per row that come from K-major sources
   constexpr int TOT2 = A2MN ? KS2 * 32 * (BM / 8) : 0, NLD2 = A2MN ? (TOT2 + NT - 1) / NT : 1;
   constexpr int RB = KSA * 64 + 16;            // LDS bytes per A row (odd multiple of 16: conflict-free 16-byte fragment reads)
@@ -124,56 +137,55 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
   bf16x8 bfr2[TPW][KS2 > 0 ? KS2 : 1];
   int cur_s = -1;
 
+  // Everything pending at this point (the B fragments) is waited for HERE, once: a wait the compiler has to place itself ends up
+  // in front of the first MFMA of the loop body (the fragments are loaded under conditions), where -- the memory counter being
+  // in-order -- it also waits for the NEXT tile's loads every iteration and the stream stops overlapping with the arithmetic.
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+
+  // The loads of a row tile are UNCONDITIONAL (clamped addresses; rows / columns outside the matrix are zeroed when the tile is
+  // moved into the LDS): the number of loads in flight behind any other memory operation is then a compile-time constant and the
+  // waits in the loop are exact counts, not "everything".
   u32x4 rs0[NLD], rs0b[NLD2], rs1[PF2 ? NLD : 1], rs1b[PF2 ? NLD2 : 1];
   auto gload = [&](int tile, u32x4 (&ra)[NLD], u32x4 (&ra2)[NLD2]) {
     const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
     const char* A1 = p.A + ((long)s * p.sA1 + (long)g * p.sA2) * 2;
-    const char* A2 = KS2 > 0 ? p.A2 + ((long)s * p.s2A1 + (long)g * p.s2A2) * 2 : nullptr;
+    const char* A2 = KS2 > 0 ? p.A2 + ((long)s * p.s2A1 + (long)g * p.s2A2) * 2 : A1;
     if constexpr (A2MN) {
 #pragma unroll
       for (int i = 0; i < NLD2; ++i) {
-        const int c = tid + i * NT;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (c < TOT2) {
-          const int k2 = c / (BM / 8), m = m0 + (c % (BM / 8)) * 8;
-          if (k2 < p.K2 && m < p.Mper) {
-            v = *(const u32x4*)(A2 + ((long)k2 * p.lda2 + m) * 2);
-            if (m + 8 > p.Mper) v = mask_tail8(v, p.Mper - m);
-          }
-        }
-        ra2[i] = v;
+        const int c = min(tid + i * NT, TOT2 - 1);
+        const int k2 = c / (BM / 8), m = m0 + (c % (BM / 8)) * 8;
+        ra2[i] = *(const u32x4*)(A2 + ((long)(k2 < p.K2 ? k2 : 0) * p.lda2 + (m < p.Mper ? m : 0)) * 2);
       }
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int c = tid + i * NT;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c < TOT) {
-        const int row = c / CPR, cc = c % CPR, gm = m0 + row;
-        if (gm < p.Mper) {
-          if (cc < KS * 4) {
-            const int k = cc * 8;
-            if (k < p.K) {
-              v = *(const u32x4*)(A1 + ((long)gm * p.lda + k) * 2);
-              if (k + 8 > p.K) v = mask_tail8(v, p.K - k);
-            }
-          } else if (KS2 > 0 && !A2MN) {
-            const int k = (cc - KS * 4) * 8;
-            if (k < p.K2) {
-              v = *(const u32x4*)(A2 + ((long)gm * p.lda2 + k) * 2);
-              if (k + 8 > p.K2) v = mask_tail8(v, p.K2 - k);
-            }
-          }
-        }
-      }
-      ra[i] = v;
+      const int c = min(tid + i * NT, TOT - 1);
+      const int row = c / CPR, cc = c % CPR, gm = min(m0 + row, p.Mper - 1);
+      const bool seg2 = KS2 > 0 && !A2MN && cc >= KS * 4;
+      const int k = (seg2 ? cc - KS * 4 : cc) * 8;
+      const char* src = seg2 ? A2 + ((long)gm * p.lda2 + (k < p.K2 ? k : 0)) * 2 : A1 + ((long)gm * p.lda + (k < p.K ? k : 0)) * 2;
+#if STREAM_DISSECT == 3
+      ra[i] = u32x4{(unsigned)c, 0u, 0u, 0u}; (void)src;
+#else
+      ra[i] = *(const u32x4*)src;
+#endif
     }
   };
-  auto lstore = [&](int buf, const u32x4 (&ra)[NLD], const u32x4 (&ra2)[NLD2]) {
+  auto lstore = [&](int buf, int tile, const u32x4 (&ra)[NLD], const u32x4 (&ra2)[NLD2]) {
+    const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * NT;
-      if (c < TOT) *(u32x4*)(smem + buf * STG + (c / CPR) * RB + (c % CPR) * 16) = ra[i];
+      if (c < TOT) {
+        const int row = c / CPR, cc = c % CPR;
+        const bool seg2 = KS2 > 0 && !A2MN && cc >= KS * 4;
+        const int k = (seg2 ? cc - KS * 4 : cc) * 8, kend = seg2 ? p.K2 : p.K;
+        u32x4 v = ra[i];
+        if (m0 + row >= p.Mper || k >= kend) v = u32x4{0u, 0u, 0u, 0u};
+        else if (k + 8 > kend) v = mask_tail8(v, kend - k);
+        *(u32x4*)(smem + buf * STG + row * RB + cc * 16) = v;
+      }
     }
     if constexpr (A2MN) {
 #pragma unroll
@@ -181,9 +193,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
         const int c = tid + i * NT;
         if (c < TOT2) {
           const int k2 = c / (BM / 8), mr = (c % (BM / 8)) * 8;
+          u32x4 v = ra2[i];
+          if (k2 >= p.K2 || m0 + mr >= p.Mper) v = u32x4{0u, 0u, 0u, 0u};
+          else if (m0 + mr + 8 > p.Mper) v = mask_tail8(v, p.Mper - m0 - mr);
           unsigned short* dst = (unsigned short*)(smem + buf * STG + mr * RB + (KS * 32 + k2) * 2);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dst[j * (RB / 2)] = (unsigned short)((ra2[i][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+          for (int j = 0; j < 8; ++j) dst[j * (RB / 2)] = (unsigned short)((v[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
         }
       }
     }
@@ -196,13 +211,18 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
   } else {
     tile = blockIdx.x; t_end = p.ntiles; step = gridDim.x;
   }
-  if (tile < t_end) { gload(tile, rs0, rs0b); lstore(0, rs0, rs0b); }
+  if (tile >= t_end) return;
+  gload(tile, rs0, rs0b); lstore(0, tile, rs0, rs0b);
   __syncthreads();
-  // one row tile: request the loads of tile `ld_tile` into one register stage, multiply the tile that sits in LDS buffer it & 1, move
-  // the stage that holds the NEXT tile into the other LDS buffer
+  // One row tile.  Order of the memory operations (the counter they share is in-order):
+  //   [B2 of a new sample] [epilogue operands of THIS tile: D, old C] [loads of tile ld_tile -> register stage ldA]
+  //   per 16-row slab: MFMAs (the loads above are in flight), epilogue arithmetic (waits for D only: an exact count), and -- for
+  //   all but the last HOLD slabs -- its stores
+  //   stage stA (the NEXT tile, requested one or two tiles ago) -> the other LDS buffer    stores of the last HOLD slabs    barrier
+  // -- consuming the stage waits for everything issued before it; the stores of the last slabs would be the freshest of those, so
+  // they are issued AFTER it (HOLD: as many slabs as the register budget of the configuration holds; accumulating variants: none).
   auto body = [&](int it, int tile, u32x4 (&ldA)[NLD], u32x4 (&ldB)[NLD2], int ld_tile, const u32x4 (&stA)[NLD], const u32x4 (&stB)[NLD2]) {
     const int nxt = tile + step;
-    if (ld_tile < t_end) gload(ld_tile, ldA, ldB);
     const char* sA = smem + (it & 1) * STG;
     const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
     if (KS2 > 0 && s != cur_s) {
@@ -219,13 +239,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
           bfr2[t][ks] = __builtin_bit_cast(bf16x8, v);
         }
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);        // (once per sample: keeps the conditional loads above out of the counts below)
     }
     char* Cb = p.C + ((long)s * p.sC1 + (long)g * p.sC2) * osz;
     const char* Db = p.D ? p.D + ((long)s * p.sD1 + (long)g * p.sD2) * 2 : nullptr;
     const float* rsb = p.rs ? p.rs + (long)s * p.sRS1 + (long)g * p.sRS2 : nullptr;
     // lane (r, q) owns C[m0 + 16 mt + r][nl .. nl + 4 TPW): tile t supplies elements 4 t .. 4 t + 3 of that run
     const int nl = nw0 + 4 * TPW * q;
-    // optional epilogue operand: all of this tile's D fragments are requested before the MFMAs start
     u32x2 dv[MT][TPW], cvn[ACC ? TPW : 1];
     float rsv[MT];
     auto ldc = [&](int mt) {
@@ -247,44 +267,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
         if (m < p.Mper) ld_run<TPW>(Db + ((long)m * p.ldd + nl) * 2, nl, p.N, dv[mt]);
       }
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      f32x4 acc[TPW];
-      u32x2 cvc[ACC ? TPW : 1];
-#pragma unroll
-      for (int t = 0; t < (ACC ? TPW : 1); ++t) cvc[t] = cvn[t];
-      if (ACC && mt + 1 < MT) ldc(mt + 1);
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + ks * 64 + q * 16);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][ks], af, acc[t], 0, 0, 0);
-      }
-      if constexpr (KS2 > 0) {
-#pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) {
-          const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + (KS + ks) * 64 + q * 16);
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr2[t][ks], af, acc[t], 0, 0, 0);
-        }
-      }
+    gload(ld_tile < t_end ? ld_tile : tile, ldA, ldB);          // (past the end: this tile again -- the count stays the same)
+    asm volatile("" ::: "memory");          // the requests stay HERE, in front of the MFMAs (free to move, the compiler sinks them to their use)
+    auto store_slab = [&](int mt, const f32x4 (&acc)[TPW]) {
       const int m = m0 + 16 * mt + r;
+#if STREAM_DISSECT == 1          // dev: no stores (kept alive by a condition that never holds)
+      if (m < p.Mper && acc[0][0] == 1.2345e-30f) {
+#else
       if (m < p.Mper) {
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[t][e] *= p.alpha;
-          if (Db) {
-            acc[t][0] += rsv[mt] * bfbits(dv[mt][t][0] & 0xFFFFu); acc[t][1] += rsv[mt] * bfbits(dv[mt][t][0] >> 16);
-            acc[t][2] += rsv[mt] * bfbits(dv[mt][t][1] & 0xFFFFu); acc[t][3] += rsv[mt] * bfbits(dv[mt][t][1] >> 16);
-          }
-          if constexpr (ACC) {
-            acc[t][0] += bfbits(cvc[t][0] & 0xFFFFu); acc[t][1] += bfbits(cvc[t][0] >> 16);
-            acc[t][2] += bfbits(cvc[t][1] & 0xFFFFu); acc[t][3] += bfbits(cvc[t][1] >> 16);
-          }
-        }
+#endif
         char* cp = Cb + ((long)m * p.ldc + nl) * osz;
         if (p.Cx && nl >= p.nsplit) {                        // this lane's run belongs to the fp32 side output
           float* xp = p.Cx + (long)g * p.sCx2 + (long)m * p.ldcx + (nl - p.nsplit);
@@ -310,14 +301,63 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
             if (nl + 4 * t < p.N) *(f32x4*)(cp + 16 * t) = acc[t];
         }
       }
+    };
+    f32x4 held[HOLD > 0 ? HOLD : 1][TPW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 acc[TPW];
+      u32x2 cvc[ACC ? TPW : 1];
+#pragma unroll
+      for (int t = 0; t < (ACC ? TPW : 1); ++t) cvc[t] = cvn[t];
+      if (ACC && mt + 1 < MT) ldc(mt + 1);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + ks * 64 + q * 16);
+#pragma unroll
+#if STREAM_DISSECT == 2          // dev: LDS reads without the MFMAs
+        for (int t = 0; t < TPW; ++t) acc[t][0] += __builtin_bit_cast(f32x4, af)[t & 3];
+#else
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][ks], af, acc[t], 0, 0, 0);
+#endif
+      }
+      if constexpr (KS2 > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + (KS + ks) * 64 + q * 16);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr2[t][ks], af, acc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] *= p.alpha;
+        if (Db) {
+          acc[t][0] += rsv[mt] * bfbits(dv[mt][t][0] & 0xFFFFu); acc[t][1] += rsv[mt] * bfbits(dv[mt][t][0] >> 16);
+          acc[t][2] += rsv[mt] * bfbits(dv[mt][t][1] & 0xFFFFu); acc[t][3] += rsv[mt] * bfbits(dv[mt][t][1] >> 16);
+        }
+        if constexpr (ACC) {
+          acc[t][0] += bfbits(cvc[t][0] & 0xFFFFu); acc[t][1] += bfbits(cvc[t][0] >> 16);
+          acc[t][2] += bfbits(cvc[t][1] & 0xFFFFu); acc[t][3] += bfbits(cvc[t][1] >> 16);
+        }
+      }
+      if (mt < MT - HOLD) store_slab(mt, acc);
+      else {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) held[HOLD > 0 ? mt - (MT - HOLD) : 0][t] = acc[t];
+      }
     }
-    if (nxt < t_end) lstore((it + 1) & 1, stA, stB);
+    if (nxt < t_end) lstore((it + 1) & 1, nxt, stA, stB);
+#pragma unroll
+    for (int h = 0; h < HOLD; ++h) store_slab(MT - HOLD + h, held[h]);
     __syncthreads();
   };
   if constexpr (!PF2) {
     for (int it = 0; tile < t_end; ++it, tile += step) body(it, tile, rs0, rs0b, tile + step, rs0, rs0b);
   } else {
-    if (tile + step < t_end) gload(tile + step, rs0, rs0b);          // stage 0: the next tile, already in flight
+    gload(tile + step < t_end ? tile + step : tile, rs0, rs0b);          // stage 0: the next tile, already in flight
     for (int it = 0; tile < t_end;) {
       body(it, tile, rs1, rs1b, tile + 2 * step, rs0, rs0b); ++it; tile += step;
       if (tile >= t_end) break;
@@ -326,10 +366,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 9 ? SC_DAP_MINW : 1)) gemm_str
   }
 }
 
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW>
 int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
-  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2>;
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW>;
   static bool attr_done = false;
   if (!attr_done) {
     if (LDS > 65536) {
@@ -350,17 +390,17 @@ int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   AVMOE_CHECK_LAUNCH("gemm_stream");
   return OK;
 }
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, int MINW = (NW == 9 ? SC_DAP_MINW : 1)>
 int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   // PF2 (two row tiles of loads in flight per block) is a development switch, AVMOE_STREAM_PF2=1: measured on MI355X it changes
   // no configuration by more than +-3 % (same-box A/B of the cfg-2 step: 6.51 vs 6.50 ms) -- these kernels are not short of
   // bytes in flight; the 9-wave dApost configuration is held back by residency (105 VGPRs x 9 waves: one block per CU).
   // (Not built for the MN-major second segment: those kernels sit at their register limit already and would spill.)
   static const bool pf2 = getenv("AVMOE_STREAM_PF2") != nullptr;
-  if constexpr (A2MN) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false>(s, nb2, per_cu, st);
+  if constexpr (A2MN) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false, MINW>(s, nb2, per_cu, st);
   else {
-    if (pf2) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, true>(s, nb2, per_cu, st);
-    return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false>(s, nb2, per_cu, st);
+    if (pf2) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, true, MINW>(s, nb2, per_cu, st);
+    return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false, MINW>(s, nb2, per_cu, st);
   }
 }
 
@@ -413,7 +453,10 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #define SC_DOWN_PC 2
 #endif
 #ifndef SC_DAP_PC
-#define SC_DAP_PC 2
+#define SC_DAP_PC 1
+#endif
+#ifndef SC_DAP_BM
+#define SC_DAP_BM 64
 #endif
 #ifndef SC_DX_PC
 #define SC_DX_PC 1
@@ -435,6 +478,29 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #endif
 // (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
 // (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
+#ifdef STREAM_SWEEP
+  // development build: AVMOE_STREAM_CFG="KS,KS2,TPW,NW,BM,blocks per CU" picks one of the configurations below for every shape it fits
+  // (scripts/stream_sweep.py); waves per SIMD of the launch bound = what that residency needs
+  if (const char* e = getenv("AVMOE_STREAM_CFG")) {
+    int c[6] = {0, 0, 0, 0, 0, 0};
+    sscanf(e, "%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5]);
+#define SW(KS_, KS2_, TPW_, NW_, BM_, PC_)                                                                                     \
+    if (!a2mn && !a.accumulate && c[0] == KS_ && c[1] == KS2_ && c[2] == TPW_ && c[3] == NW_ && c[4] == BM_ && c[5] == PC_ &&   \
+        ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {                                           \
+      s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                                                                         \
+      ProfScope ps("gemm_stream_sweep", (long)a.M * a.nb1, abytes, flops, st);                                                  \
+      return launch_inst<KS_, KS2_, TPW_, NW_, BM_, false, false, (NW_ * PC_ + 3) / 4>(s, a.nb2, PC_, st);                      \
+    }
+    SW(12, 0, 1, 9, 32, 1) SW(12, 0, 1, 9, 64, 1) SW(12, 0, 2, 5, 32, 1) SW(12, 0, 2, 5, 32, 2) SW(12, 0, 2, 5, 64, 2) SW(12, 0, 3, 3, 32, 2)
+    SW(12, 0, 3, 3, 32, 3) SW(12, 0, 3, 3, 64, 2) SW(12, 0, 2, 4, 32, 2) SW(12, 0, 2, 4, 64, 2) SW(12, 0, 2, 4, 32, 3) SW(12, 0, 1, 8, 32, 1)
+    SW(12, 0, 1, 8, 32, 2)
+    SW(5, 0, 2, 12, 64, 1) SW(5, 0, 4, 6, 64, 2) SW(5, 0, 4, 6, 32, 2) SW(5, 0, 3, 8, 64, 1) SW(5, 0, 3, 8, 32, 2) SW(5, 0, 6, 4, 32, 2)
+    SW(5, 0, 6, 4, 32, 3) SW(5, 0, 2, 12, 32, 1) SW(5, 0, 4, 6, 32, 3)
+    SW(4, 3, 2, 12, 64, 1) SW(4, 3, 4, 6, 32, 2) SW(4, 3, 3, 8, 32, 1) SW(4, 3, 3, 8, 32, 2) SW(4, 3, 2, 12, 32, 1) SW(4, 3, 4, 6, 64, 2)
+#undef SW
+    return 1;
+  }
+#endif
 #define STREAM_CASE(COND, KS_, KS2_, TPW_, NW_, BM_, PERCU_, A2MN_, ACCOK_, NAME)   \
   if ((COND) && a2mn == A2MN_ && ks <= KS_ && ks2 <= KS2_ && (ks2 > 0) == (KS2_ > 0) && tiles <= TPW_ * NW_) {   \
     s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                               \
@@ -452,7 +518,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   STREAM_CASE(tiles <= 12 && a.M % 64 == 0, 2, 3, 1, 12, 64, 1, true, true, "gemm_stream_k64+96mn_n192")   // dY into <= 192 channels
   STREAM_CASE(true, 5, 0, 2, 12, SC_OUT_BM, SC_OUT_PC, false, true, "gemm_stream_k160_n384")    // output GEMM: K = 4*32 + 12, N = 384 per group (+= for accumulate_out)
   STREAM_CASE(true, 12, 0, 2, 4, 32, SC_DOWN_PC, false, false, "gemm_stream_k384_n128")   // grouped down projection
-  STREAM_CASE(true, 12, 0, 1, 9, 32, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
+  STREAM_CASE(true, 12, 0, 1, 9, SC_DAP_BM, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
   STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, SC_DX_PC, false, true, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
   STREAM_CASE(true, 4, 3, 2, 12, 32, 1, false, true, "gemm_stream_k128+96_n384r")      // ... ragged frames
   STREAM_CASE(a.M % 64 == 0, 2, 3, 4, 12, 64, SC_DY_PC, true, true, "gemm_stream_k64+96mn_n768")   // dY = dR^T Q + [Bm ; wbar]^T dV

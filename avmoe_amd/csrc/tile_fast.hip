@@ -566,6 +566,9 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
         }
         dzo[c] = o;
       }
+      // the prefetched rows are waited for HERE, before this tile's stores are issued: a wait placed after them would (the memory
+      // counter being in-order) also wait for the stores to be acknowledged -- once per tile
+      if constexpr (PFB) __builtin_amdgcn_s_waitcnt(0x0F70);
       if (ok) {
         st_row<T, E>(dzp + tok * DZ, e, q, dzo);
         if (a.dSooT && q == 0) a.dSooT[(long)e * t.NT + tok] = dSoo;
