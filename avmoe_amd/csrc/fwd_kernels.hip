@@ -344,6 +344,29 @@ int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStrea
                       2L * d.C, 1.f / (float)d.N, st);
 }
 
+// out[i] = sum_p parts[p * n + i]  (the per-group partial row sums of the fused statistics, in group order)
+__global__ void __launch_bounds__(256) kk_sum_parts(const float* __restrict__ parts, int nparts, long n, float* __restrict__ out) {
+  if (n % 4 == 0) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+      float4 a = *(const float4*)(parts + i);
+      for (int p = 1; p < nparts; ++p) { const float4 b = *(const float4*)(parts + (long)p * n + i); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      *(float4*)(out + i) = a;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      float a = parts[i];
+      for (int p = 1; p < nparts; ++p) a += parts[(long)p * n + i];
+      out[i] = a;
+    }
+  }
+}
+int k_sum_parts(const float* parts, int nparts, long n, float* out, hipStream_t st) {
+  ProfScope ps_("k_sum_parts", 0.0, 0.0, st);
+  hipLaunchKernelGGL(kk_sum_parts, dim3((unsigned)std::min<long>(cdiv(n, 1024), 2048)), dim3(256), 0, st, parts, nparts, n, out);
+  AVMOE_CHECK_LAUNCH("sum_parts");
+  return OK;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) kk_colmean(const void* X_, int N, int C, float* out, long out_ld) {
   const T* X = (const T*)X_;

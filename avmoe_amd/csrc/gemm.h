@@ -63,6 +63,16 @@ struct GemmArgs {
   float* Cx = nullptr;
   int nsplit = 0;
   long ldcx = 0, sCx2 = 0;
+  // optional statistics of A as a side product (streaming kernel only, K_MAJOR bf16 A, no second segment; launch_gemm_stream returns
+  // 1 when it cannot honour them): per row the sum and the sum of squares over THIS group's K columns,
+  //   st_rows[(2 b2) * st_ntot + b1 * M + i] = sum_k A ,  st_rows[(2 b2 + 1) * st_ntot + b1 * M + i] = sum_k A^2 ,
+  // and per row tile the column sums  st_cols[(b1 * tiles + t) * (nb2 * K) + b2 * K + k] = sum_{i in tile t} A[b1][i][k]
+  // (tiles = row tiles per sample, returned through st_tiles) -- the LayerNorm sums and the router's token means of X without a
+  // separate pass over X.
+  float* st_rows = nullptr;
+  float* st_cols = nullptr;
+  long st_ntot = 0;
+  int* st_tiles = nullptr;
 };
 
 // Returns 0 on success, negative avmoe status otherwise (message through set_last_error).
@@ -71,6 +81,9 @@ int launch_gemm(const GemmArgs& args, hipStream_t stream);
 // Streaming (B-stationary, persistent) kernel for token-streaming shapes; 0 = launched, 1 = shape not covered, < 0 error.
 // launch_gemm tries it first.
 int launch_gemm_stream(const GemmArgs& args, hipStream_t stream);
+// Whether the streaming kernel serves a per-sample bf16 product  (M rows per sample, nb1 samples) x (K per group, lda) -> N columns per group
+// WITH the statistics of A (GemmArgs::st_rows / st_cols): what a plan asks before it drops the separate statistics pass.
+bool gemm_stream_stats_ok(int M, int nb1, int N, int K, long lda, long ldc);
 
 // Bytes of fp32 slab workspace a split-K launch of `args` needs (0 when ksplit <= 1).
 size_t gemm_slab_bytes(const GemmArgs& args);

@@ -35,6 +35,7 @@ struct StreamArgs {
   long sA1, sA2, sB2, s2A1, s2A2, s2B1, s2B2, sC1, sC2, sD1, sD2, sRS1, sRS2;   // batch strides (elements): 1 = sample, 2 = group
   float alpha; int b_mn, out_bf16;
   float* Cx; int nsplit; long ldcx, sCx2;          // fp32 side output for the columns >= nsplit (GemmArgs::Cx)
+  float* st_rows; float* st_cols; long st_ntot;    // statistics of A (GemmArgs::st_rows / st_cols)
 };
 
 __device__ __forceinline__ float bfbits(unsigned int h) { return __builtin_bit_cast(float, h << 16); }
@@ -97,8 +98,13 @@ constexpr int stream_hold(int KS, int KS2, int TPW, int NW, int MT, bool ACC) {
 #ifndef SC_DAP_MINW
 #define SC_DAP_MINW 1        // 9-wave blocks (dApost): 5 here = two resident blocks per CU (<= 96 VGPRs, 4 spills): measured no gain
 #endif
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW>
+// STATS: the row tile's statistics as a side product (GemmArgs::st_rows / st_cols), all of them on the matrix pipe from fragments of
+// the tile that sits in the LDS anyway:  sum_k A[m][k] = (ones . A^T)[.][m] ,  sum_k A[m][k]^2 = diag(A A^T)  (wave (2 mt + j) % NW
+// does statistic j of slab mt with the fragments it reads for its products) ,  column sums = (A^T-fragments . ones) with the
+// fragments read transposed (ds_read_tr16_b64: tokens along the contraction), 16-channel tile ct by wave ct % NW.
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS>
 __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const StreamArgs p) {
+  static_assert(!STATS || (KS2 == 0 && !A2MN && !ACC && BM % 32 == 0), "statistics: plain K-major single-segment products only");
   constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
   constexpr int HOLD = stream_hold(KS, KS2, TPW, NW, BM / 16, ACC);
   constexpr int CPR1 = A2MN ? KS * 4 : KSA * 4;           // 16-byte chunks per row that come from K-major sources
@@ -136,6 +142,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
   }
   bf16x8 bfr2[TPW][KS2 > 0 ? KS2 : 1];
   int cur_s = -1;
+  const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});      // 8 x bf16 1.0
 
   // Everything pending at this point (the B fragments) is waited for HERE, once: a wait the compiler has to place itself ends up
   // in front of the first MFMA of the loop body (the fragments are loaded under conditions), where -- the memory counter being
@@ -312,9 +319,15 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
       if (ACC && mt + 1 < MT) ldc(mt + 1);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+      const bool do_s = STATS && (2 * mt) % NW == wave, do_q = STATS && (2 * mt + 1) % NW == wave;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + ks * 64 + q * 16);
+        if constexpr (STATS) {
+          if (do_s) st_s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, af, st_s, 0, 0, 0);
+          if (do_q) st_q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, st_q, 0, 0, 0);
+        }
 #pragma unroll
 #if STREAM_DISSECT == 2          // dev: LDS reads without the MFMAs
         for (int t = 0; t < TPW; ++t) acc[t][0] += __builtin_bit_cast(f32x4, af)[t & 3];
@@ -343,10 +356,44 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
           acc[t][2] += bfbits(cvc[t][1] & 0xFFFFu); acc[t][3] += bfbits(cvc[t][1] >> 16);
         }
       }
+      if constexpr (STATS) {
+        const int m = m0 + 16 * mt + r;
+        if (m < p.Mper) {
+          float* sr = p.st_rows + (long)(2 * g) * p.st_ntot + (long)s * p.Mper + m;
+          if (do_s && q == 0) sr[0] = st_s[0];
+          if (do_q && q == (r >> 2)) sr[p.st_ntot] = st_q[r & 3];
+        }
+      }
       if (mt < MT - HOLD) store_slab(mt, acc);
       else {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) held[HOLD > 0 ? mt - (MT - HOLD) : 0][t] = acc[t];
+      }
+    }
+    if constexpr (STATS) {
+      typedef __attribute__((ext_vector_type(4))) short s16x4;
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+      float* cdst = p.st_cols + ((long)tile * gridDim.y + g) * p.K;
+#pragma unroll
+      for (int cj = 0; cj < (2 * KS + NW - 1) / NW; ++cj) {
+        const int ct = wave + cj * NW;                     // 16-channel tile of this wave
+        if (ct < 2 * KS) {
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tk = 0; tk < BM / 32; ++tk) {
+            const char* ad = sA + (tk * 32 + 8 * q + (r >> 2)) * RB + (ct * 16 + 4 * (r & 3)) * 2;
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad));
+            const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + 4 * RB));
+            const s16x8 w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), ones8, c, 0, 0, 0);
+          }
+          const int ch = ct * 16 + 4 * q;                  // lane (r, q): channels ch .. ch + 3 (the same on every r)
+          if (r == 0 && ch < p.K) {
+            if (ch + 4 <= p.K) *(f32x4*)(cdst + ch) = c;
+            else for (int e = 0; e < 4 && ch + e < p.K; ++e) cdst[ch + e] = c[e];
+          }
+        }
       }
     }
     if (nxt < t_end) lstore((it + 1) & 1, nxt, stA, stB);
@@ -366,10 +413,10 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
   }
 }
 
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS = false>
 int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
-  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW>;
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW, STATS>;
   static bool attr_done = false;
   if (!attr_done) {
     if (LDS > 65536) {
@@ -390,8 +437,9 @@ int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   AVMOE_CHECK_LAUNCH("gemm_stream");
   return OK;
 }
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, int MINW = (NW == 9 ? SC_DAP_MINW : 1)>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, int MINW = (NW == 9 ? SC_DAP_MINW : 1), bool STATS = false>
 int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
+  if constexpr (STATS) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false, MINW, true>(s, nb2, per_cu, st);
   // PF2 (two row tiles of loads in flight per block) is a development switch, AVMOE_STREAM_PF2=1: measured on MI355X it changes
   // no configuration by more than +-3 % (same-box A/B of the cfg-2 step: 6.51 vs 6.50 ms) -- these kernels are not short of
   // bytes in flight; the 9-wave dApost configuration is held back by residency (105 VGPRs x 9 waves: one block per CU).
@@ -478,6 +526,21 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #endif
 // (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
 // (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
+  s.st_rows = a.st_rows; s.st_cols = a.st_cols; s.st_ntot = a.st_ntot;
+  if (a.st_rows) {                  // the product + the statistics of A: the three configurations that serve down projections
+    if (a.A2 || a2mn || a.accumulate || a.D || a.Cx || !a.st_cols || !a.st_tiles || a.out_dtype != GEMM_BF16) return 1;
+#define STATS_CASE(COND, KS_, TPW_, NW_, BM_, PERCU_, NAME)                                                   \
+    if ((COND) && ks <= KS_ && tiles <= TPW_ * NW_) {                                                         \
+      s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1; *a.st_tiles = s.tps;                                  \
+      ProfScope ps(NAME, (long)a.M * a.nb1, abytes, flops, st);                                               \
+      return launch_inst<KS_, 0, TPW_, NW_, BM_, false, false, 1, true>(s, a.nb2, PERCU_, st);                \
+    }
+    STATS_CASE(ks <= 2, 2, 2, 6, 128, 4, "gemm_stream_k64_n192+stats")
+    STATS_CASE(ks <= 5, 5, 2, 12, 64, 1, "gemm_stream_k160_n384+stats")
+    STATS_CASE(true, 12, 2, 4, 32, SC_DOWN_PC, "gemm_stream_k384_n128+stats")
+#undef STATS_CASE
+    return 1;
+  }
 #ifdef STREAM_SWEEP
   // development build: AVMOE_STREAM_CFG="KS,KS2,TPW,NW,BM,blocks per CU" picks one of the configurations below for every shape it fits
   // (scripts/stream_sweep.py); waves per SIMD of the launch bound = what that residency needs
@@ -525,6 +588,12 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   STREAM_CASE(true, 2, 3, 4, 12, 32, 1, true, true, "gemm_stream_k64+96mn_n768r")      // ... ragged frames
 #undef STREAM_CASE
   return 1;
+}
+
+bool gemm_stream_stats_ok(int M, int nb1, int N, int K, long lda, long ldc) {
+  const int ks = cdiv(K, 32), tiles = cdiv(N, 16);
+  if (M < 64 || (long)M * nb1 < 256 || K > 384 || K % 8 || lda % 8 || ldc % 8 || N % 8) return false;       // (the checks of launch_gemm_stream for such a product)
+  return (ks <= 2 && tiles <= 12) || (ks <= 5 && tiles <= 24) || tiles <= 8;
 }
 
 }  // namespace avmoe

@@ -22,6 +22,7 @@ avmoe_moe_ptrs merged_grads(const Plan& pl, const avmoe_moe_ptrs& grads, char* s
 // ---- forward: token statistics ---------------------------------------------------------------
 int k_rowstats(int bf16, const void* X, long rows, int C, float* out_sum_sq /* [2][rows] */, hipStream_t st);
 int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st);   // row sums + column means of X
+int k_sum_parts(const float* parts, int nparts, long n, float* out, hipStream_t st);       // out[i] = sum_p parts[p * n + i]
 int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out_ld, hipStream_t st);
 // ---- forward: hop 1 ---------------------------------------------------------------------------
 int k_fill_ext(const Plan& pl, char* saved, hipStream_t st);

@@ -46,7 +46,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   AVMOE_TRY(k_prep_remap(pl, sv, prm.conv_w, prm.conv_b, prm.fc_w, st));
   AVMOE_TRY(k_prep_experts(pl, sv, prm, st));
   // ---- token statistics of X: row sums (LayerNorm), column means (router) ---------------------
-  AVMOE_TRY(k_xstats(pl, X, sv, sc, st));
+  if (!d.fuse_xs) AVMOE_TRY(k_xstats(pl, X, sv, sc, st));          // (fused: they come out of the down projection below)
 
   // ---- hop 1, cross-modal experts: latent tokens read the (never materialised) remapped Y -----
   if (d.Kcy > 0) {
@@ -120,9 +120,6 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     AVMOE_TRY(k_finish_T(pl, sv, sc, prm, 1, st));
   }
 
-  // ---- router -----------------------------------------------------------------------------------
-  AVMOE_TRY(k_router(pl, sv, sc, prm, noise, probs_out, idx_out, lb_out, st));
-
   // ---- per-sample K-space matrices of the latent tokens ------------------------------------------
   AVMOE_TRY(k_rowstats(d.bf16, sv + pl.o_Text, (long)d.S * d.KLT, d.C, (float*)(sv + pl.o_Tsum), st));
   if (d.El > 0) {                                          // TT[s][l] = T T^T
@@ -142,7 +139,26 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   };
   AVMOE_TRY(down_gemm(sv + pl.o_Text, (long)d.S * d.KLT, sv + pl.o_TW));   // TW (all latent rows x all experts)
   // ---- the X-side GEMMs ------------------------------------------------------------------------
-  AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z, d.zsz == 2 ? GEMM_BF16 : GEMM_F32));                                // Zx = X Wt^T
+  if (d.fuse_xs) {                                         // Zx = X Wt^T per frame, with the row sums / column sums of X as side products
+    GemmArgs g = base();
+    int tiles = 0;
+    g.A = X; g.B = sv + pl.o_Wt; g.C = sv + pl.o_Z; g.out_dtype = GEMM_BF16;
+    g.M = d.N; g.N = d.E * d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
+    g.sA1 = (long)d.N * d.C; g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC1 = (long)d.N * d.DZ; g.sC2 = (long)d.E * d.dgp;
+    g.st_rows = (float*)(sc + pl.o_sxp); g.st_cols = (float*)(sc + pl.o_xpart); g.st_ntot = d.NT; g.st_tiles = &tiles;
+    const int rc = launch_gemm_stream(g, st);
+    if (rc != OK) {
+      if (rc == 1) set_last_error("moe_forward: the streaming down projection with statistics does not serve this shape (plan / kernel mismatch)");
+      return rc == 1 ? ERR_UNSUPPORTED : rc;
+    }
+    AVMOE_TRY(k_sum_parts((const float*)(sc + pl.o_sxp), d.g, 2L * d.NT, (float*)(sv + pl.o_sx), st));
+    AVMOE_TRY(k_colsum_f32((const float*)(sc + pl.o_xpart), tiles, d.C, d.C, d.S, (long)tiles * d.C, (float*)(sv + pl.o_rin), 2L * d.C,
+                           1.f / (float)d.N, st));
+  } else {
+    AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z, d.zsz == 2 ? GEMM_BF16 : GEMM_F32));                              // Zx = X Wt^T
+  }
+  // ---- router (its input: the token means of X -- after the statistics above) ----------------------
+  AVMOE_TRY(k_router(pl, sv, sc, prm, noise, probs_out, idx_out, lb_out, st));
   if (d.KL > 0) {                                          // L2[s] = X[s] T[s]^T
     GemmArgs g = base();
     g.A = X; g.B = sv + pl.o_Text; g.C = sv + pl.o_L2;

@@ -1,6 +1,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include "moe_plan.h"
+#include "gemm.h"
 #include <algorithm>
 #include <cstring>
 
@@ -162,6 +163,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.zsz = (tile_fast_ok(d) || d.gen) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident paths
   d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2) && !getenv("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
+  d.fuse_xs = d.bf16 && d.zsz == 2 && gemm_stream_stats_ok(d.N, d.S, d.E * d.dgp, d.Cg, d.C, d.DZ) && !getenv("AVMOE_NO_FUSE_XSTATS");
 
   size_t off[2] = {0, 0};
   int n = 0;

@@ -60,6 +60,7 @@ struct Dims {
   int H, dh, Sp;         // heads, head width, frames padded to 8
   int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
   int xchunks;    // row chunks per frame of the fused X statistics pass
+  int fuse_xs;    // the statistics of X (LayerNorm row sums, router column means) come out of the down projection's streaming GEMM: no separate pass
 };
 
 // name, region (0 saved / 1 scratch), element bytes expr (4 or d.esz), element count expr
@@ -142,7 +143,8 @@ struct Dims {
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
   X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
   X(colsum, 1, 4, (size_t)4 * d.DZ)                 /* colpart summed over blocks     */       \
-  X(xpart, 1, 4, (size_t)d.S * d.xchunks * d.C)     /* column partials of X           */       \
+  X(xpart, 1, 4, (size_t)d.S * (d.fuse_xs ? (d.N + 31) / 32 : d.xchunks) * d.C)     /* column partials of X           */       \
+  X(sxp, 1, 4, d.fuse_xs ? (size_t)2 * d.g * d.NT : 1)   /* per-group row sums of X (fused statistics) */   \
   X(gpart, 1, 4, (size_t)8 * d.g * d.E * (d.dgp * d.dgp + 2 * d.dgp + 2))  /* Gram partials */ \
   X(rowpart, 1, 4, (size_t)512 * (d.C > d.Cy ? d.C : d.Cy) * 2)  /* chunked row reductions */   \
   X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \

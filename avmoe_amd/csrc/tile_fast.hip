@@ -29,6 +29,24 @@
 #ifndef LB_POSTB
 #define LB_POSTB 2
 #endif
+// Before a tile loop: everything the per-expert prologue left pending (spill reloads included) is waited for once.  Left to the
+// compiler, that wait lands INSIDE the loop (the prologue's loads sit under conditions) -- behind the tile's stores, where the
+// in-order memory counter makes it wait for the stores to be acknowledged, every tile.
+// the per-site switches of the kernels; KF_ASSUME_FULL (development builds): every one of them a compile-time constant "on"
+#if KF_ASSUME_FULL
+#define F_LN_BEFORE(a) true
+#define F_USE_BN(a) true
+#define F_BN_TRAIN(a) true
+#define F_LN_POST(a) true
+#define F_USE_GATE(a) true
+#else
+#define F_LN_BEFORE(a) (a.ln_before)
+#define F_USE_BN(a) (a.use_bn)
+#define F_BN_TRAIN(a) (a.bn_train)
+#define F_LN_POST(a) (a.ln_post)
+#define F_USE_GATE(a) (a.use_gate)
+#endif
+#define DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 #ifndef LB_POSTB_PREFETCH
 #define LB_POSTB_PREFETCH 1       // post_small_bwd (bf16, split dApost): next tile's rows requested before the current tile is computed
 #endif
@@ -147,6 +165,16 @@ __device__ __forceinline__ void unpack_seg(const uint4& u, float4& c0, float4& c
   c1 = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u));
 }
 __device__ __forceinline__ void unpack_row(const RawRow<__bf16>& i, float4 (&v)[4]) { unpack_seg(i.v[0], v[0], v[1]); unpack_seg(i.v[1], v[2], v[3]); }
+// one 32-entry segment in raw form
+template <typename T> struct RawSeg;
+template <> struct RawSeg<float> { float4 v[2]; };
+template <> struct RawSeg<__bf16> { uint4 v; };
+__device__ __forceinline__ void zero_raw(RawSeg<float>& o) { o.v[0] = o.v[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zero_raw(RawSeg<__bf16>& o) { o.v = make_uint4(0u, 0u, 0u, 0u); }
+__device__ __forceinline__ void ldraw_seg(const float* seg, int q, RawSeg<float>& o) { o.v[0] = *(const float4*)(seg + 4 * q); o.v[1] = *(const float4*)(seg + 16 + 4 * q); }
+__device__ __forceinline__ void ldraw_seg(const __bf16* seg, int q, RawSeg<__bf16>& o) { o.v = *(const uint4*)(seg + seg_off8(q)); }
+__device__ __forceinline__ void unpack_rawseg(const RawSeg<float>& i, float4& c0, float4& c1) { c0 = i.v[0]; c1 = i.v[1]; }
+__device__ __forceinline__ void unpack_rawseg(const RawSeg<__bf16>& i, float4& c0, float4& c1) { unpack_seg(i.v, c0, c1); }
 __device__ __forceinline__ void zero_row(float4 (&v)[4]) { v[0] = v[1] = v[2] = v[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
 __device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
@@ -232,6 +260,7 @@ __global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const voi
     float4 cs0[4], cs1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    DRAIN_VMEM();
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
@@ -301,6 +330,7 @@ __global__ void __launch_bounds__(256, LB_MID) kf_mid(FMidFArgs a, const void* _
 #pragma unroll
     for (int c = 0; c < 4; ++c) { sc[c] = ld4(s_c + 16 * c + 4 * q); sh[c] = ld4(s_c + FDD + 16 * c + 4 * q); cs0[c] = zero4(); }
     constexpr int UT = 4;                                            // tiles per step: all their row loads in flight together
+    DRAIN_VMEM();
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64 * UT) {
       RawRow<T> z[UT];
       bool ok[UT];
@@ -367,8 +397,9 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
     for (int gi = 0; gi < 2; ++gi) { H1 += uvh[2 * DZ + gi * E + e]; H2 += uvh[2 * DZ + 2 * E + gi * E + e]; }
     __syncthreads();
     const bool relu = a.relu_of_e[e];
-    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float gate = F_USE_GATE(a) ? a.gate.p[e][0] : 1.f;
     const float qv = probs[(long)s * E + e] * gate;
+    DRAIN_VMEM();
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
@@ -386,7 +417,7 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
         }
       }
       float rp = 1.f, mup = 0.f;
-      if (a.ln_post) {
+      if (F_LN_POST(a)) {
         float so = 0.f, soo = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -457,7 +488,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
     }
     __syncthreads();
     const bool relu = a.relu_of_e[e];
-    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    const float gate = F_USE_GATE(a) ? a.gate.p[e][0] : 1.f;
     const float qv = probs[(long)s * E + e] * gate;
     float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
     float4 cs0[4], cs1[4];
@@ -488,6 +519,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
       }
     };
     if constexpr (PFB) prefetch(n_beg + 16 * wave);
+    DRAIN_VMEM();
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
@@ -536,7 +568,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
       float dSo = 0.f, dSoo = 0.f;
       if (ok) {
         const float dq = rp * zz + rp * da1 - rp * mup * da2 + da3;
-        if (a.ln_post) {
+        if (F_LN_POST(a)) {
           const float drp = qv * zz + qv * da1 - qv * mup * da2;
           float dmup = -qv * rp * da2;
           const float dvarp = drp * (-0.5f) * rp * rp * rp;
@@ -551,14 +583,14 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
       for (int c = 0; c < 4; ++c) {
         const int gi = c >> 1, ct = c & 1;
         f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (a.ln_post) w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+        if (F_LN_POST(a)) w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
         const float4 us = ld4(s_c + oz + 16 * c + 4 * q), vh = ld4(s_c + oz + FDD + 16 * c + 4 * q);
         float4 o;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const float zv = at(zp[c], x);
           float dzv = k1 * at(d[c], x);
-          if (a.ln_post) {
+          if (F_LN_POST(a)) {
             dzv += dSo * at(us, x) + dSoo * (2.f * w[x] + 2.f * at(vh, x));
             at(cs0[c], x) += dSo * zv; at(cs1[c], x) += dSoo * zv;
           }
@@ -635,20 +667,26 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
     float4 cs0[4], cs1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    DRAIN_VMEM();
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
-      float Sx = ok ? sxs[tok] : 0.f, Sxx = ok ? sxs[t.NT + tok] : 1.f;
-      float4 z[4], zo[4];
-      zero_row(z);
-      if (ok) ld_row<T, E>(Z + tok * DZ, e, q, z);
+      float Sx = 0.f, Sxx = 1.f;
+      float4 z[4], zo[4], lg[2];
+      RawRow<T> zraw_;
+      zero_raw(zraw_); lg[0] = zero4(); lg[1] = zero4();
+      if (ok) {                    // every load of the tile, requested together
+        Sx = sxs[tok]; Sxx = sxs[t.NT + tok];
+        ldraw_row<E>(Z + tok * DZ, e, q, zraw_);
+        if (l >= 0) {
+          const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+          lg[0] = ld4(L2 + lo); lg[1] = ld4(L2 + lo + 16);
+        }
+      }
+      unpack_row(zraw_, z);
       float4 av[2] = {zero4(), zero4()};
       if (l >= 0) {
-        const long lo = tok * t.KLp + (long)l * FK + 4 * q;
-        float4 lg[2];
-        lg[0] = ok ? ld4(L2 + lo) : zero4();
-        lg[1] = ok ? ld4(L2 + lo + 16) : zero4();
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -674,7 +712,6 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
             u1 += v * at(tb, x); u2 += v * at(lg[j], x);
           }
         }
-        if (ok) st_seg<T>(aout + tok * t.KLp + (long)l * FK, av[0], av[1], q);
         u1 = qsum4(u1); u2 = qsum4(u2);
         float u3 = 0.f;
 #pragma unroll
@@ -693,7 +730,7 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
         Sxx += 2.f * gv * sxr[2L * t.NT + tok] + gv * gv * sxr[(long)t.NT + tok];
       }
       float mu = 0.f, rr = 1.f;
-      if (a.ln_before) {
+      if (F_LN_BEFORE(a)) {
         mu = Sx / (float)t.C;
         rr = rsqrtf(fmaxf(Sxx / (float)t.C - mu * mu, 0.f) + a.ln_eps);
       }
@@ -710,14 +747,19 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const float zr = at(z[c], x) + gv * p[x];
-          const float zv = rndT<T>(a.ln_before ? rr * (zr - mu * at(ws, x)) + at(dc, x) : zr);   // as stored: BN1 statistics of the stored z
+          const float zv = rndT<T>(F_LN_BEFORE(a) ? rr * (zr - mu * at(ws, x)) + at(dc, x) : zr);   // as stored: BN1 statistics of the stored z
           at(o, x) = zv;
           if (ok) { at(cs0[c], x) += zv; at(cs1[c], x) += zv * zv; }
         }
         zo[c] = o;
       }
-      if (ok) st_row<T, E>(Z + tok * DZ, e, q, zo);
-      if (ok && q == 0) { rmu[tok * E + e] = rr; rmu[(long)t.NT * E + tok * E + e] = mu; }
+      // every store of the tile is issued here, behind its last load: a wait that follows a store also waits (in-order counter)
+      // for the store to be acknowledged
+      if (ok) {
+        if (l >= 0) st_seg<T>(aout + tok * t.KLp + (long)l * FK, av[0], av[1], q);
+        st_row<T, E>(Z + tok * DZ, e, q, zo);
+        if (q == 0) { rmu[tok * E + e] = rr; rmu[(long)t.NT * E + tok * E + e] = mu; }
+      }
     }
     flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
     flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
@@ -773,7 +815,7 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
     if (threadIdx.x < FDD) {
       const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
       s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
-      s_bn[3 * FDD + dd] = a.bn_train ? dsm[3 * DZ + col] : 0.f; s_bn[4 * FDD + dd] = a.bn_train ? dsm[4 * DZ + col] : 0.f;
+      s_bn[3 * FDD + dd] = F_BN_TRAIN(a) ? dsm[3 * DZ + col] : 0.f; s_bn[4 * FDD + dd] = F_BN_TRAIN(a) ? dsm[4 * DZ + col] : 0.f;
       s_bn[5 * FDD + dd] = wsum[col]; s_bn[6 * FDD + dd] = dconst[col];
     }
     __syncthreads();
@@ -782,18 +824,35 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
     ck[0] = zero4(); ck[1] = zero4();
+    DRAIN_VMEM();
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
-      const float rr = (a.ln_before && ok) ? rmu[tok * E + e] : 1.f;
-      const float mu = (a.ln_before && ok) ? rmu[(long)t.NT * E + tok * E + e] : 0.f;
+      const float rr = (F_LN_BEFORE(a) && ok) ? rmu[tok * E + e] : 1.f;
+      const float mu = (F_LN_BEFORE(a) && ok) ? rmu[(long)t.NT * E + tok * E + e] : 0.f;
       const float irr = 1.f / rr;
       // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
       float4 dzr[4], zrow[4], dyrow[4];
       float s_dr = 0.f, s_dmu = 0.f;
-      zero_row(zrow); zero_row(dyrow);
-      if (ok) { ld_row<T, E>(Z + tok * DZ, e, q, zrow); ld_row<T, E>(dy_in + tok * DZ, e, q, dyrow); }
+      // every load of the tile is requested here, in raw form (unpacked at first use), and every store is issued at its end: a load
+      // behind a store would (the memory counter being in-order) wait for the store to be acknowledged -- three exposed round trips
+      // per tile instead of one
+      RawRow<T> zraw_, dyraw_;
+      RawSeg<T> araw_;
+      float4 av[2], lg[2];
+      float old_sx = 0.f, old_sxx = 0.f;
+      zero_raw(zraw_); zero_raw(dyraw_); zero_raw(araw_); lg[0] = zero4(); lg[1] = zero4();
+      if (ok) {
+        ldraw_row<E>(Z + tok * DZ, e, q, zraw_); ldraw_row<E>(dy_in + tok * DZ, e, q, dyraw_);
+        if (l >= 0) {
+          ldraw_seg(ain + tok * t.KLp + (long)l * FK, q, araw_);
+          const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+          lg[0] = ld4(L2 + lo); lg[1] = ld4(L2 + lo + 16);
+        }
+        if (q == 0 && e != 0) { old_sx = dsxs[tok]; old_sxx = dsxs[t.NT + tok]; }
+      }
+      unpack_row(zraw_, zrow); unpack_row(dyraw_, dyrow);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4& z = zrow[c];
@@ -807,11 +866,11 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
           if (ok) {
             const float zv = at(z, x);
             float dz = at(dyv, x);
-            if (a.use_bn) {
-              if (a.bn_train) dz = at(sc, x) * (dz - at(mdy, x) - (zv - at(mean, x)) * at(rstd, x) * at(mdyz, x));
+            if (F_USE_BN(a)) {
+              if (F_BN_TRAIN(a)) dz = at(sc, x) * (dz - at(mdy, x) - (zv - at(mean, x)) * at(rstd, x) * at(mdyz, x));
               else dz = at(sc, x) * dz;
             }
-            if (a.ln_before) {
+            if (F_LN_BEFORE(a)) {
               const float zc = (zv - at(dc, x)) * irr;
               at(cs0[c], x) += dz; at(cs1[c], x) += -rr * mu * dz;
               s_dr += dz * zc; s_dmu += dz * at(ws, x);
@@ -820,10 +879,6 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
           }
           at(dzr[c], x) = v;
         }
-      }
-      if (ok) {
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
       }
       float szr = 0.f;
       if (nxn) {                   // x' = x + g xr : d(xr Wt^T) = g dzraw, and dzraw . (xr Wt^T) for the gate
@@ -845,7 +900,7 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
         szr = qsum4(szr);
       }
       float dSx = 0.f, dSxx = 0.f;
-      if (a.ln_before) {
+      if (F_LN_BEFORE(a)) {
         const float sdr = qsum4(s_dr), sdm = qsum4(s_dmu);
         float dmu = -rr * sdm;
         const float dvar = sdr * (-0.5f) * rr * rr * rr;
@@ -853,11 +908,7 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
         dmu -= 2.f * mu * dvar;
         dSx = dmu / (float)t.C;
       }
-      float accx = dSx, accxx = dSxx;
-      if (ok && q == 0) {
-        if (e != 0) { accx += dsxs[tok]; accxx += dsxs[t.NT + tok]; }
-        dsxs[tok] = accx; dsxs[t.NT + tok] = accxx;
-      }
+      const float accx = dSx + old_sx, accxx = dSxx + old_sxx;
       if (nxn && ok && q == 0) {   // statistics gradients to (sum xr, sum xr^2, x . xr) of this expert's xr slot, and to the gate
         float* dsr = a.dsr + a.sxr_off[e];
         const float* sxr = a.sxr + a.sxr_off[e];
@@ -867,12 +918,7 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
         sdg += dSx * sxr[tok] + dSxx * (2.f * sxr[2L * t.NT + tok] + 2.f * gv * sxr[(long)t.NT + tok]) + szr;
       }
       if (l >= 0) {
-        const long lo = tok * t.KLp + (long)l * FK + 4 * q;
-        float4 av[2], lg[2];
-        av[0] = zero4(); av[1] = zero4();
-        if (ok) ld_seg<T>(ain + tok * t.KLp + (long)l * FK, av[0], av[1], q);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) lg[j] = ok ? ld4(L2 + lo + 16 * j) : zero4();
+        unpack_rawseg(araw_, av[0], av[1]);
         float u1 = 0.f, u2 = 0.f;
         float4 tb[2];
 #pragma unroll
@@ -924,6 +970,11 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
           const long so = tok * t.KLp + (long)l * FK;
           st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
         }
+      }
+      if (ok) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
+        if (q == 0) { dsxs[tok] = accx; dsxs[t.NT + tok] = accxx; }
       }
       if (e == E - 1 && ok && q == 0) {
         stT<T>(dL2x, tok * t.KLp + t.KL, accx);
