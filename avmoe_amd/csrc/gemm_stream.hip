@@ -93,7 +93,7 @@ constexpr int stream_hold(int KS, int KS2, int TPW, int NW, int MT, bool ACC) {
   return 1;                                                         // several small blocks per CU: residency first
 }
 #ifndef STREAM_DISSECT
-#define STREAM_DISSECT 0         // development builds: 1 = no stores, 2 = no MFMAs, 3 = no row-tile loads (scripts/stream_dissect.sh)
+#define STREAM_DISSECT 0         // development builds: 1 = no stores, 2 = no MFMAs, 3 = no row-tile loads, 4 = no per-sample B2 reload (scripts/stream_dissect.sh)
 #endif
 #ifndef SC_DAP_MINW
 #define SC_DAP_MINW 1        // 9-wave blocks (dApost): 5 here = two resident blocks per CU (<= 96 VGPRs, 4 spills): measured no gain
@@ -232,18 +232,64 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
     const int nxt = tile + step;
     const char* sA = smem + (it & 1) * STG;
     const int s = tile / p.tps, m0 = (tile - s * p.tps) * BM;
+#if STREAM_DISSECT == 4          // dev: no per-sample reload of the second segment's B fragments
+    if (KS2 > 0 && s != cur_s && p.K2 < 0) {
+#else
     if (KS2 > 0 && s != cur_s) {
+#endif
       cur_s = s;
       const unsigned short* B2 = (const unsigned short*)p.B2 + (long)s * p.s2B1 + (long)g * p.s2B2;
+      {
+        // The sample's B2 ([k2][n], MN-major) goes through the LDS, 32 rows (one K step) at a time: coalesced 16-byte row loads (all of
+        // them requested up front), stored with the columns in fragment order (a wave's tile t = 16 consecutive LDS columns), read
+        // back transposed (ds_read_tr16_b64) -- instead of 8 two-byte gathers per fragment register, a round trip each.
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        constexpr int NCOLS = TPW * NW * 16, CPRB = NCOLS / 8, RB2 = NCOLS * 2 + 16;
+        char* sB2 = smem + 2 * STG;
+        constexpr bool AHEAD = KS2 * TPW <= 6;             // all K steps requested up front where the registers allow, else one at a time
+        u32x4 st[AHEAD ? (KS2 > 0 ? KS2 : 1) : 1][TPW];
+        auto b2load = [&](int ks, u32x4 (&dst)[TPW]) {
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const int n = nw0 + (r >> 2) * (4 * TPW) + 4 * t + (r & 3);
+          for (int i = 0; i < TPW; ++i) {
+            const int c = tid + i * NT, row = 32 * ks + c / CPRB, col = (c % CPRB) * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < p.K2 && col < p.N) {
+              v = *(const u32x4*)(B2 + (long)row * p.ldb2 + col);
+              if (col + 8 > p.N) v = mask_tail8(v, p.N - col);
+            }
+            dst[i] = v;
+          }
+        };
+        if constexpr (AHEAD) {
+#pragma unroll
+          for (int ks = 0; ks < KS2; ++ks) b2load(ks, st[ks]);
+        }
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
-          const int k0 = 32 * ks + 8 * q;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (n < p.N && k0 < p.K2) v = frag_mn(B2, p.ldb2, n, k0, p.K2);
-          bfr2[t][ks] = __builtin_bit_cast(bf16x8, v);
+          if constexpr (!AHEAD) b2load(ks, st[0]);
+          const u32x4 (&cur)[TPW] = st[AHEAD ? ks : 0];
+#pragma unroll
+          for (int i = 0; i < TPW; ++i) {
+            const int c = tid + i * NT, row = c / CPRB, col = (c % CPRB) * 8;
+            const int w = col / (16 * TPW), loc = col % (16 * TPW);          // 8 columns = two groups of 4 (same wave, consecutive tiles or row groups)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int l4 = loc + 4 * h, hi = l4 / (4 * TPW), tt = (l4 % (4 * TPW)) / 4;
+              *(u32x2*)(sB2 + row * RB2 + (w * 16 * TPW + tt * 16 + hi * 4) * 2) = u32x2{cur[i][2 * h], cur[i][2 * h + 1]};
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            const char* ad = sB2 + (8 * q + (r >> 2)) * RB2 + (wave * 16 * TPW + t * 16 + 4 * (r & 3)) * 2;
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad));
+            const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + 4 * RB2));
+            const s16x8 wv = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+            bfr2[t][ks] = __builtin_bit_cast(bf16x8, wv);
+          }
+          __syncthreads();
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);        // (once per sample: keeps the conditional loads above out of the counts below)
@@ -415,7 +461,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
 
 template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS = false>
 int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
-  constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16);
+  constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16) + (KS2 > 0 ? 32 * (TPW * NW * 32 + 16) : 0);      // two A stages + one K step of B2
   auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW, STATS>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -484,6 +530,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   s.sA1 = a.sA1; s.sA2 = a.sA2; s.sB2 = a.sB2; s.s2A1 = a.s2A1; s.s2A2 = a.s2A2; s.s2B1 = a.s2B1; s.s2B2 = a.s2B2;
   s.sC1 = a.sC1; s.sC2 = a.sC2; s.sD1 = a.sD1; s.sD2 = a.sD2; s.sRS1 = a.sRS1; s.sRS2 = a.sRS2;
   s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
+  if (a.A2 && (((uintptr_t)a.B2 % 16) || a.ldb2 % 8 || a.s2B1 % 8 || a.s2B2 % 8)) return 1;      // B2 rows are read as 16-byte vectors
   s.contig = a.A2 != nullptr;
   s.Cx = a.Cx; s.nsplit = a.nsplit; s.ldcx = a.ldcx; s.sCx2 = a.sCx2;
   const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);

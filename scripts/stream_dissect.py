@@ -47,7 +47,8 @@ def main():
 
 def run(L, S, ws, tag):
     row = []
-    for n, (d, A, B, Cm, r_, D, nbytes) in S.items():
+    for n, ent in S.items():
+        d, A, B, Cm, r_, D, nbytes = ent[:7]
         def call():
             capi.check(L.avmoe_gemm(C.byref(d), A.data_ptr(), B.data_ptr(), Cm.data_ptr(), r_.data_ptr() if r_ is not None else None,
                                     D.data_ptr() if D is not None else None, ws.data_ptr(), None), n)
