@@ -46,7 +46,13 @@
 #define F_LN_POST(a) (a.ln_post)
 #define F_USE_GATE(a) (a.use_gate)
 #endif
+#ifndef KF_NO_TILES
+#define KF_NO_TILES 0          // development builds: 1 = the per-expert prologues / epilogues only (what the tile loops amortise)
+#endif
 #define DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#ifndef LB_MIDB_PREFETCH
+#define LB_MIDB_PREFETCH 0       // mid_bwd: the same prefetch -- measured neutral (15 spills at three waves per SIMD), off
+#endif
 #ifndef LB_POSTB_PREFETCH
 #define LB_POSTB_PREFETCH 1       // post_small_bwd (bf16, split dApost): next tile's rows requested before the current tile is computed
 #endif
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const voi
   __shared__ float s_col[4 * FDD];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     __syncthreads();
@@ -261,13 +267,27 @@ __global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const voi
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
     DRAIN_VMEM();
+    // bf16: the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores
+    constexpr bool PF = sizeof(T) == 2 && LB_MIDB_PREFETCH;
+    RawRow<T> nz, ndz;
+    zero_raw(nz); zero_raw(ndz);
+    if constexpr (PF) {
+      const int n0 = n_beg + 16 * wave;
+      if (n0 < n_end && n0 + r < t.N) { const long row = ((long)s * t.N + n0 + r) * DZ; ldraw_row<E>(Z + row, e, q, nz); ldraw_row<E>(dzp + row, e, q, ndz); }
+    }
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long row = ((long)s * t.N + n0 + r) * DZ;
       float4 z[4], dz[4], zp[4], dyo[4];
-      zero_row(z); zero_row(dz);
-      if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
+      if constexpr (PF) {
+        unpack_row(nz, z); unpack_row(ndz, dz);
+        zero_raw(nz); zero_raw(ndz);
+        if (n0 + 64 < n_end && n0 + 64 + r < t.N) { ldraw_row<E>(Z + row + 64L * DZ, e, q, nz); ldraw_row<E>(dzp + row + 64L * DZ, e, q, ndz); }
+      } else {
+        zero_row(z); zero_row(dz);
+        if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
@@ -295,6 +315,7 @@ __global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const voi
         }
         dyo[c] = dy;
       }
+      if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's store is issued
       if (ok) st_row<T, E>(dzp + row, e, q, dyo);
     }
     flush_cols<E>(cs0, s_col, colpart, blk, 2, e);
@@ -316,7 +337,7 @@ __global__ void __launch_bounds__(256, LB_MID) kf_mid(FMidFArgs a, const void* _
   __shared__ float s_col[4 * FDD];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     __syncthreads();
@@ -382,7 +403,7 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
   __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   for (int e = 0; e < E; ++e) {
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
@@ -400,13 +421,17 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
     const float gate = F_USE_GATE(a) ? a.gate.p[e][0] : 1.f;
     const float qv = probs[(long)s * E + e] * gate;
     DRAIN_VMEM();
+    RawRow<T> nz;                                             // the next tile's row of Z, raw
+    zero_raw(nz);
+    { const int n0 = n_beg + 16 * wave; if (n0 < n_end && n0 + r < t.N) ldraw_row<E>(Z + ((long)s * t.N + n0 + r) * DZ, e, q, nz); }
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
       float4 zp[4], zraw[4];
-      zero_row(zraw);
-      if (ok) ld_row<T, E>(Z + tok * DZ, e, q, zraw);
+      unpack_row(nz, zraw);                                  // requested one tile ago
+      zero_raw(nz);
+      if (n0 + 64 < n_end && n0 + 64 + r < t.N) ldraw_row<E>(Z + (tok + 64) * DZ, e, q, nz);      // the next tile's row: in flight during this tile's arithmetic
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
@@ -435,6 +460,7 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
         mup = So / (float)t.C;
         rp = rsqrtf(fmaxf(Soo / (float)t.C - mup * mup, 0.f) + a.ln_eps);
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched row, before this tile's stores are issued (see kf_post_small_bwd)
       if (ok) {
         const float sc = qv * rp;
 #pragma unroll
@@ -474,7 +500,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
   __shared__ float s_sc[4];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     __syncthreads();
@@ -641,7 +667,7 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
   __shared__ float s_col[4 * FDD];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     const int l = a.lat_of_e[e];
@@ -792,7 +818,7 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
   __shared__ float s_sc[4];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = min(t.N, n_beg + t.per);
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
     const int l = a.lat_of_e[e];
