@@ -95,6 +95,8 @@ constexpr int stream_hold(int KS, int KS2, int TPW, int NW, int MT, bool ACC) {
 #ifndef STREAM_DISSECT
 #define STREAM_DISSECT 0         // development builds: 1 = no stores, 2 = no MFMAs, 3 = no row-tile loads, 4 = no per-sample B2 reload (scripts/stream_dissect.sh)
 #endif
+// waves per SIMD promised to the compiler (second launch bound): what the intended residency needs, at most 3 (168 registers)
+constexpr int stream_minw(int NW, int per_cu) { return (NW * per_cu + 3) / 4 < 3 ? (NW * per_cu + 3) / 4 : 3; }
 #ifndef SC_DAP_MINW
 #define SC_DAP_MINW 1        // 9-wave blocks (dApost): 5 here = two resident blocks per CU (<= 96 VGPRs, 4 spills): measured no gain
 #endif
@@ -532,6 +534,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
   if (a.A2 && (((uintptr_t)a.B2 % 16) || a.ldb2 % 8 || a.s2B1 % 8 || a.s2B2 % 8)) return 1;      // B2 rows are read as 16-byte vectors
   s.contig = a.A2 != nullptr;
+  if (const char* e = getenv("AVMOE_STREAM_CONTIG")) s.contig = atoi(e);          // dev: force the tile-to-block assignment
   s.Cx = a.Cx; s.nsplit = a.nsplit; s.ldcx = a.ldcx; s.sCx2 = a.sCx2;
   const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);
   const double nb = (double)a.nb1 * a.nb2;
@@ -580,7 +583,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     if ((COND) && ks <= KS_ && tiles <= TPW_ * NW_) {                                                         \
       s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1; *a.st_tiles = s.tps;                                  \
       ProfScope ps(NAME, (long)a.M * a.nb1, abytes, flops, st);                                               \
-      return launch_inst<KS_, 0, TPW_, NW_, BM_, false, false, 1, true>(s, a.nb2, PERCU_, st);                \
+      return launch_inst<KS_, 0, TPW_, NW_, BM_, false, false, stream_minw(NW_, PERCU_), true>(s, a.nb2, PERCU_, st);                \
     }
     STATS_CASE(ks <= 2, 2, 2, 6, 128, 4, "gemm_stream_k64_n192+stats")
     STATS_CASE(ks <= 5, 5, 2, 12, 64, 1, "gemm_stream_k160_n384+stats")
@@ -616,9 +619,9 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1;                               \
     ProfScope ps(NAME, (long)a.M * a.nb1, abytes, flops, st);                       \
     if constexpr (ACCOK_) {                                                         \
-      if (a.accumulate) return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, true>(s, a.nb2, PERCU_, st);   \
+      if (a.accumulate) return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, true, stream_minw(NW_, PERCU_)>(s, a.nb2, PERCU_, st);   \
     } else if (a.accumulate) return 1;                                              \
-    return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, false>(s, a.nb2, PERCU_, st);   \
+    return launch_inst<KS_, KS2_, TPW_, NW_, BM_, A2MN_, false, stream_minw(NW_, PERCU_)>(s, a.nb2, PERCU_, st);   \
   }
   // narrow channel groups (C / g <= 64: the first stages of Swin / HTS-AT): long row tiles, few waves -- the wide configurations
   // below leave most of their waves without a column tile there
