@@ -81,6 +81,20 @@ int launch_gemm(const GemmArgs& args, hipStream_t stream);
 // Streaming (B-stationary, persistent) kernel for token-streaming shapes; 0 = launched, 1 = shape not covered, < 0 error.
 // launch_gemm tries it first.
 int launch_gemm_stream(const GemmArgs& args, hipStream_t stream);
+
+// Two token contractions against the same (S, N, g * Cg) bf16 tensor X in ONE pass over it:
+//   C1[gi][i][j]  = sum over ALL tokens t   A1[t][gi * sA1g + i] * X[t][gi * Cg + j]      i < M1 <= 128   (split over frame chunks: slabs + reduce)
+//   C2[s][i][c]   = sum over the tokens of frame s   A2[t][i] * X[t][c]                   i < M2 <= 128   (one result per frame)
+// (the backward's dWt = dZx^T X and dT[s] = dL2[s]^T X[s]).  Both results fp32.  Returns 1 when the shape is not served.
+struct TokPairArgs {
+  const void* A1 = nullptr; long lda1 = 0; int M1 = 0; long sA1g = 0;
+  const void* A2 = nullptr; long lda2 = 0; int M2 = 0;
+  const void* X = nullptr; long ldx = 0;
+  int S = 0, N = 0, g = 1, Cg = 0;
+  float* C1 = nullptr; float* C2 = nullptr;
+  float* slabs = nullptr; size_t slab_cap = 0;          // floats
+};
+int launch_gemm_tokpair(const TokPairArgs& args, hipStream_t stream);
 // Whether the streaming kernel serves a per-sample bf16 product  (M rows per sample, nb1 samples) x (K per group, lda) -> N columns per group
 // WITH the statistics of A (GemmArgs::st_rows / st_cols): what a plan asks before it drops the separate statistics pass.
 bool gemm_stream_stats_ok(int M, int nb1, int N, int K, long lda, long ldc);

@@ -481,6 +481,75 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p, int l
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Two token contractions against the same tensor in one pass (TokPairArgs, gemm.h): block (channel tile, frame chunk) runs, frame by
+// frame, the K loop of  A1^T X  into an accumulator it keeps for the whole chunk and the K loop of  A2^T X  into one it stores per
+// frame; the second loop finds the frame's X tiles in the L2 the first one just filled.
+// ---------------------------------------------------------------------------------------------
+struct TokPairDev {
+  const char* A1; const char* A2; const char* X; float* C2; float* slabs;
+  long lda1, lda2, ldx, sA1g;
+  int M1, M2, S, N, g, Cg, tiles_n, F;
+};
+template <int BM2>
+__global__ void __launch_bounds__(256, 2) gemm_tokpair_kernel(const TokPairDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {   // XCD-aware order (see gemm_kernel): the channel tiles of one frame chunk, which share their A tiles, on one XCD
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7u, idx = lin >> 3, base = total >> 3, rem = total & 7u;
+    const unsigned logical = xcd * base + min(xcd, rem) + idx;
+    bx = (int)(logical % gridDim.x); by = (int)(logical / gridDim.x);
+  }
+  const int gi = bx / p.tiles_n, n0 = (bx % p.tiles_n) * 128;
+  const int s0 = by * p.F, s1 = min(p.S, s0 + p.F);
+  constexpr int TM2 = BM2 / 32;
+  f32x4 accW[4][4], accT[TM2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accW[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wn0 = (wave & 1) * 64;
+  for (int s = s0; s < s1; ++s) {
+    const long t0 = (long)s * p.N;
+    const char* Xb = p.X + (t0 * p.ldx + (long)gi * p.Cg) * 2;
+    gemm_segment<__bf16, 128, 128, true, true, 4, 4>(smem, p.A1 + (t0 * p.lda1 + (long)gi * p.sA1g) * 2, Xb, p.lda1, p.ldx, p.M1, p.Cg, 0, n0, 0, p.N, accW);
+#pragma unroll
+    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accT[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_segment<__bf16, BM2, 128, true, true, TM2, 4>(smem, p.A2 + t0 * p.lda2 * 2, Xb, p.lda2, p.ldx, p.M2, p.Cg, 0, n0, 0, p.N, accT);
+    float* c2 = p.C2 + (long)s * p.M2 * ((long)p.g * p.Cg) + (long)gi * p.Cg;
+    const int wm2 = (wave >> 1) * (BM2 / 2);
+#pragma unroll
+    for (int tm = 0; tm < TM2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int j = n0 + wn0 + 16 * tn + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = wm2 + 16 * tm + 4 * q + e;
+          if (i < p.M2 && j < p.Cg) c2[(long)i * ((long)p.g * p.Cg) + j] = accT[tm][tn][e];
+        }
+      }
+  }
+  float* c1 = p.slabs + ((long)by * p.g + gi) * p.M1 * (long)p.Cg;
+  const int wm1 = (wave >> 1) * 64;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int j = n0 + wn0 + 16 * tn + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = wm1 + 16 * tm + 4 * q + e;
+        if (i < p.M1 && j < p.Cg) c1[(long)i * p.Cg + j] = accW[tm][tn][e];
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -655,6 +724,48 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d, lgP);
     AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
   }
+  return OK;
+}
+
+int launch_gemm_tokpair(const TokPairArgs& a, hipStream_t stream) {
+  static const bool off = getenv("AVMOE_NO_TOKPAIR") != nullptr;      // dev switch: the two engine GEMMs instead
+  if (off || a.M1 <= 0 || a.M1 > 128 || a.M2 <= 0 || a.M2 > 64 ||          // (the 128-row second accumulator spills: not served)
+       a.M1 % 8 || a.M2 % 8 || a.Cg % 8 || a.lda1 % 8 || a.lda2 % 8 || a.ldx % 8 ||
+      a.sA1g % 8 || ((uintptr_t)a.A1 % 16) || ((uintptr_t)a.A2 % 16) || ((uintptr_t)a.X % 16) || a.N < 64 || !a.slabs)
+    return 1;
+  const int tiles_n = cdiv(a.Cg, 128), nbx = a.g * tiles_n;
+  const size_t per_slab = (size_t)a.g * a.M1 * a.Cg;
+  int nchunks = std::min<long>(a.S, std::max<long>(1, cdiv(512, nbx)));
+  nchunks = (int)std::min<size_t>(nchunks, a.slab_cap / per_slab);
+  if (nchunks < 1) return 1;
+  const int F = cdiv(a.S, nchunks);
+  nchunks = cdiv(a.S, F);
+  if (nchunks > 65535) return 1;
+  TokPairDev p;
+  p.A1 = (const char*)a.A1; p.A2 = (const char*)a.A2; p.X = (const char*)a.X; p.C2 = a.C2; p.slabs = a.slabs;
+  p.lda1 = a.lda1; p.lda2 = a.lda2; p.ldx = a.ldx; p.sA1g = a.sA1g;
+  p.M1 = a.M1; p.M2 = a.M2; p.S = a.S; p.N = a.N; p.g = a.g; p.Cg = a.Cg; p.tiles_n = tiles_n; p.F = F;
+  constexpr int LDS = 2 * 2 * 64 * (128 * 2 + 16);          // two stages of the (128, 128) MN-major / MN-major segment
+  const double bytes = ((double)a.S * a.N) * ((double)a.g * a.Cg + (double)a.g * a.M1 + a.M2) * 2.0 + (double)a.S * a.M2 * a.g * a.Cg * 4.0;
+  const double flops = 2.0 * (double)a.S * a.N * (double)a.g * a.Cg * ((double)a.M1 + a.M2);
+  {
+    ProfScope ps("gemm_tokpair", (long)a.S * a.N, bytes, flops, stream);
+    static bool attr64 = false;
+    if (!attr64) { if (hipFuncSetAttribute((const void*)gemm_tokpair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return ERR_LAUNCH; attr64 = true; }
+    hipLaunchKernelGGL(gemm_tokpair_kernel<64>, dim3(nbx, nchunks), dim3(256), LDS, stream, p);
+    AVMOE_CHECK_LAUNCH("gemm_tokpair");
+  }
+  // C1 = the chunks' partial sums, in chunk order (the split-K reduce of the engine)
+  DevArgs d{};
+  d.C = (char*)a.C1; d.slabs = a.slabs; d.M = a.M1; d.N = a.Cg; d.nb2 = a.g; d.nbatch = a.g; d.ksplit = nchunks;
+  d.sCi = a.Cg; d.sCj = 1; d.sC1 = 0; d.sC2 = (long)a.M1 * a.Cg; d.alpha = 1.f; d.accumulate = 0; d.out_bf16 = 0;
+  const long total = (long)a.g * a.M1 * a.Cg, nvec = (a.Cg % 4 == 0) ? total / 4 : total;
+  int lgP = 0;
+  while (lgP < 4 && (2 << lgP) <= nchunks && (nvec << lgP) < 131072) ++lgP;
+  const long nwv = (nvec + (64 >> lgP) - 1) / (64 >> lgP);
+  ProfScope ps("gemm_splitk_reduce", (double)total * 4.0 * (nchunks + 1), 0.0, stream);
+  hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3((int)std::min<long>((nwv + 3) / 4, 4096)), dim3(256), 0, stream, d, lgP);
+  AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
   return OK;
 }
 

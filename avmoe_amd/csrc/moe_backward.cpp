@@ -179,12 +179,23 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.sCi = d.DZ; g.sC1 = (long)d.KLT * d.DZ; g.sC2 = (long)d.E * d.dgp; g.out_dtype = dt;
     AVMOE_TRY(run(g, false));
   }
+  bool pair_done = false;                                  // dWt = dZx^T X and dT[s] = dL2[s]^T X[s] in ONE pass over X (bf16 sites with latent tokens)
+  if (d.bf16 && d.El > 0) {
+    TokPairArgs t;
+    t.A1 = dZx; t.lda1 = d.DZ; t.M1 = d.E * d.dgp; t.sA1g = (long)d.E * d.dgp;
+    t.A2 = sc + pl.o_dL2x; t.lda2 = d.KLp; t.M2 = d.KL;
+    t.X = X; t.ldx = d.C; t.S = d.S; t.N = d.N; t.g = d.g; t.Cg = d.Cg;
+    t.C1 = (float*)(sc + pl.o_dWt); t.C2 = (float*)(sc + pl.o_dT); t.slabs = slabs; t.slab_cap = slab_cap;
+    const int rc = launch_gemm_tokpair(t, st);
+    if (rc < 0) return rc;
+    pair_done = rc == OK;
+  }
   {                                                        // dWt = dZx^T X  + dTW^T Text
     GemmArgs g = base();
     g.A = dZx; g.B = X; g.C = sc + pl.o_dWt;
     g.M = d.E * d.dgp; g.N = d.Cg; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.DZ; g.ldb = d.C; g.nb2 = d.g;
     g.sA2 = (long)d.E * d.dgp; g.sB2 = d.Cg; g.sCi = d.Cg; g.sC2 = (long)d.E * d.dgp * d.Cg;
-    AVMOE_TRY(run(g, true));
+    if (!pair_done) AVMOE_TRY(run(g, true));
     if (d.El > 0) {
       GemmArgs h = g;
       h.A = sc + pl.o_dTW; h.B = sv + pl.o_Text; h.K = d.S * d.KLT; h.accumulate = 1; h.ksplit = 1;
@@ -205,7 +216,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     }
   }
   if (d.El > 0) {
-    {                                                      // dT[s] = dL2[s]^T X[s]
+    if (!pair_done) {                                      // dT[s] = dL2[s]^T X[s]
       GemmArgs g = base();
       g.A = sc + pl.o_dL2x; g.B = X; g.C = sc + pl.o_dT;
       g.M = d.KL; g.N = d.C; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.C; g.nb1 = d.S;

@@ -20,7 +20,7 @@ size_t slab_floats(const Dims& d) {
   const size_t out5 = (size_t)(d.KL ? d.KL : 1) * (d.Cy > d.C ? d.Cy : d.C);
   const size_t out6 = d.mha ? (size_t)3 * d.C * d.C : 0;              // d in_proj_weight
   size_t m = std::max(std::max(std::max(out1, out2), std::max(std::max(out3, out4), out5)), out6);
-  return m * 64 + 1024;
+  return m * 96 + 1024;
 }
 
 int make_plan(const avmoe_moe_desc* q, Plan* pl) {
