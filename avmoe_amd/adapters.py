@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict
 
+import os
 import torch
 import torch.nn as nn
 
@@ -36,7 +37,8 @@ def side_stream(dev: torch.device) -> "torch.cuda.Stream":
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        prio = int(os.environ.get("AVMOE_SIDE_PRIORITY", "0"))          # dev: -1 = high-priority side stream
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=prio)
     return st
 
 
@@ -252,25 +254,35 @@ class _PairFunction(torch.autograd.Function):
             # straight through on the side stream and OVERWRITES both buffers (its dX, its dY); the other site runs the sections
             # that touch neither buffer (avmoe_moe_backward_part, 1), waits for the small site's event, and ADDS its dX / dY in the
             # GEMM epilogues (sections 2 and 4).  Saves the add's 1.2 GB of traffic at cfg-2 but serialises the tail of the large
-            # site behind the small one: measured 3 % SLOWER than the default on MI355X, kept for memory-tight callers.
+            # site behind the small one: measured 1.5 % SLOWER than the default on MI355X (6.06 vs 5.97 ms; "big" = only the large
+            # tensor accumulated in place, the small one through two buffers and an add: 6.10 ms; a high-priority side stream changes
+            # neither), kept for memory-tight callers.
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
             a_big = Xa.numel() >= Xb.numel()
             small = (site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa) if a_big else \
                     (site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb)
             big = (site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb) if a_big else \
                   (site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa)
+            hybrid = ctx.ordered == "big"           # only the LARGE token gradient is accumulated in place; the small one: two buffers + an add
+            g_small_own = gXb if a_big else gXa     # the small site's dX (gradient of the small tensor)
+            g_small_2 = torch.empty_like(g_small_own) if hybrid else None
+            if hybrid:
+                big = big[:8] + (g_small_2,)        # the big site's dY goes to its own buffer
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 cs = _SiteBackward(*small).run(0)
                 pg_small = cs.finish()
                 done = torch.cuda.Event()
                 done.record(side)
-            cb = _SiteBackward(*big, acc_dx=True, acc_dy=True).run(1)
+            cb = _SiteBackward(*big, acc_dx=True, acc_dy=not hybrid).run(1)
             main.wait_event(done)                       # both buffers hold the small site's gradients
             pg_big = cb.run(6).finish()
             for t_ in tuple(g_ for g_ in pg_small if g_ is not None) + (cs.d_out,):
                 t_.record_stream(main)
             gXa.record_stream(side); gXb.record_stream(side)
+            if hybrid:
+                capi.check(capi.lib().avmoe_add2(g_small_own.data_ptr(), g_small_2.data_ptr(), g_small_own.numel(), None, None, 0,
+                                                 capi.BF16 if g_small_own.dtype == torch.bfloat16 else capi.F32, main.cuda_stream), "avmoe_add2")
             pga, pgb = (pg_big, pg_small) if a_big else (pg_small, pg_big)
             return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
         # both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The larger
@@ -573,7 +585,7 @@ class AdapterPair(nn.Module):
         are then summed by one add); False runs them back to back on the caller's stream and adds the second gradient inside
         the GEMM epilogues instead."""
         super().__init__()
-        self.concurrent, self._side, self.ordered_accumulate = bool(concurrent), None, bool(ordered_accumulate)
+        self.concurrent, self._side, self.ordered_accumulate = bool(concurrent), None, ordered_accumulate   # False | True | "big"
         for m in (site_a, site_b):
             if m.variant not in ("ave", "avqa"):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
@@ -592,7 +604,7 @@ class AdapterPair(nn.Module):
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
-        side = ((self._side, True) if self.ordered_accumulate else self._side) if self.concurrent else None
+        side = ((self._side, self.ordered_accumulate) if self.ordered_accumulate else self._side) if self.concurrent else None
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())

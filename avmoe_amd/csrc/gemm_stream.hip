@@ -515,6 +515,13 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     a.a_layout = K_MAJOR; a.b_layout = MN_MAJOR;
     a2mn = true;
   }
+  if (a2mn && a.nb2 == 1 && a.N > 384 && a.N % 32 == 0 && !a.D && !a.Cx && !getenv("AVMOE_STREAM_DY_WHOLE")) {
+    // dY over more than 24 column tiles: the two halves of the columns as two "groups" (A shared, B / B2 / C offset by half the
+    // columns) -- two tiles per wave instead of four: the 12-wave configuration then has registers for its fragments and for the
+    // B2 staging (the four-tile one spills), at the price of reading the skinny A twice
+    a.nb2 = 2; a.N /= 2;
+    a.sA2 = 0; a.s2A2 = 0; a.sB2 = a.b_layout == MN_MAJOR ? (long)a.N : (long)a.N * a.ldb; a.s2B2 = a.N; a.sC2 = a.N;
+  }
   if (a.dtype != GEMM_BF16 || a.a_layout != K_MAJOR || a.ksplit > 1 || (a.accumulate && a.out_dtype != GEMM_BF16) || a.sCj != 1 || (long)a.M * a.nb1 < 256 ||
       a.K > 384 || a.N > 768 || (a.nb1 > 1 && (a.sB1 != 0 || a.M < 64)))
     return 1;
@@ -634,7 +641,9 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   STREAM_CASE(true, 12, 0, 1, 9, SC_DAP_BM, SC_DAP_PC, false, false, "gemm_stream_k384_n144")   // dApost = dOut Bpost (N = 140)
   STREAM_CASE(a.M % 64 == 0, 4, 3, 2, 12, 64, SC_DX_PC, false, true, "gemm_stream_k128+96_n384")   // dX = dZx Wt + [dL2|dsx|1][T;1;dm1/N] + 2 dSxx X
   STREAM_CASE(true, 4, 3, 2, 12, 32, 1, false, true, "gemm_stream_k128+96_n384r")      // ... ragged frames
-  STREAM_CASE(a.M % 64 == 0, 2, 3, 4, 12, 64, SC_DY_PC, true, true, "gemm_stream_k64+96mn_n768")   // dY = dR^T Q + [Bm ; wbar]^T dV
+  STREAM_CASE(a.M % 64 == 0 && tiles <= 24, 2, 3, 2, 12, 64, SC_DY_PC, true, true, "gemm_stream_k64+96mn_n384")   // dY = dR^T Q + [Bm ; wbar]^T dV, half the columns per block
+  STREAM_CASE(tiles <= 24, 2, 3, 2, 12, 32, 1, true, true, "gemm_stream_k64+96mn_n384r")      // ... ragged frames
+  STREAM_CASE(a.M % 64 == 0, 2, 3, 4, 12, 64, SC_DY_PC, true, true, "gemm_stream_k64+96mn_n768")   // ... all 768 columns per block
   STREAM_CASE(true, 2, 3, 4, 12, 32, 1, true, true, "gemm_stream_k64+96mn_n768r")      // ... ragged frames
 #undef STREAM_CASE
   return 1;
