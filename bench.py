@@ -308,8 +308,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skips the fp32 re-run (value_f32)")
-    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off", "ordered", "hybrid"],
-                    help="how the two sites of a layer are run: AdapterPair on two streams / on one stream / two separate calls")
+    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off", "ordered", "hybrid", "twobuf"],
+                    help="how the two sites of a layer are run: AdapterPair on two streams (its default gradient hand-over) / on one stream / two separate calls; ordered | hybrid | twobuf: the other two-stream hand-overs (dev)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])
@@ -363,7 +363,7 @@ def main():
             for j in range(cnt):
                 a, v = build_pair(c, (Ca, Na, Cv, Nv), device, seed=100 * i + j)
                 mods.append((a, v, AdapterPair(a, v, concurrent=(pair_mode != "serial"),
-                                                ordered_accumulate={"ordered": True, "hybrid": "big"}.get(pair_mode, False)) if can_pair else None))
+                                                ordered_accumulate={"ordered": True, "hybrid": "big", "twobuf": False}.get(pair_mode, "cross")) if can_pair else None))
                 sites += [a, v]
             work.append(dict(f_a=f_a, f_v=f_v, ga4=g_a.permute(0, 2, 1).unsqueeze(-1), gv4=g_v.permute(0, 2, 1).unsqueeze(-1), mods=mods))
         params = [p for m in sites for p in m.parameters()]
