@@ -85,8 +85,10 @@ __device__ __forceinline__ u32x4 frag_mn(const unsigned short* base, long ld, in
 // PF2: TWO row tiles of loads in flight per block (two register stages in front of the two LDS buffers): a block's bytes in flight
 // -- what bounds an HBM stream once the arithmetic is hidden -- double for NLD more registers per stage.
 // slabs of a row tile whose stores are issued after the next tile has been moved into the LDS (see the loop body)
+// accumulating variants whose old C values are all requested BEFORE the next tile (like the D operand): where the registers allow
+constexpr bool stream_acc_ahead(int KS, int KS2, int TPW, int NW, int MT) { return NW >= 9 && TPW * (KS + KS2) * 4 + MT * TPW * 8 + 60 <= 168; }
 constexpr int stream_hold(int KS, int KS2, int TPW, int NW, int MT, bool ACC) {
-  if (ACC) return 0;
+  if (ACC && !stream_acc_ahead(KS, KS2, TPW, NW, MT)) return 0;
   const int est = TPW * (KS + KS2) * 4 + MT * TPW * 6 + 80;          // B fragments + held accumulators + D operands + the rest
   if (NW >= 9) return est <= 168 ? MT : 1;                          // 9 / 12 waves: three per SIMD
   if (NW == 4 && KS == 12) return MT;                               // the down projection: two 4-wave blocks per CU, 256 registers
@@ -301,7 +303,8 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
     const float* rsb = p.rs ? p.rs + (long)s * p.sRS1 + (long)g * p.sRS2 : nullptr;
     // lane (r, q) owns C[m0 + 16 mt + r][nl .. nl + 4 TPW): tile t supplies elements 4 t .. 4 t + 3 of that run
     const int nl = nw0 + 4 * TPW * q;
-    u32x2 dv[MT][TPW], cvn[ACC ? TPW : 1];
+    constexpr bool ACCA = ACC && stream_acc_ahead(KS, KS2, TPW, NW, MT);      // old C of every slab requested up front
+    u32x2 dv[MT][TPW], cvn[ACC ? TPW : 1], cva[ACCA ? MT : 1][TPW];
     float rsv[MT];
     auto ldc = [&](int mt) {
 #pragma unroll
@@ -311,7 +314,15 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
         if (m < p.Mper) ld_run<TPW>(Cb + ((long)m * p.ldc + nl) * 2, nl, p.N, cvn);
       }
     };
-    if constexpr (ACC) ldc(0);
+    if constexpr (ACCA) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 16 * mt + r;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) cva[mt][t] = u32x2{0u, 0u};
+        if (m < p.Mper) ld_run<TPW>(Cb + ((long)m * p.ldc + nl) * 2, nl, p.N, cva[mt]);
+      }
+    } else if constexpr (ACC) ldc(0);
     if (Db) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -363,8 +374,8 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
       f32x4 acc[TPW];
       u32x2 cvc[ACC ? TPW : 1];
 #pragma unroll
-      for (int t = 0; t < (ACC ? TPW : 1); ++t) cvc[t] = cvn[t];
-      if (ACC && mt + 1 < MT) ldc(mt + 1);
+      for (int t = 0; t < (ACC ? TPW : 1); ++t) cvc[t] = ACCA ? cva[ACCA ? mt : 0][t] : cvn[t];
+      if (ACC && !ACCA && mt + 1 < MT) ldc(mt + 1);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
