@@ -62,18 +62,23 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int valid) {
   return v;
 }
 
+// bytes of K per operand row and stage: 128; 256 for the 64 x 64 tile with both operands MN-major (the token contractions: their K
+// loop is bound by one memory round trip per step, and half the steps measured 140 -> 117 us on dQ = sum_s dR[s] Y[s]; for K-major
+// operands -- 256-byte row pieces -- the same change measured 3 - 60 % SLOWER)
+constexpr int stage_kbytes(int BM, int BN, bool AMN, bool BMN) { return (BM <= 64 && BN <= 64 && AMN && BMN) ? 256 : 128; }
+
 // One K segment of the block's tile: 2-stage LDS pipeline over [kbeg, kend), accumulating into acc.
 // Ends on a barrier, so a following segment (or the epilogue) may reuse the LDS buffer.
 template <typename T, int BM, int BN, bool AMN, bool BMN, int TM, int TN>
 __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const char* Bb, long lda, long ldb, int M, int N, int m0,
                                              int n0, int kbeg, int kend, f32x4 (&acc)[TM][TN]) {
   constexpr int ESZ = sizeof(T);
-  constexpr int BK = 128 / ESZ;      // K elements per stage
+  constexpr int KBY = stage_kbytes(BM, BN, AMN, BMN), BK = KBY / ESZ, CPK = KBY / 16;      // K bytes / elements / 16-byte chunks per row and stage
   constexpr int EPC = 16 / ESZ;      // elements per 16-byte chunk
   constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int A_ROWB = AMN ? BM * ESZ + 16 : 144;
+  constexpr int A_ROWB = AMN ? BM * ESZ + 16 : KBY + 16;
   constexpr int A_BYTES = (AMN ? BK : BM) * A_ROWB;
-  constexpr int B_ROWB = BMN ? BN * ESZ + 16 : 144;
+  constexpr int B_ROWB = BMN ? BN * ESZ + 16 : KBY + 16;
   constexpr int B_BYTES = (BMN ? BK : BN) * B_ROWB;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int A_CPR = BM * ESZ / 16, B_CPR = BN * ESZ / 16;   // chunks per LDS row (MN_MAJOR)
@@ -83,15 +88,16 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
   const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   struct { int M, N; long lda, ldb; } p{M, N, lda, ldb};
 
-  u32x4 ra[BM / 32], rb[BN / 32];
+  constexpr int NLA = (AMN ? BK * A_CPR : BM * CPK) / 256, NLB = (BMN ? BK * B_CPR : BN * CPK) / 256;
+  u32x4 ra[NLA], rb[NLB];
   auto gload = [&](int kt) {
     const int k0 = kbeg + kt * BK;
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
+    for (int i = 0; i < NLA; ++i) {
       const int c = tid + 256 * i;
       u32x4 v = {0u, 0u, 0u, 0u};
       if constexpr (!AMN) {
-        const int row = c >> 3, cc = c & 7;
+        const int row = c / CPK, cc = c % CPK;
         const int gr = min(m0 + row, p.M - 1);
         const int k = k0 + cc * EPC;
         if (k < kend) {
@@ -106,11 +112,11 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
       ra[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
+    for (int i = 0; i < NLB; ++i) {
       const int c = tid + 256 * i;
       u32x4 v = {0u, 0u, 0u, 0u};
       if constexpr (!BMN) {
-        const int row = c >> 3, cc = c & 7;
+        const int row = c / CPK, cc = c % CPK;
         const int gr = min(n0 + row, p.N - 1);
         const int k = k0 + cc * EPC;
         if (k < kend) {
@@ -130,15 +136,15 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
+    for (int i = 0; i < NLA; ++i) {
       const int c = tid + 256 * i;
-      if constexpr (!AMN) *(u32x4*)(sA + (c >> 3) * A_ROWB + (c & 7) * 16) = ra[i];
+      if constexpr (!AMN) *(u32x4*)(sA + (c / CPK) * A_ROWB + (c % CPK) * 16) = ra[i];
       else *(u32x4*)(sA + (c / A_CPR) * A_ROWB + (c % A_CPR) * 16) = ra[i];
     }
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
+    for (int i = 0; i < NLB; ++i) {
       const int c = tid + 256 * i;
-      if constexpr (!BMN) *(u32x4*)(sB + (c >> 3) * B_ROWB + (c & 7) * 16) = rb[i];
+      if constexpr (!BMN) *(u32x4*)(sB + (c / CPK) * B_ROWB + (c % CPK) * 16) = rb[i];
       else *(u32x4*)(sB + (c / B_CPR) * B_ROWB + (c % B_CPR) * 16) = rb[i];
     }
   };
@@ -556,10 +562,10 @@ __global__ void __launch_bounds__(256, 2) gemm_tokpair_kernel(const TokPairDev p
 template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2 = false>
 static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   constexpr int ESZ = sizeof(T);
-  constexpr int BK = 128 / ESZ;
-  constexpr int A_BYTES = (AMN ? BK : BM) * (AMN ? BM * ESZ + 16 : 144);
-  constexpr int B_BYTES = (BMN ? BK : BN) * (BMN ? BN * ESZ + 16 : 144);
-  constexpr int A2_BYTES = BM * 144, B2_BYTES = BK * (BN * ESZ + 16);
+  constexpr int KBY = stage_kbytes(BM, BN, AMN, BMN), BK = KBY / ESZ, BK2 = stage_kbytes(BM, BN, false, true) / ESZ;
+  constexpr int A_BYTES = (AMN ? BK : BM) * (AMN ? BM * ESZ + 16 : KBY + 16);
+  constexpr int B_BYTES = (BMN ? BK : BN) * (BMN ? BN * ESZ + 16 : KBY + 16);
+  constexpr int A2_BYTES = BM * (BK2 * ESZ + 16), B2_BYTES = BK2 * (BN * ESZ + 16);
   constexpr int S1 = 2 * (A_BYTES + B_BYTES), S2 = SEG2 ? 2 * (A2_BYTES + B2_BYTES) : 0;
   constexpr int STAGES = S1 > S2 ? S1 : S2;
   constexpr int EPI = BM * (BN + 4) * 4;
@@ -686,7 +692,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
             ((a.sC1 * osz) % vecb == 0) && ((a.sC2 * osz) % vecb == 0);
   d.vec_d = a.D && (((uintptr_t)a.D) % (4 * esz) == 0) && ((a.sDi * esz) % (4 * esz) == 0) &&
             ((a.sD1 * esz) % (4 * esz) == 0) && ((a.sD2 * esz) % (4 * esz) == 0);
-  const int bk = 128 / esz;
+  const int bk = 256 / esz;          // (the longest K step of any instance)
   d.kper = d.ksplit > 1 ? (int)round_up(cdiv(a.K, d.ksplit), bk) : (a.K > 0 ? (int)round_up(a.K, bk) : bk);
 
   int tile = a.tile;

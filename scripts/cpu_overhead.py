@@ -6,9 +6,11 @@ import bench
 from avmoe_amd.adapters import AdapterPair
 from avmoe_amd.dp import AdapterGradReducer
 
-c = dict(bench.CFG2)
+c = dict(bench.CONFIGS["cfg2"])
+Ca, Na, Cv, Nv, _ = c["pairs"][0]
+c.update(C=Ca, N_a=Na, N_v=Nv)
 dev = torch.device("cuda:0")
-audio, visual = bench.build_site(c, dev)
+audio, visual = bench.build_pair(c, (Ca, Na, Cv, Nv), dev)
 red = AdapterGradReducer(list(audio.parameters()) + list(visual.parameters()), sites=[audio, visual])
 S = c["B"] * c["T"]
 g = torch.Generator().manual_seed(0)
