@@ -251,20 +251,23 @@ class _PairFunction(torch.autograd.Function):
             return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
         if ctx.side is not None and ctx.ordered == "cross":
             # Cross-ordered variant: ONE buffer per token tensor, no add.  Each site OVERWRITES its own token gradient with its dX
-            # (section 2) and ADDS its dY to the other tensor's buffer (section 4) once the other site's dX is there -- both sites run
-            # sections 1 and 2 without waiting for each other, the two hop-1 chains (section 4) overlap at the end.
+            # (section 2) and ADDS its dY to the other tensor's buffer (section 16) once the other site's dX is there -- both sites run
+            # sections 1, 2 and 8 (everything but the GEMM that writes dY) without waiting for each other; only the two dY GEMMs are
+            # ordered behind the events.
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa, acc_dx=False, acc_dy=True).run(3)
                 ev_b = torch.cuda.Event(); ev_b.record(side)
+                cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
             cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
             ev_a = torch.cuda.Event(); ev_a.record(main)
+            cak.run(8)
             with torch.cuda.stream(side):
                 side.wait_event(ev_a)                    # gXa holds site A's dX
-                pgb = cbk.run(4).finish()
+                pgb = cbk.run(16).finish()
             main.wait_event(ev_b)                        # gXb holds site B's dX
-            pga = cak.run(4).finish()
+            pga = cak.run(16).finish()
             main.wait_stream(side)
             for t_ in tuple(g_ for g_ in pgb if g_ is not None) + (cbk.d_out,):
                 t_.record_stream(main)

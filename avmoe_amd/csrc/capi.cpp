@@ -71,8 +71,8 @@ int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const voi
                             const avmoe_moe_ptrs* grads, int32_t parts, void* stream) {
   Plan pl;
   AVMOE_TRY(make_plan(desc, &pl));
-  if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads || parts < 0 || parts > 7) {
-    set_last_error("avmoe_moe_backward_part: null pointer or parts not in 0..7"); return ERR_BAD_ARG;
+  if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads || parts < 0 || parts > 31) {
+    set_last_error("avmoe_moe_backward_part: null pointer or parts not in 0..31"); return ERR_BAD_ARG;
   }
   return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream, parts);
 }

@@ -18,14 +18,15 @@ avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* 
 // parts: bit mask of the sections to run, 0 = 7 = the whole backward:
 //   1  phases 1-4: the GEMMs against dOut and the bottleneck / weight space (touches neither dX nor dY)
 //   2  phase 5: the GEMMs against X -- every writer of dX
-//   4  phase 6: the hop-1 chain back to Y and the remap parameters -- every writer of dY
+//   4  phase 6: the hop-1 chain back to Y and the remap parameters -- every writer of dY;  in two steps: 8 = phase 6 without the
+//      GEMM(s) that write dY (touches neither dX nor dY), 16 = those GEMMs alone (after 8)
 // Sections are stream-ordered through `scratch`: a caller may put event records / waits between them (AdapterPair orders the
 // two sites' accumulations into the shared token gradients this way) but nothing that touches the workspaces.
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const void* dOut, const float* lb_grad,
                  char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads_in, hipStream_t st, int parts) {
   const Dims& d = pl.d;
   if (parts == 0) parts = 7;
-  if (parts != 7 && d.Kcx > 0) { set_last_error("split backward: sites with latent self attention write dX in the last section"); return ERR_UNSUPPORTED; }
+  if ((parts & 7) != 7 && d.Kcx > 0) { set_last_error("split backward: sites with latent self attention write dX in the last section"); return ERR_UNSUPPORTED; }
   avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
   avmoe_moe_ptrs grads = grads_in;
   if (d.mg) { prm = merged_params(pl, prm, sv); grads = merged_grads(pl, grads_in, sc); }     // the forward left the dense copies in `saved`
@@ -252,8 +253,11 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
   if (d.mg) AVMOE_TRY(k_merge_gather(pl, sc, grads_in, st));   // diagonal blocks of the dense weight gradients -> the caller's grouped ones
   }
-  if (!(parts & 4)) return OK;   // ======================= section 3: phase 6 ====================================
+  // ======================= section 3: phase 6 (4 = all of it; 8 = everything but the writers of dY; 16 = the writers of dY) ==========
+  const bool do6a = (parts & (4 | 8)) != 0, do6b = (parts & (4 | 16)) != 0;
+  if (!do6a && !do6b) return OK;
 
+  if (do6a) {
   // ---- phase 6a: cross-modal hop-1 chain back to Y and the remap parameters -------------------------
   {                                                        // dV = dTy Wf   (row Kcy: d ybar)
     GemmArgs g = base();
@@ -275,7 +279,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(run(g, false));
   }
   AVMOE_TRY(k_prep_dBm(pl, sc, st));
+  }
   if (d.Kcy > 0) {
+    if (do6a) {
     {                                                      // dA1[s] = [dBm | dab][s] [Wc | bc]^T
       GemmArgs g = base();
       g.A = sc + pl.o_dBmT; g.B = sv + pl.o_WcK; g.C = sc + pl.o_L1;
@@ -314,6 +320,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       AVMOE_TRY(run(g, true));
     }
     AVMOE_TRY(k_cast(d.bf16, (const float*)(sc + pl.o_dQ), d.Kcy, d.Cy, d.Cy, sc + pl.o_dQT, d.Cy, st));
+    }
+    if (do6b)
     {   // dY[s] = [Bm ; wbar][s]^T dV[s] + dR[s]^T Q   -- one pass over dY (two K segments)
       GemmArgs g = base();
       g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
@@ -323,6 +331,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.accumulate = d.acc_dy;
       AVMOE_TRY(run(g, false));
     }
+    if (do6a) {
     {                                                      // dT0[y slots] += dQ Wf^T
       GemmArgs g = base();
       g.A = sc + pl.o_dQT; g.B = sv + pl.o_WfT; g.C = sc + pl.o_dT0;
@@ -336,8 +345,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.accumulate = 1;
       AVMOE_TRY(run(g, false));
     }
+    }
   }
-  if (d.Kcy == 0) {                                        // no cross-modal expert: dY[s] = wbar (x) d ybar[s]
+  if (d.Kcy == 0 && do6b) {                                // no cross-modal expert: dY[s] = wbar (x) d ybar[s]
     GemmArgs g = base();
     g.A = sv + pl.o_BmX; g.B = sc + pl.o_dV; g.C = dY;
     g.M = d.M; g.N = d.Cy; g.K = d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Mb; g.ldb = d.Cy; g.nb1 = d.S;
@@ -380,7 +390,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       AVMOE_TRY(run(g, false));
     }
   }
-  AVMOE_TRY(k_hop1_finalize(pl, sv, sc, prm, grads, st));
+  if (do6a) AVMOE_TRY(k_hop1_finalize(pl, sv, sc, prm, grads, st));
   return OK;
 }
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 4
+#define AVMOE_ABI_VERSION 5
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -123,12 +123,14 @@ int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y,
 
 /* ABI 4 -- the same backward in stream-ordered sections.  `parts` is a bit mask: 1 = the GEMMs against dOut and the bottleneck /
  * weight space (touches neither dX nor dY), 2 = the GEMMs against X (every writer of dX), 4 = the chain back to Y and the remap
- * parameters (every writer of dY); 0 or 7 = all of it (== avmoe_moe_backward).  Sections must be run in this order with the
+ * parameters (every writer of dY); 0 or 7 = all of it (== avmoe_moe_backward).  ABI 5: section 4 in two steps -- 8 = the chain
+ * without the GEMM(s) that write dY (touches neither dX nor dY), 16 = those GEMMs alone.  Sections must be run in this order with the
  * same arguments; between calls the caller may record / wait events on the stream but must leave `saved` and `scratch` alone.
  * Purpose: a token tensor that feeds two sites (the audio tokens are X of the audio site and Y of the visual site,
  * net_trans_v3.py:695-698) collects both gradients in ONE buffer while the two sites run on two streams -- the smaller site
  * runs through and overwrites (its dY / dX), an event orders the larger site's sections 2 and 4 behind it, and that site adds
- * its dX / dY in the GEMM epilogues (accumulate_dx / accumulate_dy).
+ * its dX / dY in the GEMM epilogues (accumulate_dx / accumulate_dy); or, cross-wise: each site overwrites its own tokens' gradient
+ * (sections 1, 2, 8), then adds its dY to the other tensor (16) once the other site's section 2 is done.
  * Not available (AVMOE_ERR_UNSUPPORTED) for sites with latent self attention (AVS v2), whose last section writes dX too.        */
 int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
                             const void* dOut, const float* lb_grad, void* saved, void* scratch,

@@ -59,9 +59,11 @@ def test_backward_bf16_close_to_reference_vectors(name):
     assert not bad, bad
 
 @pytest.mark.parametrize("bf16", [False, True])
-def test_backward_sections_equal_the_whole(bf16):
-    """avmoe_moe_backward_part with parts = 1, 2, 4 in turn == avmoe_moe_backward, bit for bit (ABI 4); a site with latent self
-    attention (its last section writes dX too) refuses the split."""
+@pytest.mark.parametrize("sections", [(1, 2, 4), (3, 8, 16), (1, 2, 8, 16)])
+def test_backward_sections_equal_the_whole(bf16, sections):
+    """avmoe_moe_backward_part with parts = 1, 2, 4 in turn (ABI 4), or with the last section in two steps -- 8 = without the GEMMs
+    that write dY, 16 = those GEMMs (ABI 5) -- == avmoe_moe_backward, bit for bit; a site with latent self attention (its last
+    section writes dX too) refuses the split."""
     import ctypes as C
     from avmoe_amd import _capi as capi
     from avmoe_amd import _capi_moe as cm
@@ -76,7 +78,7 @@ def test_backward_sections_equal_the_whole(bf16):
     run.grads = {k: torch.full_like(v, float("nan")) for k, v in run.params.items()}
     gptrs = cm.make_ptrs(run.grads, cfg.E_m, cfg.E_s)
     lbw = torch.zeros(1, device=run.dev)
-    for parts in (1, 2, 4):
+    for parts in sections:
         st = run.L.avmoe_moe_backward_part(C.byref(run.desc), run.X.data_ptr(), run.Y.data_ptr(), C.byref(run.ptrs), run.dOut.data_ptr(),
                                            lbw.data_ptr(), run.saved.data_ptr(), run.scratch.data_ptr(), run.dX.data_ptr(), run.dY.data_ptr(),
                                            C.byref(gptrs), parts, torch.cuda.current_stream().cuda_stream)
