@@ -379,7 +379,11 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+#if STREAM_DISSECT == 5          // dev: statistics variant without the row sums
+      const bool do_s = false, do_q = false;
+#else
       const bool do_s = STATS && (2 * mt) % NW == wave, do_q = STATS && (2 * mt + 1) % NW == wave;
+#endif
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 af = *(const bf16x8*)(sA + (16 * mt + r) * RB + ks * 64 + q * 16);
@@ -429,7 +433,11 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
         for (int t = 0; t < TPW; ++t) held[HOLD > 0 ? mt - (MT - HOLD) : 0][t] = acc[t];
       }
     }
+#if STREAM_DISSECT == 6          // dev: statistics variant without the column sums
+    if constexpr (false) {
+#else
     if constexpr (STATS) {
+#endif
       typedef __attribute__((ext_vector_type(4))) short s16x4;
       typedef __attribute__((ext_vector_type(8))) short s16x8;
       typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
@@ -526,7 +534,8 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     a.a_layout = K_MAJOR; a.b_layout = MN_MAJOR;
     a2mn = true;
   }
-  if (a2mn && a.nb2 == 1 && a.N > 384 && a.N % 32 == 0 && !a.D && !a.Cx && !getenv("AVMOE_STREAM_DY_WHOLE")) {
+  static const bool dy_whole = getenv("AVMOE_STREAM_DY_WHOLE") != nullptr;      // dev switch
+  if (a2mn && a.nb2 == 1 && a.N > 384 && a.N % 32 == 0 && !a.D && !a.Cx && !dy_whole) {
     // dY over more than 24 column tiles: the two halves of the columns as two "groups" (A shared, B / B2 / C offset by half the
     // columns) -- two tiles per wave instead of four: the 12-wave configuration then has registers for its fragments and for the
     // B2 staging (the four-tile one spills), at the price of reading the skinny A twice
@@ -552,7 +561,8 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
   if (a.A2 && (((uintptr_t)a.B2 % 16) || a.ldb2 % 8 || a.s2B1 % 8 || a.s2B2 % 8)) return 1;      // B2 rows are read as 16-byte vectors
   s.contig = a.A2 != nullptr;
-  if (const char* e = getenv("AVMOE_STREAM_CONTIG")) s.contig = atoi(e);          // dev: force the tile-to-block assignment
+  static const char* contig_env = getenv("AVMOE_STREAM_CONTIG");          // dev: force the tile-to-block assignment
+  if (contig_env) s.contig = atoi(contig_env);
   s.Cx = a.Cx; s.nsplit = a.nsplit; s.ldcx = a.ldcx; s.sCx2 = a.sCx2;
   const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);
   const double nb = (double)a.nb1 * a.nb2;
