@@ -569,6 +569,32 @@ avmoe_moe_ptrs merged_grads(const Plan& pl, const avmoe_moe_ptrs& grads, char* s
   return p;
 }
 
+// N x N block, backward: y = att dxr (fp32, rows x C) is both the direct gradient term (dX += y) and, dotted with X, the row term of the
+// softmax backward (sum_j att_ij d att_ij = X_i . y_i).  16 lanes per row.
+template <typename T>
+__global__ void __launch_bounds__(256) kk_nxn_rowdot(const void* X_, const float* __restrict__ y, long rows, int C, void* dX_, float* __restrict__ rowdot) {
+  const T* X = (const T*)X_; T* dX = (T*)dX_;
+  const int l = threadIdx.x & 15;
+  for (long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (long)gridDim.x * 16) {
+    float acc = 0.f;
+    for (int c = l; c < C; c += 16) {
+      const float yv = y[r * C + c];
+      acc += ldT<T>(X, r * C + c) * yv;
+      stT<T>(dX, r * C + c, ldT<T>(dX, r * C + c) + yv);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (l == 0) rowdot[r] = acc;
+  }
+}
+int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st) {
+  ProfScope ps_("k_nxn_rowdot", 0.0, 0.0, st);
+  if (rows <= 0) return OK;
+  DISPATCH_T(bf16, kk_nxn_rowdot, dim3((unsigned)std::min<long>((rows + 15) / 16, 16384)), dim3(256), 0, st, X, y, rows, C, dX, rowdot);
+  AVMOE_CHECK_LAUNCH("nxn_rowdot");
+  return OK;
+}
+
 int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, int slot, int replaces, hipStream_t st) {
   ProfScope ps_("k_nxn_axpy", 0.0, 0.0, st);
   const Dims& d = pl.d;

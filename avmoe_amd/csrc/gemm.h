@@ -69,6 +69,16 @@ struct GemmArgs {
   // and per row tile the column sums  st_cols[(b1 * tiles + t) * (nb2 * K) + b2 * K + k] = sum_{i in tile t} A[b1][i][k]
   // (tiles = row tiles per sample, returned through st_tiles) -- the LayerNorm sums and the router's token means of X without a
   // separate pass over X.
+  // optional softmax epilogues of the tiled engine (128 x 128 tile, no split-K, row-major C):
+  //   epi = GEMM_EPI_ROWSTATS : nothing is stored to C; per row and column tile the running softmax statistics of alpha * (A B^T)
+  //         go to row_part[((b * M + i) * tiles + t) * 2 + {0, 1}] = (max, sum of exp(v - max)), tiles = ceil(N / 128)
+  //   epi = GEMM_EPI_EXP      : C = exp(alpha * (A B^T) - row_lse[b * M + i])
+  //   epi = GEMM_EPI_MULSUB   : C = D * (alpha * (A B^T) - row_lse[b * M + i])      (D without row_scale: the softmax backward
+  //         dS = att * (d att - rowdot) with d att = the product, never stored)
+  // -- a row softmax without the scores ever leaving the chip (gemm_row_lse combines the parts).
+  int epi = 0;
+  float* row_part = nullptr;
+  const float* row_lse = nullptr;
   float* st_rows = nullptr;
   float* st_cols = nullptr;
   long st_ntot = 0;
@@ -80,6 +90,9 @@ int launch_gemm(const GemmArgs& args, hipStream_t stream);
 
 // Streaming (B-stationary, persistent) kernel for token-streaming shapes; 0 = launched, 1 = shape not covered, < 0 error.
 // launch_gemm tries it first.
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_ROWSTATS = 1, GEMM_EPI_EXP = 2, GEMM_EPI_MULSUB = 3 };
+// lse[r] = log sum_j exp(v[r][j]) from the (max, sum) parts of GEMM_EPI_ROWSTATS (rows = batch * M, tiles = ceil(N / 128))
+int gemm_row_lse(const float* row_part, long rows, int tiles, float* lse, hipStream_t stream);
 int launch_gemm_stream(const GemmArgs& args, hipStream_t stream);
 
 // Two token contractions against the same (S, N, g * Cg) bf16 tensor X in ONE pass over it:

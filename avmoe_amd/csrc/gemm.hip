@@ -37,6 +37,7 @@ struct DevArgs {
   float alpha; int accumulate, out_bf16, vec_c, vec_d;
   int fold_rps, fold_valid;      // batch folded into M: rows per sample / stored rows per sample (0 = no fold)
   const char* A2; const char* B2; int K2; long lda2, ldb2, s2A1, s2A2, s2B1, s2B2;
+  int epi; float* row_part; const float* row_lse;          // softmax epilogues (GemmArgs::epi)
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
@@ -307,6 +308,25 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
     return;
   }
 
+  if (p.epi == GEMM_EPI_ROWSTATS) {          // (max, sum exp) of this tile's part of every row; two threads per row (BM = BN = 128)
+    constexpr int TPR = 256 / BM, CPT = BN / TPR;
+    const int i = tid / TPR, h = tid % TPR, gi = m0 + i;
+    float mx = -INFINITY;
+    for (int j = h * CPT; j < (h + 1) * CPT; ++j)
+      if (n0 + j < p.N) mx = fmaxf(mx, p.alpha * Cs[i * CLD + j]);
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = h * CPT; j < (h + 1) * CPT; ++j)
+      if (n0 + j < p.N) sum += __expf(p.alpha * Cs[i * CLD + j] - mx);
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    if (h == 0 && gi < p.M) {
+      float* rp = p.row_part + (((long)b * p.M + gi) * p.tiles_n + n0 / BN) * 2;
+      rp[0] = mx; rp[1] = sum;
+    }
+    return;
+  }
   char* Cb = p.C + ((long)b1 * p.sC1 + (long)b2 * p.sC2) * (p.out_bf16 ? 2 : 4);
   const char* Db = p.D ? p.D + ((long)b1 * p.sD1 + (long)b2 * p.sD2) * ESZ : nullptr;
   const float* rsb = p.rs ? p.rs + (long)b1 * p.sRS1 + (long)b2 * p.sRS2 : nullptr;
@@ -343,7 +363,28 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
       const bool full = (gj + 3 < p.N);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (Db) {
+      if (p.epi == GEMM_EPI_EXP) {
+        const float lse = p.row_lse[(long)b * p.M + gi];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __expf(v[e] - lse);
+      } else if (p.epi == GEMM_EPI_MULSUB) {
+        const float sub = p.row_lse[(long)b * p.M + gi];
+        if (full && p.vec_d) {
+          if constexpr (ESZ == 2) {
+            const u32x2 dv = *(const u32x2*)(Db + ((long)gi * p.sDi + gj) * 2);
+            v[0] = bf16_bits_to_f32(dv[0] & 0xFFFFu) * (v[0] - sub); v[1] = bf16_bits_to_f32(dv[0] >> 16) * (v[1] - sub);
+            v[2] = bf16_bits_to_f32(dv[1] & 0xFFFFu) * (v[2] - sub); v[3] = bf16_bits_to_f32(dv[1] >> 16) * (v[3] - sub);
+          } else {
+            const f32x4 dv = *(const f32x4*)(Db + ((long)gi * p.sDi + gj) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dv[e] * (v[e] - sub);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (gj + e < p.N) ? load_d((long)gi * p.sDi + gj + e) * (v[e] - sub) : 0.f;
+        }
+      }
+      if (Db && p.epi != GEMM_EPI_MULSUB) {
         if (full && p.vec_d) {
           if constexpr (ESZ == 2) {
             const u32x2 dv = *(const u32x2*)(Db + ((long)gi * p.sDi + gj) * 2);
@@ -644,7 +685,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return ERR_ALIGNMENT;
   }
   if (a.ksplit > 1 && !a.slabs) { set_last_error("gemm: split-K without slab workspace"); return ERR_WORKSPACE; }
-  if ((a.row_scale != nullptr) != (a.D != nullptr)) { set_last_error("gemm: row_scale and D go together"); return ERR_BAD_ARG; }
+  if (a.epi != GEMM_EPI_MULSUB && (a.row_scale != nullptr) != (a.D != nullptr)) { set_last_error("gemm: row_scale and D go together"); return ERR_BAD_ARG; }
 
   DevArgs d;
   d.A = (const char*)a.A; d.B = (const char*)a.B; d.C = (char*)a.C; d.D = (const char*)a.D;
@@ -657,6 +698,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.alpha = a.alpha; d.accumulate = a.accumulate; d.out_bf16 = a.out_dtype == GEMM_BF16;
   d.A2 = (const char*)a.A2; d.B2 = (const char*)a.B2; d.K2 = a.K2; d.lda2 = a.lda2; d.ldb2 = a.ldb2;
   d.s2A1 = a.s2A1; d.s2A2 = a.s2A2; d.s2B1 = a.s2B1; d.s2B2 = a.s2B2;
+  d.epi = a.epi; d.row_part = a.row_part; d.row_lse = a.row_lse;
+  if (a.epi != GEMM_EPI_NONE) {
+    if (a.ksplit > 1 || a.sCj != 1 || (a.D != nullptr) != (a.epi == GEMM_EPI_MULSUB) || a.row_scale || a.accumulate || a.A2 || a.Cx || a.st_rows ||
+        (a.tile != 0 && a.tile != 128) || (a.epi == GEMM_EPI_ROWSTATS && !a.row_part) || (a.epi != GEMM_EPI_ROWSTATS && !a.row_lse)) {
+      set_last_error("gemm: softmax epilogue needs a plain row-major single-pass product on the 128 x 128 tile");
+      return ERR_BAD_ARG;
+    }
+  }
   if ((a.A2 != nullptr) != (a.B2 != nullptr) || (a.A2 && (a.ksplit > 1 || !aligned16(a.A2) || !aligned16(a.B2) || !mult16(a.lda2) || !mult16(a.ldb2) ||
                                                   !mult16(a.s2A1) || !mult16(a.s2A2) || !mult16(a.s2B1) || !mult16(a.s2B2)))) {
     set_last_error("gemm: bad second K segment (pair of pointers, no split-K, 16-byte aligned strides)");
@@ -664,7 +713,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   {
     static const bool nostream = getenv("AVMOE_GEMM_NOSTREAM") != nullptr;     // dev switch: A/B against the tiled engine
-    if (!nostream) {
+    if (!nostream && a.epi == GEMM_EPI_NONE) {
       const int s = launch_gemm_stream(a, stream);
       if (s <= 0) return s;
     }
@@ -676,7 +725,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.fold_rps = d.fold_valid = 0;
   {
     static const bool nofold = getenv("AVMOE_GEMM_NOFOLD") != nullptr;      // dev switch
-    if (!nofold && a.nb1 > 1 && a.nb2 == 1 && a.a_layout == K_MAJOR && a.sB1 == 0 && d.ksplit == 1 && !a.A2 && !a.D && a.lda > 0 &&
+    if (!nofold && a.epi == GEMM_EPI_NONE && a.nb1 > 1 && a.nb2 == 1 && a.a_layout == K_MAJOR && a.sB1 == 0 && d.ksplit == 1 && !a.A2 && !a.D && a.lda > 0 &&
         a.sA1 > 0 && a.sA1 % a.lda == 0) {
       const long rps = a.sA1 / a.lda, rows = (long)(a.nb1 - 1) * rps + a.M;
       const int t0 = a.tile ? a.tile : ((a.M > 64 && a.N > 64) ? 128 : 64);      // tile of the unfolded launch
@@ -696,7 +745,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.kper = d.ksplit > 1 ? (int)round_up(cdiv(a.K, d.ksplit), bk) : (a.K > 0 ? (int)round_up(a.K, bk) : bk);
 
   int tile = a.tile;
-  if (tile == 0 || d.fold_rps) tile = (d.M > 64 && a.N > 64) ? 128 : ((d.M <= 32 && a.N <= 32) ? 32 : 64);
+  if (a.epi != GEMM_EPI_NONE) tile = 128;
+  else if (tile == 0 || d.fold_rps) tile = (d.M > 64 && a.N > 64) ? 128 : ((d.M <= 32 && a.N <= 32) ? 32 : 64);
   const int bz = d.nbatch * d.ksplit;
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
   int st;
@@ -730,6 +780,24 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d, lgP);
     AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
   }
+  return OK;
+}
+
+__global__ void __launch_bounds__(256) kk_row_lse(const float* __restrict__ part, long rows, int tiles, float* __restrict__ lse) {
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    const float* p = part + r * tiles * 2;
+    float mx = -INFINITY;
+    for (int t = 0; t < tiles; ++t) mx = fmaxf(mx, p[2 * t]);
+    float sum = 0.f;
+    for (int t = 0; t < tiles; ++t) sum += p[2 * t + 1] * __expf(p[2 * t] - mx);
+    lse[r] = mx + __logf(sum);
+  }
+}
+int gemm_row_lse(const float* row_part, long rows, int tiles, float* lse, hipStream_t stream) {
+  if (rows <= 0) return OK;
+  ProfScope ps("gemm_row_lse", 0.0, 0.0, stream);
+  hipLaunchKernelGGL(kk_row_lse, dim3((unsigned)std::min<long>(cdiv(rows, 256), 4096)), dim3(256), 0, stream, row_part, rows, tiles, lse);
+  AVMOE_CHECK_LAUNCH("gemm_row_lse");
   return OK;
 }
 

@@ -185,14 +185,19 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     for (int s0 = 0; s0 < d.S; s0 += d.nxc) {              // d.nxc frames at a time through one workspace (all of them when they fit: moe_plan.cpp)
       const int ns = std::min(d.nxc, d.S - s0);
       const char* Xc = (const char*)X + (size_t)s0 * d.N * d.C * d.esz;
-      {                                                    // scores[s] = X[s] X[s]^T
+      // att[s] = softmax_rows(X[s] X[s]^T) without the scores leaving the chip: the product runs twice with softmax epilogues -- (max, sum exp)
+      // per row and column tile, then exp(score - lse) straight to att; the row log-sum-exp is kept for the backward
+      float* lse = (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
+      for (int pass = 0; pass < 2; ++pass) {
         GemmArgs g = base();
-        g.A = Xc; g.B = Xc; g.C = sc + pl.o_attS;
+        g.A = Xc; g.B = Xc; g.C = sv + pl.o_att;
         g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
-        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np;
+        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
+        if (pass == 0) { g.epi = GEMM_EPI_ROWSTATS; g.row_part = (float*)(sc + pl.o_npart); }
+        else { g.epi = GEMM_EPI_EXP; g.row_lse = lse; }
         AVMOE_TRY(launch_gemm(g, st));
+        if (pass == 0) AVMOE_TRY(gemm_row_lse((const float*)(sc + pl.o_npart), (long)ns * d.N, cdiv(d.N, 128), lse, st));
       }
-      AVMOE_TRY(k_softmax_rows(d.bf16, (const float*)(sc + pl.o_attS), (long)ns * d.N, d.N, d.Np, sv + pl.o_att, d.Np, 1, 1, 1, 1, st));
       {                                                    // xr[s] = att[s]^T X[s]
         GemmArgs g = base();
         g.A = sv + pl.o_att; g.B = Xc; g.C = sv + pl.o_xr + (size_t)s0 * d.N * d.C * d.esz;

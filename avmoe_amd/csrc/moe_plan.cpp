@@ -139,14 +139,14 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.KP = d.E * d.dgp + 3 * d.E;
   d.KPp = (int)round_up(d.KP, 8);
   d.XW = (int)round_up(d.KPp - d.E * d.dgp, 16);
-  // AVVP N x N block: scores / softmax / its gradient are (frames, N, N) tensors.  While all frames fit in a fraction of the
+  // AVVP N x N block: softmax / its gradient are (frames, N, N) tensors (the scores and d att are fused into GEMM epilogues).  While all frames fit in a fraction of the
   // 256 MiB Infinity Cache budget they are formed once and kept for the backward; beyond that the block runs a few frames at a
   // time through one workspace of at most 2 GiB (forward AND backward, which then recomputes scores + softmax; a cache-sized 96 MiB
   // workspace -- one 4096-token frame per chunk, split-K in every product -- ran 27 % slower at cfg-3): no (S, N, N) tensor in
   // HBM -- at AVVP stage 0 (N = 4096, 640 frames) that would be 21 GB (bf16) + 43 GB (fp32 scores) per site.
   d.nxc = d.S;
   if (d.nxn && !d.mha) {
-    const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (4 + 2 * (size_t)d.esz);
+    const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (2 * (size_t)d.esz);      // att + dSc (the scores / d att themselves never leave the chip)
     const size_t keep_all = (size_t)256 << 20;
     size_t budget = (size_t)2048 << 20;          // chunk workspace (scratch, reused by every site)
     if (const char* ev = getenv("AVMOE_NXN_BUDGET_MB")) budget = (size_t)std::max(1, atoi(ev)) << 20;      // dev: sweep

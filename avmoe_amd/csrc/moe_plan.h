@@ -112,10 +112,13 @@ struct Dims {
   X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
   /* ---- AVVP N x N block (only sized when present) ---- */                                     \
   X(att, 0, d.esz, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)   /* softmax_rows(X X^T), nxc frames */  \
+  X(nlse, 0, 4, (d.nxn && !d.mha) ? (size_t)d.NT : 1)                      /* row log-sum-exp of X X^T (the backward re-forms att from it) */  \
   X(xr, 0, d.esz, d.nxn ? (size_t)d.nxr * d.NT * d.C : 1)       /* att^T X  |  MHA_e(X) - X per slot */  \
   X(sxr, 0, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)            /* sum xr, sum xr^2, x . xr  per slot */  \
   X(ZR, 0, 4, d.nxn ? (size_t)d.NT * d.DZ : 1)                  /* xr through Wt                  */  \
-  X(attS, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)      /* scores ; d att in the backward */  \
+  X(nyt, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.C : 1)            /* y = att dxr of a chunk (fp32) */  \
+  X(nrd, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N : 1)                  /* its row dots with X */  \
+  X(npart, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * ((d.N + 127) / 128) * 2 : 1)   /* per column tile (max, sum exp) of the score rows */  \
   X(dZR, 1, d.esz, d.nxn ? (size_t)d.NT * d.DZ : 1)                                                    \
   X(dsr, 1, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)                                                   \
   X(dxr, 1, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)                                                     \
