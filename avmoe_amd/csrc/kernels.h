@@ -69,6 +69,10 @@ int k_down_bwd(const Plan& pl, char* scratch, const avmoe_moe_ptrs& prm, const a
 
 int k_xrstats(const Plan& pl, const void* X, char* saved, int slot, hipStream_t st);
 int k_nxn_axpy(const Plan& pl, const void* X, char* saved, char* scratch, void* dX, int slot, int replaces, hipStream_t st);
+// att = softmax_rows(X X^T) of `frames` frames in one kernel (nxn_att.hip); have_lse: the row log-sum-exp is given (only the exp sweep runs)
+bool nxn_att_ok(int bf16, int N, int C, int Np);
+int k_nxn_att(const void* X, int frames, int N, int C, int Np, float* lse, void* att, int have_lse, hipStream_t st);
+int k_nxn_att_bwd(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* rowdot, const void* att, void* dS, hipStream_t st);
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

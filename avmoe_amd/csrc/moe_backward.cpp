@@ -137,7 +137,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       const char* Xc = (const char*)X + xo;
       const char* dxc = sc + pl.o_dxr + xo;
       char* dXc = (char*)dX + xo;
-      if (d.nxc < d.S) {                                   // the forward ran in chunks too: att of these frames again, from the kept row log-sum-exp
+      if (d.nxc < d.S && nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {
+        AVMOE_TRY(k_nxn_att(Xc, ns, d.N, d.C, d.Np, (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N, sv + pl.o_att, 1, st));
+      } else if (d.nxc < d.S) {                            // the forward ran in chunks too: att of these frames again, from the kept row log-sum-exp
         GemmArgs g = base();
         g.A = Xc; g.B = Xc; g.C = sv + pl.o_att;
         g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
@@ -154,7 +156,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       }
       // dX[s] += y[s] ; rowdot_i = X_i . y_i  ( = sum_j att_ij d att_ij, with d att_ij = X_i . dxr_j )
       AVMOE_TRY(k_nxn_rowdot(d.bf16, Xc, (const float*)(sc + pl.o_nyt), (long)ns * d.N, d.C, dXc, (float*)(sc + pl.o_nrd), st));
-      {                                                    // dSc[s] = att[s] * (X[s] dxr[s]^T - rowdot): d att never leaves the chip
+      if (nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {            // dSc[s] = att[s] * (X[s] dxr[s]^T - rowdot): d att never leaves the chip
+        AVMOE_TRY(k_nxn_att_bwd(Xc, dxc, ns, d.N, d.C, d.Np, (const float*)(sc + pl.o_nrd), sv + pl.o_att, sc + pl.o_dSc, st));
+      } else {
         GemmArgs g = base();
         g.A = Xc; g.B = dxc; g.C = sc + pl.o_dSc;
         g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;

@@ -188,6 +188,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       // att[s] = softmax_rows(X[s] X[s]^T) without the scores leaving the chip: the product runs twice with softmax epilogues -- (max, sum exp)
       // per row and column tile, then exp(score - lse) straight to att; the row log-sum-exp is kept for the backward
       float* lse = (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
+      if (nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {                 // ... as one kernel for the large-N sites (nxn_att.hip)
+        AVMOE_TRY(k_nxn_att(Xc, ns, d.N, d.C, d.Np, lse, sv + pl.o_att, 0, st));
+      } else
       for (int pass = 0; pass < 2; ++pass) {
         GemmArgs g = base();
         g.A = Xc; g.B = Xc; g.C = sv + pl.o_att;

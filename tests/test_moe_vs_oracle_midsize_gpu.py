@@ -28,6 +28,11 @@ CASES = {
     # cfg-3 (AVVP, Swin-L x HTS-AT stage 2: N x N self attention in the unimodal experts, load-balancing loss)
     "cfg3_avvp_stage2_visual_side": dict(cfg=dict(Cx=768, Nx=144, Cy=384, Ny=256, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
     "cfg3_avvp_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=768, Ny=144, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
+    # cfg-3 stages 0 and 1 at reduced token counts (a multiple of 128): the sites whose N x N softmax runs as ONE kernel (nxn_att.hip:
+    # C = 96 / 192 channels); Swin-L stage 0 x HTS-AT stage 0 and HTS-AT stage 1
+    "cfg3_avvp_stage0_audio_side_n512": dict(cfg=dict(Cx=96, Nx=512, Cy=192, Ny=256, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=3),
+    "cfg3_avvp_stage0_visual_side_n384": dict(cfg=dict(Cx=192, Nx=384, Cy=96, Ny=512, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
+    "cfg3_avvp_stage1_audio_side": dict(cfg=dict(Cx=192, Nx=1024, Cy=384, Ny=576, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
     # cfg-4 (AVQA: 1 + 2 experts, 2 latent tokens, 4 groups; Swin-L stages 0 and 2)
     "cfg4_avqa_stage2_visual_side": dict(cfg=dict(Cx=768, Nx=144, Cy=384, Ny=256, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
     "cfg4_avqa_stage0_audio_side": dict(cfg=dict(Cx=96, Nx=4096, Cy=192, Ny=2304, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
@@ -141,7 +146,7 @@ def test_midsize_bf16_close_to_oracle(name):
     bad = bf16_budget_violations(O, cfg, P, B, Xb, Yb, Gb, got, grads, lb_weight=lbw, mha_keep=keep, **kw)
     assert not bad, bad
 
-@pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2)])
+@pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2), ("cfg3_avvp_stage0_audio_side_n512", 2)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
     """The AVVP N x N block run a few frames at a time through one workspace, scores and softmax recomputed in the backward (what
