@@ -4,6 +4,7 @@
 // allocation, no host sync.
 #include <cstdlib>
 #include "moe_run.h"
+#include "side.h"
 
 namespace avmoe {
 
@@ -34,16 +35,30 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
   auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
-  auto run = [&](GemmArgs& g, bool split) {
+  auto run_on = [&](GemmArgs& g, bool split, hipStream_t on) {
     if (split) g.ksplit = choose_ksplit(g, slab_cap);
-    return launch_gemm(g, st);
+    return launch_gemm(g, on);
   };
+  auto run = [&](GemmArgs& g, bool split) { return run_on(g, split, st); };
+  // Independent branches run on a helper stream (side.h) and are joined before their first consumer and before the section ends:
+  //   section 1: dBpost = dOut^T Apost (+ its split-K reduce; the only user of the slabs until the join) beside dApost -> post_small_bwd -> Gram
+  //   section 2: the dX GEMM (nothing in this call reads dX) beside the dWt / dT chain
+  Side* side = side_worth(d) ? side_acquire(st) : nullptr;
   const size_t esz = d.esz;
   if (parts & 1) {   // =============================== section 1: phases 1 - 4 ===============================
   // the accumulators that start from zero (dtbp, dTW, dWcK, dqp, dRT) are adjacent in the plan: one memset instead of five
   MEMSET0(sc + pl.o_dtbp, (pl.o_dRT - pl.o_dtbp) + (size_t)d.S * d.M * d.Kcyp * esz);
 
   // ---- phase 1: dApost = dOut Bpost ; dBpost = dOut^T Apost -------------------------------------
+  const bool fork1 = side && (side_mask() & 2) && (d.gram64 || !d.ln_post);     // (the engine's Gram path splits K itself: it needs the slabs)
+  {
+    GemmArgs g = base();
+    g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
+    g.M = d.Cg; g.N = d.KP; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = (long)d.g * d.KPp; g.nb2 = d.g;
+    g.sA2 = d.Cg; g.sB2 = d.KPp; g.sCi = d.KPp; g.sC2 = (long)d.Cg * d.KPp;
+    if (fork1) AVMOE_TRY(side_fork(side, st));
+    AVMOE_TRY(run_on(g, true, fork1 ? side->s : st));
+  }
   int dap16 = 0;     // dApost stored as [E x 32 bottleneck columns in T | 3 E scalar columns in fp32 (dApx)]: the register-resident bf16 path
   {
     GemmArgs g = base();
@@ -62,13 +77,6 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     }
     if (!dap16) AVMOE_TRY(run(g, false));
   }
-  {
-    GemmArgs g = base();
-    g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
-    g.M = d.Cg; g.N = d.KP; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = (long)d.g * d.KPp; g.nb2 = d.g;
-    g.sA2 = d.Cg; g.sB2 = d.KPp; g.sCi = d.KPp; g.sC2 = (long)d.Cg * d.KPp;
-    AVMOE_TRY(run(g, true));
-  }
   // ---- phase 2: bottleneck space (LayerNorm-post statistics), then weight space ------------------
   AVMOE_TRY(k_post_small_bwd(pl, sv, sc, prm, grads, st, dap16));
   if (d.ln_post && d.gram64) {                             // dG[i][e] = sum_t dSoo z' z'^T : one streaming pass over z (z' formed on the fly)
@@ -81,6 +89,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.nb2 = d.g * d.E; g.sA2 = g.sB2 = d.dgp; g.sCi = d.dgp; g.sC2 = (long)d.dgp * d.dgp;
     AVMOE_TRY(run(g, true));
   }
+  if (fork1) AVMOE_TRY(side_join(side, st));
   AVMOE_TRY(k_post_prep_bwd(pl, sv, sc, prm, grads, st));
   // ---- phase 3: ReLU / BN1 ; router --------------------------------------------------------------
   AVMOE_TRY(k_mid_bwd(pl, sv, sc, prm, grads, st));
@@ -91,6 +100,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   }
   if (parts & 2) {   // =============================== section 2: phase 5 ====================================
   const char* dZx = sc + pl.o_Zw;
+  const bool fork2 = side && (side_mask() & 4) && !d.mha && !d.nxn;             // (those variants go on accumulating into dX below)
 
   // ---- phase 5: GEMMs against X --------------------------------------------------------------------
   {   // dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + 2 dSxx X[s]   -- one pass: two K segments + row-scale epilogue
@@ -103,7 +113,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
     g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
     g.accumulate = d.acc_dx;
-    AVMOE_TRY(run(g, false));
+    if (fork2) AVMOE_TRY(side_fork(side, st));
+    AVMOE_TRY(run_on(g, false, fork2 ? side->s : st));
   }
   if (d.mha) {   // ---- AVS "v1": per expert back through ZR = xr Wt_e^T, the row sums and xr = MHA_e(X) - X -------------------
     for (int e = 0; e < d.E; ++e) {
@@ -258,6 +269,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_finish_dT(pl, sv, sc, st));                  // + dtbar / C ; dTy (T, with the dm2 row) ; dTx ; dT0 ; drw, dbf
   AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
   if (d.mg) AVMOE_TRY(k_merge_gather(pl, sc, grads_in, st));   // diagonal blocks of the dense weight gradients -> the caller's grouped ones
+  if (fork2) AVMOE_TRY(side_join(side, st));
   }
   // ======================= section 3: phase 6 (4 = all of it; 8 = everything but the writers of dY; 16 = the writers of dY) ==========
   const bool do6a = (parts & (4 | 8)) != 0, do6b = (parts & (4 | 16)) != 0;

@@ -3,6 +3,7 @@
 // Stage names follow oracle/algebra_ref.py::AlgebraRef.forward.
 #include <cstdlib>
 #include "moe_run.h"
+#include "side.h"
 
 namespace avmoe {
 
@@ -47,6 +48,29 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   AVMOE_TRY(k_prep_experts(pl, sv, prm, st));
   // ---- token statistics of X: row sums (LayerNorm), column means (router) ---------------------
   if (!d.fuse_xs) AVMOE_TRY(k_xstats(pl, X, sv, sc, st));          // (fused: they come out of the down projection below)
+  // Zx = X Wt^T per frame, with the row sums / column sums of X as side products (fused statistics).  It depends on X and the
+  // weights only, the hop-1 chain below on Y and the weights only: the two run on two streams and meet at the router.
+  auto fused_down = [&](hipStream_t xs) -> int {
+    GemmArgs g = base();
+    int tiles = 0;
+    g.A = X; g.B = sv + pl.o_Wt; g.C = sv + pl.o_Z; g.out_dtype = GEMM_BF16;
+    g.M = d.N; g.N = d.E * d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
+    g.sA1 = (long)d.N * d.C; g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC1 = (long)d.N * d.DZ; g.sC2 = (long)d.E * d.dgp;
+    g.st_rows = (float*)(sc + pl.o_sxp); g.st_cols = (float*)(sc + pl.o_xpart); g.st_ntot = d.NT; g.st_tiles = &tiles;
+    const int rc = launch_gemm_stream(g, xs);
+    if (rc != OK) {
+      if (rc == 1) set_last_error("moe_forward: the streaming down projection with statistics does not serve this shape (plan / kernel mismatch)");
+      return rc == 1 ? ERR_UNSUPPORTED : rc;
+    }
+    AVMOE_TRY(k_sum_parts((const float*)(sc + pl.o_sxp), d.g, 2L * d.NT, (float*)(sv + pl.o_sx), xs));
+    return k_colsum_f32((const float*)(sc + pl.o_xpart), tiles, d.C, d.C, d.S, (long)tiles * d.C, (float*)(sv + pl.o_rin), 2L * d.C,
+                        1.f / (float)d.N, xs);
+  };
+  Side* side = (d.fuse_xs && (side_mask() & 1) && side_worth(d)) ? side_acquire(st) : nullptr;
+  if (side) {
+    AVMOE_TRY(side_fork(side, st));
+    AVMOE_TRY(fused_down(side->s));
+  }
 
   // ---- hop 1, cross-modal experts: latent tokens read the (never materialised) remapped Y -----
   if (d.Kcy > 0) {
@@ -139,21 +163,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   };
   AVMOE_TRY(down_gemm(sv + pl.o_Text, (long)d.S * d.KLT, sv + pl.o_TW));   // TW (all latent rows x all experts)
   // ---- the X-side GEMMs ------------------------------------------------------------------------
-  if (d.fuse_xs) {                                         // Zx = X Wt^T per frame, with the row sums / column sums of X as side products
-    GemmArgs g = base();
-    int tiles = 0;
-    g.A = X; g.B = sv + pl.o_Wt; g.C = sv + pl.o_Z; g.out_dtype = GEMM_BF16;
-    g.M = d.N; g.N = d.E * d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
-    g.sA1 = (long)d.N * d.C; g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC1 = (long)d.N * d.DZ; g.sC2 = (long)d.E * d.dgp;
-    g.st_rows = (float*)(sc + pl.o_sxp); g.st_cols = (float*)(sc + pl.o_xpart); g.st_ntot = d.NT; g.st_tiles = &tiles;
-    const int rc = launch_gemm_stream(g, st);
-    if (rc != OK) {
-      if (rc == 1) set_last_error("moe_forward: the streaming down projection with statistics does not serve this shape (plan / kernel mismatch)");
-      return rc == 1 ? ERR_UNSUPPORTED : rc;
-    }
-    AVMOE_TRY(k_sum_parts((const float*)(sc + pl.o_sxp), d.g, 2L * d.NT, (float*)(sv + pl.o_sx), st));
-    AVMOE_TRY(k_colsum_f32((const float*)(sc + pl.o_xpart), tiles, d.C, d.C, d.S, (long)tiles * d.C, (float*)(sv + pl.o_rin), 2L * d.C,
-                           1.f / (float)d.N, st));
+  if (d.fuse_xs) {
+    if (side) AVMOE_TRY(side_join(side, st));
+    else AVMOE_TRY(fused_down(st));
   } else {
     AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z, d.zsz == 2 ? GEMM_BF16 : GEMM_F32));                              // Zx = X Wt^T
   }

@@ -5,9 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from avmoe_amd import _capi as capi
-c = dict(bench.CFG2)
+c = dict(bench.CONFIGS["cfg2"])
+C_a, N_a, C_v, N_v, _ = c["pairs"][0]
+c.update(C=C_a, N_a=N_a, N_v=N_v)
 dev = torch.device("cuda:0")
-audio, visual = bench.build_site(c, dev)
+audio, visual = bench.build_pair(c, (C_a, N_a, C_v, N_v), dev)
+if len(sys.argv) > 1: c["B"] = int(sys.argv[1])
 S = c["B"] * c["T"]
 g = torch.Generator().manual_seed(0)
 tdt = torch.bfloat16
