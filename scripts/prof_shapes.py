@@ -10,10 +10,10 @@ C_a, N_a, C_v, N_v, _ = c["pairs"][0]
 c.update(C=C_a, N_a=N_a, N_v=N_v)
 dev = torch.device("cuda:0")
 audio, visual = bench.build_pair(c, (C_a, N_a, C_v, N_v), dev)
-if len(sys.argv) > 1: c["B"] = int(sys.argv[1])
+if len(sys.argv) > 1 and sys.argv[1].isdigit(): c["B"] = int(sys.argv[1])
 S = c["B"] * c["T"]
 g = torch.Generator().manual_seed(0)
-tdt = torch.bfloat16
+tdt = torch.float32 if "f32" in sys.argv else torch.bfloat16
 f_a = (0.3 * torch.randn(S, c["N_a"], c["C"], generator=g)).to(dev, tdt).requires_grad_(True)
 f_v = (0.3 * torch.randn(S, c["N_v"], c["C"], generator=g)).to(dev, tdt).requires_grad_(True)
 g_a = torch.randn(S, c["N_a"], c["C"], generator=g).to(dev, tdt).permute(0, 2, 1).unsqueeze(-1)
