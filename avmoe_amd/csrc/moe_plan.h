@@ -100,8 +100,8 @@ struct Dims {
   X(Z, 0, d.zsz, (size_t)d.NT * d.DZ)                   /* Zx then z (in place)           */       \
   X(L2, 0, 4, (size_t)d.NT * d.KLp)                                                             \
   X(a, 0, d.esz, (size_t)d.NT * d.KLp)                                                          \
-  X(rmu, 0, 4, (size_t)2 * d.NT * d.E)              /* r, mu  per (token, expert)     */       \
-  X(rpmup, 0, 4, (size_t)2 * d.NT * d.E)            /* rp, mup                        */       \
+  X(rmu, 0, 4, (size_t)2 * d.NT * d.E)              /* [r | mu][expert][token]        */       \
+  X(rpmup, 0, 4, (size_t)2 * d.NT * d.E)            /* [rp | mup][expert][token]      */       \
   X(bn1, 0, 4, (size_t)4 * d.DZ)                    /* mean, rstd, scale, shift       */       \
   X(mz, 0, 4, (size_t)d.DZ)                                                                     \
   X(Szz, 0, 4, (size_t)d.g * d.E * d.dgp * d.dgp)                                               \

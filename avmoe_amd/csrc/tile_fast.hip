@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
           const long base = (tok * 2 + q) * t.KPp + E * FDG + 3 * e;
           stT<T>(Apost, base + 0, qv * rp); stT<T>(Apost, base + 1, -qv * rp * mup); stT<T>(Apost, base + 2, qv);
         }
-        if (q == 2) { rpmup[tok * E + e] = rp; rpmup[(long)t.NT * E + tok * E + e] = mup; }
+        if (q == 2) { rpmup[(long)e * t.NT + tok] = rp; rpmup[(long)t.NT * E + (long)e * t.NT + tok] = mup; }
       }
     }
   }
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
           const float* p = a.dApx + (tk * 2 + gi) * 16 + 3 * e;
           nx[3 * gi] = p[0]; nx[3 * gi + 1] = p[1]; nx[3 * gi + 2] = p[2];
         }
-        nx[6] = rpmup[tk * E + e]; nx[7] = rpmup[(long)t.NT * E + tk * E + e];
+        nx[6] = rpmup[(long)e * t.NT + tk]; nx[7] = rpmup[(long)t.NT * E + (long)e * t.NT + tk];
       }
     };
     if constexpr (PFB) prefetch(n_beg + 16 * wave);
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
           const float* p = D16 ? a.dApx + (tok * 2 + gi) * 16 + 3 * e : dAp + (tok * 2 + gi) * t.KPp + E * FDG + 3 * e;
           da1 += p[0]; da2 += p[1]; da3 += p[2];
         }
-        rp = rpmup[tok * E + e]; mup = rpmup[(long)t.NT * E + tok * E + e];
+        rp = rpmup[(long)e * t.NT + tok]; mup = rpmup[(long)t.NT * E + (long)e * t.NT + tok];
       }
       float zz = 0.f;
 #pragma unroll
@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
       if (ok) {
         if (l >= 0) st_seg<T>(aout + tok * t.KLp + (long)l * FK, av[0], av[1], q);
         st_row<T, E>(Z + tok * DZ, e, q, zo);
-        if (q == 0) { rmu[tok * E + e] = rr; rmu[(long)t.NT * E + tok * E + e] = mu; }
+        if (q == 0) { rmu[(long)e * t.NT + tok] = rr; rmu[(long)t.NT * E + (long)e * t.NT + tok] = mu; }
       }
     }
     flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
@@ -855,8 +855,8 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
-      const float rr = (F_LN_BEFORE(a) && ok) ? rmu[tok * E + e] : 1.f;
-      const float mu = (F_LN_BEFORE(a) && ok) ? rmu[(long)t.NT * E + tok * E + e] : 0.f;
+      const float rr = (F_LN_BEFORE(a) && ok) ? rmu[(long)e * t.NT + tok] : 1.f;
+      const float mu = (F_LN_BEFORE(a) && ok) ? rmu[(long)t.NT * E + (long)e * t.NT + tok] : 0.f;
       const float irr = 1.f / rr;
       // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
       float4 dzr[4], zrow[4], dyrow[4];

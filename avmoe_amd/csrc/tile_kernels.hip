@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
       if (r == 0) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-          if (n0 + 4 * q + x < t.N) { rmu[(t0 + 4 * q + x) * t.E + e] = rr[x]; rmu[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] = mu[x]; }
+          if (n0 + 4 * q + x < t.N) { rmu[(long)e * t.NT + (t0 + 4 * q + x)] = rr[x]; rmu[(long)t.NT * t.E + (long)e * t.NT + (t0 + 4 * q + x)] = mu[x]; }
       }
     }
     flush_colacc(t, s_col, 2, e, colpart, blk, 0);
@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* _
       if (r == 0) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-          if (n0 + 4 * q + x < t.N) { rpmup[(t0 + 4 * q + x) * t.E + e] = rp[x]; rpmup[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] = mup[x]; }
+          if (n0 + 4 * q + x < t.N) { rpmup[(long)e * t.NT + (t0 + 4 * q + x)] = rp[x]; rpmup[(long)t.NT * t.E + (long)e * t.NT + (t0 + 4 * q + x)] = mup[x]; }
       }
     }
   }
@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const flo
           const float* p = dAp + ((t0 + lane) * t.g + gi) * t.KPp + t.E * dgp + 3 * e;
           pr[0] += p[0]; pr[1] += p[1]; pr[2] += p[2];
         }
-        pr[3] = rpmup[(t0 + lane) * t.E + e]; pr[4] = rpmup[(long)t.NT * t.E + (t0 + lane) * t.E + e];
+        pr[3] = rpmup[(long)e * t.NT + (t0 + lane)]; pr[4] = rpmup[(long)t.NT * t.E + (long)e * t.NT + (t0 + lane)];
       }
     };
     if (PF && n_beg + 16 * wave < n_end) fetch(n_beg + 16 * wave);
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(256) kt_post_small_bwd(PostBTArgs a, const flo
               const float* p = dAp + ((t0 + lane) * t.g + gi) * t.KPp + t.E * dgp + 3 * e;
               d1 += p[0]; d2 += p[1]; d3 += p[2];
             }
-            rpv = rpmup[(t0 + lane) * t.E + e]; mupv = rpmup[(long)t.NT * t.E + (t0 + lane) * t.E + e];
+            rpv = rpmup[(long)e * t.NT + (t0 + lane)]; mupv = rpmup[(long)t.NT * t.E + (long)e * t.NT + (t0 + lane)];
           }
           rw[lane] = d1; rw[16 + lane] = d2; rw[32 + lane] = d3; rw[48 + lane] = rpv; rw[64 + lane] = mupv;
         }
@@ -885,8 +885,8 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         ok[x] = n0 + 4 * q + x < t.N;
-        rr[x] = (a.ln_before && ok[x]) ? rmu[(t0 + 4 * q + x) * t.E + e] : 1.f;
-        mu[x] = (a.ln_before && ok[x]) ? rmu[(long)t.NT * t.E + (t0 + 4 * q + x) * t.E + e] : 0.f;
+        rr[x] = (a.ln_before && ok[x]) ? rmu[(long)e * t.NT + (t0 + 4 * q + x)] : 1.f;
+        mu[x] = (a.ln_before && ok[x]) ? rmu[(long)t.NT * t.E + (long)e * t.NT + (t0 + 4 * q + x)] : 0.f;
       }
       // ---- BN1 input gradient, folded-LayerNorm sums, dzraw tile ----
       float s_dr[4] = {0.f, 0.f, 0.f, 0.f}, s_dmu[4] = {0.f, 0.f, 0.f, 0.f}, s_zr[4] = {0.f, 0.f, 0.f, 0.f};

@@ -142,8 +142,8 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
     Z = run.buf("Z", shape=(S, N, g, E, dgp))
     TW = run.buf("TW", shape=(S, KLT, g, E, dgp))
     TT = run.buf("TT", shape=(S, max(El, 1), K, K))
-    rmu = run.buf("rmu", shape=(2, S, N, E))
-    rpm = run.buf("rpmup", shape=(2, S, N, E))
+    rmu = run.buf("rmu", shape=(2, E, S, N))              # [r | mu][expert][token]
+    rpm = run.buf("rpmup", shape=(2, E, S, N))
     bn1 = run.buf("bn1", shape=(4, g, E, dgp))
     mz = run.buf("mz", shape=(g, E, dgp))
     Szz = run.buf("Szz", shape=(g, E, dgp, dgp))
@@ -161,8 +161,8 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
             rec(tag + "a", a[:, :, l * Kp:l * Kp + K], e["a"])
         rec(tag + "z", Z[:, :, :, j, :dg], e["z"])
         if cfg.ln_before:
-            rec(tag + "r", rmu[0, :, :, j], e["r"])
-            rec(tag + "mu", rmu[1, :, :, j], e["mu"])
+            rec(tag + "r", rmu[0, j], e["r"])
+            rec(tag + "mu", rmu[1, j], e["mu"])
         if cfg.use_bn:
             rec(tag + "bn1.rstd", bn1[1, :, j, :dg], e["r1"].expand(g, dg))
             if run.training:
@@ -173,8 +173,8 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
         rec(tag + "h2", bn2[3, j].reshape(g, -1), e["h2"])
         if cfg.ln_post:
             rec(tag + "G", Gq[:, j, :dg, :dg], e["G"])
-            rec(tag + "rp", rpm[0, :, :, j], e["rp"])
-            rec(tag + "mup", rpm[1, :, :, j], e["mup"])
+            rec(tag + "rp", rpm[0, j], e["rp"])
+            rec(tag + "mup", rpm[1, j], e["mup"])
         rec(tag + "Az", Ap[:, :, :, j * dgp:j * dgp + dg], e["Az"])
         rec(tag + "c1", Ap[:, :, 0, E * dgp + 3 * j + 0], e["c1"])
         rec(tag + "c2", Ap[:, :, 0, E * dgp + 3 * j + 1], e["c2"])
