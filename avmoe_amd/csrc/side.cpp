@@ -1,5 +1,6 @@
 #include "side.h"
 #include "common.h"
+#include "prof.h"
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -22,7 +23,7 @@ int side_mask() {
 }
 
 Side* side_acquire(hipStream_t st) {
-  if (side_disabled()) return nullptr;
+  if (side_disabled() || prof_enabled()) return nullptr;      // (per-launch timing brackets launches on the caller's stream: a forked branch would be timed with its queueing)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(g_mu);

@@ -1,7 +1,7 @@
 // A helper stream per caller stream for the independent branches inside one forward / backward call (fork: the helper waits for
 // everything enqueued on the caller's stream so far; join: the caller's stream waits for the helper).  After the join all work is
 // ordered into the caller's stream again, so the calls keep their stream-ordered contract (and stay capturable: fork / join through
-// events is the capture-legal pattern).  AVMOE_NO_SIDE=1 switches the helper streams off (everything on the caller's stream).
+// events is the capture-legal pattern).  AVMOE_NO_SIDE=1 switches the helper streams off (everything on the caller's stream); so does the per-launch timing of prof.h while it is on.
 #pragma once
 #include <hip/hip_runtime.h>
 

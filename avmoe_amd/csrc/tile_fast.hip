@@ -469,12 +469,34 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
           const float4 v1 = make_float4(sc * zp[2 * gi + 1].x, sc * zp[2 * gi + 1].y, sc * zp[2 * gi + 1].z, sc * zp[2 * gi + 1].w);
           st_seg<T>(Apost + (tok * 2 + gi) * t.KPp + e * FDG, v0, v1, q);
         }
-        if (q < 2) {
-          const long base = (tok * 2 + q) * t.KPp + E * FDG + 3 * e;
-          stT<T>(Apost, base + 0, qv * rp); stT<T>(Apost, base + 1, -qv * rp * mup); stT<T>(Apost, base + 2, qv);
-        }
         if (q == 2) { rpmup[(long)e * t.NT + tok] = rp; rpmup[(long)t.NT * E + (long)e * t.NT + tok] = mup; }
       }
+    }
+  }
+  // The 3 E scalar columns [q rp, -q rp mup, q] of every (token, group) row of Apost, for all experts at once: one thread per row
+  // writes its 6 E bytes as a run (from rp / mup as stored above, token-contiguous) -- inside the expert passes they were three 2-byte
+  // stores per lane, token and expert: 28 % of the kernel's time.
+  __syncthreads();
+  float qe[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) qe[e] = probs[(long)s * E + e] * (F_USE_GATE(a) ? a.gate.p[e][0] : 1.f);
+  for (int idx = threadIdx.x; idx < 2 * (n_end - n_beg); idx += 256) {
+    const long tok = (long)s * t.N + n_beg + (idx >> 1);
+    float v[3 * E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float rp = rpmup[(long)e * t.NT + tok], mup = rpmup[(long)t.NT * E + (long)e * t.NT + tok];
+      v[3 * e] = qe[e] * rp; v[3 * e + 1] = -qe[e] * rp * mup; v[3 * e + 2] = qe[e];
+    }
+    T* dst = Apost + (tok * 2 + (idx & 1)) * t.KPp + E * FDG;
+    if constexpr (sizeof(T) == 2) {
+      unsigned* d32 = (unsigned*)dst;                        // (E * FDG is even and KPp a multiple of 4: 4-byte aligned)
+#pragma unroll
+      for (int j = 0; j + 1 < 3 * E; j += 2) d32[j >> 1] = (unsigned)f2bf(v[j]) | ((unsigned)f2bf(v[j + 1]) << 16);
+      if constexpr ((3 * E) & 1) stT<T>(dst, 3 * E - 1, v[3 * E - 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3 * E; ++j) stT<T>(dst, j, v[j]);
     }
   }
 }

@@ -465,7 +465,8 @@ def main():
                       traffic=None, launches_per_step=dom["calls"] // nprof, avg_launch_us=round(avg_ms * 1e3, 2),
                       share_of_gpu_time=round(dom["total_ms"] / tot_ms, 3), kernel_tflops=round(tfs, 1),
                       measured=f"HIP events on the launch stream, --pair {pair_mode} (the mode of the timed region"
-                               + ("; the two sites' kernels overlap, which stretches each launch)" if pair_mode == "concurrent" else ")"))
+                               + ("; the two sites' kernels overlap, which stretches each launch" if pair_mode == "concurrent" else "")
+                               + "; the helper streams inside a site are off while launches are timed)")
             tj = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic.json")
             if os.path.isfile(tj) and args.config == "cfg2" and not args.batch and dtype == "bf16":
                 with open(tj) as fh:       # HBM bytes from THIS round's rocprofv3 --pmc passes (scripts/make_profiles.sh)
