@@ -636,8 +636,7 @@ int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
   DISPATCH_T(d.bf16, kk_prep_dBm, dim3((unsigned)(d.S * d.Kcyb)), dim3(256), 0, st, dBm, dabx, (void*)(scratch + pl.o_dBmT), d.Kcy, d.Kcyb,
              d.M, d.Mb);
   AVMOE_CHECK_LAUNCH("prep_dBm");
-  // dwbar (row Kcy of every frame's dBm), zero in the padding m >= M ; dbcbar
-  AVMOE_TRY(k_fill_f32(dvec + 2 * d.C, d.Mb + 1, 0.f, st));
+  // dwbar (row Kcy of every frame's dBm), zero in the padding m >= M (dvec lies inside the backward's one memset: moe_plan.h) ; dbcbar
   AVMOE_TRY(k_colsum_f32(dBm + (long)d.Kcy * d.Mb, d.S, d.M, (long)d.Kcyb * d.Mb, 1, 0, dvec + 2 * d.C, 0, 1.f, st));
   AVMOE_TRY(k_colsum_f32(dabx + d.Kcy, d.S, 1, d.Kcyb, 1, 0, dvec + 2 * d.C + d.Mb, 0, 1.f, st));
   return OK;

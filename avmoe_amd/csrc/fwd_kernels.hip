@@ -539,9 +539,10 @@ struct RouterArgs {
   int C2, E, S;
 };
 __global__ void __launch_bounds__(128) kk_router_tail(RouterArgs a, float* rh1, float* rh2, float* probs, float* probs_out,
-                                                      int64_t* idx_out) {
+                                                      int64_t* idx_out, float* lb_zero) {
   __shared__ float s_h1[128], s_h2[32], s_lg[MAX_E];
   const int s = blockIdx.x, t = threadIdx.x;
+  if (lb_zero && s == 0 && t == 0) *lb_zero = 0.f;          // (sites without the load-balancing loss report 0)
   {   // rh1 holds rin . W1^T (engine GEMM); add bias, ReLU, keep the activation for the backward
     const float h = fmaxf(rh1[(long)s * 128 + t] + a.b1[t], 0.f);
     s_h1[t] = h; rh1[(long)s * 128 + t] = h;
@@ -604,11 +605,10 @@ int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& p
     AVMOE_TRY(launch_gemm(g, st));
   }
   hipLaunchKernelGGL(kk_router_tail, dim3(d.S), dim3(128), 0, st, a, (float*)(saved + pl.o_rh1), (float*)(saved + pl.o_rh2),
-                     (float*)(saved + pl.o_probs), probs_out, idx_out);
+                     (float*)(saved + pl.o_probs), probs_out, idx_out, (lb_out && !d.lb_loss) ? lb_out : nullptr);
   AVMOE_CHECK_LAUNCH("router");
-  if (lb_out) {
-    if (d.lb_loss) hipLaunchKernelGGL(kk_lb_loss, dim3(1), dim3(256), 0, st, (const float*)(saved + pl.o_probs), d.S, d.E, lb_out);
-    else hipLaunchKernelGGL(kk_fill_f32, dim3(1), dim3(256), 0, st, lb_out, 1L, 0.f);
+  if (lb_out && d.lb_loss) {
+    hipLaunchKernelGGL(kk_lb_loss, dim3(1), dim3(256), 0, st, (const float*)(saved + pl.o_probs), d.S, d.E, lb_out);
     AVMOE_CHECK_LAUNCH("lb_loss");
   }
   return OK;

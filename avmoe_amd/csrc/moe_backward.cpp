@@ -333,11 +333,10 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(k_dqrqb(pl, sc, prm.conv_b, st));
     {                                                      // dQ = sum_s dR[s] Y[s]
       GemmArgs g = base();
-      g.A = sc + pl.o_dRT; g.B = Y; g.C = sc + pl.o_dQ;
+      g.A = sc + pl.o_dRT; g.B = Y; g.C = sc + pl.o_dQT; g.out_dtype = dt;      // (straight in the operand dtype of its two consumers)
       g.M = d.Kcy; g.N = d.Cy; g.K = d.S * d.M; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Kcyp; g.ldb = d.Cy; g.sCi = d.Cy;
       AVMOE_TRY(run(g, true));
     }
-    AVMOE_TRY(k_cast(d.bf16, (const float*)(sc + pl.o_dQ), d.Kcy, d.Cy, d.Cy, sc + pl.o_dQT, d.Cy, st));
     }
     if (do6b)
     {   // dY[s] = [Bm ; wbar][s]^T dV[s] + dR[s]^T Q   -- one pass over dY (two K segments)

@@ -157,6 +157,7 @@ struct Dims {
   X(dTW, 1, d.esz, (size_t)d.S * d.KLT * d.DZ)                                                  \
   X(dWcK, 1, 4, (size_t)d.N * d.Mk)                                                             \
   X(dqp, 1, 4, (size_t)2 * d.S * d.Kcyb + 2 * d.Kcyb)                                           \
+  X(dvec, 1, 4, (size_t)2 * d.C + d.Mb + 64)        /* drw, dbf, dwbar, dbcbar (the padding of dwbar stays zero) */ \
   X(dRT, 1, d.esz, (size_t)d.S * d.M * d.Kcyp)                                                  \
   X(dAp, 1, 4, (size_t)d.NT * d.g * d.KPp)          /* f32 ; T (+ dApx) on the register-resident bf16 path */ \
   X(dApx, 1, 4, d.zsz == 2 ? (size_t)d.NT * d.g * d.XW : 1)   /* the 3 E scalar columns of dApost per (token, group), fp32 */ \
@@ -191,7 +192,6 @@ struct Dims {
   X(dQ, 1, 4, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                               \
   X(dQT, 1, d.esz, (size_t)(d.Kcy ? d.Kcy : 1) * d.Cy)                                          \
   X(dWf, 1, 4, (size_t)d.C * d.Cy)                                                              \
-  X(dvec, 1, 4, (size_t)2 * d.C + d.Mb + 64)        /* drw, dbf, dwbar, dbcbar        */       \
   X(gWd, 1, 4, d.mg ? (size_t)d.E * d.d * d.C : 1)  /* merged groups: gradients of the block-diagonal copies */ \
   X(gWu, 1, 4, d.mg ? (size_t)d.E * d.C * d.d : 1)
 
