@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p, int l
 struct TokPairDev {
   const char* A1; const char* A2; const char* X; float* C2; float* slabs;
   long lda1, lda2, ldx, sA1g;
-  int M1, M2, S, N, g, Cg, tiles_n, F;
+  int M1, M2, S, N, g, Cg, tiles_n, F, TK;
 };
 template <int BM2>
 __global__ void __launch_bounds__(256, 2) gemm_tokpair_kernel(const TokPairDev p) {
@@ -562,12 +562,17 @@ __global__ void __launch_bounds__(256, 2) gemm_tokpair_kernel(const TokPairDev p
   for (int s = s0; s < s1; ++s) {
     const long t0 = (long)s * p.N;
     const char* Xb = p.X + (t0 * p.ldx + (long)gi * p.Cg) * 2;
-    gemm_segment<__bf16, 128, 128, true, true, 4, 4>(smem, p.A1 + (t0 * p.lda1 + (long)gi * p.sA1g) * 2, Xb, p.lda1, p.ldx, p.M1, p.Cg, 0, n0, 0, p.N, accW);
 #pragma unroll
     for (int i = 0; i < TM2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) accT[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_segment<__bf16, BM2, 128, true, true, TM2, 4>(smem, p.A2 + t0 * p.lda2 * 2, Xb, p.lda2, p.ldx, p.M2, p.Cg, 0, n0, 0, p.N, accT);
+    // both K loops over the same TK tokens before moving on: the second one finds its X tiles (TK x 128 channels) still in the L2
+#pragma unroll 1
+    for (int k0 = 0; k0 < p.N; k0 += p.TK) {
+      const int k1 = min(p.N, k0 + p.TK);
+      gemm_segment<__bf16, 128, 128, true, true, 4, 4>(smem, p.A1 + (t0 * p.lda1 + (long)gi * p.sA1g) * 2, Xb, p.lda1, p.ldx, p.M1, p.Cg, 0, n0, k0, k1, accW);
+      gemm_segment<__bf16, BM2, 128, true, true, TM2, 4>(smem, p.A2 + t0 * p.lda2 * 2, Xb, p.lda2, p.ldx, p.M2, p.Cg, 0, n0, k0, k1, accT);
+    }
     float* c2 = p.C2 + (long)s * p.M2 * ((long)p.g * p.Cg) + (long)gi * p.Cg;
     const int wm2 = (wave >> 1) * (BM2 / 2);
 #pragma unroll
@@ -819,6 +824,10 @@ int launch_gemm_tokpair(const TokPairArgs& a, hipStream_t stream) {
   p.A1 = (const char*)a.A1; p.A2 = (const char*)a.A2; p.X = (const char*)a.X; p.C2 = a.C2; p.slabs = a.slabs;
   p.lda1 = a.lda1; p.lda2 = a.lda2; p.ldx = a.ldx; p.sA1g = a.sA1g;
   p.M1 = a.M1; p.M2 = a.M2; p.S = a.S; p.N = a.N; p.g = a.g; p.Cg = a.Cg; p.tiles_n = tiles_n; p.F = F;
+  {
+    static const int tk = [] { const char* e = getenv("AVMOE_TOKPAIR_TK"); return e && *e ? atoi(e) : 256; }();      // dev switch (multiple of 64)
+    p.TK = tk > 0 ? (tk + 63) / 64 * 64 : a.N;
+  }
   constexpr int LDS = 2 * 2 * 64 * (128 * 2 + 16);          // two stages of the (128, 128) MN-major / MN-major segment
   const double bytes = ((double)a.S * a.N) * ((double)a.g * a.Cg + (double)a.g * a.M1 + a.M2) * 2.0 + (double)a.S * a.M2 * a.g * a.Cg * 4.0;
   const double flops = 2.0 * (double)a.S * a.N * (double)a.g * a.Cg * ((double)a.M1 + a.M2);
