@@ -128,27 +128,12 @@ __global__ void kk_prep_remap(const float* Wc, const float* bc, const float* Wf,
   }
 }
 
-// rw[c] = sum_y WfT[c][y] (T-rounded weights, so the folded bias matches the GEMM operands); one wave per row.  The block after the
-// last row block zeroes the padding of wbar (m in [M, Mb)) and leaves scal[0] = mean(bc) (fixed-order tree: reproducible).
+// rw[c] = sum_y WfT[c][y] (T-rounded weights, so the folded bias matches the GEMM operands); one wave per row
 template <typename T>
-__global__ void kk_prep_remap2(const void* WfT_, float* rw, int C, int Cy, const float* bc, int N, float* scal, float* wbar, int M, int Mb) {
+__global__ void kk_prep_remap2(const void* WfT_, float* rw, int C, int Cy) {
   const T* WfT = (const T*)WfT_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (blockIdx.x == gridDim.x - 1) {
-    __shared__ float red[256];
-    for (int m = M + threadIdx.x; m < Mb; m += 256) wbar[m] = 0.f;
-    float s = 0.f;
-    for (int n = threadIdx.x; n < N; n += 256) s += bc[n];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) scal[0] = red[0] / (float)N;
-    return;
-  }
-  for (int c = blockIdx.x * 4 + wave; c < C; c += (gridDim.x - 1) * 4) {
+  for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
     float s = 0.f;
     for (int y = lane; y < Cy; y += 64) s += ldT<T>(WfT, (long)c * Cy + y);
     s = wave_sum(s);
@@ -163,9 +148,13 @@ int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, 
   const long tot = (long)d.N * d.Mk + (long)(d.M + 1) * d.Np + (long)d.C * d.Cy;
   DISPATCH_T(d.bf16, kk_prep_remap, dim3(grid1d(tot)), dim3(256), 0, st, Wc, bc, Wf, (void*)(saved + pl.o_WcK),
              (void*)(saved + pl.o_WcT), (void*)(saved + pl.o_WfT), d.N, d.M, d.Mk, d.Np, d.C, d.Cy);
-  DISPATCH_T(d.bf16, kk_prep_remap2, dim3(cdiv(d.C, 4) + 1), dim3(256), 0, st, (const void*)(saved + pl.o_WfT), (float*)(saved + pl.o_rw), d.C, d.Cy,
-             bc, d.N, (float*)(saved + pl.o_scal), (float*)(saved + pl.o_wbar), d.M, d.Mb);      // (+ wbar's padding, scal[0] = mean(bc))
-  AVMOE_TRY(k_colsum_f32(Wc, d.N, d.M, d.M, 1, 0, (float*)(saved + pl.o_wbar), 0, 1.f / (float)d.N, st));      // wbar[m] = mean_n Wc[n][m]
+  DISPATCH_T(d.bf16, kk_prep_remap2, dim3(cdiv(d.C, 4)), dim3(256), 0, st, (const void*)(saved + pl.o_WfT), (float*)(saved + pl.o_rw), d.C, d.Cy);
+  {   // wbar[m] = mean_n Wc[n][m] (padding zero) ; scal[0] = mean(bc)
+    hipError_t e__ = hipMemsetAsync(saved + pl.o_wbar, 0, (size_t)d.Mb * 4, st);
+    if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; }
+    AVMOE_TRY(k_colsum_f32(Wc, d.N, d.M, d.M, 1, 0, (float*)(saved + pl.o_wbar), 0, 1.f / (float)d.N, st));
+    AVMOE_TRY(k_colsum_f32(bc, d.N, 1, 1, 1, 0, (float*)(saved + pl.o_scal), 0, 1.f / (float)d.N, st));
+  }
   AVMOE_CHECK_LAUNCH("prep_remap");
   return OK;
 }
