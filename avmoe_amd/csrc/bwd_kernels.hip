@@ -637,8 +637,8 @@ int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
              d.M, d.Mb);
   AVMOE_CHECK_LAUNCH("prep_dBm");
   // dwbar (row Kcy of every frame's dBm), zero in the padding m >= M (dvec lies inside the backward's one memset: moe_plan.h) ; dbcbar
-  AVMOE_TRY(k_colsum_f32(dBm + (long)d.Kcy * d.Mb, d.S, d.M, (long)d.Kcyb * d.Mb, 1, 0, dvec + 2 * d.C, 0, 1.f, st));
-  AVMOE_TRY(k_colsum_f32(dabx + d.Kcy, d.S, 1, d.Kcyb, 1, 0, dvec + 2 * d.C + d.Mb, 0, 1.f, st));
+  AVMOE_TRY(k_colsum2_f32(dBm + (long)d.Kcy * d.Mb, d.S, d.M, (long)d.Kcyb * d.Mb, dvec + 2 * d.C, 1.f,
+                          dabx + d.Kcy, d.S, 1, d.Kcyb, dvec + 2 * d.C + d.Mb, 1.f, st));
   return OK;
 }
 int k_dqrqb(const Plan& pl, char* scratch, const float* bc, hipStream_t st) {

@@ -80,6 +80,48 @@ int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, 
   AVMOE_CHECK_LAUNCH("colsum_f32");
   return OK;
 }
+// Two independent column sums of the same row-count class in ONE launch (blockIdx.y picks the job; each job runs exactly the code and
+// the summation order of kk_colsum_f32 with one slot, so the results are bit-identical to two launches).
+struct ColsumJob { const float* in; long R; int ncol; long row_stride; float* out; float scale; };
+template <int CW, int NTHR>
+__global__ void __launch_bounds__(NTHR) kk_colsum2_f32(ColsumJob j0, ColsumJob j1) {
+  constexpr int NS = NTHR / CW;
+  __shared__ double red[NS][CW];
+  const ColsumJob j = blockIdx.y == 0 ? j0 : j1;
+  const int c = threadIdx.x % CW, k = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + c;
+  if ((int)blockIdx.x * CW >= j.ncol) return;                 // (whole block past this job's columns)
+  const float* p = j.in + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < j.ncol) {
+    long r = k;
+    for (; r + 3L * NS < j.R; r += 4L * NS) {
+      a0 += p[r * j.row_stride]; a1 += p[(r + NS) * j.row_stride]; a2 += p[(r + 2L * NS) * j.row_stride]; a3 += p[(r + 3L * NS) * j.row_stride];
+    }
+    for (; r < j.R; r += NS) a0 += p[r * j.row_stride];
+  }
+  red[k][c] = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+  __syncthreads();
+  if (k == 0 && col < j.ncol) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) s += red[w][c];
+    j.out[col] = (float)(s * j.scale);
+  }
+}
+int k_colsum2_f32(const float* in0, long R0, int ncol0, long rs0, float* out0, float scale0,
+                  const float* in1, long R1, int ncol1, long rs1, float* out1, float scale1, hipStream_t st) {
+  if (ncol0 <= 0 || ncol1 <= 0 || (R0 >= 128) != (R1 >= 128)) {       // different classes (or an empty job): two launches
+    AVMOE_TRY(k_colsum_f32(in0, R0, ncol0, rs0, 1, 0, out0, 0, scale0, st));
+    return k_colsum_f32(in1, R1, ncol1, rs1, 1, 0, out1, 0, scale1, st);
+  }
+  const ColsumJob j0{in0, R0, ncol0, rs0, out0, scale0}, j1{in1, R1, ncol1, rs1, out1, scale1};
+  const int nc = std::max(ncol0, ncol1);
+  if (R0 >= 128) hipLaunchKernelGGL((kk_colsum2_f32<16, 1024>), dim3(cdiv(nc, 16), 2), dim3(1024), 0, st, j0, j1);
+  else hipLaunchKernelGGL((kk_colsum2_f32<64, 256>), dim3(cdiv(nc, 64), 2), dim3(256), 0, st, j0, j1);
+  AVMOE_CHECK_LAUNCH("colsum2_f32");
+  return OK;
+}
 int k_reduce_colpart(const Plan& pl, char* scratch, int slot0, int nslots, hipStream_t st) {
   const Dims& d = pl.d;
   return k_colsum_f32((const float*)(scratch + pl.o_colpart) + (long)slot0 * d.DZ, d.nblk_tok, d.DZ, 4L * d.DZ, nslots, d.DZ,
@@ -152,8 +194,8 @@ int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, 
   {   // wbar[m] = mean_n Wc[n][m] (padding zero) ; scal[0] = mean(bc)
     hipError_t e__ = hipMemsetAsync(saved + pl.o_wbar, 0, (size_t)d.Mb * 4, st);
     if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; }
-    AVMOE_TRY(k_colsum_f32(Wc, d.N, d.M, d.M, 1, 0, (float*)(saved + pl.o_wbar), 0, 1.f / (float)d.N, st));
-    AVMOE_TRY(k_colsum_f32(bc, d.N, 1, 1, 1, 0, (float*)(saved + pl.o_scal), 0, 1.f / (float)d.N, st));
+    AVMOE_TRY(k_colsum2_f32(Wc, d.N, d.M, d.M, (float*)(saved + pl.o_wbar), 1.f / (float)d.N,
+                            bc, d.N, 1, 1, (float*)(saved + pl.o_scal), 1.f / (float)d.N, st));
   }
   AVMOE_CHECK_LAUNCH("prep_remap");
   return OK;

@@ -218,8 +218,8 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
   }
 #undef GRAM_LAUNCH
   AVMOE_CHECK_LAUNCH("gram64");
-  if (mz) AVMOE_TRY(k_colsum_f32(colpart, used, d.DZ, d.DZ, 1, 0, mz, 0, 1.f / (float)d.NT, st));
   const int ncol = d.g * d.E * d.dgp * d.dgp;
+  if (mz) return k_colsum2_f32(colpart, used, d.DZ, d.DZ, mz, 1.f / (float)d.NT, part, used, ncol, ncol, out, scale, st);
   return k_colsum_f32(part, used, ncol, ncol, 1, 0, out, 0, scale, st);
 }
 

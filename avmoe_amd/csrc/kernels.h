@@ -96,6 +96,9 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
 // generic helpers
 int k_colsum_f32(const float* in, long R, int ncol, long row_stride, int nslot, long slot_in, float* out, long slot_out,
                  float scale, hipStream_t st);
+// two independent column sums (one slot each) in one launch when they are of the same row-count class; bit-identical to two launches
+int k_colsum2_f32(const float* in0, long R0, int ncol0, long rs0, float* out0, float scale0,
+                  const float* in1, long R1, int ncol1, long rs1, float* out1, float scale1, hipStream_t st);
 int k_reduce_colpart(const Plan& pl, char* scratch, int slot0, int nslots, hipStream_t st);   // colpart -> colsum
 int k_fill_f32(float* p, long n, float v, hipStream_t st);
 int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, void* dst, long ld_dst, hipStream_t st);
