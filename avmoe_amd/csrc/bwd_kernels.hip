@@ -418,15 +418,23 @@ __global__ void __launch_bounds__(256) kk_dqrqb_part(const void* dL1_, const flo
 // final assembly of the remap / token parameter gradients
 struct Hop1FinArgs { W16 gtok; int e_of_lat[MAX_E]; int S, N, M, Mk, Mb, C, Cy, K, Kp, KL, Kcy, Kcyb; };
 // drw[c] += sum_kc T0[kc][c] dqr[kc] ; dbf[c] += sum_kc T0[kc][c] dqb[kc]      (in place in dvec; thread per channel)
+// (a block owns 64 channels; its four waves take every fourth latent row and are combined through LDS in a fixed order)
 template <typename T>
 __global__ void __launch_bounds__(256) kk_hop1_vec(const void* T0T_, const float* dqp_fin, float* dvec, int C, int Kcy, int Kcyb) {
   const T* T0T = (const T*)T0T_;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const float* dqr = dqp_fin; const float* dqb = dqp_fin + Kcyb;
   float a0 = 0.f, a1 = 0.f;
-  for (int kc = 0; kc < Kcy; ++kc) { const float t = ldT<T>(T0T, (long)kc * C + c); a0 += t * dqr[kc]; a1 += t * dqb[kc]; }
-  dvec[c] += a0; dvec[C + c] += a1;
+  if (c < C)
+    for (int kc = part; kc < Kcy; kc += 4) { const float t = ldT<T>(T0T, (long)kc * C + c); a0 += t * dqr[kc]; a1 += t * dqb[kc]; }
+  red[0][part][cl] = a0; red[1][part][cl] = a1;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    dvec[c] += (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    dvec[C + c] += (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  }
 }
 // final assembly of the remap / token parameter gradients (pure elementwise; grid.y selects the tensor)
 template <typename T>
@@ -618,7 +626,7 @@ int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
                        (const float*)(scratch + pl.o_dtbar), (float*)(scratch + pl.o_dT0), d.S, d.KL, d.C);
   {
     const long nrows = (long)d.S * d.Kcyb;
-    const int nchunk = (int)std::min<long>(512, std::max<long>(1, nrows / 32));
+    const int nchunk = (int)std::min<long>(512, std::max<long>(1, nrows / 8));      // (short serial chains per thread: 8 rows, or nrows / 512 when there are many)
     const int rpc = cdiv(nrows, nchunk);
     DISPATCH_T(d.bf16, kk_dTy_colsums_a, dim3(cdiv(d.C, 256), nchunk), dim3(256), 0, st, (const void*)(scratch + pl.o_dTy),
                (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_scal), (float*)(scratch + pl.o_rowpart), nrows, rpc,
@@ -662,7 +670,7 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   if (big >= (1L << 31)) { set_last_error("hop1_finalize: parameter tensor too large"); return ERR_UNSUPPORTED; }
   const float* dqp_fin = (const float*)(scratch + pl.o_dqp) + 2L * d.S * d.Kcyb;
   if (d.Kcy > 0)
-    DISPATCH_T(d.bf16, kk_hop1_vec, dim3(cdiv(d.C, 256)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T), dqp_fin, (float*)(scratch + pl.o_dvec),
+    DISPATCH_T(d.bf16, kk_hop1_vec, dim3(cdiv(d.C, 64)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T), dqp_fin, (float*)(scratch + pl.o_dvec),
                d.C, d.Kcy, d.Kcyb);
   DISPATCH_T(d.bf16, kk_hop1_finalize, dim3((unsigned)cdiv(big, 256), 3), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWcK),
              (const float*)(scratch + pl.o_dWf), (const float*)(scratch + pl.o_dvec), (const float*)(scratch + pl.o_dT0), dqp_fin,
