@@ -1,6 +1,7 @@
 // Backward bottleneck-space kernels.  Every formula is the one in oracle/algebra_ref.py::AlgebraRef.backward
 // (validated there against autograd); stage names match.  Full-width tensors are only touched by GEMMs.
 #include "kernels.h"
+#include "colsum_fin.h"
 #include "moe_run.h"
 #include "device_utils.h"
 #include "prof.h"
@@ -83,10 +84,10 @@ struct MidBwdArgs {
   int relu_of_e[MAX_E]; W16 gw1, gb1;
   int S, N, E, DD, DZ, dgp, dg, g, NT, use_bn, training, nblk;
 };
-__global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* dsm) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= a.DZ) return;
-  const double s0 = colpart[2 * a.DZ + col], s1 = colpart[3 * a.DZ + col];   // block-summed (k_reduce_colpart)
+struct MidBwdFin {      // epilogue of the column sums (slots 2, 3 of the per-block partials) -- colsum_fin.h
+  MidBwdArgs a; float* dsm;
+  __device__ void operator()(int col, float cs0, float cs1) const {
+  const double s0 = cs0, s1 = cs1;
   dsm[3 * a.DZ + col] = (float)(s0 / a.NT);
   dsm[4 * a.DZ + col] = (float)(s1 / a.NT);
   const int i = col / (a.E * a.dgp), e = (col / a.dgp) % a.E, jp = col % a.dgp;
@@ -95,18 +96,16 @@ __global__ void kk_mid_bwd_finalize(MidBwdArgs a, const float* colpart, float* d
     if (a.gw1.p[e]) a.gw1.p[e][j] = (float)s1;
     if (a.gb1.p[e]) a.gb1.p[e][j] = (float)s0;
   }
-}
+  }
+};
 int k_mid_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
   MidBwdArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.relu_of_e[e] = d.relu_of_e[e]; a.gw1.p[e] = grads.e[e].bn1_w; a.gb1.p[e] = grads.e[e].bn1_b; }
   a.S = d.S; a.N = d.N; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.dg = d.dg; a.g = d.g; a.NT = d.NT;
   a.use_bn = d.use_bn; a.training = d.training; a.nblk = d.nblk_tok;
-  AVMOE_TRY(k_reduce_colpart(pl, scratch, 2, 2, st));
-  hipLaunchKernelGGL(kk_mid_bwd_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colsum),
-                     (float*)(scratch + pl.o_dsm));
-  AVMOE_CHECK_LAUNCH("mid_bwd");
-  return OK;
+  return launch_colsum_fin((const float*)(scratch + pl.o_colpart) + 2L * d.DZ, d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ,
+                           MidBwdFin{a, (float*)(scratch + pl.o_dsm)}, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 //
 // Buffers of the operand type T (float | __bf16) are passed as void* and cast inside the kernel.
 #include "kernels.h"
+#include "colsum_fin.h"
 #include "moe_run.h"
 #include "device_utils.h"
 #include "prof.h"
@@ -668,9 +669,8 @@ struct Bn1Args {
   int E, g, dg, dgp, DZ, nblk, NT, use_bn, training;
   float eps, momentum;
 };
-__global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= a.DZ) return;
+// (cs0, cs1: the two column sums of this column over all blocks -- only read in training mode)
+__device__ __forceinline__ void bn1_finalize_col(const Bn1Args& a, int col, float cs0, float cs1, float* bn1) {
   const int i = col / (a.E * a.dgp), e = (col / a.dgp) % a.E, jp = col % a.dgp;
   float mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
   if (jp < a.dg) {
@@ -679,7 +679,7 @@ __global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {
     else {
       float var;
       if (a.training) {
-        const double s0 = colpart[col], s1 = colpart[a.DZ + col];      // already summed over blocks (k_reduce_colpart)
+        const double s0 = cs0, s1 = cs1;
         const double m = s0 / a.NT;
         const double v = fmax(s1 / a.NT - m * m, 0.0);
         mean = (float)m; var = (float)v;
@@ -694,6 +694,15 @@ __global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {
   }
   bn1[col] = mean; bn1[a.DZ + col] = rstd; bn1[2 * a.DZ + col] = sc; bn1[3 * a.DZ + col] = sh;
 }
+__global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {      // eval mode / no BatchNorm: no sums needed
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.DZ) return;
+  bn1_finalize_col(a, col, 0.f, 0.f, bn1);
+}
+struct Bn1Fin {
+  Bn1Args a; float* bn1;
+  __device__ void operator()(int col, float s0, float s1) const { bn1_finalize_col(a, col, s0, s1, bn1); }
+};
 int k_bn1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   ProfScope ps_("k_bn1_finalize", 0.0, 0.0, st);
   const Dims& d = pl.d;
@@ -701,7 +710,8 @@ int k_bn1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_p
   for (int e = 0; e < MAX_E; ++e) { a.w.p[e] = prm.e[e].bn1_w; a.b.p[e] = prm.e[e].bn1_b; a.rm.p[e] = prm.e[e].bn1_rm; a.rv.p[e] = prm.e[e].bn1_rv; }
   a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.DZ = d.DZ; a.nblk = d.nblk_tok; a.NT = d.NT; a.use_bn = d.use_bn;
   a.training = d.training; a.eps = d.bn_eps; a.momentum = d.bn_momentum;
-  if (d.use_bn && d.training) AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
+  if (d.use_bn && d.training)      // the column sums over the blocks and the per-column finalize in one launch
+    return launch_colsum_fin((const float*)(scratch + pl.o_colpart), d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ, Bn1Fin{a, (float*)(saved + pl.o_bn1)}, st);
   hipLaunchKernelGGL(kk_bn1_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colsum),
                      (float*)(saved + pl.o_bn1));
   AVMOE_CHECK_LAUNCH("bn1_finalize");
