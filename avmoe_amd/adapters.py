@@ -101,6 +101,8 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None):
                              torch.cuda.current_stream(X.device).cuda_stream)
     desc.accumulate_out = 0
     capi.check(st, "avmoe_moe_forward")
+    if module.__dict__.get("_keep_saved"):                # avmoe_amd.debug.keep_saved: checker-side view of the last call's workspace
+        module.__dict__["_last_saved"] = (desc, saved)
     return out, probs, idx, lb, ((desc, keep), saved, X, Y)
 
 
@@ -194,8 +196,8 @@ class _PairFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, site_a, site_b, side, Xa, Xb, base_a, base_b, names_a, names_b, *params):
-        side, ctx.ordered = (side[0], side[1]) if isinstance(side, tuple) else (side, False)
-        """base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs)."""
+        """side: the second HIP stream (two-stream mode) or None (both sites on the caller's stream).
+        base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs)."""
         na = len(names_a)
         pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
@@ -234,26 +236,12 @@ class _PairFunction(torch.autograd.Function):
         needs_a, needs_b = ctx.needs_input_grad[9:9 + na], ctx.needs_input_grad[9 + na:]
         gba = d_a if ctx.has_base[0] else None            # out = base + adapter(...): the residual stream passes the gradient on
         gbb = d_b if ctx.has_base[1] else None
-        if ctx.side is not None and not ctx.ordered:
-            # the two backward passes run concurrently (own streams, own workspaces); each token tensor then gets its two
-            # gradients from separate buffers and ONE fused add over both tensors (avmoe_add2)
-            side, main = ctx.side, torch.cuda.current_stream(Xa.device)
-            gXa2, gXb2 = torch.empty_like(Xa), torch.empty_like(Xb)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pgb = _site_backward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb2, gXa2)
-            pga = _site_backward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb)
-            main.wait_stream(side)
-            for t_ in (gXa2, gXb2) + tuple(g_ for g_ in pgb if g_ is not None):
-                t_.record_stream(main)
-            capi.check(capi.lib().avmoe_add2(gXa.data_ptr(), gXa2.data_ptr(), gXa.numel(), gXb.data_ptr(), gXb2.data_ptr(), gXb.numel(),
-                                             capi.BF16 if gXa.dtype == torch.bfloat16 else capi.F32, main.cuda_stream), "avmoe_add2")
-            return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
-        if ctx.side is not None and ctx.ordered == "cross":
-            # Cross-ordered variant: ONE buffer per token tensor, no add.  Each site OVERWRITES its own token gradient with its dX
-            # (section 2) and ADDS its dY to the other tensor's buffer (section 16) once the other site's dX is there -- both sites run
-            # sections 1, 2 and 8 (everything but the GEMM that writes dY) without waiting for each other; only the two dY GEMMs are
-            # ordered behind the events.
+        if ctx.side is not None:
+            # Two streams, cross-ordered hand-over: ONE buffer per token tensor, no add kernel.  Each site OVERWRITES its own token
+            # gradient with its dX (section 2) and ADDS its dY to the other tensor's buffer (section 16) once the other site's dX is
+            # there -- both sites run sections 1, 2 and 8 (everything but the GEMM that writes dY) without waiting for each other; only
+            # the two dY GEMMs are ordered behind the events.  (Measured on MI355X at cfg-2, round 2: 5.79 ms per step against 5.97 for
+            # two buffers + a fused add and 6.04 / 6.06 for the variants that serialise one site's tail behind the other -- dropped.)
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -273,44 +261,8 @@ class _PairFunction(torch.autograd.Function):
                 t_.record_stream(main)
             gXa.record_stream(side); gXb.record_stream(side)
             return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
-        if ctx.side is not None:
-            # Ordered variant (AdapterPair(ordered_accumulate=True)): ONE buffer per token tensor.  The site with the smaller X runs
-            # straight through on the side stream and OVERWRITES both buffers (its dX, its dY); the other site runs the sections
-            # that touch neither buffer (avmoe_moe_backward_part, 1), waits for the small site's event, and ADDS its dX / dY in the
-            # GEMM epilogues (sections 2 and 4).  Saves the add's 1.2 GB of traffic at cfg-2 but serialises the tail of the large
-            # site behind the small one: measured 1.5 % SLOWER than the default on MI355X (6.06 vs 5.97 ms; "big" = only the large
-            # tensor accumulated in place, the small one through two buffers and an add: 6.10 ms; a high-priority side stream changes
-            # neither), kept for memory-tight callers.
-            side, main = ctx.side, torch.cuda.current_stream(Xa.device)
-            a_big = Xa.numel() >= Xb.numel()
-            small = (site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa) if a_big else \
-                    (site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb)
-            big = (site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb) if a_big else \
-                  (site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa)
-            hybrid = ctx.ordered == "big"           # only the LARGE token gradient is accumulated in place; the small one: two buffers + an add
-            g_small_own = gXb if a_big else gXa     # the small site's dX (gradient of the small tensor)
-            g_small_2 = torch.empty_like(g_small_own) if hybrid else None
-            if hybrid:
-                big = big[:8] + (g_small_2,)        # the big site's dY goes to its own buffer
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                cs = _SiteBackward(*small).run(0)
-                pg_small = cs.finish()
-                done = torch.cuda.Event()
-                done.record(side)
-            cb = _SiteBackward(*big, acc_dx=True, acc_dy=not hybrid).run(1)
-            main.wait_event(done)                       # both buffers hold the small site's gradients
-            pg_big = cb.run(6).finish()
-            for t_ in tuple(g_ for g_ in pg_small if g_ is not None) + (cs.d_out,):
-                t_.record_stream(main)
-            gXa.record_stream(side); gXb.record_stream(side)
-            if hybrid:
-                capi.check(capi.lib().avmoe_add2(g_small_own.data_ptr(), g_small_2.data_ptr(), g_small_own.numel(), None, None, 0,
-                                                 capi.BF16 if g_small_own.dtype == torch.bfloat16 else capi.F32, main.cuda_stream), "avmoe_add2")
-            pga, pgb = (pg_big, pg_small) if a_big else (pg_small, pg_big)
-            return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
-        # both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The larger
-        # tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
+        # One stream: both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The
+        # larger tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
         # larger tensor runs second
         first_b = Xa.numel() >= Xb.numel()
         def run_a(acc):
@@ -446,20 +398,29 @@ class MoEAdapter(nn.Module):
     def _site_cache(self):
         """Per-module bookkeeping that does not change from call to call (walking named_parameters / named_buffers and resolving
         state_dict keys costs ~0.25 ms per call otherwise -- at the reference's batch of 2 clips that is most of a site's step):
-        parameter names / objects, where each float buffer lives, the key -> ABI-field resolution, the BatchNorm counters.
-        `refresh()` drops it (call after adding / replacing Parameters; .to(), load_state_dict and FlatAdam keep the objects)."""
+        parameter NAMES and where each parameter / float buffer lives (owner module, attribute), the key -> ABI-field resolution,
+        the BatchNorm counters.  The tensors themselves are fetched from their owners' `_parameters` / `_buffers` on every call, so
+        a Parameter that was REPLACED (`load_state_dict(assign=True)`, `m.gate = nn.Parameter(..)`, swap-on-convert `.to()`) is
+        picked up; `refresh()` drops the cache (call after ADDING / REMOVING parameters or submodules)."""
         c = self.__dict__.get("_avmoe_cache")
         if c is None:
-            named = list(self.named_parameters())
-            names = tuple(k for k, _ in named)
-            params = [p for _, p in named]
+            owners, names = [], []                                     # (owner module, attribute) per parameter, named_parameters order
+            seen = set()
+            for mod_name, mod in self.named_modules():
+                for attr, p in mod._parameters.items():
+                    if p is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        names.append((mod_name + "." if mod_name else "") + attr)
+                        owners.append((mod, attr))
+            if tuple(names) != tuple(k for k, _ in self.named_parameters()):
+                raise capi.AvmoeError("MoEAdapter: parameter registry does not match named_parameters() (parametrized module?)")
             bufs = []                                                  # (key, owner module, attribute)
             for mod_name, mod in self.named_modules():
                 for attr, b in mod._buffers.items():
                     if b is not None and b.is_floating_point():
                         bufs.append(((mod_name + "." if mod_name else "") + attr, mod, attr))
             E_m, E_s = self.num_multimodal_experts, self.num_singlemodal_experts
-            c = dict(names=names, params=params, bufs=bufs, fill_p=cm.PtrFiller(names, E_m, E_s),
+            c = dict(names=tuple(names), owners=owners, bufs=bufs, fill_p=cm.PtrFiller(names, E_m, E_s),
                      fill_b=cm.PtrFiller([k for k, _, _ in bufs], E_m, E_s),
                      bn=[m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None])
             self.__dict__["_avmoe_cache"] = c
@@ -468,9 +429,21 @@ class MoEAdapter(nn.Module):
     def refresh(self):
         self.__dict__.pop("_avmoe_cache", None)
 
+    def __getstate__(self):
+        st = self.__dict__.copy()                                      # per-process bookkeeping does not travel (deepcopy / pickle)
+        for k in ("_avmoe_cache", "_nbt_flat", "_last_saved"):
+            st.pop(k, None)
+        return st
+
     def _param_tensors(self):
+        """{state_dict key: the Parameter CURRENTLY registered under it} (fetched from the owning modules on every call)."""
         c = self._site_cache()
-        return dict(zip(c["names"], c["params"]))
+        out = {k: m._parameters.get(a) for k, (m, a) in zip(c["names"], c["owners"])}
+        if any(v is None for v in out.values()):                       # a parameter was removed / set to None: rebuild the registry once
+            self.refresh()
+            c = self._site_cache()
+            out = {k: m._parameters[a] for k, (m, a) in zip(c["names"], c["owners"])}
+        return out
 
     def _fill_ptrs(self, params, keep=None):
         """MoePtrs of this site's parameters (in _site_cache order), float buffers and -- for the "v1" experts -- dropout draws."""
@@ -604,17 +577,12 @@ class AdapterPair(nn.Module):
     Numerically identical to calling the two sites one after the other; in the backward the gradient each token tensor
     receives from its second use is added inside the GEMM epilogues instead of by a separate accumulation kernel."""
 
-    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True, ordered_accumulate="cross"):
-        """concurrent=True runs the two sites on two HIP streams (their kernels overlap); False runs them back to back on the caller's
-        stream.  ordered_accumulate (two-stream mode): how each token tensor collects its two gradients --
-          "cross" (default): one buffer per tensor; each site overwrites its own tokens' gradient with its dX and, after an event,
-                  ADDS its dY to the other tensor in the GEMM epilogue; nobody waits before the last section (measured on MI355X,
-                  cfg-2: 5.79 ms per step against 5.97 for False, 6.04 for True, 6.06 for "big");
-          False:  two buffers per tensor and one fused add at the end;
-          True:   the small site runs straight through, the large one adds both its gradients behind an event;
-          "big":  as True for the large tensor only, the small one through two buffers and an add."""
+    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True):
+        """concurrent=True runs the two sites on two HIP streams (their kernels overlap; each token tensor collects its two gradients
+        in ONE buffer: a site overwrites its own tokens' gradient with its dX and, behind an event, adds its dY to the other tensor in
+        the GEMM epilogue -- nobody waits before the last section); False runs them back to back on the caller's stream."""
         super().__init__()
-        self.concurrent, self._side, self.ordered_accumulate = bool(concurrent), None, ordered_accumulate
+        self.concurrent, self._side = bool(concurrent), None
         for m in (site_a, site_b):
             if m.variant not in ("ave", "avqa"):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
@@ -633,7 +601,7 @@ class AdapterPair(nn.Module):
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
-        side = ((self._side, self.ordered_accumulate) if self.ordered_accumulate else self._side) if self.concurrent else None
+        side = self._side if self.concurrent else None
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())

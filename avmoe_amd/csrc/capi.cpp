@@ -74,6 +74,9 @@ int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const voi
   if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads || parts < 0 || parts > 31) {
     set_last_error("avmoe_moe_backward_part: null pointer or parts not in 0..31"); return ERR_BAD_ARG;
   }
+  if ((parts & 4) && (parts & 24)) {        // 4 IS sections 8 + 16: asking for both would run the hop-1 chain twice into the same accumulators
+    set_last_error("avmoe_moe_backward_part: parts %d combines section 4 with its halves 8 / 16", parts); return ERR_BAD_ARG;
+  }
   return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream, parts);
 }
 

@@ -44,6 +44,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   //   section 1: dBpost = dOut^T Apost (+ its split-K reduce; the only user of the slabs until the join) beside dApost -> post_small_bwd -> Gram
   //   section 2: the dX GEMM (nothing in this call reads dX) beside the dWt / dT chain
   Side* side = side_worth(d) ? side_acquire(st) : nullptr;
+  SideScope fk1(side, st), fk2(side, st);                  // joined on every way out (error returns included)
   const size_t esz = d.esz;
   if (parts & 1) {   // =============================== section 1: phases 1 - 4 ===============================
   // the accumulators that start from zero (dtbp, dTW, dWcK, dqp, dRT) are adjacent in the plan: one memset instead of five
@@ -56,7 +57,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
     g.M = d.Cg; g.N = d.KP; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = (long)d.g * d.KPp; g.nb2 = d.g;
     g.sA2 = d.Cg; g.sB2 = d.KPp; g.sCi = d.KPp; g.sC2 = (long)d.Cg * d.KPp;
-    if (fork1) AVMOE_TRY(side_fork(side, st));
+    if (fork1) AVMOE_TRY(fk1.fork());
     AVMOE_TRY(run_on(g, true, fork1 ? side->s : st));
   }
   int dap16 = 0;     // dApost stored as [E x 32 bottleneck columns in T | 3 E scalar columns in fp32 (dApx)]: the register-resident bf16 path
@@ -89,7 +90,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.nb2 = d.g * d.E; g.sA2 = g.sB2 = d.dgp; g.sCi = d.dgp; g.sC2 = (long)d.dgp * d.dgp;
     AVMOE_TRY(run(g, true));
   }
-  if (fork1) AVMOE_TRY(side_join(side, st));
+  if (fork1) AVMOE_TRY(fk1.join());
   AVMOE_TRY(k_post_prep_bwd(pl, sv, sc, prm, grads, st));
   // ---- phase 3: ReLU / BN1 ; router --------------------------------------------------------------
   AVMOE_TRY(k_mid_bwd(pl, sv, sc, prm, grads, st));
@@ -113,7 +114,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
     g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
     g.accumulate = d.acc_dx;
-    if (fork2) AVMOE_TRY(side_fork(side, st));
+    if (fork2) AVMOE_TRY(fk2.fork());
     AVMOE_TRY(run_on(g, false, fork2 ? side->s : st));
   }
   if (d.mha) {   // ---- AVS "v1": per expert back through ZR = xr Wt_e^T, the row sums and xr = MHA_e(X) - X -------------------
@@ -269,7 +270,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_finish_dT(pl, sv, sc, st));                  // + dtbar / C ; dTy (T, with the dm2 row) ; dTx ; dT0 ; drw, dbf
   AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
   if (d.mg) AVMOE_TRY(k_merge_gather(pl, sc, grads_in, st));   // diagonal blocks of the dense weight gradients -> the caller's grouped ones
-  if (fork2) AVMOE_TRY(side_join(side, st));
+  if (fork2) AVMOE_TRY(fk2.join());
   }
   // ======================= section 3: phase 6 (4 = all of it; 8 = everything but the writers of dY; 16 = the writers of dY) ==========
   const bool do6a = (parts & (4 | 8)) != 0, do6b = (parts & (4 | 16)) != 0;

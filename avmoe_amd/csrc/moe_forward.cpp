@@ -67,8 +67,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
                         1.f / (float)d.N, xs);
   };
   Side* side = (d.fuse_xs && (side_mask() & 1) && side_worth(d)) ? side_acquire(st) : nullptr;
+  SideScope fk(side, st);
   if (side) {
-    AVMOE_TRY(side_fork(side, st));
+    AVMOE_TRY(fk.fork());
     AVMOE_TRY(fused_down(side->s));
   }
 
@@ -164,7 +165,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   AVMOE_TRY(down_gemm(sv + pl.o_Text, (long)d.S * d.KLT, sv + pl.o_TW));   // TW (all latent rows x all experts)
   // ---- the X-side GEMMs ------------------------------------------------------------------------
   if (d.fuse_xs) {
-    if (side) AVMOE_TRY(side_join(side, st));
+    if (side) AVMOE_TRY(fk.join());
     else AVMOE_TRY(fused_down(st));
   } else {
     AVMOE_TRY(down_gemm(X, d.NT, sv + pl.o_Z, d.zsz == 2 ? GEMM_BF16 : GEMM_F32));                              // Zx = X Wt^T

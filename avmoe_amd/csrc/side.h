@@ -14,4 +14,16 @@ int side_mask();                           // dev: AVMOE_SIDE_MASK selects the f
 int side_fork(Side* sd, hipStream_t st);   // status codes of common.h
 int side_join(Side* sd, hipStream_t st);
 
+// A fork that is joined on EVERY way out of its scope: an error return between fork and join must not leave the helper stream
+// writing into the caller's workspaces after the call has returned (the caller may free or reuse them on its own stream).
+struct SideScope {
+  Side* sd; hipStream_t st; bool open = false;
+  SideScope(Side* sd_, hipStream_t st_) : sd(sd_), st(st_) {}
+  SideScope(const SideScope&) = delete;
+  SideScope& operator=(const SideScope&) = delete;
+  int fork() { const int r = side_fork(sd, st); open = (r == 0); return r; }
+  int join() { open = false; return side_join(sd, st); }
+  ~SideScope() { if (open) (void)side_join(sd, st); }
+};
+
 }  // namespace avmoe

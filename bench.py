@@ -20,8 +20,13 @@ The JSON line also carries
   roofline      PATH level: algorithmic bytes per clip-pair x clip-pairs/s vs the 8 TB/s HBM peak (`frac`), the
                 reference-formulation FLOPs vs the dense MFMA peak beside it (`mfma`), and the dominant kernel family of a
                 HIP-event profiling pass over the same step in the same execution mode as the timed region (`dominant_kernel`)
-  parity        max errors of this very build against oracle/avmoe_oracle.py at the benchmarked shapes with B = 2 clips
-                (fp32: outputs / gradients, router indices; bf16 the same against the oracle on bf16-rounded inputs)
+  parity        max errors of this very build against oracle/avmoe_oracle.py at the benchmarked shapes with B = 2 clips, run the
+                way the timed region runs it (AdapterPair in the same --pair mode): fp32 outputs / gradients / router indices,
+                bf16 the same against the oracle on bf16-rounded inputs.  Gradients are compared KINK-AWARE: the oracle is
+                re-run with the ReLU mask the HIP path actually used (avmoe_amd.debug.relu_masks), so units whose
+                pre-activation lies within rounding of zero sit on the same side in both; the plain comparison is reported too
+  other_configs (N = 1) 3 timed steps each of cfg-4 and cfg-5 after the cfg-2 region, with their own ms_per_step, path-level
+                roofline fraction and kink-aware parity
   value_f32     the same step in fp32 (the configuration held to the 1e-3 bar)
   cpu_baseline  oracle/avmoe_oracle.py (eager PyTorch, fp32) timed on this box's host cores on a bounded
                 sample of the same workload (same shapes, B=2 clips), rank 0 at N=1 only
@@ -43,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
-ROUND = "r02"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
+ROUND = "r03"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
 
 # ---- workloads --------------------------------------------------------------------------------
 # a site pair: (C_a, N_a, C_v, N_v, count) -- `count` identical pairs (block pairs of the stage x positions p1, p2)
@@ -152,9 +157,9 @@ def _oracle_cfgs(c, shape):
     return O.AdapterConfig(Cx=Ca, Nx=Na, Cy=Cv, Ny=Nv, **kw), O.AdapterConfig(Cx=Cv, Nx=Nv, Cy=Ca, Ny=Na, **kw)
 
 
-def cpu_baseline(c, budget_s=15.0):
+def cpu_baseline(c, budget_s=15.0, min_timed=3):
     """Eager-PyTorch fp32 oracle on the host cores, same shapes at B=2: 1 warm-up, then timed steps until ~budget_s of
-    CPU work (3 .. 8 of them); the median is reported.  Returns (json object, the inputs / parameters / results of the last
+    CPU work (min_timed .. 8 of them); the median is reported.  Returns (json object, the inputs / parameters / results of the last
     step: parity_check compares the HIP path with them)."""
     import torch
     from oracle import avmoe_oracle as O
@@ -186,7 +191,7 @@ def cpu_baseline(c, budget_s=15.0):
         dt = sum(w["dt"] * w["cnt"] for w in work)
         if it > 0:
             times.append(dt)
-        if time.time() - t_start > budget_s and len(times) >= 3:
+        if time.time() - t_start > budget_s and len(times) >= min_timed:
             break
     med = statistics.median(times)
     obj = dict(value=Bc / med, unit="clip-pairs/s", cores=cores, host_cores=os.cpu_count(), kind="port", dtype="f32", clips=Bc,
@@ -197,89 +202,147 @@ def cpu_baseline(c, budget_s=15.0):
     return obj, (work, lbw)
 
 
-def parity_check(c, material, device):
-    """This build against the oracle at the benchmarked shapes, B = 2 clips, through the C ABI behind the module API.
-    fp32: outputs max-abs relative to the tensor's max, indices bit-exact, gradients norm-wise per tensor (+ d X row by row).
-    bf16: against the oracle evaluated on the bf16-rounded inputs; outputs max-abs relative, gradients norm-wise relative
-    (worst over the tensors whose norm is at least 1e-3 of the largest gradient norm)."""
+def parity_check(c, material, device, pair_mode="concurrent"):
+    """This build against the oracle at the benchmarked shapes, B = 2 clips, through the C ABI behind the module API -- the two
+    sites of a pair run the way the timed region runs them (AdapterPair in `pair_mode` for the AVE / AVQA signatures, two module
+    calls otherwise), so each token tensor's gradient is the sum of its dX from one site and its dY from the other.
+    fp32: outputs max-abs relative to the tensor's max, indices bit-exact, gradients norm-wise per tensor (+ token rows of the
+    audio gradient one by one).  bf16: against the oracle evaluated on the bf16-rounded inputs.
+    Kink-aware: at these sizes (10^5 .. 10^6 ReLU units per cross-modal expert) a few pre-activations lie within rounding of zero
+    in ANY draw; there the mask -- and with it that token's gradient row and ~1/sqrt(tokens) of every sum over tokens -- is decided
+    by rounding, in the oracle as much as here.  The HIP path's own mask is read back (avmoe_amd.debug.relu_masks), the oracle is
+    re-run with `relu(z)` replaced by `z * mask` (identical wherever mask == z > 0) and the gradients are compared with THAT run:
+    `grad_rel_f32` / `grad_relnorm_bf16_same_mask`.  `relu_units_flipped` counts the units where the two masks differ and
+    `flipped_preact_max_rel` is the largest |pre-activation| among them relative to the rms pre-activation (rounding-sized, or
+    there is a bug); the comparison against the oracle's own mask stays in the line as `grad_rel_f32_own_mask` / `grad_relnorm_bf16`."""
     import torch
     from oracle import avmoe_oracle as O
+    from avmoe_amd.adapters import AdapterPair
+    from avmoe_amd import debug as dbg
     work, lbw = material
-    res = dict(clips=2, idx_equal=True, out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None,
-               measures="out_*: max-abs / max ; grad_rel_f32, grad_relnorm_bf16: norm-wise per tensor, worst tensor (floor 1e-3 of the largest gradient "
-                        "norm) ; dx_rows_above_1e-3: token rows of d X (fp32) whose max-abs error exceeds 1e-3 of max |d X| -- ReLU units within fp32 "
-                        "rounding of zero")
+    can_pair = c["variant"] in ("ave", "avqa") and pair_mode != "off"
+    res = dict(clips=2, path=(f"AdapterPair(--pair {pair_mode})" if can_pair else "two module calls"), idx_equal=True,
+               out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, grad_rel_f32_own_mask=0.0, worst_f32_own_mask=None,
+               relu_units=0, relu_units_flipped=0, flipped_preact_max_rel=0.0,
+               out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None, grad_relnorm_bf16_same_mask=None, worst_bf16_same_mask=None,
+               dx_rows=0, **{"dx_rows_above_1e-3": 0}, dx_row_maxabs_f32=0.0,
+               measures="out_*: max-abs / max ; grad_*: norm-wise per tensor, worst tensor (floor 1e-3 of the largest gradient norm) ; "
+                        "grad_rel_f32, *_same_mask, dx_rows*: against the oracle run with the HIP path's ReLU mask (kink-aware) ; "
+                        "*_own_mask, grad_relnorm_bf16: against the oracle's own mask ; dx_rows_above_1e-3: token rows of the audio-token "
+                        "gradient (fp32) whose max-abs error exceeds 1e-3 of its max")
     detail = [] if os.environ.get("AVMOE_PARITY_DETAIL") else None          # dev: per-tensor errors to stderr
 
-    def hip(cfg, P, B, X, Y, G, bf16):
-        m = new_site(c, cfg.Cx, cfg.Nx, cfg.Cy, cfg.Ny)
-        m.load_state_dict({**P, **B})
-        m.to(device).train()
+    def hip(w, bf16, Ga, Gv):
+        """both sites of the pair on the HIP path -> (out_a, out_v, idx_a, idx_v, grads_a, grads_v, token grads, masks_a, masks_v)"""
+        ca, cv = w["ca"], w["cv"]
+        ma, mv = new_site(c, ca.Cx, ca.Nx, ca.Cy, ca.Ny), new_site(c, cv.Cx, cv.Nx, cv.Cy, cv.Ny)
+        ma.load_state_dict({**w["Pa"], **w["Ba"]}); mv.load_state_dict({**w["Pv"], **w["Bv"]})
+        for m in (ma, mv):
+            m.to(device).train()
+            dbg.keep_saved(m)
         tdt = torch.bfloat16 if bf16 else torch.float32
-        Xd, Yd = X.to(device, tdt).requires_grad_(True), Y.to(device, tdt).requires_grad_(True)
-        x4, y4 = Xd.permute(0, 2, 1).unsqueeze(-1), Yd.permute(0, 2, 1).unsqueeze(-1)
-        lb = None
-        if c["variant"] == "avs":
-            out, idx, _p, lb = m(x4, y4, is_training=False)
+        fa, fv = w["fa"].to(device, tdt).requires_grad_(True), w["fv"].to(device, tdt).requires_grad_(True)
+        xa, xv = fa.permute(0, 2, 1).unsqueeze(-1), fv.permute(0, 2, 1).unsqueeze(-1)
+        lbs, idx_a, idx_v = [], None, None
+        if can_pair:
+            out_a, idx_a, out_v, idx_v = AdapterPair(ma, mv, concurrent=(pair_mode != "serial"))(xa, xv)
+        elif c["variant"] == "avs":
+            out_a, idx_a, _p, lb_a = ma(xa, xv, is_training=False)
+            out_v, idx_v, _p, lb_v = mv(xv, xa, is_training=False)
+            lbs = [lb_a, lb_v]
         elif c["variant"] == "avvp":
-            out, lb = m(x4, y4)
-            idx = None
+            (out_a, lb_a), (out_v, lb_v) = ma(xa, xv), mv(xv, xa)
+            lbs = [lb_a, lb_v]
         else:
-            out, idx = m(x4, y4)
-        out_tm = out.squeeze(-1).permute(0, 2, 1)
-        loss = (out_tm.float() * G.to(device)).sum()
-        if torch.is_tensor(lb) and lbw:
-            loss = loss + lbw * lb
+            (out_a, idx_a), (out_v, idx_v) = ma(xa, xv), mv(xv, xa)
+        ota, otv = out_a.squeeze(-1).permute(0, 2, 1), out_v.squeeze(-1).permute(0, 2, 1)
+        loss = (ota.float() * Ga.to(device)).sum() + (otv.float() * Gv.to(device)).sum()
+        for lb in lbs:
+            if torch.is_tensor(lb) and lbw:
+                loss = loss + lbw * lb
         loss.backward()
         torch.cuda.synchronize()
-        grads = {k: p.grad.float().cpu() for k, p in m.named_parameters()}
-        grads["X"], grads["Y"] = Xd.grad.float().cpu(), Yd.grad.float().cpu()
-        return out_tm.detach().float().cpu(), (idx.reshape(-1).cpu() if idx is not None else None), grads
+        ga = {k: p.grad.float().cpu() for k, p in ma.named_parameters()}
+        gv = {k: p.grad.float().cpu() for k, p in mv.named_parameters()}
+        tok = dict(fa=fa.grad.float().cpu(), fv=fv.grad.float().cpu())
+        flat = lambda i: i.reshape(-1).cpu() if i is not None else None
+        return (ota.detach().float().cpu(), otv.detach().float().cpu(), flat(idx_a), flat(idx_v), ga, gv, tok, dbg.relu_masks(ma), dbg.relu_masks(mv))
+
+    def oracle(w, fa, fv, Ga, Gv, masks=(None, None), recs=(None, None)):
+        ra = O.moe_forward_backward(w["Pa"], w["Ba"], fa, fv, w["ca"], Ga, training=True, lb_weight=lbw, relu_masks=masks[0], record=recs[0])
+        rv = O.moe_forward_backward(w["Pv"], w["Bv"], fv, fa, w["cv"], Gv, training=True, lb_weight=lbw, relu_masks=masks[1], record=recs[1])
+        return ra, rv
+
+    def grad_items(got, ra, rv):
+        """(tag, key, HIP tensor, oracle tensor) over both sites' parameters and the two (summed) token gradients"""
+        ga, gv, tok = got
+        items = [("a", k, ga[k], v) for k, v in ra[1].items() if k not in ("X", "Y")]
+        items += [("v", k, gv[k], v) for k, v in rv[1].items() if k not in ("X", "Y")]
+        items += [("tok", "f_a", tok["fa"], ra[1]["X"] + rv[1]["Y"]), ("tok", "f_v", tok["fv"], rv[1]["X"] + ra[1]["Y"])]
+        return items
+
+    def worst(items, floor_rel=1e-3, skip_small=False):
+        nmax = max(float(v.norm()) for _t, _k, _g, v in items)
+        e_w, k_w = 0.0, None
+        for tag, k, g, v in items:
+            if skip_small and float(v.norm()) < floor_rel * nmax:
+                continue
+            e = float((g - v).norm()) / max(float(v.norm()), floor_rel * nmax)
+            if detail is not None:
+                detail.append((tag, k, e))
+            if e > e_w:
+                e_w, k_w = e, f"{k} ({tag})"
+        return e_w, k_w
+
+    def upd(key_e, key_w, e, k):
+        if e > (res[key_e] or 0.0):
+            res[key_e], res[key_w] = e, k
 
     for w in work:
-        for cfg, P, B, X, Y, G, ref in ((w["ca"], w["Pa"], w["Ba"], w["fa"], w["fv"], w["ga"], w["ra"]),
-                                        (w["cv"], w["Pv"], w["Bv"], w["fv"], w["fa"], w["gv"], w["rv"])):
-            fwd, grads = ref
-            out, idx, got = hip(cfg, P, B, X, Y, G, False)
-            if idx is not None:
-                res["idx_equal"] = res["idx_equal"] and bool(torch.equal(idx, fwd["idx"]))
-            res["out_rel_f32"] = max(res["out_rel_f32"], float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()))
-            # Gradients.  At these sizes (10^5 .. 10^6 ReLU units per cross-modal expert) a few pre-activations lie within fp32 rounding of
-            # zero in ANY draw; there the mask -- and with it that token's gradient row and ~1/sqrt(tokens) of every sum over tokens -- is
-            # decided by rounding, in the oracle as much as here (measured: one unit at |y| = 1.8e-9 moves d X by 12 % of its maximum in
-            # ONE of 5120 rows, fp32 oracle vs fp64 oracle; the parity tests skip such draws).  So: every tensor norm-wise, d X also row by
-            # row against the 1e-3 bar, with the number of rows that miss it.
-            nmax = max(float(v.norm()) for v in grads.values())
-            for k, v in grads.items():
-                e = float((got[k] - v).norm()) / max(float(v.norm()), 1e-3 * nmax)
-                if detail is not None:
-                    detail.append((f"{cfg.Cx}x{cfg.Nx}", k, e))
-                if e > res["grad_rel_f32"]:
-                    res["grad_rel_f32"], res["worst_f32"] = e, f"{k} (C={cfg.Cx}, N={cfg.Nx})"
-            row_err = (got["X"] - grads["X"]).abs().amax(-1) / grads["X"].abs().max()
-            res["dx_rows"] = res.get("dx_rows", 0) + row_err.numel()
-            res["dx_rows_above_1e-3"] = res.get("dx_rows_above_1e-3", 0) + int((row_err > 1e-3).sum())
-            ok_rows = row_err[row_err <= 1e-3]
-            res["dx_row_maxabs_f32"] = max(res.get("dx_row_maxabs_f32", 0.0), float(ok_rows.max()) if ok_rows.numel() else 0.0)
-            if c["dtype"] == "bf16":
-                Xb, Yb, Gb = X.bfloat16().float(), Y.bfloat16().float(), G.bfloat16().float()
-                fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw)
-                out, idx, got = hip(cfg, P, B, X, Y, Gb, True)
-                if idx is not None:
-                    res["idx_equal"] = res["idx_equal"] and bool(torch.equal(idx, fwd["idx"]))
-                res["out_rel_bf16"] = max(res["out_rel_bf16"] or 0.0, float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()))
-                nmax = max(float(v.norm()) for v in grads.values())
-                for k, v in grads.items():
-                    if float(v.norm()) >= 1e-3 * nmax:
-                        e = float((got[k] - v).norm() / v.norm())
-                        if e > (res["grad_relnorm_bf16"] or 0.0):
-                            res["grad_relnorm_bf16"], res["worst_bf16"] = e, k
-    for k in ("out_rel_f32", "grad_rel_f32", "out_rel_bf16", "grad_relnorm_bf16", "dx_row_maxabs_f32"):
+        shape_tag = f"C_a={w['ca'].Cx},N_a={w['ca'].Nx}"
+        for bf16 in ([False, True] if c["dtype"] == "bf16" else [False]):
+            if bf16:
+                fa, fv, Ga, Gv = (t.bfloat16().float() for t in (w["fa"], w["fv"], w["ga"], w["gv"]))
+                ra, rv = oracle(w, fa, fv, Ga, Gv)
+            else:
+                fa, fv, Ga, Gv = w["fa"], w["fv"], w["ga"], w["gv"]
+                ra, rv = w["ra"], w["rv"]                       # the CPU-baseline leg's last step: the oracle on its own mask
+            oa, ov, ia, iv, ga, gv, tok, mka, mkv = hip(w, bf16, Ga, Gv)
+            for i_h, r in ((ia, ra), (iv, rv)):
+                if i_h is not None:
+                    res["idx_equal"] = res["idx_equal"] and bool(torch.equal(i_h, r[0]["idx"]))
+            e_out = max(float((oa - ra[0]["out"]).abs().max() / ra[0]["out"].abs().max()), float((ov - rv[0]["out"]).abs().max() / rv[0]["out"].abs().max()))
+            reca, recv = {}, {}
+            sa, sv = oracle(w, fa, fv, Ga, Gv, masks=(mka, mkv), recs=(reca, recv))      # the oracle on the HIP path's mask
+            e_own, k_own = worst(grad_items((ga, gv, tok), ra, rv), skip_small=bf16)
+            e_same, k_same = worst(grad_items((ga, gv, tok), sa, sv), skip_small=bf16)
+            if not bf16:
+                res["out_rel_f32"] = max(res["out_rel_f32"], e_out)
+                upd("grad_rel_f32", "worst_f32", e_same, f"{k_same} [{shape_tag}]")
+                upd("grad_rel_f32_own_mask", "worst_f32_own_mask", e_own, f"{k_own} [{shape_tag}]")
+                for rec, mk in ((reca, mka), (recv, mkv)):
+                    for pre, z in rec.items():
+                        flip = mk[pre] != (z > 0)
+                        res["relu_units"] += z.numel()
+                        res["relu_units_flipped"] += int(flip.sum())
+                        if bool(flip.any()):
+                            res["flipped_preact_max_rel"] = max(res["flipped_preact_max_rel"], float(z[flip].abs().max() / z.pow(2).mean().sqrt()))
+                ref_fa = sa[1]["X"] + sv[1]["Y"]
+                row_err = (tok["fa"] - ref_fa).abs().amax(-1) / ref_fa.abs().max()
+                res["dx_rows"] += row_err.numel()
+                res["dx_rows_above_1e-3"] += int((row_err > 1e-3).sum())
+                res["dx_row_maxabs_f32"] = max(res["dx_row_maxabs_f32"], float(row_err.max()))
+            else:
+                res["out_rel_bf16"] = max(res["out_rel_bf16"] or 0.0, e_out)
+                upd("grad_relnorm_bf16", "worst_bf16", e_own, f"{k_own} [{shape_tag}]")
+                upd("grad_relnorm_bf16_same_mask", "worst_bf16_same_mask", e_same, f"{k_same} [{shape_tag}]")
+    for k in ("out_rel_f32", "grad_rel_f32", "grad_rel_f32_own_mask", "flipped_preact_max_rel", "out_rel_bf16", "grad_relnorm_bf16",
+              "grad_relnorm_bf16_same_mask", "dx_row_maxabs_f32"):
         if res.get(k) is not None:
             res[k] = float(f"{res[k]:.3e}")
     if detail:
         for row in sorted(detail, key=lambda r: -r[2])[:25]:
-            print("parity f32 %-12s %-46s err %.3e" % row[:3], file=sys.stderr)
+            print("parity %-4s %-46s err %.3e" % row[:3], file=sys.stderr)
     res["checked_against"] = "oracle/avmoe_oracle.py (pinned on the reference's vectors: tests/test_oracle_golden.py)"
     return res
 
@@ -296,6 +359,134 @@ def self_launch(args, argv):
     raise SystemExit(proc.returncode)
 
 
+class Workload:
+    """Modules + resident inputs + the step function of one configuration on this rank's GPU."""
+
+    def __init__(self, c, tdt, device, rank, world, pair_mode):
+        import torch
+        from avmoe_amd.dp import AdapterGradReducer
+        from avmoe_amd.adapters import AdapterPair
+        self.c, self.world, self.device = c, world, device
+        self.can_pair = c["variant"] in ("ave", "avqa")
+        self.pair_mode = pair_mode if self.can_pair else "off"
+        S = c["B"] * c["T"]
+        self.lbw = 0.01 if c["variant"] in ("avvp", "avs") else 0.0
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.work, sites = [], []
+        for i, (Ca, Na, Cv, Nv, cnt) in enumerate(c["pairs"]):      # the `cnt` pairs of a shape share the inputs, not the modules
+            f_a = (0.3 * torch.randn(S, Na, Ca, generator=g)).to(device, tdt).requires_grad_(True)
+            f_v = (0.3 * torch.randn(S, Nv, Cv, generator=g)).to(device, tdt).requires_grad_(True)
+            g_a = torch.randn(S, Na, Ca, generator=g).to(device, tdt)
+            g_v = torch.randn(S, Nv, Cv, generator=g).to(device, tdt)
+            mods = []
+            for j in range(cnt):
+                a, v = build_pair(c, (Ca, Na, Cv, Nv), device, seed=100 * i + j)
+                mods.append((a, v, AdapterPair(a, v, concurrent=(self.pair_mode != "serial")) if self.can_pair else None))
+                sites += [a, v]
+            self.work.append(dict(f_a=f_a, f_v=f_v, ga4=g_a.permute(0, 2, 1).unsqueeze(-1), gv4=g_v.permute(0, 2, 1).unsqueeze(-1), mods=mods))
+        params = [p for m in sites for p in m.parameters()]
+        self.reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=sites)
+
+    def step(self, sync=True):
+        import torch
+        c, reducer = self.c, self.reducer
+        reducer.begin(sync=sync)
+        for w in self.work:
+            xa, xv = w["f_a"].permute(0, 2, 1).unsqueeze(-1), w["f_v"].permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
+            for a, v, pr in w["mods"]:
+                extra = []
+                if self.pair_mode != "off" and pr is not None:
+                    out_a, _, out_v, _ = pr(xa, xv)          # net_trans_v3.py:695-698 as one autograd node (AdapterPair)
+                elif c["variant"] == "avs":
+                    out_a, _, _, lb_a = a(xa, xv, is_training=True)
+                    out_v, _, _, lb_v = v(xv, xa, is_training=True)
+                    extra = [self.lbw * (lb_a + lb_v)]
+                elif c["variant"] == "avvp":
+                    out_a, lb_a = a(xa, xv)
+                    out_v, lb_v = v(xv, xa)
+                    extra = [lb_a + lb_v]
+                else:
+                    out_a, _ = a(xa, xv)                   # net_trans_v3.py:695
+                    out_v, _ = v(xv, xa)                   # net_trans_v3.py:697
+                torch.autograd.backward([out_a, out_v] + extra, [w["ga4"], w["gv4"]] + [None] * len(extra))
+            w["f_a"].grad = None
+            w["f_v"].grad = None
+        reducer.finish()
+        reducer.zero_grad()
+
+    def timed(self, steps, warmup):
+        """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over the ranks."""
+        import torch
+        import torch.distributed as dist
+
+        def barrier():
+            if self.world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], device=self.device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def release(self):
+        import torch
+        from avmoe_amd.adapters import release_workspaces
+        self.work, self.reducer = None, None
+        gc.collect()
+        release_workspaces()
+        torch.cuda.empty_cache()
+
+
+def path_roofline(c, esz, dtype, value, world):
+    abytes, rflops = algorithmic_bytes_per_clip_pair(c, esz), reference_flops_per_clip_pair(c)
+    path_gbs = abytes * value / world / 1e9
+    path_tfs = rflops * value / world / 1e12
+    return dict(bound="hbm", achieved=round(path_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(path_gbs / HBM_PEAK_GBS, 4), traffic=None,
+                level="path (SURVEY 8d): algorithmic bytes per clip-pair x clip-pairs/s per GPU",
+                algorithmic_bytes_per_clip_pair=round(abytes), algorithmic_bytes_per_step=round(abytes * c["B"]),
+                mfma=dict(achieved=round(path_tfs, 1), peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s", frac=round(path_tfs / MFMA_PEAK_TF[dtype], 4),
+                          reference_flops_per_clip_pair=round(rflops),
+                          note="FLOPs of the reference's formulation (SURVEY 8d); the factorised path executes fewer"))
+
+
+def other_config_line(name, device, pair_mode, steps=3, warmup=2):
+    """One of the multi-site configurations on the driver's line: `steps` timed steps (bf16, the configuration's own batch), the
+    path-level roofline fraction, and the kink-aware parity of its site shapes against the oracle at B = 2."""
+    import torch
+    c = dict(CONFIGS[name], name=name)
+    wl = Workload(c, torch.bfloat16 if c["dtype"] == "bf16" else torch.float32, device, 0, 1, pair_mode)
+    dt = wl.timed(steps, warmup)
+    wl.release()
+    value = c["B"] / (dt / steps)
+    esz = 2 if c["dtype"] == "bf16" else 4
+    rl = path_roofline(c, esz, c["dtype"], value, 1)
+    cpu, material = cpu_baseline(c, budget_s=0.0, min_timed=1)
+    parity = parity_check(c, material, device, pair_mode)
+    return dict(workload=f"{name}: {c['what']}", value=round(value, 2), unit="clip-pairs/s", ms_per_step=round(1e3 * dt / steps, 3), steps=steps,
+                warmup=warmup, dtype=c["dtype"], clips_per_gpu=c["B"], site_pairs=sum(p[4] for p in c["pairs"]),
+                roofline=dict(bound="hbm", frac=rl["frac"], achieved=rl["achieved"], peak=rl["peak"], unit="GB/s",
+                              algorithmic_bytes_per_step=rl["algorithmic_bytes_per_step"], level=rl["level"]),
+                parity=parity, cpu_baseline=dict(value=cpu["value"], unit=cpu["unit"], cores=cpu["cores"], kind=cpu["kind"], sample=cpu["sample"]))
+
+
+def lib_stamp():
+    """digest of the sources the loaded library was built from (avmoe_amd/build.py)"""
+    try:
+        with open(os.path.join(ROOT, "avmoe_amd", "lib", "libavmoe_hip.stamp")) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,8 +499,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skips the fp32 re-run (value_f32)")
-    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off", "ordered", "hybrid", "twobuf"],
-                    help="how the two sites of a layer are run: AdapterPair on two streams (its default gradient hand-over) / on one stream / two separate calls; ordered | hybrid | twobuf: the other two-stream hand-overs (dev)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skips the cfg-4 / cfg-5 legs of the default (cfg-2, N = 1) run")
+    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off"],
+                    help="how the two sites of a layer are run: AdapterPair on two streams / on one stream / two separate calls")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])
@@ -336,8 +528,6 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from avmoe_amd import _capi as capi
-    from avmoe_amd.dp import AdapterGradReducer
-    from avmoe_amd.adapters import AdapterPair
     os.environ.setdefault("AVMOE_PROF_SHAPES", "1")     # profiler families per kernel and launch shape (read at first launch)
     capi.lib()
     c = dict(CONFIGS[args.config], name=args.config)
@@ -345,110 +535,33 @@ def main():
         c["B"] = args.batch
     dtype = args.dtype or c["dtype"]
     c["dtype"] = dtype
-    can_pair = c["variant"] in ("ave", "avqa")
-    pair_mode = args.pair if can_pair else "off"
-    S = c["B"] * c["T"]
-    lbw = 0.01 if c["variant"] in ("avvp", "avs") else 0.0
-
-    def build_workload(tdt):
-        """modules + resident inputs of every distinct site-pair shape; the `cnt` pairs of a shape share the inputs, not the modules"""
-        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        work, sites = [], []
-        for i, (Ca, Na, Cv, Nv, cnt) in enumerate(c["pairs"]):
-            f_a = (0.3 * torch.randn(S, Na, Ca, generator=g)).to(device, tdt).requires_grad_(True)
-            f_v = (0.3 * torch.randn(S, Nv, Cv, generator=g)).to(device, tdt).requires_grad_(True)
-            g_a = torch.randn(S, Na, Ca, generator=g).to(device, tdt)
-            g_v = torch.randn(S, Nv, Cv, generator=g).to(device, tdt)
-            mods = []
-            for j in range(cnt):
-                a, v = build_pair(c, (Ca, Na, Cv, Nv), device, seed=100 * i + j)
-                mods.append((a, v, AdapterPair(a, v, concurrent=(pair_mode != "serial"),
-                                                ordered_accumulate={"ordered": True, "hybrid": "big", "twobuf": False}.get(pair_mode, "cross")) if can_pair else None))
-                sites += [a, v]
-            work.append(dict(f_a=f_a, f_v=f_v, ga4=g_a.permute(0, 2, 1).unsqueeze(-1), gv4=g_v.permute(0, 2, 1).unsqueeze(-1), mods=mods))
-        params = [p for m in sites for p in m.parameters()]
-        return work, AdapterGradReducer(params, bucket_mb=64.0, sites=sites)
-
-    def make_step(work, reducer):
-        def step(sync=True):
-            reducer.begin(sync=sync)
-            for w in work:
-                xa, xv = w["f_a"].permute(0, 2, 1).unsqueeze(-1), w["f_v"].permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
-                for a, v, pr in w["mods"]:
-                    extra = []
-                    if pair_mode != "off" and pr is not None:
-                        out_a, _, out_v, _ = pr(xa, xv)          # net_trans_v3.py:695-698 as one autograd node (AdapterPair)
-                    elif c["variant"] == "avs":
-                        out_a, _, _, lb_a = a(xa, xv, is_training=True)
-                        out_v, _, _, lb_v = v(xv, xa, is_training=True)
-                        extra = [lbw * (lb_a + lb_v)]
-                    elif c["variant"] == "avvp":
-                        out_a, lb_a = a(xa, xv)
-                        out_v, lb_v = v(xv, xa)
-                        extra = [lb_a + lb_v]
-                    else:
-                        out_a, _ = a(xa, xv)                   # net_trans_v3.py:695
-                        out_v, _ = v(xv, xa)                   # net_trans_v3.py:697
-                    torch.autograd.backward([out_a, out_v] + extra, [w["ga4"], w["gv4"]] + [None] * len(extra))
-                w["f_a"].grad = None
-                w["f_v"].grad = None
-            reducer.finish()
-            reducer.zero_grad()
-        return step
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(step, steps, warmup):
-        for _ in range(warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
-
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     esz = 2 if dtype == "bf16" else 4
-    work, reducer = build_workload(tdt)
-    msg_bytes = reducer.message_bytes()
-    step = make_step(work, reducer)
-    dt = timed(step, args.steps, args.warmup)                  # THE timed region: W warm-up steps, then exactly K steps
+
+    wl = Workload(c, tdt, device, rank, world, args.pair)
+    pair_mode = wl.pair_mode
+    msg_bytes = wl.reducer.message_bytes()
+    dt = wl.timed(args.steps, args.warmup)                     # THE timed region: W warm-up steps, then exactly K steps
     ms_per_step = 1e3 * dt / args.steps
     value = c["B"] * world / (dt / args.steps)
-    rep_ms = [ms_per_step] + [1e3 * timed(step, args.steps, 0) / args.steps for _ in range(max(0, args.reps - 1))]
+    rep_ms = [ms_per_step] + [1e3 * wl.timed(args.steps, 0) / args.steps for _ in range(max(0, args.reps - 1))]
 
     roofline = None
     if not args.no_roofline:
-        abytes, rflops = algorithmic_bytes_per_clip_pair(c, esz), reference_flops_per_clip_pair(c)
-        path_gbs = abytes * value / world / 1e9
-        path_tfs = rflops * value / world / 1e12
-        roofline = dict(bound="hbm", achieved=round(path_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(path_gbs / HBM_PEAK_GBS, 4), traffic=None,
-                        level="path (SURVEY 8d): algorithmic bytes per clip-pair x clip-pairs/s per GPU",
-                        algorithmic_bytes_per_clip_pair=round(abytes), algorithmic_bytes_per_step=round(abytes * c["B"]),
-                        mfma=dict(achieved=round(path_tfs, 1), peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s", frac=round(path_tfs / MFMA_PEAK_TF[dtype], 4),
-                                  reference_flops_per_clip_pair=round(rflops),
-                                  note="FLOPs of the reference's formulation (SURVEY 8d); the factorised path executes fewer"))
+        roofline = path_roofline(c, esz, dtype, value, world)
         if rank == 0:
-            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape), same execution mode as the
-            # timed region.  Rank 0 only: its steps must not enter a collective (sync=False = an accumulation micro-step).
+            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape), same pair mode as the timed
+            # region (the helper streams INSIDE a site are off while launches are timed: side.cpp).  Rank 0 only: its steps must not
+            # enter a collective (sync=False = an accumulation micro-step).
             L = capi.lib()
             for _ in range(2):
-                step(sync=False)
+                wl.step(sync=False)
             torch.cuda.synchronize()
             L.avmoe_prof_reset()
             L.avmoe_prof_enable(1)
             nprof = 3
             for _ in range(nprof):
-                step(sync=False)
+                wl.step(sync=False)
             torch.cuda.synchronize()
             L.avmoe_prof_enable(0)
             rep = capi.prof_report()
@@ -471,39 +584,49 @@ def main():
             if os.path.isfile(tj) and args.config == "cfg2" and not args.batch and dtype == "bf16":
                 with open(tj) as fh:       # HBM bytes from THIS round's rocprofv3 --pmc passes (scripts/make_profiles.sh)
                     tjd = json.load(fh)
-                t = tjd.get(dom["name"].split(" NT")[0].split(" M")[0])
-                if t:      # the dominant launch is the largest one of its family
-                    dk["traffic"] = t["read_bytes_largest_launch"] + t["write_bytes_largest_launch"]
-                    dk["traffic_source"] = f"profiles/{ROUND}_pmc_traffic.json"
-                if tjd.get("__total_bytes_per_step__"):
-                    roofline["traffic"] = tjd["__total_bytes_per_step__"]
-                    roofline["traffic_source"] = f"profiles/{ROUND}_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE over every kernel of one step"
+                if tjd.get("__lib_stamp__") and tjd["__lib_stamp__"] == lib_stamp():
+                    t = tjd.get(dom["name"].split(" NT")[0].split(" M")[0])
+                    if t:      # the dominant launch is the largest one of its family
+                        dk["traffic"] = t["read_bytes_largest_launch"] + t["write_bytes_largest_launch"]
+                        dk["traffic_source"] = f"profiles/{ROUND}_pmc_traffic.json"
+                    if tjd.get("__total_bytes_per_step__"):
+                        roofline["traffic"] = tjd["__total_bytes_per_step__"]
+                        roofline["traffic_source"] = f"profiles/{ROUND}_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE over every kernel of one step (PMC pass of this very build: library stamps equal)"
+                else:
+                    roofline["traffic_note"] = (f"profiles/{ROUND}_pmc_traffic.json was collected on a different build of the library "
+                                                "(stamp mismatch): not reported")
             roofline["dominant_kernel"] = dk
             roofline["gpu_time_ms_per_step"] = round(tot_ms / nprof, 3)
+            roofline["launches_per_step"] = sum(r["calls"] for r in rep) // nprof
             roofline["kernel_families"] = len(rep)
             roofline["families"] = sorted([dict(name=r["name"], calls=r["calls"] // nprof, ms_per_step=round(r["total_ms"] / nprof, 4),
                                                 gbs=round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1))
                                            for r in rep], key=lambda r: -r["ms_per_step"])[:12]
 
-    del work, reducer, step
-    gc.collect()
-    torch.cuda.empty_cache()
+    wl.release()
     value_f32 = None
     if dtype == "bf16" and not args.no_f32:
-        work, reducer = build_workload(torch.float32)
-        step = make_step(work, reducer)
+        wl = Workload(c, torch.float32, device, rank, world, args.pair)
         k32 = max(3, args.steps // 2)
-        dt32 = timed(step, k32, 2)
+        dt32 = wl.timed(k32, 2)
         value_f32 = dict(value=round(c["B"] * world / (dt32 / k32), 2), unit="clip-pairs/s", ms_per_step=round(1e3 * dt32 / k32, 4), steps=k32,
                          dtype="f32", note="fp32 activations on the exact-fp32 matrix pipe: the configuration held to the 1e-3 parity bar")
-        del work, reducer, step
-        gc.collect()
-        torch.cuda.empty_cache()
+        wl.release()
 
-    cpu = parity = None
+    cpu = parity = others = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu, material = cpu_baseline(c)
-        parity = parity_check(c, material, device)
+        parity = parity_check(c, material, device, pair_mode)
+        del material
+        if args.config == "cfg2" and not args.batch and not args.dtype and not args.no_other_configs:
+            others = {}
+            for name in ("cfg4", "cfg5"):
+                try:
+                    others[name] = other_config_line(name, device, args.pair)
+                except Exception as e:      # the headline line must not be lost to a side leg
+                    others[name] = dict(error=f"{type(e).__name__}: {e}")
+                gc.collect()
+                torch.cuda.empty_cache()
 
     if rank == 0:
         shapes = [dict(C_a=Ca, N_a=Na, C_v=Cv, N_v=Nv, site_pairs=cnt, bottleneck_a=Ca // c["reduction"], bottleneck_v=Cv // c["reduction"])
@@ -520,7 +643,7 @@ def main():
                        "grad_allreduce_bytes": msg_bytes if world > 1 else 0},
             "repeat_ms_per_step": [round(x, 4) for x in rep_ms],
             "spread_rel": round((max(rep_ms) - min(rep_ms)) / statistics.median(rep_ms), 4),
-            "roofline": roofline, "parity": parity, "value_f32": value_f32, "cpu_baseline": cpu,
+            "roofline": roofline, "parity": parity, "value_f32": value_f32, "cpu_baseline": cpu, "other_configs": others,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

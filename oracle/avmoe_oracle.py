@@ -239,8 +239,13 @@ def frames_mha(X, Win, bin_, Wout, bout, heads, keep=None):
     return o @ Wout.t() + bout
 
 
-def expert_forward(P, B, pre, X, Yf, cfg: AdapterConfig, multimodal, training, new_buffers, mha_keep=None):
-    """ExpertAdapter.forward, token-major (net_trans_v3.py:376-435)."""
+def expert_forward(P, B, pre, X, Yf, cfg: AdapterConfig, multimodal, training, new_buffers, mha_keep=None,
+                   relu_masks=None, record=None):
+    """ExpertAdapter.forward, token-major (net_trans_v3.py:376-435).
+    relu_masks / record (checker-side instruments, both None in the reference's arithmetic): `record[pre]` receives the ReLU
+    pre-activations (S, N, d) of a cross-modal expert; `relu_masks[pre]` (bool, same shape) REPLACES `relu(z)` by `z * mask` --
+    the same function wherever the mask equals `z > 0`, used to compare gradients with an implementation whose units within
+    rounding of zero fell on the other side of the kink."""
     if multimodal:
         X = X + P[f"{pre}.gate_av"] * latent_attention(X, Yf, P[f"{pre}.my_tokens"])   # :390
     elif cfg.variant == "avvp":
@@ -262,7 +267,12 @@ def expert_forward(P, B, pre, X, Yf, cfg: AdapterConfig, multimodal, training, n
                               B[f"{pre}.bn1.running_mean"], B[f"{pre}.bn1.running_var"],
                               training, cfg.bn_eps, cfg.bn_momentum, new_buffers, f"{pre}.bn1")
     if multimodal:
-        Z = F.relu(Z)                                                # :400  (cross-modal only)
+        if record is not None:
+            record[pre] = Z.detach()
+        if relu_masks is not None and pre in relu_masks:
+            Z = Z * relu_masks[pre].to(Z.dtype)
+        else:
+            Z = F.relu(Z)                                            # :400  (cross-modal only)
     O = grouped_linear(Z, P[f"{pre}.up_sampler.weight"], cfg.groups)               # :401
     if cfg.use_bn:
         O = batch_norm_tokens(O, P[f"{pre}.bn2.weight"], P[f"{pre}.bn2.bias"],
@@ -282,7 +292,8 @@ def load_balancing_loss(probs):
     return -(torch.log(pbar)).sum()
 
 
-def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, update_buffers=True, mha_keep=None):
+def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, update_buffers=True, mha_keep=None,
+                relu_masks=None, record=None):
     """MoEAdapter.forward (net_trans_v3.py:468-487) on token-major X:(S,Nx,Cx), Y:(S,Ny,Cy).
 
     Returns dict(out (S,Nx,Cx), probs (S,E), idx (S,) int64, lb (0-d), Yf, new_buffers).
@@ -303,7 +314,7 @@ def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, updat
     new_buffers = {} if (training and update_buffers and cfg.use_bn) else None
     out = torch.zeros_like(X)
     for j, pre in enumerate(cfg.expert_prefixes()):                                      # :482
-        o = expert_forward(P, B, pre, X, Yf, cfg, j < cfg.E_m, training, new_buffers, mha_keep)
+        o = expert_forward(P, B, pre, X, Yf, cfg, j < cfg.E_m, training, new_buffers, mha_keep, relu_masks, record)
         out = out + probs[:, j].reshape(-1, 1, 1) * o                                    # :485-486
     lb = load_balancing_loss(probs) if cfg.lb_loss else torch.zeros((), dtype=X.dtype)
     if new_buffers is not None:
@@ -314,13 +325,13 @@ def moe_forward(P, B, X, Y, cfg: AdapterConfig, training=True, noise=None, updat
 
 
 def moe_forward_backward(P, B, X, Y, cfg: AdapterConfig, grad_out, training=True, noise=None,
-                         lb_weight: float = 0.0, mha_keep=None):
+                         lb_weight: float = 0.0, mha_keep=None, relu_masks=None, record=None):
     """Forward + autograd backward.  Loss = <out, grad_out> + lb_weight * lb.
     Returns (fwd dict, grads dict with 'X', 'Y' and one entry per parameter key)."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     Xg = X.detach().clone().requires_grad_(True)
     Yg = Y.detach().clone().requires_grad_(True)
-    fwd = moe_forward(Pg, B, Xg, Yg, cfg, training=training, noise=noise, mha_keep=mha_keep)
+    fwd = moe_forward(Pg, B, Xg, Yg, cfg, training=training, noise=noise, mha_keep=mha_keep, relu_masks=relu_masks, record=record)
     loss = (fwd["out"] * grad_out).sum()
     if cfg.lb_loss and lb_weight != 0.0:
         loss = loss + lb_weight * fwd["lb"]

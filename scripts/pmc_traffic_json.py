@@ -71,11 +71,18 @@ def main():
     wr = load(sys.argv[2], 1.0)
     steps = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     out = {}
+    import os
+    stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avmoe_amd", "lib", "libavmoe_hip.stamp")
+    if os.path.isfile(stamp):          # which build of the library the counters belong to (bench.py reports `traffic` only for that build)
+        with open(stamp) as fh:
+            out["__lib_stamp__"] = fh.read().strip()
     if steps > 0:       # HBM-side bytes of ONE bench step over every kernel (bench.py: roofline.traffic)
         out["__total_bytes_per_step__"] = round((total_bytes(sys.argv[1], 2.0) + total_bytes(sys.argv[2], 1.0)) / steps)
         out["__read_bytes_per_step__"] = round(total_bytes(sys.argv[1], 2.0) / steps)
         out["__write_bytes_per_step__"] = round(total_bytes(sys.argv[2], 1.0) / steps)
     for f in sorted(set(rd) | set(wr)):
+        if f.startswith("__"):
+            continue
         r, w = rd.get(f, [0.0]), wr.get(f, [0.0])
         out[f] = {"launches_profiled": max(len(r), len(w)), "read_bytes_per_launch": round(sum(r) / len(r)),
                   "write_bytes_per_launch": round(sum(w) / len(w)), "read_bytes_largest_launch": round(max(r)),

@@ -97,3 +97,31 @@ def test_descriptor_validation_without_a_gpu():
     d = make_desc(cfg, 6, False, True)
     d.E_m, d.E_s = 0, 0
     assert L.avmoe_moe_saved_bytes(C.byref(d)) == 0 and b"expert count" in L.avmoe_last_error()
+
+
+def test_site_cache_follows_replaced_parameters():
+    """The per-site bookkeeping caches NAMES and owners, never Parameter objects: a Parameter replaced after the first call
+    (`load_state_dict(assign=True)`, attribute assignment) is the one the next call hands to the kernels; deepcopy / pickle do
+    not carry the cache."""
+    import copy
+    import pickle
+    _, cfg, _ = load_golden("ave_train")
+    m = build_module("ave", cfg)
+    first = m._param_tensors()
+    assert list(first) == [k for k, _ in m.named_parameters()]
+    new_gate = torch.nn.Parameter(torch.full((1,), 0.25))
+    m.multimodal_experts[0].gate = new_gate                                  # attribute assignment
+    assert m._param_tensors()["multimodal_experts.0.gate"] is new_gate
+    sd = {k: v.clone() + 1.0 for k, v in m.state_dict().items() if v.is_floating_point()}
+    m.load_state_dict(sd, strict=False, assign=True)                         # every Parameter object replaced
+    now = m._param_tensors()
+    for k, p in m.named_parameters():
+        assert now[k] is p
+        assert now[k] is not first[k]
+    m.multimodal_experts[0].gate = None                                      # a parameter removed: registry rebuilt, not a stale object
+    assert "multimodal_experts.0.gate" not in m._param_tensors()
+    m2 = copy.deepcopy(m)
+    assert "_avmoe_cache" not in m2.__dict__
+    assert all(a is b for a, b in zip(m2._param_tensors().values(), m2.parameters()))
+    m3 = pickle.loads(pickle.dumps(m))
+    assert "_avmoe_cache" not in m3.__dict__ and list(m3._param_tensors()) == [k for k, _ in m3.named_parameters()]

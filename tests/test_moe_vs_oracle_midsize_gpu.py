@@ -46,6 +46,22 @@ CASES = {
     # cfg-5 (AVS: 4 + 4 experts, bottleneck 128, latent self attention v2, 5 frames; PVT-v2-b5 stage 3 x HTS-AT)
     "cfg5_avs_stage3_visual_side": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
     "cfg5_avs_stage2_audio_side": dict(cfg=dict(Cx=384, Nx=256, Cy=320, Ny=196, reduction=3, groups=2, K=32, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
+    # cfg-5 AS BENCHMARKED (bench.py cfg5: reduction 4 at every stage, 4 + 4 experts, the AVS default of 87 latent tokens -- 96 padded
+    # slots, the 140 KB dynamic-LDS instantiation of tile_gen.inc at bottleneck 128 --, PVT_AVSModel_v2.py:255,711): PVT-v2-b5 x HTS-AT
+    # stage 3 both sides (bottleneck 128 / 192), stage 2 (96 / 80) and stage 0 (24 / 16: merged groups) sites; plus the same stage-3
+    # visual site with latent self attention ("v2": eight latent experts) and frame attention ("v1": four xr slots)
+    "cfg5_stage3_visual_k87": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage3_audio_k87": dict(cfg=dict(Cx=768, Nx=64, Cy=512, Ny=49, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage2_visual_k87": dict(cfg=dict(Cx=320, Nx=196, Cy=384, Ny=256, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage2_audio_k87": dict(cfg=dict(Cx=384, Nx=256, Cy=320, Ny=196, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage0_audio_k87": dict(cfg=dict(Cx=96, Nx=4096, Cy=64, Ny=3136, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage0_visual_k87": dict(cfg=dict(Cx=64, Nx=3136, Cy=96, Ny=4096, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage3_visual_k87_v2": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=87, variant="avs", self_attn="v2", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage3_visual_k87_v1": dict(cfg=dict(Cx=512, Nx=49, Cy=768, Ny=64, reduction=4, groups=2, K=87, variant="avs", self_attn="v1", E_m=4, E_s=4, lb_loss=True), S=5, keep=True),
+    # cfg-3 stage 0 at its REAL token counts (N = 4096 / 2304, mgn.py:132-139): the strip kernel kk_nxn_att over 32 / 18 key tiles per
+    # query strip, two frames (kept: (frames, N, N) fits; the chunked form of the same sites: test_avvp_nxn_block_in_frame_chunks)
+    "cfg3_avvp_stage0_audio_full": dict(cfg=dict(Cx=96, Nx=4096, Cy=192, Ny=2304, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
+    "cfg3_avvp_stage0_visual_full": dict(cfg=dict(Cx=192, Nx=2304, Cy=96, Ny=4096, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=2),
     # AVS self_attention_version "v1" (the S4 training script's default): MultiheadAttention across the frames, PVT-v2 stage shapes
     # (C 64 / 320, N 3136 / 196), 5 frames x 2 clips, 1 + 1 experts as in train_v2.sh and 2 + 2
     "avs_v1_stage0": dict(cfg=dict(Cx=64, Nx=3136, Cy=96, Ny=1024, reduction=8, groups=2, K=32, variant="avs", self_attn="v1", E_m=1, E_s=1, lb_loss=True), S=10, keep=True),
@@ -115,7 +131,10 @@ def test_midsize_matches_oracle_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
-                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio", "fast_avvp", "fast_avvp_e1p1_pad", "fast_v1"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
+                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio", "fast_avvp", "fast_avvp_e1p1_pad", "fast_v1",
+                                  "fast_eval", "fast_nobn",      # eval mode / no BatchNorm on the register-resident bf16 shape: no Gram pass, mz / Szz never formed
+                                  "cfg5_stage3_visual_k87", "cfg5_stage3_audio_k87", "cfg5_stage2_audio_k87", "cfg5_stage0_audio_k87", "cfg5_stage3_visual_k87_v2",
+                                  "cfg3_avvp_stage0_audio_full", "cfg3_avvp_stage0_visual_full"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path (bf16 activations AND bottleneck-space tensors, streaming GEMMs, streaming Gram) against the fp32 oracle
     on the bf16-rounded inputs: router indices bit-exact, outputs within 1e-2 (max-abs relative; 4e-2 for the frame-attention
@@ -125,7 +144,7 @@ def test_midsize_bf16_close_to_oracle(name):
     from tests.golden_util import bf16_budget_violations
     case = CASES[name]
     cfg = O.AdapterConfig(**case["cfg"])
-    S = case["S"]
+    S, training = case["S"], case.get("training", True)
     P, B = O.init_params(cfg, seed=21)
     g = torch.Generator().manual_seed(77)
     X = 0.3 * torch.randn(S, cfg.Nx, cfg.Cx, generator=g)
@@ -134,8 +153,8 @@ def test_midsize_bf16_close_to_oracle(name):
     lbw = 0.01 if cfg.lb_loss else 0.0
     Xb, Yb, Gb = X.bfloat16().float(), Y.bfloat16().float(), G.bfloat16().float()          # the oracle sees the rounded inputs
     keep = _draw_keep(cfg, S, g) if case.get("keep") else None
-    fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=True, lb_weight=lbw, mha_keep=keep)
-    run = MoeRun(cfg, P, B, X, Y, bf16=True, training=True, mha_keep=keep).forward()
+    fwd, grads = O.moe_forward_backward(P, B, Xb, Yb, cfg, Gb, training=training, lb_weight=lbw, mha_keep=keep)
+    run = MoeRun(cfg, P, B, X, Y, bf16=True, training=training, mha_keep=keep).forward()
     assert torch.equal(run.idx.cpu(), fwd["idx"])
     out = run.out.float().cpu()
     assert float((out - fwd["out"]).abs().max() / fwd["out"].abs().max()) < (4e-2 if cfg.self_attn == "v1" else 1e-2)
@@ -143,10 +162,12 @@ def test_midsize_bf16_close_to_oracle(name):
     # frame attention ("v1"): QKV / scores / P V / out-proj all run on bf16 operands here, eager autocast keeps the softmax chain in
     # fp32 -- measured 2.5 - 3 x the eager error on the router and BatchNorm-2 gradients (1.2 - 2.7 %): factor 4 and a 3 % floor there
     kw = dict(factor=4.0, floor=3e-2) if cfg.self_attn == "v1" else {}
-    bad = bf16_budget_violations(O, cfg, P, B, Xb, Yb, Gb, got, grads, lb_weight=lbw, mha_keep=keep, **kw)
+    bad = bf16_budget_violations(O, cfg, P, B, Xb, Yb, Gb, got, grads, training=training, lb_weight=lbw, mha_keep=keep, **kw)
+    assert run.guards_intact(), "a kernel wrote past its workspace"
     assert not bad, bad
 
-@pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2), ("cfg3_avvp_stage0_audio_side_n512", 2)])
+@pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2), ("cfg3_avvp_stage0_audio_side_n512", 2),
+                                        ("cfg3_avvp_stage0_audio_full", 1), ("cfg3_avvp_stage0_visual_full", 1)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
     """The AVVP N x N block run a few frames at a time through one workspace, scores and softmax recomputed in the backward (what

@@ -56,3 +56,28 @@ def test_single_expert_probs_are_one_and_lb_of_uniform():
     E = 4
     lb = O.load_balancing_loss(torch.full((5, E), 1.0 / E))
     assert abs(float(lb) - E * torch.log(torch.tensor(float(E))).item()) < 1e-5
+
+
+def test_relu_mask_instruments_do_not_change_the_arithmetic():
+    """The checker-side instruments of the oracle (record the ReLU pre-activations / replace relu(z) by z * mask) reproduce the plain
+    run exactly when the mask is the oracle's own `z > 0`, and a flipped unit changes only what passes through it."""
+    cfg = O.AdapterConfig(Cx=64, Nx=24, Cy=48, Ny=20, reduction=4, groups=2, K=8)
+    P, B = O.init_params(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    X, Y = 0.3 * torch.randn(3, cfg.Nx, cfg.Cx, generator=g), 0.3 * torch.randn(3, cfg.Ny, cfg.Cy, generator=g)
+    G = torch.randn(3, cfg.Nx, cfg.Cx, generator=g)
+    rec = {}
+    f0, g0 = O.moe_forward_backward(P, B, X, Y, cfg, G, record=rec)
+    assert set(rec) == {"multimodal_experts.0", "multimodal_experts.1"} and rec["multimodal_experts.0"].shape == (3, cfg.Nx, cfg.d)
+    masks = {k: z > 0 for k, z in rec.items()}
+    f1, g1 = O.moe_forward_backward(P, B, X, Y, cfg, G, relu_masks=masks)
+    assert torch.equal(f0["out"], f1["out"])
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    z = rec["multimodal_experts.0"]
+    s, n, j = [int(i) for i in (z.abs() == z.abs().min()).nonzero()[0]]      # the unit closest to the kink
+    masks["multimodal_experts.0"][s, n, j] ^= True
+    _f2, g2 = O.moe_forward_backward(P, B, X, Y, cfg, G, relu_masks=masks)
+    assert not torch.equal(g0["multimodal_experts.0.bn1.bias"], g2["multimodal_experts.0.bn1.bias"])
+    assert torch.equal(g0["multimodal_experts.1.bn1.bias"], g2["multimodal_experts.1.bn1.bias"]) or \
+        float((g0["multimodal_experts.1.bn1.bias"] - g2["multimodal_experts.1.bn1.bias"]).abs().max()) < 1e-3
