@@ -8,12 +8,16 @@ AVQA/net_grd_avst/main_avst_v2.py:321, AVS/avs_scripts/avs_s4/train_v2.py:140), 
 GPU 0 every step and computes BatchNorm statistics per replica.  Per-rank BatchNorm statistics are therefore
 reference semantics and are kept; only the gradient reduction is re-designed:
 
-  * gradients live in a few flat fp32 buckets (`param.grad` are views into them), so the exchange is a
-    handful of large all-reduces instead of one small one per tensor -- xGMI is point-to-point, large
-    messages are what keeps the links busy;
-  * buckets are filled in reverse registration order (the order the backward produces gradients) and each
-    bucket's all-reduce is launched asynchronously as soon as its last gradient has been accumulated, so
-    communication overlaps the rest of the backward;
+  * gradients live in a few LARGE flat fp32 buckets (`param.grad` are views into them; default 64 MB): the adapter sites
+    handed in as `sites=` take consecutive SLICES of shared buckets, in reverse execution order, and their backward writes
+    every parameter gradient straight into its slice (no per-parameter accumulation kernels) -- a Swin-L model's 48 sites
+    (345-475 MB of fp32 gradients) travel as ~7 messages, not 48: xGMI is point-to-point, large messages are what
+    keeps the seven links of a GPU busy;
+  * a bucket's all-reduce is launched asynchronously as soon as the LAST site / parameter of the bucket has reported (behind
+    the events of every stream that wrote into it), so communication overlaps the rest of the backward;
+  * the mean over the ranks costs no kernel: RCCL reduces with ncclAvg (`ReduceOp.AVG`); with `average="optimizer"` the
+    collective is a plain sum and `FlatAdam` folds 1 / world into `avmoe_adam_step`'s `grad_scale` (gloo -- CPU tests and
+    development only -- has no AVG: sum, then one division per bucket);
   * on gradient-accumulation micro-steps (`sync=False`) nothing is sent (reference accum_itr semantics,
     AVE/main_trans_v3.py:136-138).
 """
@@ -30,28 +34,59 @@ ALIGN = 64        # elements: every parameter's slice of a flat bucket starts 25
 
 
 class _Bucket:
-    def __init__(self, params: List[torch.nn.Parameter], device, dtype):
-        self.params = params
-        self.offsets, off = [], 0
-        for p in params:
-            self.offsets.append(off)
-            off += -(-p.numel() // ALIGN) * ALIGN
-        self.flat = torch.zeros(off, device=device, dtype=dtype)
-        for p, o in zip(params, self.offsets):
+    """One flat fp32 gradient buffer = one all-reduce message: slices of whole adapter sites (written by the sites' backward
+    through a _SiteSink) and / or individual parameters (accumulated by autograd, counted by a hook)."""
+
+    def __init__(self):
+        self.params: List[torch.nn.Parameter] = []
+        self.offsets: List[int] = []
+        self.size = 0
+        self.sinks: List["_SiteSink"] = []
+        self.hooked = 0                                  # parameters that report through the autograd hook
+        self.flat = None
+        self.pending = 0
+        self.work = None
+
+    def add_param(self, p):
+        self.params.append(p); self.offsets.append(self.size)
+        self.size += -(-p.numel() // ALIGN) * ALIGN
+        self.hooked += 1
+
+    def add_site(self, site):
+        """-> (base offset of the site's slice, its length) ; the slice has the layout of site.grad_layout()"""
+        names, offs, total = site.grad_layout(ALIGN)
+        ps = dict(site.named_parameters())
+        base = self.size
+        for k, o in zip(names, offs):
+            self.params.append(ps[k]); self.offsets.append(base + o)
+        self.size += total
+        return base, total
+
+    def materialize(self, device):
+        self.flat = torch.zeros(self.size, device=device, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
-        self.pending = len(params)
+
+    def arm(self):
+        self.pending = len(self.sinks) + self.hooked
         self.work = None
 
 
 class _SiteSink:
-    """Hands a MoEAdapter site its slice of gradient memory: the site's backward writes all its parameter gradients there
+    """Hands a MoEAdapter site its slice of a (shared) bucket: the site's backward writes all its parameter gradients there
     (layout = site.grad_layout()) and calls done()."""
 
-    def __init__(self, site, bucket, reducer):
-        self.names, self.offsets, self.total = site.grad_layout()
+    def __init__(self, site, bucket, base, total, reducer):
+        self.names, self.offsets, self.total = site.grad_layout(ALIGN)
+        assert self.total == total
         self.bucket, self.reducer, self.fresh = bucket, reducer, True
-        self.flat = bucket.flat
+        self.base = base
+        self.flat = None                                 # the slice (set once the bucket's memory exists)
         self.calls = 0                                   # forward calls of the site still waiting for their backward
+        self.event = None                                # recorded on the stream the site's last backward ran on
+
+    def bind(self):
+        self.flat = self.bucket.flat[self.base:self.base + self.total]
 
     def matches(self, names, tensors) -> bool:
         return tuple(names) == self.names and all(v.device == self.flat.device for v in tensors.values())
@@ -60,79 +95,96 @@ class _SiteSink:
         self.fresh = False
         self.calls -= 1
         if self.calls <= 0:
-            self.reducer._bucket_filled(self.bucket)
-
-
-class _SiteBucket:
-    def __init__(self, site):
-        names, offs, total = site.grad_layout()
-        ps = dict(site.named_parameters())
-        self.params = [ps[k] for k in names]
-        self.offsets = list(offs)
-        self.flat = torch.zeros(total, device=self.params[0].device, dtype=torch.float32)
-        for p, o in zip(self.params, offs):
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-        self.pending = 1
-        self.work = None
+            if self.flat.is_cuda:                        # the bucket's collective must wait for THIS stream's writes, whichever
+                self.event = torch.cuda.Event()          # stream context launches it (the two sites of an AdapterPair finish on
+                self.event.record(torch.cuda.current_stream(self.flat.device))      # two different streams)
+            self.reducer._reported(self.bucket)
 
 
 class AdapterGradReducer:
     """Bucketed, overlapped gradient all-reduce for the trainable parameters of adapter sites.
 
-        red = AdapterGradReducer(model.parameters(), bucket_mb=32)
+        red = AdapterGradReducer(model.parameters(), bucket_mb=64, sites=adapter_sites)
         for micro, batch in enumerate(loader):
-            red.begin(sync=(micro + 1) % accum == 0)     # arm the hooks for this backward
+            red.begin(sync=(micro + 1) % accum == 0)     # arm the buckets for this backward
             loss(model(batch)).backward()
             red.finish()                                   # wait for the buckets (no-op when sync=False)
             if sync: opt.step(); red.zero_grad()
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
-                 process_group: Optional[dist.ProcessGroup] = None, sites=None):
-        """`sites`: MoEAdapter modules (GPU) whose backward should write its parameter gradients straight into a bucket
-        of this reducer (one bucket per site, no per-parameter accumulation kernels); their parameters may also be
-        listed in `params`, all other parameters are bucketed by size."""
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0,
+                 process_group: Optional[dist.ProcessGroup] = None, sites=None, average: str = "auto"):
+        """`sites`: MoEAdapter modules, in EXECUTION order, whose backward should write its parameter gradients straight into
+        this reducer's buckets (a gradient sink per site; consecutive sites share buckets of up to `bucket_mb`, packed in reverse
+        execution order = the order the backward finishes them); their parameters may also be listed in `params`, all other
+        parameters are bucketed by size.
+        average: "auto" -- the collective itself averages where the backend can (RCCL / NCCL: ReduceOp.AVG), else sum + one
+        division per bucket; "optimizer" -- plain sum, `grad_scale` = 1 / world is left to the optimizer (FlatAdam picks it up)."""
+        if average not in ("auto", "optimizer"):
+            raise ValueError("average must be 'auto' or 'optimizer'")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self._avg_op = average == "auto" and backend == "nccl"            # RCCL: ncclAvg, no extra kernel
+        self._divide = average == "auto" and not self._avg_op and self.world > 1
+        self.grad_scale = 1.0 / self.world if average == "optimizer" else 1.0
         self.buckets: List[_Bucket] = []
         self.sinks: List[_SiteSink] = []
+        cap = max(1, int(bucket_mb * (1 << 20)) // 4)     # elements
         owned = set()
-        for site in (sites or []):
+        device = None
+        cur = None
+        for site in reversed(list(sites or [])):         # the backward finishes the sites in reverse execution order
             sp = list(site.parameters())
             if not sp or not all(p.requires_grad and p.dtype == torch.float32 for p in sp):
                 continue                                  # partly frozen site: plain autograd accumulation
-            b = _SiteBucket(site)
-            self.buckets.append(b)
-            sink = _SiteSink(site, b, self)
+            total = site.grad_layout(ALIGN)[2]
+            if cur is None or (cur.size and cur.size + total > cap):
+                cur = _Bucket()
+                self.buckets.append(cur)
+            base, total = cur.add_site(site)
+            sink = _SiteSink(site, cur, base, total, self)
+            cur.sinks.append(sink)
             site._grad_sink = sink
             self.sinks.append(sink)
             owned.update(id(p) for p in sp)
+            device = sp[0].device
         ps = [p for p in params if p.requires_grad and id(p) not in owned]
         if not ps and not self.buckets:
             raise ValueError("no trainable parameters")
-        cap = int(bucket_mb * (1 << 20))
-        cur, cur_bytes = [], 0
-        for p in reversed(ps):                       # backward produces gradients roughly in reverse order
-            if cur and cur_bytes + p.numel() * 4 > cap:
-                self.buckets.append(_Bucket(cur, p.device, torch.float32))
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-        if cur:
-            self.buckets.append(_Bucket(cur, ps[0].device, torch.float32))
-        self._sync = True
+        cur = None
+        for p in reversed(ps):                           # backward produces gradients roughly in reverse order
+            if cur is None or (cur.size and cur.size + p.numel() > cap):
+                cur = _Bucket()
+                self.buckets.append(cur)
+            cur.add_param(p)
+            device = p.device
         self._owner = {}
         for b in self.buckets:
-            if isinstance(b, _SiteBucket):
-                continue
-            for p in b.params:
-                self._owner[p] = b
-                p.register_post_accumulate_grad_hook(self._hook)
+            b.materialize(b.params[0].device if b.params else device)
+            for s in b.sinks:
+                s.bind()
+            if b.hooked:                                 # a bucket holds either site slices (their sinks report) or plain parameters
+                for p in b.params:
+                    self._owner[p] = b
+                    p.register_post_accumulate_grad_hook(self._hook)
+        self._sync = True
+        self.begin(True)
 
-    def _bucket_filled(self, b):
-        b.pending = 0
-        if self._sync and self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    # ---- launching ------------------------------------------------------------------------------------------------
+    def _launch(self, b):
+        if b.flat.is_cuda:
+            cur = torch.cuda.current_stream(b.flat.device)
+            for s in b.sinks:
+                if s.event is not None:
+                    cur.wait_event(s.event)              # every stream that wrote a slice of this bucket
+        op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
+        b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+
+    def _reported(self, b):
+        b.pending -= 1
+        if b.pending <= 0 and self._sync and self.world > 1 and b.work is None:
+            self._launch(b)
 
     def _hook(self, p):
         b = self._owner[p]
@@ -143,26 +195,25 @@ class AdapterGradReducer:
                     b.flat[off:off + p.numel()].view_as(p).copy_(p.grad)
                     p.grad = b.flat[off:off + p.numel()].view_as(p)
                     break
-        b.pending -= 1
-        if b.pending == 0 and self._sync and self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._reported(b)
 
     def begin(self, sync: bool = True):
         self._sync = sync
         for b in self.buckets:
-            b.pending = 1 if isinstance(b, _SiteBucket) else len(b.params)
-            b.work = None
+            b.arm()
         for s in self.sinks:
             s.calls = 0
+            s.event = None
 
     def finish(self):
         if not self._sync or self.world == 1:
             return
         for b in self.buckets:
-            if b.work is None:                       # a parameter received no gradient this step: reduce anyway
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if b.work is None:                       # a site / parameter received no gradient this step: reduce anyway
+                self._launch(b)
             b.work.wait()
-            b.flat.div_(self.world)
+            if self._divide:
+                b.flat.div_(self.world)
 
     def zero_grad(self):
         for b in self.buckets:
@@ -172,3 +223,7 @@ class AdapterGradReducer:
 
     def message_bytes(self) -> int:
         return sum(b.flat.numel() * 4 for b in self.buckets)
+
+    def messages(self) -> List[int]:
+        """bytes of every all-reduce message of one optimizer step"""
+        return [b.flat.numel() * 4 for b in self.buckets]

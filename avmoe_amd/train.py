@@ -106,12 +106,14 @@ class FlatAdam:
     def step(self):
         L = capi.lib()
         self.t += 1
+        # 1 / world of a sum-reducing AdapterGradReducer(average="optimizer") rides in the kernel's gradient scale: no division pass
+        scale = self.grad_scale * float(getattr(self.reducer, "grad_scale", 1.0))
         for s in self.state:
             for (o, e, r) in s["ranges"]:
                 st = L.avmoe_adam_step(s["p"].data_ptr() + 4 * o, s["g"].data_ptr() + 4 * o, s["m"].data_ptr() + 4 * o,
                                        s["v"].data_ptr() + 4 * o, C.c_int64(e - o), C.c_float(r * self.decay),
                                        C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
-                                       C.c_float(self.wd), C.c_int64(self.t), C.c_float(self.grad_scale),
+                                       C.c_float(self.wd), C.c_int64(self.t), C.c_float(scale),
                                        torch.cuda.current_stream(s["p"].device).cuda_stream)
                 capi.check(st, "avmoe_adam_step")
 

@@ -68,6 +68,91 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_sites(rank, world, port, out):
+    """Shared buckets: three adapter sites, two of them in ONE bucket; the sites' backward is emulated through the gradient-sink
+    protocol of avmoe_amd/adapters.py::_SiteBackward (write the slice at sink.offsets, done()); `average="optimizer"` leaves the
+    1 / world to the optimizer's gradient scale."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from avmoe_amd.dp import AdapterGradReducer
+        from tests.golden_util import load_golden
+        from tests.test_adapters_api import build_module
+        _, cfg, _ = load_golden("ave_train")
+        torch.manual_seed(0)
+        sites = [build_module("ave", cfg) for _ in range(3)]            # execution order
+        head = torch.nn.Linear(8, 3)                                      # a plain (non-site) parameter set beside them
+        site_bytes = sites[0].grad_layout()[2] * 4
+        ok = True
+        for average in ("auto", "optimizer"):
+            red = AdapterGradReducer([p for m in sites for p in m.parameters()] + list(head.parameters()),
+                                     bucket_mb=2.2 * site_bytes / (1 << 20), sites=sites, average=average)
+            site_buckets = [b for b in red.buckets if b.sinks]
+            ok &= [len(b.sinks) for b in site_buckets] == [2, 1]          # reverse execution order: (site 2, site 1), (site 0)
+            ok &= site_buckets[0].sinks[0] is sites[2]._grad_sink and site_buckets[0].sinks[1] is sites[1]._grad_sink
+            ok &= all(m._grad_sink.flat.data_ptr() == m._grad_sink.bucket.flat.data_ptr() + 4 * m._grad_sink.base for m in sites)
+
+            def site_backward(i, step):
+                sink = sites[i]._grad_sink
+                g = torch.Generator().manual_seed(97 * step + 13 * i + rank)
+                buf = torch.randn(sink.total, generator=g)
+                if sink.fresh:
+                    sink.flat.copy_(buf)
+                else:
+                    sink.flat.add_(buf)
+                sink.done()
+                return buf
+
+            def run(step, sync):
+                red.begin(sync=sync)
+                for m in sites:
+                    m._grad_sink.calls += 1                               # the forward of every site
+                (head(torch.ones(2, 8) * (rank + 1)).sum() * step).backward()
+                launched = []
+                for i in (2, 1, 0):                                       # backward order
+                    site_backward(i, step)
+                    launched.append([b.work is not None for b in site_buckets])
+                red.finish()
+                return launched
+
+            l1 = run(1, False)                                            # accumulation micro-step: nothing is sent
+            ok &= all(not any(x) for x in l1)
+            l2 = run(2, True)
+            if world > 1:
+                ok &= l2 == [[False, False], [True, False], [True, True]]    # a bucket goes out when its LAST site has reported
+            for i, m in enumerate(sites):
+                expect = torch.zeros(m._grad_sink.total)
+                for r in range(world):
+                    for step in (1, 2):
+                        g = torch.Generator().manual_seed(97 * step + 13 * i + r)
+                        expect += torch.randn(m._grad_sink.total, generator=g)
+                expect *= (1.0 / world) if average == "auto" else 1.0    # "optimizer": the sum; FlatAdam scales by red.grad_scale
+                ok &= torch.allclose(m._grad_sink.flat, expect, atol=1e-5)
+                for (k, p), o in zip(m.named_parameters(), m._grad_sink.offsets):
+                    ok &= p.grad.data_ptr() == m._grad_sink.flat.data_ptr() + 4 * o
+            ok &= red.grad_scale == (1.0 if average == "auto" else 1.0 / world)
+            w_expect = sum(3.0 * 2 * (r + 1) for r in range(world)) * (1.0 / world if average == "auto" else 1.0)
+            ok &= torch.allclose(head.weight.grad, torch.full_like(head.weight, w_expect), atol=1e-5)
+            red.zero_grad()
+            ok &= all(float(b.flat.abs().max()) == 0.0 for b in red.buckets) and all(m._grad_sink.fresh for m in sites)
+            for m in sites:
+                del m._grad_sink
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_site_sinks_share_buckets_world2_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_sites, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 @pytest.mark.timeout(180)
 def test_adapter_grad_reducer_world2_gloo():
     world = 2
