@@ -19,7 +19,7 @@ class MoeDesc(C.Structure):
 
 _EXPERT_FIELDS = ("gate", "my_tokens", "gate_lat", "down_w", "up_w", "bn1_w", "bn1_b", "bn2_w", "bn2_b",
                   "lnb_w", "lnb_b", "lnp_w", "lnp_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv",
-                  "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "sa_keep")
+                  "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "sa_keep", "bn1_nbt", "bn2_nbt")
 _TOP_FIELDS = ("conv_w", "conv_b", "fc_w", "fc_b", "r0_w", "r0_b", "r2_w", "r2_b", "r4_w", "r4_b")
 
 
@@ -43,7 +43,9 @@ EXPERT_KEY_TO_FIELD = {
     "self_attention.in_proj_weight": "sa_in_w", "self_attention.in_proj_bias": "sa_in_b",
     "self_attention.out_proj.weight": "sa_out_w", "self_attention.out_proj.bias": "sa_out_b",
     SA_KEEP: "sa_keep",            # not a state_dict entry: the dropout multiplier of one call (include/avmoe.h)
+    "bn1.num_batches_tracked": "bn1_nbt", "bn2.num_batches_tracked": "bn2_nbt",      # int64 counters, bumped inside the forward (ABI 6)
 }
+INT64_FIELDS = ("bn1_nbt", "bn2_nbt")
 TOP_KEY_TO_FIELD = {
     "conv_adapter.weight": "conv_w", "conv_adapter.bias": "conv_b", "fc.weight": "fc_w", "fc.bias": "fc_b",
     "router.0.weight": "r0_w", "router.0.bias": "r0_b", "router.2.weight": "r2_w", "router.2.bias": "r2_b",
@@ -100,7 +102,7 @@ def make_ptrs(tensors: Dict[str, "object"], E_m: int, E_s: int) -> MoePtrs:
         for leaf, f in EXPERT_KEY_TO_FIELD.items():
             t = tensors.get(f"{pre}.{leaf}")
             if t is not None:
-                assert t.dtype == torch.float32 and t.is_contiguous(), (pre, leaf)
+                assert t.dtype == (torch.int64 if f in INT64_FIELDS else torch.float32) and t.is_contiguous(), (pre, leaf)
                 setattr(P.e[j], f, t.data_ptr())
     return P
 

@@ -92,7 +92,7 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None):
     E = module.num_multimodal_experts + module.num_singlemodal_experts
     probs = torch.empty(S, E, device=X.device, dtype=torch.float32)
     idx = torch.empty(S, device=X.device, dtype=torch.int64)
-    lb = torch.zeros((), device=X.device, dtype=torch.float32)
+    lb = torch.empty((), device=X.device, dtype=torch.float32)      # always written by the router's kernels (0 without the LB loss)
     if noise is not None:
         noise = noise.to(torch.float32).contiguous()
     st = L.avmoe_moe_forward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs),
@@ -172,6 +172,7 @@ class AdapterFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, X, Y, noise, names, *params):
         out, probs, idx, lb, state = _site_forward(module, X, Y, noise, names, params)
+        ctx.set_materialize_grads(False)                 # no zero tensors (= fill kernels) for the gradients of probs / idx / lb nobody sent
         ctx.module, ctx.names, ctx.state = module, names, state[:2]
         sink = getattr(module, "_grad_sink", None)
         if sink is not None and any(ctx.needs_input_grad[5:]):
@@ -183,6 +184,8 @@ class AdapterFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, _d_probs, _d_idx, d_lb):
         X, Y, *params = ctx.saved_tensors
+        if d_out is None:                                # only the load-balancing loss was differentiated
+            d_out = torch.zeros_like(X)
         dX, dY = torch.empty_like(X), torch.empty_like(Y)
         pg = _site_backward(ctx.module, (*ctx.state, X, Y), ctx.names, params, ctx.needs_input_grad[5:], d_out, d_lb, dX, dY)
         return (None, dX, dY, None, None) + pg
@@ -217,6 +220,7 @@ class _PairFunction(torch.autograd.Function):
         if dirty:
             ctx.mark_dirty(*dirty)
         ctx.has_base = (base_a is not None, base_b is not None)
+        ctx.set_materialize_grads(False)                 # no zero tensors (= fill kernels) for the gradients of the index outputs
         ctx.side = side
         ctx.sites, ctx.names, ctx.states = (site_a, site_b), (names_a, names_b), (st_a[:2], st_b[:2])
         for site, needs in ((site_a, ctx.needs_input_grad[9:9 + na]), (site_b, ctx.needs_input_grad[9 + na:])):
@@ -230,6 +234,8 @@ class _PairFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_a, d_b, _ia, _ib):
         Xa, Xb, *params = ctx.saved_tensors
+        d_a = torch.zeros_like(Xa) if d_a is None else d_a
+        d_b = torch.zeros_like(Xb) if d_b is None else d_b
         (site_a, site_b), (names_a, names_b) = ctx.sites, ctx.names
         na = len(names_a)
         gXa, gXb = torch.empty_like(Xa), torch.empty_like(Xb)
@@ -414,15 +420,16 @@ class MoEAdapter(nn.Module):
                         owners.append((mod, attr))
             if tuple(names) != tuple(k for k, _ in self.named_parameters()):
                 raise capi.AvmoeError("MoEAdapter: parameter registry does not match named_parameters() (parametrized module?)")
-            bufs = []                                                  # (key, owner module, attribute)
+            bufs, nbts = [], []                                        # (key, owner module, attribute): float buffers / int64 counters
             for mod_name, mod in self.named_modules():
                 for attr, b in mod._buffers.items():
                     if b is not None and b.is_floating_point():
                         bufs.append(((mod_name + "." if mod_name else "") + attr, mod, attr))
+                    elif b is not None and attr == "num_batches_tracked" and isinstance(mod, nn.BatchNorm2d):
+                        nbts.append(((mod_name + "." if mod_name else "") + attr, mod, attr))
             E_m, E_s = self.num_multimodal_experts, self.num_singlemodal_experts
-            c = dict(names=tuple(names), owners=owners, bufs=bufs, fill_p=cm.PtrFiller(names, E_m, E_s),
-                     fill_b=cm.PtrFiller([k for k, _, _ in bufs], E_m, E_s),
-                     bn=[m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None])
+            c = dict(names=tuple(names), owners=owners, bufs=bufs, nbts=nbts, fill_p=cm.PtrFiller(names, E_m, E_s),
+                     fill_b=cm.PtrFiller([k for k, _, _ in bufs], E_m, E_s), fill_n=cm.PtrFiller([k for k, _, _ in nbts], E_m, E_s))
             self.__dict__["_avmoe_cache"] = c
         return c
 
@@ -431,7 +438,7 @@ class MoEAdapter(nn.Module):
 
     def __getstate__(self):
         st = self.__dict__.copy()                                      # per-process bookkeeping does not travel (deepcopy / pickle)
-        for k in ("_avmoe_cache", "_nbt_flat", "_last_saved"):
+        for k in ("_avmoe_cache", "_last_saved"):
             st.pop(k, None)
         return st
 
@@ -455,6 +462,12 @@ class MoEAdapter(nn.Module):
             if b.dtype != torch.float32 or not b.is_contiguous():
                 raise capi.AvmoeError("BatchNorm running statistics must be contiguous float32 tensors")
         c["fill_b"].fill(P, bufs)
+        if self.training and self.use_bn and c["nbts"]:              # num_batches_tracked += 1 happens inside the forward's kernels (ABI 6)
+            cnts = [m._buffers[a] for _, m, a in c["nbts"]]
+            for t in cnts:
+                if t.dtype != torch.int64 or t.device != bufs[0].device:
+                    raise capi.AvmoeError("BatchNorm num_batches_tracked must be int64 tensors on the module's device")
+            c["fill_n"].fill(P, cnts)
         if keep:
             P2 = cm.make_ptrs(keep, self.num_multimodal_experts, self.num_singlemodal_experts)
             for j in range(self.num_multimodal_experts + self.num_singlemodal_experts):
@@ -471,23 +484,6 @@ class MoEAdapter(nn.Module):
             off += -(-v.numel() // align) * align
         return tuple(names), tuple(offs), off
 
-    def _bump_batches_tracked(self):
-        """num_batches_tracked += 1 of every BatchNorm of the site in ONE kernel: the buffers are kept as views of one
-        int64 tensor (rebuilt whenever .to() / load_state_dict detached them)."""
-        mods = self._site_cache()["bn"]
-        if not mods:
-            return
-        flat = self.__dict__.get("_nbt_flat")
-        ok = flat is not None and flat.numel() == len(mods) and all(
-            m._buffers["num_batches_tracked"].data_ptr() == flat.data_ptr() + 8 * i for i, m in enumerate(mods)) and \
-            mods[0]._buffers["num_batches_tracked"].device == flat.device
-        if not ok:
-            flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in mods])
-            for i, m in enumerate(mods):
-                m.num_batches_tracked = flat[i]
-            self.__dict__["_nbt_flat"] = flat
-        flat += 1
-
     def _buffer_tensors(self):
         return {k: v for k, v in self.named_buffers() if v.is_floating_point()}
 
@@ -498,9 +494,6 @@ class MoEAdapter(nn.Module):
         P = self._param_tensors()
         names = tuple(P.keys())
         out, probs, idx, lb = AdapterFunction.apply(self, X, Y, noise, names, *P.values())
-        if self.training and self.use_bn:
-            with torch.no_grad():
-                self._bump_batches_tracked()
         return out.permute(0, 2, 1).unsqueeze(-1), probs, idx, lb
 
     def forward(self, x, vis_token=None):
@@ -605,9 +598,5 @@ class AdapterPair(nn.Module):
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())
-        with torch.no_grad():
-            for m in (self.site_a, self.site_b):
-                if m.training and m.use_bn:
-                    m._bump_batches_tracked()
         return (out_a.permute(0, 2, 1).unsqueeze(-1), idx_a.unsqueeze(-1),
                 out_b.permute(0, 2, 1).unsqueeze(-1), idx_b.unsqueeze(-1))

@@ -30,36 +30,33 @@ static inline unsigned grid1db(long n, int cap = 4096) { return (unsigned)std::m
 
 // (the per-token backward kernels live in tile_kernels.hip; this file keeps their finalize / weight-space parts)
 
-// finalize: dusum, dvh (column sums), dp[s][e], dH1[e], dH2[e], grads.gate
+// finalize of POST_SMALL backward in ONE launch: the column sums of the per-block partials with their epilogue (dusum, dvh) and, in
+// E extra blocks, the per-expert sums over the frames: dp[s][e], dH1[e], dH2[e], grads.gate
 struct PostFinArgs { P16 gate; W16 ggate; int S, E, DZ, nblk, bps, use_gate; };
-__global__ void __launch_bounds__(256) kk_post_bwd_finalize(PostFinArgs a, const float* colpart, const float* blkscal,
-                                                            const float* probs, float* dsm, float* dp) {
+struct PostFin {
+  PostFinArgs a; const float* blkscal; const float* probs; float* dsm; float* dp;
   // dsm layout: [0]=dusum [1]=dvh [2]=dmz/NT [3]=mdy [4]=mdyz [5]=ddconst [6]=dwsum [7]=spare (each DZ) ; then dH1[E], dH2[E]
-  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {   // colpart = block-summed (k_reduce_colpart)
-    dsm[col] = colpart[col]; dsm[a.DZ + col] = 2.f * colpart[a.DZ + col];
-  }
-  if (blockIdx.x == 0) {
-    __shared__ float red[4];
-    for (int e = 0; e < a.E; ++e) {
-      float h1 = 0.f, h2 = 0.f, gsum = 0.f;
-      for (int s = threadIdx.x; s < a.S; s += 256) {
-        float dq = 0.f;
-        for (int b = 0; b < a.bps; ++b) {
-          const float* p = blkscal + (((long)s * a.bps + b) * a.E + e) * 4;
-          dq += p[0]; h1 += p[1]; h2 += p[2];
-        }
-        const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
-        dp[(long)s * a.E + e] = gate * dq;
-        gsum += probs[(long)s * a.E + e] * dq;
+  __device__ void operator()(int col, float s0, float s1) const { dsm[col] = s0; dsm[a.DZ + col] = 2.f * s1; }
+  template <int NTHR> __device__ void extra(int e, int) const {
+    __shared__ float red[NTHR / 64];
+    float h1 = 0.f, h2 = 0.f, gsum = 0.f;
+    const float gate = a.use_gate ? a.gate.p[e][0] : 1.f;
+    for (int s = threadIdx.x; s < a.S; s += NTHR) {
+      float dq = 0.f;
+      for (int b = 0; b < a.bps; ++b) {
+        const float* p = blkscal + (((long)s * a.bps + b) * a.E + e) * 4;
+        dq += p[0]; h1 += p[1]; h2 += p[2];
       }
-      h1 = block_sum256(h1, red); h2 = block_sum256(h2, red); gsum = block_sum256(gsum, red);
-      if (threadIdx.x == 0) {
-        dsm[8 * a.DZ + e] = h1; dsm[8 * a.DZ + a.E + e] = h2;
-        if (a.use_gate && a.ggate.p[e]) a.ggate.p[e][0] = gsum;
-      }
+      dp[(long)s * a.E + e] = gate * dq;
+      gsum += probs[(long)s * a.E + e] * dq;
+    }
+    h1 = block_sum_fixed<NTHR>(h1, red); h2 = block_sum_fixed<NTHR>(h2, red); gsum = block_sum_fixed<NTHR>(gsum, red);
+    if (threadIdx.x == 0) {
+      dsm[8 * a.DZ + e] = h1; dsm[8 * a.DZ + a.E + e] = h2;
+      if (a.use_gate && a.ggate.p[e]) a.ggate.p[e][0] = gsum;
     }
   }
-}
+};
 
 int k_post_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                               hipStream_t st) {
@@ -67,12 +64,9 @@ int k_post_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const 
   PostFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gate.p[e] = prm.e[e].gate; f.ggate.p[e] = grads.e[e].gate; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S; f.use_gate = d.use_gate;
-  AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
-  hipLaunchKernelGGL(kk_post_bwd_finalize, dim3(std::max(1, cdiv(d.DZ, 256))), dim3(256), 0, st, f,
-                     (const float*)(scratch + pl.o_colsum), (const float*)(scratch + pl.o_blkscal),
-                     (const float*)(saved + pl.o_probs), (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_dp));
-  AVMOE_CHECK_LAUNCH("post_small_bwd");
-  return OK;
+  return launch_colsum_fin((const float*)(scratch + pl.o_colpart), d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ,
+                           PostFin{f, (const float*)(scratch + pl.o_blkscal), (const float*)(saved + pl.o_probs), (float*)(scratch + pl.o_dsm),
+                                   (float*)(scratch + pl.o_dp)}, st, d.E);
 }
 
 // (POST_PREP backward lives in weight_kernels.hip)
@@ -84,7 +78,7 @@ struct MidBwdArgs {
   int relu_of_e[MAX_E]; W16 gw1, gb1;
   int S, N, E, DD, DZ, dgp, dg, g, NT, use_bn, training, nblk;
 };
-struct MidBwdFin {      // epilogue of the column sums (slots 2, 3 of the per-block partials) -- colsum_fin.h
+struct MidBwdFin : NoExtra {      // epilogue of the column sums (slots 2, 3 of the per-block partials) -- colsum_fin.h
   MidBwdArgs a; float* dsm;
   __device__ void operator()(int col, float cs0, float cs1) const {
   const double s0 = cs0, s1 = cs1;
@@ -105,47 +99,47 @@ int k_mid_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_m
   a.S = d.S; a.N = d.N; a.E = d.E; a.DD = d.DD; a.DZ = d.DZ; a.dgp = d.dgp; a.dg = d.dg; a.g = d.g; a.NT = d.NT;
   a.use_bn = d.use_bn; a.training = d.training; a.nblk = d.nblk_tok;
   return launch_colsum_fin((const float*)(scratch + pl.o_colpart) + 2L * d.DZ, d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ,
-                           MidBwdFin{a, (float*)(scratch + pl.o_dsm)}, st);
+                           MidBwdFin{{}, a, (float*)(scratch + pl.o_dsm)}, st);
 }
 
 // ---------------------------------------------------------------------------------------------
 // PRE_SMALL backward: BN1 input gradient, folded-LayerNorm statistics, hop-2 softmax.
 // ---------------------------------------------------------------------------------------------
+// finalize in ONE launch: the column sums of the per-block partials (ddconst, dwsum) and, in extra blocks, one per expert with a
+// latent / attention gate (its gradient: a sum over the blocks' scalars) and a few for dtbar[s][kc] = sum over the frame's blocks
 struct PreFinArgs { W16 gglat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int S, E, DZ, KL, nblk, bps; };
-__global__ void __launch_bounds__(256) kk_pre_bwd_finalize(PreFinArgs a, const float* colpart, const float* blkscal,
-                                                           const float* dtbp, float* dsm, float* dtbar) {
-  for (int col = blockIdx.x * 256 + threadIdx.x; col < a.DZ; col += gridDim.x * 256) {   // block-summed (k_reduce_colpart)
-    dsm[5 * a.DZ + col] = colpart[col]; dsm[6 * a.DZ + col] = colpart[a.DZ + col];
-  }
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)a.S * a.KL; i += (long)gridDim.x * 256) {
-    const int s = (int)(i / a.KL), kc = (int)(i % a.KL);
-    float acc = 0.f;
-    for (int b = 0; b < a.bps; ++b) acc += dtbp[((long)s * a.bps + b) * a.KL + kc];
-    dtbar[i] = acc;
-  }
-  if (blockIdx.x == 0) {
-    __shared__ float red[4];
-    for (int e = 0; e < a.E; ++e) {
-      if (a.lat_of_e[e] < 0 && !a.nxn_of_e[e]) continue;
+struct PreFin {
+  PreFinArgs a; const float* blkscal; const float* dtbp; float* dsm; float* dtbar;
+  __device__ void operator()(int col, float s0, float s1) const { dsm[5 * a.DZ + col] = s0; dsm[6 * a.DZ + col] = s1; }
+  template <int NTHR> __device__ void extra(int bx, int nextra) const {
+    if (bx < a.E) {
+      __shared__ float red[NTHR / 64];
+      const int e = bx;
+      if (a.lat_of_e[e] < 0 && !a.nxn_of_e[e]) return;
       float acc = 0.f;
-      for (int b = threadIdx.x; b < a.nblk; b += 256) acc += blkscal[((long)b * a.E + e) * 4 + 3];
-      acc = block_sum256(acc, red);
+      for (int b = threadIdx.x; b < a.nblk; b += NTHR) acc += blkscal[((long)b * a.E + e) * 4 + 3];
+      acc = block_sum_fixed<NTHR>(acc, red);
       if (threadIdx.x == 0 && a.gglat.p[e]) a.gglat.p[e][0] = acc;
+      return;
+    }
+    for (long i = (long)(bx - a.E) * NTHR + threadIdx.x; i < (long)a.S * a.KL; i += (long)(nextra - a.E) * NTHR) {
+      const int s = (int)(i / a.KL), kc = (int)(i % a.KL);
+      float acc = 0.f;
+      for (int b = 0; b < a.bps; ++b) acc += dtbp[((long)s * a.bps + b) * a.KL + kc];
+      dtbar[i] = acc;
     }
   }
-}
+};
 int k_pre_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                              hipStream_t st) {
   const Dims& d = pl.d;
   PreFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gglat.p[e] = grads.e[e].gate_lat; f.lat_of_e[e] = d.lat_of_e[e]; f.nxn_of_e[e] = d.nxn_of_e[e]; }
   f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.KL = d.KL; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S;
-  AVMOE_TRY(k_reduce_colpart(pl, scratch, 0, 2, st));
-  hipLaunchKernelGGL(kk_pre_bwd_finalize, dim3(std::max(1, cdiv(std::max((long)d.DZ, (long)d.S * d.KL), 256))), dim3(256), 0, st, f,
-                     (const float*)(scratch + pl.o_colsum), (const float*)(scratch + pl.o_blkscal),
-                     (const float*)(scratch + pl.o_dtbp), (float*)(scratch + pl.o_dsm), (float*)(scratch + pl.o_dtbar));
-  AVMOE_CHECK_LAUNCH("pre_small_bwd");
-  return OK;
+  const int nb_dtbar = d.KL > 0 ? std::max(1, std::min(64, cdiv((long)d.S * d.KL, 1024))) : 0;
+  return launch_colsum_fin((const float*)(scratch + pl.o_colpart), d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ,
+                           PreFin{f, (const float*)(scratch + pl.o_blkscal), (const float*)(scratch + pl.o_dtbp), (float*)(scratch + pl.o_dsm),
+                                  (float*)(scratch + pl.o_dtbar)}, st, d.E + nb_dtbar);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -153,79 +147,116 @@ int k_pre_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const a
 // rbw layout: dlog [S][E] | dh2r [S][32] | dh1 [S][128] | drin [S][2C]
 // ---------------------------------------------------------------------------------------------
 struct RouterBwdArgs { const float *W1, *W2, *W3; int C2, E, S, lb_loss; const float* lb_grad; };
-__global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const float* probs, const float* dp, const float* rh1,
-                                                       const float* rh2, float* rbw, void* drinT_, int bf16, void* Text_, int KLT,
-                                                       int KL, int C, int N) {
-  __shared__ float s_dl[MAX_E], s_d2[32], s_d1[128], s_pm[MAX_E];
-  const int s = blockIdx.x;
-  float* dh1 = rbw + (long)s * 128;
-  float* dh2 = rbw + (long)a.S * (128 + a.C2) + (long)s * 32;
-  float* dlog = rbw + (long)a.S * (128 + a.C2 + 32) + (long)s * a.E;
+// Launch 1 of 2, RBF frames per block: dlog / dh2 / dh1 of every frame (softmax, LB loss, the two small layers), then the input
+// gradient drin = dh1 W1 -- thread per input column, the rows of W1 read coalesced and once per block for all its frames --,
+// kept in fp32 (dm2 is consumed by k_finish_dT) with dm1 / N written into the extra row of Text[s] (operand of the dX GEMM).
+constexpr int RBF = 4;
+__global__ void __launch_bounds__(256) kk_router_bwd_in(RouterBwdArgs a, const float* probs, const float* dp, const float* rh1,
+                                                        const float* rh2, float* rbw, int bf16, void* Text_, int KLT, int KL, int C, int N) {
+  __shared__ float s_dl[RBF][MAX_E], s_d2[RBF][32], s_d1[RBF][128], s_pm[MAX_E];
+  const int s0 = blockIdx.x * RBF, nf = min(RBF, a.S - s0), t = threadIdx.x;
+  float* dh1_g = rbw;
+  float* drin_g = rbw + (long)a.S * 128;
+  float* dh2_g = rbw + (long)a.S * (128 + a.C2);
+  float* dlog_g = rbw + (long)a.S * (128 + a.C2 + 32);
   if (a.lb_loss && a.lb_grad) {                  // column means of p for the LB loss: 256 / 16 frame streams per expert
     __shared__ float s_part[16][MAX_E];
-    const int e = threadIdx.x % MAX_E, u = threadIdx.x / MAX_E;
+    const int e = t % MAX_E, u = t / MAX_E;
     float acc = 0.f;
     if (e < a.E) for (int ss = u; ss < a.S; ss += 16) acc += probs[(long)ss * a.E + e];
     s_part[u][e] = acc;
     __syncthreads();
-    if (threadIdx.x < a.E) {
-      float t = 0.f;
-      for (int k = 0; k < 16; ++k) t += s_part[k][threadIdx.x];
-      s_pm[threadIdx.x] = t / (float)a.S;
+    if (t < a.E) {
+      float tt = 0.f;
+      for (int k = 0; k < 16; ++k) tt += s_part[k][t];
+      s_pm[t] = tt / (float)a.S;
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (t < nf) {
+    const int s = s0 + t;
     float dot = 0.f, dpv[MAX_E];
     for (int e = 0; e < a.E; ++e) {
       dpv[e] = dp[(long)s * a.E + e];
       if (a.lb_loss && a.lb_grad) dpv[e] += a.lb_grad[0] * (-1.f / ((float)a.S * s_pm[e]));
       dot += probs[(long)s * a.E + e] * dpv[e];
     }
-    for (int e = 0; e < a.E; ++e) { const float v = probs[(long)s * a.E + e] * (dpv[e] - dot); s_dl[e] = v; dlog[e] = v; }
+    for (int e = 0; e < a.E; ++e) { const float v = probs[(long)s * a.E + e] * (dpv[e] - dot); s_dl[t][e] = v; dlog_g[(long)s * a.E + e] = v; }
   }
   __syncthreads();
-  if (threadIdx.x < 32) {
-    float acc = 0.f;
-    for (int e = 0; e < a.E; ++e) acc += s_dl[e] * a.W3[e * 32 + threadIdx.x];
-    const float v = rh2[(long)s * 32 + threadIdx.x] > 0.f ? acc : 0.f;
-    s_d2[threadIdx.x] = v; dh2[threadIdx.x] = v;
+  if (t < RBF * 32) {
+    const int f = t >> 5, o = t & 31;
+    float v = 0.f;
+    if (f < nf) {
+      float acc = 0.f;
+      for (int e = 0; e < a.E; ++e) acc += s_dl[f][e] * a.W3[e * 32 + o];
+      v = rh2[(long)(s0 + f) * 32 + o] > 0.f ? acc : 0.f;
+      dh2_g[(long)(s0 + f) * 32 + o] = v;
+    }
+    s_d2[f][o] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 128) {
-    float acc = 0.f;
-    for (int j = 0; j < 32; ++j) acc += s_d2[j] * a.W2[j * 128 + threadIdx.x];
-    const float v = rh1[(long)s * 128 + threadIdx.x] > 0.f ? acc : 0.f;
-    s_d1[threadIdx.x] = v; dh1[threadIdx.x] = v;
+  for (int i = t; i < RBF * 128; i += 256) {
+    const int f = i >> 7, o = i & 127;
+    float v = 0.f;
+    if (f < nf) {
+      float acc = 0.f;
+      for (int j = 0; j < 32; ++j) acc += s_d2[f][j] * a.W2[j * 128 + o];
+      v = rh1[(long)(s0 + f) * 128 + o] > 0.f ? acc : 0.f;
+      dh1_g[(long)(s0 + f) * 128 + o] = v;
+    }
+    s_d1[f][o] = v;
   }
   __syncthreads();
-}
-// drin (engine GEMM output) -> T copy for the GEMMs that consume dm2, and dm1 / N into the extra row of Text[s]
-__global__ void kk_router_bwd_c(const float* drin, void* drinT_, int bf16, void* Text_, int S, int C2, int KLT, int KL, int C, int N) {
-  const long total = (long)S * C2;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int s = (int)(idx / C2), i = (int)(idx % C2);
-    const float acc = drin[idx];
-    if (bf16) ((unsigned short*)drinT_)[idx] = f2bf(acc); else ((float*)drinT_)[idx] = acc;
-    if (i < C) {
-      const long o = ((long)s * KLT + KL + 1) * C + i;
-      const float v = acc / (float)N;
-      if (bf16) ((unsigned short*)Text_)[o] = f2bf(v); else ((float*)Text_)[o] = v;
+  const float invN = 1.f / (float)N;
+  for (int i = t; i < a.C2; i += 256) {
+    float acc[RBF];
+#pragma unroll
+    for (int f = 0; f < RBF; ++f) acc[f] = 0.f;
+    for (int j = 0; j < 128; ++j) {
+      const float w = a.W1[(long)j * a.C2 + i];
+#pragma unroll
+      for (int f = 0; f < RBF; ++f) acc[f] += s_d1[f][j] * w;
+    }
+#pragma unroll
+    for (int f = 0; f < RBF; ++f) {
+      if (f < nf) {
+        const int s = s0 + f;
+        drin_g[(long)s * a.C2 + i] = acc[f];
+        if (i < C) {
+          const long o = ((long)s * KLT + KL + 1) * C + i;
+          const float v = acc[f] * invN;
+          if (bf16) ((unsigned short*)Text_)[o] = f2bf(v); else ((float*)Text_)[o] = v;
+        }
+      }
     }
   }
 }
-// weight gradients: thread per weight element, loop over frames
-__global__ void __launch_bounds__(256) kk_router_bwd_b(int S, int E, int C2, const float* rbw, const float* rin, const float* rh1, const float* rh2,
-                                                       float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
-  // dW1 = dh1^T rin is an engine GEMM (k_router_bwd); here the small layers: one output per lane, 4 frame streams per
-  // output, combined through LDS in a fixed order
+// Launch 2 of 2, the router's weight gradients: blocks [0, nb_w1) own 64 columns x 4 rows of dW1 = dh1^T rin (sum over the frames,
+// in frame order: one thread per element), the others the two small layers and the biases (one output per lane, 4 frame streams per
+// output, combined through LDS in a fixed order)
+__global__ void __launch_bounds__(256) kk_router_bwd_w(int S, int E, int C2, int nb_w1, const float* rbw, const float* rin, const float* rh1,
+                                                       const float* rh2, float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
   __shared__ float red[4][64];
   const float* dh1 = rbw;
   const float* dh2 = rbw + (long)S * (128 + C2);
   const float* dlog = rbw + (long)S * (128 + C2 + 32);
-  const int n2 = 32 * 128, n3 = E * 32, nb = 128 + 32 + E;
   const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + l;
+  if ((int)blockIdx.x < nb_w1) {
+    if (!gW1) return;
+    const int cblocks = (C2 + 63) / 64;
+    const int cb = blockIdx.x % cblocks, jb = blockIdx.x / cblocks;
+    const int i = cb * 64 + l, j = jb * 4 + u;
+    if (i >= C2) return;
+    float a0 = 0.f, a1 = 0.f;
+    int s = 0;
+    for (; s + 1 < S; s += 2) { a0 += dh1[(long)s * 128 + j] * rin[(long)s * C2 + i]; a1 += dh1[(long)(s + 1) * 128 + j] * rin[(long)(s + 1) * C2 + i]; }
+    if (s < S) a0 += dh1[(long)s * 128 + j] * rin[(long)s * C2 + i];
+    gW1[(long)j * C2 + i] = a0 + a1;
+    return;
+  }
+  const int n2 = 32 * 128, n3 = E * 32, nb = 128 + 32 + E;
+  const int i = (blockIdx.x - nb_w1) * 64 + l;
   float acc = 0.f;
   float* dst = nullptr;
   if (i < n2) {
@@ -251,31 +282,12 @@ int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   ProfScope ps_("k_router_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   RouterBwdArgs a{prm.r0_w, prm.r2_w, prm.r4_w, 2 * d.C, d.E, d.S, d.lb_loss, lb_grad};
-  hipLaunchKernelGGL(kk_router_bwd_a, dim3(d.S), dim3(256), 0, st, a, (const float*)(saved + pl.o_probs),
+  hipLaunchKernelGGL(kk_router_bwd_in, dim3(cdiv(d.S, RBF)), dim3(256), 0, st, a, (const float*)(saved + pl.o_probs),
                      (const float*)(scratch + pl.o_dp), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
-                     (float*)(scratch + pl.o_rbw), (void*)(scratch + pl.o_drinT), d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL,
-                     d.C, d.N);
-  float* rbw = (float*)(scratch + pl.o_rbw);
-  float* dh1 = rbw;
-  float* drin = rbw + (long)d.S * 128;
-  {   // drin = dh1 W1   (fp32 engine GEMM)
-    GemmArgs g;
-    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
-    g.A = dh1; g.B = prm.r0_w; g.C = drin;
-    g.M = d.S; g.N = 2 * d.C; g.K = 128; g.lda = 128; g.b_layout = MN_MAJOR; g.ldb = 2L * d.C; g.sCi = 2L * d.C; g.tile = 64;
-    AVMOE_TRY(launch_gemm(g, st));
-  }
-  hipLaunchKernelGGL(kk_router_bwd_c, dim3(grid1db((long)d.S * 2 * d.C)), dim3(256), 0, st, (const float*)drin, (void*)(scratch + pl.o_drinT),
-                     d.bf16, (void*)(saved + pl.o_Text), d.S, 2 * d.C, d.KLT, d.KL, d.C, d.N);
-  if (grads.r0_w) {   // dW1 = dh1^T rin
-    GemmArgs g;
-    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
-    g.A = dh1; g.B = saved + pl.o_rin; g.C = grads.r0_w;
-    g.M = 128; g.N = 2 * d.C; g.K = d.S; g.a_layout = g.b_layout = MN_MAJOR; g.lda = 128; g.ldb = 2L * d.C; g.sCi = 2L * d.C;
-    g.tile = 64; g.slabs = (float*)(scratch + pl.o_slabs); g.ksplit = choose_ksplit(g, slab_floats(d));
-    AVMOE_TRY(launch_gemm(g, st));
-  }
-  hipLaunchKernelGGL(kk_router_bwd_b, dim3((unsigned)cdiv(32 * 128 + d.E * 32 + 160 + d.E, 64)), dim3(256), 0, st, d.S, d.E, 2 * d.C, (const float*)(scratch + pl.o_rbw),
+                     (float*)(scratch + pl.o_rbw), d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL, d.C, d.N);
+  const int nb_w1 = cdiv(2 * d.C, 64) * 32;                 // 64 columns x 4 rows of dW1 per block, 128 rows
+  const int nb_small = cdiv(32 * 128 + d.E * 32 + 160 + d.E, 64);
+  hipLaunchKernelGGL(kk_router_bwd_w, dim3((unsigned)(nb_w1 + nb_small)), dim3(256), 0, st, d.S, d.E, 2 * d.C, nb_w1, (const float*)(scratch + pl.o_rbw),
                      (const float*)(saved + pl.o_rin), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
                      grads.r0_w, grads.r0_b, grads.r2_w, grads.r2_b, grads.r4_w, grads.r4_b);
   AVMOE_CHECK_LAUNCH("router_bwd");
@@ -345,37 +357,42 @@ __global__ void __launch_bounds__(256) kk_finish_dT(const float* dT, const float
     }
   }
 }
-// dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)   block = 64 columns x 4 frame streams (two loads in flight each),
-// combined through LDS in a fixed order
-__global__ void __launch_bounds__(256) kk_dT0(const float* dT, const float* dtbar, float* dT0, int S, int KL, int C) {
-  __shared__ float red[4][64];
-  const long n1 = (long)KL * C;
-  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + l;
-  float a0 = 0.f, a1 = 0.f;
-  if (i < n1) {
-    const int kc = (int)(i / C);
-    const float ic = 1.f / (float)C;
-    int s = u;
-    for (; s + 4 < S; s += 8) {
-      a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
-      a1 += dT[(long)(s + 4) * n1 + i] + dtbar[(long)(s + 4) * KL + kc] * ic;
-    }
-    for (; s < S; s += 4) a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
-  }
-  red[u][l] = a0 + a1;
-  __syncthreads();
-  if (u == 0 && i < n1) dT0[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-}
-// drw[c] = sum_r dTy[r][c] abx[r] ; dbf[c] = sum_r dTy[r][c]   over the S*Kcyb rows r, in two stages:
-// grid (ceil(C/256), nchunk) -> rowpart[chunk][2][C], then a sum over chunks.
+// Two independent sums over the frames in ONE launch:
+//   blocks [0, nb0): dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)   block = 64 columns x 4 frame streams (two loads in flight each),
+//                    combined through LDS in a fixed order
+//   the others:      drw[c] = sum_r dTy[r][c] abx[r] ; dbf[c] = sum_r dTy[r][c]   over the S*Kcyb rows r, first stage: block (channel
+//                    tile cx, chunk) -> rowpart[chunk][2][C] (a sum over the chunks follows)
 template <typename T>
-__global__ void __launch_bounds__(256) kk_dTy_colsums_a(const void* dTy_, const void* BmX_, const float* scal, float* rowpart, long rows,
-                                                        int rows_per_chunk, int Kcy, int Kcyb, int C, int Mb, int M) {
+__global__ void __launch_bounds__(256) kk_dT0_dTy(const float* dT, const float* dtbar, float* dT0, int S, int KL, int C, int nb0,
+                                                  const void* dTy_, const void* BmX_, const float* scal, float* rowpart, long rows,
+                                                  int rows_per_chunk, int Kcy, int Kcyb, int Mb, int M) {
+  if ((int)blockIdx.x < nb0) {
+    __shared__ float red[4][64];
+    const long n1 = (long)KL * C;
+    const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + l;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n1) {
+      const int kc = (int)(i / C);
+      const float ic = 1.f / (float)C;
+      int s = u;
+      for (; s + 4 < S; s += 8) {
+        a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
+        a1 += dT[(long)(s + 4) * n1 + i] + dtbar[(long)(s + 4) * KL + kc] * ic;
+      }
+      for (; s < S; s += 4) a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
+    }
+    red[u][l] = a0 + a1;
+    __syncthreads();
+    if (u == 0 && i < n1) dT0[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    return;
+  }
   const T* dTy = (const T*)dTy_; const T* BmX = (const T*)BmX_;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int ncx = (C + 255) / 256;
+  const int bx = ((int)blockIdx.x - nb0) % ncx, by = ((int)blockIdx.x - nb0) / ncx;
+  const int c = bx * 256 + threadIdx.x;
   if (c >= C) return;
-  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  const long r0 = (long)by * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float drw = 0.f, dbf = 0.f;
   for (long r = r0; r < r1; ++r) {
     const int q = (int)(r % Kcyb);
@@ -383,8 +400,8 @@ __global__ void __launch_bounds__(256) kk_dTy_colsums_a(const void* dTy_, const 
     const float ab = q < Kcy ? ldT<T>(BmX, r * Mb + M) : scal[0];
     drw += v * ab; dbf += v;
   }
-  rowpart[((long)blockIdx.y * 2 + 0) * C + c] = drw;
-  rowpart[((long)blockIdx.y * 2 + 1) * C + c] = dbf;
+  rowpart[((long)by * 2 + 0) * C + c] = drw;
+  rowpart[((long)by * 2 + 1) * C + c] = dbf;
 }
 // dBmT = T([dBm | dabx | 0])   (one block per (frame, latent row));  dwbar[m] = sum_s dBm[s][Kcy][m] and
 // dbcbar = sum_s dabx[s][Kcy] are column sums over the frames (k_prep_dBm)
@@ -620,16 +637,15 @@ int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   DISPATCH_T(d.bf16, kk_finish_dT, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st,
              (const float*)(scratch + pl.o_dT), (const float*)(scratch + pl.o_dtbar), drin, (const float*)(saved + pl.o_rw),
              (void*)(scratch + pl.o_dTy), (void*)(scratch + pl.o_dTx), (float*)(scratch + pl.o_dabx), d.S, d.KL, d.Kcy, d.Kcyb, d.Kcx, d.C);
-  if (d.KL > 0)
-    hipLaunchKernelGGL(kk_dT0, dim3((unsigned)cdiv((long)d.KL * d.C, 64)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
-                       (const float*)(scratch + pl.o_dtbar), (float*)(scratch + pl.o_dT0), d.S, d.KL, d.C);
   {
     const long nrows = (long)d.S * d.Kcyb;
     const int nchunk = (int)std::min<long>(512, std::max<long>(1, nrows / 8));      // (short serial chains per thread: 8 rows, or nrows / 512 when there are many)
     const int rpc = cdiv(nrows, nchunk);
-    DISPATCH_T(d.bf16, kk_dTy_colsums_a, dim3(cdiv(d.C, 256), nchunk), dim3(256), 0, st, (const void*)(scratch + pl.o_dTy),
+    const int nb0 = d.KL > 0 ? cdiv((long)d.KL * d.C, 64) : 0;
+    DISPATCH_T(d.bf16, kk_dT0_dTy, dim3((unsigned)(nb0 + cdiv(d.C, 256) * nchunk)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
+               (const float*)(scratch + pl.o_dtbar), (float*)(scratch + pl.o_dT0), d.S, d.KL, d.C, nb0, (const void*)(scratch + pl.o_dTy),
                (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_scal), (float*)(scratch + pl.o_rowpart), nrows, rpc,
-               d.Kcy, d.Kcyb, d.C, d.Mb, d.M);
+               d.Kcy, d.Kcyb, d.Mb, d.M);
     AVMOE_TRY(k_colsum_f32((const float*)(scratch + pl.o_rowpart), nchunk, 2 * d.C, 2L * d.C, 1, 0, (float*)(scratch + pl.o_dvec), 0, 1.f, st));
   }
   AVMOE_CHECK_LAUNCH("finish_dT");

@@ -149,76 +149,88 @@ int k_cast(int bf16_out, const float* src, long rows, int cols, long ld_src, voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight preparation: remap operands   (conv_adapter / fc: net_trans_v3.py:445-446,469-470)
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void kk_prep_remap(const float* Wc, const float* bc, const float* Wf, void* WcK_, void* WcT_, void* WfT_,
-                              int N, int M, int Mk, int Np, int C, int Cy) {
-  T* WcK = (T*)WcK_; T* WcT = (T*)WcT_; T* WfT = (T*)WfT_;
-  const long n1 = (long)N * Mk, n2 = (long)(M + 1) * Np, n3 = (long)C * Cy;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3; i += (long)gridDim.x * 256) {
-    if (i < n1) {                                   // WcK[n] = [Wc[n,:] | bc[n] | 1 | 0..]
-      const int n = (int)(i / Mk), m = (int)(i % Mk);
-      stT<T>(WcK, i, m < M ? Wc[(long)n * M + m] : (m == M ? bc[n] : (m == M + 1 ? 1.f : 0.f)));
-    } else if (i < n1 + n2) {                       // WcT[m] = Wc[:,m]^T ; row M = bc
-      const long j = i - n1;
-      const int m = (int)(j / Np), n = (int)(j % Np);
-      stT<T>(WcT, j, n < N ? (m < M ? Wc[(long)n * M + m] : bc[n]) : 0.f);
-    } else {
-      const long j = i - n1 - n2;
-      stT<T>(WfT, j, Wf[j]);
-    }
-  }
-}
-
-// rw[c] = sum_y WfT[c][y] (T-rounded weights, so the folded bias matches the GEMM operands); one wave per row
-template <typename T>
-__global__ void kk_prep_remap2(const void* WfT_, float* rw, int C, int Cy) {
-  const T* WfT = (const T*)WfT_;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
-    float s = 0.f;
-    for (int y = lane; y < Cy; y += 64) s += ldT<T>(WfT, (long)c * Cy + y);
-    s = wave_sum(s);
-    if (lane == 0) rw[c] = s;
-  }
-}
-
-int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, const float* Wf, hipStream_t st) {
-  ProfScope ps_("k_prep_remap", 0.0, 0.0, st);
-  const Dims& d = pl.d;
-  if (!Wc || !bc || !Wf) { set_last_error("moe: conv_adapter / fc parameters missing"); return ERR_BAD_ARG; }
-  const long tot = (long)d.N * d.Mk + (long)(d.M + 1) * d.Np + (long)d.C * d.Cy;
-  DISPATCH_T(d.bf16, kk_prep_remap, dim3(grid1d(tot)), dim3(256), 0, st, Wc, bc, Wf, (void*)(saved + pl.o_WcK),
-             (void*)(saved + pl.o_WcT), (void*)(saved + pl.o_WfT), d.N, d.M, d.Mk, d.Np, d.C, d.Cy);
-  DISPATCH_T(d.bf16, kk_prep_remap2, dim3(cdiv(d.C, 4)), dim3(256), 0, st, (const void*)(saved + pl.o_WfT), (float*)(saved + pl.o_rw), d.C, d.Cy);
-  {   // wbar[m] = mean_n Wc[n][m] (padding zero) ; scal[0] = mean(bc)
-    hipError_t e__ = hipMemsetAsync(saved + pl.o_wbar, 0, (size_t)d.Mb * 4, st);
-    if (e__ != hipSuccess) { set_last_error("memset: %s", hipGetErrorString(e__)); return ERR_LAUNCH; }
-    AVMOE_TRY(k_colsum2_f32(Wc, d.N, d.M, d.M, (float*)(saved + pl.o_wbar), 1.f / (float)d.N,
-                            bc, d.N, 1, 1, (float*)(saved + pl.o_scal), 1.f / (float)d.N, st));
-  }
-  AVMOE_CHECK_LAUNCH("prep_remap");
-  return OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight preparation: experts.  One block per row (i, e, jp) of Wt = Wd * gamma_before  (LayerNorm
-// folded into the down projection: net_trans_v3.py:392-395), plus the stacked latent tokens in T.
+// weight preparation -- ONE launch, every block picks its job from its index (the jobs are independent):
+//   remap operands  WcK / WcT / WfT in T, rw = Wf 1, wbar = mean_n Wc, mean(bc)     (conv_adapter / fc: net_trans_v3.py:445-446,469-470)
+//   experts         Wt = Wd * gamma_before (LayerNorm folded into the down projection: net_trans_v3.py:392-395), wsum, dconst,
+//                   the stacked latent tokens in T
+//   constants       the ones row and the (forward: zero) dm1 / N row of every frame's Text, with their row sums
 // ---------------------------------------------------------------------------------------------
 struct PrepExpArgs {
   P16 down, lnbw, lnbb, tok;
   int e_of_lat[MAX_E];
   int E, g, dg, dgp, Cg, C, K, Kp, KL, ln_before;
 };
+struct PrepAllArgs {
+  const float *Wc, *bc, *Wf;
+  int N, M, Mk, Mb, Np, C, Cy, S, KL, KLT;
+  int b_rw, b_wbar, b_scal, b_exp, b_const, b_end;      // first block of every job after the casts (which own [0, b_rw))
+  PrepExpArgs x;
+};
 
 template <typename T>
-__global__ void __launch_bounds__(256) kk_prep_experts(PrepExpArgs a, void* Wt_, float* wsum, float* dconst, void* T0T_) {
-  T* Wt = (T*)Wt_; T* T0T = (T*)T0T_;
+__device__ __forceinline__ void prep_remap_cast(const PrepAllArgs& a, T* WcK, T* WcT, T* WfT, int bx, int nbx) {
+  const long n1 = (long)a.N * a.Mk, n2 = (long)(a.M + 1) * a.Np, n3 = (long)a.C * a.Cy;
+  for (long i = (long)bx * 256 + threadIdx.x; i < n1 + n2 + n3; i += (long)nbx * 256) {
+    if (i < n1) {                                   // WcK[n] = [Wc[n,:] | bc[n] | 1 | 0..]
+      const int n = (int)(i / a.Mk), m = (int)(i % a.Mk);
+      stT<T>(WcK, i, m < a.M ? a.Wc[(long)n * a.M + m] : (m == a.M ? a.bc[n] : (m == a.M + 1 ? 1.f : 0.f)));
+    } else if (i < n1 + n2) {                       // WcT[m] = Wc[:,m]^T ; row M = bc
+      const long j = i - n1;
+      const int m = (int)(j / a.Np), n = (int)(j % a.Np);
+      stT<T>(WcT, j, n < a.N ? (m < a.M ? a.Wc[(long)n * a.M + m] : a.bc[n]) : 0.f);
+    } else {
+      const long j = i - n1 - n2;
+      stT<T>(WfT, j, a.Wf[j]);
+    }
+  }
+}
+// rw[c] = sum_y T(Wf[c][y]) (T-rounded weights, so the folded bias matches the GEMM operands); one wave per row
+template <typename T>
+__device__ __forceinline__ void prep_rw(const PrepAllArgs& a, float* rw, int bx) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = bx * 4 + wave;
+  if (c >= a.C) return;
+  float s = 0.f;
+  for (int y = lane; y < a.Cy; y += 64) s += roundT<T>(a.Wf[(long)c * a.Cy + y]);
+  s = wave_sum(s);
+  if (lane == 0) rw[c] = s;
+}
+// wbar[m] = mean_n Wc[n][m], zero in the padding m >= M: a block owns 16 columns x 16 row streams (stream k adds rows k, k + 16, ..),
+// combined in double in a fixed order (no float atomics: bit-reproducible)
+__device__ __forceinline__ void prep_wbar(const PrepAllArgs& a, float* wbar, int bx) {
+  __shared__ double red[16][16];
+  const int c = threadIdx.x & 15, k = threadIdx.x >> 4;
+  const int m = bx * 16 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (m < a.M) {
+    int n = k;
+    for (; n + 16 < a.N; n += 32) { a0 += a.Wc[(long)n * a.M + m]; a1 += a.Wc[(long)(n + 16) * a.M + m]; }
+    for (; n < a.N; n += 16) a0 += a.Wc[(long)n * a.M + m];
+  }
+  red[k][c] = (double)a0 + (double)a1;
+  __syncthreads();
+  if (k == 0 && m < a.Mb) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][c];
+    wbar[m] = m < a.M ? (float)(t / a.N) : 0.f;
+  }
+}
+// scal[0] = mean(bc) ; scal[1] = 1 (the unit gate of the "v1" experts, moe_forward.cpp::with_unit_gates)
+__device__ __forceinline__ void prep_scal(const PrepAllArgs& a, float* scal) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < a.N; n += 256) acc += a.bc[n];
+  acc = block_sum256(acc, red);
+  if (threadIdx.x == 0) { scal[0] = acc / (float)a.N; scal[1] = 1.f; }
+}
+// one block per row (i, e, jp) of Wt, then one per stacked latent-token row
+template <typename T>
+__device__ __forceinline__ void prep_experts(const PrepExpArgs& a, T* Wt, float* wsum, float* dconst, T* T0T, int bx) {
   __shared__ float red[4];
   const int nrow = a.g * a.E * a.dgp;
-  if ((int)blockIdx.x < nrow) {
-    const int row = blockIdx.x;
+  if (bx < nrow) {
+    const int row = bx;
     const int i = row / (a.E * a.dgp), e = (row / a.dgp) % a.E, jp = row % a.dgp;
     const float* Wd = a.down.p[e];
     float s1 = 0.f, s2 = 0.f;
@@ -235,7 +247,7 @@ __global__ void __launch_bounds__(256) kk_prep_experts(PrepExpArgs a, void* Wt_,
     s2 = block_sum256(s2, red);
     if (threadIdx.x == 0) { wsum[row] = s1; dconst[row] = s2; }
   } else {
-    const int r = blockIdx.x - nrow;
+    const int r = bx - nrow;
     if (r < a.KL) {
       const int l = r / a.Kp, k = r % a.Kp;
       const float* tk = a.tok.p[a.e_of_lat[l]];
@@ -243,14 +255,42 @@ __global__ void __launch_bounds__(256) kk_prep_experts(PrepExpArgs a, void* Wt_,
     }
   }
 }
+// Text[s][KL][:] = 1 (ones row), Text[s][KL+1][:] = 0 (dm1 / N row, written by the backward) and their row sums in Tsum
+template <typename T>
+__device__ __forceinline__ void prep_const_rows(const PrepAllArgs& a, T* Text, float* Tsum, int bx, int nbx) {
+  const long n3 = (long)a.S * 2 * a.C, rows = (long)a.S * a.KLT;
+  for (long j = (long)bx * 256 + threadIdx.x; j < n3; j += (long)nbx * 256) {
+    const int s = (int)(j / (2 * a.C)), rr = (int)((j / a.C) % 2), c = (int)(j % a.C);
+    stT<T>(Text, ((long)s * a.KLT + a.KL + rr) * a.C + c, rr == 0 ? 1.f : 0.f);
+    if (c == 0) {
+      const long row = (long)s * a.KLT + a.KL + rr;
+      Tsum[row] = rr == 0 ? (float)a.C : 0.f; Tsum[rows + row] = rr == 0 ? (float)a.C : 0.f;
+    }
+  }
+}
 
-int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st) {
-  ProfScope ps_("k_prep_experts", 0.0, 0.0, st);
+template <typename T>
+__global__ void __launch_bounds__(256) kk_prep_all(PrepAllArgs a, void* WcK, void* WcT, void* WfT, float* rw, float* wbar, float* scal,
+                                                   void* Wt, float* wsum, float* dconst, void* T0T, void* Text, float* Tsum) {
+  const int b = blockIdx.x;
+  if (b < a.b_rw) prep_remap_cast<T>(a, (T*)WcK, (T*)WcT, (T*)WfT, b, a.b_rw);
+  else if (b < a.b_wbar) prep_rw<T>(a, rw, b - a.b_rw);
+  else if (b < a.b_scal) prep_wbar(a, wbar, b - a.b_wbar);
+  else if (b < a.b_exp) prep_scal(a, scal);
+  else if (b < a.b_const) prep_experts<T>(a.x, (T*)Wt, wsum, dconst, (T*)T0T, b - a.b_exp);
+  else prep_const_rows<T>(a, (T*)Text, Tsum, b - a.b_const, a.b_end - a.b_const);
+}
+
+int k_prep_all(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  ProfScope ps_("k_prep_all", 0.0, 0.0, st);
   const Dims& d = pl.d;
-  PrepExpArgs a;
+  if (!prm.conv_w || !prm.conv_b || !prm.fc_w) { set_last_error("moe: conv_adapter / fc parameters missing"); return ERR_BAD_ARG; }
+  PrepAllArgs a;
+  a.Wc = prm.conv_w; a.bc = prm.conv_b; a.Wf = prm.fc_w;
+  a.N = d.N; a.M = d.M; a.Mk = d.Mk; a.Mb = d.Mb; a.Np = d.Np; a.C = d.C; a.Cy = d.Cy; a.S = d.S; a.KL = d.KL; a.KLT = d.KLT;
   for (int e = 0; e < MAX_E; ++e) {
-    a.down.p[e] = prm.e[e].down_w; a.lnbw.p[e] = prm.e[e].lnb_w; a.lnbb.p[e] = prm.e[e].lnb_b;
-    a.tok.p[e] = prm.e[e].my_tokens; a.e_of_lat[e] = d.e_of_lat[e];
+    a.x.down.p[e] = prm.e[e].down_w; a.x.lnbw.p[e] = prm.e[e].lnb_w; a.x.lnbb.p[e] = prm.e[e].lnb_b;
+    a.x.tok.p[e] = prm.e[e].my_tokens; a.x.e_of_lat[e] = d.e_of_lat[e];
   }
   for (int e = 0; e < d.E; ++e) {
     const avmoe_expert_ptrs& x = prm.e[e];
@@ -263,11 +303,20 @@ int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipSt
     }
     if (d.lat_of_e[e] >= 0 && (!x.my_tokens || !x.gate_lat)) { set_last_error("moe: expert %d lacks my_tokens / gate_av", e); return ERR_BAD_ARG; }
   }
-  a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.Cg = d.Cg; a.C = d.C; a.K = d.K; a.Kp = d.Kp; a.KL = d.KL; a.ln_before = d.ln_before;
-  const int nblk = d.g * d.E * d.dgp + d.KL;
-  DISPATCH_T(d.bf16, kk_prep_experts, dim3(nblk), dim3(256), 0, st, a, (void*)(saved + pl.o_Wt),
-             (float*)(saved + pl.o_wsum), (float*)(saved + pl.o_dconst), (void*)(saved + pl.o_T0T));
-  AVMOE_CHECK_LAUNCH("prep_experts");
+  a.x.E = d.E; a.x.g = d.g; a.x.dg = d.dg; a.x.dgp = d.dgp; a.x.Cg = d.Cg; a.x.C = d.C; a.x.K = d.K; a.x.Kp = d.Kp; a.x.KL = d.KL;
+  a.x.ln_before = d.ln_before;
+  const long tot = (long)d.N * d.Mk + (long)(d.M + 1) * d.Np + (long)d.C * d.Cy;
+  a.b_rw = (int)grid1d(tot, 2048);
+  a.b_wbar = a.b_rw + cdiv(d.C, 4);
+  a.b_scal = a.b_wbar + cdiv(d.Mb, 16);
+  a.b_exp = a.b_scal + 1;
+  a.b_const = a.b_exp + d.g * d.E * d.dgp + d.KL;
+  a.b_end = a.b_const + (int)grid1d((long)d.S * 2 * d.C, 256);
+  DISPATCH_T(d.bf16, kk_prep_all, dim3((unsigned)a.b_end), dim3(256), 0, st, a, (void*)(saved + pl.o_WcK), (void*)(saved + pl.o_WcT),
+             (void*)(saved + pl.o_WfT), (float*)(saved + pl.o_rw), (float*)(saved + pl.o_wbar), (float*)(saved + pl.o_scal),
+             (void*)(saved + pl.o_Wt), (float*)(saved + pl.o_wsum), (float*)(saved + pl.o_dconst), (void*)(saved + pl.o_T0T),
+             (void*)(saved + pl.o_Text), (float*)(saved + pl.o_Tsum));
+  AVMOE_CHECK_LAUNCH("prep_all");
   return OK;
 }
 
@@ -403,6 +452,44 @@ __global__ void __launch_bounds__(256) kk_sum_parts(const float* __restrict__ pa
     }
   }
 }
+// The two finishing sums of the fused X statistics in ONE launch (they are independent): blocks [0, nb_sum) add the per-group row sums
+// (kk_sum_parts), the others the per-tile column sums of every frame into the router's token mean  rin[s][c] = scale * sum_tile xpart
+__global__ void __launch_bounds__(256) kk_xstats_fin(const float* __restrict__ parts, int nparts, long n, float* __restrict__ out, int nb_sum,
+                                                     const float* __restrict__ xpart, int tiles, int C, int S, float* __restrict__ rin, long rin_ld,
+                                                     float scale) {
+  if ((int)blockIdx.x < nb_sum) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)nb_sum * 1024) {
+      if (i + 3 < n) {
+        float4 a = *(const float4*)(parts + i);
+        for (int p = 1; p < nparts; ++p) { const float4 b = *(const float4*)(parts + (long)p * n + i); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        *(float4*)(out + i) = a;
+      } else {
+        for (long k = i; k < n; ++k) { float a = parts[k]; for (int p = 1; p < nparts; ++p) a += parts[(long)p * n + k]; out[k] = a; }
+      }
+    }
+    return;
+  }
+  const long total = (long)S * C;
+  for (long i = (long)(blockIdx.x - nb_sum) * 256 + threadIdx.x; i < total; i += (long)(gridDim.x - nb_sum) * 256) {
+    const int s = (int)(i / C), c = (int)(i % C);
+    const float* p = xpart + (long)s * tiles * C + c;
+    float a0 = 0.f, a1 = 0.f;
+    int tl = 0;
+    for (; tl + 1 < tiles; tl += 2) { a0 += p[(long)tl * C]; a1 += p[(long)(tl + 1) * C]; }
+    if (tl < tiles) a0 += p[(long)tl * C];
+    rin[(long)s * rin_ld + c] = (a0 + a1) * scale;
+  }
+}
+int k_xstats_fin(const float* parts, int nparts, long n, float* out, const float* xpart, int tiles, int C, int S, float* rin, long rin_ld,
+                 float scale, hipStream_t st) {
+  ProfScope ps_("k_xstats_fin", 0.0, 0.0, st);
+  if (n % 4) { set_last_error("xstats_fin: row count not a multiple of 4"); return ERR_UNSUPPORTED; }
+  const int nb_sum = (int)std::min<long>(cdiv(n, 1024), 2048), nb_col = (int)grid1d((long)S * C, 1024);
+  hipLaunchKernelGGL(kk_xstats_fin, dim3((unsigned)(nb_sum + nb_col)), dim3(256), 0, st, parts, nparts, n, out, nb_sum, xpart, tiles, C, S, rin,
+                     rin_ld, scale);
+  AVMOE_CHECK_LAUNCH("xstats_fin");
+  return OK;
+}
 int k_sum_parts(const float* parts, int nparts, long n, float* out, hipStream_t st) {
   ProfScope ps_("k_sum_parts", 0.0, 0.0, st);
   hipLaunchKernelGGL(kk_sum_parts, dim3((unsigned)std::min<long>(cdiv(n, 1024), 2048)), dim3(256), 0, st, parts, nparts, n, out);
@@ -430,65 +517,52 @@ int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out
 // ---------------------------------------------------------------------------------------------
 // hop 1 helpers
 // ---------------------------------------------------------------------------------------------
-// Rext[s][kc][M] = qr[kc], [M+1] = qb[kc], rest of the padding 0, row Kcy all 0 ; BmX[s][Kcy][:] = wbar ;
-// Text[s][KL][:] = 1 (ones row), Text[s][KL+1][:] = 0 (dm1/N row, written by the backward)
+// One launch after Q = T0 Wf:
+//   blocks [0, nb_q): qr[kc] = T0[kc] . rw ; qb[kc] = T0[kc] . bf  (one wave per latent row), written into qrqb AND into the
+//                     extension columns of every frame's Rext row:  Rext[s][kc][M] = qr[kc], [M+1] = qb[kc], rest of the padding 0
+//   the others:       Rext[s][Kcy][:] = 0 (the ybar row has no logits) ; BmX[s][Kcy][:] = wbar
 template <typename T>
-__global__ void kk_fill_ext(void* Rext_, const float* qrqb, void* BmX_, const float* wbar, void* Text_, int S, int Kcy,
-                            int Kcyb, int M, int Mk, int Mb, int KL, int KLT, int C) {
-  T* Rext = (T*)Rext_; T* BmX = (T*)BmX_; T* Text = (T*)Text_;
-  const int padw = Mk - M;
-  const long n1 = (long)S * Kcy * padw, n1b = (long)S * Mk, n2 = (long)S * Mb, n3 = (long)S * 2 * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n1b + n2 + n3; i += (long)gridDim.x * 256) {
+__global__ void __launch_bounds__(256) kk_qrqb_fill(const void* T0T_, const float* rw, const float* bf, float* qrqb, void* Rext_, void* BmX_,
+                                                    const float* wbar, int nb_q, int S, int Kcy, int Kcyb, int C, int M, int Mk, int Mb) {
+  const T* T0T = (const T*)T0T_;
+  T* Rext = (T*)Rext_; T* BmX = (T*)BmX_;
+  if ((int)blockIdx.x < nb_q) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kc = blockIdx.x * 4 + wave;
+    if (kc >= Kcy) return;
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < C; c += 64) { const float t = ldT<T>(T0T, (long)kc * C + c); a += t * rw[c]; b += t * bf[c]; }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) { qrqb[kc] = a; qrqb[Kcy + kc] = b; }
+    const int padw = Mk - M;
+    for (int i = lane; i < S * padw; i += 64) {
+      const int s = i / padw, w = i - s * padw;
+      stT<T>(Rext, ((long)s * Kcyb + kc) * Mk + M + w, w == 0 ? a : (w == 1 ? b : 0.f));
+    }
+    return;
+  }
+  const long n1 = (long)S * Mk, n2 = (long)S * Mb;
+  for (long i = (long)(blockIdx.x - nb_q) * 256 + threadIdx.x; i < n1 + n2; i += (long)(gridDim.x - nb_q) * 256) {
     if (i < n1) {
-      const int w = (int)(i % padw);
-      const long row = i / padw;                  // s * Kcy + kc
-      const int kc = (int)(row % Kcy), s = (int)(row / Kcy);
-      stT<T>(Rext, ((long)s * Kcyb + kc) * Mk + M + w, w == 0 ? qrqb[kc] : (w == 1 ? qrqb[Kcy + kc] : 0.f));
-    } else if (i < n1 + n1b) {
-      const long j = i - n1;
-      const int s = (int)(j / Mk), m = (int)(j % Mk);
+      const int s = (int)(i / Mk), m = (int)(i % Mk);
       stT<T>(Rext, ((long)s * Kcyb + Kcy) * Mk + m, 0.f);
-    } else if (i < n1 + n1b + n2) {
-      const long j = i - n1 - n1b;
+    } else {
+      const long j = i - n1;
       const int s = (int)(j / Mb), m = (int)(j % Mb);
       stT<T>(BmX, ((long)s * Kcyb + Kcy) * Mb + m, wbar[m]);
-    } else {
-      const long j = i - n1 - n1b - n2;
-      const int s = (int)(j / (2 * C)), rr = (int)((j / C) % 2), c = (int)(j % C);
-      stT<T>(Text, ((long)s * KLT + KL + rr) * C + c, rr == 0 ? 1.f : 0.f);
     }
   }
 }
-int k_fill_ext(const Plan& pl, char* saved, hipStream_t st) {
-  ProfScope ps_("k_fill_ext", 0.0, 0.0, st);
+int k_qrqb_fill(const Plan& pl, char* saved, const float* bf, hipStream_t st) {
+  ProfScope ps_("k_qrqb_fill", 0.0, 0.0, st);
   const Dims& d = pl.d;
-  const long tot = (long)d.S * d.Kcy * (d.Mk - d.M) + (long)d.S * d.Mk + (long)d.S * d.Mb + (long)d.S * 2 * d.C;
-  DISPATCH_T(d.bf16, kk_fill_ext, dim3(grid1d(tot)), dim3(256), 0, st, (void*)(saved + pl.o_Rext),
-             (const float*)(saved + pl.o_qrqb), (void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_wbar),
-             (void*)(saved + pl.o_Text), d.S, d.Kcy, d.Kcyb, d.M, d.Mk, d.Mb, d.KL, d.KLT, d.C);
-  AVMOE_CHECK_LAUNCH("fill_ext");
-  return OK;
-}
-
-// qr[kc] = T0[kc] . rw ; qb[kc] = T0[kc] . bf   (one wave per latent row)
-template <typename T>
-__global__ void __launch_bounds__(256) kk_qrqb(const void* T0T_, const float* rw, const float* bf, float* qrqb, int Kcy, int C) {
-  const T* T0T = (const T*)T0T_;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int kc = blockIdx.x * 4 + wave;
-  if (kc >= Kcy) return;
-  float a = 0.f, b = 0.f;
-  for (int c = lane; c < C; c += 64) { const float t = ldT<T>(T0T, (long)kc * C + c); a += t * rw[c]; b += t * bf[c]; }
-  a = wave_sum(a); b = wave_sum(b);
-  if (lane == 0) { qrqb[kc] = a; qrqb[Kcy + kc] = b; }
-}
-int k_qrqb(const Plan& pl, char* saved, const float* bf, hipStream_t st) {
-  ProfScope ps_("k_qrqb", 0.0, 0.0, st);
-  const Dims& d = pl.d;
-  if (d.Kcy <= 0) return OK;
-  DISPATCH_T(d.bf16, kk_qrqb, dim3(cdiv(d.Kcy, 4)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T),
-             (const float*)(saved + pl.o_rw), bf, (float*)(saved + pl.o_qrqb), d.Kcy, d.C);
-  AVMOE_CHECK_LAUNCH("qrqb");
+  const int nb_q = d.Kcy > 0 ? cdiv(d.Kcy, 4) : 0;
+  if (nb_q > 0 && !bf) { set_last_error("moe: fc.bias missing"); return ERR_BAD_ARG; }
+  const int nb_f = (int)grid1d((long)d.S * (d.Mk + d.Mb), 1024);
+  DISPATCH_T(d.bf16, kk_qrqb_fill, dim3((unsigned)(nb_q + nb_f)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T),
+             (const float*)(saved + pl.o_rw), bf, (float*)(saved + pl.o_qrqb), (void*)(saved + pl.o_Rext), (void*)(saved + pl.o_BmX),
+             (const float*)(saved + pl.o_wbar), nb_q, d.S, d.Kcy, d.Kcyb, d.C, d.M, d.Mk, d.Mb);
+  AVMOE_CHECK_LAUNCH("qrqb_fill");
   return OK;
 }
 
@@ -533,9 +607,10 @@ struct FinishTArgs {
 };
 template <typename T>
 __global__ void __launch_bounds__(256) kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, const float* rw, const float* bf,
-                                                   const float* scal, void* Text_, float* rin) {
+                                                   const float* scal, void* Text_, float* rin, float* Tsum) {
   const T* BmX = (const T*)BmX_;
   T* Text = (T*)Text_;
+  __shared__ float red[4];
   const int rows = a.src == 0 ? a.Kcyb : a.Kcx;
   const int s = blockIdx.x / rows, kr = blockIdx.x - s * rows;           // one block per (frame, latent row)
   const float* tvr = TV + (long)blockIdx.x * a.C;
@@ -544,18 +619,26 @@ __global__ void __launch_bounds__(256) kk_finish_T(FinishTArgs a, const float* T
     return;
   }
   const int slot = a.lat0 + kr / a.Kp, k = kr % a.Kp;
-  T* out = Text + ((long)s * a.KLT + (long)slot * a.Kp + k) * a.C;
+  const long trow = (long)s * a.KLT + (long)slot * a.Kp + k, trows = (long)a.S * a.KLT;
+  T* out = Text + trow * a.C;
   if (k >= a.K) {                                    // padding rows of a slot stay exactly zero
     for (int c = threadIdx.x; c < a.C; c += 256) stT<T>(out, c, 0.f);
+    if (threadIdx.x == 0) { Tsum[trow] = 0.f; Tsum[trows + trow] = 0.f; }
     return;
   }
   const float* tok = a.tok.p[a.e_of_lat[slot]] + (long)k * a.C;
   const float ab = a.src == 0 ? ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) : 0.f;
+  float sm = 0.f, ss = 0.f;                          // row sum / sum of squares of the row AS STORED (the LayerNorm folds use the same numbers)
   for (int c = threadIdx.x; c < a.C; c += 256) {
     float v = tok[c] + tvr[c];
     if (a.src == 0) v += ab * rw[c] + bf[c];
+    v = roundT<T>(v);
     stT<T>(out, c, v);
+    sm += v; ss += v * v;
   }
+  sm = block_sum256(sm, red);
+  ss = block_sum256(ss, red);
+  if (threadIdx.x == 0) { Tsum[trow] = sm; Tsum[trows + trow] = ss; }
 }
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src, hipStream_t st) {
   const Dims& d = pl.d;
@@ -569,7 +652,7 @@ int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs&
   (void)total;
   DISPATCH_T(d.bf16, kk_finish_T, dim3((unsigned)(d.S * rows)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_TV),
              (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_rw), (const float*)prm.fc_b,
-             (const float*)(saved + pl.o_scal), (void*)(saved + pl.o_Text), (float*)(saved + pl.o_rin));
+             (const float*)(saved + pl.o_scal), (void*)(saved + pl.o_Text), (float*)(saved + pl.o_rin), (float*)(saved + pl.o_Tsum));
   AVMOE_CHECK_LAUNCH("finish_T");
   return OK;
 }
@@ -581,37 +664,69 @@ struct RouterArgs {
   const float *W1, *b1, *W2, *b2, *W3, *b3, *noise;
   int C2, E, S;
 };
-__global__ void __launch_bounds__(128) kk_router_tail(RouterArgs a, float* rh1, float* rh2, float* probs, float* probs_out,
-                                                      int64_t* idx_out, float* lb_zero) {
-  __shared__ float s_h1[128], s_h2[32], s_lg[MAX_E];
-  const int s = blockIdx.x, t = threadIdx.x;
-  if (lb_zero && s == 0 && t == 0) *lb_zero = 0.f;          // (sites without the load-balancing loss report 0)
-  {   // rh1 holds rin . W1^T (engine GEMM); add bias, ReLU, keep the activation for the backward
-    const float h = fmaxf(rh1[(long)s * 128 + t] + a.b1[t], 0.f);
-    s_h1[t] = h; rh1[(long)s * 128 + t] = h;
+// The whole router for RF frames per block: layer 1 (2C -> 128) with one wave per output row -- the lanes stride over the inputs,
+// so the rows of W1 are read coalesced and ONCE per block for all its frames --, then the two small layers, the softmax and the
+// first-max argmax with one thread per output.  fp32 throughout, fixed summation order (bit-reproducible indices).
+constexpr int RF = 4;
+__global__ void __launch_bounds__(256) kk_router_fwd(RouterArgs a, const float* __restrict__ rin, float* rh1, float* rh2, float* probs,
+                                                     float* probs_out, int64_t* idx_out, float* lb_zero) {
+  extern __shared__ float s_rin[];                       // RF x C2
+  __shared__ float s_h1[RF][128], s_h2[RF][32], s_lg[RF][MAX_E];
+  const int s0 = blockIdx.x * RF, nf = min(RF, a.S - s0), t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63;
+  if (lb_zero && blockIdx.x == 0 && t == 0) *lb_zero = 0.f;          // (sites without the load-balancing loss report 0)
+  for (int i = t; i < RF * a.C2; i += 256) { const int f = i / a.C2; s_rin[i] = f < nf ? rin[(long)s0 * a.C2 + i] : 0.f; }
+  __syncthreads();
+  for (int j = wave; j < 128; j += 4) {
+    const float* w = a.W1 + (long)j * a.C2;
+    float acc[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) acc[f] = 0.f;
+    for (int i = lane; i < a.C2; i += 64) {
+      const float wv = w[i];
+#pragma unroll
+      for (int f = 0; f < RF; ++f) acc[f] += wv * s_rin[f * a.C2 + i];
+    }
+#pragma unroll
+    for (int f = 0; f < RF; ++f) acc[f] = wave_sum(acc[f]);
+    if (lane == 0) {
+      const float b = a.b1[j];
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        const float h = fmaxf(acc[f] + b, 0.f);
+        s_h1[f][j] = h;
+        if (f < nf) rh1[(long)(s0 + f) * 128 + j] = h;      // kept for the backward
+      }
+    }
   }
   __syncthreads();
-  if (t < 32) {
+  if (t < RF * 32) {
+    const int f = t >> 5, o = t & 31;
     float acc = 0.f;
-    for (int i = 0; i < 128; ++i) acc += a.W2[t * 128 + i] * s_h1[i];
-    const float h = fmaxf(acc + a.b2[t], 0.f);
-    s_h2[t] = h; rh2[(long)s * 32 + t] = h;
+    for (int i = 0; i < 128; ++i) acc += a.W2[o * 128 + i] * s_h1[f][i];
+    const float h = fmaxf(acc + a.b2[o], 0.f);
+    s_h2[f][o] = h;
+    if (f < nf) rh2[(long)(s0 + f) * 32 + o] = h;
   }
   __syncthreads();
-  if (t < a.E) {
-    float acc = 0.f;
-    for (int i = 0; i < 32; ++i) acc += a.W3[t * 32 + i] * s_h2[i];
-    s_lg[t] = acc + a.b3[t] + (a.noise ? a.noise[(long)s * a.E + t] : 0.f);
+  if (t < RF * MAX_E) {
+    const int f = t / MAX_E, e = t % MAX_E;
+    if (e < a.E && f < nf) {
+      float acc = 0.f;
+      for (int i = 0; i < 32; ++i) acc += a.W3[e * 32 + i] * s_h2[f][i];
+      s_lg[f][e] = acc + a.b3[e] + (a.noise ? a.noise[(long)(s0 + f) * a.E + e] : 0.f);
+    }
   }
   __syncthreads();
-  if (t == 0) {
-    float mx = s_lg[0];
-    for (int e = 1; e < a.E; ++e) mx = fmaxf(mx, s_lg[e]);
+  if (t < nf) {
+    const int s = s0 + t;
+    float mx = s_lg[t][0];
+    for (int e = 1; e < a.E; ++e) mx = fmaxf(mx, s_lg[t][e]);
     float sum = 0.f;
-    for (int e = 0; e < a.E; ++e) sum += expf(s_lg[e] - mx);
+    for (int e = 0; e < a.E; ++e) sum += expf(s_lg[t][e] - mx);
     int best = 0; float bp = -1.f;
     for (int e = 0; e < a.E; ++e) {
-      const float p = expf(s_lg[e] - mx) / sum;
+      const float p = expf(s_lg[t][e] - mx) / sum;
       probs[(long)s * a.E + e] = p;
       if (probs_out) probs_out[(long)s * a.E + e] = p;
       if (p > bp) { bp = p; best = e; }            // strict '>' : first maximum wins (torch.argmax)
@@ -639,16 +754,13 @@ int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& p
     set_last_error("moe: router parameters missing"); return ERR_BAD_ARG;
   }
   RouterArgs a{prm.r0_w, prm.r0_b, prm.r2_w, prm.r2_b, prm.r4_w, prm.r4_b, noise, 2 * d.C, d.E, d.S};
-  {   // layer 1 on the matrix pipe in exact fp32 whatever the activation dtype (bit-stable argmax): rh1 = rin W1^T
-    GemmArgs g;
-    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
-    g.A = saved + pl.o_rin; g.B = prm.r0_w; g.C = saved + pl.o_rh1;
-    g.M = d.S; g.N = 128; g.K = 2 * d.C; g.lda = 2L * d.C; g.ldb = 2L * d.C; g.sCi = 128;
-    g.tile = 64; g.slabs = (float*)(scratch + pl.o_slabs); g.ksplit = choose_ksplit(g, slab_floats(d));   // few tiles, long K
-    AVMOE_TRY(launch_gemm(g, st));
+  const size_t sh = (size_t)RF * 2 * d.C * sizeof(float);
+  if (sh > 160 * 1024) { set_last_error("router: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
+  if (sh > 48 * 1024 && hipFuncSetAttribute((const void*)kk_router_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_last_error("router: LDS attribute"); return ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(kk_router_tail, dim3(d.S), dim3(128), 0, st, a, (float*)(saved + pl.o_rh1), (float*)(saved + pl.o_rh2),
-                     (float*)(saved + pl.o_probs), probs_out, idx_out, (lb_out && !d.lb_loss) ? lb_out : nullptr);
+  hipLaunchKernelGGL(kk_router_fwd, dim3(cdiv(d.S, RF)), dim3(256), sh, st, a, (const float*)(saved + pl.o_rin), (float*)(saved + pl.o_rh1),
+                     (float*)(saved + pl.o_rh2), (float*)(saved + pl.o_probs), probs_out, idx_out, (lb_out && !d.lb_loss) ? lb_out : nullptr);
   AVMOE_CHECK_LAUNCH("router");
   if (lb_out && d.lb_loss) {
     hipLaunchKernelGGL(kk_lb_loss, dim3(1), dim3(256), 0, st, (const float*)(saved + pl.o_probs), d.S, d.E, lb_out);
@@ -665,7 +777,7 @@ int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& p
 // net_trans_v3.py:397-398 ; torch BatchNorm2d semantics.
 // ---------------------------------------------------------------------------------------------
 struct Bn1Args {
-  P16 w, b; W16 rm, rv;
+  P16 w, b; W16 rm, rv; N16 nbt;
   int E, g, dg, dgp, DZ, nblk, NT, use_bn, training;
   float eps, momentum;
 };
@@ -686,6 +798,7 @@ __device__ __forceinline__ void bn1_finalize_col(const Bn1Args& a, int col, floa
         const double unb = a.NT > 1 ? v * ((double)a.NT / (a.NT - 1)) : v;
         a.rm.p[e][j] = (1.f - a.momentum) * a.rm.p[e][j] + a.momentum * mean;
         a.rv.p[e][j] = (1.f - a.momentum) * a.rv.p[e][j] + a.momentum * (float)unb;
+        if (j == 0 && a.nbt.p[e]) a.nbt.p[e][0] += 1;          // bn1.num_batches_tracked (one column per expert gets here)
       } else { mean = a.rm.p[e][j]; var = a.rv.p[e][j]; }
       rstd = rsqrtf(var + a.eps);
       sc = a.w.p[e][j] * rstd;
@@ -699,7 +812,7 @@ __global__ void kk_bn1_finalize(Bn1Args a, const float* colpart, float* bn1) {  
   if (col >= a.DZ) return;
   bn1_finalize_col(a, col, 0.f, 0.f, bn1);
 }
-struct Bn1Fin {
+struct Bn1Fin : NoExtra {
   Bn1Args a; float* bn1;
   __device__ void operator()(int col, float s0, float s1) const { bn1_finalize_col(a, col, s0, s1, bn1); }
 };
@@ -707,11 +820,13 @@ int k_bn1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_p
   ProfScope ps_("k_bn1_finalize", 0.0, 0.0, st);
   const Dims& d = pl.d;
   Bn1Args a;
-  for (int e = 0; e < MAX_E; ++e) { a.w.p[e] = prm.e[e].bn1_w; a.b.p[e] = prm.e[e].bn1_b; a.rm.p[e] = prm.e[e].bn1_rm; a.rv.p[e] = prm.e[e].bn1_rv; }
+  for (int e = 0; e < MAX_E; ++e) {
+    a.w.p[e] = prm.e[e].bn1_w; a.b.p[e] = prm.e[e].bn1_b; a.rm.p[e] = prm.e[e].bn1_rm; a.rv.p[e] = prm.e[e].bn1_rv; a.nbt.p[e] = prm.e[e].bn1_nbt;
+  }
   a.E = d.E; a.g = d.g; a.dg = d.dg; a.dgp = d.dgp; a.DZ = d.DZ; a.nblk = d.nblk_tok; a.NT = d.NT; a.use_bn = d.use_bn;
   a.training = d.training; a.eps = d.bn_eps; a.momentum = d.bn_momentum;
   if (d.use_bn && d.training)      // the column sums over the blocks and the per-column finalize in one launch
-    return launch_colsum_fin((const float*)(scratch + pl.o_colpart), d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ, Bn1Fin{a, (float*)(saved + pl.o_bn1)}, st);
+    return launch_colsum_fin((const float*)(scratch + pl.o_colpart), d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ, Bn1Fin{{}, a, (float*)(saved + pl.o_bn1)}, st);
   hipLaunchKernelGGL(kk_bn1_finalize, dim3(cdiv(d.DZ, 256)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_colsum),
                      (float*)(saved + pl.o_bn1));
   AVMOE_CHECK_LAUNCH("bn1_finalize");

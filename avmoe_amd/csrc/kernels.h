@@ -8,11 +8,12 @@ namespace avmoe {
 
 struct P16 { const float* p[MAX_E]; };
 struct W16 { float* p[MAX_E]; };
+struct N16 { int64_t* p[MAX_E]; };       // num_batches_tracked counters (avmoe_expert_ptrs::bn1_nbt / bn2_nbt), NULL = none
 
 // All wrappers return 0 or a negative status; `bf16` selects the operand type T.
 // ---- forward: weight preparation -------------------------------------------------------------
-int k_prep_remap(const Plan& pl, char* saved, const float* Wc, const float* bc, const float* Wf, hipStream_t st);
-int k_prep_experts(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st);
+// remap operands, folded expert weights, stacked latent tokens, the constant rows of Text: one launch
+int k_prep_all(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st);
 // merged groups (Dims::mg): block-diagonal dense copies of the grouped down_sampler / up_sampler weights, and the way back for
 // their gradients (only the diagonal blocks are parameters)
 int k_merge_expand(const Plan& pl, char* saved, const avmoe_moe_ptrs& prm, hipStream_t st);
@@ -23,10 +24,13 @@ avmoe_moe_ptrs merged_grads(const Plan& pl, const avmoe_moe_ptrs& grads, char* s
 int k_rowstats(int bf16, const void* X, long rows, int C, float* out_sum_sq /* [2][rows] */, hipStream_t st);
 int k_xstats(const Plan& pl, const void* X, char* saved, char* scratch, hipStream_t st);   // row sums + column means of X
 int k_sum_parts(const float* parts, int nparts, long n, float* out, hipStream_t st);       // out[i] = sum_p parts[p * n + i]
+// ... and, in the same launch, rin[s][c] = scale * sum over the `tiles` column partials xpart[s][tile][c] (fused X statistics)
+int k_xstats_fin(const float* parts, int nparts, long n, float* out, const float* xpart, int tiles, int C, int S, float* rin, long rin_ld,
+                 float scale, hipStream_t st);
 int k_colmean(int bf16, const void* X, int S, int N, int C, float* out, long out_ld, hipStream_t st);
 // ---- forward: hop 1 ---------------------------------------------------------------------------
-int k_fill_ext(const Plan& pl, char* saved, hipStream_t st);
-int k_qrqb(const Plan& pl, char* saved, const float* fc_b, hipStream_t st);
+// qr / qb (after Q = T0 Wf) into qrqb and the extension columns of Rext ; the ybar rows of Rext / BmX
+int k_qrqb_fill(const Plan& pl, char* saved, const float* fc_b, hipStream_t st);
 int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, int grp, int valid,
                    int slot, int kvalid, hipStream_t st);
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src /*0 y, 1 x*/,

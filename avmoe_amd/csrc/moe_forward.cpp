@@ -33,7 +33,6 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
                 float* probs_out, int64_t* idx_out, float* lb_out, char* sv, char* sc, hipStream_t st) {
   const Dims& d = pl.d;
   avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
-  if (d.mha) AVMOE_TRY(k_fill_f32((float*)(sv + pl.o_scal) + 1, 1, 1.f, st));
   if (d.mg) {                                              // merged groups: run on block-diagonal dense copies of the grouped weights
     AVMOE_TRY(k_merge_expand(pl, sv, prm_in, st));
     prm = merged_params(pl, prm, sv);
@@ -44,8 +43,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
 
   // ---- weights-derived operands --------------------------------------------------------------
-  AVMOE_TRY(k_prep_remap(pl, sv, prm.conv_w, prm.conv_b, prm.fc_w, st));
-  AVMOE_TRY(k_prep_experts(pl, sv, prm, st));
+  AVMOE_TRY(k_prep_all(pl, sv, prm, st));                  // (also scal[1] = 1: the unit gate of with_unit_gates)
   // ---- token statistics of X: row sums (LayerNorm), column means (router) ---------------------
   if (!d.fuse_xs) AVMOE_TRY(k_xstats(pl, X, sv, sc, st));          // (fused: they come out of the down projection below)
   // Zx = X Wt^T per frame, with the row sums / column sums of X as side products (fused statistics).  It depends on X and the
@@ -62,6 +60,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       if (rc == 1) set_last_error("moe_forward: the streaming down projection with statistics does not serve this shape (plan / kernel mismatch)");
       return rc == 1 ? ERR_UNSUPPORTED : rc;
     }
+    if ((2L * d.NT) % 4 == 0)      // the two finishing sums (row sums over the groups, column means over the tiles) in one launch
+      return k_xstats_fin((const float*)(sc + pl.o_sxp), d.g, 2L * d.NT, (float*)(sv + pl.o_sx), (const float*)(sc + pl.o_xpart), tiles, d.C, d.S,
+                          (float*)(sv + pl.o_rin), 2L * d.C, 1.f / (float)d.N, xs);
     AVMOE_TRY(k_sum_parts((const float*)(sc + pl.o_sxp), d.g, 2L * d.NT, (float*)(sv + pl.o_sx), xs));
     return k_colsum_f32((const float*)(sc + pl.o_xpart), tiles, d.C, d.C, d.S, (long)tiles * d.C, (float*)(sv + pl.o_rin), 2L * d.C,
                         1.f / (float)d.N, xs);
@@ -80,9 +81,8 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     g.M = d.Kcy; g.N = d.Cy; g.K = d.C; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.Cy;
     g.sCi = d.Cy; g.out_dtype = dt;
     AVMOE_TRY(launch_gemm(g, st));
-    AVMOE_TRY(k_qrqb(pl, sv, prm.fc_b, st));
   }
-  AVMOE_TRY(k_fill_ext(pl, sv, st));
+  AVMOE_TRY(k_qrqb_fill(pl, sv, prm.fc_b, st));
   if (d.Kcy > 0) {
     {                                                      // R[s] = Q Y[s]^T
       GemmArgs g = base();
@@ -146,7 +146,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   }
 
   // ---- per-sample K-space matrices of the latent tokens ------------------------------------------
-  AVMOE_TRY(k_rowstats(d.bf16, sv + pl.o_Text, (long)d.S * d.KLT, d.C, (float*)(sv + pl.o_Tsum), st));
+  // (row sums of Text: k_finish_T writes them with the rows, k_prep_all those of the constant rows)
   if (d.El > 0) {                                          // TT[s][l] = T T^T
     GemmArgs g = base();
     g.A = sv + pl.o_Text; g.B = sv + pl.o_Text; g.C = sv + pl.o_TT;

@@ -170,7 +170,6 @@ struct Dims {
   X(dmodv, 1, 4, (size_t)2 * d.E * d.C)             /* dmo, dv2 per (e, c)            */       \
   X(dp, 1, 4, (size_t)d.S * d.E)                                                                \
   X(rbw, 1, 4, (size_t)d.S * (d.E + 32 + 128 + 2 * d.C))   /* dlog, dh2r, dh1, drin   */       \
-  X(drinT, 1, d.esz, (size_t)d.S * 2 * d.C)                                                     \
   X(dsxs, 1, 4, (size_t)2 * d.NT)                                                               \
   X(rs2x, 1, 4, (size_t)d.NT)                       /* 2 * sum_e dSxx                 */       \
   X(dL2x, 1, d.esz, (size_t)d.NT * d.KLp)           /* [dL2 | dsx | 1]                */       \

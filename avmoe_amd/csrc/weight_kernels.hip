@@ -22,7 +22,7 @@ static inline unsigned grid1dw(long n, int cap = 4096) { return (unsigned)std::m
 constexpr int GCS = 8;       // channel chunks of the Gram kernels
 
 struct WArgs {
-  P16 up, w2, b2, lpw, lpb; W16 rm, rv, gup, gw2, gb2, glpw, glpb;
+  P16 up, w2, b2, lpw, lpb; W16 rm, rv, gup, gw2, gb2, glpw, glpb; N16 nbt2;
   int E, g, dg, dgp, Cg, C, KPp, NT, DZ, use_bn, training, ln_post;
   float eps, momentum;
 };
@@ -30,6 +30,7 @@ static void fill_w(const Dims& d, const avmoe_moe_ptrs& prm, const avmoe_moe_ptr
   for (int e = 0; e < MAX_E; ++e) {
     a->up.p[e] = prm.e[e].up_w; a->w2.p[e] = prm.e[e].bn2_w; a->b2.p[e] = prm.e[e].bn2_b;
     a->lpw.p[e] = prm.e[e].lnp_w; a->lpb.p[e] = prm.e[e].lnp_b; a->rm.p[e] = prm.e[e].bn2_rm; a->rv.p[e] = prm.e[e].bn2_rv;
+    a->nbt2.p[e] = prm.e[e].bn2_nbt;
     a->gup.p[e] = grads ? grads->e[e].up_w : nullptr; a->gw2.p[e] = grads ? grads->e[e].bn2_w : nullptr;
     a->gb2.p[e] = grads ? grads->e[e].bn2_b : nullptr; a->glpw.p[e] = grads ? grads->e[e].lnp_w : nullptr;
     a->glpb.p[e] = grads ? grads->e[e].lnp_b : nullptr;
@@ -56,6 +57,7 @@ __global__ void __launch_bounds__(256) kw_bn2_stats(WArgs a, const float* mz, co
   const bool on = cl < a.Cg;
   const int c = i * a.Cg + (on ? cl : 0);
   const bool stats = a.use_bn && a.training;
+  if (stats && i == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.nbt2.p[e]) a.nbt2.p[e][0] += 1;      // bn2.num_batches_tracked
   if (stats) {
     for (int k = threadIdx.x; k < dgp * dgp; k += 256) { const int r = k / dgp; s_S[r * ldm + (k - r * dgp)] = Szz[(long)cb * dgp * dgp + k]; }
     for (int k = threadIdx.x; k < dgp; k += 256) s_m[k] = mz[(long)cb * dgp + k];
@@ -97,11 +99,11 @@ __global__ void __launch_bounds__(256) kw_bn2_stats(WArgs a, const float* mz, co
 
 // thread per (c, k'): Bpost[c][k']
 template <typename T>
-__global__ void kw_build_bpost(WArgs a, const float* bn2, void* Bpost_) {
+__device__ __forceinline__ void build_bpost_body(const WArgs& a, const float* bn2, void* Bpost_, int bx, int nbx) {
   T* Bpost = (T*)Bpost_;
   const long total = (long)a.C * a.KPp;
   const long EC = (long)a.E * a.C;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)nbx * 256) {
     const int c = (int)(idx / a.KPp), kp = (int)(idx % a.KPp);
     float v = 0.f;
     if (kp < a.E * a.dgp) {
@@ -128,12 +130,12 @@ __global__ void kw_build_bpost(WArgs a, const float* bn2, void* Bpost_) {
 //   mode 1 (backward): U = Wu, w = dv2, v1 = dmz (x1 = dmo, U1 = Wu)
 // partial layout per (chunk, cb): [dgp*dgp | dgp | dgp | 2]
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kw_gram(WArgs a, int mode, const float* bn2, const float* dmodv, float* gpart) {
+__device__ __forceinline__ void gram_body(const WArgs& a, int mode, const float* bn2, const float* dmodv, float* gpart, int cb, int chunk, int ncb) {
   extern __shared__ float sm[];
   const int dg = a.dg, dgp = a.dgp;
-  const int cb = blockIdx.x, i = cb / a.E, e = cb % a.E;
+  const int i = cb / a.E, e = cb % a.E;
   const int cc = (a.Cg + GCS - 1) / GCS;
-  const int c0 = blockIdx.y * cc, c1 = min(a.Cg, c0 + cc), nc = max(0, c1 - c0);
+  const int c0 = chunk * cc, c1 = min(a.Cg, c0 + cc), nc = max(0, c1 - c0);
   float* s_U = sm;                     // cc x dgp
   float* s_w = s_U + cc * dgp;         // cc : Gram weight
   float* s_x1 = s_w + cc;              // cc
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) kw_gram(WArgs a, int mode, const float* b
   }
   __syncthreads();
   const int stride = dgp * dgp + 2 * dgp + 2;
-  float* out = gpart + ((long)blockIdx.y * gridDim.x + cb) * stride;
+  float* out = gpart + ((long)chunk * ncb + cb) * stride;
   for (int pr = threadIdx.x; pr < dgp * dgp; pr += 256) {
     const int j = pr / dgp, l = pr % dgp;
     float acc = 0.f;
@@ -172,6 +174,16 @@ __global__ void __launch_bounds__(256) kw_gram(WArgs a, int mode, const float* b
     for (int c = 0; c < nc; ++c) { s1 += s_x2[c]; s2 += s_x2[c] * s_x2[c]; }
     out[dgp * dgp + 2 * dgp] = s1; out[dgp * dgp + 2 * dgp + 1] = s2;
   }
+}
+__global__ void __launch_bounds__(256) kw_gram(WArgs a, int mode, const float* bn2, const float* dmodv, float* gpart) {
+  gram_body(a, mode, bn2, dmodv, gpart, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// forward: the Gram partials (mode 0) and the folded output weights Bpost -- both hang on bn2 only -- in ONE launch
+template <typename T>
+__global__ void __launch_bounds__(256) kw_gram_bpost(WArgs a, const float* bn2, float* gpart, void* Bpost, int ncb) {
+  const int ngram = ncb * GCS;
+  if ((int)blockIdx.x < ngram) gram_body(a, 0, bn2, nullptr, gpart, blockIdx.x % ncb, blockIdx.x / ncb, ncb);
+  else build_bpost_body<T>(a, bn2, Bpost, (int)blockIdx.x - ngram, (int)gridDim.x - ngram);
 }
 // sum the GCS partials and scatter into the consumers' layouts
 //   mode 0: Gq[cb][dgp*dgp], uvh = [usum (DZ) | vh (DZ) | H1[g*E] | H2[g*E]]
@@ -220,11 +232,18 @@ int k_post_prep(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs
   }
   hipLaunchKernelGGL(kw_bn2_stats, dim3(d.g * d.E, cdiv(d.Cg, BS_CH)), dim3(256), sh, st, a, (const float*)(saved + pl.o_mz),
                      (const float*)(saved + pl.o_Szz), (float*)(saved + pl.o_bn2));
-  DISPATCH_T(d.bf16, kw_build_bpost, dim3(grid1dw((long)d.C * d.KPp)), dim3(256), 0, st, a, (const float*)(saved + pl.o_bn2),
-             (void*)(saved + pl.o_Bpost));
+  {
+    const int ncb = d.g * d.E, cc = cdiv(d.Cg, GCS);
+    const size_t shg = (size_t)(cc * d.dgp + 3 * cc) * sizeof(float);
+    const int nb_bp = (int)grid1dw((long)d.C * d.KPp, 1024);
+    DISPATCH_T(d.bf16, kw_gram_bpost, dim3((unsigned)(ncb * GCS + nb_bp)), dim3(256), shg, st, a, (const float*)(saved + pl.o_bn2),
+               (float*)(scratch + pl.o_gpart), (void*)(saved + pl.o_Bpost), ncb);
+    const long total = (long)ncb * (d.dgp * d.dgp + 2 * d.dgp + 2);
+    hipLaunchKernelGGL(kw_gram_finish, dim3(grid1dw(total)), dim3(256), 0, st, a, 0, (const float*)(scratch + pl.o_gpart), (float*)(saved + pl.o_Gq),
+                       (float*)(saved + pl.o_uvh));
+  }
   AVMOE_CHECK_LAUNCH("post_prep");
-  return run_gram(pl, a, 0, (const float*)(saved + pl.o_bn2), nullptr, (float*)(scratch + pl.o_gpart), (float*)(saved + pl.o_Gq),
-                  (float*)(saved + pl.o_uvh), st);
+  return OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 5
+#define AVMOE_ABI_VERSION 6
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -96,6 +96,9 @@ typedef struct avmoe_expert_ptrs {        /* <list>.{j}.*  ; unused entries NULL
    * only, sa_keep: the dropout multiplier of the attention weights, (N * 4, S, S) f32 holding 0 or 1 / (1 - p), or NULL for
    * no dropout (eval).  The caller draws it (the reference uses the global RNG) and keeps it alive until the backward.  */
   float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b, *sa_keep;
+  /* ABI 6 -- bn1.num_batches_tracked / bn2.num_batches_tracked (one int64 each), or NULL: a training-mode forward with BatchNorm
+   * adds 1 to each inside its own kernels (torch.nn.BatchNorm2d semantics), so the caller needs no extra launch for the counters. */
+  int64_t *bn1_nbt, *bn2_nbt;
 } avmoe_expert_ptrs;
 
 typedef struct avmoe_moe_ptrs {

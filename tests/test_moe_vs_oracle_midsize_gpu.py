@@ -193,9 +193,19 @@ def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
     assert run.table["att"][2] < whole.table["att"][2]                  # the (frames, N, N) workspace shrank
     g1 = run.backward(G, lb_weight=lbw)
     monkeypatch.delenv("AVMOE_NXN_CHUNK")
-    assert torch.equal(run.out, whole.out) and torch.equal(run.idx, whole.idx)
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
+    assert torch.equal(run.idx, whole.idx)
+    if name.endswith("_full"):
+        # at the real token counts the skinny products of a chunk (att^T X: few frames x few column tiles) are split over the token
+        # contraction to fill the chip, and the split factor depends on the frames per chunk: same numbers in another summation order
+        tol = 2e-2 if bf16 else 2e-5
+        assert float((run.out.float() - whole.out.float()).abs().max()) <= tol * float(whole.out.float().abs().max())
+        gmax0 = max(float(v.abs().max()) for v in g0.values())
+        for k in g0:
+            assert float((g0[k] - g1[k]).abs().max()) <= tol * max(float(g0[k].abs().max()), 1e-3 * gmax0), k
+    else:
+        assert torch.equal(run.out, whole.out)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
     if not bf16:
         fwd, grads = O.moe_forward_backward(P, B, X, Y, cfg, G, training=True, lb_weight=lbw)
         gmax = max(float(v.abs().max()) for v in grads.values())

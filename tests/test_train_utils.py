@@ -68,7 +68,10 @@ def test_plain_bucket_offsets_are_aligned_and_flat_adam_ranges_cover_the_bucket(
     GEMM engine needs 16-byte aligned operands); FlatAdam's per-learning-rate ranges tile the whole bucket in order."""
     from avmoe_amd.dp import _Bucket
     ps = [nn.Parameter(torch.zeros(n)) for n in (1, 2, 130, 64, 7)]
-    b = _Bucket(ps, torch.device("cpu"), torch.float32)
+    b = _Bucket()
+    for p in ps:
+        b.add_param(p)
+    b.materialize(torch.device("cpu"))
     assert b.offsets == [0, 64, 128, 320, 384] and b.flat.numel() == 448
     for p, o in zip(ps, b.offsets):
         assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * o and p.grad.data_ptr() % 16 == 0
