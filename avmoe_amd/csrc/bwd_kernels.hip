@@ -147,149 +147,144 @@ int k_pre_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const a
 // rbw layout: dlog [S][E] | dh2r [S][32] | dh1 [S][128] | drin [S][2C]
 // ---------------------------------------------------------------------------------------------
 struct RouterBwdArgs { const float *W1, *W2, *W3; int C2, E, S, lb_loss; const float* lb_grad; };
-// Launch 1 of 2, RBF frames per block: dlog / dh2 / dh1 of every frame (softmax, LB loss, the two small layers), then the input
-// gradient drin = dh1 W1 -- thread per input column, the rows of W1 read coalesced and once per block for all its frames --,
-// kept in fp32 (dm2 is consumed by k_finish_dT) with dm1 / N written into the extra row of Text[s] (operand of the dX GEMM).
-constexpr int RBF = 4;
-__global__ void __launch_bounds__(256) kk_router_bwd_in(RouterBwdArgs a, const float* probs, const float* dp, const float* rh1,
-                                                        const float* rh2, float* rbw, int bf16, void* Text_, int KLT, int KL, int C, int N) {
-  __shared__ float s_dl[RBF][MAX_E], s_d2[RBF][32], s_d1[RBF][128], s_pm[MAX_E];
-  const int s0 = blockIdx.x * RBF, nf = min(RBF, a.S - s0), t = threadIdx.x;
-  float* dh1_g = rbw;
-  float* drin_g = rbw + (long)a.S * 128;
-  float* dh2_g = rbw + (long)a.S * (128 + a.C2);
-  float* dlog_g = rbw + (long)a.S * (128 + a.C2 + 32);
+// Launch 1: per frame dlog / dh2 / dh1 (softmax, LB loss, the two small layers), one block per frame
+__global__ void __launch_bounds__(256) kk_router_bwd_a(RouterBwdArgs a, const float* probs, const float* dp, const float* rh1,
+                                                       const float* rh2, float* rbw) {
+  __shared__ float s_dl[MAX_E], s_d2[32], s_pm[MAX_E];
+  const int s = blockIdx.x;
+  float* dh1 = rbw + (long)s * 128;
+  float* dh2 = rbw + (long)a.S * (128 + a.C2) + (long)s * 32;
+  float* dlog = rbw + (long)a.S * (128 + a.C2 + 32) + (long)s * a.E;
   if (a.lb_loss && a.lb_grad) {                  // column means of p for the LB loss: 256 / 16 frame streams per expert
     __shared__ float s_part[16][MAX_E];
-    const int e = t % MAX_E, u = t / MAX_E;
+    const int e = threadIdx.x % MAX_E, u = threadIdx.x / MAX_E;
     float acc = 0.f;
     if (e < a.E) for (int ss = u; ss < a.S; ss += 16) acc += probs[(long)ss * a.E + e];
     s_part[u][e] = acc;
     __syncthreads();
-    if (t < a.E) {
-      float tt = 0.f;
-      for (int k = 0; k < 16; ++k) tt += s_part[k][t];
-      s_pm[t] = tt / (float)a.S;
+    if (threadIdx.x < a.E) {
+      float t = 0.f;
+      for (int k = 0; k < 16; ++k) t += s_part[k][threadIdx.x];
+      s_pm[threadIdx.x] = t / (float)a.S;
     }
   }
   __syncthreads();
-  if (t < nf) {
-    const int s = s0 + t;
+  if (threadIdx.x == 0) {
     float dot = 0.f, dpv[MAX_E];
     for (int e = 0; e < a.E; ++e) {
       dpv[e] = dp[(long)s * a.E + e];
       if (a.lb_loss && a.lb_grad) dpv[e] += a.lb_grad[0] * (-1.f / ((float)a.S * s_pm[e]));
       dot += probs[(long)s * a.E + e] * dpv[e];
     }
-    for (int e = 0; e < a.E; ++e) { const float v = probs[(long)s * a.E + e] * (dpv[e] - dot); s_dl[t][e] = v; dlog_g[(long)s * a.E + e] = v; }
+    for (int e = 0; e < a.E; ++e) { const float v = probs[(long)s * a.E + e] * (dpv[e] - dot); s_dl[e] = v; dlog[e] = v; }
   }
   __syncthreads();
-  if (t < RBF * 32) {
-    const int f = t >> 5, o = t & 31;
-    float v = 0.f;
-    if (f < nf) {
-      float acc = 0.f;
-      for (int e = 0; e < a.E; ++e) acc += s_dl[f][e] * a.W3[e * 32 + o];
-      v = rh2[(long)(s0 + f) * 32 + o] > 0.f ? acc : 0.f;
-      dh2_g[(long)(s0 + f) * 32 + o] = v;
-    }
-    s_d2[f][o] = v;
+  if (threadIdx.x < 32) {
+    float acc = 0.f;
+    for (int e = 0; e < a.E; ++e) acc += s_dl[e] * a.W3[e * 32 + threadIdx.x];
+    const float v = rh2[(long)s * 32 + threadIdx.x] > 0.f ? acc : 0.f;
+    s_d2[threadIdx.x] = v; dh2[threadIdx.x] = v;
   }
   __syncthreads();
-  for (int i = t; i < RBF * 128; i += 256) {
-    const int f = i >> 7, o = i & 127;
-    float v = 0.f;
-    if (f < nf) {
-      float acc = 0.f;
-      for (int j = 0; j < 32; ++j) acc += s_d2[f][j] * a.W2[j * 128 + o];
-      v = rh1[(long)(s0 + f) * 128 + o] > 0.f ? acc : 0.f;
-      dh1_g[(long)(s0 + f) * 128 + o] = v;
-    }
-    s_d1[f][o] = v;
-  }
-  __syncthreads();
-  const float invN = 1.f / (float)N;
-  for (int i = t; i < a.C2; i += 256) {
-    float acc[RBF];
-#pragma unroll
-    for (int f = 0; f < RBF; ++f) acc[f] = 0.f;
-    for (int j = 0; j < 128; ++j) {
-      const float w = a.W1[(long)j * a.C2 + i];
-#pragma unroll
-      for (int f = 0; f < RBF; ++f) acc[f] += s_d1[f][j] * w;
-    }
-#pragma unroll
-    for (int f = 0; f < RBF; ++f) {
-      if (f < nf) {
-        const int s = s0 + f;
-        drin_g[(long)s * a.C2 + i] = acc[f];
-        if (i < C) {
-          const long o = ((long)s * KLT + KL + 1) * C + i;
-          const float v = acc[f] * invN;
-          if (bf16) ((unsigned short*)Text_)[o] = f2bf(v); else ((float*)Text_)[o] = v;
-        }
-      }
-    }
+  if (threadIdx.x < 128) {
+    float acc = 0.f;
+    for (int j = 0; j < 32; ++j) acc += s_d2[j] * a.W2[j * 128 + threadIdx.x];
+    dh1[threadIdx.x] = rh1[(long)s * 128 + threadIdx.x] > 0.f ? acc : 0.f;
   }
 }
-// Launch 2 of 2, the router's weight gradients: blocks [0, nb_w1) own 64 columns x 4 rows of dW1 = dh1^T rin (sum over the frames,
-// in frame order: one thread per element), the others the two small layers and the biases (one output per lane, 4 frame streams per
-// output, combined through LDS in a fixed order)
-__global__ void __launch_bounds__(256) kk_router_bwd_w(int S, int E, int C2, int nb_w1, const float* rbw, const float* rin, const float* rh1,
-                                                       const float* rh2, float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3) {
-  __shared__ float red[4][64];
+// Last launch, three independent jobs picked by the block index:
+//   [0, nb_small)  the weight gradients of the two small layers and all biases: one output per lane, 4 frame streams per output,
+//                  combined through LDS in a fixed order
+//   then nb_c      dm1 / N (from drin, the engine GEMM before) into the extra row of Text[s] -- operand of the dX GEMM
+//   then the rest  dW1 = sum over the split-K slabs of dh1^T rin, in slab order (the engine GEMM kept its slabs: no reduce launch)
+__global__ void __launch_bounds__(256) kk_router_bwd_fin(int S, int E, int C2, int nb_small, int nb_c, const float* rbw, const float* rh1,
+                                                         const float* rh2, float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3,
+                                                         const float* slabs, int ks, int bf16, void* Text_, int KLT, int KL, int C, int N) {
   const float* dh1 = rbw;
+  const float* drin = rbw + (long)S * 128;
   const float* dh2 = rbw + (long)S * (128 + C2);
   const float* dlog = rbw + (long)S * (128 + C2 + 32);
-  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
-  if ((int)blockIdx.x < nb_w1) {
-    if (!gW1) return;
-    const int cblocks = (C2 + 63) / 64;
-    const int cb = blockIdx.x % cblocks, jb = blockIdx.x / cblocks;
-    const int i = cb * 64 + l, j = jb * 4 + u;
-    if (i >= C2) return;
-    float a0 = 0.f, a1 = 0.f;
-    int s = 0;
-    for (; s + 1 < S; s += 2) { a0 += dh1[(long)s * 128 + j] * rin[(long)s * C2 + i]; a1 += dh1[(long)(s + 1) * 128 + j] * rin[(long)(s + 1) * C2 + i]; }
-    if (s < S) a0 += dh1[(long)s * 128 + j] * rin[(long)s * C2 + i];
-    gW1[(long)j * C2 + i] = a0 + a1;
+  if ((int)blockIdx.x < nb_small) {
+    __shared__ float red[4][64];
+    const int n2 = 32 * 128, n3 = E * 32, nb = 128 + 32 + E;
+    const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l;
+    float acc = 0.f;
+    float* dst = nullptr;
+    if (i < n2) {
+      const int j = i / 128, c = i % 128;
+      for (int s = u; s < S; s += 4) acc += dh2[(long)s * 32 + j] * rh1[(long)s * 128 + c];
+      if (gW2) dst = gW2 + i;
+    } else if (i < n2 + n3) {
+      const int k = i - n2, j = k / 32, c = k % 32;
+      for (int s = u; s < S; s += 4) acc += dlog[(long)s * E + j] * rh2[(long)s * 32 + c];
+      if (gW3) dst = gW3 + k;
+    } else if (i < n2 + n3 + nb) {
+      const int k = i - n2 - n3;
+      if (k < 128) { for (int s = u; s < S; s += 4) acc += dh1[(long)s * 128 + k]; if (gb1) dst = gb1 + k; }
+      else if (k < 160) { for (int s = u; s < S; s += 4) acc += dh2[(long)s * 32 + (k - 128)]; if (gb2) dst = gb2 + (k - 128); }
+      else { for (int s = u; s < S; s += 4) acc += dlog[(long)s * E + (k - 160)]; if (gb3) dst = gb3 + (k - 160); }
+    }
+    red[u][l] = acc;
+    __syncthreads();
+    if (u == 0 && dst) *dst = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
     return;
   }
-  const int n2 = 32 * 128, n3 = E * 32, nb = 128 + 32 + E;
-  const int i = (blockIdx.x - nb_w1) * 64 + l;
-  float acc = 0.f;
-  float* dst = nullptr;
-  if (i < n2) {
-    const int j = i / 128, c = i % 128;
-    for (int s = u; s < S; s += 4) acc += dh2[(long)s * 32 + j] * rh1[(long)s * 128 + c];
-    if (gW2) dst = gW2 + i;
-  } else if (i < n2 + n3) {
-    const int k = i - n2, j = k / 32, c = k % 32;
-    for (int s = u; s < S; s += 4) acc += dlog[(long)s * E + j] * rh2[(long)s * 32 + c];
-    if (gW3) dst = gW3 + k;
-  } else if (i < n2 + n3 + nb) {
-    const int k = i - n2 - n3;
-    if (k < 128) { for (int s = u; s < S; s += 4) acc += dh1[(long)s * 128 + k]; if (gb1) dst = gb1 + k; }
-    else if (k < 160) { for (int s = u; s < S; s += 4) acc += dh2[(long)s * 32 + (k - 128)]; if (gb2) dst = gb2 + (k - 128); }
-    else { for (int s = u; s < S; s += 4) acc += dlog[(long)s * E + (k - 160)]; if (gb3) dst = gb3 + (k - 160); }
+  if ((int)blockIdx.x < nb_small + nb_c) {
+    const long total = (long)S * C;
+    const float invN = 1.f / (float)N;
+    for (long idx = (long)(blockIdx.x - nb_small) * 256 + threadIdx.x; idx < total; idx += (long)nb_c * 256) {
+      const int s = (int)(idx / C), i = (int)(idx % C);
+      const long o = ((long)s * KLT + KL + 1) * C + i;
+      const float v = drin[(long)s * C2 + i] * invN;
+      if (bf16) ((unsigned short*)Text_)[o] = f2bf(v); else ((float*)Text_)[o] = v;
+    }
+    return;
   }
-  red[u][l] = acc;
-  __syncthreads();
-  if (u == 0 && dst) *dst = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  const long per = 128L * C2;
+  const int nb_w = (int)gridDim.x - nb_small - nb_c;
+  for (long idx = ((long)(blockIdx.x - nb_small - nb_c) * 256 + threadIdx.x) * 4; idx < per; idx += (long)nb_w * 1024) {
+    f32x4_t acc = *(const f32x4_t*)(slabs + idx);
+    for (int k = 1; k < ks; ++k) { const f32x4_t b = *(const f32x4_t*)(slabs + (long)k * per + idx); acc += b; }
+    *(f32x4_t*)(gW1 + idx) = acc;
+  }
 }
 int k_router_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads,
                  const float* lb_grad, hipStream_t st) {
   ProfScope ps_("k_router_bwd", 0.0, 0.0, st);
   const Dims& d = pl.d;
   RouterBwdArgs a{prm.r0_w, prm.r2_w, prm.r4_w, 2 * d.C, d.E, d.S, d.lb_loss, lb_grad};
-  hipLaunchKernelGGL(kk_router_bwd_in, dim3(cdiv(d.S, RBF)), dim3(256), 0, st, a, (const float*)(saved + pl.o_probs),
+  hipLaunchKernelGGL(kk_router_bwd_a, dim3(d.S), dim3(256), 0, st, a, (const float*)(saved + pl.o_probs),
                      (const float*)(scratch + pl.o_dp), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
-                     (float*)(scratch + pl.o_rbw), d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL, d.C, d.N);
-  const int nb_w1 = cdiv(2 * d.C, 64) * 32;                 // 64 columns x 4 rows of dW1 per block, 128 rows
+                     (float*)(scratch + pl.o_rbw));
+  float* rbw = (float*)(scratch + pl.o_rbw);
+  float* dh1 = rbw;
+  float* drin = rbw + (long)d.S * 128;
+  {   // drin = dh1 W1   (fp32 engine GEMM)
+    GemmArgs g;
+    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
+    g.A = dh1; g.B = prm.r0_w; g.C = drin;
+    g.M = d.S; g.N = 2 * d.C; g.K = 128; g.lda = 128; g.b_layout = MN_MAJOR; g.ldb = 2L * d.C; g.sCi = 2L * d.C; g.tile = 64;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  int ks = 1;
+  if (grads.r0_w) {   // dW1 = dh1^T rin ; split over the frames, the slabs are added by the last launch (no reduce pass)
+    GemmArgs g;
+    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
+    g.A = dh1; g.B = saved + pl.o_rin; g.C = grads.r0_w;
+    g.M = 128; g.N = 2 * d.C; g.K = d.S; g.a_layout = g.b_layout = MN_MAJOR; g.lda = 128; g.ldb = 2L * d.C; g.sCi = 2L * d.C;
+    g.tile = 64; g.slabs = (float*)(scratch + pl.o_slabs); g.ksplit = choose_ksplit(g, slab_floats(d));
+    g.keep_slabs = 1;
+    ks = g.ksplit;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
   const int nb_small = cdiv(32 * 128 + d.E * 32 + 160 + d.E, 64);
-  hipLaunchKernelGGL(kk_router_bwd_w, dim3((unsigned)(nb_w1 + nb_small)), dim3(256), 0, st, d.S, d.E, 2 * d.C, nb_w1, (const float*)(scratch + pl.o_rbw),
-                     (const float*)(saved + pl.o_rin), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
-                     grads.r0_w, grads.r0_b, grads.r2_w, grads.r2_b, grads.r4_w, grads.r4_b);
+  const int nb_c = (int)grid1db((long)d.S * d.C, 512);
+  const int nb_w = (grads.r0_w && ks > 1) ? (int)grid1db(128L * 2 * d.C / 4, 512) : 0;
+  hipLaunchKernelGGL(kk_router_bwd_fin, dim3((unsigned)(nb_small + nb_c + nb_w)), dim3(256), 0, st, d.S, d.E, 2 * d.C, nb_small, nb_c,
+                     (const float*)(scratch + pl.o_rbw), (const float*)(saved + pl.o_rh1), (const float*)(saved + pl.o_rh2),
+                     grads.r0_w, grads.r0_b, grads.r2_w, grads.r2_b, grads.r4_w, grads.r4_b, (const float*)(scratch + pl.o_slabs), ks,
+                     d.bf16, (void*)(saved + pl.o_Text), d.KLT, d.KL, d.C, d.N);
   AVMOE_CHECK_LAUNCH("router_bwd");
   return OK;
 }

@@ -664,69 +664,45 @@ struct RouterArgs {
   const float *W1, *b1, *W2, *b2, *W3, *b3, *noise;
   int C2, E, S;
 };
-// The whole router for RF frames per block: layer 1 (2C -> 128) with one wave per output row -- the lanes stride over the inputs,
-// so the rows of W1 are read coalesced and ONCE per block for all its frames --, then the two small layers, the softmax and the
-// first-max argmax with one thread per output.  fp32 throughout, fixed summation order (bit-reproducible indices).
-constexpr int RF = 4;
-__global__ void __launch_bounds__(256) kk_router_fwd(RouterArgs a, const float* __restrict__ rin, float* rh1, float* rh2, float* probs,
-                                                     float* probs_out, int64_t* idx_out, float* lb_zero) {
-  extern __shared__ float s_rin[];                       // RF x C2
-  __shared__ float s_h1[RF][128], s_h2[RF][32], s_lg[RF][MAX_E];
-  const int s0 = blockIdx.x * RF, nf = min(RF, a.S - s0), t = threadIdx.x;
-  const int wave = t >> 6, lane = t & 63;
-  if (lb_zero && blockIdx.x == 0 && t == 0) *lb_zero = 0.f;          // (sites without the load-balancing loss report 0)
-  for (int i = t; i < RF * a.C2; i += 256) { const int f = i / a.C2; s_rin[i] = f < nf ? rin[(long)s0 * a.C2 + i] : 0.f; }
-  __syncthreads();
-  for (int j = wave; j < 128; j += 4) {
-    const float* w = a.W1 + (long)j * a.C2;
-    float acc[RF];
-#pragma unroll
-    for (int f = 0; f < RF; ++f) acc[f] = 0.f;
-    for (int i = lane; i < a.C2; i += 64) {
-      const float wv = w[i];
-#pragma unroll
-      for (int f = 0; f < RF; ++f) acc[f] += wv * s_rin[f * a.C2 + i];
-    }
-#pragma unroll
-    for (int f = 0; f < RF; ++f) acc[f] = wave_sum(acc[f]);
-    if (lane == 0) {
-      const float b = a.b1[j];
-#pragma unroll
-      for (int f = 0; f < RF; ++f) {
-        const float h = fmaxf(acc[f] + b, 0.f);
-        s_h1[f][j] = h;
-        if (f < nf) rh1[(long)(s0 + f) * 128 + j] = h;      // kept for the backward
-      }
-    }
+// one block per frame: layer-1 pre-activations from the engine GEMM -- summed here over its split-K slabs, in slab order, when it
+// ran split (no separate reduce pass) --, then bias / ReLU, the two small layers, softmax and first-max argmax.  fp32, fixed order.
+__global__ void __launch_bounds__(128) kk_router_tail(RouterArgs a, float* rh1, const float* slabs, int ks, float* rh2, float* probs,
+                                                      float* probs_out, int64_t* idx_out, float* lb_zero) {
+  __shared__ float s_h1[128], s_h2[32], s_lg[MAX_E];
+  const int s = blockIdx.x, t = threadIdx.x;
+  if (lb_zero && s == 0 && t == 0) *lb_zero = 0.f;          // (sites without the load-balancing loss report 0)
+  {
+    float pre;
+    if (ks > 1) {
+      pre = 0.f;
+      const long per = (long)a.S * 128;
+      for (int k = 0; k < ks; ++k) pre += slabs[(long)k * per + (long)s * 128 + t];
+    } else pre = rh1[(long)s * 128 + t];
+    const float h = fmaxf(pre + a.b1[t], 0.f);
+    s_h1[t] = h; rh1[(long)s * 128 + t] = h;                 // kept for the backward
   }
   __syncthreads();
-  if (t < RF * 32) {
-    const int f = t >> 5, o = t & 31;
+  if (t < 32) {
     float acc = 0.f;
-    for (int i = 0; i < 128; ++i) acc += a.W2[o * 128 + i] * s_h1[f][i];
-    const float h = fmaxf(acc + a.b2[o], 0.f);
-    s_h2[f][o] = h;
-    if (f < nf) rh2[(long)(s0 + f) * 32 + o] = h;
+    for (int i = 0; i < 128; ++i) acc += a.W2[t * 128 + i] * s_h1[i];
+    const float h = fmaxf(acc + a.b2[t], 0.f);
+    s_h2[t] = h; rh2[(long)s * 32 + t] = h;
   }
   __syncthreads();
-  if (t < RF * MAX_E) {
-    const int f = t / MAX_E, e = t % MAX_E;
-    if (e < a.E && f < nf) {
-      float acc = 0.f;
-      for (int i = 0; i < 32; ++i) acc += a.W3[e * 32 + i] * s_h2[f][i];
-      s_lg[f][e] = acc + a.b3[e] + (a.noise ? a.noise[(long)(s0 + f) * a.E + e] : 0.f);
-    }
+  if (t < a.E) {
+    float acc = 0.f;
+    for (int i = 0; i < 32; ++i) acc += a.W3[t * 32 + i] * s_h2[i];
+    s_lg[t] = acc + a.b3[t] + (a.noise ? a.noise[(long)s * a.E + t] : 0.f);
   }
   __syncthreads();
-  if (t < nf) {
-    const int s = s0 + t;
-    float mx = s_lg[t][0];
-    for (int e = 1; e < a.E; ++e) mx = fmaxf(mx, s_lg[t][e]);
+  if (t == 0) {
+    float mx = s_lg[0];
+    for (int e = 1; e < a.E; ++e) mx = fmaxf(mx, s_lg[e]);
     float sum = 0.f;
-    for (int e = 0; e < a.E; ++e) sum += expf(s_lg[t][e] - mx);
+    for (int e = 0; e < a.E; ++e) sum += expf(s_lg[e] - mx);
     int best = 0; float bp = -1.f;
     for (int e = 0; e < a.E; ++e) {
-      const float p = expf(s_lg[t][e] - mx) / sum;
+      const float p = expf(s_lg[e] - mx) / sum;
       probs[(long)s * a.E + e] = p;
       if (probs_out) probs_out[(long)s * a.E + e] = p;
       if (p > bp) { bp = p; best = e; }            // strict '>' : first maximum wins (torch.argmax)
@@ -754,12 +730,18 @@ int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& p
     set_last_error("moe: router parameters missing"); return ERR_BAD_ARG;
   }
   RouterArgs a{prm.r0_w, prm.r0_b, prm.r2_w, prm.r2_b, prm.r4_w, prm.r4_b, noise, 2 * d.C, d.E, d.S};
-  const size_t sh = (size_t)RF * 2 * d.C * sizeof(float);
-  if (sh > 160 * 1024) { set_last_error("router: C=%d too wide", d.C); return ERR_UNSUPPORTED; }
-  if (sh > 48 * 1024 && hipFuncSetAttribute((const void*)kk_router_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
-    set_last_error("router: LDS attribute"); return ERR_LAUNCH;
+  int ks = 1;
+  {   // layer 1 on the matrix pipe in exact fp32 whatever the activation dtype (bit-stable argmax): rh1 = rin W1^T
+    GemmArgs g;
+    g.dtype = GEMM_F32; g.out_dtype = GEMM_F32;
+    g.A = saved + pl.o_rin; g.B = prm.r0_w; g.C = saved + pl.o_rh1;
+    g.M = d.S; g.N = 128; g.K = 2 * d.C; g.lda = 2L * d.C; g.ldb = 2L * d.C; g.sCi = 128;
+    g.tile = 64; g.slabs = (float*)(scratch + pl.o_slabs); g.ksplit = choose_ksplit(g, slab_floats(d));   // few tiles, long K
+    g.keep_slabs = 1;                                      // the tail kernel adds the slabs: no reduce launch
+    ks = g.ksplit;
+    AVMOE_TRY(launch_gemm(g, st));
   }
-  hipLaunchKernelGGL(kk_router_fwd, dim3(cdiv(d.S, RF)), dim3(256), sh, st, a, (const float*)(saved + pl.o_rin), (float*)(saved + pl.o_rh1),
+  hipLaunchKernelGGL(kk_router_tail, dim3(d.S), dim3(128), 0, st, a, (float*)(saved + pl.o_rh1), (const float*)(scratch + pl.o_slabs), ks,
                      (float*)(saved + pl.o_rh2), (float*)(saved + pl.o_probs), probs_out, idx_out, (lb_out && !d.lb_loss) ? lb_out : nullptr);
   AVMOE_CHECK_LAUNCH("router");
   if (lb_out && d.lb_loss) {

@@ -49,6 +49,7 @@ struct GemmArgs {
   // split-K: partial sums go to fp32 slabs [ksplit][batch][M][N] in `slabs`, then a reduce pass
   int ksplit = 1;
   float* slabs = nullptr;
+  int keep_slabs = 0;                   // split-K: leave the partial sums in `slabs` (no reduce pass): the caller's consumer adds them
   int tile = 0;                         // 0 = auto, 64 or 128 = force block tile
   // optional second K segment, accumulated into the same tile before the epilogue:
   //   C += alpha * A2[b][i][k2] * B2[b][j][k2]   with A2 K_MAJOR (lda2), B2 MN_MAJOR (ldb2), own batch strides.

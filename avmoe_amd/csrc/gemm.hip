@@ -772,7 +772,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return ERR_UNSUPPORTED;
   }
   if (st != OK) return st;
-  if (d.ksplit > 1) {
+  if (d.ksplit > 1 && !a.keep_slabs) {
     const long total = (long)d.nbatch * a.M * a.N;
     if (total >= (1L << 31)) { set_last_error("gemm: split-K result too large"); return ERR_UNSUPPORTED; }
     const long nvec = (a.N % 4 == 0) ? total / 4 : total;

@@ -197,7 +197,7 @@ def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
     if name.endswith("_full"):
         # at the real token counts the skinny products of a chunk (att^T X: few frames x few column tiles) are split over the token
         # contraction to fill the chip, and the split factor depends on the frames per chunk: same numbers in another summation order
-        tol = 2e-2 if bf16 else 2e-5
+        tol = 2e-2 if bf16 else 2e-4
         assert float((run.out.float() - whole.out.float()).abs().max()) <= tol * float(whole.out.float().abs().max())
         gmax0 = max(float(v.abs().max()) for v in g0.values())
         for k in g0:
