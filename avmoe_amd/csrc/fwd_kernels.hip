@@ -195,19 +195,26 @@ __device__ __forceinline__ void prep_rw(const PrepAllArgs& a, float* rw, int bx)
   s = wave_sum(s);
   if (lane == 0) rw[c] = s;
 }
-// wbar[m] = mean_n Wc[n][m], zero in the padding m >= M: a block owns 16 columns x 16 row streams (stream k adds rows k, k + 16, ..),
-// combined in double in a fixed order (no float atomics: bit-reproducible)
+// wbar[m] = mean_n Wc[n][m], zero in the padding m >= M: a block owns 16 columns x 16 row streams (stream k adds rows k, k + 16, ..,
+// eight independent loads in flight: at N = 4096 a stream is 256 rows long and the walk is latency-bound), combined in double in a fixed
+// order (no float atomics: bit-reproducible)
 __device__ __forceinline__ void prep_wbar(const PrepAllArgs& a, float* wbar, int bx) {
   __shared__ double red[16][16];
   const int c = threadIdx.x & 15, k = threadIdx.x >> 4;
   const int m = bx * 16 + c;
-  float a0 = 0.f, a1 = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
   if (m < a.M) {
+    const float* p = a.Wc + m;
     int n = k;
-    for (; n + 16 < a.N; n += 32) { a0 += a.Wc[(long)n * a.M + m]; a1 += a.Wc[(long)(n + 16) * a.M + m]; }
-    for (; n < a.N; n += 16) a0 += a.Wc[(long)n * a.M + m];
+    for (; n + 7 * 16 < a.N; n += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(long)(n + 16 * u) * a.M];
+    }
+    for (; n < a.N; n += 16) acc[0] += p[(long)n * a.M];
   }
-  red[k][c] = (double)a0 + (double)a1;
+  red[k][c] = (((double)acc[0] + (double)acc[1]) + ((double)acc[2] + (double)acc[3])) + (((double)acc[4] + (double)acc[5]) + ((double)acc[6] + (double)acc[7]));
   __syncthreads();
   if (k == 0 && m < a.Mb) {
     double t = 0.0;
@@ -469,22 +476,29 @@ __global__ void __launch_bounds__(256) kk_xstats_fin(const float* __restrict__ p
     }
     return;
   }
-  const long total = (long)S * C;
-  for (long i = (long)(blockIdx.x - nb_sum) * 256 + threadIdx.x; i < total; i += (long)(gridDim.x - nb_sum) * 256) {
-    const int s = (int)(i / C), c = (int)(i % C);
+  // a block owns 64 columns of one frame x 4 tile streams (stream u adds tiles u, u + 4, .., two loads in flight), combined through LDS
+  // in a fixed order
+  __shared__ float red[4][64];
+  const int ncb = (C + 63) / 64;
+  const int b = (int)blockIdx.x - nb_sum, s = b / ncb, cb = b - s * ncb;
+  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+  const int c = cb * 64 + l;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
     const float* p = xpart + (long)s * tiles * C + c;
-    float a0 = 0.f, a1 = 0.f;
-    int tl = 0;
-    for (; tl + 1 < tiles; tl += 2) { a0 += p[(long)tl * C]; a1 += p[(long)(tl + 1) * C]; }
+    int tl = u;
+    for (; tl + 4 < tiles; tl += 8) { a0 += p[(long)tl * C]; a1 += p[(long)(tl + 4) * C]; }
     if (tl < tiles) a0 += p[(long)tl * C];
-    rin[(long)s * rin_ld + c] = (a0 + a1) * scale;
   }
+  red[u][l] = a0 + a1;
+  __syncthreads();
+  if (u == 0 && c < C) rin[(long)s * rin_ld + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
 }
 int k_xstats_fin(const float* parts, int nparts, long n, float* out, const float* xpart, int tiles, int C, int S, float* rin, long rin_ld,
                  float scale, hipStream_t st) {
   ProfScope ps_("k_xstats_fin", 0.0, 0.0, st);
   if (n % 4) { set_last_error("xstats_fin: row count not a multiple of 4"); return ERR_UNSUPPORTED; }
-  const int nb_sum = (int)std::min<long>(cdiv(n, 1024), 2048), nb_col = (int)grid1d((long)S * C, 1024);
+  const int nb_sum = (int)std::min<long>(cdiv(n, 1024), 2048), nb_col = S * cdiv(C, 64);
   hipLaunchKernelGGL(kk_xstats_fin, dim3((unsigned)(nb_sum + nb_col)), dim3(256), 0, st, parts, nparts, n, out, nb_sum, xpart, tiles, C, S, rin,
                      rin_ld, scale);
   AVMOE_CHECK_LAUNCH("xstats_fin");
