@@ -398,21 +398,40 @@ __global__ void __launch_bounds__(256) kk_dT0_dTy(const float* dT, const float* 
   rowpart[((long)by * 2 + 0) * C + c] = drw;
   rowpart[((long)by * 2 + 1) * C + c] = dbf;
 }
-// dBmT = T([dBm | dabx | 0])   (one block per (frame, latent row));  dwbar[m] = sum_s dBm[s][Kcy][m] and
-// dbcbar = sum_s dabx[s][Kcy] are column sums over the frames (k_prep_dBm)
+// ONE launch: blocks [0, rows): dBmT = T([dBm | dabx | 0]) (one block per (frame, latent row));  the others: the two sums over the
+// frames  dwbar[m] = sum_s dBm[s][Kcy][m]  and  dbcbar = sum_s dabx[s][Kcy]  (64 outputs x 4 frame streams per block, fixed order)
 template <typename T>
-__global__ void __launch_bounds__(256) kk_prep_dBm(const float* dBm, const float* dabx, void* dBmT_, int Kcy, int Kcyb, int M, int Mb) {
+__global__ void __launch_bounds__(256) kk_prep_dBm(const float* dBm, const float* dabx, void* dBmT_, float* dvec_wbar, int rows, int S, int Kcy,
+                                                   int Kcyb, int M, int Mb) {
   T* dBmT = (T*)dBmT_;
-  const long row = blockIdx.x;
-  const int q = (int)(row % Kcyb);
-  const float* src = dBm + row * Mb;
-  T* dst = dBmT + row * Mb;
-  const float ab = q < Kcy ? dabx[row] : 0.f;
-  for (int m = threadIdx.x; m < Mb; m += 256) {
-    float v = 0.f;
-    if (q < Kcy) v = m < M ? src[m] : (m == M ? ab : 0.f);
-    stT<T>(dst, m, v);
+  if ((int)blockIdx.x < rows) {
+    const long row = blockIdx.x;
+    const int q = (int)(row % Kcyb);
+    const float* src = dBm + row * Mb;
+    T* dst = dBmT + row * Mb;
+    const float ab = q < Kcy ? dabx[row] : 0.f;
+    for (int m = threadIdx.x; m < Mb; m += 256) {
+      float v = 0.f;
+      if (q < Kcy) v = m < M ? src[m] : (m == M ? ab : 0.f);
+      stT<T>(dst, m, v);
+    }
+    return;
   }
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
+  const int m = ((int)blockIdx.x - rows) * 64 + l;             // m < M: dwbar[m] ; m == Mb: dbcbar (dvec layout: [dwbar (Mb) | dbcbar])
+  float a0 = 0.f, a1 = 0.f;
+  if (m < M) {
+    const float* p = dBm + (long)Kcy * Mb + m;
+    int s = u;
+    for (; s + 4 < S; s += 8) { a0 += p[(long)s * Kcyb * Mb]; a1 += p[(long)(s + 4) * Kcyb * Mb]; }
+    if (s < S) a0 += p[(long)s * Kcyb * Mb];
+  } else if (m == Mb) {
+    for (int s = u; s < S; s += 4) a0 += dabx[(long)s * Kcyb + Kcy];
+  }
+  red[u][l] = a0 + a1;
+  __syncthreads();
+  if (u == 0 && (m < M || m == Mb)) dvec_wbar[m] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 // dqr[kc] = sum_{s,n} dL1 bc[n] ; dqb[kc] = sum_{s,n} dL1     (partials per (s,kc) row, then over s)
 template <typename T>
@@ -430,19 +449,40 @@ __global__ void __launch_bounds__(256) kk_dqrqb_part(const void* dL1_, const flo
 struct Hop1FinArgs { W16 gtok; int e_of_lat[MAX_E]; int S, N, M, Mk, Mb, C, Cy, K, Kp, KL, Kcy, Kcyb; };
 // drw[c] += sum_kc T0[kc][c] dqr[kc] ; dbf[c] += sum_kc T0[kc][c] dqb[kc]      (in place in dvec; thread per channel)
 // (a block owns 64 channels; its four waves take every fourth latent row and are combined through LDS in a fixed order)
+// dqr / dqb themselves are sums over the frames of the per-(frame, row) partials `part` ([2][S * Kcyb]): every block adds them up
+// for itself (thread = latent row x 4 frame streams, fixed order -- they are S x Kcyb numbers), block 0 also leaves them in dqp_fin
 template <typename T>
-__global__ void __launch_bounds__(256) kk_hop1_vec(const void* T0T_, const float* dqp_fin, float* dvec, int C, int Kcy, int Kcyb) {
+__global__ void __launch_bounds__(256) kk_hop1_vec(const void* T0T_, const float* part, float* dqp_fin, float* dvec, int C, int Kcy, int Kcyb, int S) {
   const T* T0T = (const T*)T0T_;
   __shared__ float red[2][4][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  extern __shared__ float s_q[];                     // dqr [Kcyb] | dqb [Kcyb]
+  const int cl = threadIdx.x & 63, pt = threadIdx.x >> 6;
+  const long rows = (long)S * Kcyb;
+  for (int k0 = 0; k0 < Kcyb; k0 += 64) {            // 64 latent rows at a time
+    const int kc = k0 + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (kc < Kcyb)
+      for (int s = pt; s < S; s += 4) { a0 += part[(long)s * Kcyb + kc]; a1 += part[rows + (long)s * Kcyb + kc]; }
+    red[0][pt][cl] = a0; red[1][pt][cl] = a1;
+    __syncthreads();
+    if (pt == 0 && kc < Kcyb) {
+      const float q0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+      const float q1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+      s_q[kc] = q0; s_q[Kcyb + kc] = q1;
+      if (blockIdx.x == 0) { dqp_fin[kc] = q0; dqp_fin[Kcyb + kc] = q1; }
+    }
+    __syncthreads();
+  }
   const int c = blockIdx.x * 64 + cl;
-  const float* dqr = dqp_fin; const float* dqb = dqp_fin + Kcyb;
   float a0 = 0.f, a1 = 0.f;
   if (c < C)
-    for (int kc = part; kc < Kcy; kc += 4) { const float t = ldT<T>(T0T, (long)kc * C + c); a0 += t * dqr[kc]; a1 += t * dqb[kc]; }
-  red[0][part][cl] = a0; red[1][part][cl] = a1;
+    for (int kc = pt; kc < Kcy; kc += 4) {
+      const float t = ldT<T>(T0T, (long)kc * C + c);
+      a0 += t * s_q[kc]; a1 += t * s_q[Kcyb + kc];
+    }
+  red[0][pt][cl] = a0; red[1][pt][cl] = a1;
   __syncthreads();
-  if (part == 0 && c < C) {
+  if (pt == 0 && c < C) {
     dvec[c] += (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
     dvec[C + c] += (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   }
@@ -651,22 +691,20 @@ int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
   const float* dBm = (const float*)(scratch + pl.o_dBm);
   const float* dabx = (const float*)(scratch + pl.o_dabx);
   float* dvec = (float*)(scratch + pl.o_dvec);
-  DISPATCH_T(d.bf16, kk_prep_dBm, dim3((unsigned)(d.S * d.Kcyb)), dim3(256), 0, st, dBm, dabx, (void*)(scratch + pl.o_dBmT), d.Kcy, d.Kcyb,
-             d.M, d.Mb);
-  AVMOE_CHECK_LAUNCH("prep_dBm");
   // dwbar (row Kcy of every frame's dBm), zero in the padding m >= M (dvec lies inside the backward's one memset: moe_plan.h) ; dbcbar
-  AVMOE_TRY(k_colsum2_f32(dBm + (long)d.Kcy * d.Mb, d.S, d.M, (long)d.Kcyb * d.Mb, dvec + 2 * d.C, 1.f,
-                          dabx + d.Kcy, d.S, 1, d.Kcyb, dvec + 2 * d.C + d.Mb, 1.f, st));
+  const int rows = d.S * d.Kcyb;
+  DISPATCH_T(d.bf16, kk_prep_dBm, dim3((unsigned)(rows + cdiv(d.Mb + 1, 64))), dim3(256), 0, st, dBm, dabx, (void*)(scratch + pl.o_dBmT),
+             dvec + 2 * d.C, rows, d.S, d.Kcy, d.Kcyb, d.M, d.Mb);
+  AVMOE_CHECK_LAUNCH("prep_dBm");
   return OK;
 }
 int k_dqrqb(const Plan& pl, char* scratch, const float* bc, hipStream_t st) {
   ProfScope ps_("k_dqrqb", 0.0, 0.0, st);
   const Dims& d = pl.d;
   const long rows = (long)d.S * d.Kcyb;
-  float* part = (float*)(scratch + pl.o_dqp);
+  float* part = (float*)(scratch + pl.o_dqp);              // per (frame, row) partials; k_hop1_finalize adds them over the frames
   DISPATCH_T(d.bf16, kk_dqrqb_part, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st,
              (const void*)(scratch + pl.o_dL1), bc, part, rows, d.N, d.Np);
-  AVMOE_TRY(k_colsum_f32(part, d.S, d.Kcyb, d.Kcyb, 2, rows, part + 2 * rows, d.Kcyb, 1.f, st));
   AVMOE_CHECK_LAUNCH("dqrqb");
   return OK;
 }
@@ -678,10 +716,10 @@ int k_hop1_finalize(const Plan& pl, char* saved, char* scratch, const avmoe_moe_
   a.S = d.S; a.N = d.N; a.M = d.M; a.Mk = d.Mk; a.Mb = d.Mb; a.C = d.C; a.Cy = d.Cy; a.K = d.K; a.Kp = d.Kp; a.KL = d.KL; a.Kcy = d.Kcy; a.Kcyb = d.Kcyb;
   const long big = std::max(std::max((long)d.N * d.M + d.N, (long)d.C * d.Cy + d.C), (long)d.KL * d.C);
   if (big >= (1L << 31)) { set_last_error("hop1_finalize: parameter tensor too large"); return ERR_UNSUPPORTED; }
-  const float* dqp_fin = (const float*)(scratch + pl.o_dqp) + 2L * d.S * d.Kcyb;
+  float* dqp_fin = (float*)(scratch + pl.o_dqp) + 2L * d.S * d.Kcyb;
   if (d.Kcy > 0)
-    DISPATCH_T(d.bf16, kk_hop1_vec, dim3(cdiv(d.C, 64)), dim3(256), 0, st, (const void*)(saved + pl.o_T0T), dqp_fin, (float*)(scratch + pl.o_dvec),
-               d.C, d.Kcy, d.Kcyb);
+    DISPATCH_T(d.bf16, kk_hop1_vec, dim3(cdiv(d.C, 64)), dim3(256), (size_t)2 * d.Kcyb * sizeof(float), st, (const void*)(saved + pl.o_T0T),
+               (const float*)(scratch + pl.o_dqp), dqp_fin, (float*)(scratch + pl.o_dvec), d.C, d.Kcy, d.Kcyb, d.S);
   DISPATCH_T(d.bf16, kk_hop1_finalize, dim3((unsigned)cdiv(big, 256), 3), dim3(256), 0, st, a, (const float*)(scratch + pl.o_dWcK),
              (const float*)(scratch + pl.o_dWf), (const float*)(scratch + pl.o_dvec), (const float*)(scratch + pl.o_dT0), dqp_fin,
              (const float*)(saved + pl.o_rw), (const float*)prm.fc_b, grads.conv_w, grads.conv_b, grads.fc_w, grads.fc_b);

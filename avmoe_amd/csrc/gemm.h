@@ -33,6 +33,8 @@ struct GemmArgs {
   void* C = nullptr;
   int M = 0, N = 0, K = 0;
   int nb1 = 1, nb2 = 1;                 // batch = nb1 * nb2 ; b = b1 * nb2 + b2
+  int nb3 = 1;                          // optional third batch level (tiled engine only, no D term): batch = nb1 * nb3 * nb2,
+  long sA3 = 0, sB3 = 0, sC3 = 0;       // b = (b1 * nb3 + b3) * nb2 + b2 ; strides in elements
   int dtype = GEMM_F32;                 // A, B (and D) element type
   int out_dtype = GEMM_F32;             // C element type
   int a_layout = K_MAJOR, b_layout = K_MAJOR;

@@ -32,7 +32,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct DevArgs {
   const char* A; const char* B; char* C; const char* D; const float* rs; float* slabs;
-  int M, N, K, nb2, ksplit, kper, nbatch, tiles_n;
+  int M, N, K, nb2, nb3, ksplit, kper, nbatch, tiles_n;
+  long sA3, sB3, sC3;
   long lda, ldb, sA1, sA2, sB1, sB2, sCi, sCj, sC1, sC2, sRS1, sRS2, sDi, sD1, sD2;
   float alpha; int accumulate, out_bf16, vec_c, vec_d;
   int fold_rps, fold_valid;      // batch folded into M: rows per sample / stored rows per sample (0 = no fold)
@@ -260,9 +261,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
   }
   const int m0 = (bx / p.tiles_n) * BM, n0 = (bx % p.tiles_n) * BN;
   const int split = by % p.ksplit, b = by / p.ksplit;
-  const int b1 = b / p.nb2, b2 = b % p.nb2;
-  const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2) * ESZ;
-  const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2) * ESZ;
+  const int b13 = b / p.nb2, b2 = b % p.nb2;
+  const int b1 = b13 / p.nb3, b3 = b13 % p.nb3;
+  const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2 + (long)b3 * p.sA3) * ESZ;
+  const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2 + (long)b3 * p.sB3) * ESZ;
   const int kbeg = split * p.kper;
   const int kend = min(p.K, kbeg + p.kper);
 
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
     }
     return;
   }
-  char* Cb = p.C + ((long)b1 * p.sC1 + (long)b2 * p.sC2) * (p.out_bf16 ? 2 : 4);
+  char* Cb = p.C + ((long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)b3 * p.sC3) * (p.out_bf16 ? 2 : 4);
   const char* Db = p.D ? p.D + ((long)b1 * p.sD1 + (long)b2 * p.sD2) * ESZ : nullptr;
   const float* rsb = p.rs ? p.rs + (long)b1 * p.sRS1 + (long)b2 * p.sRS2 : nullptr;
 
@@ -503,7 +505,8 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p, int l
     if (!live || part != 0u) continue;
     const unsigned b = idx / per, rem = idx - b * per;
     const unsigned i = rem / N, j = rem - i * N;
-    const int b1 = (int)b / p.nb2, b2 = (int)b % p.nb2;
+    const int b13 = (int)b / p.nb2, b2 = (int)b % p.nb2;
+    const int b1 = b13 / p.nb3, b3 = b13 % p.nb3;
     const float rsv = (p.D && p.rs) ? p.rs[(long)b1 * p.sRS1 + (long)b2 * p.sRS2 + i] : 0.f;
     for (unsigned e = 0; e < VEC; ++e) {
       float x = s[e] * p.alpha;
@@ -514,7 +517,7 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce(const DevArgs p, int l
         else dv = ((const float*)p.D)[off];
         x += rsv * dv;
       }
-      const long coff = (long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)i * p.sCi + (long)(j + e) * p.sCj;
+      const long coff = (long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)b3 * p.sC3 + (long)i * p.sCi + (long)(j + e) * p.sCj;
       if (p.out_bf16) {
         unsigned short* c = (unsigned short*)p.C + coff;
         if (p.accumulate) x += bf16_bits_to_f32(*c);
@@ -671,7 +674,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0
 
 size_t gemm_slab_bytes(const GemmArgs& a) {
   if (a.ksplit <= 1) return 0;
-  return (size_t)a.ksplit * a.nb1 * a.nb2 * (size_t)a.M * a.N * sizeof(float);
+  return (size_t)a.ksplit * a.nb1 * a.nb2 * a.nb3 * (size_t)a.M * a.N * sizeof(float);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
@@ -695,8 +698,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   DevArgs d;
   d.A = (const char*)a.A; d.B = (const char*)a.B; d.C = (char*)a.C; d.D = (const char*)a.D;
   d.rs = a.row_scale; d.slabs = a.slabs;
-  d.M = a.M; d.N = a.N; d.K = a.K; d.nb2 = a.nb2; d.ksplit = a.ksplit > 1 ? a.ksplit : 1;
-  d.nbatch = a.nb1 * a.nb2;
+  d.M = a.M; d.N = a.N; d.K = a.K; d.nb2 = a.nb2; d.nb3 = a.nb3 > 1 ? a.nb3 : 1; d.ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  d.nbatch = a.nb1 * a.nb2 * d.nb3;
+  d.sA3 = a.sA3; d.sB3 = a.sB3; d.sC3 = a.sC3;
+  if (d.nb3 > 1 && (a.D || a.A2 || a.epi != GEMM_EPI_NONE || a.Cx || a.st_rows || !mult16(a.sA3) || !mult16(a.sB3))) {
+    set_last_error("gemm: the third batch level serves plain products only (16-byte aligned strides)"); return ERR_BAD_ARG;
+  }
   d.lda = a.lda; d.ldb = a.ldb; d.sA1 = a.sA1; d.sA2 = a.sA2; d.sB1 = a.sB1; d.sB2 = a.sB2;
   d.sCi = a.sCi; d.sCj = a.sCj; d.sC1 = a.sC1; d.sC2 = a.sC2;
   d.sRS1 = a.sRS1; d.sRS2 = a.sRS2; d.sDi = a.sDi; d.sD1 = a.sD1; d.sD2 = a.sD2;
@@ -718,7 +725,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   {
     static const bool nostream = getenv("AVMOE_GEMM_NOSTREAM") != nullptr;     // dev switch: A/B against the tiled engine
-    if (!nostream && a.epi == GEMM_EPI_NONE) {
+    if (!nostream && a.epi == GEMM_EPI_NONE && a.nb3 <= 1) {
       const int s = launch_gemm_stream(a, stream);
       if (s <= 0) return s;
     }
@@ -730,7 +737,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.fold_rps = d.fold_valid = 0;
   {
     static const bool nofold = getenv("AVMOE_GEMM_NOFOLD") != nullptr;      // dev switch
-    if (!nofold && a.epi == GEMM_EPI_NONE && a.nb1 > 1 && a.nb2 == 1 && a.a_layout == K_MAJOR && a.sB1 == 0 && d.ksplit == 1 && !a.A2 && !a.D && a.lda > 0 &&
+    if (!nofold && a.epi == GEMM_EPI_NONE && a.nb1 > 1 && a.nb2 == 1 && d.nb3 == 1 && a.a_layout == K_MAJOR && a.sB1 == 0 && d.ksplit == 1 && !a.A2 && !a.D && a.lda > 0 &&
         a.sA1 > 0 && a.sA1 % a.lda == 0) {
       const long rps = a.sA1 / a.lda, rows = (long)(a.nb1 - 1) * rps + a.M;
       const int t0 = a.tile ? a.tile : ((a.M > 64 && a.N > 64) ? 128 : 64);      // tile of the unfolded launch
@@ -840,7 +847,7 @@ int launch_gemm_tokpair(const TokPairArgs& a, hipStream_t stream) {
   }
   // C1 = the chunks' partial sums, in chunk order (the split-K reduce of the engine)
   DevArgs d{};
-  d.C = (char*)a.C1; d.slabs = a.slabs; d.M = a.M1; d.N = a.Cg; d.nb2 = a.g; d.nbatch = a.g; d.ksplit = nchunks;
+  d.C = (char*)a.C1; d.slabs = a.slabs; d.M = a.M1; d.N = a.Cg; d.nb2 = a.g; d.nb3 = 1; d.sA3 = d.sB3 = d.sC3 = 0; d.nbatch = a.g; d.ksplit = nchunks;
   d.sCi = a.Cg; d.sCj = 1; d.sC1 = 0; d.sC2 = (long)a.M1 * a.Cg; d.alpha = 1.f; d.accumulate = 0; d.out_bf16 = 0;
   const long total = (long)a.g * a.M1 * a.Cg, nvec = (a.Cg % 4 == 0) ? total / 4 : total;
   int lgP = 0;

@@ -188,13 +188,14 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       }
     }
   }
-  for (int l = 0; l < d.El; ++l) {                         // dTW[s][slot l] = gate * a^T dzraw  (own expert's columns)
-    const int e = d.e_of_lat[l];
+  if (d.El > 0) {                                          // dTW[s][slot l] = gate * a^T dzraw  (own expert's columns), all slots in one launch
+    const int e0 = d.e_of_lat[0];                          // (latent experts are consecutive: the multimodal ones come first, AVS v2 makes all of them latent)
     GemmArgs g = base();
-    g.A = sc + pl.o_ag + (size_t)l * d.Kp * esz; g.B = dZx + (size_t)e * d.dgp * esz;
-    g.C = sc + pl.o_dTW + ((size_t)l * d.Kp * d.DZ + (size_t)e * d.dgp) * esz;
-    g.M = d.K; g.N = d.dgp; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.DZ; g.nb1 = d.S; g.nb2 = d.g;
+    g.A = sc + pl.o_ag; g.B = dZx + (size_t)e0 * d.dgp * esz;
+    g.C = sc + pl.o_dTW + (size_t)e0 * d.dgp * esz;
+    g.M = d.K; g.N = d.dgp; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.DZ; g.nb1 = d.S; g.nb2 = d.g; g.nb3 = d.El;
     g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.N * d.DZ; g.sB2 = (long)d.E * d.dgp;
+    g.sA3 = d.Kp; g.sB3 = d.dgp; g.sC3 = (long)d.Kp * d.DZ + d.dgp;
     g.sCi = d.DZ; g.sC1 = (long)d.KLT * d.DZ; g.sC2 = (long)d.E * d.dgp; g.out_dtype = dt;
     AVMOE_TRY(run(g, false));
   }
