@@ -37,8 +37,7 @@ def side_stream(dev: torch.device) -> "torch.cuda.Stream":
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        prio = int(os.environ.get("AVMOE_SIDE_PRIORITY", "0"))          # dev: -1 = high-priority side stream
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=prio)
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -73,16 +72,17 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None):
     Y = Y.contiguous()
     S, N, Cc = X.shape
     desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
-    for k, v in zip(names, params):
-        if v.dtype != torch.float32 or not v.is_contiguous() or v.device != X.device:
-            raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {X.device}")
     keep = module._attention_keep(S, N, X.device)
-    ptrs = module._fill_ptrs(params, keep)
-    nsaved = L.avmoe_moe_saved_bytes(C.byref(desc))
-    if nsaved == 0:
-        raise capi.AvmoeError(L.avmoe_last_error().decode())
-    saved = torch.empty(nsaved, dtype=torch.uint8, device=X.device)
-    scratch = _scratch(X.device, L.avmoe_moe_scratch_bytes(C.byref(desc)))
+    ptrs = module._fill_ptrs(params, keep, names=names, device=X.device)
+    wkey = (S, N, Y.shape[1], X.dtype, module.training)
+    sizes = module.__dict__.setdefault("_ws_sizes", {}).get(wkey)      # workspace sizes of this call shape (two plan evaluations otherwise)
+    if sizes is None:
+        sizes = (L.avmoe_moe_saved_bytes(C.byref(desc)), L.avmoe_moe_scratch_bytes(C.byref(desc)))
+        if sizes[0] == 0:
+            raise capi.AvmoeError(L.avmoe_last_error().decode())
+        module.__dict__["_ws_sizes"][wkey] = sizes
+    saved = torch.empty(sizes[0], dtype=torch.uint8, device=X.device)
+    scratch = _scratch(X.device, sizes[1])
     if add_to is not None:
         if add_to.shape != X.shape or add_to.dtype != X.dtype or not add_to.is_contiguous() or add_to.device != X.device:
             raise capi.AvmoeError("add_to must be a contiguous tensor with the shape, dtype and device of the tokens")
@@ -124,18 +124,25 @@ class _SiteBackward:
         sink = self.sink = getattr(module, "_grad_sink", None)
         self.use_sink = sink is not None and all(needs) and sink.matches(names, tensors)
         filler = module._site_cache()["fill_p"]
-        self.gptrs = cm.MoePtrs()
         if self.use_sink:
             # zeros, not empty: on accumulation micro-steps the alignment padding is added to the bucket as well
             self.flat = sink.flat if sink.fresh else torch.zeros_like(sink.flat)
             self.grads = None                            # the kernels write at flat + offset: no per-parameter views needed
-            filler.fill(self.gptrs, None, base_ptr=self.flat.data_ptr(), offsets=sink.offsets)
+            hit = module.__dict__.get("_gptrs_cache")     # the struct of the last call, as long as the sink's memory is the same
+            if hit is not None and hit[0] == (self.flat.data_ptr(), id(sink)):
+                self.gptrs = hit[1]
+            else:
+                self.gptrs = filler.fill(cm.MoePtrs(), None, base_ptr=self.flat.data_ptr(), offsets=sink.offsets)
+                module.__dict__["_gptrs_cache"] = ((self.flat.data_ptr(), id(sink)), self.gptrs)
         else:
+            self.gptrs = cm.MoePtrs()
             self.grads = {k: (torch.empty_like(v) if needs[i] else None) for i, (k, v) in enumerate(tensors.items())}
             filler.fill(self.gptrs, [self.grads[k] for k in names])
         self.d_out = d_out.to(self.X.dtype).contiguous()
         self.lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
-        self.scratch = _scratch(self.X.device, self.L.avmoe_moe_scratch_bytes(C.byref(desc)))
+        wkey = (desc.S, desc.N, desc.M, self.X.dtype, bool(desc.training))
+        sizes = module.__dict__.get("_ws_sizes", {}).get(wkey)
+        self.scratch = _scratch(self.X.device, sizes[1] if sizes else self.L.avmoe_moe_scratch_bytes(C.byref(desc)))
         self.dX, self.dY, self.acc = dX, dY, (int(acc_dx), int(acc_dy))
 
     def run(self, parts=0):
@@ -434,11 +441,12 @@ class MoEAdapter(nn.Module):
         return c
 
     def refresh(self):
-        self.__dict__.pop("_avmoe_cache", None)
+        for k in ("_avmoe_cache", "_ptrs_cache", "_gptrs_cache", "_ws_sizes"):
+            self.__dict__.pop(k, None)
 
     def __getstate__(self):
         st = self.__dict__.copy()                                      # per-process bookkeeping does not travel (deepcopy / pickle)
-        for k in ("_avmoe_cache", "_last_saved"):
+        for k in ("_avmoe_cache", "_last_saved", "_ptrs_cache", "_gptrs_cache", "_ws_sizes"):
             st.pop(k, None)
         return st
 
@@ -452,20 +460,32 @@ class MoEAdapter(nn.Module):
             out = {k: m._parameters[a] for k, (m, a) in zip(c["names"], c["owners"])}
         return out
 
-    def _fill_ptrs(self, params, keep=None):
-        """MoePtrs of this site's parameters (in _site_cache order), float buffers and -- for the "v1" experts -- dropout draws."""
+    def _fill_ptrs(self, params, keep=None, names=None, device=None):
+        """MoePtrs of this site's parameters (in _site_cache order), float buffers, BatchNorm counters and -- for the "v1" experts --
+        dropout draws.  The filled struct is kept and handed out again while every pointer is the one it was built from (a call
+        costs ~60 data_ptr() reads instead of ~60 validations + ctypes stores: at the reference's batch of 2 clips the host side of
+        a site step is what bounds it); `names` / `device`: validate dtype / layout / placement when the struct is (re)built."""
         c = self._site_cache()
+        bufs = [m._buffers[a] for _, m, a in c["bufs"]]
+        bump = bool(self.training and self.use_bn and c["nbts"])
+        cnts = [m._buffers[a] for _, m, a in c["nbts"]] if bump else []
+        key = (bump, tuple(t.data_ptr() for t in params), tuple(t.data_ptr() for t in bufs), tuple(t.data_ptr() for t in cnts))
+        hit = self.__dict__.get("_ptrs_cache")
+        if not keep and hit is not None and hit[0] == key:
+            return hit[1]
+        if names is not None:
+            for k, v in zip(names, params):
+                if v.dtype != torch.float32 or not v.is_contiguous() or v.device != device:
+                    raise capi.AvmoeError(f"parameter {k} must be a contiguous float32 tensor on {device}")
         P = cm.MoePtrs()
         c["fill_p"].fill(P, params)
-        bufs = [m._buffers[a] for _, m, a in c["bufs"]]
         for b in bufs:
             if b.dtype != torch.float32 or not b.is_contiguous():
                 raise capi.AvmoeError("BatchNorm running statistics must be contiguous float32 tensors")
         c["fill_b"].fill(P, bufs)
-        if self.training and self.use_bn and c["nbts"]:              # num_batches_tracked += 1 happens inside the forward's kernels (ABI 6)
-            cnts = [m._buffers[a] for _, m, a in c["nbts"]]
+        if bump:                                                      # num_batches_tracked += 1 happens inside the forward's kernels (ABI 6)
             for t in cnts:
-                if t.dtype != torch.int64 or t.device != bufs[0].device:
+                if t.dtype != torch.int64 or (bufs and t.device != bufs[0].device):
                     raise capi.AvmoeError("BatchNorm num_batches_tracked must be int64 tensors on the module's device")
             c["fill_n"].fill(P, cnts)
         if keep:
@@ -473,6 +493,8 @@ class MoEAdapter(nn.Module):
             for j in range(self.num_multimodal_experts + self.num_singlemodal_experts):
                 if P2.e[j].sa_keep:
                     P.e[j].sa_keep = P2.e[j].sa_keep
+        elif names is not None:
+            self.__dict__["_ptrs_cache"] = (key, P)                   # (only structs built WITH validation are kept)
         return P
 
     def grad_layout(self, align: int = 64):

@@ -16,6 +16,8 @@ LIB = os.path.join(LIBDIR, "libavmoe_hip.so")
 STAMP = os.path.join(LIBDIR, "libavmoe_hip.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
+if os.environ.get("AVMOE_DEV_BUILD"):        # development build: the A/B switches of scripts/README.md are compiled in (csrc/common.h: dev_env)
+    FLAGS.append("-DAVMOE_DEV")
 
 
 def sources():

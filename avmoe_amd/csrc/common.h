@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace avmoe {
 
@@ -32,6 +33,17 @@ const char* last_error();
     int s__ = (expr);                   \
     if (s__ != 0) return s__;           \
   } while (0)
+
+// Development switches (A/B toggles, sweep overrides: scripts/README.md) exist only in builds made with -DAVMOE_DEV
+// (AVMOE_DEV_BUILD=1 python -m avmoe_amd.build); the product library never reads them.  Four environment variables are part of
+// the product and read with plain getenv: AVMOE_PROF_SHAPES (profiler families per launch shape, prof.cpp), AVMOE_NO_SIDE /
+// AVMOE_SIDE_MIN (helper streams inside a call: off / smallest site in token elements that forks, side.cpp, moe_run.h) and
+// AVMOE_NXN_CHUNK (test hook: frames per chunk of the AVVP N x N block, moe_plan.cpp).
+#ifdef AVMOE_DEV
+static inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -724,7 +724,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return ERR_BAD_ARG;
   }
   {
-    static const bool nostream = getenv("AVMOE_GEMM_NOSTREAM") != nullptr;     // dev switch: A/B against the tiled engine
+    static const bool nostream = dev_env("AVMOE_GEMM_NOSTREAM") != nullptr;     // dev switch: A/B against the tiled engine
     if (!nostream && a.epi == GEMM_EPI_NONE && a.nb3 <= 1) {
       const int s = launch_gemm_stream(a, stream);
       if (s <= 0) return s;
@@ -736,7 +736,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   // latent rows on a 64-row tile).  Rows of the gaps between the samples' blocks are computed and not stored.
   d.fold_rps = d.fold_valid = 0;
   {
-    static const bool nofold = getenv("AVMOE_GEMM_NOFOLD") != nullptr;      // dev switch
+    static const bool nofold = dev_env("AVMOE_GEMM_NOFOLD") != nullptr;      // dev switch
     if (!nofold && a.epi == GEMM_EPI_NONE && a.nb1 > 1 && a.nb2 == 1 && d.nb3 == 1 && a.a_layout == K_MAJOR && a.sB1 == 0 && d.ksplit == 1 && !a.A2 && !a.D && a.lda > 0 &&
         a.sA1 > 0 && a.sA1 % a.lda == 0) {
       const long rps = a.sA1 / a.lda, rows = (long)(a.nb1 - 1) * rps + a.M;
@@ -814,7 +814,7 @@ int gemm_row_lse(const float* row_part, long rows, int tiles, float* lse, hipStr
 }
 
 int launch_gemm_tokpair(const TokPairArgs& a, hipStream_t stream) {
-  static const bool off = getenv("AVMOE_NO_TOKPAIR") != nullptr;      // dev switch: the two engine GEMMs instead
+  static const bool off = dev_env("AVMOE_NO_TOKPAIR") != nullptr;      // dev switch: the two engine GEMMs instead
   if (off || a.M1 <= 0 || a.M1 > 128 || a.M2 <= 0 || a.M2 > 64 ||          // (the 128-row second accumulator spills: not served)
        a.M1 % 8 || a.M2 % 8 || a.Cg % 8 || a.lda1 % 8 || a.lda2 % 8 || a.ldx % 8 ||
       a.sA1g % 8 || ((uintptr_t)a.A1 % 16) || ((uintptr_t)a.A2 % 16) || ((uintptr_t)a.X % 16) || a.N < 64 || !a.slabs)
@@ -832,7 +832,7 @@ int launch_gemm_tokpair(const TokPairArgs& a, hipStream_t stream) {
   p.lda1 = a.lda1; p.lda2 = a.lda2; p.ldx = a.ldx; p.sA1g = a.sA1g;
   p.M1 = a.M1; p.M2 = a.M2; p.S = a.S; p.N = a.N; p.g = a.g; p.Cg = a.Cg; p.tiles_n = tiles_n; p.F = F;
   {
-    static const int tk = [] { const char* e = getenv("AVMOE_TOKPAIR_TK"); return e && *e ? atoi(e) : 256; }();      // dev switch (multiple of 64)
+    static const int tk = [] { const char* e = dev_env("AVMOE_TOKPAIR_TK"); return e && *e ? atoi(e) : 256; }();      // dev switch (multiple of 64)
     p.TK = tk > 0 ? (tk + 63) / 64 * 64 : a.N;
   }
   constexpr int LDS = 2 * 2 * 64 * (128 * 2 + 16);          // two stages of the (128, 128) MN-major / MN-major segment

@@ -511,7 +511,7 @@ int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   // no configuration by more than +-3 % (same-box A/B of the cfg-2 step: 6.51 vs 6.50 ms) -- these kernels are not short of
   // bytes in flight; the 9-wave dApost configuration is held back by residency (105 VGPRs x 9 waves: one block per CU).
   // (Not built for the MN-major second segment: those kernels sit at their register limit already and would spill.)
-  static const bool pf2 = getenv("AVMOE_STREAM_PF2") != nullptr;
+  static const bool pf2 = dev_env("AVMOE_STREAM_PF2") != nullptr;
   if constexpr (A2MN) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false, MINW>(s, nb2, per_cu, st);
   else {
     if (pf2) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, true, MINW>(s, nb2, per_cu, st);
@@ -534,7 +534,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
     a.a_layout = K_MAJOR; a.b_layout = MN_MAJOR;
     a2mn = true;
   }
-  static const bool dy_whole = getenv("AVMOE_STREAM_DY_WHOLE") != nullptr;      // dev switch
+  static const bool dy_whole = dev_env("AVMOE_STREAM_DY_WHOLE") != nullptr;      // dev switch
   if (a2mn && a.nb2 == 1 && a.N > 384 && a.N % 32 == 0 && !a.D && !a.Cx && !dy_whole) {
     // dY over more than 24 column tiles: the two halves of the columns as two "groups" (A shared, B / B2 / C offset by half the
     // columns) -- two tiles per wave instead of four: the 12-wave configuration then has registers for its fragments and for the
@@ -561,7 +561,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
   s.alpha = a.alpha; s.b_mn = a.b_layout == MN_MAJOR; s.out_bf16 = a.out_dtype == GEMM_BF16;
   if (a.A2 && (((uintptr_t)a.B2 % 16) || a.ldb2 % 8 || a.s2B1 % 8 || a.s2B2 % 8)) return 1;      // B2 rows are read as 16-byte vectors
   s.contig = a.A2 != nullptr;
-  static const char* contig_env = getenv("AVMOE_STREAM_CONTIG");          // dev: force the tile-to-block assignment
+  static const char* contig_env = dev_env("AVMOE_STREAM_CONTIG");          // dev: force the tile-to-block assignment
   if (contig_env) s.contig = atoi(contig_env);
   s.Cx = a.Cx; s.nsplit = a.nsplit; s.ldcx = a.ldcx; s.sCx2 = a.sCx2;
   const int ks = cdiv(a.K, 32), ks2 = a.A2 ? cdiv(a.K2, 32) : 0, tiles = cdiv(a.N, 16);
@@ -622,7 +622,7 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #ifdef STREAM_SWEEP
   // development build: AVMOE_STREAM_CFG="KS,KS2,TPW,NW,BM,blocks per CU" picks one of the configurations below for every shape it fits
   // (scripts/stream_sweep.py); waves per SIMD of the launch bound = what that residency needs
-  if (const char* e = getenv("AVMOE_STREAM_CFG")) {
+  if (const char* e = dev_env("AVMOE_STREAM_CFG")) {
     int c[6] = {0, 0, 0, 0, 0, 0};
     sscanf(e, "%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5]);
 #define SW(KS_, KS2_, TPW_, NW_, BM_, PC_)                                                                                     \

@@ -68,7 +68,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     // kernel wants whole 4-column vectors, and nobody reads the padding of dAp
     g.M = d.NT; g.N = (d.KP % 4 == 0) ? d.KP : d.KPp; g.K = d.Cg; g.lda = d.C; g.b_layout = MN_MAJOR; g.ldb = d.KPp; g.nb2 = d.g;
     g.sA2 = d.Cg; g.sB2 = (long)d.Cg * d.KPp; g.sCi = (long)d.g * d.KPp; g.sC2 = d.KPp;
-    static const bool dap_f32 = getenv("AVMOE_DAP_F32") != nullptr;      // dev switch
+    static const bool dap_f32 = dev_env("AVMOE_DAP_F32") != nullptr;      // dev switch
     if (d.zsz == 2 && !dap_f32) {          // bf16 main columns + fp32 scalar columns: 640 instead of 1152 bytes per token, written and re-read
       GemmArgs h = g;
       h.out_dtype = GEMM_BF16; h.Cx = (float*)(sc + pl.o_dApx); h.nsplit = d.E * d.dgp; h.ldcx = (long)d.g * d.XW; h.sCx2 = d.XW;

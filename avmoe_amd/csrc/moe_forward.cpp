@@ -11,7 +11,7 @@ int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap) {
   const int tile = (g.tile ? g.tile : ((g.M > 64 && g.N > 64) ? 128 : ((g.M <= 32 && g.N <= 32) ? 32 : 64)));
   const long tiles = (long)cdiv(g.M, tile) * cdiv(g.N, tile) * g.nb1 * g.nb2;
   const int bk = g.dtype == GEMM_BF16 ? 64 : 32;
-  static const long target = getenv("AVMOE_KS_TARGET") ? atol(getenv("AVMOE_KS_TARGET")) : 512;     // workgroups wanted (dev override)
+  static const long target = dev_env("AVMOE_KS_TARGET") ? atol(dev_env("AVMOE_KS_TARGET")) : 512;     // workgroups wanted (dev override)
   long ks = std::max<long>(1, target / std::max<long>(tiles, 1));
   ks = std::min<long>(ks, std::max<long>(1, g.K / (4 * bk)));
   ks = std::min<long>(ks, 64);

@@ -87,7 +87,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Ex = d.El - d.Ey;
   if (d.El == 0) d.K = d.K > 0 ? d.K : 1;
   // ---- bottleneck layout ------------------------------------------------------------------------------------------------
-  static const bool no_gen = getenv("AVMOE_NO_GEN") != nullptr;          // development: without the generalised register-resident kernels
+  static const bool no_gen = dev_env("AVMOE_NO_GEN") != nullptr;          // development: without the generalised register-resident kernels
   const int g_site = d.g;
   // Merged groups.  A grouped 1x1 convolution is a dense one with a block-diagonal weight.  When the per-group bottleneck is tiny
   // (AVQA: 4 groups, bottleneck 12 -> 3 per group) padding every GROUP to the 16-entry granule of the register-resident kernels
@@ -99,7 +99,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   {
     const int merged = (int)round_up(d.d, 16), dg0 = d.d / g_site, grouped = g_site * (int)round_up(dg0, 16), ncg = merged / 16;
     const bool fast_shape = g_site == 2 && dg0 > 16 && dg0 <= 32 && d.K == 32 && d.E >= 2 && d.E <= 4;
-    try_merge = !no_gen && !getenv("AVMOE_NO_MERGE") && g_site > 1 && d.C <= 384 && merged < grouped && (ncg <= 4 || ncg == 6) && !fast_shape;
+    try_merge = !no_gen && !dev_env("AVMOE_NO_MERGE") && g_site > 1 && d.C <= 384 && merged < grouped && (ncg <= 4 || ncg == 6) && !fast_shape;
   }
   for (int attempt = try_merge ? 0 : 1; attempt < 2; ++attempt) {
     const bool merge = attempt == 0;
@@ -111,7 +111,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
     // that run 1.3-3x faster than the generic ones (HTS-AT / Swin-B sites at r = 8: bottleneck 48: -29 %, 32: -15 %, 24: -19 %,
     // 12 / 16: -4 % of the site step).  Padding columns are zero weights, as for every other padded width.
     // (Per-group bottlenecks up to 16 stay at 16 entries and run on the generalised kernels of tile_gen.hip instead -- half the Z-space bytes.)
-    if (d.g == 2 && d.dg < 32 && (d.dg > 16 || no_gen) && d.K == 32 && d.E >= 2 && d.E <= 4 && !getenv("AVMOE_NO_PAD32")) d.dgp = 32;
+    if (d.g == 2 && d.dg < 32 && (d.dg > 16 || no_gen) && d.K == 32 && d.E >= 2 && d.E <= 4 && !dev_env("AVMOE_NO_PAD32")) d.dgp = 32;
     d.Cg = d.C / d.g;
     d.DD = d.g * d.dgp;
     d.DZ = d.E * d.DD;
@@ -149,7 +149,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
     const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (2 * (size_t)d.esz);      // att + dSc (the scores / d att themselves never leave the chip)
     const size_t keep_all = (size_t)256 << 20;
     size_t budget = (size_t)2048 << 20;          // chunk workspace (scratch, reused by every site)
-    if (const char* ev = getenv("AVMOE_NXN_BUDGET_MB")) budget = (size_t)std::max(1, atoi(ev)) << 20;      // dev: sweep
+    if (const char* ev = dev_env("AVMOE_NXN_BUDGET_MB")) budget = (size_t)std::max(1, atoi(ev)) << 20;      // dev: sweep
     if ((size_t)d.S * per_frame > keep_all) d.nxc = (int)std::max<size_t>(1, std::min<size_t>((size_t)d.S, budget / per_frame));
     if (const char* ev = getenv("AVMOE_NXN_CHUNK")) d.nxc = std::max(1, std::min(d.S, atoi(ev)));     // tests: force the chunked path on small shapes
   }
@@ -158,15 +158,15 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Np = (int)round_up(d.N, 8);
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
   int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(256, d.S))));     // (A/B on the concurrent cfg-2 step)
-  if (const char* ev = getenv("AVMOE_BPS")) {     // development: "<bps for N >= 512>,<bps for N < 512>"
+  if (const char* ev = dev_env("AVMOE_BPS")) {     // development: "<bps for N >= 512>,<bps for N < 512>"
     int a = 0, b = 0;
     if (sscanf(ev, "%d,%d", &a, &b) == 2) bps = std::max(1, d.N >= 512 ? a : b);
   }
   d.nblk_tok = bps * d.S;
   d.zsz = (tile_fast_ok(d) || d.gen) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident paths
-  d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2) && !getenv("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
+  d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2) && !dev_env("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
-  d.fuse_xs = d.bf16 && d.zsz == 2 && gemm_stream_stats_ok(d.N, d.S, d.E * d.dgp, d.Cg, d.C, d.DZ) && !getenv("AVMOE_NO_FUSE_XSTATS");
+  d.fuse_xs = d.bf16 && d.zsz == 2 && gemm_stream_stats_ok(d.N, d.S, d.E * d.dgp, d.Cg, d.C, d.DZ) && !dev_env("AVMOE_NO_FUSE_XSTATS");
 
   size_t off[2] = {0, 0};
   int n = 0;

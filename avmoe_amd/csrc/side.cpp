@@ -18,7 +18,7 @@ bool side_disabled() {
 }  // namespace
 
 int side_mask() {
-  static const int m = [] { const char* e = getenv("AVMOE_SIDE_MASK"); return e && *e ? atoi(e) : 7; }();
+  static const int m = [] { const char* e = dev_env("AVMOE_SIDE_MASK"); return e && *e ? atoi(e) : 7; }();
   return m;
 }
 

@@ -1051,7 +1051,7 @@ namespace avmoe {
 // waves per block (1 .. 4): the count that puts the most waves on a CU within its 160 KB of LDS -- e.g. 3 waves x 2 blocks
 // rather than 4 waves x 1 block when a 4-wave block needs more than half of it (bottlenecks above 64)
 static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes) {
-  static const bool old_rule = getenv("AVMOE_PICK_WAVES_POW2") != nullptr;      // dev switch
+  static const bool old_rule = dev_env("AVMOE_PICK_WAVES_POW2") != nullptr;      // dev switch
   int best = 0, best_occ = 0;
   for (int nw = 4; nw >= 1; --nw) {
     if (old_rule && nw == 3) continue;
