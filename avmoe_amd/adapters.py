@@ -29,23 +29,6 @@ from . import _capi_moe as cm
 
 _SCRATCH: Dict[tuple, torch.Tensor] = {}
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
-_WORKER = None
-
-
-def _on_side(dev, side, fn):
-    """Runs fn() on THE helper host thread with `side` as its current HIP stream and returns a future.  The C-ABI calls release the
-    GIL, so the two sites of an AdapterPair are ENQUEUED by two host threads at once -- at the reference's batch of 2 clips a site
-    step is bounded by the host's launch rate (~100 launches of ~4.5 us per site and direction), not by the GPU."""
-    global _WORKER
-    if _WORKER is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="avmoe-side")
-
-    def job():
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(side):
-            return fn()
-    return _WORKER.submit(job)
 
 
 def side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -229,18 +212,11 @@ class _PairFunction(torch.autograd.Function):
         pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
         main = torch.cuda.current_stream(Xa.device)
-        side, threads = (side[0], side[1]) if isinstance(side, tuple) else (side, False)
-        ctx.threads = threads
         if side is not None:                           # site B on the side stream, concurrently with site A
             side.wait_stream(main)
-            if threads:                                # ... and enqueued by the helper host thread while this one enqueues site A
-                fut = _on_side(Xa.device, side, lambda: _site_forward(site_b, Xb, Xa, None, names_b, pb, add_to=base_b))
-                out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
-                out_b, _pb, idx_b, _lbb, st_b = fut.result()
-            else:
-                with torch.cuda.stream(side):
-                    out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb, add_to=base_b)
-                out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
+            with torch.cuda.stream(side):
+                out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb, add_to=base_b)
+            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
             main.wait_stream(side)
             for t_ in (out_b, idx_b, st_b[1]):
                 t_.record_stream(main)
@@ -281,44 +257,18 @@ class _PairFunction(torch.autograd.Function):
             # two buffers + a fused add and 6.04 / 6.06 for the variants that serialise one site's tail behind the other -- dropped.)
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
             side.wait_stream(main)
-            mk_b = lambda: _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa, acc_dx=False, acc_dy=True)
-            mk_a = lambda: _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb, acc_dx=False, acc_dy=True)
-            if ctx.threads:
-                # the same choreography with site B's calls enqueued by the helper host thread (its current stream: `side`)
-                def first_b():
-                    cb = mk_b().run(3)
-                    ev = torch.cuda.Event(); ev.record(side)
-                    cb.run(8)                            # the hop-1 chain up to (not including) the GEMM that writes dY
-                    return cb, ev
-                fut = _on_side(Xa.device, side, first_b)
-                cak = mk_a().run(3)
-                ev_a = torch.cuda.Event(); ev_a.record(main)
-                cak.run(8)
-                cbk, ev_b = fut.result()
-
-                def last_b():
-                    side.wait_event(ev_a)                # gXa holds site A's dX
-                    cbk.run(16)
-                fut = _on_side(Xa.device, side, last_b)
-                main.wait_event(ev_b)                    # gXb holds site B's dX
-                cak.run(16)
-                fut.result()
-                with torch.cuda.stream(side):            # (the sinks report from THIS thread, in a fixed order: collectives are launched
-                    pgb = cbk.finish()                   #  in the same order on every rank)
-                pga = cak.finish()
-            else:
-                with torch.cuda.stream(side):
-                    cbk = mk_b().run(3)
-                    ev_b = torch.cuda.Event(); ev_b.record(side)
-                    cbk.run(8)                           # the hop-1 chain up to (not including) the GEMM that writes dY
-                cak = mk_a().run(3)
-                ev_a = torch.cuda.Event(); ev_a.record(main)
-                cak.run(8)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev_a)                # gXa holds site A's dX
-                    pgb = cbk.run(16).finish()
-                main.wait_event(ev_b)                    # gXb holds site B's dX
-                pga = cak.run(16).finish()
+            with torch.cuda.stream(side):
+                cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa, acc_dx=False, acc_dy=True).run(3)
+                ev_b = torch.cuda.Event(); ev_b.record(side)
+                cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
+            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
+            ev_a = torch.cuda.Event(); ev_a.record(main)
+            cak.run(8)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_a)                    # gXa holds site A's dX
+                pgb = cbk.run(16).finish()
+            main.wait_event(ev_b)                        # gXb holds site B's dX
+            pga = cak.run(16).finish()
             main.wait_stream(side)
             for t_ in tuple(g_ for g_ in pgb if g_ is not None) + (cbk.d_out,):
                 t_.record_stream(main)
@@ -642,14 +592,12 @@ class AdapterPair(nn.Module):
     Numerically identical to calling the two sites one after the other; in the backward the gradient each token tensor
     receives from its second use is added inside the GEMM epilogues instead of by a separate accumulation kernel."""
 
-    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True, host_threads: bool = True):
+    def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True):
         """concurrent=True runs the two sites on two HIP streams (their kernels overlap; each token tensor collects its two gradients
         in ONE buffer: a site overwrites its own tokens' gradient with its dX and, behind an event, adds its dY to the other tensor in
-        the GEMM epilogue -- nobody waits before the last section); False runs them back to back on the caller's stream.
-        host_threads (two-stream mode): site B's C-ABI calls are issued from a helper host thread while the caller's thread issues
-        site A's (the calls release the GIL) -- halves the host's enqueue time, which is what bounds small batches."""
+        the GEMM epilogue -- nobody waits before the last section); False runs them back to back on the caller's stream."""
         super().__init__()
-        self.concurrent, self._side, self.host_threads = bool(concurrent), None, bool(host_threads)
+        self.concurrent, self._side = bool(concurrent), None
         for m in (site_a, site_b):
             if m.variant not in ("ave", "avqa"):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
@@ -668,7 +616,7 @@ class AdapterPair(nn.Module):
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
-        side = (self._side, self.host_threads) if self.concurrent else None
+        side = self._side if self.concurrent else None
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())
