@@ -461,8 +461,17 @@ __global__ void __launch_bounds__(256) kk_hop1_vec(const void* T0T_, const float
   for (int k0 = 0; k0 < Kcyb; k0 += 64) {            // 64 latent rows at a time
     const int kc = k0 + cl;
     float a0 = 0.f, a1 = 0.f;
-    if (kc < Kcyb)
-      for (int s = pt; s < S; s += 4) { a0 += part[(long)s * Kcyb + kc]; a1 += part[rows + (long)s * Kcyb + kc]; }
+    if (kc < Kcyb) {
+      float b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;      // eight loads in flight: the walk over the frames is latency-bound
+      const float* p0 = part + kc; const float* p1 = part + rows + kc;
+      int s = pt;
+      for (; s + 12 < S; s += 16) {
+        a0 += p0[(long)s * Kcyb]; a1 += p1[(long)s * Kcyb]; b0 += p0[(long)(s + 4) * Kcyb]; b1 += p1[(long)(s + 4) * Kcyb];
+        c0 += p0[(long)(s + 8) * Kcyb]; c1 += p1[(long)(s + 8) * Kcyb]; d0 += p0[(long)(s + 12) * Kcyb]; d1 += p1[(long)(s + 12) * Kcyb];
+      }
+      for (; s < S; s += 4) { a0 += p0[(long)s * Kcyb]; a1 += p1[(long)s * Kcyb]; }
+      a0 = (a0 + b0) + (c0 + d0); a1 = (a1 + b1) + (c1 + d1);
+    }
     red[0][pt][cl] = a0; red[1][pt][cl] = a1;
     __syncthreads();
     if (pt == 0 && kc < Kcyb) {
