@@ -71,13 +71,16 @@ constexpr int stage_kbytes(int BM, int BN, bool AMN, bool BMN) { return (BM <= 6
 
 // One K segment of the block's tile: 2-stage LDS pipeline over [kbeg, kend), accumulating into acc.
 // Ends on a barrier, so a following segment (or the epilogue) may reuse the LDS buffer.
-template <typename T, int BM, int BN, bool AMN, bool BMN, int TM, int TN>
+// (NTHR threads = NTHR / 64 waves arranged WGM x WGN over the block tile; the defaults are the 2 x 2 waves of gemm_kernel)
+template <typename T, int BM, int BN, bool AMN, bool BMN, int TM, int TN, int NTHR = 256, int WGN = 2>
 __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const char* Bb, long lda, long ldb, int M, int N, int m0,
                                              int n0, int kbeg, int kend, f32x4 (&acc)[TM][TN]) {
   constexpr int ESZ = sizeof(T);
   constexpr int KBY = stage_kbytes(BM, BN, AMN, BMN), BK = KBY / ESZ, CPK = KBY / 16;      // K bytes / elements / 16-byte chunks per row and stage
   constexpr int EPC = 16 / ESZ;      // elements per 16-byte chunk
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WGM = NTHR / 64 / WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  static_assert(WM == 16 * TM && WN == 16 * TN, "wave tile");
   constexpr int A_ROWB = AMN ? BM * ESZ + 16 : KBY + 16;
   constexpr int A_BYTES = (AMN ? BK : BM) * A_ROWB;
   constexpr int B_ROWB = BMN ? BN * ESZ + 16 : KBY + 16;
@@ -86,17 +89,17 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
   constexpr int A_CPR = BM * ESZ / 16, B_CPR = BN * ESZ / 16;   // chunks per LDS row (MN_MAJOR)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   struct { int M, N; long lda, ldb; } p{M, N, lda, ldb};
 
-  constexpr int NLA = (AMN ? BK * A_CPR : BM * CPK) / 256, NLB = (BMN ? BK * B_CPR : BN * CPK) / 256;
+  constexpr int NLA = (AMN ? BK * A_CPR : BM * CPK) / NTHR, NLB = (BMN ? BK * B_CPR : BN * CPK) / NTHR;
   u32x4 ra[NLA], rb[NLB];
   auto gload = [&](int kt) {
     const int k0 = kbeg + kt * BK;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + NTHR * i;
       u32x4 v = {0u, 0u, 0u, 0u};
       if constexpr (!AMN) {
         const int row = c / CPK, cc = c % CPK;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + NTHR * i;
       u32x4 v = {0u, 0u, 0u, 0u};
       if constexpr (!BMN) {
         const int row = c / CPK, cc = c % CPK;
@@ -139,13 +142,13 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
     char* sB = sA + A_BYTES;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + NTHR * i;
       if constexpr (!AMN) *(u32x4*)(sA + (c / CPK) * A_ROWB + (c % CPK) * 16) = ra[i];
       else *(u32x4*)(sA + (c / A_CPR) * A_ROWB + (c % A_CPR) * 16) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + NTHR * i;
       if constexpr (!BMN) *(u32x4*)(sB + (c / CPK) * B_ROWB + (c % CPK) * 16) = rb[i];
       else *(u32x4*)(sB + (c / B_CPR) * B_ROWB + (c % B_CPR) * 16) = rb[i];
     }
@@ -461,6 +464,125 @@ __global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
   }
 }
 
+// Large plain products (both extents in the thousands: the token remap's logits / weight gradients at the stage-0 sites of the real
+// backbones, N x M = 4096 x 2304 ..): 256 x 256 block tile, 8 waves (2 x 4, a wave owns 128 x 64 = 32 MFMA tiles: 12 LDS fragment
+// reads feed 32 MFMAs per K step, against 8 for 16 on the 128 x 128 tile, whose LDS traffic bounds it at ~0.55 PFLOP/s).  bf16
+// operands, fp32 accumulation, the same two-stage K pipeline (gemm_segment); plain epilogue only (alpha, accumulate, split-K slabs),
+// staged through LDS one half of the rows at a time.
+template <bool AMN, bool BMN>
+__global__ void __launch_bounds__(512) gemm_big_kernel(const DevArgs p) {
+  constexpr int BM = 256, BN = 256, NTHR = 512, WGN = 4, WM = 128, WN = 64, TM = 8, TN = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wrow = wave / WGN, wn0 = (wave % WGN) * WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {   // XCD-aware tile order (see gemm_kernel)
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7u, idx = lin >> 3, base = total >> 3, rem = total & 7u;
+    const unsigned logical = xcd * base + min(xcd, rem) + idx;
+    bx = (int)(logical % gridDim.x); by = (int)(logical / gridDim.x);
+  }
+  const int m0 = (bx / p.tiles_n) * BM, n0 = (bx % p.tiles_n) * BN;
+  const int split = by % p.ksplit, b = by / p.ksplit;
+  const int b13 = b / p.nb2, b2 = b % p.nb2;
+  const int b1 = b13 / p.nb3, b3 = b13 % p.nb3;
+  const char* Ab = p.A + ((long)b1 * p.sA1 + (long)b2 * p.sA2 + (long)b3 * p.sA3) * 2;
+  const char* Bb = p.B + ((long)b1 * p.sB1 + (long)b2 * p.sB2 + (long)b3 * p.sB3) * 2;
+  const int kbeg = split * p.kper, kend = min(p.K, kbeg + p.kper);
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_segment<__bf16, BM, BN, AMN, BMN, TM, TN, NTHR, WGN>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend, acc);
+
+  constexpr int CLD = BN + 4;
+  float* Cs = (float*)smem;
+  const int osz = p.out_bf16 ? 2 : 4;
+  char* Cb = p.C + ((long)b1 * p.sC1 + (long)b2 * p.sC2 + (long)b3 * p.sC3) * osz;
+  float* slab = p.ksplit > 1 ? p.slabs + ((long)split * p.nbatch + b) * (long)p.M * p.N : nullptr;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {                      // rows [128 h, 128 h + 128) of the tile: the waves of wave-row h hand over
+    if (wrow == h) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Cs[(16 * tm + 4 * q + e) * CLD + wn0 + 16 * tn + r] = acc[tm][tn][e];
+    }
+    __syncthreads();
+    if (p.sCj == 1 || slab) {
+      constexpr int TPR = BN / 4, RPP = NTHR / TPR;
+#pragma unroll 1
+      for (int pass = 0; pass < WM / RPP; ++pass) {
+        const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
+        const int gi = m0 + 128 * h + i, gj = n0 + j;
+        if (gi >= p.M || gj >= p.N) continue;
+        f32x4 v = *(const f32x4*)&Cs[i * CLD + j];
+        if (slab) {
+          float* d = slab + (long)gi * p.N + gj;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (gj + e < p.N) d[e] = v[e];
+          continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        char* cp = Cb + ((long)gi * p.sCi + gj) * osz;
+        if (gj + 3 < p.N && p.vec_c) {
+          if (p.out_bf16) {
+            if (p.accumulate) {
+              const u32x2 o = *(const u32x2*)cp;
+              v[0] += bf16_bits_to_f32(o[0] & 0xFFFFu); v[1] += bf16_bits_to_f32(o[0] >> 16);
+              v[2] += bf16_bits_to_f32(o[1] & 0xFFFFu); v[3] += bf16_bits_to_f32(o[1] >> 16);
+            }
+            u32x2 o;
+            o[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+            o[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+            *(u32x2*)cp = o;
+          } else {
+            if (p.accumulate) {
+              const f32x4 o = *(const f32x4*)cp;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += o[e];
+            }
+            *(f32x4*)cp = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (gj + e < p.N) {
+              float x = v[e];
+              char* ce = cp + e * osz;
+              if (p.accumulate) x += p.out_bf16 ? bf16_bits_to_f32(*(const unsigned short*)ce) : *(const float*)ce;
+              if (p.out_bf16) *(unsigned short*)ce = f32_to_bf16_bits(x); else *(float*)ce = x;
+            }
+          }
+        }
+      }
+    } else {   // sCi == 1 : C stored transposed (i contiguous)
+      constexpr int TPC = WM / 4, CPP = NTHR / TPC;
+#pragma unroll 1
+      for (int pass = 0; pass < BN / CPP; ++pass) {
+        const int j = pass * CPP + tid / TPC, i = (tid % TPC) * 4;
+        const int gi = m0 + 128 * h + i, gj = n0 + j;
+        if (gi >= p.M || gj >= p.N) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (gi + e < p.M) {
+            char* ce = Cb + ((long)gj * p.sCj + gi + e) * osz;
+            float x = p.alpha * Cs[(i + e) * CLD + j];
+            if (p.accumulate) x += p.out_bf16 ? bf16_bits_to_f32(*(const unsigned short*)ce) : *(const float*)ce;
+            if (p.out_bf16) *(unsigned short*)ce = f32_to_bf16_bits(x); else *(float*)ce = x;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // split-K second pass: C = alpha * sum_s slab[s] (+ row_scale * D) (+ C)
 // A wave covers 64 / P consecutive output vectors; the slabs of one vector are shared by P lanes (lane = part * (64 / P) + vector,
 // part p sums slabs p, p + P, ...) and the P partial sums are combined by a fixed xor-shuffle tree -- a deterministic order.
@@ -655,6 +777,38 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   return OK;
 }
 
+template <bool AMN, bool BMN>
+static int launch_big_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
+  constexpr int A_BYTES = AMN ? 64 * (256 * 2 + 16) : 256 * (128 + 16), B_BYTES = BMN ? 64 * (256 * 2 + 16) : 256 * (128 + 16);
+  constexpr int STAGES = 2 * (A_BYTES + B_BYTES), EPI = 128 * (256 + 4) * 4;
+  constexpr int LDS = STAGES > EPI ? STAGES : EPI;
+  static bool attr_done = false;
+  auto kern = gemm_big_kernel<AMN, BMN>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { set_last_error("gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return ERR_LAUNCH; }
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(cdiv(d.M, 256) * d.tiles_n), (unsigned)batch_z, 1);
+  static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
+  static char name[64];
+  if (!name[0]) snprintf(name, sizeof(name), "%s_bf16_256", names[AMN][BMN]);
+  static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
+  const char* pname = name;
+  if (shapes && prof_enabled()) {
+    char* nm = (char*)malloc(96);
+    snprintf(nm, 96, "%s M%d N%d K%d b%d ks%d", name, d.M, d.N, d.K, d.nbatch, d.ksplit);
+    pname = nm;
+  }
+  const double nb = (double)d.nbatch, osz = d.ksplit > 1 ? 4.0 : (d.out_bf16 ? 2.0 : 4.0);
+  const double abytes = ((d.sA1 == 0 && d.sA2 == 0 ? 1.0 : nb) * d.M * (double)d.K + (d.sB1 == 0 && d.sB2 == 0 ? 1.0 : nb) * d.N * (double)d.K) * 2.0 +
+                        nb * d.M * (double)d.N * osz * (d.accumulate ? 2.0 : 1.0);
+  ProfScope ps(pname, abytes, 2.0 * nb * d.M * (double)d.N * d.K, stream);
+  hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, d);
+  AVMOE_CHECK_LAUNCH("gemm_big_kernel");
+  return OK;
+}
+
 template <typename T, int BM, int BN>
 static int launch_layout(const GemmArgs& a, const DevArgs& d, int bz, hipStream_t s) {
   const bool amn = a.a_layout == MN_MAJOR, bmn = a.b_layout == MN_MAJOR;
@@ -762,7 +916,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   const int bz = d.nbatch * d.ksplit;
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
   int st;
-  if (tile == 128) {
+  // the 256 x 256 tile for large plain bf16 products (enough tiles of it to fill the chip)
+  const bool big = a.dtype == GEMM_BF16 && a.tile == 0 && tile == 128 && !d.fold_rps && a.epi == GEMM_EPI_NONE && !a.A2 && !a.D && d.M >= 1024 && a.N >= 1024 &&
+                   a.K >= 256 && (long)cdiv(d.M, 256) * cdiv(a.N, 256) * bz >= 160;
+  if (big) {
+    d.tiles_n = cdiv(a.N, 256);
+    const bool amn = a.a_layout == MN_MAJOR, bmn = a.b_layout == MN_MAJOR;
+    st = amn ? (bmn ? launch_big_inst<true, true>(d, bz, stream) : launch_big_inst<true, false>(d, bz, stream))
+             : (bmn ? launch_big_inst<false, true>(d, bz, stream) : launch_big_inst<false, false>(d, bz, stream));
+  } else if (tile == 128) {
     d.tiles_n = cdiv(a.N, 128);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 128, 128>(a, d, bz, stream)
                               : launch_layout<float, 128, 128>(a, d, bz, stream);

@@ -290,3 +290,50 @@ def test_streaming_kernel_narrow_channel_groups(case):
     got, ref = _run_gemm(case.pop("M"), case.pop("N"), case.pop("K"), 1, False, case.pop("b_mn"), seed=17, **case)
     err = (got - ref).abs().max() / ref.abs().max()
     assert err < (2e-2 if out_bf16 else 1e-4), float(err)
+
+
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+def test_big_tile_exact_integers(a_mn, b_mn):
+    """The 256 x 256 tile (large plain bf16 products; tile = 0 picks it): small-integer operands make every product and partial sum
+    exact, so a fragment-layout slip in the 2 x 4 wave grid or the two-half epilogue is a hard mismatch.  Ragged M / N / K."""
+    got, ref = _run_gemm(2100, 2700, 300, 1, a_mn, b_mn, exact_ints=True, seed=5)
+    assert torch.equal(got, ref), f"max err {(got - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+@pytest.mark.parametrize("kw", [dict(), dict(out_bf16=True), dict(accumulate=True), dict(c_transposed=True), dict(accumulate=True, out_bf16=True),
+                                dict(ksplit=3), dict(nb1=2, nb2=2), dict(c_transposed=True, accumulate=True)])
+def test_big_tile_variants(a_mn, b_mn, kw):
+    M, N, K = (1100, 1300, 520) if kw.get("nb1") else (2300, 2052, 1030)
+    got, ref = _run_gemm(M, N, K, 1, a_mn, b_mn, seed=11, **kw)
+    err = (got - ref).abs().max() / (ref.abs().max() + 1e-9)
+    assert err < (1e-2 if kw.get("out_bf16") else 1e-4), float(err)
+
+
+def test_big_tile_throughput():
+    """(informational) the large-product tile against the 128 x 128 one on a stage-0 remap shape: 4096 x 3136 x 15400"""
+    import time
+    from avmoe_amd import _capi as capi
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    M, N, K = 4096, 3136, 15400
+    A = torch.randn(M, K, device=dev).bfloat16()
+    B = torch.randn(N, K, device=dev).bfloat16()
+    Cd = torch.empty(M, N, device=dev)
+    for tile in (128, 0):
+        d = capi.GemmDesc()
+        d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, 1, 1
+        d.dtype, d.out_dtype, d.a_layout, d.b_layout = capi.BF16, capi.F32, 0, 0
+        d.accumulate, d.ksplit, d.tile, d.alpha = 0, 1, tile, 1.0
+        d.lda, d.ldb, d.sCi, d.sCj = K, K, N, 1
+        run = lambda: capi.check(L.avmoe_gemm(C.byref(d), A.data_ptr(), B.data_ptr(), Cd.data_ptr(), None, None, None,
+                                              torch.cuda.current_stream().cuda_stream), "gemm")
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        print(f"\n[gemm {M}x{N}x{K} bf16] tile {'256 (auto)' if tile == 0 else tile}: {dt * 1e3:.3f} ms  {2.0 * M * N * K / dt / 1e12:.0f} TFLOP/s")
