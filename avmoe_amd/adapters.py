@@ -212,12 +212,21 @@ class _PairFunction(torch.autograd.Function):
         pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
         main = torch.cuda.current_stream(Xa.device)
+        side, ctx.events = (side[0], side[1:]) if isinstance(side, tuple) else (side, None)
+        # fork / join through the pair's OWN events, made once and re-recorded every step (Stream.wait_stream makes and destroys an
+        # event per call, and destroying an event that is still pending blocks the host until the GPU reaches it: the host then never
+        # runs ahead of the GPU across a step boundary -- measured: 167 us of GPU idle time per cfg-2 step)
+        def fork(ev):
+            ev.record(main); side.wait_event(ev)
+        def join(ev):
+            ev.record(side); main.wait_event(ev)
         if side is not None:                           # site B on the side stream, concurrently with site A
-            side.wait_stream(main)
+            ctx_ev = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
+            fork(ctx_ev[2])
             with torch.cuda.stream(side):
                 out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb, add_to=base_b)
             out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
-            main.wait_stream(side)
+            join(ctx_ev[3])
             for t_ in (out_b, idx_b, st_b[1]):
                 t_.record_stream(main)
         else:
@@ -256,20 +265,21 @@ class _PairFunction(torch.autograd.Function):
             # the two dY GEMMs are ordered behind the events.  (Measured on MI355X at cfg-2, round 2: 5.79 ms per step against 5.97 for
             # two buffers + a fused add and 6.04 / 6.06 for the variants that serialise one site's tail behind the other -- dropped.)
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
-            side.wait_stream(main)
+            ev_a, ev_b, ev_fork, ev_join = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
+            ev_fork.record(main); side.wait_event(ev_fork)
             with torch.cuda.stream(side):
                 cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa, acc_dx=False, acc_dy=True).run(3)
-                ev_b = torch.cuda.Event(); ev_b.record(side)
+                ev_b.record(side)
                 cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
             cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
-            ev_a = torch.cuda.Event(); ev_a.record(main)
+            ev_a.record(main)
             cak.run(8)
             with torch.cuda.stream(side):
                 side.wait_event(ev_a)                    # gXa holds site A's dX
                 pgb = cbk.run(16).finish()
             main.wait_event(ev_b)                        # gXb holds site B's dX
             pga = cak.run(16).finish()
-            main.wait_stream(side)
+            ev_join.record(side); main.wait_event(ev_join)
             for t_ in tuple(g_ for g_ in pgb if g_ is not None) + (cbk.d_out,):
                 t_.record_stream(main)
             gXa.record_stream(side); gXb.record_stream(side)
@@ -597,7 +607,7 @@ class AdapterPair(nn.Module):
         in ONE buffer: a site overwrites its own tokens' gradient with its dX and, behind an event, adds its dY to the other tensor in
         the GEMM epilogue -- nobody waits before the last section); False runs them back to back on the caller's stream."""
         super().__init__()
-        self.concurrent, self._side = bool(concurrent), None
+        self.concurrent, self._side, self._events = bool(concurrent), None, None
         for m in (site_a, site_b):
             if m.variant not in ("ave", "avqa"):
                 raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
@@ -613,10 +623,11 @@ class AdapterPair(nn.Module):
         Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
         if self.concurrent and self._side is None:
             self._side = side_stream(x_a.device)
+            self._events = tuple(torch.cuda.Event() for _ in range(4))      # backward hand-over (2), fork, join
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
-        side = self._side if self.concurrent else None
+        side = (self._side,) + self._events if self.concurrent else None
         out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
                                                          add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
                                                          *Pa.values(), *Pb.values())

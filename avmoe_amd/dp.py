@@ -84,6 +84,7 @@ class _SiteSink:
         self.flat = None                                 # the slice (set once the bucket's memory exists)
         self.calls = 0                                   # forward calls of the site still waiting for their backward
         self.event = None                                # recorded on the stream the site's last backward ran on
+        self._ev = None
 
     def bind(self):
         self.flat = self.bucket.flat[self.base:self.base + self.total]
@@ -96,8 +97,10 @@ class _SiteSink:
         self.calls -= 1
         if self.calls <= 0:
             if self.flat.is_cuda:                        # the bucket's collective must wait for THIS stream's writes, whichever
-                self.event = torch.cuda.Event()          # stream context launches it (the two sites of an AdapterPair finish on
-                self.event.record(torch.cuda.current_stream(self.flat.device))      # two different streams)
+                if self._ev is None:                     # stream context launches it (the two sites of an AdapterPair finish on
+                    self._ev = torch.cuda.Event()        # two different streams).  One event per sink, re-recorded every step.
+                self.event = self._ev
+                self.event.record(torch.cuda.current_stream(self.flat.device))
             self.reducer._reported(self.bucket)
 
 
