@@ -125,10 +125,21 @@ class AdapterGradReducer:
         division per bucket; "optimizer" -- plain sum, `grad_scale` = 1 / world is left to the optimizer (FlatAdam picks it up)."""
         if average not in ("auto", "optimizer"):
             raise ValueError("average must be 'auto' or 'optimizer'")
+        params = list(params)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
-        self._avg_op = average == "auto" and backend == "nccl"            # RCCL: ncclAvg, no extra kernel
+        self._avg_op = average == "auto" and backend == "nccl" and self.world > 1      # RCCL: ncclAvg, no extra kernel
+        if self._avg_op:
+            # probe once (every rank takes the same branch: the probe is itself a collective): a communicator that refuses AVG
+            # falls back to sum + one division per bucket instead of failing in the first training step
+            try:
+                dev = next((p.device for p in params if p.is_cuda), None)
+                probe = torch.ones(1, device=dev if dev is not None else "cuda")
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                self._avg_op = bool(abs(float(probe.item()) - 1.0) < 1e-6)
+            except Exception:
+                self._avg_op = False
         self._divide = average == "auto" and not self._avg_op and self.world > 1
         self.grad_scale = 1.0 / self.world if average == "optimizer" else 1.0
         self.buckets: List[_Bucket] = []
