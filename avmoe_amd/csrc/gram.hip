@@ -187,7 +187,7 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
              float* colpart, float* mz) {
   const Dims& d = pl.d;
   ProfScope ps_("k_gram64", (long)d.NT, (double)d.NT * (d.DZ * 2.0 + (w ? 4.0 * d.E : 0.0)), 2.0 * d.NT * (double)d.g * d.E * d.dgp * d.dgp, st);
-  if (!tile_fast_ok(d) || !d.bf16 || (d.E != 4 && d.E != 2)) { set_last_error("gram64: shape not covered"); return ERR_UNSUPPORTED; }
+  if (!tile_fast_shape(d) || !d.bf16 || (d.E != 4 && d.E != 2)) { set_last_error("gram64: shape not covered"); return ERR_UNSUPPORTED; }
   const long ntiles = cdiv((long)d.NT, GT);
   const int nblk = (int)std::min<long>(GRAM_BLOCKS, ntiles);
   const int tpb = (int)cdiv(ntiles, (long)nblk);

@@ -8,6 +8,7 @@
 namespace avmoe {
 
 bool tile_fast_ok(const Dims& d);   // tile_fast.hip
+bool tile_fast_shape(const Dims& d);
 bool tile_gen_ok(const Dims& d);    // tile_gen.hip
 
 size_t slab_floats(const Dims& d) {
@@ -119,7 +120,8 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
     // Generalised register-resident kernels (tile_gen.hip) for every other shape they are built for: bottleneck entries per group
     // padded to a multiple of 16, latent-token slots to 16 / 32 / 96 (zero weights / masked slots, as for every padded width).
     d.gen = 0;
-    if (!no_gen && !(d.g == 2 && d.dgp == 32 && d.K == 32 && d.E >= 2 && d.E <= 4)) {
+    static const bool no_fast = dev_env("AVMOE_NO_FAST") != nullptr;      // development: the generalised kernels at the tuned shape too (A/B)
+    if (!no_gen && (no_fast || !(d.g == 2 && d.dgp == 32 && d.K == 32 && d.E >= 2 && d.E <= 4))) {
       Dims t = d;
       t.dgp = (int)round_up(d.dg, 16);
       if (d.El > 0) t.Kp = d.K <= 16 ? 16 : (d.K <= 32 ? 32 : (d.K <= 96 ? 96 : (int)round_up(d.K, 16)));
@@ -164,7 +166,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   }
   d.nblk_tok = bps * d.S;
   d.zsz = (tile_fast_ok(d) || d.gen) ? d.esz : 4;     // Z / dz' in the activation type on the register-resident paths
-  d.gram64 = tile_fast_ok(d) && d.bf16 && (d.E == 4 || d.E == 2) && !dev_env("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
+  d.gram64 = tile_fast_shape(d) && d.bf16 && (d.E == 4 || d.E == 2) && !dev_env("AVMOE_NO_GRAM64");      // gram.hip is built for 2 and 4 experts
   d.xchunks = std::max(1, std::min(cdiv(d.N, 32), cdiv(4096, d.S)));
   d.fuse_xs = d.bf16 && d.zsz == 2 && gemm_stream_stats_ok(d.N, d.S, d.E * d.dgp, d.Cg, d.C, d.DZ) && !dev_env("AVMOE_NO_FUSE_XSTATS");
 

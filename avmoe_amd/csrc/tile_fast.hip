@@ -1066,9 +1066,10 @@ void fast_grid(const Dims& d, dim3* grid, int* per) {
 }  // namespace
 
 // The register-resident kernels cover exactly: bottleneck 64 in 2 groups, 32 latent tokens, 2 - 4 experts (any variant).
-bool tile_fast_ok(const Dims& d) {
+bool tile_fast_shape(const Dims& d) {
   return d.DD == FDD && d.dgp == FDG && d.g == 2 && d.K == FK && d.Kp == FK && d.E >= 2 && d.E <= 4;
 }
+bool tile_fast_ok(const Dims& d) { return tile_fast_shape(d) && !d.gen; }      // (d.gen at this shape: the development A/B against tile_gen.inc)
 
 #define LAUNCH_TE1(bf16, KERN, NE, ...)                                                                \
   do {                                                                                                 \
