@@ -25,8 +25,8 @@ The JSON line also carries
                 bf16 the same against the oracle on bf16-rounded inputs.  Gradients are compared KINK-AWARE: the oracle is
                 re-run with the ReLU mask the HIP path actually used (avmoe_amd.debug.relu_masks), so units whose
                 pre-activation lies within rounding of zero sit on the same side in both; the plain comparison is reported too
-  other_configs (N = 1) 3 timed steps each of cfg-4 and cfg-5 after the cfg-2 region, with their own ms_per_step, path-level
-                roofline fraction and kink-aware parity
+  other_configs (N = 1) 3 timed steps each of cfg-1 (the reference's own operating point: B = 2, fp32, 24 site pairs), cfg-4 and cfg-5
+                after the cfg-2 region, with their own ms_per_step, path-level roofline fraction and kink-aware parity
   value_f32     the same step in fp32 (the configuration held to the 1e-3 bar)
   cpu_baseline  oracle/avmoe_oracle.py (eager PyTorch, fp32) timed on this box's host cores on a bounded
                 sample of the same workload (same shapes, B=2 clips), rank 0 at N=1 only
@@ -499,7 +499,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skips the fp32 re-run (value_f32)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skips the cfg-4 / cfg-5 legs of the default (cfg-2, N = 1) run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skips the cfg-1 / cfg-4 / cfg-5 legs of the default (cfg-2, N = 1) run")
     ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off"],
                     help="how the two sites of a layer are run: AdapterPair on two streams / on one stream / two separate calls")
     args = ap.parse_args()
@@ -620,7 +620,7 @@ def main():
         del material
         if args.config == "cfg2" and not args.batch and not args.dtype and not args.no_other_configs:
             others = {}
-            for name in ("cfg4", "cfg5"):
+            for name in ("cfg1", "cfg4", "cfg5"):
                 try:
                     others[name] = other_config_line(name, device, args.pair)
                 except Exception as e:      # the headline line must not be lost to a side leg
