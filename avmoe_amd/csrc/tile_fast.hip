@@ -692,7 +692,11 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
+#ifdef KF_PREB_NO_LAT          // development (timing only): without the hop-2 block of the latent experts
+    const int l = -1;
+#else
     const int l = a.lat_of_e[e];
+#endif
     const bool nxn = XR && a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
