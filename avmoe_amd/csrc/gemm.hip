@@ -520,6 +520,12 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(const DevArgs p) {
         const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
         const int gi = m0 + 128 * h + i, gj = n0 + j;
         if (gi >= p.M || gj >= p.N) continue;
+        long crow = (long)gi * p.sCi;
+        if (p.fold_rps) {                                 // row gi of the folded GEMM = row ri of sample sidx; gap rows are not stored
+          const int sidx = gi / p.fold_rps, ri = gi - sidx * p.fold_rps;
+          if (ri >= p.fold_valid) continue;
+          crow = (long)sidx * p.sC1 + (long)ri * p.sCi;
+        }
         f32x4 v = *(const f32x4*)&Cs[i * CLD + j];
         if (slab) {
           float* d = slab + (long)gi * p.N + gj;
@@ -529,7 +535,7 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(const DevArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-        char* cp = Cb + ((long)gi * p.sCi + gj) * osz;
+        char* cp = Cb + (crow + gj) * osz;
         if (gj + 3 < p.N && p.vec_c) {
           if (p.out_bf16) {
             if (p.accumulate) {
@@ -572,6 +578,11 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(const DevArgs p) {
         for (int e = 0; e < 4; ++e) {
           if (gi + e < p.M) {
             char* ce = Cb + ((long)gj * p.sCj + gi + e) * osz;
+            if (p.fold_rps) {
+              const int sidx = (gi + e) / p.fold_rps, ri = (gi + e) - sidx * p.fold_rps;
+              if (ri >= p.fold_valid) continue;
+              ce = Cb + ((long)sidx * p.sC1 + (long)gj * p.sCj + ri) * osz;
+            }
             float x = p.alpha * Cs[(i + e) * CLD + j];
             if (p.accumulate) x += p.out_bf16 ? bf16_bits_to_f32(*(const unsigned short*)ce) : *(const float*)ce;
             if (p.out_bf16) *(unsigned short*)ce = f32_to_bf16_bits(x); else *(float*)ce = x;
@@ -896,7 +907,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       const long rps = a.sA1 / a.lda, rows = (long)(a.nb1 - 1) * rps + a.M;
       const int t0 = a.tile ? a.tile : ((a.M > 64 && a.N > 64) ? 128 : 64);      // tile of the unfolded launch
       const bool wasteful = round_up(a.M, t0) * 4 >= (long)a.M * 5;             // >= 25 % of its tile rows are padding (measured:
-      if (wasteful && rps >= a.M && (rps - a.M) * 8 <= a.M && rows < (1L << 30)) {   // folding full tiles gains nothing)
+                                                                                  // folding full tiles of the same size gains nothing)
+      // ... or the samples' blocks are too short for the 256 x 256 tile while the tall product is not (cfg-5: 384 latent rows per frame
+      // against the 4096 x 3138 remap matrix, 40 frames)
+      const bool for_big = a.dtype == GEMM_BF16 && a.tile == 0 && a.M < 1024 && rows >= 2048 && a.N >= 1024 && a.K >= 256;
+      if ((wasteful || for_big) && rps >= a.M && (rps - a.M) * 8 <= a.M && rows < (1L << 30)) {
         d.fold_rps = (int)rps; d.fold_valid = a.M; d.M = (int)rows; d.nbatch = 1; d.sA1 = 0;
       }
     }
@@ -917,7 +932,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
   int st;
   // the 256 x 256 tile for large plain bf16 products (enough tiles of it to fill the chip)
-  const bool big = a.dtype == GEMM_BF16 && a.tile == 0 && tile == 128 && !d.fold_rps && a.epi == GEMM_EPI_NONE && !a.A2 && !a.D && d.M >= 1024 && a.N >= 1024 &&
+  const bool big = a.dtype == GEMM_BF16 && a.tile == 0 && tile == 128 && a.epi == GEMM_EPI_NONE && !a.A2 && !a.D && d.M >= 1024 && a.N >= 1024 &&
                    a.K >= 256 && (long)cdiv(d.M, 256) * cdiv(a.N, 256) * bz >= 160;
   if (big) {
     d.tiles_n = cdiv(a.N, 256);

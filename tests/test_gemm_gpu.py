@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=False, out_bf16=False,
-              accumulate=False, epilogue=False, ksplit=1, bcast_a=False, seed=0, exact_ints=False):
+              accumulate=False, epilogue=False, ksplit=1, bcast_a=False, seed=0, exact_ints=False, bcast_b=False):
     from avmoe_amd import _capi as capi
     L = capi.lib()
     dev = torch.device("cuda:0")
@@ -27,7 +27,7 @@ def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=Fal
 
     Kp, Mp, Np = -(-K // epc) * epc, -(-M // epc) * epc, -(-N // epc) * epc
     A = rnd(1 if bcast_a else nb, M, K)
-    Bm = rnd(nb, N, K)
+    Bm = rnd(1 if bcast_b else nb, N, K)
     # device storage with padded leading dims; padding holds finite garbage (7.0) except A's K padding
     if a_mn:
         Ad = torch.full((A.shape[0], K, Mp), 7.0, dtype=tdt)
@@ -38,17 +38,17 @@ def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=Fal
         Ad[:, :, :K] = A.to(tdt)
         lda, sA = Kp, M * Kp
     if b_mn:
-        Bd = torch.full((nb, K, Np), 7.0, dtype=tdt)
+        Bd = torch.full((Bm.shape[0], K, Np), 7.0, dtype=tdt)
         Bd[:, :, :N] = Bm.transpose(1, 2).to(tdt)
         ldb, sB = Np, K * Np
     else:
-        Bd = torch.full((nb, N, Kp), 7.0, dtype=tdt)      # garbage in the K padding: the engine masks it
+        Bd = torch.full((Bm.shape[0], N, Kp), 7.0, dtype=tdt)      # garbage in the K padding: the engine masks it
         Bd[:, :, :K] = Bm.to(tdt)
         ldb, sB = Kp, N * Kp
     Ad, Bd = Ad.to(dev), Bd.to(dev)
     Ar = (Ad[:, :, :M].transpose(1, 2) if a_mn else Ad[:, :, :K]).double().cpu()
     Br = (Bd[:, :, :N].transpose(1, 2) if b_mn else Bd[:, :, :K]).double().cpu()
-    ref = 0.5 * torch.matmul(Ar.expand(nb, M, K), Br.transpose(1, 2))
+    ref = 0.5 * torch.matmul(Ar.expand(nb, M, K), Br.expand(nb, N, K).transpose(1, 2))
 
     odt = torch.bfloat16 if out_bf16 else torch.float32
     Cd = torch.zeros((nb, N, M) if c_transposed else (nb, M, N), dtype=odt)
@@ -71,7 +71,7 @@ def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=Fal
     d.accumulate, d.ksplit, d.tile, d.alpha = int(accumulate), ksplit, tile, 0.5
     d.lda, d.ldb = lda, ldb
     d.sA1, d.sA2 = (0, 0) if bcast_a else (sA * nb2, sA)
-    d.sB1, d.sB2 = sB * nb2, sB
+    d.sB1, d.sB2 = (0, 0) if bcast_b else (sB * nb2, sB)
     if c_transposed:
         d.sCi, d.sCj = 1, M
     else:
@@ -337,3 +337,14 @@ def test_big_tile_throughput():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         print(f"\n[gemm {M}x{N}x{K} bf16] tile {'256 (auto)' if tile == 0 else tile}: {dt * 1e3:.3f} ms  {2.0 * M * N * K / dt / 1e12:.0f} TFLOP/s")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(out_bf16=True), dict(c_transposed=True)])
+def test_batch_fold_onto_the_big_tile(kw):
+    """Per-sample row blocks too short for the 256 x 256 tile (384 latent rows per frame) against ONE shared B fold into a tall
+    product that takes it (cfg-5: the remap logits of a stage-0 site)."""
+    got, ref = _run_gemm(384, 1100, 520, 1, False, False, nb1=6, bcast_b=True, seed=3, **kw)
+    err = (got - ref).abs().max() / (ref.abs().max() + 1e-9)
+    assert err < (1e-2 if kw.get("out_bf16") else 1e-4), float(err)
+    got, ref = _run_gemm(384, 1100, 520, 1, False, False, nb1=6, bcast_b=True, exact_ints=True, seed=4)
+    assert torch.equal(got, ref)
