@@ -205,9 +205,10 @@ class _PairFunction(torch.autograd.Function):
     accumulation pass over the token gradients runs."""
 
     @staticmethod
-    def forward(ctx, site_a, site_b, side, Xa, Xb, base_a, base_b, names_a, names_b, *params):
+    def forward(ctx, site_a, site_b, side, Xa, Xb, base_a, base_b, names_a, names_b, noises, *params):
         """side: the second HIP stream (two-stream mode) or None (both sites on the caller's stream).
-        base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs)."""
+        base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs).
+        noises: (noise_a, noise_b) -- the AVS logit noise of the two sites, (S, E) already scaled, or None each."""
         na = len(names_a)
         pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
@@ -224,14 +225,14 @@ class _PairFunction(torch.autograd.Function):
             ctx_ev = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
             fork(ctx_ev[2])
             with torch.cuda.stream(side):
-                out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, Xb, Xa, None, names_b, pb, add_to=base_b)
-            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
+                out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, Xb, Xa, noises[1], names_b, pb, add_to=base_b)
+            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a)
             join(ctx_ev[3])
-            for t_ in (out_b, idx_b, st_b[1]):
+            for t_ in (out_b, idx_b, pr_b, lb_b, st_b[1]):
                 t_.record_stream(main)
         else:
-            out_a, _pa, idx_a, _lba, st_a = _site_forward(site_a, Xa, Xb, None, names_a, pa, add_to=base_a)
-            out_b, _pb, idx_b, _lbb, st_b = _site_forward(site_b, st_a[3], st_a[2], None, names_b, pb, add_to=base_b)
+            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a)
+            out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, st_a[3], st_a[2], noises[1], names_b, pb, add_to=base_b)
         dirty = [t for t in (base_a, base_b) if t is not None]
         if dirty:
             ctx.mark_dirty(*dirty)
@@ -239,23 +240,23 @@ class _PairFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)                 # no zero tensors (= fill kernels) for the gradients of the index outputs
         ctx.side = side
         ctx.sites, ctx.names, ctx.states = (site_a, site_b), (names_a, names_b), (st_a[:2], st_b[:2])
-        for site, needs in ((site_a, ctx.needs_input_grad[9:9 + na]), (site_b, ctx.needs_input_grad[9 + na:])):
+        for site, needs in ((site_a, ctx.needs_input_grad[10:10 + na]), (site_b, ctx.needs_input_grad[10 + na:])):
             sink = getattr(site, "_grad_sink", None)
             if sink is not None and any(needs):
                 sink.calls += 1
         ctx.save_for_backward(st_a[2], st_a[3], *params)
-        ctx.mark_non_differentiable(idx_a, idx_b)
-        return out_a, out_b, idx_a, idx_b
+        ctx.mark_non_differentiable(idx_a, idx_b, pr_a, pr_b)
+        return out_a, out_b, idx_a, idx_b, pr_a, pr_b, lb_a, lb_b
 
     @staticmethod
-    def backward(ctx, d_a, d_b, _ia, _ib):
+    def backward(ctx, d_a, d_b, _ia, _ib, _pa, _pb, d_lba, d_lbb):
         Xa, Xb, *params = ctx.saved_tensors
         d_a = torch.zeros_like(Xa) if d_a is None else d_a
         d_b = torch.zeros_like(Xb) if d_b is None else d_b
         (site_a, site_b), (names_a, names_b) = ctx.sites, ctx.names
         na = len(names_a)
         gXa, gXb = torch.empty_like(Xa), torch.empty_like(Xb)
-        needs_a, needs_b = ctx.needs_input_grad[9:9 + na], ctx.needs_input_grad[9 + na:]
+        needs_a, needs_b = ctx.needs_input_grad[10:10 + na], ctx.needs_input_grad[10 + na:]
         gba = d_a if ctx.has_base[0] else None            # out = base + adapter(...): the residual stream passes the gradient on
         gbb = d_b if ctx.has_base[1] else None
         if ctx.side is not None:
@@ -268,10 +269,10 @@ class _PairFunction(torch.autograd.Function):
             ev_a, ev_b, ev_fork, ev_join = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
             ev_fork.record(main); side.wait_event(ev_fork)
             with torch.cuda.stream(side):
-                cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, None, gXb, gXa, acc_dx=False, acc_dy=True).run(3)
+                cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, d_lbb, gXb, gXa, acc_dx=False, acc_dy=True).run(3)
                 ev_b.record(side)
                 cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
-            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, None, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
+            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, d_lba, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
             ev_a.record(main)
             cak.run(8)
             with torch.cuda.stream(side):
@@ -283,22 +284,22 @@ class _PairFunction(torch.autograd.Function):
             for t_ in tuple(g_ for g_ in pgb if g_ is not None) + (cbk.d_out,):
                 t_.record_stream(main)
             gXa.record_stream(side); gXb.record_stream(side)
-            return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
+            return (None, None, None, gXa, gXb, gba, gbb, None, None, None) + pga + pgb
         # One stream: both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The
         # larger tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
         # larger tensor runs second
         first_b = Xa.numel() >= Xb.numel()
         def run_a(acc):
             return _site_backward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a,
-                                  None, gXa, gXb, acc_dx=acc, acc_dy=acc)              # dX -> gXa, dY -> gXb
+                                  d_lba, gXa, gXb, acc_dx=acc, acc_dy=acc)             # dX -> gXa, dY -> gXb
         def run_b(acc):
             return _site_backward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b,
-                                  None, gXb, gXa, acc_dx=acc, acc_dy=acc)              # dX -> gXb, dY -> gXa
+                                  d_lbb, gXb, gXa, acc_dx=acc, acc_dy=acc)             # dX -> gXb, dY -> gXa
         if first_b:
             pgb = run_b(False); pga = run_a(True)
         else:
             pga = run_a(False); pgb = run_b(True)
-        return (None, None, None, gXa, gXb, gba, gbb, None, None) + pga + pgb
+        return (None, None, None, gXa, gXb, gba, gbb, None, None, None) + pga + pgb
 
 
 class ExpertAdapter(nn.Module):
@@ -594,10 +595,12 @@ def _safe_inplace(base: torch.Tensor, others) -> bool:
 
 
 class AdapterPair(nn.Module):
-    """The two AVE / AVQA adapter sites of one backbone layer run as one autograd node:
+    """The two adapter sites of one backbone layer run as one autograd node:
 
-        pair = AdapterPair(audio_site, visual_site)            # two MoEAdapter / MoEAdapterAVQA modules (shared, not copied)
-        out_a, idx_a, out_v, idx_v = pair(f_a, f_v)            # == audio_site(f_a, f_v), visual_site(f_v, f_a)
+        pair = AdapterPair(audio_site, visual_site)            # two MoEAdapter* modules of one variant (shared, not copied)
+        out_a, idx_a, out_v, idx_v = pair(f_a, f_v)            # AVE / AVQA: == audio_site(f_a, f_v) + visual_site(f_v, f_a)
+        out_a, lb_a, out_v, lb_v = pair(f_a, f_v)              # AVVP  (mgn.py:212-217)
+        out_a, idx_a, probs_a, lb_a, out_v, idx_v, probs_v, lb_v = pair(f_a, f_v, is_training=True)      # AVS (PVT_AVSModel_v2.py:294-312)
 
     Numerically identical to calling the two sites one after the other; in the backward the gradient each token tensor
     receives from its second use is added inside the GEMM epilogues instead of by a separate accumulation kernel."""
@@ -605,19 +608,23 @@ class AdapterPair(nn.Module):
     def __init__(self, site_a: MoEAdapter, site_b: MoEAdapter, concurrent: bool = True):
         """concurrent=True runs the two sites on two HIP streams (their kernels overlap; each token tensor collects its two gradients
         in ONE buffer: a site overwrites its own tokens' gradient with its dX and, behind an event, adds its dY to the other tensor in
-        the GEMM epilogue -- nobody waits before the last section); False runs them back to back on the caller's stream."""
+        the GEMM epilogue -- nobody waits before the last section); False runs them back to back on the caller's stream.  Sites with
+        latent self attention on their own tokens (AVS "v2") write dX in their last section too, so their backward cannot be split:
+        such a pair always runs back to back."""
         super().__init__()
-        self.concurrent, self._side, self._events = bool(concurrent), None, None
-        for m in (site_a, site_b):
-            if m.variant not in ("ave", "avqa"):
-                raise ValueError("AdapterPair covers the AVE / AVQA signatures (no gating noise, no load-balancing loss)")
+        if site_a.variant != site_b.variant:
+            raise ValueError(f"AdapterPair: the two sites have different signatures ({site_a.variant} / {site_b.variant})")
+        splittable = all(m._self_attn() != "v2" for m in (site_a, site_b))
+        self.concurrent, self._side, self._events = bool(concurrent) and splittable, None, None
+        self.variant = site_a.variant
         self.site_a, self.site_b = site_a, site_b
 
-    def forward(self, x_a, x_b, add_to=(None, None)):
+    def forward(self, x_a, x_b, add_to=(None, None), is_training=True):
         """add_to = (base_a, base_b): token-major (S, N, C) residual streams (or None) that receive `+= adapter output` IN PLACE
         inside the output GEMM and are returned (in the (S, C, N, 1) view) instead of the bare adapter outputs -- the
         `f = f + f_res` of net_trans_v3.py:709,712 without a separate pass.  Only hand in tensors nobody else needs at their
-        old value (e.g. the fresh result of `x + attention(x)`)."""
+        old value (e.g. the fresh result of `x + attention(x)`).
+        is_training: the AVS sites' flag (logit noise, drawn for site A first -- the order of two separate calls)."""
         Xa = x_a.squeeze(-1).permute(0, 2, 1)
         Xb = x_b.squeeze(-1).permute(0, 2, 1)
         Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
@@ -627,9 +634,19 @@ class AdapterPair(nn.Module):
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")
+        noises = (None, None)
+        if self.variant == "avs" and is_training:                             # PVT_AVSModel_v2.py:294-296
+            noises = tuple(torch.randn(x.shape[0], m.num_multimodal_experts + m.num_singlemodal_experts, device=x.device,
+                                       dtype=torch.float32) * 0.01 for m, x in ((self.site_a, x_a), (self.site_b, x_b)))
         side = (self._side,) + self._events if self.concurrent else None
-        out_a, out_b, idx_a, idx_b = _PairFunction.apply(self.site_a, self.site_b, side, Xa, Xb,
-                                                         add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()),
-                                                         *Pa.values(), *Pb.values())
-        return (out_a.permute(0, 2, 1).unsqueeze(-1), idx_a.unsqueeze(-1),
-                out_b.permute(0, 2, 1).unsqueeze(-1), idx_b.unsqueeze(-1))
+        out_a, out_b, idx_a, idx_b, pr_a, pr_b, lb_a, lb_b = _PairFunction.apply(
+            self.site_a, self.site_b, side, Xa, Xb, add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()), noises,
+            *Pa.values(), *Pb.values())
+        out_a, out_b = out_a.permute(0, 2, 1).unsqueeze(-1), out_b.permute(0, 2, 1).unsqueeze(-1)
+        if self.variant in ("ave", "avqa"):
+            return out_a, idx_a.unsqueeze(-1), out_b, idx_b.unsqueeze(-1)
+        use_lb = (self.site_a.opt.use_load_balacing_loss == 1, self.site_b.opt.use_load_balacing_loss == 1)
+        lb_a, lb_b = (lb_a if use_lb[0] else 0.), (lb_b if use_lb[1] else 0.)
+        if self.variant == "avvp":
+            return out_a, lb_a, out_b, lb_b
+        return (out_a, idx_a.unsqueeze(-1), pr_a.unsqueeze(1), lb_a, out_b, idx_b.unsqueeze(-1), pr_b.unsqueeze(1), lb_b)

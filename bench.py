@@ -204,8 +204,7 @@ def cpu_baseline(c, budget_s=15.0, min_timed=3):
 
 def parity_check(c, material, device, pair_mode="concurrent"):
     """This build against the oracle at the benchmarked shapes, B = 2 clips, through the C ABI behind the module API -- the two
-    sites of a pair run the way the timed region runs them (AdapterPair in `pair_mode` for the AVE / AVQA signatures, two module
-    calls otherwise), so each token tensor's gradient is the sum of its dX from one site and its dY from the other.
+    sites of a pair run the way the timed region runs them (AdapterPair in `pair_mode`; two module calls with --pair off), so each token tensor's gradient is the sum of its dX from one site and its dY from the other.
     fp32: outputs max-abs relative to the tensor's max, indices bit-exact, gradients norm-wise per tensor (+ token rows of the
     audio gradient one by one).  bf16: against the oracle evaluated on the bf16-rounded inputs.
     Kink-aware: at these sizes (10^5 .. 10^6 ReLU units per cross-modal expert) a few pre-activations lie within rounding of zero
@@ -220,7 +219,7 @@ def parity_check(c, material, device, pair_mode="concurrent"):
     from avmoe_amd.adapters import AdapterPair
     from avmoe_amd import debug as dbg
     work, lbw = material
-    can_pair = c["variant"] in ("ave", "avqa") and pair_mode != "off"
+    can_pair = pair_mode != "off"
     res = dict(clips=2, path=(f"AdapterPair(--pair {pair_mode})" if can_pair else "two module calls"), idx_equal=True,
                out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, grad_rel_f32_own_mask=0.0, worst_f32_own_mask=None,
                relu_units=0, relu_units_flipped=0, flipped_preact_max_rel=0.0,
@@ -244,8 +243,15 @@ def parity_check(c, material, device, pair_mode="concurrent"):
         fa, fv = w["fa"].to(device, tdt).requires_grad_(True), w["fv"].to(device, tdt).requires_grad_(True)
         xa, xv = fa.permute(0, 2, 1).unsqueeze(-1), fv.permute(0, 2, 1).unsqueeze(-1)
         lbs, idx_a, idx_v = [], None, None
-        if can_pair:
-            out_a, idx_a, out_v, idx_v = AdapterPair(ma, mv, concurrent=(pair_mode != "serial"))(xa, xv)
+        pair = AdapterPair(ma, mv, concurrent=(pair_mode != "serial")) if can_pair else None
+        if can_pair and c["variant"] == "avs":
+            out_a, idx_a, _p, lb_a, out_v, idx_v, _q, lb_v = pair(xa, xv, is_training=False)
+            lbs = [lb_a, lb_v]
+        elif can_pair and c["variant"] == "avvp":
+            out_a, lb_a, out_v, lb_v = pair(xa, xv)
+            lbs = [lb_a, lb_v]
+        elif can_pair:
+            out_a, idx_a, out_v, idx_v = pair(xa, xv)
         elif c["variant"] == "avs":
             out_a, idx_a, _p, lb_a = ma(xa, xv, is_training=False)
             out_v, idx_v, _p, lb_v = mv(xv, xa, is_training=False)
@@ -367,8 +373,8 @@ class Workload:
         from avmoe_amd.dp import AdapterGradReducer
         from avmoe_amd.adapters import AdapterPair
         self.c, self.world, self.device = c, world, device
-        self.can_pair = c["variant"] in ("ave", "avqa")
-        self.pair_mode = pair_mode if self.can_pair else "off"
+        self.can_pair = True
+        self.pair_mode = pair_mode
         S = c["B"] * c["T"]
         self.lbw = 0.01 if c["variant"] in ("avvp", "avs") else 0.0
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -395,7 +401,14 @@ class Workload:
             xa, xv = w["f_a"].permute(0, 2, 1).unsqueeze(-1), w["f_v"].permute(0, 2, 1).unsqueeze(-1)   # the reference's (S,C,N,1) views
             for a, v, pr in w["mods"]:
                 extra = []
-                if self.pair_mode != "off" and pr is not None:
+                paired = self.pair_mode != "off" and pr is not None
+                if paired and c["variant"] == "avs":
+                    out_a, _, _, lb_a, out_v, _, _, lb_v = pr(xa, xv, is_training=True)
+                    extra = [self.lbw * (lb_a + lb_v)]
+                elif paired and c["variant"] == "avvp":
+                    out_a, lb_a, out_v, lb_v = pr(xa, xv)
+                    extra = [lb_a + lb_v]
+                elif paired:
                     out_a, _, out_v, _ = pr(xa, xv)          # net_trans_v3.py:695-698 as one autograd node (AdapterPair)
                 elif c["variant"] == "avs":
                     out_a, _, _, lb_a = a(xa, xv, is_training=True)

@@ -272,6 +272,61 @@ def test_adapter_pair_with_frame_attention_experts(concurrent):
     assert any("self_attention.in_proj_weight" in k for k, _ in sa.named_parameters())
 
 
+@pytest.mark.parametrize("concurrent", [False, True])
+@pytest.mark.parametrize("which", ["avvp", "avs", "avs_v2"])
+def test_adapter_pair_avvp_avs_signatures(which, concurrent):
+    """AdapterPair over the AVVP (out, lb) and AVS (out, idx, probs, lb) signatures == two module calls, including the gradient
+    of the load-balancing losses and the AVS logit noise (drawn in the order of the two calls).  "avs_v2": latent self attention
+    on the site's own tokens -- the pair then runs back to back whatever `concurrent` says."""
+    from avmoe_amd.adapters import AdapterPair
+    dev = torch.device("cuda:0")
+    variant = "avvp" if which == "avvp" else "avs"
+    kw = dict(reduction=4, groups=2, K=8, variant=variant, lb_loss=True, self_attn=("v2" if which == "avs_v2" else "none"))
+    ca = O.AdapterConfig(Cx=64, Nx=72, Cy=48, Ny=40, **kw)
+    cb = O.AdapterConfig(Cx=48, Nx=40, Cy=64, Ny=72, **kw)
+    torch.manual_seed(5)
+    sa, sb = build_module(variant, ca).to(dev).train(), build_module(variant, cb).to(dev).train()
+    with torch.no_grad():
+        for m in (sa, sb):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.3)
+    g = torch.Generator().manual_seed(9)
+    S = 6
+    fa, fv = (0.5 * torch.randn(S, ca.Cx, ca.Nx, 1, generator=g)).to(dev), (0.5 * torch.randn(S, cb.Cx, cb.Nx, 1, generator=g)).to(dev)
+    ga, gv = torch.randn(S, ca.Cx, ca.Nx, 1, generator=g).to(dev), torch.randn(S, cb.Cx, cb.Nx, 1, generator=g).to(dev)
+    bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in (sa, sb)]
+    pair = AdapterPair(sa, sb, concurrent=concurrent)
+    assert pair.concurrent == (concurrent and which != "avs_v2")
+
+    def run(paired):
+        for m, bb in zip((sa, sb), bufs):
+            m.zero_grad()
+            m.load_state_dict({**m.state_dict(), **bb})
+        torch.manual_seed(77)                          # the AVS noise of both runs
+        xa, xv = fa.clone().requires_grad_(True), fv.clone().requires_grad_(True)
+        extra = ()
+        if variant == "avvp":
+            oa, la, ov, lv = pair(xa, xv) if paired else (*sa(xa, xv), *sb(xv, xa))
+        else:
+            r = pair(xa, xv, is_training=True) if paired else (*sa(xa, xv, is_training=True), *sb(xv, xa, is_training=True))
+            oa, ia, pa, la, ov, iv, pv, lv = r
+            assert pa.shape == (S, 1, ca.E) and ia.shape == (S, 1)
+            extra = (ia, pa, iv, pv)
+        torch.autograd.backward([oa, ov, 0.7 * la + 1.3 * lv], [ga, gv, None])
+        return (oa.detach(), ov.detach(), la.detach(), lv.detach(), *extra), (xa.grad, xv.grad), [p.grad.clone() for m in (sa, sb) for p in m.parameters()]
+
+    ref, got = run(False), run(True)
+    for r_, g_ in zip(ref[0], got[0]):
+        assert torch.equal(r_, g_)
+    for r_, g_ in zip(ref[1], got[1]):
+        assert float((r_ - g_).abs().max()) <= 1e-5 * float(r_.abs().max())
+    for r_, g_ in zip(ref[2], got[2]):
+        assert torch.equal(r_, g_)
+    with pytest.raises(ValueError):
+        AdapterPair(sa, build_module("ave", O.AdapterConfig(Cx=48, Nx=40, Cy=64, Ny=72, reduction=4, groups=2, K=8)).to(dev))
+
+
 def test_flat_adam_two_lr_groups_and_plain_buckets():
     """(1) the reference's two Adam learning-rate groups (AVE/main_trans_v3.py:313-322: lr_mlp for 'mlp_class', lr for the
     adapters; train.sh ships a factor of 100 between them) through select_trainable -> FlatAdam(param_groups=...) against
