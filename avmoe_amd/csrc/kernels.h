@@ -87,6 +87,7 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
 int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+int kf_pre_lat_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 // register-resident kernels generalised over groups (1 / 2 / 4), per-group bottleneck (16 .. 96) and latent slots (16 / 32 / 96): tile_gen.hip
 bool tile_gen_ok(const Dims& d);
 int kg_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);

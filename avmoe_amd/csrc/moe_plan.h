@@ -172,6 +172,7 @@ struct Dims {
   X(rbw, 1, 4, (size_t)d.S * (d.E + 32 + 128 + 2 * d.C))   /* dlog, dh2r, dh1, drin   */       \
   X(dsxs, 1, 4, (size_t)2 * d.NT)                                                               \
   X(rs2x, 1, 4, (size_t)d.NT)                       /* 2 * sum_e dSxx                 */       \
+  X(dslat, 1, 4, (size_t)2 * (d.El ? d.El : 1) * d.NT)   /* dSx, dSxx per (latent expert, token): pre_small_bwd -> pre_lat_bwd */ \
   X(dL2x, 1, d.esz, (size_t)d.NT * d.KLp)           /* [dL2 | dsx | 1]                */       \
   X(aw, 1, d.esz, (size_t)d.NT * d.KLp)             /* du3 * a                        */       \
   X(ag, 1, d.esz, (size_t)d.NT * d.KLp)             /* gate_lat * a                   */       \

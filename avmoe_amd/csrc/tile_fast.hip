@@ -323,6 +323,103 @@ __global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const voi
   }
 }
 
+template <typename T, int E>
+__global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd_we(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
+                                                  const float* __restrict__ sdSzz, void* __restrict__ dzp_, float* __restrict__ colpart) {
+  constexpr int DZ = E * FDD;
+  const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
+  static_assert(E == 4, "wave-per-expert experiment");
+  __shared__ float s_Sw[4][2 * FDG * LD32];
+  __shared__ float s_bnw[4][5 * FDD];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const int e = wave;
+    float* s_S = s_Sw[wave]; float* s_bn = s_bnw[wave];
+    if (a.moments)
+      for (int i = lane; i < 2 * FDG * FDG; i += 64) {
+        const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
+        s_S[(gi * FDG + c) * LD32 + k] = sdSzz[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
+      }
+    {
+      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
+      s_bn[3 * FDD + dd] = bn1[3 * DZ + col]; s_bn[4 * FDD + dd] = a.moments ? dsm[2 * DZ + col] : 0.f;
+    }
+    __syncthreads();
+    const bool relu = a.relu_of_e[e];
+    float4 cs0[4], cs1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    DRAIN_VMEM();
+    // bf16: the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores
+    constexpr bool PF = sizeof(T) == 2 && LB_MIDB_PREFETCH;
+    RawRow<T> nz, ndz;
+    zero_raw(nz); zero_raw(ndz);
+    if constexpr (PF) {
+      const int n0 = n_beg;
+      if (n0 < n_end && n0 + r < t.N) { const long row = ((long)s * t.N + n0 + r) * DZ; ldraw_row<E>(Z + row, e, q, nz); ldraw_row<E>(dzp + row, e, q, ndz); }
+    }
+    for (int n0 = n_beg; n0 < n_end; n0 += 16) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long row = ((long)s * t.N + n0 + r) * DZ;
+      float4 z[4], dz[4], zp[4], dyo[4];
+      if constexpr (PF) {
+        unpack_row(nz, z); unpack_row(ndz, dz);
+        zero_raw(nz); zero_raw(ndz);
+        if (n0 + 16 < n_end && n0 + 16 + r < t.N) { ldraw_row<E>(Z + row + 16L * DZ, e, q, nz); ldraw_row<E>(dzp + row + 16L * DZ, e, q, ndz); }
+      } else {
+        zero_row(z); zero_row(dz);
+        if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float y = at(z[c], x) * at(sc, x) + at(sh, x);
+          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gi = c >> 1, ct = c & 1;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (a.moments) w = mmT<2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+        const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), dm = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
+        float4 dy;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float zv = at(z[c], x);
+          const float zh = (zv - at(mean, x)) * at(rstd, x);
+          const float d = at(dz[c], x) + at(dm, x) + w[x];
+          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : rndT<T>(d);     // as stored: the BN1 sums see the same numbers
+          at(dy, x) = v;
+          at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
+        }
+        dyo[c] = dy;
+      }
+      if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's store is issued
+      if (ok) st_row<T, E>(dzp + row, e, q, dyo);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const float v0 = rsum16(at(cs0[c], x)), v1 = rsum16(at(cs1[c], x));
+        if (r == 0) {
+          const int dd = 16 * c + 4 * q + x;
+          const long o = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+          colpart[((long)blk * 4 + 2) * (E * FDD) + o] = v0; colpart[((long)blk * 4 + 3) * (E * FDD) + o] = v1;
+        }
+      }
+  }
+}
+
+
 // =====================================================================================================
 // MID forward: z' = act(BN1(z)) -> Zp (operand of the second-moment GEMM) + column sums of z'   (net_trans_v3.py:397-400)
 // =====================================================================================================
@@ -692,11 +789,7 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   for (int e = 0; e < E; ++e) {
-#ifdef KF_PREB_NO_LAT          // development (timing only): without the hop-2 block of the latent experts
-    const int l = -1;
-#else
     const int l = a.lat_of_e[e];
-#endif
     const bool nxn = XR && a.nxn_of_e[e] != 0;
     float gv = 0.f;
     __syncthreads();
@@ -819,26 +912,29 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
 }
 
 // =====================================================================================================
-// PRE_SMALL backward
+// PRE_SMALL backward, two kernels:
+//   kf_pre_small_bwd : BN1 input gradient + folded-LayerNorm sums + dzraw for every expert (136 VGPRs, three waves per SIMD);
+//   kf_pre_lat_bwd   : the hop-2 block of the cross-modal experts (softmax backward over the latent tokens, the mat-vecs against
+//                      TW / TT on the matrix pipe), from dzraw as stored and the expert's LayerNorm sums (dslat).
+// As ONE kernel the hop-2 block's registers (256 + spills) set the occupancy of the whole sweep -- two waves per SIMD for the
+// unimodal experts' passes too: 363 us at the cfg-2 audio site, 188 us of it the first kernel's work once that runs alone.
 // =====================================================================================================
-struct FPreBArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int first_of_slot[MAX_E]; long sxr_off[MAX_E]; FastDims t;
+#ifndef LB_PRELB
+#define LB_PRELB 2
+#endif
+struct FPreBArgs { int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int first_of_slot[MAX_E]; long sxr_off[MAX_E]; P16 glat; FastDims t;
                    int ln_before, use_bn, bn_train; const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
 template <typename T, int E, bool XR>
-__global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ TT,
-                                                        const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
-                                                        const float* __restrict__ dconst, const void* __restrict__ ain_, const float* __restrict__ rmu,
+__global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ wsum,
+                                                        const float* __restrict__ dconst, const float* __restrict__ rmu,
                                                         const float* __restrict__ bn1, const float* __restrict__ dsm, const void* __restrict__ dy_in_,
-                                                        void* __restrict__ dZx_, void* __restrict__ dL2x_, void* __restrict__ aw_, void* __restrict__ ag_,
+                                                        void* __restrict__ dZx_, void* __restrict__ dL2x_, float* __restrict__ dslat,
                                                         float* __restrict__ dsxs, float* __restrict__ rs2x, float* __restrict__ colpart,
-                                                        float* __restrict__ blkscal, float* __restrict__ dtbp) {
+                                                        float* __restrict__ blkscal) {
   constexpr int DZ = E * FDD;
-  const T* ain = (const T*)ain_; const T* Z = (const T*)Z_; const T* dy_in = (const T*)dy_in_;
-  T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
-  __shared__ float s_TT[FK * LD32];
-  __shared__ float s_TW[FK * LD64];     // [k][dd]
-  __shared__ float s_TWt[FDD * LD32];   // [dd][k]
-  __shared__ float s_tb[FK];
+  const T* Z = (const T*)Z_; const T* dy_in = (const T*)dy_in_;
+  T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_;
   __shared__ float s_bn[7 * FDD];       // mean, rstd, sc, mdy, mdyz, wsum, dconst
   __shared__ float s_col[4 * FDD];
   __shared__ float s_sc[4];
@@ -852,18 +948,6 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
     float gv = 0.f;
     __syncthreads();
     if (nxn) gv = a.glat.p[e][0];
-    if (l >= 0) {
-      gv = a.glat.p[e][0];
-      const float* tt = TT + ((long)s * t.El + l) * FK * FK;
-      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
-      for (int i = threadIdx.x; i < FK * FDD; i += 256) {
-        const int k = i >> 6, dd = i & 63;
-        const float v = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
-        s_TW[k * LD64 + dd] = v;
-        s_TWt[dd * LD32 + k] = v;
-      }
-      if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
-    }
     if (threadIdx.x < FDD) {
       const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
       s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
@@ -872,38 +956,35 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
     }
     __syncthreads();
     float sdg = 0.f;
-    float4 cs0[4], cs1[4], ck[2];
+    float4 cs0[4], cs1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
-    ck[0] = zero4(); ck[1] = zero4();
     DRAIN_VMEM();
+    // the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores (a load
+    // behind a store would -- the memory counter being in-order -- wait for the store to be acknowledged)
+    RawRow<T> nz_, ndy_;
+    float nrr = 1.f, nmu = 0.f, nsx = 0.f, nsxx = 0.f;
+    auto request = [&](int n0) {
+      zero_raw(nz_); zero_raw(ndy_); nrr = 1.f; nmu = 0.f; nsx = 0.f; nsxx = 0.f;
+      if (n0 < n_end && n0 + r < t.N) {
+        const long tok = (long)s * t.N + n0 + r;
+        ldraw_row<E>(Z + tok * DZ, e, q, nz_); ldraw_row<E>(dy_in + tok * DZ, e, q, ndy_);
+        if (F_LN_BEFORE(a)) { nrr = rmu[(long)e * t.NT + tok]; nmu = rmu[(long)t.NT * E + (long)e * t.NT + tok]; }
+        if (q == 0 && e != 0) { nsx = dsxs[tok]; nsxx = dsxs[t.NT + tok]; }
+      }
+    };
+    request(n_beg + 16 * wave);
     for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
-      const float rr = (F_LN_BEFORE(a) && ok) ? rmu[(long)e * t.NT + tok] : 1.f;
-      const float mu = (F_LN_BEFORE(a) && ok) ? rmu[(long)t.NT * E + (long)e * t.NT + tok] : 0.f;
+      const RawRow<T> zraw_ = nz_, dyraw_ = ndy_;
+      const float rr = nrr, mu = nmu, old_sx = nsx, old_sxx = nsxx;
+      request(n0 + 64);
       const float irr = 1.f / rr;
       // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
       float4 dzr[4], zrow[4], dyrow[4];
       float s_dr = 0.f, s_dmu = 0.f;
-      // every load of the tile is requested here, in raw form (unpacked at first use), and every store is issued at its end: a load
-      // behind a store would (the memory counter being in-order) wait for the store to be acknowledged -- three exposed round trips
-      // per tile instead of one
-      RawRow<T> zraw_, dyraw_;
-      RawSeg<T> araw_;
-      float4 av[2], lg[2];
-      float old_sx = 0.f, old_sxx = 0.f;
-      zero_raw(zraw_); zero_raw(dyraw_); zero_raw(araw_); lg[0] = zero4(); lg[1] = zero4();
-      if (ok) {
-        ldraw_row<E>(Z + tok * DZ, e, q, zraw_); ldraw_row<E>(dy_in + tok * DZ, e, q, dyraw_);
-        if (l >= 0) {
-          ldraw_seg(ain + tok * t.KLp + (long)l * FK, q, araw_);
-          const long lo = tok * t.KLp + (long)l * FK + 4 * q;
-          lg[0] = ld4(L2 + lo); lg[1] = ld4(L2 + lo + 16);
-        }
-        if (q == 0 && e != 0) { old_sx = dsxs[tok]; old_sxx = dsxs[t.NT + tok]; }
-      }
       unpack_row(zraw_, zrow); unpack_row(dyraw_, dyrow);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -969,64 +1050,14 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
         else { dsr[tok] += v0; dsr[(long)t.NT + tok] += v1; dsr[2L * t.NT + tok] += v2; }
         sdg += dSx * sxr[tok] + dSxx * (2.f * sxr[2L * t.NT + tok] + 2.f * gv * sxr[(long)t.NT + tok]) + szr;
       }
-      if (l >= 0) {
-        unpack_rawseg(araw_, av[0], av[1]);
-        float u1 = 0.f, u2 = 0.f;
-        float4 tb[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          tb[j] = ld4(s_tb + oz + 16 * j + 4 * q);
-#pragma unroll
-          for (int x = 0; x < 4; ++x) { u1 += at(av[j], x) * at(tb[j], x); u2 += at(av[j], x) * at(lg[j], x); }
-        }
-        u1 = qsum4(u1); u2 = qsum4(u2);
-        float dgr = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
-          const f32x4 p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
-#pragma unroll
-          for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
-        }
-        dgr = qsum4(dgr);
-        const float du1 = dSx * gv * (float)t.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
-        float u3 = 0.f, sada = 0.f;
-        float4 da[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
-          const f32x4 twd = mmT<4>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const float ac = at(av[ct], x);
-            u3 += ta[x] * ac;
-            float d = 0.f;
-            if (ok) {
-              d = gv * twd[x] + du1 * at(tb[ct], x) + du2 * at(lg[ct], x) + 2.f * du3 * ta[x];
-              sada += ac * d;
-              at(ck[ct], x) += du1 * ac;
-            }
-            at(da[ct], x) = d;
-          }
-        }
-        u3 = qsum4(u3); sada = qsum4(sada);
-        if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
-        if (ok) {
-          float4 v0[2], v1[2], v2[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const float ac = at(av[j], x);
-              at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
-            }
-          const long so = tok * t.KLp + (long)l * FK;
-          st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
-        }
-      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
       if (ok) {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
-        if (q == 0) { dsxs[tok] = accx; dsxs[t.NT + tok] = accxx; }
+        if (q == 0) {
+          dsxs[tok] = accx; dsxs[t.NT + tok] = accxx;
+          if (l >= 0) { dslat[(2L * l) * t.NT + tok] = dSx; dslat[(2L * l + 1) * t.NT + tok] = dSxx; }      // this expert's own sums: pre_lat_bwd
+        }
       }
       if (e == E - 1 && ok && q == 0) {
         stT<T>(dL2x, tok * t.KLp + t.KL, accx);
@@ -1037,22 +1068,151 @@ __global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, co
     flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
     flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
     const float vg = block_scalar(wave_sum(sdg), s_sc);
-    if (threadIdx.x == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;
-    if (l >= 0) {
+    if (threadIdx.x == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;      // (a cross-modal expert's slot is rewritten by pre_lat_bwd)
+  }
+}
+
+struct FPreLArgs { int lat_of_e[MAX_E]; P16 glat; FastDims t; };
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, const float* __restrict__ L2, const float* __restrict__ TT,
+                                                       const float* __restrict__ TW, const float* __restrict__ Tsum, const void* __restrict__ ain_,
+                                                       const void* __restrict__ dZx_, const float* __restrict__ dslat, void* __restrict__ dL2x_,
+                                                       void* __restrict__ aw_, void* __restrict__ ag_, float* __restrict__ blkscal,
+                                                       float* __restrict__ dtbp) {
+  constexpr int DZ = E * FDD;
+  const T* ain = (const T*)ain_; const T* dZx = (const T*)dZx_;
+  T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
+  __shared__ float s_TT[FK * LD32];
+  __shared__ float s_TW[FK * LD64];     // [k][dd]
+  __shared__ float s_TWt[FDD * LD32];   // [dd][k]
+  __shared__ float s_tb[FK];
+  __shared__ float s_col[4 * FDD];
+  __shared__ float s_sc[4];
+  const FastDims& t = a.t;
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll 1
+  for (int e = 0; e < E; ++e) {
+    const int l = a.lat_of_e[e];
+    if (l < 0) continue;
+    __syncthreads();
+    const float gv = a.glat.p[e][0];
+    {
+      const float* tt = TT + ((long)s * t.El + l) * FK * FK;
+      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
+      for (int i = threadIdx.x; i < FK * FDD; i += 256) {
+        const int k = i >> 6, dd = i & 63;
+        const float v = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
+        s_TW[k * LD64 + dd] = v;
+        s_TWt[dd * LD32 + k] = v;
+      }
+      if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
+    }
+    __syncthreads();
+    float sdg = 0.f;
+    float4 ck[2];
+    ck[0] = zero4(); ck[1] = zero4();
+    DRAIN_VMEM();
+    // the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores: load
+    // latency and the acknowledgement of the previous tile's stores pass under the mat-vecs instead of in front of them
+    RawRow<T> ndraw_;
+    RawSeg<T> naraw_;
+    float4 nlg[2];
+    float ndSx = 0.f, ndSxx = 0.f;
+    auto request = [&](int n0) {
+      zero_raw(ndraw_); zero_raw(naraw_); nlg[0] = zero4(); nlg[1] = zero4(); ndSx = 0.f; ndSxx = 0.f;
+      if (n0 < n_end && n0 + r < t.N) {
+        const long tok = (long)s * t.N + n0 + r;
+        ldraw_row<E>(dZx + tok * DZ, e, q, ndraw_);
+        ldraw_seg(ain + tok * t.KLp + (long)l * FK, q, naraw_);
+        const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+        nlg[0] = ld4(L2 + lo); nlg[1] = ld4(L2 + lo + 16);
+        ndSx = dslat[(2L * l) * t.NT + tok]; ndSxx = dslat[(2L * l + 1) * t.NT + tok];
+      }
+    };
+    request(n_beg + 16 * wave);
+    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+      const int oz = opaque0();
+      const bool ok = n0 + r < t.N;
+      const long tok = (long)s * t.N + n0 + r;
+      const RawRow<T> draw_ = ndraw_;
+      const RawSeg<T> araw_ = naraw_;
+      float4 dzr[4], av[2], lg[2];
+      lg[0] = nlg[0]; lg[1] = nlg[1];
+      const float dSx = ndSx, dSxx = ndSxx;
+      request(n0 + 64);
+      unpack_row(draw_, dzr);
+      unpack_rawseg(araw_, av[0], av[1]);
+      float u1 = 0.f, u2 = 0.f;
+      float4 tb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
+        tb[j] = ld4(s_tb + oz + 16 * j + 4 * q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { u1 += at(av[j], x) * at(tb[j], x); u2 += at(av[j], x) * at(lg[j], x); }
+      }
+      u1 = qsum4(u1); u2 = qsum4(u2);
+      float dgr = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
+        const f32x4 p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
+      }
+      dgr = qsum4(dgr);
+      const float du1 = dSx * gv * (float)t.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
+      float u3 = 0.f, sada = 0.f;
+      float4 da[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
+        const f32x4 twd = mmT<4>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-          const float v = rsum16(at(ck[j], x));
-          if (r == 0) s_col[wave * FDD + 16 * j + 4 * q + x] = v;
+          const float ac = at(av[ct], x);
+          u3 += ta[x] * ac;
+          float d = 0.f;
+          if (ok) {
+            d = gv * twd[x] + du1 * at(tb[ct], x) + du2 * at(lg[ct], x) + 2.f * du3 * ta[x];
+            sada += ac * d;
+            at(ck[ct], x) += du1 * ac;
+          }
+          at(da[ct], x) = d;
         }
-      __syncthreads();
-      if (threadIdx.x < FK) {
-        const int k = threadIdx.x;
-        dtbp[(long)blk * t.KL + (long)l * FK + k] = s_col[k] + s_col[FDD + k] + s_col[2 * FDD + k] + s_col[3 * FDD + k];
       }
-      __syncthreads();
+      u3 = qsum4(u3); sada = qsum4(sada);
+      if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
+      if (ok) {
+        float4 v0[2], v1[2], v2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float ac = at(av[j], x);
+            at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
+          }
+        const long so = tok * t.KLp + (long)l * FK;
+        st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
+      }
     }
+    const float vg = block_scalar(wave_sum(sdg), s_sc);
+    if (threadIdx.x == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const float v = rsum16(at(ck[j], x));
+        if (r == 0) s_col[wave * FDD + 16 * j + 4 * q + x] = v;
+      }
+    __syncthreads();
+    if (threadIdx.x < FK) {
+      const int k = threadIdx.x;
+      dtbp[(long)blk * t.KL + (long)l * FK + k] = s_col[k] + s_col[FDD + k] + s_col[2 * FDD + k] + s_col[3 * FDD + k];
+    }
+    __syncthreads();
   }
 }
 
@@ -1174,6 +1334,11 @@ int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per); a.moments = d.use_bn && d.training;
+#if KF_WAVE_EXPERT
+  if (d.E == 4) { LAUNCH_TE1(d.bf16, kf_mid_bwd_we, 4, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+            (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (void*)(scratch + pl.o_dzp),
+            (float*)(scratch + pl.o_colpart)); } else
+#endif
   LAUNCH_TE(d.bf16, kf_mid_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
             (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (void*)(scratch + pl.o_dzp),
             (float*)(scratch + pl.o_colpart));
@@ -1200,14 +1365,30 @@ int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.dZR = (void*)(scratch + pl.o_dZR); a.dsr = (float*)(scratch + pl.o_dsr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
-  LAUNCH_TEX(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT),
-            (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum), (const float*)(saved + pl.o_wsum),
-            (const float*)(saved + pl.o_dconst), (const void*)(saved + pl.o_a), (const float*)(saved + pl.o_rmu),
+  LAUNCH_TEX(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_wsum),
+            (const float*)(saved + pl.o_dconst), (const float*)(saved + pl.o_rmu),
             (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const void*)(scratch + pl.o_dzp),
-            (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw), (void*)(scratch + pl.o_ag),
+            (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (float*)(scratch + pl.o_dslat),
             (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x), (float*)(scratch + pl.o_colpart),
-            (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
+            (float*)(scratch + pl.o_blkscal));
   AVMOE_CHECK_LAUNCH("pre_small_bwd (64/32)");
+  return OK;
+}
+
+// the hop-2 block of the cross-modal experts; after kf_pre_small_bwd on the same stream (reads dZx and dslat, rewrites the experts'
+// gate partials in blkscal)
+int kf_pre_lat_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (d.KL == 0) return OK;
+  dim3 grid; int per; fast_grid(d, &grid, &per);
+  FPreLArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = e < d.E ? d.lat_of_e[e] : -1; }
+  a.t = make_fd(d, per);
+  LAUNCH_TE(d.bf16, kf_pre_lat_bwd, a, (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW),
+            (const float*)(saved + pl.o_Tsum), (const void*)(saved + pl.o_a), (const void*)(scratch + pl.o_Zw),
+            (const float*)(scratch + pl.o_dslat), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw), (void*)(scratch + pl.o_ag),
+            (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
+  AVMOE_CHECK_LAUNCH("pre_lat_bwd (64/32)");
   return OK;
 }
 

@@ -1133,11 +1133,20 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_pre_small_bwd", (long)d.NT, bytes_pre_small_bwd(d), 0.0, st);
-  if (tile_fast_ok(d)) {
-    AVMOE_TRY(kf_pre_small_bwd(pl, saved, scratch, prm, st));
+  if (tile_fast_ok(d)) {      // two kernels: every expert's BN1 / LayerNorm part, then the cross-modal experts' hop-2 block (tile_fast.hip)
+    const double lat = (double)d.NT * ((double)d.El * d.DD * d.esz + (d.KL ? (double)d.KL * (4 + 4 * d.esz) : 0.0) + 8.0 * d.El);
+    {
+      ProfScope ps_("k_pre_small_bwd", (long)d.NT, (double)d.NT * ((double)d.DZ * (2.0 * d.zsz + d.esz) + 8.0 * d.E + 8.0 * d.El + 12.0), 0.0, st);
+      AVMOE_TRY(kf_pre_small_bwd(pl, saved, scratch, prm, st));
+    }
+    if (d.KL) {
+      ProfScope ps_("k_pre_lat_bwd", (long)d.NT, lat, 0.0, st);
+      AVMOE_TRY(kf_pre_lat_bwd(pl, saved, scratch, prm, st));
+    }
+    ProfScope ps_("k_pre_bwd_finalize", 0.0, 0.0, st);
     return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
   }
+  ProfScope ps_("k_pre_small_bwd", (long)d.NT, bytes_pre_small_bwd(d), 0.0, st);
   if (d.gen) {
     AVMOE_TRY(kg_pre_small_bwd(pl, saved, scratch, prm, st));
     return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
