@@ -24,7 +24,7 @@
 #define LB_MID 4
 #endif
 #ifndef LB_POST
-#define LB_POST 5
+#define LB_POST 4
 #endif
 #ifndef LB_POSTB
 #define LB_POSTB 2
@@ -232,193 +232,142 @@ __device__ __forceinline__ float block_scalar(float v, float* s4) {   // sum of 
   return s4[0] + s4[1] + s4[2] + s4[3];
 }
 
+// ---- wave-per-expert form --------------------------------------------------------------------------------------------------
+// The waves of a block take DIFFERENT experts of the SAME 16-token tiles (wave = tile slot * E + expert), so the E 64-byte segments
+// of a Z-space row [group][expert][32] are requested within the same few hundred cycles -- one DRAM page, neighbouring sectors of
+// the same lines -- instead of E sweeps over the block's tokens apart.  Measured on kf_mid_bwd at the cfg-2 audio site (same
+// bytes, same occupancy): 183 -> 125 us; with an expert-outer loop the HBM traffic is the same but every sweep touches one
+// 64-byte sector in four of each row.
+template <int E> struct WE {
+  static constexpr int NS = (E == 2) ? 2 : 1;      // tile slots: tiles a block works on at a time
+  static constexpr int NW = E * NS, NTHR = 64 * NW;
+};
+// fold per-lane token-slot accumulators (acc[c][x] for dd = 16 c + 4 q + x of expert e) over the 16 token slots and the tile slots,
+// then write colpart[blk][slot][colmap(e, dd)]          s_x: [NW][64]
+template <int E>
+__device__ __forceinline__ void flush_cols_we(float4 (&acc)[4], float* s_x, float* colpart, int blk, int slot, int e, int ts) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float v = rsum16(at(acc[c], x));
+      if (r == 0) s_x[wave * FDD + 16 * c + 4 * q + x] = v;
+    }
+  __syncthreads();
+  if (ts == 0) {
+    const int dd = lane;
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < WE<E>::NS; ++u) v += s_x[(u * E + e) * FDD + dd];
+    colpart[((long)blk * 4 + slot) * (E * FDD) + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)] = v;
+  }
+  __syncthreads();
+}
+// sum of per-wave values (already wave-uniform) over the tile slots of expert e          s_w: [NW]
+template <int E>
+__device__ __forceinline__ float expert_scalar(float v, float* s_w, int e) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) s_w[wave] = v;
+  __syncthreads();
+  float o = 0.f;
+#pragma unroll
+  for (int u = 0; u < WE<E>::NS; ++u) o += s_w[u * E + e];
+  return o;
+}
+
 // =====================================================================================================
 // MID backward      (BN2-moment terms + BN1/ReLU mask; algebra_ref.py MID backward)
 // =====================================================================================================
 struct FMidArgs { int relu_of_e[MAX_E]; FastDims t; int moments; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
+__global__ void __launch_bounds__(WE<E>::NTHR, LB_MIDB) kf_mid_bwd(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
                                                   const float* __restrict__ sdSzz, void* __restrict__ dzp_, float* __restrict__ colpart) {
-  constexpr int DZ = E * FDD;
+  constexpr int DZ = E * FDD, NS = WE<E>::NS, NTHR = WE<E>::NTHR;
   const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
-  __shared__ float s_S[2 * FDG * LD32];
-  __shared__ float s_bn[5 * FDD];
-  __shared__ float s_col[4 * FDD];
+  __shared__ float s_Se[E][2 * FDG * LD32];
+  __shared__ float s_bne[E][5 * FDD];
+  __shared__ float s_col[WE<E>::NW * FDD];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int e = 0; e < E; ++e) {
-    __syncthreads();
-    if (a.moments)
-      for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
-        const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-        s_S[(gi * FDG + c) * LD32 + k] = sdSzz[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
-      }
-    if (threadIdx.x < FDD) {
-      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
-      s_bn[3 * FDD + dd] = bn1[3 * DZ + col]; s_bn[4 * FDD + dd] = a.moments ? dsm[2 * DZ + col] : 0.f;
+  if (a.moments)
+    for (int i = threadIdx.x; i < E * 2 * FDG * FDG; i += NTHR) {
+      const int ee = i >> 11, gi = (i >> 10) & 1, k = (i >> 5) & 31, c = i & 31;
+      s_Se[ee][(gi * FDG + c) * LD32 + k] = sdSzz[(long)(gi * E + ee) * FDG * FDG + k * FDG + c];     // transposed (mmT)
     }
-    __syncthreads();
-    const bool relu = a.relu_of_e[e];
-    float4 cs0[4], cs1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
-    DRAIN_VMEM();
-    // bf16: the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores
-    constexpr bool PF = sizeof(T) == 2 && LB_MIDB_PREFETCH;
-    RawRow<T> nz, ndz;
-    zero_raw(nz); zero_raw(ndz);
-    if constexpr (PF) {
-      const int n0 = n_beg + 16 * wave;
-      if (n0 < n_end && n0 + r < t.N) { const long row = ((long)s * t.N + n0 + r) * DZ; ldraw_row<E>(Z + row, e, q, nz); ldraw_row<E>(dzp + row, e, q, ndz); }
-    }
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
-      const int oz = opaque0();
-      const bool ok = n0 + r < t.N;
-      const long row = ((long)s * t.N + n0 + r) * DZ;
-      float4 z[4], dz[4], zp[4], dyo[4];
-      if constexpr (PF) {
-        unpack_row(nz, z); unpack_row(ndz, dz);
-        zero_raw(nz); zero_raw(ndz);
-        if (n0 + 64 < n_end && n0 + 64 + r < t.N) { ldraw_row<E>(Z + row + 64L * DZ, e, q, nz); ldraw_row<E>(dzp + row + 64L * DZ, e, q, ndz); }
-      } else {
-        zero_row(z); zero_row(dz);
-        if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const float y = at(z[c], x) * at(sc, x) + at(sh, x);
-          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int gi = c >> 1, ct = c & 1;
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (a.moments) w = mmT<2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
-        const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), dm = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
-        float4 dy;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const float zv = at(z[c], x);
-          const float zh = (zv - at(mean, x)) * at(rstd, x);
-          const float d = at(dz[c], x) + at(dm, x) + w[x];
-          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : rndT<T>(d);     // as stored: the BN1 sums see the same numbers
-          at(dy, x) = v;
-          at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
-        }
-        dyo[c] = dy;
-      }
-      if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's store is issued
-      if (ok) st_row<T, E>(dzp + row, e, q, dyo);
-    }
-    flush_cols<E>(cs0, s_col, colpart, blk, 2, e);
-    flush_cols<E>(cs1, s_col, colpart, blk, 3, e);
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    float* b = s_bne[ee];
+    b[dd] = bn1[col]; b[FDD + dd] = bn1[DZ + col]; b[2 * FDD + dd] = bn1[2 * DZ + col];
+    b[3 * FDD + dd] = bn1[3 * DZ + col]; b[4 * FDD + dd] = a.moments ? dsm[2 * DZ + col] : 0.f;
   }
-}
-
-template <typename T, int E>
-__global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd_we(FMidArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ dsm,
-                                                  const float* __restrict__ sdSzz, void* __restrict__ dzp_, float* __restrict__ colpart) {
-  constexpr int DZ = E * FDD;
-  const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
-  static_assert(E == 4, "wave-per-expert experiment");
-  __shared__ float s_Sw[4][2 * FDG * LD32];
-  __shared__ float s_bnw[4][5 * FDD];
-  const FastDims& t = a.t;
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  {
-    const int e = wave;
-    float* s_S = s_Sw[wave]; float* s_bn = s_bnw[wave];
-    if (a.moments)
-      for (int i = lane; i < 2 * FDG * FDG; i += 64) {
-        const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-        s_S[(gi * FDG + c) * LD32 + k] = sdSzz[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
-      }
-    {
-      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
-      s_bn[3 * FDD + dd] = bn1[3 * DZ + col]; s_bn[4 * FDD + dd] = a.moments ? dsm[2 * DZ + col] : 0.f;
-    }
-    __syncthreads();
-    const bool relu = a.relu_of_e[e];
-    float4 cs0[4], cs1[4];
+  __syncthreads();
+  const float* s_S = s_Se[e];
+  const float* s_bn = s_bne[e];
+  const bool relu = a.relu_of_e[e];
+  float4 cs0[4], cs1[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
-    DRAIN_VMEM();
-    // bf16: the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores
-    constexpr bool PF = sizeof(T) == 2 && LB_MIDB_PREFETCH;
-    RawRow<T> nz, ndz;
-    zero_raw(nz); zero_raw(ndz);
+  for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+  DRAIN_VMEM();
+  // bf16: the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores
+  constexpr bool PF = sizeof(T) == 2 && LB_MIDB_PREFETCH;
+  RawRow<T> nz, ndz;
+  zero_raw(nz); zero_raw(ndz);
+  if constexpr (PF) {
+    const int n0 = n_beg + 16 * ts;
+    if (n0 < n_end && n0 + r < t.N) { const long row = ((long)s * t.N + n0 + r) * DZ; ldraw_row<E>(Z + row, e, q, nz); ldraw_row<E>(dzp + row, e, q, ndz); }
+  }
+  for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS) {
+    const int oz = opaque0();
+    const bool ok = n0 + r < t.N;
+    const long row = ((long)s * t.N + n0 + r) * DZ;
+    float4 z[4], dz[4], zp[4], dyo[4];
     if constexpr (PF) {
-      const int n0 = n_beg;
-      if (n0 < n_end && n0 + r < t.N) { const long row = ((long)s * t.N + n0 + r) * DZ; ldraw_row<E>(Z + row, e, q, nz); ldraw_row<E>(dzp + row, e, q, ndz); }
-    }
-    for (int n0 = n_beg; n0 < n_end; n0 += 16) {
-      const int oz = opaque0();
-      const bool ok = n0 + r < t.N;
-      const long row = ((long)s * t.N + n0 + r) * DZ;
-      float4 z[4], dz[4], zp[4], dyo[4];
-      if constexpr (PF) {
-        unpack_row(nz, z); unpack_row(ndz, dz);
-        zero_raw(nz); zero_raw(ndz);
-        if (n0 + 16 < n_end && n0 + 16 + r < t.N) { ldraw_row<E>(Z + row + 16L * DZ, e, q, nz); ldraw_row<E>(dzp + row + 16L * DZ, e, q, ndz); }
-      } else {
-        zero_row(z); zero_row(dz);
-        if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const float y = at(z[c], x) * at(sc, x) + at(sh, x);
-          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int gi = c >> 1, ct = c & 1;
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (a.moments) w = mmT<2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
-        const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), dm = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
-        float4 dy;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const float zv = at(z[c], x);
-          const float zh = (zv - at(mean, x)) * at(rstd, x);
-          const float d = at(dz[c], x) + at(dm, x) + w[x];
-          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : rndT<T>(d);     // as stored: the BN1 sums see the same numbers
-          at(dy, x) = v;
-          at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
-        }
-        dyo[c] = dy;
-      }
-      if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's store is issued
-      if (ok) st_row<T, E>(dzp + row, e, q, dyo);
+      unpack_row(nz, z); unpack_row(ndz, dz);
+      zero_raw(nz); zero_raw(ndz);
+      if (n0 + 16 * NS < n_end && n0 + 16 * NS + r < t.N) { ldraw_row<E>(Z + row + 16L * NS * DZ, e, q, nz); ldraw_row<E>(dzp + row + 16L * NS * DZ, e, q, ndz); }
+    } else {
+      zero_row(z); zero_row(dz);
+      if (ok) { ld_row<T, E>(Z + row, e, q, z); ld_row<T, E>(dzp + row, e, q, dz); }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c) {
+      const float4 sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        const float v0 = rsum16(at(cs0[c], x)), v1 = rsum16(at(cs1[c], x));
-        if (r == 0) {
-          const int dd = 16 * c + 4 * q + x;
-          const long o = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-          colpart[((long)blk * 4 + 2) * (E * FDD) + o] = v0; colpart[((long)blk * 4 + 3) * (E * FDD) + o] = v1;
-        }
+        const float y = at(z[c], x) * at(sc, x) + at(sh, x);
+        at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
       }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gi = c >> 1, ct = c & 1;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (a.moments) w = mmT<2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+      const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), dm = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
+      float4 dy;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const float zv = at(z[c], x);
+        const float zh = (zv - at(mean, x)) * at(rstd, x);
+        const float d = at(dz[c], x) + at(dm, x) + w[x];
+        const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : rndT<T>(d);     // as stored: the BN1 sums see the same numbers
+        at(dy, x) = v;
+        at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
+      }
+      dyo[c] = dy;
+    }
+    if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's store is issued
+    if (ok) st_row<T, E>(dzp + row, e, q, dyo);
   }
+  flush_cols_we<E>(cs0, s_col, colpart, blk, 2, e, ts);
+  flush_cols_we<E>(cs1, s_col, colpart, blk, 3, e, ts);
 }
-
 
 // =====================================================================================================
 // MID forward: z' = act(BN1(z)) -> Zp (operand of the second-moment GEMM) + column sums of z'   (net_trans_v3.py:397-400)
@@ -426,63 +375,57 @@ __global__ void __launch_bounds__(256, LB_MIDB) kf_mid_bwd_we(FMidArgs a, const 
 struct FMidFArgs { int relu_of_e[MAX_E]; FastDims t; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, LB_MID) kf_mid(FMidFArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, void* __restrict__ Zp_,
+__global__ void __launch_bounds__(WE<E>::NTHR, LB_MID) kf_mid(FMidFArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, void* __restrict__ Zp_,
                                                  float* __restrict__ colpart) {
-  constexpr int DZ = E * FDD;
+  constexpr int DZ = E * FDD, NS = WE<E>::NS;
   T* Zp = (T*)Zp_; const T* Z = (const T*)Z_;
-  __shared__ float s_c[2 * FDD];      // sc, sh
-  __shared__ float s_col[4 * FDD];
+  __shared__ float s_col[WE<E>::NW * FDD];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int e = 0; e < E; ++e) {
-    __syncthreads();
-    if (threadIdx.x < FDD) {
-      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_c[dd] = bn1[2 * DZ + col]; s_c[FDD + dd] = bn1[3 * DZ + col];
-    }
-    __syncthreads();
-    const bool relu = a.relu_of_e[e];
-    float4 sc[4], sh[4], cs0[4];
+  const bool relu = a.relu_of_e[e];
+  float4 sc[4], sh[4], cs0[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { sc[c] = ld4(s_c + 16 * c + 4 * q); sh[c] = ld4(s_c + FDD + 16 * c + 4 * q); cs0[c] = zero4(); }
-    constexpr int UT = 4;                                            // tiles per step: all their row loads in flight together
-    DRAIN_VMEM();
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64 * UT) {
-      RawRow<T> z[UT];
-      bool ok[UT];
-      long tok[UT];
-#pragma unroll
-      for (int u = 0; u < UT; ++u) {
-        const int n = n0 + 64 * u;
-        ok[u] = n < n_end && n + r < t.N;
-        tok[u] = (long)s * t.N + n + r;
-        zero_raw(z[u]);
-        if (ok[u]) ldraw_row<E>(Z + tok[u] * DZ, e, q, z[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < UT; ++u) {
-        if (!ok[u]) continue;
-        float4 zr[4], zp[4];
-        unpack_row(z[u], zr);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            float y = at(zr[c], x) * at(sc[c], x) + at(sh[c], x);
-            if (relu) y = fmaxf(y, 0.f);
-            y = rndT<T>(y);
-            at(zp[c], x) = y;
-            at(cs0[c], x) += y;
-          }
-        }
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) st_seg<T>(Zp + tok[u] * DZ + gi * (E * FDG) + e * FDG, zp[2 * gi], zp[2 * gi + 1], q);
-      }
-    }
-    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
+  for (int c = 0; c < 4; ++c) {
+    sc[c] = ld4(bn1 + 2 * DZ + zcol<E>(c, e, q)); sh[c] = ld4(bn1 + 3 * DZ + zcol<E>(c, e, q)); cs0[c] = zero4();
   }
+  constexpr int UT = 4;                                            // tiles per step: all their row loads in flight together
+  DRAIN_VMEM();
+  for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS * UT) {
+    RawRow<T> z[UT];
+    bool ok[UT];
+    long tok[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int n = n0 + 16 * NS * u;
+      ok[u] = n < n_end && n + r < t.N;
+      tok[u] = (long)s * t.N + n + r;
+      zero_raw(z[u]);
+      if (ok[u]) ldraw_row<E>(Z + tok[u] * DZ, e, q, z[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (!ok[u]) continue;
+      float4 zr[4], zp[4];
+      unpack_row(z[u], zr);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          float y = at(zr[c], x) * at(sc[c], x) + at(sh[c], x);
+          if (relu) y = fmaxf(y, 0.f);
+          y = rndT<T>(y);
+          at(zp[c], x) = y;
+          at(cs0[c], x) += y;
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) st_seg<T>(Zp + tok[u] * DZ + gi * (E * FDG) + e * FDG, zp[2 * gi], zp[2 * gi + 1], q);
+    }
+  }
+  flush_cols_we<E>(cs0, s_col, colpart, blk, 0, e, ts);
 }
 
 // =====================================================================================================
@@ -491,26 +434,29 @@ __global__ void __launch_bounds__(256, LB_MID) kf_mid(FMidFArgs a, const void* _
 struct FPostArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; float ln_eps; };
 
 template <typename T, int E>
-__global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(WE<E>::NTHR, LB_POST) kf_post_small(FPostArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                      const float* __restrict__ uvh, const float* __restrict__ probs, void* __restrict__ Apost_,
                                                      float* __restrict__ rpmup) {
-  constexpr int DZ = E * FDD;
+  constexpr int DZ = E * FDD, NS = WE<E>::NS, NTHR = WE<E>::NTHR;
   T* Apost = (T*)Apost_; const T* Z = (const T*)Z_;
-  __shared__ float s_G[2 * FDG * LD32];
-  __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
+  __shared__ float s_Ge[E][2 * FDG * LD32];
+  __shared__ float s_ce[E][4 * FDD];      // us, vh, sc, sh
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
-  for (int e = 0; e < E; ++e) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
-      const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-      s_G[(gi * FDG + c) * LD32 + k] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
+  {
+    for (int i = threadIdx.x; i < E * 2 * FDG * FDG; i += NTHR) {
+      const int ee = i >> 11, gi = (i >> 10) & 1, k = (i >> 5) & 31, c = i & 31;
+      s_Ge[ee][(gi * FDG + c) * LD32 + k] = Gq[(long)(gi * E + ee) * FDG * FDG + k * FDG + c];     // transposed (mmT)
     }
-    if (threadIdx.x < FDD) {
-      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_c[dd] = uvh[col]; s_c[FDD + dd] = uvh[DZ + col]; s_c[2 * FDD + dd] = bn1[2 * DZ + col]; s_c[3 * FDD + dd] = bn1[3 * DZ + col];
+    for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+      const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+      float* c_ = s_ce[ee];
+      c_[dd] = uvh[col]; c_[FDD + dd] = uvh[DZ + col]; c_[2 * FDD + dd] = bn1[2 * DZ + col]; c_[3 * FDD + dd] = bn1[3 * DZ + col];
     }
+    const float* s_G = s_Ge[e];
+    const float* s_c = s_ce[e];
     float H1 = 0.f, H2 = 0.f;
     for (int gi = 0; gi < 2; ++gi) { H1 += uvh[2 * DZ + gi * E + e]; H2 += uvh[2 * DZ + 2 * E + gi * E + e]; }
     __syncthreads();
@@ -520,15 +466,15 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
     DRAIN_VMEM();
     RawRow<T> nz;                                             // the next tile's row of Z, raw
     zero_raw(nz);
-    { const int n0 = n_beg + 16 * wave; if (n0 < n_end && n0 + r < t.N) ldraw_row<E>(Z + ((long)s * t.N + n0 + r) * DZ, e, q, nz); }
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+    { const int n0 = n_beg + 16 * ts; if (n0 < n_end && n0 + r < t.N) ldraw_row<E>(Z + ((long)s * t.N + n0 + r) * DZ, e, q, nz); }
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
       float4 zp[4], zraw[4];
       unpack_row(nz, zraw);                                  // requested one tile ago
       zero_raw(nz);
-      if (n0 + 64 < n_end && n0 + 64 + r < t.N) ldraw_row<E>(Z + (tok + 64) * DZ, e, q, nz);      // the next tile's row: in flight during this tile's arithmetic
+      if (n0 + 16 * NS < n_end && n0 + 16 * NS + r < t.N) ldraw_row<E>(Z + (tok + 16 * NS) * DZ, e, q, nz);      // the next tile's row: in flight during this tile's arithmetic
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4 sc = ld4(s_c + oz + 2 * FDD + 16 * c + 4 * q), sh = ld4(s_c + oz + 3 * FDD + 16 * c + 4 * q);
@@ -577,7 +523,7 @@ __global__ void __launch_bounds__(256, LB_POST) kf_post_small(FPostArgs a, const
   float qe[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) qe[e] = probs[(long)s * E + e] * (F_USE_GATE(a) ? a.gate.p[e][0] : 1.f);
-  for (int idx = threadIdx.x; idx < 2 * (n_end - n_beg); idx += 256) {
+  for (int idx = threadIdx.x; idx < 2 * (n_end - n_beg); idx += NTHR) {
     const long tok = (long)s * t.N + n_beg + (idx >> 1);
     float v[3 * E];
 #pragma unroll
@@ -606,31 +552,34 @@ struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use
 // D16: dApost arrives as T columns (the E x 32 bottleneck entries per group, row stride KPp) + an fp32 side array dApx
 // [token][group][16] with the 3 E scalar columns (the streaming GEMM's split output); otherwise one fp32 array.
 template <typename T, int E, bool D16>
-__global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
+__global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPostBArgs a, const void* __restrict__ Z_, const float* __restrict__ bn1, const float* __restrict__ Gq,
                                                          const float* __restrict__ uvh, const float* __restrict__ probs, const float* __restrict__ rpmup,
                                                          const void* __restrict__ dAp_, void* __restrict__ dzp_, void* __restrict__ Zp_, void* __restrict__ Zw_,
                                                          float* __restrict__ colpart, float* __restrict__ blkscal) {
-  constexpr int DZ = E * FDD;
+  constexpr int DZ = E * FDD, NS = WE<E>::NS, NTHR = WE<E>::NTHR;
   T* Zp = (T*)Zp_; T* Zw = (T*)Zw_; const T* Z = (const T*)Z_; T* dzp = (T*)dzp_;
   const float* dAp = (const float*)dAp_; const T* dAp16 = (const T*)dAp_;
-  __shared__ float s_G[2 * FDG * LD32];
-  __shared__ float s_c[4 * FDD];      // us, vh, sc, sh
-  __shared__ float s_col[4 * FDD];
-  __shared__ float s_sc[4];
+  __shared__ float s_Ge[E][2 * FDG * LD32];
+  __shared__ float s_ce[E][4 * FDD];      // us, vh, sc, sh
+  __shared__ float s_col[WE<E>::NW * FDD];
+  __shared__ float s_sc[WE<E>::NW];
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int e = 0; e < E; ++e) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * FDG * FDG; i += 256) {
-      const int gi = i >> 10, k = (i >> 5) & 31, c = i & 31;
-      s_G[(gi * FDG + c) * LD32 + k] = Gq[(long)(gi * E + e) * FDG * FDG + k * FDG + c];     // transposed (mmT)
+  const int e = wave % E, ts = wave / E;
+  {
+    for (int i = threadIdx.x; i < E * 2 * FDG * FDG; i += NTHR) {
+      const int ee = i >> 11, gi = (i >> 10) & 1, k = (i >> 5) & 31, c = i & 31;
+      s_Ge[ee][(gi * FDG + c) * LD32 + k] = Gq[(long)(gi * E + ee) * FDG * FDG + k * FDG + c];     // transposed (mmT)
     }
-    if (threadIdx.x < FDD) {
-      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_c[dd] = uvh[col]; s_c[FDD + dd] = uvh[DZ + col]; s_c[2 * FDD + dd] = bn1[2 * DZ + col]; s_c[3 * FDD + dd] = bn1[3 * DZ + col];
+    for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+      const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+      float* c_ = s_ce[ee];
+      c_[dd] = uvh[col]; c_[FDD + dd] = uvh[DZ + col]; c_[2 * FDD + dd] = bn1[2 * DZ + col]; c_[3 * FDD + dd] = bn1[3 * DZ + col];
     }
+    const float* s_G = s_Ge[e];
+    const float* s_c = s_ce[e];
     __syncthreads();
     const bool relu = a.relu_of_e[e];
     const float gate = F_USE_GATE(a) ? a.gate.p[e][0] : 1.f;
@@ -663,9 +612,9 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
         nx[6] = rpmup[(long)e * t.NT + tk]; nx[7] = rpmup[(long)t.NT * E + (long)e * t.NT + tk];
       }
     };
-    if constexpr (PFB) prefetch(n_beg + 16 * wave);
+    if constexpr (PFB) prefetch(n_beg + 16 * ts);
     DRAIN_VMEM();
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
@@ -676,7 +625,7 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
         unpack_row(nz, zraw); unpack_row(nd, d);
         da1 = nx[0] + nx[3]; da2 = nx[1] + nx[4]; da3 = nx[2] + nx[5];
         if (ok) { rp = nx[6]; mup = nx[7]; }
-        prefetch(n0 + 64);
+        prefetch(n0 + 16 * NS);
       } else {
         zero_row(zraw);
         if (ok) ld_row<T, E>((saved_zp ? (const T*)a.ZpS : Z) + tok * DZ, e, q, zraw);
@@ -759,10 +708,10 @@ __global__ void __launch_bounds__(256, LB_POSTB) kf_post_small_bwd(FPostBArgs a,
         }
       }
     }
-    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
-    flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
-    const float v0 = block_scalar(wave_sum(sdq), s_sc), v1 = block_scalar(wave_sum(sdSo), s_sc), v2 = block_scalar(wave_sum(sdSoo), s_sc);
-    if (threadIdx.x == 0) { float* o = blkscal + ((long)blk * E + e) * 4; o[0] = v0; o[1] = v1; o[2] = v2; }
+    flush_cols_we<E>(cs0, s_col, colpart, blk, 0, e, ts);
+    flush_cols_we<E>(cs1, s_col, colpart, blk, 1, e, ts);
+    const float v0 = expert_scalar<E>(wave_sum(sdq), s_sc, e), v1 = expert_scalar<E>(wave_sum(sdSo), s_sc, e), v2 = expert_scalar<E>(wave_sum(sdSoo), s_sc, e);
+    if (ts == 0 && lane == 0) { float* o = blkscal + ((long)blk * E + e) * 4; o[0] = v0; o[1] = v1; o[2] = v2; }
   }
 }
 
@@ -773,47 +722,53 @@ struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; long sxr_o
                   const float* ZR; const float* sxr; };      // x + g xr experts (AVVP N x N block, frame attention): xr through Wt, row sums
 
 template <typename T, int E, bool XR>      // XR: the site has x + g xr experts (AVVP N x N block, frame attention)
-__global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
+__global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
                                                     const float* __restrict__ TT, const float* __restrict__ TW, const float* __restrict__ Tsum,
                                                     const float* __restrict__ wsum, const float* __restrict__ dconst, void* __restrict__ aout_,
                                                     float* __restrict__ rmu, float* __restrict__ colpart) {
-  constexpr int DZ = E * FDD;
+  constexpr int DZ = E * FDD, NS = WE<E>::NS, NTHR = WE<E>::NTHR;
   T* aout = (T*)aout_; T* Z = (T*)Z_;
-  __shared__ float s_TT[FK * LD32];
-  __shared__ float s_TWt[FDD * LD32];   // [dd][k]: transposed TW slice (mmT)
-  __shared__ float s_tb[FK];
-  __shared__ float s_c[2 * FDD];      // wsum, dconst
-  __shared__ float s_col[4 * FDD];
+  // dynamic LDS: per cross-modal expert [TT^T (FK x LD32) | TW^T slice (FDD x LD32) | tb (FK)], then per expert [wsum | dconst], then
+  // the column-flush scratch
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  constexpr int LATF = FK * LD32 + FDD * LD32 + FK;
+  float* s_ce = s_dyn + a.t.El * LATF;
+  float* s_col = s_ce + E * 2 * FDD;
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int e = 0; e < E; ++e) {
+  const int e = wave % E, ts = wave / E;
+  for (int ee = 0; ee < E; ++ee) {          // every expert's per-frame constants, by the whole block
+    const int ll = a.lat_of_e[ee];
+    if (ll < 0) continue;
+    float* lt = s_dyn + ll * LATF;
+    const float* tt = TT + ((long)s * t.El + ll) * FK * FK;
+    for (int i = threadIdx.x; i < FK * FK; i += NTHR) lt[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
+    for (int i = threadIdx.x; i < FK * FDD; i += NTHR) {
+      const int k = i >> 6, dd = i & 63;
+      lt[FK * LD32 + dd * LD32 + k] = TW[((long)s * t.KLT + (long)ll * FK + k) * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31)];
+    }
+    if (threadIdx.x < FK) lt[FK * LD32 + FDD * LD32 + threadIdx.x] = Tsum[(long)s * t.KLT + (long)ll * FK + threadIdx.x] / (float)t.C;
+  }
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    s_ce[ee * 2 * FDD + dd] = wsum[col]; s_ce[ee * 2 * FDD + FDD + dd] = dconst[col];
+  }
+  {
     const int l = a.lat_of_e[e];
     const bool nxn = XR && a.nxn_of_e[e] != 0;
-    float gv = 0.f;
-    __syncthreads();
-    if (nxn) gv = a.glat.p[e][0];
-    if (l >= 0) {
-      gv = a.glat.p[e][0];
-      const float* tt = TT + ((long)s * t.El + l) * FK * FK;
-      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
-      for (int i = threadIdx.x; i < FK * FDD; i += 256) {
-        const int k = i >> 6, dd = i & 63;
-        s_TWt[dd * LD32 + k] = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
-      }
-      if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
-    }
-    if (threadIdx.x < FDD) {
-      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_c[dd] = wsum[col]; s_c[FDD + dd] = dconst[col];
-    }
+    const float gv = (nxn || l >= 0) ? a.glat.p[e][0] : 0.f;
+    const float* s_TT = s_dyn + (l >= 0 ? l : 0) * LATF;
+    const float* s_TWt = s_TT + FK * LD32;
+    const float* s_tb = s_TWt + FDD * LD32;
+    const float* s_c = s_ce + e * 2 * FDD;
     __syncthreads();
     float4 cs0[4], cs1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
     DRAIN_VMEM();
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
@@ -906,8 +861,8 @@ __global__ void __launch_bounds__(256, LB_PRE) kf_pre_small(FPreArgs a, void* __
         if (q == 0) { rmu[(long)e * t.NT + tok] = rr; rmu[(long)t.NT * E + (long)e * t.NT + tok] = mu; }
       }
     }
-    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
-    flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
+    flush_cols_we<E>(cs0, s_col, colpart, blk, 0, e, ts);
+    flush_cols_we<E>(cs1, s_col, colpart, blk, 1, e, ts);
   }
 }
 
@@ -926,153 +881,165 @@ struct FPreBArgs { int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; int first_of_slot[M
                    int ln_before, use_bn, bn_train; const float* ZR; const float* sxr; void* dZR; float* dsr; };
 
 template <typename T, int E, bool XR>
-__global__ void __launch_bounds__(256, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ wsum,
+__global__ void __launch_bounds__(WE<E>::NTHR, LB_PREB) kf_pre_small_bwd(FPreBArgs a, const void* __restrict__ Z_, const float* __restrict__ wsum,
                                                         const float* __restrict__ dconst, const float* __restrict__ rmu,
                                                         const float* __restrict__ bn1, const float* __restrict__ dsm, const void* __restrict__ dy_in_,
                                                         void* __restrict__ dZx_, void* __restrict__ dL2x_, float* __restrict__ dslat,
-                                                        float* __restrict__ dsxs, float* __restrict__ rs2x, float* __restrict__ colpart,
-                                                        float* __restrict__ blkscal) {
-  constexpr int DZ = E * FDD;
+                                                        float* __restrict__ rs2x, float* __restrict__ colpart, float* __restrict__ blkscal) {
+  constexpr int DZ = E * FDD, NS = WE<E>::NS, NW = WE<E>::NW, NTHR = WE<E>::NTHR;
   const T* Z = (const T*)Z_; const T* dy_in = (const T*)dy_in_;
   T* dZx = (T*)dZx_; T* dL2x = (T*)dL2x_;
-  __shared__ float s_bn[7 * FDD];       // mean, rstd, sc, mdy, mdyz, wsum, dconst
-  __shared__ float s_col[4 * FDD];
-  __shared__ float s_sc[4];
+  __shared__ float s_bne[E][7 * FDD];       // mean, rstd, sc, mdy, mdyz, wsum, dconst
+  __shared__ float s_col[NW * FDD];
+  __shared__ float s_sc[NW];
+  __shared__ float s_ln[2][NW][16][2];      // (dSx, dSxx) of each wave's expert for the tile's 16 tokens, two tiles deep
   const FastDims& t = a.t;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
   const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int e = 0; e < E; ++e) {
-    const int l = a.lat_of_e[e];
-    const bool nxn = XR && a.nxn_of_e[e] != 0;
-    float gv = 0.f;
-    __syncthreads();
-    if (nxn) gv = a.glat.p[e][0];
-    if (threadIdx.x < FDD) {
-      const int dd = threadIdx.x, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      s_bn[dd] = bn1[col]; s_bn[FDD + dd] = bn1[DZ + col]; s_bn[2 * FDD + dd] = bn1[2 * DZ + col];
-      s_bn[3 * FDD + dd] = F_BN_TRAIN(a) ? dsm[3 * DZ + col] : 0.f; s_bn[4 * FDD + dd] = F_BN_TRAIN(a) ? dsm[4 * DZ + col] : 0.f;
-      s_bn[5 * FDD + dd] = wsum[col]; s_bn[6 * FDD + dd] = dconst[col];
-    }
-    __syncthreads();
-    float sdg = 0.f;
-    float4 cs0[4], cs1[4];
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    float* b = s_bne[ee];
+    b[dd] = bn1[col]; b[FDD + dd] = bn1[DZ + col]; b[2 * FDD + dd] = bn1[2 * DZ + col];
+    b[3 * FDD + dd] = F_BN_TRAIN(a) ? dsm[3 * DZ + col] : 0.f; b[4 * FDD + dd] = F_BN_TRAIN(a) ? dsm[4 * DZ + col] : 0.f;
+    b[5 * FDD + dd] = wsum[col]; b[6 * FDD + dd] = dconst[col];
+  }
+  const float* s_bn = s_bne[e];
+  const int l = a.lat_of_e[e];
+  const bool nxn = XR && a.nxn_of_e[e] != 0;
+  const float gv = nxn ? a.glat.p[e][0] : 0.f;
+  __syncthreads();
+  float sdg = 0.f;
+  float4 cs0[4], cs1[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
-    DRAIN_VMEM();
-    // the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores (a load
-    // behind a store would -- the memory counter being in-order -- wait for the store to be acknowledged)
-    RawRow<T> nz_, ndy_;
-    float nrr = 1.f, nmu = 0.f, nsx = 0.f, nsxx = 0.f;
-    auto request = [&](int n0) {
-      zero_raw(nz_); zero_raw(ndy_); nrr = 1.f; nmu = 0.f; nsx = 0.f; nsxx = 0.f;
-      if (n0 < n_end && n0 + r < t.N) {
-        const long tok = (long)s * t.N + n0 + r;
-        ldraw_row<E>(Z + tok * DZ, e, q, nz_); ldraw_row<E>(dy_in + tok * DZ, e, q, ndy_);
-        if (F_LN_BEFORE(a)) { nrr = rmu[(long)e * t.NT + tok]; nmu = rmu[(long)t.NT * E + (long)e * t.NT + tok]; }
-        if (q == 0 && e != 0) { nsx = dsxs[tok]; nsxx = dsxs[t.NT + tok]; }
-      }
-    };
-    request(n_beg + 16 * wave);
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
-      const int oz = opaque0();
-      const bool ok = n0 + r < t.N;
+  for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+  DRAIN_VMEM();
+  // the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores (a load
+  // behind a store would -- the memory counter being in-order -- wait for the store to be acknowledged)
+  RawRow<T> nz_, ndy_;
+  float nrr = 1.f, nmu = 0.f;
+  auto request = [&](int n0) {
+    zero_raw(nz_); zero_raw(ndy_); nrr = 1.f; nmu = 0.f;
+    if (n0 < n_end && n0 + r < t.N) {
       const long tok = (long)s * t.N + n0 + r;
-      const RawRow<T> zraw_ = nz_, dyraw_ = ndy_;
-      const float rr = nrr, mu = nmu, old_sx = nsx, old_sxx = nsxx;
-      request(n0 + 64);
-      const float irr = 1.f / rr;
-      // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
-      float4 dzr[4], zrow[4], dyrow[4];
-      float s_dr = 0.f, s_dmu = 0.f;
-      unpack_row(zraw_, zrow); unpack_row(dyraw_, dyrow);
+      ldraw_row<E>(Z + tok * DZ, e, q, nz_); ldraw_row<E>(dy_in + tok * DZ, e, q, ndy_);
+      if (F_LN_BEFORE(a)) { nrr = rmu[(long)e * t.NT + tok]; nmu = rmu[(long)t.NT * E + (long)e * t.NT + tok]; }
+    }
+  };
+  request(n_beg + 16 * ts);
+  int par = 0;
+  for (int nb = n_beg; nb < n_end; nb += 16 * NS, par ^= 1) {      // (uniform trip count: one barrier per step)
+    const int n0 = nb + 16 * ts;
+    const int oz = opaque0();
+    const bool ok = n0 < n_end && n0 + r < t.N;
+    const long tok = (long)s * t.N + n0 + r;
+    const RawRow<T> zraw_ = nz_, dyraw_ = ndy_;
+    const float rr = nrr, mu = nmu;
+    request(n0 + 16 * NS);
+    const float irr = 1.f / rr;
+    // ---- BN1 input gradient, folded-LayerNorm sums, dzraw ----
+    float4 dzr[4], zrow[4], dyrow[4];
+    float s_dr = 0.f, s_dmu = 0.f;
+    unpack_row(zraw_, zrow); unpack_row(dyraw_, dyrow);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4& z = zrow[c];
-        const float4& dyv = dyrow[c];
-        const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q);
-        const float4 mdy = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q), mdyz = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
-        const float4 ws = ld4(s_bn + oz + 5 * FDD + 16 * c + 4 * q), dc = ld4(s_bn + oz + 6 * FDD + 16 * c + 4 * q);
+    for (int c = 0; c < 4; ++c) {
+      const float4& z = zrow[c];
+      const float4& dyv = dyrow[c];
+      const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), sc = ld4(s_bn + oz + 2 * FDD + 16 * c + 4 * q);
+      const float4 mdy = ld4(s_bn + oz + 3 * FDD + 16 * c + 4 * q), mdyz = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
+      const float4 ws = ld4(s_bn + oz + 5 * FDD + 16 * c + 4 * q), dc = ld4(s_bn + oz + 6 * FDD + 16 * c + 4 * q);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          float v = 0.f;
-          if (ok) {
-            const float zv = at(z, x);
-            float dz = at(dyv, x);
-            if (F_USE_BN(a)) {
-              if (F_BN_TRAIN(a)) dz = at(sc, x) * (dz - at(mdy, x) - (zv - at(mean, x)) * at(rstd, x) * at(mdyz, x));
-              else dz = at(sc, x) * dz;
-            }
-            if (F_LN_BEFORE(a)) {
-              const float zc = (zv - at(dc, x)) * irr;
-              at(cs0[c], x) += dz; at(cs1[c], x) += -rr * mu * dz;
-              s_dr += dz * zc; s_dmu += dz * at(ws, x);
-              v = rr * dz;
-            } else v = dz;
-          }
-          at(dzr[c], x) = v;
-        }
-      }
-      float szr = 0.f;
-      if (nxn) {                   // x' = x + g xr : d(xr Wt^T) = g dzraw, and dzraw . (xr Wt^T) for the gate
+      for (int x = 0; x < 4; ++x) {
+        float v = 0.f;
         if (ok) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float4 zr4 = ld4(a.ZR + tok * DZ + (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) szr += at(dzr[c], x) * at(zr4, x);
+          const float zv = at(z, x);
+          float dz = at(dyv, x);
+          if (F_USE_BN(a)) {
+            if (F_BN_TRAIN(a)) dz = at(sc, x) * (dz - at(mdy, x) - (zv - at(mean, x)) * at(rstd, x) * at(mdyz, x));
+            else dz = at(sc, x) * dz;
           }
-#pragma unroll
-          for (int gi = 0; gi < 2; ++gi) {
-            float4 g0, g1;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) { at(g0, x) = gv * at(dzr[2 * gi], x); at(g1, x) = gv * at(dzr[2 * gi + 1], x); }
-            st_seg<T>((T*)a.dZR + tok * DZ + gi * (E * FDG) + e * FDG, g0, g1, q);
-          }
+          if (F_LN_BEFORE(a)) {
+            const float zc = (zv - at(dc, x)) * irr;
+            at(cs0[c], x) += dz; at(cs1[c], x) += -rr * mu * dz;
+            s_dr += dz * zc; s_dmu += dz * at(ws, x);
+            v = rr * dz;
+          } else v = dz;
         }
-        szr = qsum4(szr);
+        at(dzr[c], x) = v;
       }
-      float dSx = 0.f, dSxx = 0.f;
-      if (F_LN_BEFORE(a)) {
-        const float sdr = qsum4(s_dr), sdm = qsum4(s_dmu);
-        float dmu = -rr * sdm;
-        const float dvar = sdr * (-0.5f) * rr * rr * rr;
-        dSxx = dvar / (float)t.C;
-        dmu -= 2.f * mu * dvar;
-        dSx = dmu / (float)t.C;
-      }
-      const float accx = dSx + old_sx, accxx = dSxx + old_sxx;
-      if (nxn && ok && q == 0) {   // statistics gradients to (sum xr, sum xr^2, x . xr) of this expert's xr slot, and to the gate
-        float* dsr = a.dsr + a.sxr_off[e];
-        const float* sxr = a.sxr + a.sxr_off[e];
-        const float v0 = gv * dSx, v1 = 2.f * gv * gv * dSxx, v2 = 2.f * gv * dSxx;
-        if (a.first_of_slot[e]) { dsr[tok] = v0; dsr[(long)t.NT + tok] = v1; dsr[2L * t.NT + tok] = v2; }
-        else { dsr[tok] += v0; dsr[(long)t.NT + tok] += v1; dsr[2L * t.NT + tok] += v2; }
-        sdg += dSx * sxr[tok] + dSxx * (2.f * sxr[2L * t.NT + tok] + 2.f * gv * sxr[(long)t.NT + tok]) + szr;
-      }
-      __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
+    }
+    float szr = 0.f;
+    if (nxn) {                   // x' = x + g xr : d(xr Wt^T) = g dzraw, and dzraw . (xr Wt^T) for the gate
       if (ok) {
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
-        if (q == 0) {
-          dsxs[tok] = accx; dsxs[t.NT + tok] = accxx;
-          if (l >= 0) { dslat[(2L * l) * t.NT + tok] = dSx; dslat[(2L * l + 1) * t.NT + tok] = dSxx; }      // this expert's own sums: pre_lat_bwd
+        for (int c = 0; c < 4; ++c) {
+          const float4 zr4 = ld4(a.ZR + tok * DZ + (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) szr += at(dzr[c], x) * at(zr4, x);
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          float4 g0, g1;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { at(g0, x) = gv * at(dzr[2 * gi], x); at(g1, x) = gv * at(dzr[2 * gi + 1], x); }
+          st_seg<T>((T*)a.dZR + tok * DZ + gi * (E * FDG) + e * FDG, g0, g1, q);
         }
       }
-      if (e == E - 1 && ok && q == 0) {
-        stT<T>(dL2x, tok * t.KLp + t.KL, accx);
-        stT<T>(dL2x, tok * t.KLp + t.KL + 1, 1.f);
-        rs2x[tok] = 2.f * accxx;
-      }
+      szr = qsum4(szr);
     }
-    flush_cols<E>(cs0, s_col, colpart, blk, 0, e);
-    flush_cols<E>(cs1, s_col, colpart, blk, 1, e);
-    const float vg = block_scalar(wave_sum(sdg), s_sc);
-    if (threadIdx.x == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;      // (a cross-modal expert's slot is rewritten by pre_lat_bwd)
+    float dSx = 0.f, dSxx = 0.f;
+    if (F_LN_BEFORE(a)) {
+      const float sdr = qsum4(s_dr), sdm = qsum4(s_dmu);
+      float dmu = -rr * sdm;
+      const float dvar = sdr * (-0.5f) * rr * rr * rr;
+      dSxx = dvar / (float)t.C;
+      dmu -= 2.f * mu * dvar;
+      dSx = dmu / (float)t.C;
+    }
+    if (!ok) { dSx = 0.f; dSxx = 0.f; }
+    if (q == 0) { s_ln[par][wave][r][0] = dSx; s_ln[par][wave][r][1] = dSxx; }      // for the sum over the experts below
+    if (nxn && ok && q == 0) {   // the gate's share of the statistics gradients of this expert's xr slot
+      const float* sxr = a.sxr + a.sxr_off[e];
+      sdg += dSx * sxr[tok] + dSxx * (2.f * sxr[2L * t.NT + tok] + 2.f * gv * sxr[(long)t.NT + tok]) + szr;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
+    if (ok) {
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) st_seg<T>(dZx + tok * DZ + gi * (E * FDG) + e * FDG, dzr[2 * gi], dzr[2 * gi + 1], q);
+      if (q == 0 && l >= 0) { dslat[(2L * l) * t.NT + tok] = dSx; dslat[(2L * l + 1) * t.NT + tok] = dSxx; }      // this expert's own sums: pre_lat_bwd
+    }
+    __syncthreads();             // every expert's sums of this step are in s_ln[par]
+    if (XR && nxn && a.first_of_slot[e] && ok && q == 0) {
+      // statistics gradients to (sum xr, sum xr^2, x . xr) of the xr slot: the experts that share it, in expert order
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int ee = 0; ee < E; ++ee)
+        if (a.nxn_of_e[ee] && a.sxr_off[ee] == a.sxr_off[e]) {
+          const float g = a.glat.p[ee][0], dx = s_ln[par][ts * E + ee][r][0], dxx = s_ln[par][ts * E + ee][r][1];
+          v0 += g * dx; v1 += 2.f * g * g * dxx; v2 += 2.f * g * dxx;
+        }
+      float* dsr = a.dsr + a.sxr_off[e];
+      dsr[tok] = v0; dsr[(long)t.NT + tok] = v1; dsr[2L * t.NT + tok] = v2;
+    }
+    if (e == 0 && ok && q == 0) {
+      float accx = 0.f, accxx = 0.f;
+#pragma unroll
+      for (int ee = 0; ee < E; ++ee) { accx += s_ln[par][ts * E + ee][r][0]; accxx += s_ln[par][ts * E + ee][r][1]; }
+      stT<T>(dL2x, tok * t.KLp + t.KL, accx);
+      stT<T>(dL2x, tok * t.KLp + t.KL + 1, 1.f);
+      rs2x[tok] = 2.f * accxx;
+    }
   }
+  flush_cols_we<E>(cs0, s_col, colpart, blk, 0, e, ts);
+  flush_cols_we<E>(cs1, s_col, colpart, blk, 1, e, ts);
+  const float vg = expert_scalar<E>(wave_sum(sdg), s_sc, e);
+  if (ts == 0 && lane == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;      // (a cross-modal expert's slot is rewritten by pre_lat_bwd)
 }
 
-struct FPreLArgs { int lat_of_e[MAX_E]; P16 glat; FastDims t; };
+// The hop-2 block: the block's waves take DIFFERENT cross-modal experts of the same tiles (wave = tile slot * El + latent index);
+// El is a run-time value (1 .. 4 cross-modal experts), the row stride E * 64 a compile-time one.
+struct FPreLArgs { int e_of_lat[MAX_E]; P16 glat; FastDims t; };
 
 template <typename T, int E>
 __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, const float* __restrict__ L2, const float* __restrict__ TT,
@@ -1083,136 +1050,145 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
   constexpr int DZ = E * FDD;
   const T* ain = (const T*)ain_; const T* dZx = (const T*)dZx_;
   T* dL2x = (T*)dL2x_; T* aw_o = (T*)aw_; T* ag_o = (T*)ag_;
-  __shared__ float s_TT[FK * LD32];
-  __shared__ float s_TW[FK * LD64];     // [k][dd]
-  __shared__ float s_TWt[FDD * LD32];   // [dd][k]
-  __shared__ float s_tb[FK];
-  __shared__ float s_col[4 * FDD];
-  __shared__ float s_sc[4];
+  // dynamic LDS: per cross-modal expert [TT^T (FK x LD32) | TW (FK x LD64) | TW^T (FDD x LD32) | tb (FK)], then scratch [4][64] + [4]
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  constexpr int LATF = FK * LD32 + FK * LD64 + FDD * LD32 + FK;
   const FastDims& t = a.t;
+  const int El = t.El, NSL = El >= 3 ? 1 : 4 / El;          // tile slots (El = 3: the fourth wave idles)
+  float* s_col = s_dyn + El * LATF;
+  float* s_sc = s_col + 4 * FDD;
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int n_beg = blockIdx.x * t.per, n_end = KF_NO_TILES ? n_beg : min(t.N, n_beg + t.per);
+  const bool act = wave < El * NSL;
+  const int l = act ? wave % El : 0, ts = act ? wave / El : 0;
+  const int e = a.e_of_lat[l];
+  const int n_beg = blockIdx.x * t.per, n_end = (KF_NO_TILES || !act) ? n_beg : min(t.N, n_beg + t.per);
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-#pragma unroll 1
-  for (int e = 0; e < E; ++e) {
-    const int l = a.lat_of_e[e];
-    if (l < 0) continue;
-    __syncthreads();
-    const float gv = a.glat.p[e][0];
-    {
-      const float* tt = TT + ((long)s * t.El + l) * FK * FK;
-      for (int i = threadIdx.x; i < FK * FK; i += 256) s_TT[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
-      for (int i = threadIdx.x; i < FK * FDD; i += 256) {
-        const int k = i >> 6, dd = i & 63;
-        const float v = TW[((long)s * t.KLT + (long)l * FK + k) * DZ + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)];
-        s_TW[k * LD64 + dd] = v;
-        s_TWt[dd * LD32 + k] = v;
-      }
-      if (threadIdx.x < FK) s_tb[threadIdx.x] = Tsum[(long)s * t.KLT + (long)l * FK + threadIdx.x] / (float)t.C;
+  for (int ll = 0; ll < El; ++ll) {
+    const int ee = a.e_of_lat[ll];
+    float* lt = s_dyn + ll * LATF;
+    const float* tt = TT + ((long)s * t.El + ll) * FK * FK;
+    for (int i = threadIdx.x; i < FK * FK; i += 256) lt[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
+    for (int i = threadIdx.x; i < FK * FDD; i += 256) {
+      const int k = i >> 6, dd = i & 63;
+      const float v = TW[((long)s * t.KLT + (long)ll * FK + k) * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31)];
+      lt[FK * LD32 + k * LD64 + dd] = v;
+      lt[FK * LD32 + FK * LD64 + dd * LD32 + k] = v;
     }
-    __syncthreads();
-    float sdg = 0.f;
-    float4 ck[2];
-    ck[0] = zero4(); ck[1] = zero4();
-    DRAIN_VMEM();
-    // the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores: load
-    // latency and the acknowledgement of the previous tile's stores pass under the mat-vecs instead of in front of them
-    RawRow<T> ndraw_;
-    RawSeg<T> naraw_;
-    float4 nlg[2];
-    float ndSx = 0.f, ndSxx = 0.f;
-    auto request = [&](int n0) {
-      zero_raw(ndraw_); zero_raw(naraw_); nlg[0] = zero4(); nlg[1] = zero4(); ndSx = 0.f; ndSxx = 0.f;
-      if (n0 < n_end && n0 + r < t.N) {
-        const long tok = (long)s * t.N + n0 + r;
-        ldraw_row<E>(dZx + tok * DZ, e, q, ndraw_);
-        ldraw_seg(ain + tok * t.KLp + (long)l * FK, q, naraw_);
-        const long lo = tok * t.KLp + (long)l * FK + 4 * q;
-        nlg[0] = ld4(L2 + lo); nlg[1] = ld4(L2 + lo + 16);
-        ndSx = dslat[(2L * l) * t.NT + tok]; ndSxx = dslat[(2L * l + 1) * t.NT + tok];
-      }
-    };
-    request(n_beg + 16 * wave);
-    for (int n0 = n_beg + 16 * wave; n0 < n_end; n0 += 64) {
-      const int oz = opaque0();
-      const bool ok = n0 + r < t.N;
+    if (threadIdx.x < FK) lt[FK * LD32 + FK * LD64 + FDD * LD32 + threadIdx.x] = Tsum[(long)s * t.KLT + (long)ll * FK + threadIdx.x] / (float)t.C;
+  }
+  const float* s_TT = s_dyn + l * LATF;
+  const float* s_TW = s_TT + FK * LD32;       // [k][dd]
+  const float* s_TWt = s_TW + FK * LD64;      // [dd][k]
+  const float* s_tb = s_TWt + FDD * LD32;
+  const float gv = a.glat.p[e][0];
+  __syncthreads();
+  float sdg = 0.f;
+  float4 ck[2];
+  ck[0] = zero4(); ck[1] = zero4();
+  DRAIN_VMEM();
+  // the rows of the NEXT tile are requested (raw) before the current tile is computed and waited for before its stores: load
+  // latency and the acknowledgement of the previous tile's stores pass under the mat-vecs instead of in front of them
+  RawRow<T> ndraw_;
+  RawSeg<T> naraw_;
+  float4 nlg[2];
+  float ndSx = 0.f, ndSxx = 0.f;
+  auto request = [&](int n0) {
+    zero_raw(ndraw_); zero_raw(naraw_); nlg[0] = zero4(); nlg[1] = zero4(); ndSx = 0.f; ndSxx = 0.f;
+    if (n0 < n_end && n0 + r < t.N) {
       const long tok = (long)s * t.N + n0 + r;
-      const RawRow<T> draw_ = ndraw_;
-      const RawSeg<T> araw_ = naraw_;
-      float4 dzr[4], av[2], lg[2];
-      lg[0] = nlg[0]; lg[1] = nlg[1];
-      const float dSx = ndSx, dSxx = ndSxx;
-      request(n0 + 64);
-      unpack_row(draw_, dzr);
-      unpack_rawseg(araw_, av[0], av[1]);
-      float u1 = 0.f, u2 = 0.f;
-      float4 tb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        tb[j] = ld4(s_tb + oz + 16 * j + 4 * q);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { u1 += at(av[j], x) * at(tb[j], x); u2 += at(av[j], x) * at(lg[j], x); }
-      }
-      u1 = qsum4(u1); u2 = qsum4(u2);
-      float dgr = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
-        const f32x4 p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
-      }
-      dgr = qsum4(dgr);
-      const float du1 = dSx * gv * (float)t.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
-      float u3 = 0.f, sada = 0.f;
-      float4 da[2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
-        const f32x4 twd = mmT<4>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const float ac = at(av[ct], x);
-          u3 += ta[x] * ac;
-          float d = 0.f;
-          if (ok) {
-            d = gv * twd[x] + du1 * at(tb[ct], x) + du2 * at(lg[ct], x) + 2.f * du3 * ta[x];
-            sada += ac * d;
-            at(ck[ct], x) += du1 * ac;
-          }
-          at(da[ct], x) = d;
-        }
-      }
-      u3 = qsum4(u3); sada = qsum4(sada);
-      if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
-      __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
-      if (ok) {
-        float4 v0[2], v1[2], v2[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const float ac = at(av[j], x);
-            at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
-          }
-        const long so = tok * t.KLp + (long)l * FK;
-        st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
-      }
+      ldraw_row<E>(dZx + tok * DZ, e, q, ndraw_);
+      ldraw_seg(ain + tok * t.KLp + (long)l * FK, q, naraw_);
+      const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+      nlg[0] = ld4(L2 + lo); nlg[1] = ld4(L2 + lo + 16);
+      ndSx = dslat[(2L * l) * t.NT + tok]; ndSxx = dslat[(2L * l + 1) * t.NT + tok];
     }
-    const float vg = block_scalar(wave_sum(sdg), s_sc);
-    if (threadIdx.x == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;
+  };
+  request(n_beg + 16 * ts);
+  for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NSL) {
+    const int oz = opaque0();
+    const bool ok = n0 + r < t.N;
+    const long tok = (long)s * t.N + n0 + r;
+    const RawRow<T> draw_ = ndraw_;
+    const RawSeg<T> araw_ = naraw_;
+    float4 dzr[4], av[2], lg[2];
+    lg[0] = nlg[0]; lg[1] = nlg[1];
+    const float dSx = ndSx, dSxx = ndSxx;
+    request(n0 + 16 * NSL);
+    unpack_row(draw_, dzr);
+    unpack_rawseg(araw_, av[0], av[1]);
+    float u1 = 0.f, u2 = 0.f;
+    float4 tb[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      tb[j] = ld4(s_tb + oz + 16 * j + 4 * q);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { u1 += at(av[j], x) * at(tb[j], x); u2 += at(av[j], x) * at(lg[j], x); }
+    }
+    u1 = qsum4(u1); u2 = qsum4(u2);
+    float dgr = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
+      const f32x4 p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
+    }
+    dgr = qsum4(dgr);
+    const float du1 = dSx * gv * (float)t.C, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
+    float u3 = 0.f, sada = 0.f;
+    float4 da[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
+      const f32x4 twd = mmT<4>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        const float v = rsum16(at(ck[j], x));
-        if (r == 0) s_col[wave * FDD + 16 * j + 4 * q + x] = v;
+        const float ac = at(av[ct], x);
+        u3 += ta[x] * ac;
+        float d = 0.f;
+        if (ok) {
+          d = gv * twd[x] + du1 * at(tb[ct], x) + du2 * at(lg[ct], x) + 2.f * du3 * ta[x];
+          sada += ac * d;
+          at(ck[ct], x) += du1 * ac;
+        }
+        at(da[ct], x) = d;
       }
-    __syncthreads();
-    if (threadIdx.x < FK) {
-      const int k = threadIdx.x;
-      dtbp[(long)blk * t.KL + (long)l * FK + k] = s_col[k] + s_col[FDD + k] + s_col[2 * FDD + k] + s_col[3 * FDD + k];
     }
-    __syncthreads();
+    u3 = qsum4(u3); sada = qsum4(sada);
+    if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
+    if (ok) {
+      float4 v0[2], v1[2], v2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float ac = at(av[j], x);
+          at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
+        }
+      const long so = tok * t.KLp + (long)l * FK;
+      st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
+    }
+  }
+  // per cross-modal expert: the gate partial and the column sums of du1 * a, folded over the expert's tile slots
+  const float ws = wave_sum(sdg);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float v = rsum16(at(ck[j], x));
+      if (r == 0) s_col[wave * FDD + 16 * j + 4 * q + x] = v;
+    }
+  if (lane == 0) s_sc[wave] = ws;
+  __syncthreads();
+  if (act && ts == 0) {
+    float vg = 0.f;
+    for (int u = 0; u < NSL; ++u) vg += s_sc[u * El + l];
+    if (lane == 0) blkscal[((long)blk * E + e) * 4 + 3] = vg;
+    if (lane < FK) {
+      float v = 0.f;
+      for (int u = 0; u < NSL; ++u) v += s_col[(u * El + l) * FDD + lane];
+      dtbp[(long)blk * t.KL + (long)l * FK + lane] = v;
+    }
   }
 }
 
@@ -1235,34 +1211,57 @@ bool tile_fast_shape(const Dims& d) {
 }
 bool tile_fast_ok(const Dims& d) { return tile_fast_shape(d) && !d.gen; }      // (d.gen at this shape: the development A/B against tile_gen.inc)
 
-#define LAUNCH_TE1(bf16, KERN, NE, ...)                                                                \
+// (kernels still in the expert-outer form run 256 threads whatever E is: LAUNCH_TEX*)
+#define NTHR_OF(NE) (WE<NE>::NTHR)
+// dynamic LDS above the default limit needs the attribute once per kernel function
+static int fast_lds(const void* fn, size_t bytes, const char* what) {
+  if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_last_error("%s: %zu bytes of dynamic LDS refused", what, bytes); return ERR_UNSUPPORTED;
+  }
+  return OK;
+}
+#define LAUNCH_K(FN, NTH, SH, ...)                                                                     \
   do {                                                                                                 \
-    if (bf16) hipLaunchKernelGGL((KERN<__bf16, NE>), grid, dim3(256), 0, st, __VA_ARGS__);             \
-    else hipLaunchKernelGGL((KERN<float, NE>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+    AVMOE_TRY(fast_lds((const void*)(FN), (SH), #FN));                                                 \
+    hipLaunchKernelGGL((FN), grid, dim3(NTH), (SH), st, __VA_ARGS__);                                  \
+  } while (0)
+#define LAUNCH_TE1(bf16, KERN, NE, NTH, SH, ...)                                                       \
+  do {                                                                                                 \
+    if (bf16) LAUNCH_K((KERN<__bf16, NE>), NTH, SH, __VA_ARGS__);                                      \
+    else LAUNCH_K((KERN<float, NE>), NTH, SH, __VA_ARGS__);                                            \
   } while (0)
 // 4 experts: the cfg-2 configuration; 2 (1 + 1): what the reference's AVE / AVVP launchers ship (AVE/train.sh:7-8); 3: 1 + 2 / 2 + 1
-#define LAUNCH_TE(bf16, KERN, ...)                                                                     \
+// (wave-per-expert blocks: 256 / 256 / 192 threads)
+#define LAUNCH_TE(bf16, KERN, SH, ...)                                                                 \
   do {                                                                                                 \
-    if (d.E == 4) LAUNCH_TE1(bf16, KERN, 4, __VA_ARGS__);                                              \
-    else if (d.E == 2) LAUNCH_TE1(bf16, KERN, 2, __VA_ARGS__);                                         \
-    else LAUNCH_TE1(bf16, KERN, 3, __VA_ARGS__);                                                       \
+    if (d.E == 4) LAUNCH_TE1(bf16, KERN, 4, NTHR_OF(4), SH, __VA_ARGS__);                              \
+    else if (d.E == 2) LAUNCH_TE1(bf16, KERN, 2, NTHR_OF(2), SH, __VA_ARGS__);                         \
+    else LAUNCH_TE1(bf16, KERN, 3, NTHR_OF(3), SH, __VA_ARGS__);                                       \
+  } while (0)
+// the same kernels launched with 256 threads whatever E is (pre_lat_bwd: its waves map to the cross-modal experts)
+#define LAUNCH_TE256(bf16, KERN, SH, ...)                                                              \
+  do {                                                                                                 \
+    if (d.E == 4) LAUNCH_TE1(bf16, KERN, 4, 256, SH, __VA_ARGS__);                                     \
+    else if (d.E == 2) LAUNCH_TE1(bf16, KERN, 2, 256, SH, __VA_ARGS__);                                \
+    else LAUNCH_TE1(bf16, KERN, 3, 256, SH, __VA_ARGS__);                                              \
   } while (0)
 
-#define LAUNCH_TEX1(bf16, KERN, NE, XR_, ...)                                                          \
+#define LAUNCH_TEX1(bf16, KERN, NE, XR_, SH, ...)                                                      \
   do {                                                                                                 \
-    if (bf16) hipLaunchKernelGGL((KERN<__bf16, NE, XR_>), grid, dim3(256), 0, st, __VA_ARGS__);        \
-    else hipLaunchKernelGGL((KERN<float, NE, XR_>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+    if (bf16) LAUNCH_K((KERN<__bf16, NE, XR_>), NTHR_OF(NE), SH, __VA_ARGS__);                         \
+    else LAUNCH_K((KERN<float, NE, XR_>), NTHR_OF(NE), SH, __VA_ARGS__);                               \
   } while (0)
-#define LAUNCH_TEX2(bf16, KERN, XR_, ...)                                                              \
+#define LAUNCH_TEX2(bf16, KERN, XR_, SH, ...)                                                          \
   do {                                                                                                 \
-    if (d.E == 4) LAUNCH_TEX1(bf16, KERN, 4, XR_, __VA_ARGS__);                                        \
-    else if (d.E == 2) LAUNCH_TEX1(bf16, KERN, 2, XR_, __VA_ARGS__);                                   \
-    else LAUNCH_TEX1(bf16, KERN, 3, XR_, __VA_ARGS__);                                                 \
+    if (d.E == 4) LAUNCH_TEX1(bf16, KERN, 4, XR_, SH, __VA_ARGS__);                                    \
+    else if (d.E == 2) LAUNCH_TEX1(bf16, KERN, 2, XR_, SH, __VA_ARGS__);                               \
+    else LAUNCH_TEX1(bf16, KERN, 3, XR_, SH, __VA_ARGS__);                                             \
   } while (0)
-#define LAUNCH_TEX(bf16, KERN, ...)                                                                    \
+#define LAUNCH_TEX(bf16, KERN, SH, ...)                                                                \
   do {                                                                                                 \
-    if (d.nxn) LAUNCH_TEX2(bf16, KERN, true, __VA_ARGS__);                                             \
-    else LAUNCH_TEX2(bf16, KERN, false, __VA_ARGS__);                                                  \
+    if (d.nxn) LAUNCH_TEX2(bf16, KERN, true, SH, __VA_ARGS__);                                         \
+    else LAUNCH_TEX2(bf16, KERN, false, SH, __VA_ARGS__);                                              \
   } while (0)
 
 int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
@@ -1275,7 +1274,8 @@ int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   }
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
-  LAUNCH_TEX(d.bf16, kf_pre_small, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
+  const size_t sh = ((size_t)d.El * (FK * LD32 + FDD * LD32 + FK) + (size_t)d.E * 2 * FDD + 4 * FDD) * sizeof(float);
+  LAUNCH_TEX(d.bf16, kf_pre_small, sh, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
             (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
             (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (void*)(saved + pl.o_a), (float*)(saved + pl.o_rmu),
             (float*)(scratch + pl.o_colpart));
@@ -1289,7 +1289,7 @@ int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidFArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per);
-  LAUNCH_TE(d.bf16, kf_mid, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
+  LAUNCH_TE(d.bf16, kf_mid, 0, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (void*)(scratch + pl.o_Zp),
             (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("mid (64/32)");
   return OK;
@@ -1301,7 +1301,7 @@ int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_pt
   FPostArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
-  LAUNCH_TE(d.bf16, kf_post_small, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
+  LAUNCH_TE(d.bf16, kf_post_small, 0, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
   AVMOE_CHECK_LAUNCH("post_small (64/32)");
   return OK;
@@ -1321,8 +1321,8 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),                     \
             (const void*)(scratch + pl.o_dAp), (void*)(scratch + pl.o_dzp), (void*)(scratch + pl.o_Zp), (void*)(scratch + pl.o_Zw),       \
             (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal)
-  if (dap16) LAUNCH_TEX2(true, kf_post_small_bwd, true, POSTB_ARGS);
-  else LAUNCH_TEX2(d.bf16, kf_post_small_bwd, false, POSTB_ARGS);
+  if (dap16) LAUNCH_TEX2(true, kf_post_small_bwd, true, 0, POSTB_ARGS);
+  else LAUNCH_TEX2(d.bf16, kf_post_small_bwd, false, 0, POSTB_ARGS);
 #undef POSTB_ARGS
   AVMOE_CHECK_LAUNCH("post_small_bwd (64/32)");
   return OK;
@@ -1334,12 +1334,7 @@ int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
   FMidArgs a;
   for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
   a.t = make_fd(d, per); a.moments = d.use_bn && d.training;
-#if KF_WAVE_EXPERT
-  if (d.E == 4) { LAUNCH_TE1(d.bf16, kf_mid_bwd_we, 4, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
-            (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (void*)(scratch + pl.o_dzp),
-            (float*)(scratch + pl.o_colpart)); } else
-#endif
-  LAUNCH_TE(d.bf16, kf_mid_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
+  LAUNCH_TE(d.bf16, kf_mid_bwd, 0, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1),
             (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (void*)(scratch + pl.o_dzp),
             (float*)(scratch + pl.o_colpart));
   AVMOE_CHECK_LAUNCH("mid_bwd (64/32)");
@@ -1365,12 +1360,11 @@ int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
   a.dZR = (void*)(scratch + pl.o_dZR); a.dsr = (float*)(scratch + pl.o_dsr);
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
-  LAUNCH_TEX(d.bf16, kf_pre_small_bwd, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_wsum),
+  LAUNCH_TEX(d.bf16, kf_pre_small_bwd, 0, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_wsum),
             (const float*)(saved + pl.o_dconst), (const float*)(saved + pl.o_rmu),
             (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const void*)(scratch + pl.o_dzp),
             (void*)(scratch + pl.o_Zw), (void*)(scratch + pl.o_dL2x), (float*)(scratch + pl.o_dslat),
-            (float*)(scratch + pl.o_dsxs), (float*)(scratch + pl.o_rs2x), (float*)(scratch + pl.o_colpart),
-            (float*)(scratch + pl.o_blkscal));
+            (float*)(scratch + pl.o_rs2x), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
   AVMOE_CHECK_LAUNCH("pre_small_bwd (64/32)");
   return OK;
 }
@@ -1382,9 +1376,11 @@ int kf_pre_lat_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_p
   if (d.KL == 0) return OK;
   dim3 grid; int per; fast_grid(d, &grid, &per);
   FPreLArgs a;
-  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = e < d.E ? d.lat_of_e[e] : -1; }
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.e_of_lat[e] = 0; }
+  for (int e = 0; e < d.E; ++e) if (d.lat_of_e[e] >= 0) a.e_of_lat[d.lat_of_e[e]] = e;
   a.t = make_fd(d, per);
-  LAUNCH_TE(d.bf16, kf_pre_lat_bwd, a, (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW),
+  const size_t sh = ((size_t)d.El * (FK * LD32 + FK * LD64 + FDD * LD32 + FK) + 4 * FDD + 4) * sizeof(float);
+  LAUNCH_TE256(d.bf16, kf_pre_lat_bwd, sh, a, (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW),
             (const float*)(saved + pl.o_Tsum), (const void*)(saved + pl.o_a), (const void*)(scratch + pl.o_Zw),
             (const float*)(scratch + pl.o_dslat), (void*)(scratch + pl.o_dL2x), (void*)(scratch + pl.o_aw), (void*)(scratch + pl.o_ag),
             (float*)(scratch + pl.o_blkscal), (float*)(scratch + pl.o_dtbp));
