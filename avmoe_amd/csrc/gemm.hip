@@ -964,7 +964,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     while (lgP < 4 && (2 << lgP) <= d.ksplit && (nvec << lgP) < 131072) ++lgP;
     const long nwv = (nvec + (64 >> lgP) - 1) / (64 >> lgP);
     const int blocks = (int)std::min<long>((nwv + 3) / 4, 4096);
-    ProfScope ps("gemm_splitk_reduce", (double)total * 4.0 * (d.ksplit + 1), 0.0, stream);
+    ProfScope ps("gemm_splitk_reduce", total, (double)total * 4.0 * (d.ksplit + 1), 0.0, stream);      // (tagged with the result's element count)
     if (a.dtype == GEMM_BF16) hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3(blocks), dim3(256), 0, stream, d, lgP);
     else hipLaunchKernelGGL(gemm_splitk_reduce<float>, dim3(blocks), dim3(256), 0, stream, d, lgP);
     AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
@@ -1030,7 +1030,7 @@ int launch_gemm_tokpair(const TokPairArgs& a, hipStream_t stream) {
   int lgP = 0;
   while (lgP < 4 && (2 << lgP) <= nchunks && (nvec << lgP) < 131072) ++lgP;
   const long nwv = (nvec + (64 >> lgP) - 1) / (64 >> lgP);
-  ProfScope ps("gemm_splitk_reduce", (double)total * 4.0 * (nchunks + 1), 0.0, stream);
+  ProfScope ps("gemm_splitk_reduce", total, (double)total * 4.0 * (nchunks + 1), 0.0, stream);
   hipLaunchKernelGGL(gemm_splitk_reduce<__bf16>, dim3((int)std::min<long>((nwv + 3) / 4, 4096)), dim3(256), 0, stream, d, lgP);
   AVMOE_CHECK_LAUNCH("gemm_splitk_reduce");
   return OK;

@@ -159,7 +159,8 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.Mb = (int)round_up(d.M + 1, 8);
   d.Np = (int)round_up(d.N, 8);
   // per-token kernels: blocks per sample so that the grid has a few waves per SIMD
-  int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, 256), cdiv(256, d.S))));     // (A/B on the concurrent cfg-2 step)
+  // (A/B at cfg-2 with the wave-per-expert kernels: 256 tokens per block at N = 1024, two blocks for the 196 tokens of the visual side)
+  int bps = std::max(1, std::min(cdiv(d.N, 64), std::max(cdiv(d.N, d.N >= 512 ? 256 : 112), cdiv(256, d.S))));
   if (const char* ev = dev_env("AVMOE_BPS")) {     // development: "<bps for N >= 512>,<bps for N < 512>"
     int a = 0, b = 0;
     if (sscanf(ev, "%d,%d", &a, &b) == 2) bps = std::max(1, d.N >= 512 ? a : b);

@@ -191,8 +191,14 @@ template <int E> __device__ __forceinline__ int zcol(int c, int e, int q) { retu
 // W[tok r][col0 + 4 q + x] = sum over NJ chunks of  P[r][16 j + 4 q' + x'] * M[16 j + 4 q' + x'][col0 + ...]
 // Mt: the matrix TRANSPOSED in LDS, Mt[n][k] (leading dim ld, a multiple of 4): the A operands of the four MFMA steps x' = 0..3
 // of a chunk are then one 16-byte read  Mt[col0 + r][16 j + 4 q .. + 3].   p[j]: this lane's chunk registers.
+#ifndef KF_NO_MFMA
+#define KF_NO_MFMA 0           // development builds (timing only): 1 = the mat-vecs skip the matrix pipe and the LDS reads
+#endif
 template <int NJ>
 __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
+#if KF_NO_MFMA
+  return f32x4{p[0].x, p[0].y, p[0].z, p[0].w};
+#endif
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* mp = Mt + (col0 + r) * ld + 4 * q;
 #pragma unroll

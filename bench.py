@@ -19,7 +19,7 @@ positions p1 and p2; clip-pairs/s = clips through ALL of them per second).
 The JSON line also carries
   roofline      PATH level: algorithmic bytes per clip-pair x clip-pairs/s vs the 8 TB/s HBM peak (`frac`), the
                 reference-formulation FLOPs vs the dense MFMA peak beside it (`mfma`), and the dominant kernel family of a
-                HIP-event profiling pass over the same step in the same execution mode as the timed region (`dominant_kernel`)
+                HIP-event profiling pass over the same step with every launch alone on the GPU (`dominant_kernel`)
   parity        max errors of this very build against oracle/avmoe_oracle.py at the benchmarked shapes with B = 2 clips, run the
                 way the timed region runs it (AdapterPair in the same --pair mode): fp32 outputs / gradients / router indices,
                 bf16 the same against the oracle on bf16-rounded inputs.  Gradients are compared KINK-AWARE: the oracle is
@@ -393,6 +393,16 @@ class Workload:
         params = [p for m in sites for p in m.parameters()]
         self.reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=sites)
 
+    def set_concurrent(self, on):
+        """two-stream / one-stream execution of every AdapterPair of the workload; returns the previous setting"""
+        prev = False
+        for w in self.work:
+            for _a, _v, pr in w["mods"]:
+                if pr is not None:
+                    prev = prev or pr.concurrent
+                    pr.concurrent = bool(on) and pr.site_a._self_attn() != "v2" and pr.site_b._self_attn() != "v2"
+        return prev
+
     def step(self, sync=True):
         import torch
         c, reducer = self.c, self.reducer
@@ -563,10 +573,14 @@ def main():
     if not args.no_roofline:
         roofline = path_roofline(c, esz, dtype, value, world)
         if rank == 0:
-            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape), same pair mode as the timed
-            # region (the helper streams INSIDE a site are off while launches are timed: side.cpp).  Rank 0 only: its steps must not
-            # enter a collective (sync=False = an accumulation micro-step).
+            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape).  The two sites of a pair run
+            # back to back on ONE stream here whatever the timed region does (and the helper streams INSIDE a site are off: side.cpp):
+            # an event bracket on a stream that shares the GPU with another stream also measures the time a launch WAITS for
+            # compute units behind the other stream's kernels (a 10 us split-K reduction reads 100 us), which is neither the kernel's
+            # duration nor what rocprofv3 reports for it.  Rank 0 only: its steps must not enter a collective (sync=False = an
+            # accumulation micro-step).
             L = capi.lib()
+            flipped = wl.set_concurrent(False)
             for _ in range(2):
                 wl.step(sync=False)
             torch.cuda.synchronize()
@@ -577,6 +591,7 @@ def main():
                 wl.step(sync=False)
             torch.cuda.synchronize()
             L.avmoe_prof_enable(0)
+            wl.set_concurrent(flipped)
             rep = capi.prof_report()
             L.avmoe_prof_reset()
             if os.environ.get("AVMOE_FAMILIES_OUT"):      # dev: every family of the profiling pass
@@ -590,9 +605,9 @@ def main():
             dk = dict(kernel=dom["name"], bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                       traffic=None, launches_per_step=dom["calls"] // nprof, avg_launch_us=round(avg_ms * 1e3, 2),
                       share_of_gpu_time=round(dom["total_ms"] / tot_ms, 3), kernel_tflops=round(tfs, 1),
-                      measured=f"HIP events on the launch stream, --pair {pair_mode} (the mode of the timed region"
-                               + ("; the two sites' kernels overlap, which stretches each launch" if pair_mode == "concurrent" else "")
-                               + "; the helper streams inside a site are off while launches are timed)")
+                      measured="HIP events on the launch stream, every launch alone on the GPU (profiling pass of 3 steps after the timed "
+                               "region: the two sites of a pair back to back on one stream, helper streams off); the largest (kernel, launch "
+                               "shape) family by time per step")
             tj = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic.json")
             if os.path.isfile(tj) and args.config == "cfg2" and not args.batch and dtype == "bf16":
                 with open(tj) as fh:       # HBM bytes from THIS round's rocprofv3 --pmc passes (scripts/make_profiles.sh)
