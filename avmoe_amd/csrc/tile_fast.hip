@@ -620,7 +620,8 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPost
     };
     if constexpr (PFB) prefetch(n_beg + 16 * ts);
     DRAIN_VMEM();
-    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS) {
+    int qsel = 0;      // the lane (of the four that hold a token) that takes this tile's scalar terms: four times as many partial sums
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, qsel = (qsel + 1) & 3) {
       const int oz = opaque0();
       const bool ok = n0 + r < t.N;
       const long tok = (long)s * t.N + n0 + r;
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPost
           dmup -= 2.f * mup * dvarp;
           dSo = dmup / (float)t.C;
         }
-        if (q == 0) { sdq += dq; sdSo += dSo; sdSoo += dSoo; }
+        if (q == qsel) { sdq += dq; sdSo += dSo; sdSoo += dSoo; }
       }
       const float k1 = qv * rp;
 #pragma unroll
@@ -935,7 +936,8 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PREB) kf_pre_small_bwd(FPreBAr
   };
   request(n_beg + 16 * ts);
   int par = 0;
-  for (int nb = n_beg; nb < n_end; nb += 16 * NS, par ^= 1) {      // (uniform trip count: one barrier per step)
+  int qsel = 0;      // the lane (of the four that hold a token) that takes this tile's scalar terms: four times as many partial sums
+  for (int nb = n_beg; nb < n_end; nb += 16 * NS, par ^= 1, qsel = (qsel + 1) & 3) {      // (uniform trip count: one barrier per step)
     const int n0 = nb + 16 * ts;
     const int oz = opaque0();
     const bool ok = n0 < n_end && n0 + r < t.N;
@@ -1005,7 +1007,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PREB) kf_pre_small_bwd(FPreBAr
     }
     if (!ok) { dSx = 0.f; dSxx = 0.f; }
     if (q == 0) { s_ln[par][wave][r][0] = dSx; s_ln[par][wave][r][1] = dSxx; }      // for the sum over the experts below
-    if (nxn && ok && q == 0) {   // the gate's share of the statistics gradients of this expert's xr slot
+    if (nxn && ok && q == qsel) {   // the gate's share of the statistics gradients of this expert's xr slot
       const float* sxr = a.sxr + a.sxr_off[e];
       sdg += dSx * sxr[tok] + dSxx * (2.f * sxr[2L * t.NT + tok] + 2.f * gv * sxr[(long)t.NT + tok]) + szr;
     }
@@ -1110,7 +1112,8 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
     }
   };
   request(n_beg + 16 * ts);
-  for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NSL) {
+  int qsel = 0;      // the lane (of the four that hold a token) that takes this tile's scalar terms: four times as many partial sums
+  for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NSL, qsel = (qsel + 1) & 3) {
     const int oz = opaque0();
     const bool ok = n0 + r < t.N;
     const long tok = (long)s * t.N + n0 + r;
@@ -1160,7 +1163,7 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
       }
     }
     u3 = qsum4(u3); sada = qsum4(sada);
-    if (ok && q == 0) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
+    if (ok && q == qsel) sdg += dSx * (float)t.C * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
     __builtin_amdgcn_s_waitcnt(0x0F70);          // the prefetched rows, before this tile's stores are issued
     if (ok) {
       float4 v0[2], v1[2], v2[2];
