@@ -788,6 +788,9 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   return OK;
 }
 
+#ifndef GEMM_BIG_MIN
+#define GEMM_BIG_MIN 768       // smallest extent (both M and N) that takes the 256 x 256 tile
+#endif
 template <bool AMN, bool BMN>
 static int launch_big_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   constexpr int A_BYTES = AMN ? 64 * (256 * 2 + 16) : 256 * (128 + 16), B_BYTES = BMN ? 64 * (256 * 2 + 16) : 256 * (128 + 16);
@@ -910,7 +913,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
                                                                                   // folding full tiles of the same size gains nothing)
       // ... or the samples' blocks are too short for the 256 x 256 tile while the tall product is not (cfg-5: 384 latent rows per frame
       // against the 4096 x 3138 remap matrix, 40 frames)
-      const bool for_big = a.dtype == GEMM_BF16 && a.tile == 0 && a.M < 1024 && rows >= 2048 && a.N >= 1024 && a.K >= 256;
+      const bool for_big = a.dtype == GEMM_BF16 && a.tile == 0 && a.M < 1024 && rows >= 2048 && a.N >= GEMM_BIG_MIN && a.K >= 256;
       if ((wasteful || for_big) && rps >= a.M && (rps - a.M) * 8 <= a.M && rows < (1L << 30)) {
         d.fold_rps = (int)rps; d.fold_valid = a.M; d.M = (int)rows; d.nbatch = 1; d.sA1 = 0;
       }
@@ -932,7 +935,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
   int st;
   // the 256 x 256 tile for large plain bf16 products (enough tiles of it to fill the chip)
-  const bool big = a.dtype == GEMM_BF16 && a.tile == 0 && tile == 128 && a.epi == GEMM_EPI_NONE && !a.A2 && !a.D && d.M >= 1024 && a.N >= 1024 &&
+  const bool big = a.dtype == GEMM_BF16 && a.tile == 0 && tile == 128 && a.epi == GEMM_EPI_NONE && !a.A2 && !a.D && d.M >= GEMM_BIG_MIN && a.N >= GEMM_BIG_MIN &&
                    a.K >= 256 && (long)cdiv(d.M, 256) * cdiv(a.N, 256) * bz >= 160;
   if (big) {
     d.tiles_n = cdiv(a.N, 256);

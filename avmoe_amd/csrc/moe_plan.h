@@ -12,7 +12,7 @@
 namespace avmoe {
 
 constexpr int MAX_E = AVMOE_MAX_EXPERTS;
-constexpr int GRAM_BLOCKS = 256;   // blocks (= partial sums) of the streaming Gram kernel
+constexpr int GRAM_BLOCKS = 512;   // blocks (= partial sums) of the streaming Gram kernel
 
 struct Dims {
   // raw
