@@ -25,7 +25,7 @@ The JSON line also carries
                 bf16 the same against the oracle on bf16-rounded inputs.  Gradients are compared KINK-AWARE: the oracle is
                 re-run with the ReLU mask the HIP path actually used (avmoe_amd.debug.relu_masks), so units whose
                 pre-activation lies within rounding of zero sit on the same side in both; the plain comparison is reported too
-  other_configs (N = 1) 3 timed steps each of cfg-1 (the reference's own operating point: B = 2, fp32, 24 site pairs), cfg-4 and cfg-5
+  other_configs (N = 1) 3 timed steps each of cfg-1 (the reference's own operating point: B = 2, fp32, 24 site pairs), cfg-4 and cfg-5, 2 of cfg-3,
                 after the cfg-2 region, with their own ms_per_step, path-level roofline fraction and kink-aware parity
   value_f32     the same step in fp32 (the configuration held to the 1e-3 bar)
   cpu_baseline  oracle/avmoe_oracle.py (eager PyTorch, fp32) timed on this box's host cores on a bounded
@@ -648,9 +648,9 @@ def main():
         del material
         if args.config == "cfg2" and not args.batch and not args.dtype and not args.no_other_configs:
             others = {}
-            for name in ("cfg1", "cfg4", "cfg5"):
-                try:
-                    others[name] = other_config_line(name, device, args.pair)
+            for name in ("cfg1", "cfg4", "cfg5", "cfg3"):
+                try:       # (cfg-3: 0.7 s per step -- two timed steps)
+                    others[name] = other_config_line(name, device, args.pair, **(dict(steps=2, warmup=1) if name == "cfg3" else {}))
                 except Exception as e:      # the headline line must not be lost to a side leg
                     others[name] = dict(error=f"{type(e).__name__}: {e}")
                 gc.collect()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces the round's judged artefacts on the GPU box (into gpurun_out/prof_final; copy them to profiles/<round>_* afterwards):
 #   PMC read / write traffic per kernel and per step (first: bench.py's `traffic` field reads the round's pmc_traffic.json), matrix-pipe
-#   utilisation counters, rocprofv3 kernel-trace stats of the default command (+ --pair serial), then the bench line (default flags).
+#   utilisation counters, rocprofv3 kernel-trace stats of the default command (+ --pair serial, + every launch alone), then the bench line.
 #   usage: scripts/make_profiles.sh [round tag, default r03]
 R=$PWD; O=$R/gpurun_out/prof_final; T=${1:-r03}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -19,7 +19,10 @@ cp $O/pmc_traffic.json $R/profiles/${T}_pmc_traffic.json          # (on the box:
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- $B --pair serial > $O/kts.log 2>&1
+# every launch alone on the GPU (one stream, no helper streams inside a site): what bench.py's profiling pass times with HIP events
+AVMOE_NO_SIDE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kta -- $B --pair serial > $O/kta.log 2>&1
 cd $R
+cp $O/kta/*/*kernel_stats.csv $O/kernel_stats_alone.csv
 cp $O/kt/*/*kernel_stats.csv $O/kernel_stats_default.csv
 cp $O/kts/*/*kernel_stats.csv $O/kernel_stats_serial.csv
 grep -h "^{\"metric\"" $O/kts.log | tail -1 > $O/bench_line_serial.json
