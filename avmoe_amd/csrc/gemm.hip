@@ -788,6 +788,9 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   return OK;
 }
 
+#ifndef GEMM_MIN_BLOCKS
+#define GEMM_MIN_BLOCKS 160   // fewer blocks than this: the next smaller tile
+#endif
 #ifndef GEMM_BIG_MIN
 #define GEMM_BIG_MIN 768       // smallest extent (both M and N) that takes the 256 x 256 tile
 #endif
@@ -933,6 +936,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   else if (tile == 0 || d.fold_rps) tile = (d.M > 64 && a.N > 64) ? 128 : ((d.M <= 32 && a.N <= 32) ? 32 : 64);
   const int bz = d.nbatch * d.ksplit;
   if (bz > 65535) { set_last_error("gemm: batch*ksplit=%d exceeds grid.y", bz); return ERR_UNSUPPORTED; }
+  // Small products are bound by the latency of their K loop, not by throughput: a tile size that leaves most of the 256 CUs without
+  // a block is replaced by the next smaller one (same K order per output element: bit-identical results).  Measured at cfg-1 (fp32,
+  // 20 frames): 1300 x 384 x 512 on 33 blocks of 128 x 128 takes 52 us.
+  if (a.tile == 0 && a.epi == GEMM_EPI_NONE) {
+    auto nblk = [&](int t) { return (long)cdiv(d.M, t) * cdiv(a.N, t) * bz; };
+    if (tile == 128 && nblk(128) < GEMM_MIN_BLOCKS) tile = 64;
+    if (tile == 64 && nblk(64) < GEMM_MIN_BLOCKS) tile = 32;
+  }
   int st;
   // the 256 x 256 tile for large plain bf16 products (enough tiles of it to fill the chip)
   const bool big = a.dtype == GEMM_BF16 && a.tile == 0 && tile == 128 && a.epi == GEMM_EPI_NONE && !a.A2 && !a.D && d.M >= GEMM_BIG_MIN && a.N >= GEMM_BIG_MIN &&
