@@ -20,6 +20,10 @@ CASES = {
     "fast_avs_lb": dict(cfg=dict(Cx=128, Nx=256, Cy=128, Ny=33, reduction=2, groups=2, K=32, variant="avs", lb_loss=True), S=3),
     "fast_e3p1": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=3, E_s=1), S=2),
     "fast_e1p3": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=1, E_s=3), S=2),
+    # wave-per-expert blocks of the register-resident kernels: three cross-modal experts (192 threads; the hop-2 kernel's fourth wave
+    # idles), and two experts over several tiles per block with a ragged tail (fast_e1p1 / e2p1 / e1p2 below: 2 and 3 experts)
+    "fast_e3p0": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=3, E_s=0), S=2),
+    "fast_e1p1_long": dict(cfg=dict(Cx=128, Nx=277, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=3),
     # BASELINE.json configs[0] (cfg-1): the Swin-B x HTS-AT adapter sites the AVE model really has (stages 0 and 2,
     # reduction 8, 2+2 experts, 32 latent tokens), two frames
     "cfg1_stage0_audio_side": dict(cfg=dict(Cx=96, Nx=4096, Cy=128, Ny=2304, reduction=8, groups=2, K=32, variant="ave"), S=2),
@@ -132,7 +136,7 @@ def test_midsize_matches_oracle_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["ave_mid", "fast_avs_lb", "fast_e3p1", "avs_v1_stage2", "cfg1_stage2_audio_side", "cfg1_stage0_audio_side",
-                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "ship_stage2_audio", "fast_avvp", "fast_avvp_e1p1_pad", "fast_v1",
+                                  "cfg1_stage0_visual_side", "fast_v2", "fast_e1p1", "fast_e2p1", "fast_e3p0", "fast_e1p1_long", "ship_stage2_audio", "fast_avvp", "fast_avvp_e1p1_pad", "fast_v1",
                                   "fast_eval", "fast_nobn_b",      # eval mode / no BatchNorm on the register-resident bf16 shape: no Gram pass, mz / Szz never formed
                                   # (fast_nobn's 4 frames x 97 tokens are too few for the router.0 budget in bf16, with or without BatchNorm: its gradient is
                                   # a sum over the frames that cancels the common part of the token means -- 14 % / 23 % against 4 % for eager autocast)
