@@ -23,6 +23,11 @@ CASES = {
     # wave-per-expert blocks of the register-resident kernels: three cross-modal experts (192 threads; the hop-2 kernel's fourth wave
     # idles), and two experts over several tiles per block with a ragged tail (fast_e1p1 / e2p1 / e1p2 below: 2 and 3 experts)
     "fast_e3p0": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=3, E_s=0), S=2),
+    # generalised kernels with 5 and 7 experts resident in one round (320- and 448-thread blocks) and 6 experts at a bottleneck
+    # whose per-expert constants allow only three of them at a time (two rounds)
+    "gen_e2p3": dict(cfg=dict(Cx=96, Nx=200, Cy=64, Ny=50, reduction=3, groups=2, K=8, variant="avs", E_m=2, E_s=3, lb_loss=True), S=3),
+    "gen_e4p3": dict(cfg=dict(Cx=96, Nx=130, Cy=64, Ny=50, reduction=3, groups=2, K=8, variant="ave", E_m=4, E_s=3), S=2),
+    "gen_e3p3_wide": dict(cfg=dict(Cx=192, Nx=130, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=3, E_s=3), S=2),
     "fast_e1p1_long": dict(cfg=dict(Cx=128, Nx=277, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="ave", E_m=1, E_s=1), S=3),
     # BASELINE.json configs[0] (cfg-1): the Swin-B x HTS-AT adapter sites the AVE model really has (stages 0 and 2,
     # reduction 8, 2+2 experts, 32 latent tokens), two frames
