@@ -2,15 +2,18 @@
 // bottleneck 64 in 2 conv groups (reduction 12 of 768 channels), 32 latent tokens (net_trans_v3.py:296-487).
 // Same arithmetic as the run-time-shaped kernels of tile_kernels.hip (names: oracle/algebra_ref.py), different data path:
 //
-//   * a wavefront owns 16 tokens; lane (r = lane & 15, q = lane >> 4) holds, for token r, the bottleneck entries
-//     dd = 16 c + 4 q + x  (c = 0..3 chunk, x = 0..3)  of the current expert -- exactly one 16-byte global access per chunk,
+//   * a wavefront owns 16 tokens of ONE expert; lane (r = lane & 15, q = lane >> 4) holds, for token r, the bottleneck entries
+//     dd = 16 c + 4 q + x  (c = 0..3 chunk, x = 0..3)  of that expert -- exactly one 16-byte global access per chunk,
 //     so Z-space tensors go HBM <-> registers directly, no LDS staging;
+//   * the waves of a block take DIFFERENT experts of the SAME tiles (WE<E> below), so that the experts' 64-byte segments of a
+//     row are requested together; every expert's per-frame constants sit in LDS at once;
 //   * every per-token mat-vec  W[tok][n] = sum_k P[tok][k] M[k][n]  is computed TRANSPOSED on the fp32 matrix pipe:
 //     A operand = M^T (lane supplies M[k(step,q)][16 ct + r], from LDS), B operand = P^T (lane supplies its own register
 //     P[r][k(step,q)]), and D^T leaves W[tok r][16 ct + 4 q + x] in the same lane layout -- so chains of mat-vecs and
 //     elementwise work never leave the register file;
 //   * sums over the bottleneck index = in-lane + 2 cross-row shuffles; sums over tokens (BatchNorm statistics) are carried
-//     in per-lane accumulators over the whole expert pass and folded once at its end (no float atomics: reproducible).
+//     in per-lane accumulators over the whole kernel and folded once at its end (no float atomics: reproducible); sums over the
+//     experts of one token go through LDS in expert order.
 #include "kernels.h"
 #include "device_utils.h"
 #include "prof.h"
@@ -208,34 +211,6 @@ __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const fl
     for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a, x), at(p[j], x), acc, 0, 0, 0);
   }
   return acc;
-}
-
-// fold per-lane token-slot accumulators (acc[c][x] for dd = 16 c + 4 q + x) over the 16 token slots and the waves of the
-// block, then write colpart[blk][slot][colmap(e, dd)]
-template <int E>
-__device__ __forceinline__ void flush_cols(float4 (&acc)[4], float* s_col /* [4 waves][64] */, float* colpart, int blk, int slot, int e) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const float v = rsum16(at(acc[c], x));
-      if (r == 0) s_col[wave * FDD + 16 * c + 4 * q + x] = v;
-    }
-  __syncthreads();
-  if (threadIdx.x < FDD) {
-    const int dd = threadIdx.x;
-    const float v = s_col[dd] + s_col[FDD + dd] + s_col[2 * FDD + dd] + s_col[3 * FDD + dd];
-    colpart[((long)blk * 4 + slot) * (E * FDD) + (dd >> 5) * (E * FDG) + e * FDG + (dd & 31)] = v;
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ float block_scalar(float v, float* s4) {   // sum of per-wave values (already wave-uniform)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) s4[wave] = v;
-  __syncthreads();
-  return s4[0] + s4[1] + s4[2] + s4[3];
 }
 
 // ---- wave-per-expert form --------------------------------------------------------------------------------------------------
