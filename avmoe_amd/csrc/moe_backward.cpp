@@ -193,9 +193,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     GemmArgs g = base();
     g.A = sc + pl.o_ag; g.B = dZx + (size_t)e0 * d.dgp * esz;
     g.C = sc + pl.o_dTW + (size_t)e0 * d.dgp * esz;
-    g.M = d.K; g.N = d.dgp; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.DZ; g.nb1 = d.S; g.nb2 = d.g; g.nb3 = d.El;
-    g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.N * d.DZ; g.sB2 = (long)d.E * d.dgp;
-    g.sA3 = d.Kp; g.sB3 = d.dgp; g.sC3 = (long)d.Kp * d.DZ + d.dgp;
+    g.M = d.K; g.N = d.dgp; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Kp; g.ldb = d.DZ; g.nb1 = d.S; g.nb2 = d.g; g.nb3 = d.El;
+    g.sA1 = (long)d.N * d.Kp; g.sB1 = (long)d.N * d.DZ; g.sB2 = (long)d.E * d.dgp;
+    g.sA3 = d.aL; g.sB3 = d.dgp; g.sC3 = (long)d.Kp * d.DZ + d.dgp;      // (ag: per-slot planes [slot][token][Kp])
     g.sCi = d.DZ; g.sC1 = (long)d.KLT * d.DZ; g.sC2 = (long)d.E * d.dgp; g.out_dtype = dt;
     AVMOE_TRY(run(g, false));
   }
@@ -254,8 +254,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     {                                                      // dTT[s][l] = sum_t du3 a a^T   (symmetric)
       GemmArgs g = base();
       g.A = sc + pl.o_aw; g.B = sv + pl.o_a; g.C = sc + pl.o_dTT;
-      g.M = d.K; g.N = d.K; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = g.ldb = d.KLp; g.nb1 = d.S; g.nb2 = d.El;
-      g.sA1 = g.sB1 = (long)d.N * d.KLp; g.sA2 = g.sB2 = d.Kp;
+      g.M = d.K; g.N = d.K; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = g.ldb = d.Kp; g.nb1 = d.S; g.nb2 = d.El;
+      g.sA1 = g.sB1 = (long)d.N * d.Kp; g.sA2 = g.sB2 = d.aL;      // (aw, a: per-slot planes)
       g.sCi = d.Kp; g.sC1 = (long)d.El * d.K * d.Kp; g.sC2 = (long)d.K * d.Kp; g.out_dtype = dt;
       AVMOE_TRY(run(g, false));
     }

@@ -133,6 +133,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.KL = d.El * d.Kp;          // latent rows per sample, each slot padded to Kp rows (pad rows are zero)
   d.KLT = d.KL + 2;
   d.KLp = (int)round_up(d.KL + 2, 8);
+  d.aL = (long)d.NT * d.Kp;
   d.Kcy = d.Ey * d.Kp;
   d.Kcyb = d.Kcy + 1;
   d.Kcx = d.Ex * d.Kp;

@@ -35,7 +35,8 @@ struct Dims {
   int El, Ey, Ex; // latent experts: total / source Y (cross-modal) / source X (AVS v2)
   int KL;         // El * Kp latent rows per sample (latent experts in expert order, slots padded to Kp rows)
   int KLT;        // KL + 2 : rows of the extended token matrix Text[s] (ones row, dm1/N row)
-  int KLp;        // row width of L2 / a / dL2ext  (>= KL + 2, multiple of 8)
+  int KLp;        // row width of L2 / dL2ext  (>= KL + 2, multiple of 8)
+  long aL;        // a / aw / ag are per-latent planes [latent slot][token][Kp] (whole-line stores, their GEMMs run per slot): plane stride NT * Kp
   int Kcy, Kcyb;  // Ey * Kp ; Kcy + 1 (extra wbar / ybar row)
   int Kcx;        // Ex * Kp
   int Kp, Kcyp, Kcxp;  // K, Kcy, Kcx padded to 8 (row strides of dTT / dRT / dL1xT)
@@ -99,7 +100,7 @@ struct Dims {
   X(sx, 0, 4, (size_t)2 * d.NT)                     /* row sum / sumsq of X           */       \
   X(Z, 0, d.zsz, (size_t)d.NT * d.DZ)                   /* Zx then z (in place)           */       \
   X(L2, 0, 4, (size_t)d.NT * d.KLp)                                                             \
-  X(a, 0, d.esz, (size_t)d.NT * d.KLp)                                                          \
+  X(a, 0, d.esz, (size_t)(d.El ? d.El : 1) * d.NT * (d.Kp ? d.Kp : 8))                                                     \
   X(rmu, 0, 4, (size_t)2 * d.NT * d.E)              /* [r | mu][expert][token]        */       \
   X(rpmup, 0, 4, (size_t)2 * d.NT * d.E)            /* [rp | mup][expert][token]      */       \
   X(bn1, 0, 4, (size_t)4 * d.DZ)                    /* mean, rstd, scale, shift       */       \
@@ -174,8 +175,8 @@ struct Dims {
   X(rs2x, 1, 4, (size_t)d.NT)                       /* 2 * sum_e dSxx                 */       \
   X(dslat, 1, 4, (size_t)2 * (d.El ? d.El : 1) * d.NT)   /* dSx, dSxx per (latent expert, token): pre_small_bwd -> pre_lat_bwd */ \
   X(dL2x, 1, d.esz, (size_t)d.NT * d.KLp)           /* [dL2 | dsx | 1]                */       \
-  X(aw, 1, d.esz, (size_t)d.NT * d.KLp)             /* du3 * a                        */       \
-  X(ag, 1, d.esz, (size_t)d.NT * d.KLp)             /* gate_lat * a                   */       \
+  X(aw, 1, d.esz, (size_t)(d.El ? d.El : 1) * d.NT * (d.Kp ? d.Kp : 8))   /* du3 * a  (planes)       */       \
+  X(ag, 1, d.esz, (size_t)(d.El ? d.El : 1) * d.NT * (d.Kp ? d.Kp : 8))   /* gate_lat * a  (planes)  */       \
   X(dtbar, 1, 4, (size_t)d.S * (d.KL ? d.KL : 1))                                               \
   X(dTT, 1, d.esz, (size_t)d.S * (d.El ? d.El : 1) * d.K * d.Kp)                                \
   X(dWt, 1, 4, (size_t)d.g * d.E * d.dgp * d.Cg)                                                \

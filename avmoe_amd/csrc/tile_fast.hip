@@ -78,7 +78,7 @@ constexpr int FK = 32;      // latent tokens
 constexpr int LD32 = 36;    // leading dim of LDS matrices with 32 columns   (4*ld = 16 mod 32: conflict-free A-operand reads)
 constexpr int LD64 = 68;    // ... with 64 columns
 
-struct FastDims { int S, N, C, El, KL, KLT, KLp, KPp, NT, per; };
+struct FastDims { int S, N, C, El, KL, KLT, KLp, KPp, NT, per; long aL; };      // aL: plane stride of a / aw / ag ([slot][token][32])
 
 // reductions over the 4 lanes that hold one token (same r, q = 0..3): the gfx950 row swaps v_permlane16_swap (rows 0<->1,
 // 2<->3) and v_permlane32_swap (rows 0,1 <-> 2,3) -- plain VALU, no LDS crossbar round trip as with ds_bpermute
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
       // every store of the tile is issued here, behind its last load: a wait that follows a store also waits (in-order counter)
       // for the store to be acknowledged
       if (ok) {
-        if (l >= 0) st_seg<T>(aout + tok * t.KLp + (long)l * FK, av[0], av[1], q);
+        if (l >= 0) st_seg<T>(aout + (long)l * t.aL + tok * FK, av[0], av[1], q);
         st_row<T, E>(Z + tok * DZ, e, q, zo);
         if (q == 0) { rmu[(long)e * t.NT + tok] = rr; rmu[(long)t.NT * E + (long)e * t.NT + tok] = mu; }
       }
@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
     if (n0 < n_end && n0 + r < t.N) {
       const long tok = (long)s * t.N + n0 + r;
       ldraw_row<E>(dZx + tok * DZ, e, q, ndraw_);
-      ldraw_seg(ain + tok * t.KLp + (long)l * FK, q, naraw_);
+      ldraw_seg(ain + (long)l * t.aL + tok * FK, q, naraw_);
       const long lo = tok * t.KLp + (long)l * FK + 4 * q;
       nlg[0] = ld4(L2 + lo); nlg[1] = ld4(L2 + lo + 16);
       ndSx = dslat[(2L * l) * t.NT + tok]; ndSxx = dslat[(2L * l + 1) * t.NT + tok];
@@ -1149,8 +1149,8 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
           const float ac = at(av[j], x);
           at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
         }
-      const long so = tok * t.KLp + (long)l * FK;
-      st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + so, v1[0], v1[1], q); st_seg<T>(ag_o + so, v2[0], v2[1], q);
+      const long so = tok * t.KLp + (long)l * FK, sa = (long)l * t.aL + tok * FK;      // rows of dL2x ; planes of aw / ag
+      st_seg<T>(dL2x + so, v0[0], v0[1], q); st_seg<T>(aw_o + sa, v1[0], v1[1], q); st_seg<T>(ag_o + sa, v2[0], v2[1], q);
     }
   }
   // per cross-modal expert: the gate partial and the column sums of du1 * a, folded over the expert's tile slots
@@ -1178,7 +1178,7 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
 
 FastDims make_fd(const Dims& d, int per) {
   FastDims t;
-  t.S = d.S; t.N = d.N; t.C = d.C; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp; t.KPp = d.KPp; t.NT = d.NT; t.per = per;
+  t.S = d.S; t.N = d.N; t.C = d.C; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp; t.KPp = d.KPp; t.NT = d.NT; t.per = per; t.aL = d.aL;
   return t;
 }
 void fast_grid(const Dims& d, dim3* grid, int* per) {

@@ -78,6 +78,7 @@ static int set_lds(const void* fn, size_t bytes, const char* what) {
 
 struct TileDims {
   int S, N, C, E, K, Kp, El, KL, KLT, KLp, DD, DZ, dgp, g, KPp, NT, per;
+  long aL;       // plane stride of a / aw / ag ([slot][token][Kp])
   int k4;        // ceil(K / 4): contraction steps over the latent index
   int lda_k;     // leading dim of per-wave K-wide tiles
   int ldb_k;     // leading dim of LDS matrices with K columns
@@ -89,7 +90,7 @@ struct TileDims {
 };
 static TileDims make_td(const Dims& d, int per) {
   TileDims t;
-  t.S = d.S; t.N = d.N; t.C = d.C; t.E = d.E; t.K = d.K; t.Kp = d.Kp; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp;
+  t.S = d.S; t.N = d.N; t.C = d.C; t.E = d.E; t.K = d.K; t.Kp = d.Kp; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp; t.aL = d.aL;
   t.DD = d.DD; t.DZ = d.DZ; t.dgp = d.dgp; t.g = d.g; t.KPp = d.KPp; t.NT = d.NT; t.per = per;
   t.k4 = cdiv(d.K, 4);
   t.lda_k = pad_lda(4 * t.k4); t.ldb_k = pad_ldb(4 * t.k4);
@@ -324,9 +325,9 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
             u1 += av * s_tb[k]; u2 += av * lv;
           }
           At[r * t.lda_k + k] = av;
-          if (rowok && k < t.Kp) stT<T>(aout, (t0 + r) * t.KLp + (long)l * t.Kp + k, av);
+          if (rowok && k < t.Kp) stT<T>(aout, (long)l * t.aL + (t0 + r) * t.Kp + k, av);
         }
-        if (rowok) for (int k = K4 + q; k < t.Kp; k += 4) stT<T>(aout, (t0 + r) * t.KLp + (long)l * t.Kp + k, 0.f);
+        if (rowok) for (int k = K4 + q; k < t.Kp; k += 4) stT<T>(aout, (long)l * t.aL + (t0 + r) * t.Kp + k, 0.f);
         u1 = qsum4(u1); u2 = qsum4(u2);
         if (q == 0) { rv[r] = u1; rv[16 + r] = u2; }
         wsync();
@@ -955,12 +956,12 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
       if (l >= 0) {
         // ---- a tile (A operand + C layout source), u1, u2 ----
         const bool rowok = (n0 + r) < t.N;
-        const long arow = (t0 + r) * t.KLp + (long)l * t.Kp;
+        const long arow = (t0 + r) * t.KLp + (long)l * t.Kp, aplane = (long)l * t.aL + (t0 + r) * t.Kp;      // row of L2 ; plane row of a
         float u1 = 0.f, u2 = 0.f;
         for (int kk = 0; kk < t.k4; ++kk) {
           const int k = 4 * kk + q;
           float av = 0.f;
-          if (rowok && k < K) { av = ldT<T>(ain, arow + k); u1 += av * s_tb[k]; u2 += av * L2[arow + k]; }
+          if (rowok && k < K) { av = ldT<T>(ain, aplane + k); u1 += av * s_tb[k]; u2 += av * L2[arow + k]; }
           At[r * t.lda_k + k] = av;
         }
         u1 = qsum4(u1); u2 = qsum4(u2);
@@ -1008,13 +1009,13 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
 #pragma unroll
             for (int x = 0; x < 4; ++x)
               if (ok[x]) {
-                const long o = (t0 + 4 * q + x) * t.KLp + (long)l * t.Kp + k;
+                const long o = (t0 + 4 * q + x) * t.KLp + (long)l * t.Kp + k, oa = (long)l * t.aL + (t0 + 4 * q + x) * t.Kp + k;
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;
                 if (k < K) {
                   const float ac = At[(4 * q + x) * t.lda_k + k], da = Da[(4 * q + x) * t.lda_k + k];
                   v0 = du2[x] * ac + ac * (da - sada[x]); v1 = du3[x] * ac; v2 = gv * ac;
                 }
-                stT<T>(dL2x, o, v0); stT<T>(aw_o, o, v1); stT<T>(ag_o, o, v2);
+                stT<T>(dL2x, o, v0); stT<T>(aw_o, oa, v1); stT<T>(ag_o, oa, v2);
               }
           }
         }

@@ -138,7 +138,7 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
     rec("probs", run.probs.cpu(), sv["p"])
     Text = run.buf("Text", T, (S, KLT, Cc))
     L2 = run.buf("L2", shape=(S, N, KLp))
-    a = run.buf("a", T, (S, N, KLp))
+    a = run.buf("a", T, (max(El, 1), S, N, Kp))           # per-latent-slot planes [slot][token][Kp]
     Z = run.buf("Z", shape=(S, N, g, E, dgp))
     TW = run.buf("TW", shape=(S, KLT, g, E, dgp))
     TT = run.buf("TT", shape=(S, max(El, 1), K, K))
@@ -158,7 +158,7 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
             rec(tag + "TT", TT[:, l], e["TT"])
             rec(tag + "TW", TW[:, l * Kp:l * Kp + K, :, j, :dg], e["TW"])
             rec(tag + "L2", L2[:, :, l * Kp:l * Kp + K], e["L2"])
-            rec(tag + "a", a[:, :, l * Kp:l * Kp + K], e["a"])
+            rec(tag + "a", a[l, :, :, :K], e["a"])
         rec(tag + "z", Z[:, :, :, j, :dg], e["z"])
         if cfg.ln_before:
             rec(tag + "r", rmu[0, j], e["r"])
