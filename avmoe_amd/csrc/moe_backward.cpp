@@ -72,6 +72,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     if (d.zsz == 2 && !dap_f32) {          // bf16 main columns + fp32 scalar columns: 640 instead of 1152 bytes per token, written and re-read
       GemmArgs h = g;
       h.out_dtype = GEMM_BF16; h.Cx = (float*)(sc + pl.o_dApx); h.nsplit = d.E * d.dgp; h.ldcx = (long)d.g * d.XW; h.sCx2 = d.XW;
+      h.sCi = (long)d.g * h.nsplit; h.sC2 = h.nsplit;      // the T columns as rows of their own (E * dgp wide: whole 128-byte lines), not inside KPp-wide rows
       const int r = launch_gemm_stream(h, st);
       if (r < 0) return r;
       dap16 = r == 0;

@@ -528,7 +528,8 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POST) kf_post_small(FPostArgs 
 // =====================================================================================================
 // POST_SMALL backward
 // =====================================================================================================
-struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; const void* ZpS; float* dSooT; const float* dApx; };   // ZpS / dSooT: gram64 mode
+struct FPostBArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate; const void* ZpS; float* dSooT; const float* dApx;
+                    int dapw; };      // dapw: row width of the split dApost's T columns (E * 32: whole lines)   // ZpS / dSooT: gram64 mode
 
 // D16: dApost arrives as T columns (the E x 32 bottleneck entries per group, row stride KPp) + an fp32 side array dApx
 // [token][group][16] with the 3 E scalar columns (the streaming GEMM's split output); otherwise one fp32 array.
@@ -582,8 +583,8 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPost
         const long tk = (long)s * t.N + n0p + r;
         ldraw_row<E>(Z + tk * DZ, e, q, nz);
         if constexpr (sizeof(T) == 2) {
-          nd.v[0] = *(const uint4*)(dAp16 + (tk * 2) * t.KPp + e * FDG + seg_off8(q));
-          nd.v[1] = *(const uint4*)(dAp16 + (tk * 2 + 1) * t.KPp + e * FDG + seg_off8(q));
+          nd.v[0] = *(const uint4*)(dAp16 + (tk * 2) * a.dapw + e * FDG + seg_off8(q));
+          nd.v[1] = *(const uint4*)(dAp16 + (tk * 2 + 1) * a.dapw + e * FDG + seg_off8(q));
         }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
@@ -613,7 +614,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPost
         if (ok) ld_row<T, E>((saved_zp ? (const T*)a.ZpS : Z) + tok * DZ, e, q, zraw);
         if constexpr (D16) {
           zero_row(d);
-          if (ok) { ld_seg<T>(dAp16 + (tok * 2) * t.KPp + e * FDG, d[0], d[1], q); ld_seg<T>(dAp16 + (tok * 2 + 1) * t.KPp + e * FDG, d[2], d[3], q); }
+          if (ok) { ld_seg<T>(dAp16 + (tok * 2) * a.dapw + e * FDG, d[0], d[1], q); ld_seg<T>(dAp16 + (tok * 2 + 1) * a.dapw + e * FDG, d[2], d[3], q); }
         }
       }
 #pragma unroll
@@ -1299,7 +1300,7 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
   a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
   a.ZpS = nullptr;          // z' is recomputed from z (no stored copy any more: the Gram kernel forms it on the fly too)
   a.dSooT = d.gram64 ? (float*)(scratch + pl.o_dSooT) : nullptr;
-  a.dApx = (const float*)(scratch + pl.o_dApx);
+  a.dApx = (const float*)(scratch + pl.o_dApx); a.dapw = d.E * d.dgp;
   if (dap16 && !d.bf16) { set_last_error("post_small_bwd: split dApost is a bf16 form"); return ERR_BAD_ARG; }
 #define POSTB_ARGS a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),                       \
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (const float*)(saved + pl.o_rpmup),                     \
