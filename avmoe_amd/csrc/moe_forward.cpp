@@ -176,7 +176,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     GemmArgs g = base();
     g.A = X; g.B = sv + pl.o_Text; g.C = sv + pl.o_L2;
     g.M = d.N; g.N = d.KL; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S;
-    g.sA1 = (long)d.N * d.C; g.sB1 = (long)d.KLT * d.C; g.sCi = d.KLp; g.sC1 = (long)d.N * d.KLp;
+    g.sA1 = (long)d.N * d.C; g.sB1 = (long)d.KLT * d.C; g.sCi = d.KL; g.sC1 = (long)d.N * d.KL;
     AVMOE_TRY(launch_gemm(g, st));
   }
   // ---- AVVP unimodal N x N block (mgn.py:132-139): xr = softmax_rows(X X^T)^T X, shared by the unimodal experts;

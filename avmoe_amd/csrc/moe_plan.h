@@ -35,7 +35,7 @@ struct Dims {
   int El, Ey, Ex; // latent experts: total / source Y (cross-modal) / source X (AVS v2)
   int KL;         // El * Kp latent rows per sample (latent experts in expert order, slots padded to Kp rows)
   int KLT;        // KL + 2 : rows of the extended token matrix Text[s] (ones row, dm1/N row)
-  int KLp;        // row width of L2 / dL2ext  (>= KL + 2, multiple of 8)
+  int KLp;        // row width of dL2ext  (>= KL + 2, multiple of 8); the logits L2 are (NT, KL) rows: 256 bytes at two slots of 32
   long aL;        // a / aw / ag are per-latent planes [latent slot][token][Kp] (whole-line stores, their GEMMs run per slot): plane stride NT * Kp
   int Kcy, Kcyb;  // Ey * Kp ; Kcy + 1 (extra wbar / ybar row)
   int Kcx;        // Ex * Kp
@@ -99,7 +99,7 @@ struct Dims {
   /* ---- per token ---- */                                                                    \
   X(sx, 0, 4, (size_t)2 * d.NT)                     /* row sum / sumsq of X           */       \
   X(Z, 0, d.zsz, (size_t)d.NT * d.DZ)                   /* Zx then z (in place)           */       \
-  X(L2, 0, 4, (size_t)d.NT * d.KLp)                                                             \
+  X(L2, 0, 4, (size_t)d.NT * (d.KL ? d.KL : 8))                                                             \
   X(a, 0, d.esz, (size_t)(d.El ? d.El : 1) * d.NT * (d.Kp ? d.Kp : 8))                                                     \
   X(rmu, 0, 4, (size_t)2 * d.NT * d.E)              /* [r | mu][expert][token]        */       \
   X(rpmup, 0, 4, (size_t)2 * d.NT * d.E)            /* [rp | mup][expert][token]      */       \

@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
         Sx = sxs[tok]; Sxx = sxs[t.NT + tok];
         ldraw_row<E>(Z + tok * DZ, e, q, zraw_);
         if (l >= 0) {
-          const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+          const long lo = tok * t.KL + (long)l * FK + 4 * q;
           lg[0] = ld4(L2 + lo); lg[1] = ld4(L2 + lo + 16);
         }
       }
@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
       const long tok = (long)s * t.N + n0 + r;
       ldraw_row<E>(dZx + tok * DZ, e, q, ndraw_);
       ldraw_seg(ain + (long)l * t.aL + tok * FK, q, naraw_);
-      const long lo = tok * t.KLp + (long)l * FK + 4 * q;
+      const long lo = tok * t.KL + (long)l * FK + 4 * q;
       nlg[0] = ld4(L2 + lo); nlg[1] = ld4(L2 + lo + 16);
       ndSx = dslat[(2L * l) * t.NT + tok]; ndSxx = dslat[(2L * l + 1) * t.NT + tok];
     }

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) kt_pre_small(PreTArgs a, float* __restric
       if (l >= 0) {
         // ---- softmax of the hop-2 logits, token r spread over the 4 lanes q (k = 4*kk + q) ----
         const bool rowok = (n0 + r) < t.N;
-        const float* l2 = L2 + (t0 + r) * t.KLp + (long)l * t.Kp;
+        const float* l2 = L2 + (t0 + r) * t.KL + (long)l * t.Kp;
         float mx = -INFINITY;
         for (int kk = 0; kk < t.k4; ++kk) { const int k = 4 * kk + q; if (rowok && k < K) mx = fmaxf(mx, l2[k]); }
         mx = qmax4(mx);
@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
       if (l >= 0) {
         // ---- a tile (A operand + C layout source), u1, u2 ----
         const bool rowok = (n0 + r) < t.N;
-        const long arow = (t0 + r) * t.KLp + (long)l * t.Kp, aplane = (long)l * t.aL + (t0 + r) * t.Kp;      // row of L2 ; plane row of a
+        const long arow = (t0 + r) * t.KL + (long)l * t.Kp, aplane = (long)l * t.aL + (t0 + r) * t.Kp;      // row of L2 ; plane row of a
         float u1 = 0.f, u2 = 0.f;
         for (int kk = 0; kk < t.k4; ++kk) {
           const int k = 4 * kk + q;
@@ -987,7 +987,7 @@ __global__ void __launch_bounds__(256) kt_pre_small_bwd(PreBTArgs a, const float
             u3[x] += ta[x] * ac;
             float da = 0.f;
             if (k < K && ok[x]) {
-              da = gv * twd[x] + du1[x] * s_tb[k] + du2[x] * L2[(t0 + 4 * q + x) * t.KLp + (long)l * t.Kp + k] + 2.f * du3[x] * ta[x];
+              da = gv * twd[x] + du1[x] * s_tb[k] + du2[x] * L2[(t0 + 4 * q + x) * t.KL + (long)l * t.Kp + k] + 2.f * du3[x] * ta[x];
               sada[x] += ac * da;
               ck += du1[x] * ac;
             }

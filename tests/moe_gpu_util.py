@@ -137,7 +137,7 @@ def compare_forward_intermediates(run: MoeRun, A, verbose=True):
     rec("rin", run.buf("rin", shape=(S, 2 * Cc)), sv["rin"])
     rec("probs", run.probs.cpu(), sv["p"])
     Text = run.buf("Text", T, (S, KLT, Cc))
-    L2 = run.buf("L2", shape=(S, N, KLp))
+    L2 = run.buf("L2", shape=(S, N, max(KL, 8)))
     a = run.buf("a", T, (max(El, 1), S, N, Kp))           # per-latent-slot planes [slot][token][Kp]
     Z = run.buf("Z", shape=(S, N, g, E, dgp))
     TW = run.buf("TW", shape=(S, KLT, g, E, dgp))
