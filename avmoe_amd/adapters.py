@@ -208,9 +208,15 @@ class _PairFunction(torch.autograd.Function):
     def forward(ctx, site_a, site_b, side, Xa, Xb, base_a, base_b, names_a, names_b, noises, *params):
         """side: the second HIP stream (two-stream mode) or None (both sites on the caller's stream).
         base_a / base_b: None, or the residual streams that take `+= adapter output` in place (returned as the outputs).
-        noises: (noise_a, noise_b) -- the AVS logit noise of the two sites, (S, E) already scaled, or None each."""
+        noises: (noise_a, noise_b) -- the AVS logit noise of the two sites, (S, E) already scaled, or None each.
+        params: every parameter of the two sites -- or, with gradient sinks on both (`lean`, AdapterPair.forward), ONE anchor
+        parameter: the sinks take the gradients, autograd only has to know that the outputs depend on something trainable."""
         na = len(names_a)
-        pa, pb = params[:na], params[na:]
+        ctx.lean = len(params) == 1 and na > 1
+        if ctx.lean:
+            pa, pb = tuple(site_a._param_tensors().values()), tuple(site_b._param_tensors().values())
+        else:
+            pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
         main = torch.cuda.current_stream(Xa.device)
         side, ctx.events = (side[0], side[1:]) if isinstance(side, tuple) else (side, None)
@@ -240,9 +246,10 @@ class _PairFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)                 # no zero tensors (= fill kernels) for the gradients of the index outputs
         ctx.side = side
         ctx.sites, ctx.names, ctx.states = (site_a, site_b), (names_a, names_b), (st_a[:2], st_b[:2])
-        for site, needs in ((site_a, ctx.needs_input_grad[10:10 + na]), (site_b, ctx.needs_input_grad[10 + na:])):
+        needs_ab = ((True,), (True,)) if ctx.lean else (ctx.needs_input_grad[10:10 + na], ctx.needs_input_grad[10 + na:])
+        for site, needs in ((site_a, needs_ab[0]), (site_b, needs_ab[1])):
             sink = getattr(site, "_grad_sink", None)
-            if sink is not None and any(needs):
+            if sink is not None and any(needs) and (not ctx.lean or ctx.needs_input_grad[10]):
                 sink.calls += 1
         ctx.save_for_backward(st_a[2], st_a[3], *params)
         ctx.mark_non_differentiable(idx_a, idx_b, pr_a, pr_b)
@@ -256,7 +263,13 @@ class _PairFunction(torch.autograd.Function):
         (site_a, site_b), (names_a, names_b) = ctx.sites, ctx.names
         na = len(names_a)
         gXa, gXb = torch.empty_like(Xa), torch.empty_like(Xb)
-        needs_a, needs_b = ctx.needs_input_grad[10:10 + na], ctx.needs_input_grad[10 + na:]
+        if ctx.lean:                                       # the sinks take every parameter gradient; autograd gets None for the anchor
+            if getattr(site_a, "_grad_sink", None) is None or getattr(site_b, "_grad_sink", None) is None:
+                raise capi.AvmoeError("AdapterPair: the gradient sink of a site was detached between its forward and its backward")
+            params = tuple(site_a._param_tensors().values()) + tuple(site_b._param_tensors().values())
+            needs_a, needs_b = (True,) * na, (True,) * len(names_b)
+        else:
+            needs_a, needs_b = ctx.needs_input_grad[10:10 + na], ctx.needs_input_grad[10 + na:]
         gba = d_a if ctx.has_base[0] else None            # out = base + adapter(...): the residual stream passes the gradient on
         gbb = d_b if ctx.has_base[1] else None
         if ctx.side is not None:
@@ -284,7 +297,7 @@ class _PairFunction(torch.autograd.Function):
             for t_ in tuple(g_ for g_ in pgb if g_ is not None) + (cbk.d_out,):
                 t_.record_stream(main)
             gXa.record_stream(side); gXb.record_stream(side)
-            return (None, None, None, gXa, gXb, gba, gbb, None, None, None) + pga + pgb
+            return (None, None, None, gXa, gXb, gba, gbb, None, None, None) + ((None,) if ctx.lean else pga + pgb)
         # One stream: both sites add into both token gradients; the second one to run re-reads them in its GEMM epilogues.  The
         # larger tensor is re-read more cheaply by the dX kernel (fewer stationary fragments per wave), so the site whose X is the
         # larger tensor runs second
@@ -299,7 +312,7 @@ class _PairFunction(torch.autograd.Function):
             pgb = run_b(False); pga = run_a(True)
         else:
             pga = run_a(False); pgb = run_b(True)
-        return (None, None, None, gXa, gXb, gba, gbb, None, None, None) + pga + pgb
+        return (None, None, None, gXa, gXb, gba, gbb, None, None, None) + ((None,) if ctx.lean else pga + pgb)
 
 
 class ExpertAdapter(nn.Module):
@@ -639,9 +652,16 @@ class AdapterPair(nn.Module):
             noises = tuple(torch.randn(x.shape[0], m.num_multimodal_experts + m.num_singlemodal_experts, device=x.device,
                                        dtype=torch.float32) * 0.01 for m, x in ((self.site_a, x_a), (self.site_b, x_b)))
         side = (self._side,) + self._events if self.concurrent else None
+        # With a gradient sink on both sites (avmoe_amd.dp.AdapterGradReducer(sites=...)) and every parameter trainable, the backward
+        # writes the parameter gradients into the reducer's buckets and autograd gets None for them anyway: ONE anchor parameter
+        # then stands in for the ~120 of the pair (unwrapping, saving and returning a gradient slot for each of them is a third of
+        # the host time of a step at the reference's batch of 2 clips -- tests/dev/host_split.py).
+        lean = torch.is_grad_enabled() and all(
+            getattr(m, "_grad_sink", None) is not None and m._grad_sink.flat is not None and all(p.requires_grad for p in P.values())
+            and m._grad_sink.matches(tuple(P.keys()), P) for m, P in ((self.site_a, Pa), (self.site_b, Pb)))
+        plist = (next(iter(Pa.values())),) if lean and len(Pa) > 1 else (*Pa.values(), *Pb.values())
         out_a, out_b, idx_a, idx_b, pr_a, pr_b, lb_a, lb_b = _PairFunction.apply(
-            self.site_a, self.site_b, side, Xa, Xb, add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()), noises,
-            *Pa.values(), *Pb.values())
+            self.site_a, self.site_b, side, Xa, Xb, add_to[0], add_to[1], tuple(Pa.keys()), tuple(Pb.keys()), noises, *plist)
         out_a, out_b = out_a.permute(0, 2, 1).unsqueeze(-1), out_b.permute(0, 2, 1).unsqueeze(-1)
         if self.variant in ("ave", "avqa"):
             return out_a, idx_a.unsqueeze(-1), out_b, idx_b.unsqueeze(-1)

@@ -1,12 +1,13 @@
-"""dev: does the host run ahead of the GPU in the cfg-2 step?  Enqueue time of each step (no synchronisation inside) against the
-GPU time per step:   python tests/dev/host_ahead.py [steps]"""
+"""dev: does the host run ahead of the GPU?  Enqueue time of each step (no synchronisation inside) against the GPU time per step:
+python tests/dev/host_ahead.py [steps] [cfg2|cfg1|...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
-c = dict(bench.CONFIGS["cfg2"], name="cfg2")
+name = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+c = dict(bench.CONFIGS[name], name=name)
 dev = torch.device("cuda:0")
-wl = bench.Workload(c, torch.bfloat16, dev, 0, 1, "concurrent")
+wl = bench.Workload(c, torch.bfloat16 if c["dtype"] == "bf16" else torch.float32, dev, 0, 1, "concurrent")
 for _ in range(5):
     wl.step()
 torch.cuda.synchronize()

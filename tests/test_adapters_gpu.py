@@ -272,6 +272,62 @@ def test_adapter_pair_with_frame_attention_experts(concurrent):
     assert any("self_attention.in_proj_weight" in k for k, _ in sa.named_parameters())
 
 
+@pytest.mark.parametrize("frozen_inputs", [False, True])
+def test_adapter_pair_with_gradient_sinks_is_lean_and_equal(frozen_inputs):
+    """With AdapterGradReducer(sites=...) on both sites the pair hands autograd ONE anchor parameter instead of every parameter (the
+    sinks take the gradients): same outputs, same parameter gradients (now views of the reducer's bucket) and token gradients as
+    the plain pair -- also when the token tensors come from a frozen backbone (nothing but the anchor requires grad)."""
+    import copy
+    from avmoe_amd.adapters import AdapterPair, _PairFunction
+    from avmoe_amd.dp import AdapterGradReducer
+    dev = torch.device("cuda:0")
+    ca = O.AdapterConfig(Cx=64, Nx=150, Cy=48, Ny=80, reduction=4, groups=2, K=8)
+    cb = O.AdapterConfig(Cx=48, Nx=80, Cy=64, Ny=150, reduction=4, groups=2, K=8)
+    torch.manual_seed(3)
+    sa, sb = build_module("ave", ca).to(dev).train(), build_module("ave", cb).to(dev).train()
+    with torch.no_grad():
+        for m in (sa, sb):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.3)
+    ra, rb = copy.deepcopy(sa), copy.deepcopy(sb)                       # the plain pair (no sinks)
+    red = AdapterGradReducer([p for m in (sa, sb) for p in m.parameters()], sites=[sa, sb])
+    g = torch.Generator().manual_seed(9)
+    fa = (0.5 * torch.randn(4, ca.Cx, ca.Nx, 1, generator=g)).to(dev)
+    fv = (0.5 * torch.randn(4, cb.Cx, cb.Nx, 1, generator=g)).to(dev)
+    ga, gv = torch.randn(4, ca.Cx, ca.Nx, 1, generator=g).to(dev), torch.randn(4, cb.Cx, cb.Nx, 1, generator=g).to(dev)
+
+    def run(pair, begin=None):
+        xa, xv = fa.clone().requires_grad_(not frozen_inputs), fv.clone().requires_grad_(not frozen_inputs)
+        seen = []
+        orig = _PairFunction.apply
+        if begin is not None:
+            begin()
+        oa, _, ov, _ = pair(xa, xv)
+        torch.autograd.backward([oa, ov], [ga, gv])
+        return oa.detach(), ov.detach(), xa.grad, xv.grad
+
+    ref = run(AdapterPair(ra, rb))
+    lean_pair = AdapterPair(sa, sb)
+    n_inputs = []
+    orig_apply = _PairFunction.apply
+    _PairFunction.apply = staticmethod(lambda *a: (n_inputs.append(len(a)), orig_apply(*a))[1])
+    try:
+        got = run(lean_pair, begin=lambda: red.begin(sync=True))
+        red.finish()
+    finally:
+        _PairFunction.apply = orig_apply
+    assert n_inputs == [11]                                              # ten fixed arguments + one anchor parameter
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    if not frozen_inputs:
+        assert torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3])
+    else:
+        assert got[2] is None and got[3] is None
+    for (k, p), (_, q) in zip(list(ra.named_parameters()) + list(rb.named_parameters()), list(sa.named_parameters()) + list(sb.named_parameters())):
+        assert q.grad.data_ptr() >= red.buckets[0].flat.data_ptr()
+        assert torch.equal(p.grad, q.grad), k
+
+
 @pytest.mark.parametrize("concurrent", [False, True])
 @pytest.mark.parametrize("which", ["avvp", "avs", "avs_v2"])
 def test_adapter_pair_avvp_avs_signatures(which, concurrent):
