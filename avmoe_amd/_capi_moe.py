@@ -64,6 +64,11 @@ def declare(L):
     L.avmoe_expert_histogram.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.avmoe_router_forward.restype = C.c_int
     L.avmoe_router_forward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.POINTER(MoePtrs)] + [C.c_void_p] * 7
+    for fn in (L.avmoe_expert_forward_cross, L.avmoe_expert_forward_uni):      # sub-ops (ABI 7): one expert's output alone
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_int32] + [C.c_void_p] * 4
+    L.avmoe_remap_forward.restype = C.c_int                                    # the remap materialised
+    L.avmoe_remap_forward.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.POINTER(MoePtrs)] + [C.c_void_p] * 5
     L.avmoe_moe_saved_bytes.restype = C.c_size_t
     L.avmoe_moe_saved_bytes.argtypes = [C.POINTER(MoeDesc)]
     L.avmoe_moe_scratch_bytes.restype = C.c_size_t

@@ -92,6 +92,32 @@ int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avm
   return k_router(pl, (char*)saved, (char*)scratch, *params, noise, probs, idx, lb, (hipStream_t)stream);
 }
 
+int avmoe_expert_forward_cross(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params, int32_t j,
+                               void* out, void* saved, void* scratch, void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!X || !Y || !params || !out || !saved || !scratch) { set_last_error("avmoe_expert_forward_cross: null pointer"); return ERR_BAD_ARG; }
+  if (j < 0 || j >= desc->E_m) { set_last_error("avmoe_expert_forward_cross: expert %d of %d cross-modal experts", j, desc->E_m); return ERR_BAD_ARG; }
+  return expert_forward(pl, X, Y, *params, j, out, (char*)saved, (char*)scratch, (hipStream_t)stream);
+}
+
+int avmoe_expert_forward_uni(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params, int32_t j,
+                             void* out, void* saved, void* scratch, void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!X || !Y || !params || !out || !saved || !scratch) { set_last_error("avmoe_expert_forward_uni: null pointer"); return ERR_BAD_ARG; }
+  if (j < 0 || j >= desc->E_s) { set_last_error("avmoe_expert_forward_uni: expert %d of %d unimodal experts", j, desc->E_s); return ERR_BAD_ARG; }
+  return expert_forward(pl, X, Y, *params, desc->E_m + j, out, (char*)saved, (char*)scratch, (hipStream_t)stream);
+}
+
+int avmoe_remap_forward(const avmoe_moe_desc* desc, const void* Y, const avmoe_moe_ptrs* params, void* Yt, void* Yf, void* saved,
+                        void* scratch, void* stream) {
+  Plan pl;
+  AVMOE_TRY(make_plan(desc, &pl));
+  if (!Y || !params || !Yt || !Yf || !saved || !scratch) { set_last_error("avmoe_remap_forward: null pointer"); return ERR_BAD_ARG; }
+  return remap_forward(pl, Y, *params, Yt, Yf, (char*)saved, (char*)scratch, (hipStream_t)stream);
+}
+
 int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char** name, int32_t* region, size_t* offset,
                           size_t* bytes) {
   Plan pl;

@@ -765,6 +765,34 @@ int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& p
   return OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// sub-ops of the C ABI (tests / partial adoption; not on the product path)
+// ---------------------------------------------------------------------------------------------
+// noise[s][e] = (e == hot) * value : logit "noise" that turns the router's softmax into an exact one-hot (avmoe_expert_forward_*)
+__global__ void kk_onehot_noise(float* noise, long n, int E, int hot, float value) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) noise[i] = ((int)(i % E) == hot) ? value : 0.f;
+}
+int k_onehot_noise(float* noise, int S, int E, int hot, float value, hipStream_t st) {
+  hipLaunchKernelGGL(kk_onehot_noise, dim3(grid1d((long)S * E, 256)), dim3(256), 0, st, noise, (long)S * E, E, hot, value);
+  AVMOE_CHECK_LAUNCH("onehot_noise");
+  return OK;
+}
+// Z[row][col] += rowb[row % period] + colb[col]   (either bias may be NULL): the biases of conv_adapter / fc on a materialised remap
+template <typename T>
+__global__ void kk_add_bias(void* Z_, long rows, int cols, int period, const float* rowb, const float* colb) {
+  T* Z = (T*)Z_;
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / cols; const int col = (int)(i - row * cols);
+    stT<T>(Z, i, ldT<T>(Z, i) + (rowb ? rowb[row % period] : 0.f) + (colb ? colb[col] : 0.f));
+  }
+}
+int k_add_bias(bool bf16, void* Z, long rows, int cols, int period, const float* rowb, const float* colb, hipStream_t st) {
+  DISPATCH_T(bf16, kk_add_bias, dim3(grid1d(rows * cols, 4096)), dim3(256), 0, st, Z, rows, cols, period, rowb, colb);
+  AVMOE_CHECK_LAUNCH("add_bias");
+  return OK;
+}
+
 // (PRE_SMALL / POST_SMALL live in tile_kernels.hip: 16-token MFMA tiles)
 
 // ---------------------------------------------------------------------------------------------

@@ -36,6 +36,8 @@ int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, v
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src /*0 y, 1 x*/,
                hipStream_t st);
 // ---- forward: router --------------------------------------------------------------------------
+int k_onehot_noise(float* noise, int S, int E, int hot, float value, hipStream_t st);      // sub-ops of the C ABI (fwd_kernels.hip)
+int k_add_bias(bool bf16, void* Z, long rows, int cols, int period, const float* rowb, const float* colb, hipStream_t st);
 int k_router(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const float* noise, float* probs_out,
              int64_t* idx_out, float* lb_out, hipStream_t st);
 // ---- forward: per token -----------------------------------------------------------------------

@@ -257,4 +257,42 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   return OK;
 }
 
+// ---- sub-ops of the C ABI (for tests / partial adoption; the product path never calls them) -------------------------
+// What ExpertAdapter.forward of expert e returns -- gate * LN_post(BN2(up(act(BN1(down(LN_before(x'))))))), net_trans_v3.py:377-435 --
+// as the site forward with the router pushed to an exact one-hot on that expert: a logit offset of 3e4 makes softmax return 1.0 for it
+// and 0.0 for the others (exp underflows to zero), so out = 1 * out_e + 0 * out_others.  Same kernels, same workspaces and the same
+// side effects as avmoe_moe_forward (training mode: the BatchNorm running statistics of EVERY expert advance).
+int expert_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, int e, void* out, char* sv, char* sc, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (e < 0 || e >= d.E) { set_last_error("expert_forward: expert %d of %d", e, d.E); return ERR_BAD_ARG; }
+  float* noise = (float*)(sc + pl.o_dp);                   // (S, E) floats of a backward-only buffer
+  AVMOE_TRY(k_onehot_noise(noise, d.S, d.E, e, 3.0e4f, st));
+  return moe_forward(pl, X, Y, prm, noise, out, nullptr, nullptr, nullptr, sv, sc, st);
+}
+
+// The remap MATERIALISED (the product path folds it away): Yt = conv_adapter(Y) (S, N, Cy), then
+// Yf = fc(Yt) (S, N, C) -- `vis_token` of net_trans_v3.py:469-471, token-major.  Two engine GEMMs on the T-typed weight copies of
+// k_prep_all + the two biases.
+int remap_forward(const Plan& pl, const void* Y, const avmoe_moe_ptrs& prm, void* Yt, void* Yf, char* sv, char* sc, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!prm.fc_b) { set_last_error("remap_forward: fc.bias missing"); return ERR_BAD_ARG; }
+  const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
+  AVMOE_TRY(k_prep_all(pl, sv, prm, st));
+  {                                                        // Yt[s] = Wc Y[s]
+    GemmArgs g; g.dtype = dt; g.out_dtype = dt; g.slabs = (float*)(sc + pl.o_slabs);
+    g.A = sv + pl.o_WcK; g.B = Y; g.C = Yt;
+    g.M = d.N; g.N = d.Cy; g.K = d.M; g.lda = d.Mk; g.b_layout = MN_MAJOR; g.ldb = d.Cy; g.nb1 = d.S; g.sB1 = (long)d.M * d.Cy;
+    g.sCi = d.Cy; g.sC1 = (long)d.N * d.Cy;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  AVMOE_TRY(k_add_bias(d.bf16, Yt, (long)d.S * d.N, d.Cy, d.N, prm.conv_b, nullptr, st));
+  {                                                        // Yf = Yt Wf^T
+    GemmArgs g; g.dtype = dt; g.out_dtype = dt; g.slabs = (float*)(sc + pl.o_slabs);
+    g.A = Yt; g.B = sv + pl.o_WfT; g.C = Yf;
+    g.M = d.S * d.N; g.N = d.C; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.sCi = d.C;
+    AVMOE_TRY(launch_gemm(g, st));
+  }
+  return k_add_bias(d.bf16, Yf, (long)d.S * d.N, d.C, 1, nullptr, prm.fc_b, st);
+}
+
 }  // namespace avmoe

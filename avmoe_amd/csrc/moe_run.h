@@ -26,4 +26,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, const float* lb_grad,
                  char* saved, char* scratch, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st, int parts = 0);
 
+// sub-ops of the C ABI (moe_forward.cpp): one expert's output alone ; the remap materialised
+int expert_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, int e, void* out, char* saved, char* scratch,
+                   hipStream_t st);
+int remap_forward(const Plan& pl, const void* Y, const avmoe_moe_ptrs& prm, void* Yt, void* Yf, char* saved, char* scratch, hipStream_t st);
+
 }  // namespace avmoe

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 6
+#define AVMOE_ABI_VERSION 7
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -143,11 +143,25 @@ int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const voi
  * Linear(32,E)) + optional logit noise + softmax + first-max argmax  (net_trans_v3.py:460-466,477-479).
  * rin (S, 2C) f32 = [mean over tokens of x | mean over tokens of the remapped other modality]; same workspaces as the
  * site calls (rin is copied into `saved`; a following avmoe_moe_backward on it is not meaningful).  probs (S,E) f32,
- * idx (S) int64, lb (1 float, written only when desc.lb_loss) may each be NULL.
- * (The remap and the experts have no stand-alone sub-op: in this library they are never materialised on their own --
- *  DESIGN.md section 3 -- their intermediates are reachable through avmoe_moe_buffer_info.)                       */
+ * idx (S) int64, lb (1 float, written only when desc.lb_loss) may each be NULL.                                    */
 int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avmoe_moe_ptrs* params, const float* noise,
                          float* probs, int64_t* idx, float* lb, void* saved, void* scratch, void* stream);
+
+/* ABI 7 -- sub-ops (tests / partial adoption), same workspaces as the site calls; a following avmoe_moe_backward on them is not
+ * meaningful.  The product path never materialises either; these exist so that a maintainer can compare the
+ * library with the reference one module at a time.
+ * avmoe_expert_forward_cross / _uni: what ExpertAdapter.forward returns for multimodal_experts[j] / singlemodal_experts[j]
+ * (gate * LN_post(BN2(up(act(BN1(down(LN_before(x'))))))), net_trans_v3.py:377-435 ; mgn.py:132-139 and PVT_AVSModel_v2.py:210-227
+ * for the unimodal variants) into out (S, N, C): the site forward with the router pushed to an exact one-hot on that expert.  In
+ * training mode it has the side effects of a site forward (the BatchNorm running statistics and counters of EVERY expert advance).
+ * avmoe_remap_forward: the remapped other modality, materialised -- Yt = conv_adapter(Y) (S, N, Cy) and Yf = fc(Yt) (S, N, C), the
+ * `vis_token` every expert and the router read (net_trans_v3.py:469-471); both in desc.dtype, both written.                      */
+int avmoe_expert_forward_cross(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params, int32_t j,
+                               void* out, void* saved, void* scratch, void* stream);
+int avmoe_expert_forward_uni(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params, int32_t j,
+                             void* out, void* saved, void* scratch, void* stream);
+int avmoe_remap_forward(const avmoe_moe_desc* desc, const void* Y, const avmoe_moe_ptrs* params, void* Yt, void* Yf, void* saved,
+                        void* scratch, void* stream);
 
 /* Workspace introspection for tests: buffer `index` -> name / region (0 saved, 1 scratch) / offset / bytes.
  * Returns 0, or AVMOE_ERR_BAD_ARG when index is past the last buffer.                                 */
