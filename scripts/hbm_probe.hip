@@ -3,7 +3,8 @@
 //   read   : sum of a buffer (one partial per block)          write : fill
 //   copy   : dst = src (1 : 1)                                 mix21 : dst = a + b (2 reads : 1 write, the shape of an accumulating GEMM epilogue)
 //   inplace: dst += a (2 reads : 1 write, the write on the row just read)      seg : the read as 64-byte segments of 512-byte rows, a block's
-//            four waves taking the segments of the same 16 rows (the request shape of the bottleneck-space kernels)
+//            four waves taking the segments of the same 16 rows (the request shape of the bottleneck-space kernels); seg 2r1w : the memory
+//            side of kf_mid_bwd without its arithmetic (two segment reads, the segment write in place)
 //   build (here, no GPU needed):  hipcc --offload-arch=gfx950 -O3 scripts/hbm_probe.hip -o avmoe_amd/lib/variants/hbm_probe
 //   run (GPU box):                avmoe_amd/lib/variants/hbm_probe [MiB per buffer, default 1024]
 #include <hip/hip_runtime.h>
@@ -39,6 +40,16 @@ __global__ void __launch_bounds__(256) k_seg(const u32x4* __restrict__ a, long n
   }
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) out[blockIdx.x] = 1u;
 }
+// the memory side of kf_mid_bwd without its arithmetic: two segment reads (a, d) and the segment write back into d
+__global__ void __launch_bounds__(256) k_seg3(const u32x4* __restrict__ a, u32x4* d, long n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const long rows = n / 32;
+  for (long r0 = (long)blockIdx.x * 16; r0 < rows; r0 += (long)gridDim.x * 16) {
+    const long o = (r0 + r) * 32 + wave * 4 + q;
+    const u32x4 x0 = a[o], x1 = a[o + 16], y0 = d[o], y1 = d[o + 16];
+    d[o] = x0 + y0; d[o + 16] = x1 + y1;
+  }
+}
 __global__ void __launch_bounds__(256) k_mix21(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ d, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = a[i] + b[i];
 }
@@ -52,19 +63,20 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&d, bytes)); CK(hipMalloc(&out, 1 << 20));
   CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes)); CK(hipMemset(d, 0, bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int grids[] = {256, 512, 1024, 2048, 4096, 16384};
-  printf("%ld MiB per buffer; GB/s of bytes moved (best of 5 per grid)\n%8s %10s %10s %10s %10s %10s %10s\n", mib, "blocks", "read", "write", "copy", "mix 2:1", "in place", "seg read");
+  const int grids[] = {256, 512, 768, 1024, 2048, 4096, 16384};
+  printf("%ld MiB per buffer; GB/s of bytes moved (best of 5 per grid)\n%8s %10s %10s %10s %10s %10s %10s %10s\n", mib, "blocks", "read", "write", "copy", "mix 2:1", "in place", "seg read", "seg 2r1w");
   for (int g : grids) {
-    double best[6] = {0, 0, 0, 0, 0, 0};
+    double best[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int rep = 0; rep < 6; ++rep) {
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 7; ++k) {
         CK(hipEventRecord(e0, 0));
         if (k == 0) hipLaunchKernelGGL(k_read, dim3(g), dim3(256), 0, 0, a, n, out);
         else if (k == 1) hipLaunchKernelGGL(k_write, dim3(g), dim3(256), 0, 0, d, n);
         else if (k == 2) hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, 0, a, d, n);
         else if (k == 3) hipLaunchKernelGGL(k_mix21, dim3(g), dim3(256), 0, 0, a, b, d, n);
         else if (k == 4) hipLaunchKernelGGL(k_inplace, dim3(g), dim3(256), 0, 0, a, d, n);
-        else hipLaunchKernelGGL(k_seg, dim3(g), dim3(256), 0, 0, a, n, out);
+        else if (k == 5) hipLaunchKernelGGL(k_seg, dim3(g), dim3(256), 0, 0, a, n, out);
+        else hipLaunchKernelGGL(k_seg3, dim3(g), dim3(256), 0, 0, a, d, n);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
         const double moved = (double)bytes * (k == 0 || k == 1 || k == 5 ? 1 : (k == 2 ? 2 : 3));
@@ -72,7 +84,7 @@ int main(int argc, char** argv) {
         if (rep > 0 && gbs > best[k]) best[k] = gbs;
       }
     }
-    printf("%8d %10.0f %10.0f %10.0f %10.0f %10.0f %10.0f\n", g, best[0], best[1], best[2], best[3], best[4], best[5]);
+    printf("%8d %10.0f %10.0f %10.0f %10.0f %10.0f %10.0f %10.0f\n", g, best[0], best[1], best[2], best[3], best[4], best[5], best[6]);
   }
   return 0;
 }
