@@ -334,52 +334,77 @@ __global__ void __launch_bounds__(256) kk_finish_dT(const float* dT, const float
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const int s = (int)(r / (Kcyb + Kcx)), q = (int)(r % (Kcyb + Kcx));
     float dot = 0.f;
+    const bool vec = (C & 3) == 0;                           // 16-byte loads, 8 / 16-byte stores
     if (q < Kcyb) {
-      for (int c = lane; c < C; c += 64) {
-        float v;
-        if (q < Kcy) v = dT[((long)s * KL + q) * C + c] + dtbar[(long)s * KL + q] / (float)C;
-        else v = rbw_drin[(long)s * 2 * C + C + c];                                    // dm2
-        v = roundTb<T>(v);
-        stT<T>(dTy, ((long)s * Kcyb + q) * C + c, v);
-        dot += v * rw[c];
+      T* dst = dTy + ((long)s * Kcyb + q) * C;
+      const float* src = q < Kcy ? dT + ((long)s * KL + q) * C : rbw_drin + (long)s * 2 * C + C;      // (row Kcy: dm2)
+      const float add = q < Kcy ? dtbar[(long)s * KL + q] / (float)C : 0.f;
+      if (vec) {
+        for (int c = 4 * lane; c < C; c += 256) {
+          const float4 x = *(const float4*)(src + c), w = *(const float4*)(rw + c);
+          const float4 v = make_float4(roundTb<T>(x.x + add), roundTb<T>(x.y + add), roundTb<T>(x.z + add), roundTb<T>(x.w + add));
+          st4T<T>(dst, c, v);
+          dot += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) {
+          const float v = roundTb<T>(src[c] + add);
+          stT<T>(dst, c, v);
+          dot += v * rw[c];
+        }
       }
       dot = wave_sum(dot);
       if (lane == 0) dabx[(long)s * Kcyb + q] = dot;
     } else {
       const int kx = q - Kcyb;
-      for (int c = lane; c < C; c += 64)
-        stT<T>(dTx, ((long)s * Kcx + kx) * C + c, dT[((long)s * KL + Kcy + kx) * C + c] + dtbar[(long)s * KL + Kcy + kx] / (float)C);
+      T* dst = dTx + ((long)s * Kcx + kx) * C;
+      const float* src = dT + ((long)s * KL + Kcy + kx) * C;
+      const float add = dtbar[(long)s * KL + Kcy + kx] / (float)C;
+      if (vec) {
+        for (int c = 4 * lane; c < C; c += 256) {
+          const float4 x = *(const float4*)(src + c);
+          st4T<T>(dst, c, make_float4(x.x + add, x.y + add, x.z + add, x.w + add));
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) stT<T>(dst, c, src[c] + add);
+      }
     }
   }
 }
 // Two independent sums over the frames in ONE launch:
-//   blocks [0, nb0): dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)   block = 64 columns x 4 frame streams (two loads in flight each),
-//                    combined through LDS in a fixed order
+//   blocks [0, nb0): dT0[kc][c] = sum_s (dT[s][kc][c] + dtbar[s][kc] / C)   block = 32 columns x 8 frame streams, eight frames of a
+//                    stream requested before the first add (a plain loop is one global round trip per frame), combined through LDS in
+//                    a fixed order
 //   the others:      drw[c] = sum_r dTy[r][c] abx[r] ; dbf[c] = sum_r dTy[r][c]   over the S*Kcyb rows r, first stage: block (channel
-//                    tile cx, chunk) -> rowpart[chunk][2][C] (a sum over the chunks follows)
+//                    tile cx, chunk) -> rowpart[chunk][2][C] (a sum over the chunks follows); eight rows in flight
 template <typename T>
 __global__ void __launch_bounds__(256) kk_dT0_dTy(const float* dT, const float* dtbar, float* dT0, int S, int KL, int C, int nb0,
                                                   const void* dTy_, const void* BmX_, const float* scal, float* rowpart, long rows,
                                                   int rows_per_chunk, int Kcy, int Kcyb, int Mb, int M) {
   if ((int)blockIdx.x < nb0) {
-    __shared__ float red[4][64];
+    __shared__ float red[8][32];
     const long n1 = (long)KL * C;
-    const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + l;
-    float a0 = 0.f, a1 = 0.f;
+    const int l = threadIdx.x & 31, u = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + l;
+    double acc = 0.0;
     if (i < n1) {
       const int kc = (int)(i / C);
       const float ic = 1.f / (float)C;
-      int s = u;
-      for (; s + 4 < S; s += 8) {
-        a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
-        a1 += dT[(long)(s + 4) * n1 + i] + dtbar[(long)(s + 4) * KL + kc] * ic;
+      for (int s0 = u; s0 < S; s0 += 8 * 8) {
+        float v[8], w[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const int s = min(s0 + 8 * x, S - 1);              // (clamped: the loads stay unconditional, the adds are masked)
+          v[x] = dT[(long)s * n1 + i]; w[x] = dtbar[(long)s * KL + kc];
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (s0 + 8 * x < S) acc += v[x] + w[x] * ic;
       }
-      for (; s < S; s += 4) a0 += dT[(long)s * n1 + i] + dtbar[(long)s * KL + kc] * ic;
     }
-    red[u][l] = a0 + a1;
+    red[u][l] = (float)acc;
     __syncthreads();
-    if (u == 0 && i < n1) dT0[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (u == 0 && i < n1) dT0[i] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
     return;
   }
   const T* dTy = (const T*)dTy_; const T* BmX = (const T*)BmX_;
@@ -389,49 +414,73 @@ __global__ void __launch_bounds__(256) kk_dT0_dTy(const float* dT, const float* 
   if (c >= C) return;
   const long r0 = (long)by * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float drw = 0.f, dbf = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    const int q = (int)(r % Kcyb);
-    const float v = ldT<T>(dTy, r * C + c);
-    const float ab = q < Kcy ? ldT<T>(BmX, r * Mb + M) : scal[0];
-    drw += v * ab; dbf += v;
+  const float s0 = scal[0];
+  for (long rb = r0; rb < r1; rb += 8) {
+    float v[8], ab[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const long r = min(rb + x, rows - 1);
+      v[x] = ldT<T>(dTy, r * C + c);
+      ab[x] = ldT<T>(BmX, r * Mb + M);
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      if (rb + x < r1) { const float a = (int)((rb + x) % Kcyb) < Kcy ? ab[x] : s0; drw += v[x] * a; dbf += v[x]; }
   }
   rowpart[((long)by * 2 + 0) * C + c] = drw;
   rowpart[((long)by * 2 + 1) * C + c] = dbf;
 }
-// ONE launch: blocks [0, rows): dBmT = T([dBm | dabx | 0]) (one block per (frame, latent row));  the others: the two sums over the
-// frames  dwbar[m] = sum_s dBm[s][Kcy][m]  and  dbcbar = sum_s dabx[s][Kcy]  (64 outputs x 4 frame streams per block, fixed order)
+// ONE launch: blocks [0, ncast): dBmT = T([dBm | dabx | 0]), the (frame, latent row) rows flattened -- four consecutive entries per thread
+// (16-byte loads where the row length allows), grid-stride;  the others: the two sums over the frames  dwbar[m] = sum_s dBm[s][Kcy][m]
+// and  dbcbar = sum_s dabx[s][Kcy]  -- 16 outputs x 16 frame streams per block, every stream's loads requested before the first add
+// (the walk over the frames is a chain of global round trips otherwise), combined through LDS in a fixed order
 template <typename T>
 __global__ void __launch_bounds__(256) kk_prep_dBm(const float* dBm, const float* dabx, void* dBmT_, float* dvec_wbar, int rows, int S, int Kcy,
-                                                   int Kcyb, int M, int Mb) {
+                                                   int Kcyb, int M, int Mb, int ncast) {
   T* dBmT = (T*)dBmT_;
-  if ((int)blockIdx.x < rows) {
-    const long row = blockIdx.x;
-    const int q = (int)(row % Kcyb);
-    const float* src = dBm + row * Mb;
-    T* dst = dBmT + row * Mb;
-    const float ab = q < Kcy ? dabx[row] : 0.f;
-    for (int m = threadIdx.x; m < Mb; m += 256) {
-      float v = 0.f;
-      if (q < Kcy) v = m < M ? src[m] : (m == M ? ab : 0.f);
-      stT<T>(dst, m, v);
+  if ((int)blockIdx.x < ncast) {
+    const long nq = (long)rows * (Mb / 4);                   // Mb % 4 == 0 (moe_plan.cpp: padded to 8)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)ncast * 256) {
+      const long row = i / (Mb / 4);
+      const int m = (int)(i - row * (Mb / 4)) * 4;
+      const int q = (int)(row % Kcyb);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < Kcy) {
+        if (m + 3 < M) v = *(const float4*)(dBm + row * Mb + m);
+        else {
+          const float ab = dabx[row];
+          float* e = (float*)&v;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) e[x] = m + x < M ? dBm[row * Mb + m + x] : (m + x == M ? ab : 0.f);
+        }
+      }
+      st4T<T>(dBmT, row * Mb + m, v);
     }
     return;
   }
-  __shared__ float red[4][64];
-  const int l = threadIdx.x & 63, u = threadIdx.x >> 6;
-  const int m = ((int)blockIdx.x - rows) * 64 + l;             // m < M: dwbar[m] ; m == Mb: dbcbar (dvec layout: [dwbar (Mb) | dbcbar])
-  float a0 = 0.f, a1 = 0.f;
-  if (m < M) {
-    const float* p = dBm + (long)Kcy * Mb + m;
-    int s = u;
-    for (; s + 4 < S; s += 8) { a0 += p[(long)s * Kcyb * Mb]; a1 += p[(long)(s + 4) * Kcyb * Mb]; }
-    if (s < S) a0 += p[(long)s * Kcyb * Mb];
-  } else if (m == Mb) {
-    for (int s = u; s < S; s += 4) a0 += dabx[(long)s * Kcyb + Kcy];
+  __shared__ float red[16][16];
+  const int l = threadIdx.x & 15, u = threadIdx.x >> 4;
+  const int m = ((int)blockIdx.x - ncast) * 16 + l;            // m < M: dwbar[m] ; m == Mb: dbcbar (dvec layout: [dwbar (Mb) | dbcbar])
+  double acc = 0.0;
+  if (m < M || m == Mb) {
+    const float* p = m < M ? dBm + (long)Kcy * Mb + m : dabx + Kcy;
+    const long st = m < M ? (long)Kcyb * Mb : (long)Kcyb;
+    for (int s0 = u; s0 < S; s0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] = s0 + 16 * x < S ? p[(long)(s0 + 16 * x) * st] : 0.f;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) acc += v[x];
+    }
   }
-  red[u][l] = a0 + a1;
+  red[u][l] = (float)acc;
   __syncthreads();
-  if (u == 0 && (m < M || m == Mb)) dvec_wbar[m] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  if (u == 0 && (m < M || m == Mb)) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][l];
+    dvec_wbar[m] = t;
+  }
 }
 // dqr[kc] = sum_{s,n} dL1 bc[n] ; dqb[kc] = sum_{s,n} dL1     (partials per (s,kc) row, then over s)
 template <typename T>
@@ -458,36 +507,49 @@ __global__ void __launch_bounds__(256) kk_hop1_vec(const void* T0T_, const float
   extern __shared__ float s_q[];                     // dqr [Kcyb] | dqb [Kcyb]
   const int cl = threadIdx.x & 63, pt = threadIdx.x >> 6;
   const long rows = (long)S * Kcyb;
-  for (int k0 = 0; k0 < Kcyb; k0 += 64) {            // 64 latent rows at a time
-    const int kc = k0 + cl;
-    float a0 = 0.f, a1 = 0.f;
-    if (kc < Kcyb) {
-      float b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;      // eight loads in flight: the walk over the frames is latency-bound
-      const float* p0 = part + kc; const float* p1 = part + rows + kc;
-      int s = pt;
-      for (; s + 12 < S; s += 16) {
-        a0 += p0[(long)s * Kcyb]; a1 += p1[(long)s * Kcyb]; b0 += p0[(long)(s + 4) * Kcyb]; b1 += p1[(long)(s + 4) * Kcyb];
-        c0 += p0[(long)(s + 8) * Kcyb]; c1 += p1[(long)(s + 8) * Kcyb]; d0 += p0[(long)(s + 12) * Kcyb]; d1 += p1[(long)(s + 12) * Kcyb];
+  for (int k0 = 0; k0 < Kcyb; k0 += 128) {           // 128 latent rows at a time: rows k0 + cl and k0 + 64 + cl, their loads in flight together
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};            // (sums of both signs over all frames: accumulated in double)
+    for (int s0 = pt; s0 < S; s0 += 4 * 8) {           // eight frames of this stream per trip: 32 loads requested before the first add
+      float v[2][2][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kc = min(k0 + 64 * h + cl, Kcyb - 1);   // (clamped: unconditional loads, masked adds)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const long o = (long)min(s0 + 4 * x, S - 1) * Kcyb + kc;
+          v[h][0][x] = part[o]; v[h][1][x] = part[rows + o];
+        }
       }
-      for (; s < S; s += 4) { a0 += p0[(long)s * Kcyb]; a1 += p1[(long)s * Kcyb]; }
-      a0 = (a0 + b0) + (c0 + d0); a1 = (a1 + b1) + (c1 + d1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (s0 + 4 * x < S) { acc[h][0] += v[h][0][x]; acc[h][1] += v[h][1][x]; }
     }
-    red[0][pt][cl] = a0; red[1][pt][cl] = a1;
-    __syncthreads();
-    if (pt == 0 && kc < Kcyb) {
-      const float q0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-      const float q1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-      s_q[kc] = q0; s_q[Kcyb + kc] = q1;
-      if (blockIdx.x == 0) { dqp_fin[kc] = q0; dqp_fin[Kcyb + kc] = q1; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kc = k0 + 64 * h + cl;
+      red[0][pt][cl] = (float)acc[h][0]; red[1][pt][cl] = (float)acc[h][1];
+      __syncthreads();
+      if (pt == 0 && kc < Kcyb) {
+        const float q0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        const float q1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        s_q[kc] = q0; s_q[Kcyb + kc] = q1;
+        if (blockIdx.x == 0) { dqp_fin[kc] = q0; dqp_fin[Kcyb + kc] = q1; }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   const int c = blockIdx.x * 64 + cl;
   float a0 = 0.f, a1 = 0.f;
   if (c < C)
-    for (int kc = pt; kc < Kcy; kc += 4) {
-      const float t = ldT<T>(T0T, (long)kc * C + c);
-      a0 += t * s_q[kc]; a1 += t * s_q[Kcyb + kc];
+    for (int kb = pt; kb < Kcy; kb += 4 * 8) {             // eight rows of T0 in flight
+      float t[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) t[x] = ldT<T>(T0T, (long)min(kb + 4 * x, Kcy - 1) * C + c);
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+        if (kb + 4 * x < Kcy) { a0 += t[x] * s_q[kb + 4 * x]; a1 += t[x] * s_q[Kcyb + kb + 4 * x]; }
     }
   red[0][pt][cl] = a0; red[1][pt][cl] = a1;
   __syncthreads();
@@ -685,7 +747,7 @@ int k_finish_dT(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
     const long nrows = (long)d.S * d.Kcyb;
     const int nchunk = (int)std::min<long>(512, std::max<long>(1, nrows / 8));      // (short serial chains per thread: 8 rows, or nrows / 512 when there are many)
     const int rpc = cdiv(nrows, nchunk);
-    const int nb0 = d.KL > 0 ? cdiv((long)d.KL * d.C, 64) : 0;
+    const int nb0 = d.KL > 0 ? cdiv((long)d.KL * d.C, 32) : 0;
     DISPATCH_T(d.bf16, kk_dT0_dTy, dim3((unsigned)(nb0 + cdiv(d.C, 256) * nchunk)), dim3(256), 0, st, (const float*)(scratch + pl.o_dT),
                (const float*)(scratch + pl.o_dtbar), (float*)(scratch + pl.o_dT0), d.S, d.KL, d.C, nb0, (const void*)(scratch + pl.o_dTy),
                (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_scal), (float*)(scratch + pl.o_rowpart), nrows, rpc,
@@ -702,8 +764,10 @@ int k_prep_dBm(const Plan& pl, char* scratch, hipStream_t st) {
   float* dvec = (float*)(scratch + pl.o_dvec);
   // dwbar (row Kcy of every frame's dBm), zero in the padding m >= M (dvec lies inside the backward's one memset: moe_plan.h) ; dbcbar
   const int rows = d.S * d.Kcyb;
-  DISPATCH_T(d.bf16, kk_prep_dBm, dim3((unsigned)(rows + cdiv(d.Mb + 1, 64))), dim3(256), 0, st, dBm, dabx, (void*)(scratch + pl.o_dBmT),
-             dvec + 2 * d.C, rows, d.S, d.Kcy, d.Kcyb, d.M, d.Mb);
+  if (d.Mb % 4) { set_last_error("prep_dBm: padded row length %d not a multiple of 4", d.Mb); return ERR_UNSUPPORTED; }
+  const int ncast = (int)std::min<long>(cdiv((long)rows * (d.Mb / 4), 256L), 4096);
+  DISPATCH_T(d.bf16, kk_prep_dBm, dim3((unsigned)(ncast + cdiv(d.Mb + 1, 16))), dim3(256), 0, st, dBm, dabx, (void*)(scratch + pl.o_dBmT),
+             dvec + 2 * d.C, rows, d.S, d.Kcy, d.Kcyb, d.M, d.Mb, ncast);
   AVMOE_CHECK_LAUNCH("prep_dBm");
   return OK;
 }

@@ -27,6 +27,22 @@ template <> __device__ __forceinline__ void stT<__bf16>(__bf16* p, long i, float
   ((unsigned short*)p)[i] = f2bf(v);
 }
 
+// four consecutive elements (index i a multiple of 4, base 16-byte aligned): one 16-byte / 8-byte access
+template <typename T> __device__ __forceinline__ float4 ld4T(const T* p, long i);
+template <> __device__ __forceinline__ float4 ld4T<float>(const float* p, long i) { return *(const float4*)(p + i); }
+template <> __device__ __forceinline__ float4 ld4T<__bf16>(const __bf16* p, long i) {
+  const u32x2_t u = *(const u32x2_t*)((const unsigned short*)p + i);
+  return make_float4(__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                     __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4T(T* p, long i, const float4& v);
+template <> __device__ __forceinline__ void st4T<float>(float* p, long i, const float4& v) { *(float4*)(p + i) = v; }
+template <> __device__ __forceinline__ void st4T<__bf16>(__bf16* p, long i, const float4& v) {
+  u32x2_t u;
+  u[0] = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16); u[1] = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+  *(u32x2_t*)((unsigned short*)p + i) = u;
+}
+
 // wave64 all-reduce (every lane gets the result)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -619,40 +619,70 @@ struct FinishTArgs {
   P16 tok; int e_of_lat[MAX_E];
   int S, C, K, Kp, KL, KLT, Kcy, Kcyb, Kcx, Mb, M, src, lat0;
 };
+// one WAVE per (frame, latent row): 16-byte accesses where C allows, the two row sums folded inside the wave (no block barriers --
+// with one short block per row the kernel was bound by block turnover, not by its bytes)
 template <typename T>
 __global__ void __launch_bounds__(256) kk_finish_T(FinishTArgs a, const float* TV, const void* BmX_, const float* rw, const float* bf,
-                                                   const float* scal, void* Text_, float* rin, float* Tsum) {
+                                                   const float* scal, void* Text_, float* rin, float* Tsum, int nrow) {
   const T* BmX = (const T*)BmX_;
   T* Text = (T*)Text_;
-  __shared__ float red[4];
+  const int lane = threadIdx.x & 63;
+  const int gr = blockIdx.x * 4 + (threadIdx.x >> 6);        // (frame, latent row)
+  if (gr >= nrow) return;
   const int rows = a.src == 0 ? a.Kcyb : a.Kcx;
-  const int s = blockIdx.x / rows, kr = blockIdx.x - s * rows;           // one block per (frame, latent row)
-  const float* tvr = TV + (long)blockIdx.x * a.C;
+  const int s = gr / rows, kr = gr - s * rows;
+  const float* tvr = TV + (long)gr * a.C;
+  const bool vec = (a.C & 3) == 0;
   if (a.src == 0 && kr == a.Kcy) {
-    for (int c = threadIdx.x; c < a.C; c += 256) rin[(long)s * 2 * a.C + a.C + c] = tvr[c] + scal[0] * rw[c] + bf[c];
+    float* dst = rin + (long)s * 2 * a.C + a.C;
+    const float s0 = scal[0];
+    if (vec) {
+      for (int c = 4 * lane; c < a.C; c += 256) {
+        const float4 t = *(const float4*)(tvr + c), r = *(const float4*)(rw + c), b = *(const float4*)(bf + c);
+        *(float4*)(dst + c) = make_float4(t.x + s0 * r.x + b.x, t.y + s0 * r.y + b.y, t.z + s0 * r.z + b.z, t.w + s0 * r.w + b.w);
+      }
+    } else {
+      for (int c = lane; c < a.C; c += 64) dst[c] = tvr[c] + s0 * rw[c] + bf[c];
+    }
     return;
   }
   const int slot = a.lat0 + kr / a.Kp, k = kr % a.Kp;
   const long trow = (long)s * a.KLT + (long)slot * a.Kp + k, trows = (long)a.S * a.KLT;
   T* out = Text + trow * a.C;
   if (k >= a.K) {                                    // padding rows of a slot stay exactly zero
-    for (int c = threadIdx.x; c < a.C; c += 256) stT<T>(out, c, 0.f);
-    if (threadIdx.x == 0) { Tsum[trow] = 0.f; Tsum[trows + trow] = 0.f; }
+    if (vec) { for (int c = 4 * lane; c < a.C; c += 256) st4T<T>(out, c, make_float4(0.f, 0.f, 0.f, 0.f)); }
+    else { for (int c = lane; c < a.C; c += 64) stT<T>(out, c, 0.f); }
+    if (lane == 0) { Tsum[trow] = 0.f; Tsum[trows + trow] = 0.f; }
     return;
   }
   const float* tok = a.tok.p[a.e_of_lat[slot]] + (long)k * a.C;
   const float ab = a.src == 0 ? ldT<T>(BmX, ((long)s * a.Kcyb + kr) * a.Mb + a.M) : 0.f;
-  float sm = 0.f, ss = 0.f;                          // row sum / sum of squares of the row AS STORED (the LayerNorm folds use the same numbers)
-  for (int c = threadIdx.x; c < a.C; c += 256) {
-    float v = tok[c] + tvr[c];
-    if (a.src == 0) v += ab * rw[c] + bf[c];
-    v = roundT<T>(v);
-    stT<T>(out, c, v);
-    sm += v; ss += v * v;
+  double sm = 0.0, ss = 0.0;                         // row sum / sum of squares of the row AS STORED (the LayerNorm folds use the same numbers); in double:
+                                                     // the variance the folds form from them is a difference of the two
+  if (vec) {
+    for (int c = 4 * lane; c < a.C; c += 256) {
+      const float4 tk = *(const float4*)(tok + c), tv = *(const float4*)(tvr + c);
+      float4 v = make_float4(tk.x + tv.x, tk.y + tv.y, tk.z + tv.z, tk.w + tv.w);
+      if (a.src == 0) {
+        const float4 r = *(const float4*)(rw + c), b = *(const float4*)(bf + c);
+        v.x += ab * r.x + b.x; v.y += ab * r.y + b.y; v.z += ab * r.z + b.z; v.w += ab * r.w + b.w;
+      }
+      v.x = roundT<T>(v.x); v.y = roundT<T>(v.y); v.z = roundT<T>(v.z); v.w = roundT<T>(v.w);
+      st4T<T>(out, c, v);
+      sm += ((double)v.x + v.y) + ((double)v.z + v.w); ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  } else {
+    for (int c = lane; c < a.C; c += 64) {
+      float v = tok[c] + tvr[c];
+      if (a.src == 0) v += ab * rw[c] + bf[c];
+      v = roundT<T>(v);
+      stT<T>(out, c, v);
+      sm += v; ss += (double)v * v;
+    }
   }
-  sm = block_sum256(sm, red);
-  ss = block_sum256(ss, red);
-  if (threadIdx.x == 0) { Tsum[trow] = sm; Tsum[trows + trow] = ss; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if (lane == 0) { Tsum[trow] = (float)sm; Tsum[trows + trow] = (float)ss; }
 }
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src, hipStream_t st) {
   const Dims& d = pl.d;
@@ -662,11 +692,9 @@ int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs&
   a.Mb = d.Mb; a.M = d.M; a.src = src; a.lat0 = src == 0 ? 0 : d.Ey;
   const int rows = src == 0 ? d.Kcyb : d.Kcx;
   if (rows <= 0) return OK;
-  const long total = (long)d.S * rows * d.C;
-  (void)total;
-  DISPATCH_T(d.bf16, kk_finish_T, dim3((unsigned)(d.S * rows)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_TV),
+  DISPATCH_T(d.bf16, kk_finish_T, dim3((unsigned)cdiv((long)d.S * rows, 4)), dim3(256), 0, st, a, (const float*)(scratch + pl.o_TV),
              (const void*)(saved + pl.o_BmX), (const float*)(saved + pl.o_rw), (const float*)prm.fc_b,
-             (const float*)(saved + pl.o_scal), (void*)(saved + pl.o_Text), (float*)(saved + pl.o_rin), (float*)(saved + pl.o_Tsum));
+             (const float*)(saved + pl.o_scal), (void*)(saved + pl.o_Text), (float*)(saved + pl.o_rin), (float*)(saved + pl.o_Tsum), d.S * rows);
   AVMOE_CHECK_LAUNCH("finish_T");
   return OK;
 }
