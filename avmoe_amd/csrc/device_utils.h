@@ -55,6 +55,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// the same for a double per lane (row statistics whose consumer takes a DIFFERENCE of sums: variance, softmax denominators)
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // block (256 threads) sum through LDS scratch of >= 4 floats; result valid in every thread
 __device__ __forceinline__ float block_sum256(float v, float* scratch4) {
   v = wave_sum(v);

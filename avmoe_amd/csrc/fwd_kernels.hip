@@ -603,12 +603,62 @@ __global__ void __launch_bounds__(256) kk_softmax_rows(const float* in, long row
     for (int j = lane; j < ld_out; j += 64) stT<T>(out, row * ld_out + j, j < n ? __expf(p[j] - mx) * inv : 0.f);
   }
 }
+// the same with the row in registers (NV 16-byte vectors per lane: rows of up to 256 NV entries, leading dimensions multiples of 4):
+// ONE pass over the logits, one exp per entry, 16-byte loads and 8 / 16-byte stores
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) kk_softmax_rows_reg(const float* in, long rows, int n, int ld_in, void* out_, int ld_out,
+                                                           int grp, int valid, int slot, int kvalid) {
+  T* out = (T*)out_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    T* o = out + row * ld_out;
+    if ((int)(row % grp) >= valid || (int)((row % grp) % slot) >= kvalid) {
+      for (int j = 4 * lane; j < ld_out; j += 256) st4T<T>(o, j, make_float4(0.f, 0.f, 0.f, 0.f));
+      continue;
+    }
+    const float* p = in + row * ld_in;
+    float4 v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = 4 * lane + 256 * k;
+      v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (j < ld_in) {                                        // (a whole vector lies inside the padded row: ld_in % 4 == 0)
+        v[k] = *(const float4*)(p + j);
+        if (j + 3 >= n) { float* e = (float*)&v[k]; for (int x = 0; x < 4; ++x) if (j + x >= n) e[x] = -INFINITY; }
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+    }
+    mx = wave_max(mx);
+    double smd = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k].x = __expf(v[k].x - mx); v[k].y = __expf(v[k].y - mx); v[k].z = __expf(v[k].z - mx); v[k].w = __expf(v[k].w - mx);   // exp(-inf) = 0: the padding
+      smd += ((double)v[k].x + v[k].y) + ((double)v[k].z + v[k].w);
+    }
+    const float inv = (float)(1.0 / wave_sum_d(smd));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = 4 * lane + 256 * k;
+      if (j < ld_out) st4T<T>(o, j, make_float4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv));
+    }
+  }
+}
 int k_softmax_rows(int bf16_out, const float* in, long rows, int n, int ld_in, void* out, int ld_out, int grp, int valid,
                    int slot, int kvalid, hipStream_t st) {
   ProfScope ps_("k_softmax_rows", 0.0, 0.0, st);
   if (rows <= 0) return OK;
-  DISPATCH_T(bf16_out, kk_softmax_rows, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, in, rows,
-             n, ld_in, out, ld_out, grp, valid, slot, kvalid);
+  const dim3 grid((unsigned)std::min<long>((rows + 3) / 4, 8192));
+  const bool reg = ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out <= ld_in && n <= 4096;
+  if (reg && n <= 1024) {
+    if (bf16_out) hipLaunchKernelGGL((kk_softmax_rows_reg<__bf16, 4>), grid, dim3(256), 0, st, in, rows, n, ld_in, out, ld_out, grp, valid, slot, kvalid);
+    else hipLaunchKernelGGL((kk_softmax_rows_reg<float, 4>), grid, dim3(256), 0, st, in, rows, n, ld_in, out, ld_out, grp, valid, slot, kvalid);
+  } else if (reg) {
+    if (bf16_out) hipLaunchKernelGGL((kk_softmax_rows_reg<__bf16, 16>), grid, dim3(256), 0, st, in, rows, n, ld_in, out, ld_out, grp, valid, slot, kvalid);
+    else hipLaunchKernelGGL((kk_softmax_rows_reg<float, 16>), grid, dim3(256), 0, st, in, rows, n, ld_in, out, ld_out, grp, valid, slot, kvalid);
+  } else {
+    DISPATCH_T(bf16_out, kk_softmax_rows, grid, dim3(256), 0, st, in, rows, n, ld_in, out, ld_out, grp, valid, slot, kvalid);
+  }
   AVMOE_CHECK_LAUNCH("softmax_rows");
   return OK;
 }
@@ -680,8 +730,7 @@ __global__ void __launch_bounds__(256) kk_finish_T(FinishTArgs a, const float* T
       sm += v; ss += (double)v * v;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); ss += __shfl_xor(ss, o, 64); }
+  sm = wave_sum_d(sm); ss = wave_sum_d(ss);
   if (lane == 0) { Tsum[trow] = (float)sm; Tsum[trows + trow] = (float)ss; }
 }
 int k_finish_T(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, int src, hipStream_t st) {

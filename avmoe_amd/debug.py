@@ -41,7 +41,11 @@ def relu_masks(module) -> Dict[str, torch.Tensor]:
     st = module.__dict__.get("_last_saved")
     if st is None:
         raise capi.AvmoeError("relu_masks: call keep_saved(module) before the forward")
-    desc, saved = st
+    return relu_masks_of(*st)
+
+
+def relu_masks_of(desc, saved) -> Dict[str, torch.Tensor]:
+    """The same from a descriptor and the `saved` workspace (uint8 tensor) a forward call through the C ABI filled."""
     table, E, NT, DZ, g, dgp, zsz = _layout(desc)
     torch.cuda.synchronize(saved.device)
 

@@ -136,6 +136,23 @@ def test_midsize_matches_oracle_fp32(name):
     errs = grad_errors(got, t)
     gmax = max(s for _, s in errs.values())
     bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax)}
+    if bad and cfg.E_m:
+        # Kink-aware second look (as bench.py's parity leg): a ReLU unit whose pre-activation lies within rounding of zero falls on
+        # either side of the kink by rounding -- in the oracle as much as here -- and moves the token row it belongs to by a percent.
+        # The oracle is re-run with the mask the HIP path used; the units that differ must be a handful, all of them rounding-sized.
+        from avmoe_amd import debug as dbg
+        masks, rec = dbg.relu_masks_of(run.desc, run.saved), {}
+        _fwd2, grads2 = O.moe_forward_backward(P, B, X, Y, cfg, G, training=training, lb_weight=lbw, mha_keep=keep, relu_masks=masks, record=rec)
+        nflip, worst = 0, 0.0
+        for pre, z in rec.items():
+            flip = (z > 0) != masks[pre]
+            nflip += int(flip.sum())
+            if bool(flip.any()):
+                worst = max(worst, float(z[flip].abs().max() / z.pow(2).mean().sqrt()))
+        assert 0 < nflip <= 8 and worst < 1e-5, (nflip, worst, bad)
+        errs = grad_errors(got, {f"grad.{k}": v for k, v in grads2.items()})
+        gmax = max(s for _, s in errs.values())
+        bad = {k: (e, s) for k, (e, s) in errs.items() if e > 1e-3 * max(s, 1e-3 * gmax)}
     assert not bad, bad
     assert run.guards_intact(), "a kernel wrote past its workspace"
 
