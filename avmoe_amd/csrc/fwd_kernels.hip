@@ -191,7 +191,15 @@ __device__ __forceinline__ void prep_rw(const PrepAllArgs& a, float* rw, int bx)
   const int c = bx * 4 + wave;
   if (c >= a.C) return;
   float s = 0.f;
-  for (int y = lane; y < a.Cy; y += 64) s += roundT<T>(a.Wf[(long)c * a.Cy + y]);
+  const float* row = a.Wf + (long)c * a.Cy;
+  for (int y0 = lane; y0 < a.Cy; y0 += 64 * 8) {            // eight loads requested before the first add (same order of additions)
+    float v[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = row[min(y0 + 64 * x, a.Cy - 1)];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      if (y0 + 64 * x < a.Cy) s += roundT<T>(v[x]);
+  }
   s = wave_sum(s);
   if (lane == 0) rw[c] = s;
 }
@@ -545,7 +553,14 @@ __global__ void __launch_bounds__(256) kk_qrqb_fill(const void* T0T_, const floa
     const int kc = blockIdx.x * 4 + wave;
     if (kc >= Kcy) return;
     float a = 0.f, b = 0.f;
-    for (int c = lane; c < C; c += 64) { const float t = ldT<T>(T0T, (long)kc * C + c); a += t * rw[c]; b += t * bf[c]; }
+    for (int c0 = lane; c0 < C; c0 += 64 * 8) {              // eight channels requested before the first add (same order of additions)
+      float t[8], r[8], f[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { const int c = min(c0 + 64 * x, C - 1); t[x] = ldT<T>(T0T, (long)kc * C + c); r[x] = rw[c]; f[x] = bf[c]; }
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+        if (c0 + 64 * x < C) { a += t[x] * r[x]; b += t[x] * f[x]; }
+    }
     a = wave_sum(a); b = wave_sum(b);
     if (lane == 0) { qrqb[kc] = a; qrqb[Kcy + kc] = b; }
     const int padw = Mk - M;
