@@ -432,8 +432,10 @@ class Workload:
                     out_a, _ = a(xa, xv)                   # net_trans_v3.py:695
                     out_v, _ = v(xv, xa)                   # net_trans_v3.py:697
                 torch.autograd.backward([out_a, out_v] + extra, [w["ga4"], w["gv4"]] + [None] * len(extra))
-            w["f_a"].grad = None
-            w["f_v"].grad = None
+                # the pairs of a shape share the synthetic inputs, not the modules: every pair's input gradients are its own (in the
+                # model they flow into different layers), so they are dropped here instead of being summed over the pairs
+                w["f_a"].grad = None
+                w["f_v"].grad = None
         reducer.finish()
         reducer.zero_grad()
 
