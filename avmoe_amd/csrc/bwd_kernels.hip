@@ -654,11 +654,32 @@ __global__ void __launch_bounds__(256) kk_xrstats(const void* X_, const void* R_
     if (lane == 0) { out[row] = s0; out[rows + row] = s1; out[2 * rows + row] = s2; }
   }
 }
+// the same for C % 4 == 0: 16 lanes per row, four consecutive entries per lane and access (rows of 96 - 192 channels: a wave per row
+// leaves most of its lanes idle)
+template <typename T>
+__global__ void __launch_bounds__(256) kk_xrstats_v4(const void* X_, const void* R_, long rows, int C, float* out) {
+  const T* X = (const T*)X_; const T* R = (const T*)R_;
+  const int l = threadIdx.x & 15;
+  for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < rows; row += (long)gridDim.x * 16) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = 4 * l; c < C; c += 64) {
+      const float4 x = ld4T<T>(X, row * C + c), v = ld4T<T>(R, row * C + c);
+      s0 += (v.x + v.y) + (v.z + v.w); s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); s2 += (x.x * v.x + x.y * v.y) + (x.z * v.z + x.w * v.w);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (l == 0) { out[row] = s0; out[rows + row] = s1; out[2 * rows + row] = s2; }
+  }
+}
 int k_xrstats(const Plan& pl, const void* X, char* saved, int slot, hipStream_t st) {
   ProfScope ps_("k_xrstats", 0.0, 0.0, st);
   const Dims& d = pl.d;
-  DISPATCH_T(d.bf16, kk_xrstats, dim3((unsigned)std::min<long>((d.NT + 3) / 4, 8192)), dim3(256), 0, st, X,
-             (const void*)(saved + pl.o_xr + (size_t)slot * d.NT * d.C * d.esz), (long)d.NT, d.C, (float*)(saved + pl.o_sxr) + (size_t)slot * 3 * d.NT);
+  if (d.C % 4 == 0)
+    DISPATCH_T(d.bf16, kk_xrstats_v4, dim3((unsigned)std::min<long>((d.NT + 15) / 16, 16384)), dim3(256), 0, st, X,
+               (const void*)(saved + pl.o_xr + (size_t)slot * d.NT * d.C * d.esz), (long)d.NT, d.C, (float*)(saved + pl.o_sxr) + (size_t)slot * 3 * d.NT);
+  else
+    DISPATCH_T(d.bf16, kk_xrstats, dim3((unsigned)std::min<long>((d.NT + 3) / 4, 8192)), dim3(256), 0, st, X,
+               (const void*)(saved + pl.o_xr + (size_t)slot * d.NT * d.C * d.esz), (long)d.NT, d.C, (float*)(saved + pl.o_sxr) + (size_t)slot * 3 * d.NT);
   AVMOE_CHECK_LAUNCH("xrstats");
   return OK;
 }
@@ -669,6 +690,18 @@ __global__ void kk_nxn_axpy(const void* X_, const void* R_, const float* dsr, lo
   const T* X = (const T*)X_; const T* R = (const T*)R_;
   T* dxr = (T*)dxr_; T* dX = (T*)dX_;
   const long total = NT * C;
+  if ((C & 3) == 0) {                                        // four consecutive entries of a row per thread and access
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 1024) {
+      const long t = i / C;
+      const float d0 = dsr[t], d2 = dsr[2 * NT + t];
+      const float4 a = ld4T<T>(dxr, i), x = ld4T<T>(X, i), o = ld4T<T>(dX, i), r = ld4T<T>(R, i);
+      const float4 g = make_float4(roundTb<T>(a.x + d2 * x.x + d0), roundTb<T>(a.y + d2 * x.y + d0), roundTb<T>(a.z + d2 * x.z + d0), roundTb<T>(a.w + d2 * x.w + d0));
+      st4T<T>(dxr, i, g);
+      const float4 sub = replaces ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+      st4T<T>(dX, i, make_float4(o.x + d2 * r.x - sub.x, o.y + d2 * r.y - sub.y, o.z + d2 * r.z - sub.z, o.w + d2 * r.w - sub.w));
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long t = i / C;
     const float d0 = dsr[t], d2 = dsr[2 * NT + t];
@@ -721,10 +754,18 @@ __global__ void __launch_bounds__(256) kk_nxn_rowdot(const void* X_, const float
   const int l = threadIdx.x & 15;
   for (long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (long)gridDim.x * 16) {
     float acc = 0.f;
-    for (int c = l; c < C; c += 16) {
-      const float yv = y[r * C + c];
-      acc += ldT<T>(X, r * C + c) * yv;
-      stT<T>(dX, r * C + c, ldT<T>(dX, r * C + c) + yv);
+    if ((C & 3) == 0) {                                      // four consecutive entries per lane and access
+      for (int c = 4 * l; c < C; c += 64) {
+        const float4 yv = *(const float4*)(y + r * C + c), x = ld4T<T>(X, r * C + c), o = ld4T<T>(dX, r * C + c);
+        acc += (x.x * yv.x + x.y * yv.y) + (x.z * yv.z + x.w * yv.w);
+        st4T<T>(dX, r * C + c, make_float4(o.x + yv.x, o.y + yv.y, o.z + yv.z, o.w + yv.w));
+      }
+    } else {
+      for (int c = l; c < C; c += 16) {
+        const float yv = y[r * C + c];
+        acc += ldT<T>(X, r * C + c) * yv;
+        stT<T>(dX, r * C + c, ldT<T>(dX, r * C + c) + yv);
+      }
     }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) acc += __shfl_xor(acc, o, 64);

@@ -216,6 +216,13 @@ __device__ __forceinline__ void prep_wbar(const PrepAllArgs& a, float* wbar, int
   if (m < a.M) {
     const float* p = a.Wc + m;
     int n = k;
+    for (; n + 31 * 16 < a.N; n += 32 * 16) {                 // long columns (N in the thousands): 32 loads requested before the first add
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = p[(long)(n + 16 * u) * a.M];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc[u & 7] += v[u];        // (accumulator u & 7 takes rows n + 16 u: the same partition and order as below)
+    }
     for (; n + 7 * 16 < a.N; n += 8 * 16) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] += p[(long)(n + 16 * u) * a.M];
