@@ -49,9 +49,10 @@ def release_workspaces():
     _SCRATCH.clear()
 
 
-def _scratch(dev: torch.device, nbytes: int) -> torch.Tensor:
-    """Transient workspace per (device, stream), grown on demand and reused (its users are ordered by that stream)."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+def _scratch(dev: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
+    """Transient workspace per (device, stream), grown on demand and reused (its users are ordered by that stream).
+    slot: a second workspace on the same stream (AdapterPair.same_stream interleaves the sections of two sites on ONE stream)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, slot)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -112,7 +113,7 @@ class _SiteBackward:
     writer of dX, 4: every writer of dY), in this order.  finish() returns the parameter gradients in `names` order (None where not needed,
     or for all of them when a gradient sink took them)."""
 
-    def __init__(self, module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False):
+    def __init__(self, module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False, scratch_slot=0):
         self.L = capi.lib()
         (desc, keep), self.saved, self.X, self.Y = state
         self.desc, self.names, self.module = desc, names, module
@@ -142,7 +143,7 @@ class _SiteBackward:
         self.lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
         wkey = (desc.S, desc.N, desc.M, self.X.dtype, bool(desc.training))
         sizes = module.__dict__.get("_ws_sizes", {}).get(wkey)
-        self.scratch = _scratch(self.X.device, sizes[1] if sizes else self.L.avmoe_moe_scratch_bytes(C.byref(desc)))
+        self.scratch = _scratch(self.X.device, sizes[1] if sizes else self.L.avmoe_moe_scratch_bytes(C.byref(desc)), scratch_slot)
         self.dX, self.dY, self.acc = dX, dY, (int(acc_dx), int(acc_dy))
 
     def run(self, parts=0):
@@ -215,6 +216,9 @@ class _PairFunction(torch.autograd.Function):
         ctx.lean = len(params) == 1 and na > 1
         if ctx.lean:
             pa, pb = tuple(site_a._param_tensors().values()), tuple(site_b._param_tensors().values())
+            # autograd's saved-tensor checks see the anchor only: remember which memory and which version every other parameter
+            # had, the backward re-fetches them by name and refuses to run on anything else
+            ctx.pstamp = tuple((t.data_ptr(), t._version) for t in pa + pb)
         else:
             pa, pb = params[:na], params[na:]
         Xa, Xb = Xa.contiguous(), Xb.contiguous()
@@ -267,6 +271,9 @@ class _PairFunction(torch.autograd.Function):
             if getattr(site_a, "_grad_sink", None) is None or getattr(site_b, "_grad_sink", None) is None:
                 raise capi.AvmoeError("AdapterPair: the gradient sink of a site was detached between its forward and its backward")
             params = tuple(site_a._param_tensors().values()) + tuple(site_b._param_tensors().values())
+            if tuple((t.data_ptr(), t._version) for t in params) != ctx.pstamp:
+                raise capi.AvmoeError("AdapterPair: a parameter of the pair was replaced or modified in place between the forward and "
+                                      "its backward (optimizer step / load_state_dict between micro-steps, or a retained graph)")
             needs_a, needs_b = (True,) * na, (True,) * len(names_b)
         else:
             needs_a, needs_b = ctx.needs_input_grad[10:10 + na], ctx.needs_input_grad[10 + na:]
@@ -281,8 +288,10 @@ class _PairFunction(torch.autograd.Function):
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
             ev_a, ev_b, ev_fork, ev_join = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
             ev_fork.record(main); side.wait_event(ev_fork)
+            slot_b = 1 if side.cuda_stream == main.cuda_stream else 0      # (same_stream: the two sites' sections interleave on ONE stream)
             with torch.cuda.stream(side):
-                cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, d_lbb, gXb, gXa, acc_dx=False, acc_dy=True).run(3)
+                cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, d_lbb, gXb, gXa, acc_dx=False, acc_dy=True,
+                                    scratch_slot=slot_b).run(3)
                 ev_b.record(side)
                 cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
             cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, d_lba, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
@@ -629,6 +638,10 @@ class AdapterPair(nn.Module):
             raise ValueError(f"AdapterPair: the two sites have different signatures ({site_a.variant} / {site_b.variant})")
         splittable = all(m._self_attn() != "v2" for m in (site_a, site_b))
         self.concurrent, self._side, self._events = bool(concurrent) and splittable, None, None
+        # same_stream (measurement aid, bench.py's per-launch profiling pass): the two-stream SCHEDULE -- every kernel in the variant
+        # the concurrent mode launches (dX overwrites, dY adds behind the other site's dX) -- issued on the caller's stream alone,
+        # so that an event bracket around a launch measures that launch and not the other stream's kernels
+        self.same_stream = False
         self.variant = site_a.variant
         self.site_a, self.site_b = site_a, site_b
 
@@ -651,7 +664,7 @@ class AdapterPair(nn.Module):
         if self.variant == "avs" and is_training:                             # PVT_AVSModel_v2.py:294-296
             noises = tuple(torch.randn(x.shape[0], m.num_multimodal_experts + m.num_singlemodal_experts, device=x.device,
                                        dtype=torch.float32) * 0.01 for m, x in ((self.site_a, x_a), (self.site_b, x_b)))
-        side = (self._side,) + self._events if self.concurrent else None
+        side = ((torch.cuda.current_stream(x_a.device) if self.same_stream else self._side,) + self._events) if self.concurrent else None
         # With a gradient sink on both sites (avmoe_amd.dp.AdapterGradReducer(sites=...)) and every parameter trainable, the backward
         # writes the parameter gradients into the reducer's buckets and autograd gets None for them anyway: ONE anchor parameter
         # then stands in for the ~120 of the pair (unwrapping, saving and returning a gradient slot for each of them is a third of

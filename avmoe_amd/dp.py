@@ -23,6 +23,7 @@ reference semantics and are kept; only the gradient reduction is re-designed:
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
@@ -46,6 +47,7 @@ class _Bucket:
         self.flat = None
         self.pending = 0
         self.work = None
+        self.seen = set()                                # hooked parameters that have reported since arm()
 
     def add_param(self, p):
         self.params.append(p); self.offsets.append(self.size)
@@ -70,6 +72,7 @@ class _Bucket:
     def arm(self):
         self.pending = len(self.sinks) + self.hooked
         self.work = None
+        self.seen.clear()
 
 
 class _SiteSink:
@@ -80,9 +83,12 @@ class _SiteSink:
         self.names, self.offsets, self.total = site.grad_layout(ALIGN)
         assert self.total == total
         self.bucket, self.reducer, self.fresh = bucket, reducer, True
+        self.site = site
         self.base = base
         self.flat = None                                 # the slice (set once the bucket's memory exists)
         self.calls = 0                                   # forward calls of the site still waiting for their backward
+        self.reported = False                            # counted against the bucket's `pending` since the last begin()
+        self.stale = False                               # the slice still holds the PREVIOUS optimizer step's gradient (lazy zero_grad)
         self.event = None                                # recorded on the stream the site's last backward ran on
         self._ev = None
 
@@ -94,6 +100,7 @@ class _SiteSink:
 
     def done(self):
         self.fresh = False
+        self.stale = False
         self.calls -= 1
         if self.calls <= 0:
             if self.flat.is_cuda:                        # the bucket's collective must wait for THIS stream's writes, whichever
@@ -101,7 +108,7 @@ class _SiteSink:
                     self._ev = torch.cuda.Event()        # two different streams).  One event per sink, re-recorded every step.
                 self.event = self._ev
                 self.event.record(torch.cuda.current_stream(self.flat.device))
-            self.reducer._reported(self.bucket)
+            self.reducer._sink_reported(self)
 
 
 class AdapterGradReducer:
@@ -126,6 +133,12 @@ class AdapterGradReducer:
         if average not in ("auto", "optimizer"):
             raise ValueError("average must be 'auto' or 'optimizer'")
         params = list(params)
+        # a reducer built earlier over the same sites / parameters lets go of them first (its hooks would keep firing otherwise)
+        for owner in list(sites or []) + params:
+            ref = getattr(owner, "_avmoe_reducer_ref", None)
+            old = ref() if ref is not None else None
+            if old is not None and old is not self:
+                old.close()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
@@ -160,6 +173,7 @@ class AdapterGradReducer:
             sink = _SiteSink(site, cur, base, total, self)
             cur.sinks.append(sink)
             site._grad_sink = sink
+            site._avmoe_reducer_ref = weakref.ref(self)
             self.sinks.append(sink)
             owned.update(id(p) for p in sp)
             device = sp[0].device
@@ -174,6 +188,7 @@ class AdapterGradReducer:
             cur.add_param(p)
             device = p.device
         self._owner = {}
+        self._hooks = []
         for b in self.buckets:
             b.materialize(b.params[0].device if b.params else device)
             for s in b.sinks:
@@ -181,8 +196,11 @@ class AdapterGradReducer:
             if b.hooked:                                 # a bucket holds either site slices (their sinks report) or plain parameters
                 for p in b.params:
                     self._owner[p] = b
-                    p.register_post_accumulate_grad_hook(self._hook)
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
+                    p._avmoe_reducer_ref = weakref.ref(self)
         self._sync = True
+        self.time_exposed = False                        # measurement aid: event-time what finish() waits for (exposed_ms)
+        self._exposed = []
         self.begin(True)
 
     # ---- launching ------------------------------------------------------------------------------------------------
@@ -195,10 +213,27 @@ class AdapterGradReducer:
         op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
         b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
 
-    def _reported(self, b):
-        b.pending -= 1
-        if b.pending <= 0 and self._sync and self.world > 1 and b.work is None:
+    def _late(self, b):
+        # a gradient arriving after the bucket's collective went out would be written under the in-flight all-reduce and
+        # never be reduced: fail loudly (every backward of a sync step but the last belongs in begin(sync=False) micro-steps)
+        if b.work is not None:
+            raise RuntimeError("AdapterGradReducer: a gradient was produced after its bucket's all-reduce had been launched "
+                               "(a second backward in one begin(sync=True) step?) -- run all but the last backward under "
+                               "begin(sync=False)")
+
+    def _maybe_launch(self, b):
+        # a bucket goes out when every sink / hooked parameter has reported ONCE since begin() and no site of it still owes a
+        # backward (a site may report several times: forward + backward twice in sequence, or two backward passes)
+        if b.pending <= 0 and self._sync and self.world > 1 and b.work is None and all(s.calls <= 0 for s in b.sinks):
             self._launch(b)
+
+    def _sink_reported(self, s):
+        b = s.bucket
+        self._late(b)
+        if not s.reported:
+            s.reported = True
+            b.pending -= 1
+        self._maybe_launch(b)
 
     def _hook(self, p):
         b = self._owner[p]
@@ -209,7 +244,11 @@ class AdapterGradReducer:
                     b.flat[off:off + p.numel()].view_as(p).copy_(p.grad)
                     p.grad = b.flat[off:off + p.numel()].view_as(p)
                     break
-        self._reported(b)
+        self._late(b)
+        if id(p) not in b.seen:
+            b.seen.add(id(p))
+            b.pending -= 1
+        self._maybe_launch(b)
 
     def begin(self, sync: bool = True):
         self._sync = sync
@@ -217,23 +256,71 @@ class AdapterGradReducer:
             b.arm()
         for s in self.sinks:
             s.calls = 0
+            s.reported = False
             s.event = None
 
     def finish(self):
+        if self._sync:
+            for s in self.sinks:                     # lazy zero_grad: a site that received no gradient this step contributes zeros,
+                if s.stale:                          # not what the previous step left in its slice
+                    s.flat.zero_()
+                    s.stale = False
         if not self._sync or self.world == 1:
             return
+        timed = self.time_exposed and self.buckets[0].flat.is_cuda
+        if timed:                                    # what the compute stream still has to wait for once the backward is enqueued
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for b in self.buckets:
             if b.work is None:                       # a site / parameter received no gradient this step: reduce anyway
                 self._launch(b)
             b.work.wait()
             if self._divide:
                 b.flat.div_(self.world)
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
 
-    def zero_grad(self):
+    def exposed_ms(self) -> List[float]:
+        """per finish() call since `time_exposed` was switched on: milliseconds the caller's stream spent between the end of the
+        enqueued backward and the last bucket's all-reduce (the part of the exchange the backward did not hide).  Synchronises."""
+        out = []
+        for e0, e1 in self._exposed:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        self._exposed = []
+        return out
+
+    def zero_grad(self, lazy: bool = False):
+        """lazy=False: every bucket is filled with zeros (one fill kernel per bucket).  lazy=True: buckets made of site slices
+        only are NOT filled -- the next backward of a site OVERWRITES its whole slice (`fresh`; the alignment padding between the
+        parameters is never written by anybody and stays zero), so the fill is a launch and a pass for nothing; until then
+        `param.grad` of those sites still shows the previous step's values, and a site that gets no backward in the next sync
+        step is zeroed by finish() before the collective goes out.  Needs finish() to be called every step (as documented)."""
         for b in self.buckets:
-            b.flat.zero_()
+            if not (lazy and b.sinks and not b.hooked):
+                b.flat.zero_()
         for s in self.sinks:
             s.fresh = True                               # the next backward of the site overwrites instead of adding
+            s.stale = bool(lazy and not s.bucket.hooked)
+
+    def close(self):
+        """Detach from the parameters: removes the autograd hooks and the sites' gradient sinks (a second reducer built over
+        the same parameters would otherwise keep firing this one's hooks and launch collectives on its stale buckets)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for s in self.sinks:
+            site = getattr(s, "site", None)
+            if site is not None and getattr(site, "_grad_sink", None) is s:
+                del site._grad_sink
+        self.sinks = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def message_bytes(self) -> int:
         return sum(b.flat.numel() * 4 for b in self.buckets)

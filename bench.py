@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
-ROUND = "r03"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
+ROUND = "r04"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
 
 # ---- workloads --------------------------------------------------------------------------------
 # a site pair: (C_a, N_a, C_v, N_v, count) -- `count` identical pairs (block pairs of the stage x positions p1, p2)
@@ -350,6 +350,27 @@ def parity_check(c, material, device, pair_mode="concurrent"):
         for row in sorted(detail, key=lambda r: -r[2])[:25]:
             print("parity %-4s %-46s err %.3e" % row[:3], file=sys.stderr)
     res["checked_against"] = "oracle/avmoe_oracle.py (pinned on the reference's vectors: tests/test_oracle_golden.py)"
+    return parity_verdict(res)
+
+
+# The bars of the parity leg (the same numbers the -m gpu tests assert).  HARD ones fail the run (non-zero exit AFTER the line is
+# printed): the fp32 path is the one held to north_star's 1e-3, indices are bit-exact, and a bf16 output off by more than the test
+# bound is a bug (round 3: a run-to-run blip of the cfg-3 forward went unnoticed because this leg only printed numbers).  The bf16
+# gradient bar is reported as `ok_bf16_grads` (SOFT: bf16 activations have an error budget of their own).
+PARITY_BARS = dict(out_rel_f32=1e-3, grad_rel_f32=1e-3, out_rel_bf16=1e-2, grad_relnorm_bf16_same_mask=5e-2)
+
+
+def parity_verdict(res):
+    """adds ok / ok_bf16_grads / failed (list of the keys above their bar) to a parity object"""
+    failed = [] if res.get("idx_equal", True) else ["idx_equal"]
+    for k in ("out_rel_f32", "grad_rel_f32", "out_rel_bf16"):
+        if res.get(k) is not None and not (res[k] <= PARITY_BARS[k]):
+            failed.append(k)
+    soft = res.get("grad_relnorm_bf16_same_mask")
+    res["ok"] = not failed
+    res["ok_bf16_grads"] = None if soft is None else bool(soft <= PARITY_BARS["grad_relnorm_bf16_same_mask"])
+    res["failed"] = failed
+    res["bars"] = PARITY_BARS
     return res
 
 
@@ -393,14 +414,16 @@ class Workload:
         params = [p for m in sites for p in m.parameters()]
         self.reducer = AdapterGradReducer(params, bucket_mb=64.0, sites=sites)
 
-    def set_concurrent(self, on):
-        """two-stream / one-stream execution of every AdapterPair of the workload; returns the previous setting"""
+    def set_same_stream(self, on):
+        """every AdapterPair of the workload keeps its mode's SCHEDULE (two-stream mode: dX overwrites, dY adds behind the other
+        site's dX -- the kernel variants of the timed region) but issues it on the caller's stream alone (AdapterPair.same_stream):
+        an event bracket around a launch then measures that launch, not the other stream's kernels.  Returns the previous setting."""
         prev = False
         for w in self.work:
             for _a, _v, pr in w["mods"]:
                 if pr is not None:
-                    prev = prev or pr.concurrent
-                    pr.concurrent = bool(on) and pr.site_a._self_attn() != "v2" and pr.site_b._self_attn() != "v2"
+                    prev = prev or pr.same_stream
+                    pr.same_stream = bool(on)
         return prev
 
     def step(self, sync=True):
@@ -437,7 +460,7 @@ class Workload:
                 w["f_a"].grad = None
                 w["f_v"].grad = None
         reducer.finish()
-        reducer.zero_grad()
+        reducer.zero_grad(lazy=True)           # site slices are overwritten by the next backward: no fill launch (dp.py)
 
     def timed(self, steps, warmup):
         """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over the ranks."""
@@ -478,7 +501,8 @@ def path_roofline(c, esz, dtype, value, world):
     return dict(bound="hbm", achieved=round(path_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(path_gbs / HBM_PEAK_GBS, 4), traffic=None,
                 level="path (SURVEY 8d): algorithmic bytes per clip-pair x clip-pairs/s per GPU",
                 algorithmic_bytes_per_clip_pair=round(abytes), algorithmic_bytes_per_step=round(abytes * c["B"]),
-                mfma=dict(achieved=round(path_tfs, 1), peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s", frac=round(path_tfs / MFMA_PEAK_TF[dtype], 4),
+                mfma_frac=round(path_tfs / MFMA_PEAK_TF[dtype], 4), mfma_tflops=round(path_tfs, 1),
+                mfma_detail=dict(achieved=round(path_tfs, 1), peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s", frac=round(path_tfs / MFMA_PEAK_TF[dtype], 4),
                           reference_flops_per_clip_pair=round(rflops),
                           note="FLOPs of the reference's formulation (SURVEY 8d); the factorised path executes fewer"))
 
@@ -570,19 +594,32 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = c["B"] * world / (dt / args.steps)
     rep_ms = [ms_per_step] + [1e3 * wl.timed(args.steps, 0) / args.steps for _ in range(max(0, args.reps - 1))]
+    rccl = None
+    if world > 1:       # the exchange, outside the timed region: bytes / messages per step and what the backward does not hide of it
+        wl.reducer.time_exposed = True
+        for _ in range(5):
+            wl.step()
+        ex = wl.reducer.exposed_ms()
+        wl.reducer.time_exposed = False
+        rccl = dict(rccl_ranks=world, backend=dist.get_backend(), grad_allreduce_bytes=msg_bytes, buckets=len(wl.reducer.messages()),
+                    bucket_bytes=wl.reducer.messages(), reduce_op="avg (ncclAvg)" if wl.reducer._avg_op else "sum",
+                    exposed_allreduce_ms=round(statistics.median(ex), 4) if ex else None,
+                    exposed_note="median over 5 extra steps of the HIP-event time between the end of the enqueued backward and the last "
+                                 "bucket's all-reduce on the compute stream (AdapterGradReducer.exposed_ms)")
 
     roofline = None
     if not args.no_roofline:
         roofline = path_roofline(c, esz, dtype, value, world)
         if rank == 0:
-            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape).  The two sites of a pair run
-            # back to back on ONE stream here whatever the timed region does (and the helper streams INSIDE a site are off: side.cpp):
-            # an event bracket on a stream that shares the GPU with another stream also measures the time a launch WAITS for
-            # compute units behind the other stream's kernels (a 10 us split-K reduction reads 100 us), which is neither the kernel's
-            # duration nor what rocprofv3 reports for it.  Rank 0 only: its steps must not enter a collective (sync=False = an
-            # accumulation micro-step).
+            # Profiling pass: HIP events around every launch (one family per kernel AND launch shape).  The pair keeps the SCHEDULE of
+            # the timed region -- in two-stream mode every kernel in the variant that mode launches: dX overwrites, dY adds behind
+            # the other site's dX -- but issues it on ONE stream (AdapterPair.same_stream; the helper streams INSIDE a site are off
+            # while the profiler is on: side.cpp): an event bracket on a stream that shares the GPU with another stream also measures
+            # the time a launch WAITS for compute units behind the other stream's kernels (a 10 us split-K reduction reads 100 us),
+            # which is neither the kernel's duration nor what rocprofv3 reports for it.  Rank 0 only: its steps must not enter a
+            # collective (sync=False = an accumulation micro-step).
             L = capi.lib()
-            flipped = wl.set_concurrent(False)
+            flipped = wl.set_same_stream(True)
             for _ in range(2):
                 wl.step(sync=False)
             torch.cuda.synchronize()
@@ -593,7 +630,7 @@ def main():
                 wl.step(sync=False)
             torch.cuda.synchronize()
             L.avmoe_prof_enable(0)
-            wl.set_concurrent(flipped)
+            wl.set_same_stream(flipped)
             rep = capi.prof_report()
             L.avmoe_prof_reset()
             if os.environ.get("AVMOE_FAMILIES_OUT"):      # dev: every family of the profiling pass
@@ -608,8 +645,9 @@ def main():
                       traffic=None, launches_per_step=dom["calls"] // nprof, avg_launch_us=round(avg_ms * 1e3, 2),
                       share_of_gpu_time=round(dom["total_ms"] / tot_ms, 3), kernel_tflops=round(tfs, 1),
                       measured="HIP events on the launch stream, every launch alone on the GPU (profiling pass of 3 steps after the timed "
-                               "region: the two sites of a pair back to back on one stream, helper streams off); the largest (kernel, launch "
-                               "shape) family by time per step")
+                               f"region: the schedule and kernel variants of --pair {pair_mode}"
+                               + (" -- dX overwrites (non-accumulating), dY accumulates --" if pair_mode == "concurrent" else "") +
+                               " issued on one stream, helper streams off); the largest (kernel, launch shape) family by time per step")
             tj = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic.json")
             if os.path.isfile(tj) and args.config == "cfg2" and not args.batch and dtype == "bf16":
                 with open(tj) as fh:       # HBM bytes from THIS round's rocprofv3 --pmc passes (scripts/make_profiles.sh)
@@ -625,7 +663,14 @@ def main():
                 else:
                     roofline["traffic_note"] = (f"profiles/{ROUND}_pmc_traffic.json was collected on a different build of the library "
                                                 "(stamp mismatch): not reported")
-            roofline["dominant_kernel"] = dk
+            # scalars first (the driver's record keeps the scalar members of `roofline`), the full objects beside them
+            roofline["dominant_kernel"] = dk["kernel"]
+            roofline["dominant_frac"] = dk["frac"]
+            roofline["dominant_us"] = dk["avg_launch_us"]
+            roofline["dominant_gbs"] = dk["achieved"]
+            roofline["dominant_traffic"] = dk["traffic"]
+            roofline["dominant_variant"] = f"as launched by --pair {pair_mode}" + (": dX non-accumulating" if pair_mode == "concurrent" else "")
+            roofline["dominant_detail"] = dk
             roofline["gpu_time_ms_per_step"] = round(tot_ms / nprof, 3)
             roofline["launches_per_step"] = sum(r["calls"] for r in rep) // nprof
             roofline["kernel_families"] = len(rep)
@@ -635,7 +680,7 @@ def main():
 
     wl.release()
     value_f32 = None
-    if dtype == "bf16" and not args.no_f32:
+    if dtype == "bf16" and not args.no_f32 and world == 1:
         wl = Workload(c, torch.float32, device, rank, world, args.pair)
         k32 = max(3, args.steps // 2)
         dt32 = wl.timed(k32, 2)
@@ -644,6 +689,7 @@ def main():
         wl.release()
 
     cpu = parity = others = None
+    exit_code = 0
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu, material = cpu_baseline(c)
         parity = parity_check(c, material, device, pair_mode)
@@ -673,12 +719,31 @@ def main():
                        "grad_allreduce_bytes": msg_bytes if world > 1 else 0},
             "repeat_ms_per_step": [round(x, 4) for x in rep_ms],
             "spread_rel": round((max(rep_ms) - min(rep_ms)) / statistics.median(rep_ms), 4),
-            "roofline": roofline, "parity": parity, "value_f32": value_f32, "cpu_baseline": cpu, "other_configs": others,
+            "roofline": roofline, "parity": parity,
+            # top-level scalars (the driver's record keeps scalars): the fp32 configuration and the other configurations' steps
+            "value_f32": value_f32["value"] if value_f32 else None, "ms_per_step_f32": value_f32["ms_per_step"] if value_f32 else None,
+            "f32_detail": value_f32, "cpu_baseline": cpu, "other_configs": others,
         }
+        if others:
+            for name, o in others.items():
+                line[f"{name}_ms_per_step"] = o.get("ms_per_step")
+                line[f"{name}_parity_ok"] = (o.get("parity") or {}).get("ok")
+        if parity is not None:
+            line["parity_ok"] = parity["ok"]
+        if rccl:
+            line.update(rccl_ranks=rccl["rccl_ranks"], grad_allreduce_bytes=rccl["grad_allreduce_bytes"], allreduce_buckets=rccl["buckets"],
+                        exposed_allreduce_ms=rccl["exposed_allreduce_ms"], rccl=rccl)
         print(json.dumps(line), flush=True)
+        bad = [("cfg2" if args.config == "cfg2" else args.config, parity["failed"])] if (parity and not parity["ok"]) else []
+        bad += [(n, o["parity"]["failed"]) for n, o in (others or {}).items() if o.get("parity") and not o["parity"]["ok"]]
+        if bad:
+            print(f"bench.py: PARITY FAILED (bars {PARITY_BARS}): {bad}", file=sys.stderr, flush=True)
+            exit_code = 1
     if world > 1:
         dist.barrier()                       # the other ranks wait for rank 0's extra passes: clean teardown of the communicator
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

@@ -161,3 +161,112 @@ def test_adapter_grad_reducer_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _local_reducer(n_sites=3, **kw):
+    """A reducer over real adapter sites in ONE process: `world` is forced to 2 and `_launch` recorded instead of run, so the
+    bookkeeping that decides WHEN a bucket goes out can be checked without a process group."""
+    sys.path.insert(0, ROOT)
+    from avmoe_amd.dp import AdapterGradReducer
+    from tests.golden_util import load_golden
+    from tests.test_adapters_api import build_module
+    _, cfg, _ = load_golden("ave_train")
+    torch.manual_seed(0)
+    sites = [build_module("ave", cfg) for _ in range(n_sites)]
+    site_bytes = sites[0].grad_layout()[2] * 4
+    red = AdapterGradReducer([p for m in sites for p in m.parameters()], bucket_mb=2.2 * site_bytes / (1 << 20), sites=sites, **kw)
+    launched = []
+
+    class _Work:
+        def wait(self):
+            pass
+
+    def fake_launch(b):
+        launched.append(b)
+        b.work = _Work()
+    red.world, red._launch = 2, fake_launch
+    return red, sites, launched
+
+
+def _sink_backward(site, value):
+    sink = site._grad_sink
+    buf = torch.full((sink.total,), float(value))
+    if sink.fresh:
+        sink.flat.copy_(buf)
+    else:
+        sink.flat.add_(buf)
+    sink.done()
+
+
+def test_sink_reporting_twice_does_not_release_the_bucket_early():
+    """A site whose forward + backward run twice in sequence inside one step reports twice; the bucket it shares with another
+    site must still wait for THAT site (round-3 advisor finding: `pending` was decremented per report)."""
+    red, sites, launched = _local_reducer()
+    b01 = sites[2]._grad_sink.bucket
+    assert sites[1]._grad_sink.bucket is b01 and sites[0]._grad_sink.bucket is not b01
+    red.begin(sync=True)
+    for _ in range(2):                                    # site 2: forward, backward, forward, backward
+        sites[2]._grad_sink.calls += 1
+        _sink_backward(sites[2], 1.0)
+    assert launched == []                                 # site 1 has not written its slice yet
+    sites[1]._grad_sink.calls += 1
+    _sink_backward(sites[1], 3.0)
+    assert launched == [b01]
+    assert float(sites[2]._grad_sink.flat[0]) == 2.0      # the second backward was accumulated, not lost
+    # a site with two forward calls pending holds its bucket until the second backward
+    red.begin(sync=True); red.zero_grad(); launched.clear()
+    sites[0]._grad_sink.calls += 2
+    _sink_backward(sites[0], 1.0)
+    assert launched == []
+    _sink_backward(sites[0], 1.0)
+    assert launched == [sites[0]._grad_sink.bucket]
+
+
+def test_gradient_after_the_collective_went_out_fails_loudly():
+    red, sites, launched = _local_reducer()
+    red.begin(sync=True)
+    sites[0]._grad_sink.calls += 1
+    _sink_backward(sites[0], 1.0)                         # its bucket (one site) goes out
+    assert launched == [sites[0]._grad_sink.bucket]
+    sites[0]._grad_sink.calls += 1
+    with pytest.raises(RuntimeError, match="after its bucket's all-reduce"):
+        _sink_backward(sites[0], 1.0)
+
+
+def test_lazy_zero_grad_skips_the_fill_and_finish_zeroes_idle_sites():
+    red, sites, launched = _local_reducer()
+    red.begin(sync=True)
+    for m in sites:
+        m._grad_sink.calls += 1
+    for m in reversed(sites):
+        _sink_backward(m, 5.0)
+    red.finish()
+    red.zero_grad(lazy=True)
+    assert all(m._grad_sink.fresh and m._grad_sink.stale for m in sites)
+    assert float(sites[0]._grad_sink.flat[0]) == 5.0      # no fill kernel ran
+    red.begin(sync=True)                                  # next step: only site 2 and site 1 get a backward
+    for m in sites[1:]:
+        m._grad_sink.calls += 1
+    _sink_backward(sites[2], 7.0); _sink_backward(sites[1], 7.0)
+    red.finish()
+    assert float(sites[2]._grad_sink.flat[0]) == 7.0 and float(sites[1]._grad_sink.flat.abs().max()) == 7.0
+    assert float(sites[0]._grad_sink.flat.abs().max()) == 0.0      # idle site: zeros went out, not the previous step's gradient
+    red.zero_grad()                                       # the eager form still zeroes everything
+    assert all(float(b.flat.abs().max()) == 0.0 for b in red.buckets)
+
+
+def test_second_reducer_detaches_the_first():
+    sys.path.insert(0, ROOT)
+    from avmoe_amd.dp import AdapterGradReducer
+    lin = torch.nn.Linear(4, 4)
+    r1 = AdapterGradReducer(lin.parameters())
+    assert len(r1._hooks) == 2
+    r2 = AdapterGradReducer(lin.parameters())
+    assert r1._hooks == [] and len(r2._hooks) == 2
+    r2.begin(sync=False)
+    lin(torch.ones(1, 4)).sum().backward()                # only r2's hooks fire: r1's buckets see nothing
+    assert all(b.pending == b.hooked for b in r1.buckets) and all(b.pending == 0 for b in r2.buckets)
+    assert lin.weight.grad.data_ptr() == r2.buckets[0].flat.data_ptr() or lin.bias.grad.data_ptr() == r2.buckets[0].flat.data_ptr()
+    red, sites, _ = _local_reducer(2)
+    red.close()
+    assert all(not hasattr(m, "_grad_sink") for m in sites)

@@ -133,4 +133,8 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_allreduce_bytes"] > 0
-    assert d["roofline"]["achieved"] > 0 and d["roofline"]["mfma"]["achieved"] > 0 and d["roofline"]["dominant_kernel"]["kernel"]
+    assert d["roofline"]["achieved"] > 0 and d["roofline"]["mfma_frac"] > 0 and isinstance(d["roofline"]["dominant_kernel"], str)
+    assert d["roofline"]["dominant_us"] > 0 and 0 < d["roofline"]["dominant_frac"] < 1
+    # the exchange on the line (scalars + the `rccl` object): ranks, bytes, messages, the exposed part of the all-reduce
+    assert d["rccl_ranks"] == 2 and d["grad_allreduce_bytes"] == d["config"]["grad_allreduce_bytes"] and d["allreduce_buckets"] >= 1
+    assert d["exposed_allreduce_ms"] is not None and d["exposed_allreduce_ms"] >= 0.0 and d["rccl"]["backend"] == "gloo"
