@@ -13,4 +13,19 @@ void set_last_error(const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
+int LdsAttrOnce::ensure(const void* fn, int bytes, const char* what) {
+  if (bytes <= 65536) return OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;      // (slot 63: set on every call)
+  if (done[dev] && dev != 63) return OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_last_error("%s: hipFuncSetAttribute(%d B of dynamic LDS): %s", what, bytes, hipGetErrorString(e));
+    return ERR_LAUNCH;
+  }
+  done[dev] = true;
+  return OK;
+}
+
 }  // namespace avmoe

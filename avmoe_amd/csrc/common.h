@@ -45,6 +45,13 @@ static inline const char* dev_env(const char* name) { return getenv(name); }
 static inline const char* dev_env(const char*) { return nullptr; }
 #endif
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel function: one flag per (kernel instantiation,
+// device), so a second GPU in the same process gets its attribute too (a process-wide `static bool` set it on the first one only).
+struct LdsAttrOnce {
+  bool done[64] = {};
+  int ensure(const void* fn, int bytes, const char* what);      // OK / ERR_LAUNCH ; no-op for <= 64 KiB and after the first call per device
+};
+
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -752,18 +752,9 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   constexpr int STAGES = S1 > S2 ? S1 : S2;
   constexpr int EPI = BM * (BN + 4) * 4;
   constexpr int LDS = STAGES > EPI ? STAGES : EPI;
-  static bool attr_done = false;
+  static LdsAttrOnce attr;
   auto kern = gemm_kernel<T, BM, BN, AMN, BMN, SEG2>;
-  if (!attr_done) {
-    if (LDS > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) {
-        set_last_error("gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
-        return ERR_LAUNCH;
-      }
-    }
-    attr_done = true;
-  }
+  AVMOE_TRY(attr.ensure((const void*)kern, LDS, "gemm"));
   const int tiles_m = cdiv(d.M, BM);
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
@@ -799,13 +790,9 @@ static int launch_big_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   constexpr int A_BYTES = AMN ? 64 * (256 * 2 + 16) : 256 * (128 + 16), B_BYTES = BMN ? 64 * (256 * 2 + 16) : 256 * (128 + 16);
   constexpr int STAGES = 2 * (A_BYTES + B_BYTES), EPI = 128 * (256 + 4) * 4;
   constexpr int LDS = STAGES > EPI ? STAGES : EPI;
-  static bool attr_done = false;
+  static LdsAttrOnce attr;
   auto kern = gemm_big_kernel<AMN, BMN>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { set_last_error("gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e)); return ERR_LAUNCH; }
-    attr_done = true;
-  }
+  AVMOE_TRY(attr.ensure((const void*)kern, LDS, "gemm (256 x 256 tile)"));
   dim3 grid((unsigned)(cdiv(d.M, 256) * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];

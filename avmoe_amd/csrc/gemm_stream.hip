@@ -484,14 +484,8 @@ template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF
 int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16) + (KS2 > 0 ? 32 * (TPW * NW * 32 + 16) : 0);      // two A stages + one K step of B2
   auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW, STATS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (LDS > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) { set_last_error("gemm_stream: LDS attribute: %s", hipGetErrorString(e)); return ERR_LAUNCH; }
-    }
-    attr_done = true;
-  }
+  static LdsAttrOnce attr;
+  AVMOE_TRY(attr.ensure((const void*)kern, LDS, "gemm_stream"));
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;

@@ -9,13 +9,14 @@ namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap) {
   const int tile = (g.tile ? g.tile : ((g.M > 64 && g.N > 64) ? 128 : ((g.M <= 32 && g.N <= 32) ? 32 : 64)));
-  const long tiles = (long)cdiv(g.M, tile) * cdiv(g.N, tile) * g.nb1 * g.nb2;
+  const long nb = (long)g.nb1 * g.nb2 * (g.nb3 > 0 ? g.nb3 : 1);          // (every batch level has its own slabs: gemm_slab_bytes)
+  const long tiles = (long)cdiv(g.M, tile) * cdiv(g.N, tile) * nb;
   const int bk = g.dtype == GEMM_BF16 ? 64 : 32;
   static const long target = dev_env("AVMOE_KS_TARGET") ? atol(dev_env("AVMOE_KS_TARGET")) : 512;     // workgroups wanted (dev override)
   long ks = std::max<long>(1, target / std::max<long>(tiles, 1));
   ks = std::min<long>(ks, std::max<long>(1, g.K / (4 * bk)));
   ks = std::min<long>(ks, 64);
-  const size_t per = (size_t)g.nb1 * g.nb2 * g.M * g.N;
+  const size_t per = (size_t)nb * g.M * g.N;
   while (ks > 1 && per * ks > slab_floats_cap) --ks;
   return (int)ks;
 }
@@ -260,14 +261,28 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
 // ---- sub-ops of the C ABI (for tests / partial adoption; the product path never calls them) -------------------------
 // What ExpertAdapter.forward of expert e returns -- gate * LN_post(BN2(up(act(BN1(down(LN_before(x'))))))), net_trans_v3.py:377-435 --
 // as the site forward with the router pushed to an exact one-hot on that expert: a logit offset of 3e4 makes softmax return 1.0 for it
-// and 0.0 for the others (exp underflows to zero), so out = 1 * out_e + 0 * out_others.  Same kernels, same workspaces and the same
-// side effects as avmoe_moe_forward (training mode: the BatchNorm running statistics of EVERY expert advance).
+// and 0.0 for the others (exp underflows to zero), so out = 1 * out_e + 0 * out_others.  Same kernels and workspaces as
+// avmoe_moe_forward.  A NON-FINITE value in another expert's output still propagates (0 * Inf = NaN), exactly as it does in the
+// reference's own mixture (net_trans_v3.py:485-486) -- compare modules on finite parameters.
 int expert_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, int e, void* out, char* sv, char* sc, hipStream_t st) {
   const Dims& d = pl.d;
   if (e < 0 || e >= d.E) { set_last_error("expert_forward: expert %d of %d", e, d.E); return ERR_BAD_ARG; }
   float* noise = (float*)(sc + pl.o_dp);                   // (S, E) floats of a backward-only buffer
   AVMOE_TRY(k_onehot_noise(noise, d.S, d.E, e, 3.0e4f, st));
-  return moe_forward(pl, X, Y, prm, noise, out, nullptr, nullptr, nullptr, sv, sc, st);
+  // Training mode: only the SELECTED expert's BatchNorm running statistics and counters advance (what ExpertAdapter.forward of that
+  // one module does).  The other experts still run -- their outputs enter the mixture with weight exactly 0 -- but their
+  // running_mean / running_var / num_batches_tracked updates go to a write-only dump in a backward-only scratch buffer (training
+  // mode never READS running statistics), so comparing a site module by module does not advance every module E times.
+  avmoe_moe_ptrs q = prm;
+  if (d.training && d.use_bn) {
+    float* dump = (float*)(sc + pl.o_dWf);               // C x Cy floats >= max(C, d) ; 256-byte aligned
+    for (int o = 0; o < d.E; ++o) {
+      if (o == e) continue;
+      q.e[o].bn1_rm = q.e[o].bn1_rv = q.e[o].bn2_rm = q.e[o].bn2_rv = dump;
+      q.e[o].bn1_nbt = q.e[o].bn2_nbt = nullptr;
+    }
+  }
+  return moe_forward(pl, X, Y, q, noise, out, nullptr, nullptr, nullptr, sv, sc, st);
 }
 
 // The remap MATERIALISED (the product path folds it away): Yt = conv_adapter(Y) (S, N, Cy), then

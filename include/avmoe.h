@@ -153,7 +153,8 @@ int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avm
  * avmoe_expert_forward_cross / _uni: what ExpertAdapter.forward returns for multimodal_experts[j] / singlemodal_experts[j]
  * (gate * LN_post(BN2(up(act(BN1(down(LN_before(x'))))))), net_trans_v3.py:377-435 ; mgn.py:132-139 and PVT_AVSModel_v2.py:210-227
  * for the unimodal variants) into out (S, N, C): the site forward with the router pushed to an exact one-hot on that expert.  In
- * training mode it has the side effects of a site forward (the BatchNorm running statistics and counters of EVERY expert advance).
+ * training mode only THAT expert's BatchNorm running statistics and counters advance (the others' updates are discarded); a
+ * non-finite value in another expert's output propagates (0 * Inf), as in the reference's mixture.
  * avmoe_remap_forward: the remapped other modality, materialised -- Yt = conv_adapter(Y) (S, N, Cy) and Yf = fc(Yt) (S, N, C), the
  * `vis_token` every expert and the router read (net_trans_v3.py:469-471); both in desc.dtype, both written.                      */
 int avmoe_expert_forward_cross(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params, int32_t j,

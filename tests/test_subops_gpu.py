@@ -56,6 +56,34 @@ def test_expert_subops_match_expert_forward(name):
     assert float((mix - t["out"]).abs().max() / t["out"].abs().max()) < 1e-3
 
 
+def test_expert_subop_advances_only_its_own_running_statistics():
+    """Training mode: the sub-op is ExpertAdapter.forward of ONE module -- only that expert's BatchNorm running statistics move
+    (to what the site forward gives them); the other experts' buffers stay bit for bit what they were (round-3 advisor finding:
+    a module-by-module comparison advanced every module E times)."""
+    from avmoe_amd import _capi as capi
+    from tests.moe_gpu_util import MoeRun
+    meta, cfg, t = load_golden("ave_train")
+    P, B = split_params(t)
+    full = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=True).forward()         # the site forward: every expert advances
+    for e, pre in enumerate(cfg.expert_prefixes()):
+        run = MoeRun(cfg, P, B, t["X"], t["Y"], bf16=False, training=True)
+        before = {k: v.clone() for k, v in run.buffers.items()}
+        out = torch.empty_like(run.X)
+        fn, j = (run.L.avmoe_expert_forward_cross, e) if e < cfg.E_m else (run.L.avmoe_expert_forward_uni, e - cfg.E_m)
+        capi.check(fn(C.byref(run.desc), run.X.data_ptr(), run.Y.data_ptr(), C.byref(run.ptrs), j, out.data_ptr(), run.saved.data_ptr(),
+                      run.scratch.data_ptr(), _stream()), "avmoe_expert_forward")
+        torch.cuda.synchronize()
+        assert run.guards_intact()
+        moved = 0
+        for k, v in run.buffers.items():
+            if k.startswith(pre + "."):
+                assert torch.allclose(v, full.buffers[k], rtol=1e-5, atol=1e-7), k      # what the site forward leaves for this expert
+                moved += int(not torch.equal(v, before[k]))
+            else:
+                assert torch.equal(v, before[k]), (pre, k)
+        assert moved >= 4                                                                   # bn1 / bn2 running_mean and running_var
+
+
 def test_expert_subop_rejects_bad_index():
     from avmoe_amd import _capi as capi
     from tests.moe_gpu_util import MoeRun
