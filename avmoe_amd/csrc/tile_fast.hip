@@ -197,8 +197,44 @@ template <int E> __device__ __forceinline__ int zcol(int c, int e, int q) { retu
 #ifndef KF_NO_MFMA
 #define KF_NO_MFMA 0           // development builds (timing only): 1 = the mat-vecs skip the matrix pipe and the LDS reads
 #endif
+// The same product on the bf16 matrix pipe in split form (hi.hi + hi.lo + lo.hi of two bf16 planes per operand, fp32 accumulation:
+// tile_gen.inc::mmT_split has the derivation and the reason): what the bf16 instantiations of this file run.  Three
+// v_mfma_f32_16x16x32_bf16 per pair of 16-entry chunks instead of eight v_mfma_f32_16x16x4_f32: the cfg-2 step 5.12 -> 5.05 ms
+// (same-box A/B, round 4).  KF_MMT_BF16=0 (development builds): the exact-fp32 instruction everywhere.
+#ifndef KF_MMT_BF16
+#define KF_MMT_BF16 1
+#endif
+typedef __attribute__((ext_vector_type(8))) __bf16 kf_bf16x8;
+__device__ __forceinline__ void kf_split8(const float4& v0, const float4& v1, kf_bf16x8& hi, kf_bf16x8& lo) {
+  const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)f[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(f[i] - (float)h);
+  }
+}
 template <int NJ>
+__device__ __forceinline__ f32x4 mmT_split(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
+  static_assert(NJ % 2 == 0, "chunk pairs");
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* mp = Mt + (col0 + r) * ld + 4 * q;
+#pragma unroll
+  for (int j = 0; j < NJ; j += 2) {
+    kf_bf16x8 ah, al, ph, pl;
+    kf_split8(*(const float4*)(mp + 16 * j), *(const float4*)(mp + 16 * (j + 1)), ah, al);
+    kf_split8(p[j], p[j + 1], ph, pl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph, acc, 0, 0, 0);
+  }
+  return acc;
+}
+template <int NJ, bool SPLIT>
 __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
+#if KF_MMT_BF16
+  if constexpr (SPLIT) return mmT_split<NJ>(Mt, ld, col0, p, r, q);
+#endif
 #if KF_NO_MFMA
   return f32x4{p[0].x, p[0].y, p[0].z, p[0].w};
 #endif
@@ -329,7 +365,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_MIDB) kf_mid_bwd(FMidArgs a, c
     for (int c = 0; c < 4; ++c) {
       const int gi = c >> 1, ct = c & 1;
       f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (a.moments) w = mmT<2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+      if (a.moments) w = mmT<2, sizeof(T) == 2>(s_S + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
       const float4 mean = ld4(s_bn + oz + 16 * c + 4 * q), rstd = ld4(s_bn + oz + FDD + 16 * c + 4 * q), dm = ld4(s_bn + oz + 4 * FDD + 16 * c + 4 * q);
       float4 dy;
 #pragma unroll
@@ -471,7 +507,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POST) kf_post_small(FPostArgs 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int gi = c >> 1, ct = c & 1;
-          const f32x4 w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+          const f32x4 w = mmT<2, sizeof(T) == 2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
           const float4 us = ld4(s_c + oz + 16 * c + 4 * q), vh = ld4(s_c + oz + FDD + 16 * c + 4 * q);
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
@@ -660,7 +696,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPost
       for (int c = 0; c < 4; ++c) {
         const int gi = c >> 1, ct = c & 1;
         f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (F_LN_POST(a)) w = mmT<2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
+        if (F_LN_POST(a)) w = mmT<2, sizeof(T) == 2>(s_G + oz + gi * FDG * LD32, LD32, 16 * ct, zp + 2 * gi, r, q);
         const float4 us = ld4(s_c + oz + 16 * c + 4 * q), vh = ld4(s_c + oz + FDD + 16 * c + 4 * q);
         float4 o;
 #pragma unroll
@@ -799,7 +835,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
         float u3 = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 w = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
+          const f32x4 w = mmT<2, sizeof(T) == 2>(s_TT + oz, LD32, 16 * ct, av, r, q);
 #pragma unroll
           for (int x = 0; x < 4; ++x) u3 += w[x] * at(av[ct], x);
         }
@@ -820,7 +856,7 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 p = {0.f, 0.f, 0.f, 0.f};
-        if (l >= 0) p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
+        if (l >= 0) p = mmT<2, sizeof(T) == 2>(s_TWt + oz, LD32, 16 * c, av, r, q);
         if (nxn && ok) {           // xr through Wt (fp32 rows in the Z layout)
           const float4 zr4 = ld4(a.ZR + tok * DZ + (c >> 1) * (E * FDG) + e * FDG + (c & 1) * 16 + 4 * q);
           p = f32x4{zr4.x, zr4.y, zr4.z, zr4.w};
@@ -1113,7 +1149,7 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
     float dgr = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
-      const f32x4 p = mmT<2>(s_TWt + oz, LD32, 16 * c, av, r, q);
+      const f32x4 p = mmT<2, sizeof(T) == 2>(s_TWt + oz, LD32, 16 * c, av, r, q);
 #pragma unroll
       for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
     }
@@ -1123,8 +1159,8 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
     float4 da[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const f32x4 ta = mmT<2>(s_TT + oz, LD32, 16 * ct, av, r, q);
-      const f32x4 twd = mmT<4>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
+      const f32x4 ta = mmT<2, sizeof(T) == 2>(s_TT + oz, LD32, 16 * ct, av, r, q);
+      const f32x4 twd = mmT<4, sizeof(T) == 2>(s_TW + oz, LD64, 16 * ct, dzr, r, q);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const float ac = at(av[ct], x);

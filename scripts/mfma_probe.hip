@@ -1,0 +1,243 @@
+// dev probe (round 4): do the fp32-MFMA mat-vecs of the bottleneck-space kernels (mmT: A operand from LDS, four dependent
+// v_mfma_f32_16x16x4_f32 per 16-column tile, results consumed by VALU right away) return the same bits when ANOTHER kernel hammers the
+// matrix pipe of the same SIMDs from a second stream?   build:  hipcc --offload-arch=gfx950 -O3 scripts/mfma_probe.hip -o avmoe_amd/lib/variants/mfma_probe
+//   ./mfma_probe [iters] [aggressor: 0 none, 1 bf16 32x32x16 MFMA loop, 2 LDS + MFMA loop]
+// The victim computes, per tile step, W = P x M (16 tokens x 32 -> 32) with mmT and the same numbers with plain FMAs through shuffles,
+// and counts the lanes whose results differ by more than 1e-4 relative.  Expected: 0, with or without the aggressor.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ int opaque0() { int v = 0; asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
+__device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
+
+template <int NJ>
+__device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* mp = Mt + (col0 + r) * ld + 4 * q;
+#ifndef MIT
+#define MIT 0      // mitigation under test: 1 = drain the LDS counter + s_nop before the MFMAs, 2 = the LDS data through a VALU move, 3 = both
+#endif
+  float4 a[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) a[j] = *(const float4*)(mp + 16 * j);
+#if MIT == 1 || MIT == 3
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+  asm volatile("s_nop 7" ::: "memory");
+#endif
+#if MIT == 2 || MIT == 3
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) asm volatile("v_mov_b32 %0, %0" : "+v"(at(a[j], x)));
+#endif
+#if MIT == 4       // two independent accumulator chains
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a[j], 0), at(p[j], 0), acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a[j], 1), at(p[j], 1), acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a[j], 2), at(p[j], 2), acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a[j], 3), at(p[j], 3), acc2, 0, 0, 0);
+  }
+  return acc + acc2;
+#else
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at(a[j], x), at(p[j], x), acc, 0, 0, 0);
+#if MIT == 5
+      asm volatile("s_nop 7\n s_nop 7" ::: "memory");
+#endif
+#if MIT == 9
+      asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
+#if MIT == 12
+      asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
+#if MIT == 13
+      asm volatile("s_sleep 2" ::: "memory");
+#endif
+    }
+  }
+  return acc;
+#endif
+}
+template <int NJ>
+__device__ __forceinline__ f32x4 mmV(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+      for (int xx = 0; xx < 4; ++xx) {
+        const float pv = __shfl(at(p[j], xx), r + 16 * qq);
+        const int k = 16 * j + 4 * qq + xx;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[x] += pv * Mt[(col0 + 4 * q + x) * ld + k];
+      }
+  return acc;
+}
+
+constexpr int LD = 36;
+__global__ void __launch_bounds__(256) victim(const float* __restrict__ M, const float* __restrict__ P, int tiles, unsigned* __restrict__ bad, float* __restrict__ sink,
+                                               float* __restrict__ outU, float* __restrict__ outV) {
+#if MIT == 6
+  __builtin_amdgcn_s_setprio(3);
+#endif
+  __shared__ float s_M[2][32 * LD];
+#if MIT == 7
+  extern __shared__ float hog[];
+  if (threadIdx.x == 0 && tiles < 0) hog[0] = 1.f;
+#endif
+  for (int i = threadIdx.x; i < 2 * 32 * 32; i += 256) { const int m = i >> 10, n = (i >> 5) & 31, k = i & 31; s_M[m][n * LD + k] = M[i]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+  unsigned nbad = 0;
+  float keep = 0.f;
+  for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+    const int oz = opaque0();
+    float4 p[2];
+    p[0] = *(const float4*)(P + ((long)t * 16 + r) * 32 + 4 * q);
+    p[1] = *(const float4*)(P + ((long)t * 16 + r) * 32 + 16 + 4 * q);
+    float u3 = 0.f, v3 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 w = mmT<2>(s_M[m] + oz, LD, 16 * ct, p, r, q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) u3 += w[x] * at(p[ct], x);
+      }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 w = mmV<2>(s_M[m] + oz, LD, 16 * ct, p, r, q);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v3 += w[x] * at(p[ct], x);
+      }
+    if (fabsf(u3 - v3) > 1e-4f * fmaxf(fabsf(v3), 1.f)) ++nbad;
+    if (outU) { outU[(long)t * 64 + lane] = u3; outV[(long)t * 64 + lane] = v3; }
+    keep += u3;
+  }
+  if (nbad) atomicAdd(bad, nbad);
+  sink[blockIdx.x * 256 + threadIdx.x] = keep;
+}
+
+// aggressor: long dependent-free chains of the widest bf16 MFMA on every wave (optionally with LDS traffic in between)
+__global__ void __launch_bounds__(256) aggressor_lds(int iters, int lds, float* __restrict__ sink) {      // LDS traffic only
+  __shared__ float s[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) s[i] = (float)i * 1e-6f;
+  __syncthreads();
+  float acc = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    if (lds & 1) acc += s[(threadIdx.x * 17 + i) & 4095];
+    if (lds & 2) { const float4 t4 = *(const float4*)(s + ((threadIdx.x * 4 + 16 * i) & 4092)); acc += t4.x + t4.w; }
+  }
+  sink[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) aggressor16(int iters, int lds, int f32, float* __restrict__ sink) {      // 16x16 MFMAs (bf16 x32 or f32 x4) + LDS
+  __shared__ float s[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) s[i] = (float)i * 1e-6f;
+  __syncthreads();
+  const bf16x8 a = {(__bf16)1.f, (__bf16)0.5f, (__bf16)0.25f, (__bf16)1.f, (__bf16)0.5f, (__bf16)0.25f, (__bf16)1.f, (__bf16)0.5f};
+  f32x4 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  float acc = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    if (f32) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(0.5f, 0.25f, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(0.5f, 0.25f, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(0.5f, 0.25f, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(0.5f, 0.25f, c3, 0, 0, 0);
+    } else {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c3, 0, 0, 0);
+    }
+    if (lds & 2) { const float4 t4 = *(const float4*)(s + ((threadIdx.x * 4 + 16 * i) & 4092)); acc += t4.x + t4.w; }
+  }
+  sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + acc;
+}
+__global__ void __launch_bounds__(256) aggressor(int iters, int lds, float* __restrict__ sink) {
+  __shared__ float s[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) s[i] = (float)i * 1e-6f;
+  __syncthreads();
+  const bf16x8 a = {(__bf16)1.f, (__bf16)0.5f, (__bf16)0.25f, (__bf16)1.f, (__bf16)0.5f, (__bf16)0.25f, (__bf16)1.f, (__bf16)0.5f};
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  float acc = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c3, 0, 0, 0);
+    if (lds & 1) acc += s[(threadIdx.x * 17 + i) & 4095];
+    if (lds & 2) { const float4 t4 = *(const float4*)(s + ((threadIdx.x * 4 + 16 * i) & 4092)); acc += t4.x + t4.w; }
+  }
+  sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + acc;
+}
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 20, mode = argc > 2 ? atoi(argv[2]) : 1;
+  const int tiles = 1 << 17;
+  std::vector<float> hM(2 * 32 * 32), hP((size_t)tiles * 16 * 32);
+  unsigned seed = 12345u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xFFFF) / 65536.f - 0.5f; };
+  for (auto& v : hM) v = rnd();
+  for (auto& v : hP) v = rnd();
+  float *dM, *dP, *sink1, *sink2; unsigned* dbad;
+  hipMalloc(&dM, hM.size() * 4); hipMalloc(&dP, hP.size() * 4); hipMalloc(&sink1, 4096 * 256 * 4); hipMalloc(&sink2, 4096 * 256 * 4); hipMalloc(&dbad, 4);
+  hipMemcpy(dM, hM.data(), hM.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dP, hP.data(), hP.size() * 4, hipMemcpyHostToDevice);
+  float *dU, *dV; hipMalloc(&dU, (size_t)tiles * 64 * 4); hipMalloc(&dV, (size_t)tiles * 64 * 4);
+  std::vector<float> hU((size_t)tiles * 64), hV((size_t)tiles * 64);
+  unsigned long badU = 0, badV = 0;
+#if MIT == 7
+  const int vict_lds = 100 * 1024;
+  hipFuncSetAttribute((const void*)victim, hipFuncAttributeMaxDynamicSharedMemorySize, vict_lds);
+#else
+  const int vict_lds = 0;
+#endif
+  hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+  unsigned total = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    hipMemsetAsync(dbad, 0, 4, s1);
+    hipStreamSynchronize(s1);
+    // mode: 1 MFMA only ; 2 MFMA + ds_read_b32 ; 3 MFMA + ds_read_b128 ; 4 ds_read_b32 only ; 5 ds_read_b128 only
+    if (mode >= 1 && mode <= 3) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, s2, 20000, mode == 2 ? 1 : (mode == 3 ? 2 : 0), sink2);
+    if (mode == 6 || mode == 7) hipLaunchKernelGGL(aggressor16, dim3(1024), dim3(256), 0, s2, 60000, 2, mode == 7, sink2);      // 6: bf16 16x16x32 + b128 ; 7: f32 16x16x4 + b128
+    if (mode == 4 || mode == 5) hipLaunchKernelGGL(aggressor_lds, dim3(1024), dim3(256), 0, s2, 80000, mode == 4 ? 1 : 2, sink2);
+    for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(victim, dim3(1024), dim3(256), vict_lds, s1, dM, dP, tiles, dbad, sink1, k == 3 ? dU : nullptr, k == 3 ? dV : nullptr);
+    hipDeviceSynchronize();
+    if (rep < 3) {      // which of the two methods is off?  exact reference (double) on the host for the lanes the GPU flagged (u3 != v3)
+      hipMemcpy(hU.data(), dU, hU.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hV.data(), dV, hV.size() * 4, hipMemcpyDeviceToHost);
+      int shown = 0;
+      for (long i = 0; i < (long)tiles * 64; ++i) {
+        const float u = hU[i], v = hV[i];
+        if (fabsf(u - v) <= 1e-4f * fmaxf(fabsf(v), 1.f)) continue;
+        const long t = i / 64; const int lane = (int)(i % 64), r = lane & 15, q = lane >> 4;
+        double ref = 0.0;
+        for (int m = 0; m < 2; ++m)
+          for (int ct = 0; ct < 2; ++ct)
+            for (int x = 0; x < 4; ++x) {
+              double w = 0.0;
+              for (int k = 0; k < 32; ++k) w += (double)hP[((size_t)t * 16 + r) * 32 + k] * hM[(m * 32 + 16 * ct + 4 * q + x) * 32 + k];
+              ref += w * hP[((size_t)t * 16 + r) * 32 + 16 * ct + 4 * q + x];
+            }
+        const bool ub = fabs(u - ref) > 1e-4 * fmax(fabs(ref), 1.0), vb = fabs(v - ref) > 1e-4 * fmax(fabs(ref), 1.0);
+        badU += ub; badV += vb;
+        if (shown++ < 4) printf("   tile %ld lane %d: mfma %.6f  valu %.6f  exact %.6f\n", t, lane, u, v, ref);
+      }
+    }
+    unsigned b = 0; hipMemcpy(&b, dbad, 4, hipMemcpyDeviceToHost);
+    if (b) printf("rep %d: %u mismatching lanes\n", rep, b);
+    total += b;
+  }
+  printf("MFMA_PROBE MIT %d mode %d: %u mismatches over %d reps; of the lanes checked exactly: MFMA path wrong %lu, VALU path wrong %lu (%s)\n", MIT, mode, total, reps,
+         badU, badV, hipGetErrorString(hipGetLastError()));
+  return 0;
+}

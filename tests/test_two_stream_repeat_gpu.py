@@ -1,0 +1,61 @@
+"""Two-stream mode must not change a single bit: AdapterPair(concurrent=True) repeated on identical inputs, and against the same pair
+on one stream (forward).  Round 4 found v_mfma_f32_16x16x4_f32 returning wrong sums in the bottleneck-space kernels of bf16 sites
+whenever a bf16 GEMM of the engine ran on the same compute units from the other stream (one 16-token tile in ~10^3, off by ~1 %; about
+every second step at the Swin-L / HTS-AT stage-0 shapes; never on one stream): the mat-vecs of the bf16 instantiations now run on the
+bf16 matrix pipe in split form (csrc/tile_gen.inc::mmT_split).  This is the guard: the stage-0 site shape of BASELINE configs 3 / 4
+(C 96 / 192, 4096 / 2304 tokens, 20 frames), forward + backward, workspaces poisoned."""
+import pytest
+import torch
+
+from oracle import avmoe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(dev, concurrent, Pa, Ba, Pv, Bv, ca, cv):
+    from tests.test_adapters_api import build_module
+    from avmoe_amd.adapters import AdapterPair
+    ma, mv = build_module("ave", ca).to(dev).train(), build_module("ave", cv).to(dev).train()
+    ma.load_state_dict({**Pa, **Ba}); mv.load_state_dict({**Pv, **Bv})
+    return ma, mv, AdapterPair(ma, mv, concurrent=concurrent)
+
+
+@pytest.mark.timeout(600)
+def test_two_stream_pair_repeats_bit_for_bit_at_the_stage0_shape():
+    from avmoe_amd.adapters import release_workspaces
+    dev = torch.device("cuda:0")
+    kw = dict(reduction=8, groups=2, K=32, E_m=2, E_s=2)
+    ca = O.AdapterConfig(Cx=96, Nx=4096, Cy=192, Ny=2304, **kw)
+    cv = O.AdapterConfig(Cx=192, Nx=2304, Cy=96, Ny=4096, **kw)
+    Pa, Ba = O.init_params(ca, seed=0)
+    Pv, Bv = O.init_params(cv, seed=1)
+    g = torch.Generator().manual_seed(1234)
+    S = 20
+    fa, fv = 0.3 * torch.randn(S, ca.Nx, ca.Cx, generator=g), 0.3 * torch.randn(S, cv.Nx, cv.Cx, generator=g)
+    ga, gv = torch.randn(fa.shape, generator=g).bfloat16(), torch.randn(fv.shape, generator=g).bfloat16()
+
+    def run(concurrent):
+        release_workspaces()
+        torch.cuda.empty_cache()
+        junk = torch.full((1 << 30,), 0xFF, dtype=torch.uint8, device=dev)      # the next workspaces come out of NaN-patterned memory
+        torch.cuda.synchronize()
+        del junk
+        ma, mv, pair = _pair(dev, concurrent, Pa, Ba, Pv, Bv, ca, cv)
+        xa = fa.to(dev, torch.bfloat16).requires_grad_(True)
+        xv = fv.to(dev, torch.bfloat16).requires_grad_(True)
+        out_a, _ia, out_v, _iv = pair(xa.permute(0, 2, 1).unsqueeze(-1), xv.permute(0, 2, 1).unsqueeze(-1))
+        torch.autograd.backward([out_a, out_v], [ga.to(dev).permute(0, 2, 1).unsqueeze(-1), gv.to(dev).permute(0, 2, 1).unsqueeze(-1)])
+        torch.cuda.synchronize()
+        res = {"out_a": out_a.detach().float().cpu(), "out_v": out_v.detach().float().cpu(), "d_fa": xa.grad.float().cpu(), "d_fv": xv.grad.float().cpu()}
+        for tag, m in (("a", ma), ("v", mv)):
+            res.update({f"{tag}.{k}": p.grad.float().cpu() for k, p in m.named_parameters()})
+        return res
+
+    ref = run(True)
+    assert all(torch.isfinite(v).all() for v in ref.values())
+    for it in range(5):
+        got = run(True)
+        moved = [k for k, v in got.items() if not torch.equal(v, ref[k])]
+        assert not moved, f"two-stream run {it + 1} differs from run 0 in {moved[:8]}"
+    one = run(False)                                      # one stream: the forward is the same arithmetic, bit for bit
+    assert torch.equal(one["out_a"], ref["out_a"]) and torch.equal(one["out_v"], ref["out_v"])
