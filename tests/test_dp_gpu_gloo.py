@@ -134,7 +134,7 @@ def test_bench_self_launches_its_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_allreduce_bytes"] > 0
     assert d["roofline"]["achieved"] > 0 and d["roofline"]["mfma_frac"] > 0 and isinstance(d["roofline"]["dominant_kernel"], str)
-    assert d["roofline"]["dominant_us"] > 0 and 0 < d["roofline"]["dominant_frac"] < 1
+    assert d["roofline"]["dominant_us"] > 0 and 0 <= d["roofline"]["dominant_frac"] < 1      # (B = 2: the dominant launch may be a glue kernel without algorithmic bytes)
     # the exchange on the line (scalars + the `rccl` object): ranks, bytes, messages, the exposed part of the all-reduce
     assert d["rccl_ranks"] == 2 and d["grad_allreduce_bytes"] == d["config"]["grad_allreduce_bytes"] and d["allreduce_buckets"] >= 1
     assert d["exposed_allreduce_ms"] is not None and d["exposed_allreduce_ms"] >= 0.0 and d["rccl"]["backend"] == "gloo"
