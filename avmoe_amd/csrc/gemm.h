@@ -86,6 +86,16 @@ struct GemmArgs {
   float* st_cols = nullptr;
   long st_ntot = 0;
   int* st_tiles = nullptr;
+  // optional EXTRA output columns against a per-sample matrix, from the same pass over A (streaming kernel with statistics only;
+  // launch_gemm_stream returns 1 when it cannot honour them):
+  //   C3[b1][b2][i][j] = sum_k A[b1][b2][i][k] * B3[b1][b2][j][k]      j < N3 <= 64, B3 K_MAJOR (ldb3), fp32 result (row stride ldc3)
+  // -- the hop-2 logits of a site, X[s] T[s]^T, as per-group partial sums out of the down projection's pass over X (the caller adds
+  // the groups): X is read once instead of twice.
+  const void* B3 = nullptr;
+  int N3 = 0;
+  long ldb3 = 0, s3B1 = 0, s3B2 = 0;
+  float* C3 = nullptr;
+  long ldc3 = 0, s3C1 = 0, s3C2 = 0;
 };
 
 // Returns 0 on success, negative avmoe status otherwise (message through set_last_error).

@@ -36,6 +36,7 @@ struct StreamArgs {
   float alpha; int b_mn, out_bf16;
   float* Cx; int nsplit; long ldcx, sCx2;          // fp32 side output for the columns >= nsplit (GemmArgs::Cx)
   float* st_rows; float* st_cols; long st_ntot;    // statistics of A (GemmArgs::st_rows / st_cols)
+  const char* B3; float* C3; int N3; long ldb3, s3B1, s3B2, ldc3, s3C1, s3C2;      // extra columns against a per-sample matrix (GemmArgs::B3)
 };
 
 __device__ __forceinline__ float bfbits(unsigned int h) { return __builtin_bit_cast(float, h << 16); }
@@ -106,9 +107,12 @@ constexpr int stream_minw(int NW, int per_cu) { return (NW * per_cu + 3) / 4 < 3
 // the tile that sits in the LDS anyway:  sum_k A[m][k] = (ones . A^T)[.][m] ,  sum_k A[m][k]^2 = diag(A A^T)  (wave (2 mt + j) % NW
 // does statistic j of slab mt with the fragments it reads for its products) ,  column sums = (A^T-fragments . ones) with the
 // fragments read transposed (ds_read_tr16_b64: tokens along the contraction), 16-channel tile ct by wave ct % NW.
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS>
+// X3: 16-column tiles per wave of the EXTRA product against the per-sample matrix B3 (GemmArgs::B3; statistics variants only): their
+// fragments are re-read whenever the block moves on to the next sample (contiguous tile ranges: once or twice per block).
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS, int X3 = 0>
 __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const StreamArgs p) {
   static_assert(!STATS || (KS2 == 0 && !A2MN && !ACC && BM % 32 == 0), "statistics: plain K-major single-segment products only");
+  static_assert(X3 == 0 || STATS, "extra per-sample columns: statistics variants only");
   constexpr int NT = NW * 64, MT = BM / 16, KSA = KS + KS2;
   constexpr int HOLD = stream_hold(KS, KS2, TPW, NW, BM / 16, ACC);
   constexpr int CPR1 = A2MN ? KS * 4 : KSA * 4;           // 16-byte chunks per row that come from K-major sources
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
     for (int ks = 0; ks < KS; ++ks) {
       const int k0 = 32 * ks + 8 * q;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < p.N && k0 < p.K) {
+      if (n < p.N && k0 < p.K && !(X3 > 0 && nw0 >= p.N)) {
         if (!p.b_mn) {
           v = *(const u32x4*)(Bb + ((long)n * p.ldb + k0) * 2);
           if (k0 + 8 > p.K) v = mask_tail8(v, p.K - k0);
@@ -146,6 +150,10 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
   }
   bf16x8 bfr2[TPW][KS2 > 0 ? KS2 : 1];
   int cur_s = -1;
+  // X3: the waves whose column tiles lie beyond the N columns of B own tiles of the EXTRA product against the per-sample B3 instead
+  // (same fragments, same loop; their fragments are re-read when the block moves on to the next sample and their results go, in fp32,
+  // to C3).  Wave-uniform.
+  const bool xw = X3 > 0 && nw0 >= p.N;
   const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});      // 8 x bf16 1.0
 
   // Everything pending at this point (the B fragments) is waited for HERE, once: a wait the compiler has to place itself ends up
@@ -298,6 +306,27 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);        // (once per sample: keeps the conditional loads above out of the counts below)
     }
+    if constexpr (X3 > 0) {
+      if (xw && s != cur_s) {                // this sample's B3 fragments: row n - N of [N3][K], eight k per lane
+        cur_s = s;
+        const char* B3b = p.B3 + ((long)s * p.s3B1 + (long)g * p.s3B2) * 2;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int n = nw0 - p.N + (r >> 2) * (4 * TPW) + 4 * t + (r & 3);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 32 * ks + 8 * q;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (n < p.N3 && k0 < p.K) {
+              v = *(const u32x4*)(B3b + ((long)n * p.ldb3 + k0) * 2);
+              if (k0 + 8 > p.K) v = mask_tail8(v, p.K - k0);
+            }
+            bfr[t][ks] = __builtin_bit_cast(bf16x8, v);
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // (keeps the conditional loads above out of the counts below; every wave, every tile: nothing else is in flight here)
+    }
     char* Cb = p.C + ((long)s * p.sC1 + (long)g * p.sC2) * osz;
     const char* Db = p.D ? p.D + ((long)s * p.sD1 + (long)g * p.sD2) * 2 : nullptr;
     const float* rsb = p.rs ? p.rs + (long)s * p.sRS1 + (long)g * p.sRS2 : nullptr;
@@ -343,7 +372,12 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
       if (m < p.Mper) {
 #endif
         char* cp = Cb + ((long)m * p.ldc + nl) * osz;
-        if (p.Cx && nl >= p.nsplit) {                        // this lane's run belongs to the fp32 side output
+        if (X3 > 0 && xw) {                                  // the extra product: fp32 rows of C3, columns nl - N ..
+          float* c3 = p.C3 + (long)s * p.s3C1 + (long)g * p.s3C2 + (long)m * p.ldc3 + (nl - p.N);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            if (nl - p.N + 4 * t < p.N3) *(f32x4*)(c3 + 4 * t) = acc[t];
+        } else if (p.Cx && nl >= p.nsplit) {                        // this lane's run belongs to the fp32 side output
           float* xp = p.Cx + (long)g * p.sCx2 + (long)m * p.ldcx + (nl - p.nsplit);
 #pragma unroll
           for (int t = 0; t < TPW; ++t)
@@ -379,6 +413,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+
 #if STREAM_DISSECT == 5          // dev: statistics variant without the row sums
       const bool do_s = false, do_q = false;
 #else
@@ -480,10 +515,10 @@ __global__ void __launch_bounds__(NW * 64, MINW) gemm_stream_kernel(const Stream
   }
 }
 
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS = false>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, bool PF2, int MINW, bool STATS = false, int X3 = 0>
 int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   constexpr int LDS = 2 * BM * ((KS + KS2) * 64 + 16) + (KS2 > 0 ? 32 * (TPW * NW * 32 + 16) : 0);      // two A stages + one K step of B2
-  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW, STATS>;
+  auto kern = gemm_stream_kernel<KS, KS2, TPW, NW, BM, A2MN, ACC, PF2, MINW, STATS, X3>;
   static LdsAttrOnce attr;
   AVMOE_TRY(attr.ensure((const void*)kern, LDS, "gemm_stream"));
   static int cus = 0;
@@ -498,9 +533,9 @@ int launch_inst2(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
   AVMOE_CHECK_LAUNCH("gemm_stream");
   return OK;
 }
-template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, int MINW = (NW == 9 ? SC_DAP_MINW : 1), bool STATS = false>
+template <int KS, int KS2, int TPW, int NW, int BM, bool A2MN, bool ACC, int MINW = (NW == 9 ? SC_DAP_MINW : 1), bool STATS = false, int X3 = 0>
 int launch_inst(const StreamArgs& s, int nb2, int per_cu, hipStream_t st) {
-  if constexpr (STATS) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false, MINW, true>(s, nb2, per_cu, st);
+  if constexpr (STATS) return launch_inst2<KS, KS2, TPW, NW, BM, A2MN, ACC, false, MINW, true, X3>(s, nb2, per_cu, st);
   // PF2 (two row tiles of loads in flight per block) is a development switch, AVMOE_STREAM_PF2=1: measured on MI355X it changes
   // no configuration by more than +-3 % (same-box A/B of the cfg-2 step: 6.51 vs 6.50 ms) -- these kernels are not short of
   // bytes in flight; the 9-wave dApost configuration is held back by residency (105 VGPRs x 9 waves: one block per CU).
@@ -599,8 +634,21 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 // (K steps of 32 of segment 1 / 2, column tiles per wave, waves, rows per tile, blocks per CU) -- picked by a sweep on MI355X
 // (scripts/stream_sweep.py): many waves per block and ONE block per CU win for the write-heavy shapes
   s.st_rows = a.st_rows; s.st_cols = a.st_cols; s.st_ntot = a.st_ntot;
+  s.B3 = (const char*)a.B3; s.C3 = a.C3; s.N3 = a.N3; s.ldb3 = a.ldb3; s.s3B1 = a.s3B1; s.s3B2 = a.s3B2; s.ldc3 = a.ldc3; s.s3C1 = a.s3C1; s.s3C2 = a.s3C2;
+  if (a.B3 && !a.st_rows) return 1;
   if (a.st_rows) {                  // the product + the statistics of A: the three configurations that serve down projections
     if (a.A2 || a2mn || a.accumulate || a.D || a.Cx || !a.st_cols || !a.st_tiles || a.out_dtype != GEMM_BF16) return 1;
+    if (a.B3) {                     // + the extra columns against the per-sample B3: the k384_n128 configuration, one more tile per wave
+      if (!a.C3 || a.N3 < 1 || a.N3 > 64 || a.N3 % 4 || a.nb1 < 2 || ((uintptr_t)a.B3 % 16) || (a.ldb3 * 2) % 16 || (a.s3B1 * 2) % 16 || (a.s3B2 * 2) % 16 ||
+          ((uintptr_t)a.C3 % 16) || a.ldc3 % 4 || a.s3C1 % 4 || a.s3C2 % 4 || tiles > 8 || ks > 12 || a.N3 % 16)
+        return 1;
+      s.contig = 1;                 // (contiguous tile ranges: a block changes sample once or twice)
+      if (a.N != 128) return 1;     // (eight stationary tiles + four per-sample ones: twelve waves, one tile each, one 64-row block per CU)
+      s.tps = cdiv(a.M, 64); s.ntiles = s.tps * a.nb1; *a.st_tiles = s.tps;
+      const double b3 = nb * a.N3 * (double)a.K * 2.0 + nb * a.M * (double)a.N3 * 4.0;
+      ProfScope ps("gemm_stream_k384_n128+stats+x64", (long)a.M * a.nb1, abytes + b3, flops + 2.0 * nb * a.M * (double)a.N3 * a.K, st);
+      return launch_inst<12, 0, 1, 12, 64, false, false, stream_minw(12, 1), true, 1>(s, a.nb2, 1, st);
+    }
 #define STATS_CASE(COND, KS_, TPW_, NW_, BM_, PERCU_, NAME)                                                   \
     if ((COND) && ks <= KS_ && tiles <= TPW_ * NW_) {                                                         \
       s.tps = cdiv(a.M, BM_); s.ntiles = s.tps * a.nb1; *a.st_tiles = s.tps;                                  \

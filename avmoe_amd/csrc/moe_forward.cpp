@@ -56,6 +56,10 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     g.M = d.N; g.N = d.E * d.dgp; g.K = d.Cg; g.lda = d.C; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
     g.sA1 = (long)d.N * d.C; g.sA2 = d.Cg; g.sB2 = (long)d.E * d.dgp * d.Cg; g.sCi = d.DZ; g.sC1 = (long)d.N * d.DZ; g.sC2 = (long)d.E * d.dgp;
     g.st_rows = (float*)(sc + pl.o_sxp); g.st_cols = (float*)(sc + pl.o_xpart); g.st_ntot = d.NT; g.st_tiles = &tiles;
+    if (d.fuse_l2) {                                       // + L2g[gi][s] = X[s][:, group gi] T[s][:, group gi]^T : the hop-2 logits, per group
+      g.B3 = sv + pl.o_Text; g.N3 = d.KL; g.ldb3 = d.C; g.s3B1 = (long)d.KLT * d.C; g.s3B2 = d.Cg;
+      g.C3 = (float*)(sc + pl.o_L2g); g.ldc3 = d.KL; g.s3C1 = (long)d.N * d.KL; g.s3C2 = (long)d.NT * d.KL;
+    }
     const int rc = launch_gemm_stream(g, xs);
     if (rc != OK) {
       if (rc == 1) set_last_error("moe_forward: the streaming down projection with statistics does not serve this shape (plan / kernel mismatch)");
@@ -68,7 +72,8 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     return k_colsum_f32((const float*)(sc + pl.o_xpart), tiles, d.C, d.C, d.S, (long)tiles * d.C, (float*)(sv + pl.o_rin), 2L * d.C,
                         1.f / (float)d.N, xs);
   };
-  Side* side = (d.fuse_xs && (side_mask() & 1) && side_worth(d)) ? side_acquire(st) : nullptr;
+  // (with the logits fused in, the pass needs the latent tokens T: it runs behind the hop-1 chain, on the caller's stream)
+  Side* side = (d.fuse_xs && !d.fuse_l2 && (side_mask() & 1) && side_worth(d)) ? side_acquire(st) : nullptr;
   SideScope fk(side, st);
   if (side) {
     AVMOE_TRY(fk.fork());
@@ -173,7 +178,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   }
   // ---- router (its input: the token means of X -- after the statistics above) ----------------------
   AVMOE_TRY(k_router(pl, sv, sc, prm, noise, probs_out, idx_out, lb_out, st));
-  if (d.KL > 0) {                                          // L2[s] = X[s] T[s]^T
+  if (d.KL > 0 && !d.fuse_l2) {                            // L2[s] = X[s] T[s]^T   (fused: per-group partial sums came out of the down projection; pre_small adds them into L2)
     GemmArgs g = base();
     g.A = X; g.B = sv + pl.o_Text; g.C = sv + pl.o_L2;
     g.M = d.N; g.N = d.KL; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = d.S;

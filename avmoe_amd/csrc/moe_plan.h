@@ -62,6 +62,7 @@ struct Dims {
   int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
   int xchunks;    // row chunks per frame of the fused X statistics pass
   int fuse_xs;    // the statistics of X (LayerNorm row sums, router column means) come out of the down projection's streaming GEMM: no separate pass
+  int fuse_l2;    // ... and so do the hop-2 logits X[s] T[s]^T, as per-group partial sums (L2g) that pre_small adds up: X is read ONCE by the forward's X-side products
 };
 
 // name, region (0 saved / 1 scratch), element bytes expr (4 or d.esz), element count expr
@@ -149,6 +150,7 @@ struct Dims {
   X(colsum, 1, 4, (size_t)4 * d.DZ)                 /* colpart summed over blocks     */       \
   X(xpart, 1, 4, (size_t)d.S * (d.fuse_xs ? (d.N + 31) / 32 : d.xchunks) * d.C)     /* column partials of X           */       \
   X(sxp, 1, 4, d.fuse_xs ? (size_t)2 * d.g * d.NT : 1)   /* per-group row sums of X (fused statistics) */   \
+  X(L2g, 1, 4, d.fuse_l2 ? (size_t)d.g * d.NT * d.KL : 1)   /* per-group partial hop-2 logits (fused into the down projection) */   \
   X(gpart, 1, 4, (size_t)8 * d.g * d.E * (d.dgp * d.dgp + 2 * d.dgp + 2))  /* Gram partials */ \
   X(rowpart, 1, 4, (size_t)512 * (d.C > d.Cy ? d.C : d.Cy) * 2)  /* chunked row reductions */   \
   X(slabs, 1, 4, slab_floats(d))                    /* split-K partials               */       \

@@ -738,7 +738,8 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_POSTB) kf_post_small_bwd(FPost
 // PRE_SMALL forward   (net_trans_v3.py:385-395)
 // =====================================================================================================
 struct FPreArgs { P16 glat; int lat_of_e[MAX_E]; int nxn_of_e[MAX_E]; long sxr_off[MAX_E]; FastDims t; int ln_before; float ln_eps;
-                  const float* ZR; const float* sxr; };      // x + g xr experts (AVVP N x N block, frame attention): xr through Wt, row sums
+                  const float* ZR; const float* sxr;         // x + g xr experts (AVVP N x N block, frame attention): xr through Wt, row sums
+                  const float* L2g; float* L2w; };           // fused logits (Dims::fuse_l2): two per-group partial planes (NT, KL) to add; the sums go to L2w
 
 template <typename T, int E, bool XR>      // XR: the site has x + g xr experts (AVVP N x N block, frame attention)
 __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, void* __restrict__ Z_, const float* __restrict__ L2, const float* __restrict__ sxs,
@@ -800,7 +801,12 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
         ldraw_row<E>(Z + tok * DZ, e, q, zraw_);
         if (l >= 0) {
           const long lo = tok * t.KL + (long)l * FK + 4 * q;
-          lg[0] = ld4(L2 + lo); lg[1] = ld4(L2 + lo + 16);
+          if (a.L2g) {             // per-group partial sums out of the down projection's pass over X: group 0 + group 1
+            const float4 a0 = ld4(a.L2g + lo), a1 = ld4(a.L2g + lo + 16);
+            const float4 b0 = ld4(a.L2g + (long)t.NT * t.KL + lo), b1 = ld4(a.L2g + (long)t.NT * t.KL + lo + 16);
+            lg[0] = make_float4(a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w);
+            lg[1] = make_float4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
+          } else { lg[0] = ld4(L2 + lo); lg[1] = ld4(L2 + lo + 16); }
         }
       }
       unpack_row(zraw_, z);
@@ -876,6 +882,10 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
       // for the store to be acknowledged
       if (ok) {
         if (l >= 0) st_seg<T>(aout + (long)l * t.aL + tok * FK, av[0], av[1], q);
+        if (l >= 0 && a.L2w) {       // the logits themselves (the backward's hop-2 block reads them)
+          float* lw = a.L2w + tok * t.KL + (long)l * FK + 4 * q;
+          *(float4*)lw = lg[0]; *(float4*)(lw + 16) = lg[1];
+        }
         st_row<T, E>(Z + tok * DZ, e, q, zo);
         if (q == 0) { rmu[(long)e * t.NT + tok] = rr; rmu[(long)t.NT * E + (long)e * t.NT + tok] = mu; }
       }
@@ -1294,6 +1304,8 @@ int kf_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
     a.sxr_off[e] = (e < d.E && d.xr_of_e[e] > 0) ? (long)d.xr_of_e[e] * 3 * d.NT : 0;
   }
   a.ZR = (const float*)(saved + pl.o_ZR); a.sxr = (const float*)(saved + pl.o_sxr);
+  a.L2g = d.fuse_l2 ? (const float*)(scratch + pl.o_L2g) : nullptr; a.L2w = d.fuse_l2 ? (float*)(saved + pl.o_L2) : nullptr;
+  if (d.fuse_l2 && d.g != 2) { set_last_error("pre_small: fused logits are built for two groups"); return ERR_UNSUPPORTED; }
   a.t = make_fd(d, per); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps;
   const size_t sh = ((size_t)d.El * (FK * LD32 + FDD * LD32 + FK) + (size_t)d.E * 2 * FDD + 4 * FDD) * sizeof(float);
   LAUNCH_TEX(d.bf16, kf_pre_small, sh, a, (void*)(saved + pl.o_Z), (const float*)(saved + pl.o_L2), (const float*)(saved + pl.o_sx),
