@@ -224,6 +224,7 @@ def parity_check(c, material, device, pair_mode="concurrent"):
                out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, grad_rel_f32_own_mask=0.0, worst_f32_own_mask=None,
                relu_units=0, relu_units_flipped=0, flipped_preact_max_rel=0.0,
                out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None, grad_relnorm_bf16_same_mask=None, worst_bf16_same_mask=None,
+               grad_relnorm_bf16_major=None, worst_bf16_major=None, grad_relnorm_bf16_tiny_joint=None,
                dx_rows=0, **{"dx_rows_above_1e-3": 0}, dx_row_maxabs_f32=0.0,
                measures="out_*: max-abs / max ; grad_*: norm-wise per tensor, worst tensor (floor 1e-3 of the largest gradient norm) ; "
                         "grad_rel_f32, *_same_mask, dx_rows*: against the oracle run with the HIP path's ReLU mask (kink-aware) ; "
@@ -300,6 +301,25 @@ def parity_check(c, material, device, pair_mode="concurrent"):
                 e_w, k_w = e, f"{k} ({tag})"
         return e_w, k_w
 
+    def split_view(items):
+        """the same comparison the way the -m gpu tests bar it (tests/golden_util.py::bf16_budget_violations): the tensors of <= 16
+        elements (scalar gates, the router's last bias: single sums of both signs over every token, each of which can cancel to a
+        small fraction of its terms) as ONE vector; the tensors that carry >= 1 % of the largest gradient norm one by one"""
+        nmax = max(float(v.norm()) for _t, _k, _g, v in items)
+        tiny = [(g, v) for _t, _k, g, v in items if v.numel() <= 16]
+        tj = None
+        if tiny:
+            gt, vt = torch.cat([g.reshape(-1) for g, _ in tiny]), torch.cat([v.reshape(-1) for _, v in tiny])
+            tj = float((gt - vt).norm() / vt.norm().clamp_min(1e-30))
+        e_w, k_w = 0.0, None
+        for tag, k, g, v in items:
+            if v.numel() <= 16 or float(v.norm()) < 1e-2 * nmax:
+                continue
+            e = float((g - v).norm() / v.norm())
+            if e > e_w:
+                e_w, k_w = e, f"{k} ({tag})"
+        return tj, e_w, k_w
+
     def upd(key_e, key_w, e, k):
         if e > (res[key_e] or 0.0):
             res[key_e], res[key_w] = e, k
@@ -342,8 +362,12 @@ def parity_check(c, material, device, pair_mode="concurrent"):
                 res["out_rel_bf16"] = max(res["out_rel_bf16"] or 0.0, e_out)
                 upd("grad_relnorm_bf16", "worst_bf16", e_own, f"{k_own} [{shape_tag}]")
                 upd("grad_relnorm_bf16_same_mask", "worst_bf16_same_mask", e_same, f"{k_same} [{shape_tag}]")
+                tj, e_major, k_major = split_view(grad_items((ga, gv, tok), sa, sv))
+                upd("grad_relnorm_bf16_major", "worst_bf16_major", e_major, f"{k_major} [{shape_tag}]")
+                if tj is not None:
+                    res["grad_relnorm_bf16_tiny_joint"] = max(res.get("grad_relnorm_bf16_tiny_joint") or 0.0, tj)
     for k in ("out_rel_f32", "grad_rel_f32", "grad_rel_f32_own_mask", "flipped_preact_max_rel", "out_rel_bf16", "grad_relnorm_bf16",
-              "grad_relnorm_bf16_same_mask", "dx_row_maxabs_f32"):
+              "grad_relnorm_bf16_same_mask", "grad_relnorm_bf16_major", "grad_relnorm_bf16_tiny_joint", "dx_row_maxabs_f32"):
         if res.get(k) is not None:
             res[k] = float(f"{res[k]:.3e}")
     if detail:
@@ -357,7 +381,8 @@ def parity_check(c, material, device, pair_mode="concurrent"):
 # printed): the fp32 path is the one held to north_star's 1e-3, indices are bit-exact, and a bf16 output off by more than the test
 # bound is a bug (round 3: a run-to-run blip of the cfg-3 forward went unnoticed because this leg only printed numbers).  The bf16
 # gradient bar is reported as `ok_bf16_grads` (SOFT: bf16 activations have an error budget of their own).
-PARITY_BARS = dict(out_rel_f32=1e-3, grad_rel_f32=1e-3, out_rel_bf16=1e-2, grad_relnorm_bf16_same_mask=5e-2)
+PARITY_BARS = dict(out_rel_f32=1e-3, grad_rel_f32=1e-3, out_rel_bf16=1e-2, grad_relnorm_bf16_same_mask=5e-2, grad_relnorm_bf16_major=5e-2,
+                   grad_relnorm_bf16_tiny_joint=5e-2)
 
 
 def parity_verdict(res):
@@ -368,7 +393,9 @@ def parity_verdict(res):
             failed.append(k)
     soft = res.get("grad_relnorm_bf16_same_mask")
     res["ok"] = not failed
-    res["ok_bf16_grads"] = None if soft is None else bool(soft <= PARITY_BARS["grad_relnorm_bf16_same_mask"])
+    res["ok_bf16_grads"] = None if soft is None else bool(soft <= PARITY_BARS["grad_relnorm_bf16_same_mask"])      # every tensor >= 1e-3 of the largest norm, one by one
+    mj, tj = res.get("grad_relnorm_bf16_major"), res.get("grad_relnorm_bf16_tiny_joint")
+    res["ok_bf16_grads_as_tested"] = None if mj is None else bool(mj <= PARITY_BARS["grad_relnorm_bf16_major"] and (tj is None or tj <= PARITY_BARS["grad_relnorm_bf16_tiny_joint"]))
     res["failed"] = failed
     res["bars"] = PARITY_BARS
     return res

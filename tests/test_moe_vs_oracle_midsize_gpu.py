@@ -163,7 +163,11 @@ def test_midsize_matches_oracle_fp32(name):
                                   # (fast_nobn's 4 frames x 97 tokens are too few for the router.0 budget in bf16, with or without BatchNorm: its gradient is
                                   # a sum over the frames that cancels the common part of the token means -- 14 % / 23 % against 4 % for eager autocast)
                                   "cfg5_stage3_visual_k87", "cfg5_stage3_audio_k87", "cfg5_stage2_audio_k87", "cfg5_stage0_audio_k87", "cfg5_stage3_visual_k87_v2",
-                                  "cfg3_avvp_stage0_audio_full", "cfg3_avvp_stage0_visual_full"])      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
+                                  "cfg3_avvp_stage0_audio_full", "cfg3_avvp_stage0_visual_full",      # the cfg1 ones: bottlenecks 48 / 12 / 16 zero-padded to the register-resident shape
+                                  # round 4: the shapes the other configurations are BENCHMARKED in bf16 at -- cfg-4 (AVQA: merged groups,
+                                  # 2 latent tokens, 1 + 2 experts), cfg-3 stage 2, the 64 / 36-token stage-3 sites
+                                  "cfg4_avqa_stage0_audio_side", "cfg4_avqa_stage2_audio_side", "cfg4_avqa_stage2_visual_side", "cfg4_avqa_stage2_audio_side_b2",
+                                  "cfg3_avvp_stage2_audio_side", "cfg3_avvp_stage2_visual_side", "cfg1_stage3_audio_side", "cfg1_stage3_visual_side"])
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path (bf16 activations AND bottleneck-space tensors, streaming GEMMs, streaming Gram) against the fp32 oracle
     on the bf16-rounded inputs: router indices bit-exact, outputs within 1e-2 (max-abs relative; 4e-2 for the frame-attention
