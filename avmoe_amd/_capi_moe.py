@@ -14,7 +14,7 @@ class MoeDesc(C.Structure):
                                          "use_gate", "ln_before", "ln_post", "variant", "self_attn", "lb_loss",
                                          "dtype", "training")] + \
                [(n, C.c_float) for n in ("bn_eps", "ln_eps", "bn_momentum")] + \
-               [(n, C.c_int32) for n in ("accumulate_dx", "accumulate_dy", "accumulate_out")]
+               [(n, C.c_int32) for n in ("accumulate_dx", "accumulate_dy", "accumulate_out", "shared_gpu")]
 
 
 _EXPERT_FIELDS = ("gate", "my_tokens", "gate_lat", "down_w", "up_w", "bn1_w", "bn1_b", "bn2_w", "bn2_b",

@@ -60,7 +60,7 @@ def _scratch(dev: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
     return buf
 
 
-def _site_forward(module, X, Y, noise, names, params, add_to=None):
+def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=False):
     """One avmoe_moe_forward call.  Returns (out, probs, idx, lb, state) with state = what the backward needs.
     add_to: a contiguous tensor like X that receives `+= adapter(X, Y)` in place (avmoe_moe_desc.accumulate_out) and is
     returned as `out`."""
@@ -73,9 +73,10 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None):
     Y = Y.contiguous()
     S, N, Cc = X.shape
     desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
+    desc.shared_gpu = int(bool(shared_gpu))               # (include/avmoe.h: kernels of another stream may be on the GPU during this call and its backward)
     keep = module._attention_keep(S, N, X.device)
     ptrs = module._fill_ptrs(params, keep, names=names, device=X.device)
-    wkey = (S, N, Y.shape[1], X.dtype, module.training)
+    wkey = (S, N, Y.shape[1], X.dtype, module.training, bool(shared_gpu))
     sizes = module.__dict__.setdefault("_ws_sizes", {}).get(wkey)      # workspace sizes of this call shape (two plan evaluations otherwise)
     if sizes is None:
         sizes = (L.avmoe_moe_saved_bytes(C.byref(desc)), L.avmoe_moe_scratch_bytes(C.byref(desc)))
@@ -141,7 +142,7 @@ class _SiteBackward:
             filler.fill(self.gptrs, [self.grads[k] for k in names])
         self.d_out = d_out.to(self.X.dtype).contiguous()
         self.lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
-        wkey = (desc.S, desc.N, desc.M, self.X.dtype, bool(desc.training))
+        wkey = (desc.S, desc.N, desc.M, self.X.dtype, bool(desc.training), bool(desc.shared_gpu))
         sizes = module.__dict__.get("_ws_sizes", {}).get(wkey)
         self.scratch = _scratch(self.X.device, sizes[1] if sizes else self.L.avmoe_moe_scratch_bytes(C.byref(desc)), scratch_slot)
         self.dX, self.dY, self.acc = dX, dY, (int(acc_dx), int(acc_dy))
@@ -234,9 +235,10 @@ class _PairFunction(torch.autograd.Function):
         if side is not None:                           # site B on the side stream, concurrently with site A
             ctx_ev = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
             fork(ctx_ev[2])
+            two = side.cuda_stream != main.cuda_stream      # (same_stream: the schedule of the two-stream mode on one stream -- nothing overlaps)
             with torch.cuda.stream(side):
-                out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, Xb, Xa, noises[1], names_b, pb, add_to=base_b)
-            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a)
+                out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, Xb, Xa, noises[1], names_b, pb, add_to=base_b, shared_gpu=two)
+            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a, shared_gpu=two)
             join(ctx_ev[3])
             for t_ in (out_b, idx_b, pr_b, lb_b, st_b[1]):
                 t_.record_stream(main)

@@ -46,12 +46,18 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   Side* side = side_worth(d) ? side_acquire(st) : nullptr;
   SideScope fk1(side, st), fk2(side, st);                  // joined on every way out (error returns included)
   const size_t esz = d.esz;
+  // development builds: AVMOE_BWD_STOP=n returns after the n-th step of section 1 (1 the two GEMMs against dOut, 2 post_small_bwd, 3 the
+  // Gram products, 4 post_prep_bwd, 5 mid_bwd, 6 router_bwd) -- workspaces as that step left them (tests/dev/race_buffers.py)
+  static const int bwd_stop = dev_env("AVMOE_BWD_STOP") ? atoi(dev_env("AVMOE_BWD_STOP")) : 0;
+#define BWD_STOP(n) do { if (bwd_stop == (n)) return OK; } while (0)
   if (parts & 1) {   // =============================== section 1: phases 1 - 4 ===============================
   // the accumulators that start from zero (dtbp, dTW, dWcK, dqp, dRT) are adjacent in the plan: one memset instead of five
   MEMSET0(sc + pl.o_dtbp, (pl.o_dRT - pl.o_dtbp) + (size_t)d.S * d.M * d.Kcyp * esz);
 
   // ---- phase 1: dApost = dOut Bpost ; dBpost = dOut^T Apost -------------------------------------
-  const bool fork1 = side && (side_mask() & 2) && (d.gram64 || !d.ln_post);     // (the engine's Gram path splits K itself: it needs the slabs)
+  // (the engine's Gram path splits K itself: it needs the slabs; sites on the generalised kernels keep post_small_bwd off the GPU while
+  // a GEMM of the helper stream runs -- tile_gen.inc::gen_lds_request has the reason)
+  const bool fork1 = side && (side_mask() & 2) && (d.gram64 || !d.ln_post) && !d.gen;
   {
     GemmArgs g = base();
     g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
@@ -79,8 +85,10 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     }
     if (!dap16) AVMOE_TRY(run(g, false));
   }
+  BWD_STOP(1);
   // ---- phase 2: bottleneck space (LayerNorm-post statistics), then weight space ------------------
   AVMOE_TRY(k_post_small_bwd(pl, sv, sc, prm, grads, st, dap16));
+  BWD_STOP(2);
   if (d.ln_post && d.gram64) {                             // dG[i][e] = sum_t dSoo z' z'^T : one streaming pass over z (z' formed on the fly)
     AVMOE_TRY(k_gram64(pl, sv + pl.o_Z, (const float*)(sc + pl.o_dSooT), 1.f, (float*)(sc + pl.o_gpartT), (float*)(sc + pl.o_dGq), st,
                        (const float*)(sv + pl.o_bn1)));
@@ -92,10 +100,14 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(run(g, true));
   }
   if (fork1) AVMOE_TRY(fk1.join());
+  BWD_STOP(3);
   AVMOE_TRY(k_post_prep_bwd(pl, sv, sc, prm, grads, st));
+  BWD_STOP(4);
   // ---- phase 3: ReLU / BN1 ; router --------------------------------------------------------------
   AVMOE_TRY(k_mid_bwd(pl, sv, sc, prm, grads, st));
+  BWD_STOP(5);
   AVMOE_TRY(k_router_bwd(pl, sv, sc, prm, grads, lb_grad, st));
+  BWD_STOP(6);
   // ---- phase 4: folded LayerNorm / hop-2 softmax ---------------------------------------------------
   if (d.nxn) MEMSET0(sc + pl.o_dZR, (size_t)d.NT * d.DZ * esz);
   AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));

@@ -36,6 +36,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.bf16 = q->dtype == AVMOE_BF16;
   d.bn_eps = q->bn_eps; d.ln_eps = q->ln_eps; d.bn_momentum = q->bn_momentum;
   d.acc_dx = q->accumulate_dx != 0; d.acc_dy = q->accumulate_dy != 0; d.acc_out = q->accumulate_out != 0;
+  d.excl = q->shared_gpu != 0;
   if (q->dtype != AVMOE_F32 && q->dtype != AVMOE_BF16) { set_last_error("moe: dtype %d", q->dtype); return ERR_BAD_ARG; }
   if (d.S <= 0 || d.N <= 0 || d.C <= 0 || d.M <= 0 || d.Cy <= 0) {
     set_last_error("moe: non-positive extent S=%d N=%d C=%d M=%d Cy=%d", d.S, d.N, d.C, d.M, d.Cy);

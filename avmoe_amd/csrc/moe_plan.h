@@ -8,6 +8,7 @@
 #include "../../include/avmoe.h"
 #include "common.h"
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace avmoe {
 
@@ -62,6 +63,7 @@ struct Dims {
   int nblk_tok;   // blocks used by the per-token kernels (column-partial slabs are sized by it)
   int xchunks;    // row chunks per frame of the fused X statistics pass
   int fuse_xs;    // the statistics of X (LayerNorm row sums, router column means) come out of the down projection's streaming GEMM: no separate pass
+  int excl;       // other kernels may share the GPU with this call (avmoe_moe_desc::shared_gpu): the generalised bottleneck-space kernels take a CU's LDS to themselves
   int fuse_l2;    // ... and so do the hop-2 logits X[s] T[s]^T, as per-group partial sums (L2g) that pre_small adds up: X is read ONCE by the forward's X-side products
 };
 
@@ -199,6 +201,11 @@ struct Dims {
   X(gWu, 1, 4, d.mg ? (size_t)d.E * d.C * d.d : 1)
 
 size_t slab_floats(const Dims& d);
+// smallest site (token elements) that forks a helper stream inside its calls (side.h; AVMOE_SIDE_MIN)
+inline long side_min_elements() {
+  static const long thr = [] { const char* e = getenv("AVMOE_SIDE_MIN"); return e && *e ? atol(e) : (1L << 25); }();
+  return thr;
+}
 
 struct BufInfo { const char* name; int region; size_t offset, bytes; };
 

@@ -10,10 +10,7 @@ namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap);
 // helper streams (side.h) pay for their two event hand-overs only when the forked GEMM is long: sites of at least 2^25 token elements
-inline bool side_worth(const Dims& d) {
-  static const long thr = [] { const char* e = getenv("AVMOE_SIDE_MIN"); return e && *e ? atol(e) : (1L << 25); }();
-  return (long)d.NT * d.C >= thr;
-}
+inline bool side_worth(const Dims& d) { return (long)d.NT * d.C >= side_min_elements(); }
 
 // AVS "v1" unimodal expert: xr slot = MultiheadAttention_e(X) - X across the frames, and its backward (mha_frames.hip)
 int mha_frames_forward(const Plan& pl, const void* X, const avmoe_expert_ptrs& ep, int slot, char* saved, char* scratch, hipStream_t st);

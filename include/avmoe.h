@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 7
+#define AVMOE_ABI_VERSION 8
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -83,6 +83,14 @@ typedef struct avmoe_moe_desc {
   /* forward only (ABI 3): out += adapter(X, Y) instead of out = ... -- the caller's residual stream (x + attention(x), then
    * "+ adapter residual", net_trans_v3.py:706-709) takes the adapter's contribution inside the output GEMM's epilogue */
   int32_t accumulate_out;
+  /* ABI 8: 1 = kernels of OTHER streams may be on the GPU while this call runs (a caller that overlaps two sites on two streams:
+   * AdapterPair's two-stream mode).  The bottleneck-space kernels then launch with a compute unit's LDS to themselves (one block
+   * per CU): on MI355X / ROCm 7.2 a block of theirs that shares a CU with a block of another kernel doing wide LDS reads beside
+   * matrix instructions occasionally gets wrong 16-byte LDS reads (one 16-token tile in ~10^3; scripts/mfma_probe.hip reproduces
+   * it outside this library).  0 = the call is alone on the GPU (its own helper stream never runs beside those kernels).
+   * The flag changes the block shape of those kernels, i.e. the summation order of the per-block BatchNorm column sums: results
+   * agree to fp32 rounding of those sums, and repeat bit for bit for a given flag. */
+  int32_t shared_gpu;
 } avmoe_moe_desc;
 
 typedef struct avmoe_expert_ptrs {        /* <list>.{j}.*  ; unused entries NULL                     */

@@ -197,7 +197,7 @@ int main(int argc, char** argv) {
   std::vector<float> hU((size_t)tiles * 64), hV((size_t)tiles * 64);
   unsigned long badU = 0, badV = 0;
 #if MIT == 7
-  const int vict_lds = 100 * 1024;
+  const int vict_lds = 140 * 1024;      // with the 9 KB of static LDS: 149 KB -- no 16 KB block of the aggressor fits beside it on the CU
   hipFuncSetAttribute((const void*)victim, hipFuncAttributeMaxDynamicSharedMemorySize, vict_lds);
 #else
   const int vict_lds = 0;

@@ -125,10 +125,17 @@ def main():
                     r = mv(xv, xa)
                 background()
             else:
-                r = ma(xa, xv)
                 side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    background()
+                if a.backward:                 # forward alone, then the backward beside the background work
+                    r = ma(xa, xv)
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(side):
+                        background()
+                    r[0].backward(Ga.to(dev).to(r[0].dtype).permute(0, 2, 1).unsqueeze(-1))
+                else:
+                    r = ma(xa, xv)
+                    with torch.cuda.stream(side):
+                        background()
             torch.cuda.synchronize()
             outs["out"] = r[0].detach().float().cpu()
         else:
@@ -168,7 +175,8 @@ def main():
             continue
         moved = [(k, int((v != ref[k]).sum()), v.numel()) for k, v in snap.items() if k in ref and v.numel() == ref[k].numel() and not torch.equal(v, ref[k])]
         print(f"run {it}: {len(moved)} buffers moved: " + "; ".join(f"{k} {n}/{t}" for k, n, t in moved[:40]), flush=True)
-        for key, dt_ in (("v.sv.rmu", torch.float32), ("v.sv.Z", tdt), ("v.sv.sx", torch.float32), ("a.sv.rmu", torch.float32), ("a.sv.Z", tdt)):
+        for key, dt_ in (("v.sv.rmu", torch.float32), ("v.sv.Z", tdt), ("v.sv.sx", torch.float32), ("a.sv.rmu", torch.float32), ("a.sv.Z", tdt),
+                         ("a.sc.colpart", torch.float32), ("a.sc.dsm", torch.float32), ("v.sc.colpart", torch.float32)):
             if key in snap and key in ref and not torch.equal(snap[key], ref[key]):
                 x, y = snap[key].view(dt_).float(), ref[key].view(dt_).float()
                 idx = (x != y).nonzero().reshape(-1)
