@@ -174,7 +174,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.fuse_xs = d.bf16 && d.zsz == 2 && gemm_stream_stats_ok(d.N, d.S, d.E * d.dgp, d.Cg, d.C, d.DZ) && !dev_env("AVMOE_NO_FUSE_XSTATS");
   // the hop-2 logits out of the same pass over X: the tuned shape (tile_fast.hip's pre_small adds the per-group partial sums), no latent
   // self attention (its latent tokens come from X itself), <= 64 latent rows per frame, the k384_n128 streaming configuration
-  d.fuse_l2 = d.fuse_xs && tile_fast_ok(d) && !d.gen && d.El > 0 && d.Ex == 0 && d.KL <= 64 && d.KL % 4 == 0 && d.S >= 2 && d.E * d.dgp <= 128 && d.Cg <= 384 &&
+  d.fuse_l2 = d.fuse_xs && tile_fast_ok(d) && !d.gen && d.El > 0 && d.Ex == 0 && d.KL <= 64 && d.KL % 16 == 0 && d.S >= 2 && d.E * d.dgp == 128 && d.Cg <= 384 &&
               d.Cg > 160 && !dev_env("AVMOE_NO_FUSE_L2");
 
   size_t off[2] = {0, 0};

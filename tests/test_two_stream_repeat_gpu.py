@@ -20,17 +20,28 @@ def _pair(dev, concurrent, Pa, Ba, Pv, Bv, ca, cv):
     return ma, mv, AdapterPair(ma, mv, concurrent=concurrent)
 
 
-@pytest.mark.timeout(600)
-def test_two_stream_pair_repeats_bit_for_bit_at_the_stage0_shape():
+SHAPES = {
+    # the stage-0 shape of BASELINE configs 3 / 4 (generalised kernels, merged groups): moved every second step before the fix
+    "stage0_swinl_htsat": (dict(reduction=8, groups=2, K=32, E_m=2, E_s=2), (96, 4096), (192, 2304), 20),
+    # stage 2 / 3 shapes at 8 clips (generalised kernels, small grids): 4 - 9 of 9 steps moved before the CU-exclusive launches
+    "stage2_swinl_htsat_8clips": (dict(reduction=8, groups=2, K=32, E_m=2, E_s=2), (384, 256), (768, 144), 80),
+    "stage3_swinl_htsat_8clips": (dict(reduction=8, groups=2, K=32, E_m=2, E_s=2), (768, 64), (1536, 36), 80),
+    # the benchmarked shape (tuned register-resident kernels): has never moved -- kept as a guard
+    "cfg2": (dict(reduction=12, groups=2, K=32, E_m=2, E_s=2), (768, 1024), (768, 196), 20),
+}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_two_stream_pair_repeats_bit_for_bit(shape):
     from avmoe_amd.adapters import release_workspaces
     dev = torch.device("cuda:0")
-    kw = dict(reduction=8, groups=2, K=32, E_m=2, E_s=2)
-    ca = O.AdapterConfig(Cx=96, Nx=4096, Cy=192, Ny=2304, **kw)
-    cv = O.AdapterConfig(Cx=192, Nx=2304, Cy=96, Ny=4096, **kw)
+    kw, (Ca, Na), (Cv, Nv), S = SHAPES[shape]
+    ca = O.AdapterConfig(Cx=Ca, Nx=Na, Cy=Cv, Ny=Nv, **kw)
+    cv = O.AdapterConfig(Cx=Cv, Nx=Nv, Cy=Ca, Ny=Na, **kw)
     Pa, Ba = O.init_params(ca, seed=0)
     Pv, Bv = O.init_params(cv, seed=1)
     g = torch.Generator().manual_seed(1234)
-    S = 20
     fa, fv = 0.3 * torch.randn(S, ca.Nx, ca.Cx, generator=g), 0.3 * torch.randn(S, cv.Nx, cv.Cx, generator=g)
     ga, gv = torch.randn(fa.shape, generator=g).bfloat16(), torch.randn(fv.shape, generator=g).bfloat16()
 
