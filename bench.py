@@ -245,6 +245,8 @@ def parity_check(c, material, device, pair_mode="concurrent"):
         xa, xv = fa.permute(0, 2, 1).unsqueeze(-1), fv.permute(0, 2, 1).unsqueeze(-1)
         lbs, idx_a, idx_v = [], None, None
         pair = AdapterPair(ma, mv, concurrent=(pair_mode != "serial")) if can_pair else None
+        if pair is not None and pair_mode == "same":
+            pair.same_stream = True
         if can_pair and c["variant"] == "avs":
             out_a, idx_a, _p, lb_a, out_v, idx_v, _q, lb_v = pair(xa, xv, is_training=False)
             lbs = [lb_a, lb_v]
@@ -435,7 +437,10 @@ class Workload:
             mods = []
             for j in range(cnt):
                 a, v = build_pair(c, (Ca, Na, Cv, Nv), device, seed=100 * i + j)
-                mods.append((a, v, AdapterPair(a, v, concurrent=(self.pair_mode != "serial")) if self.can_pair else None))
+                pr = AdapterPair(a, v, concurrent=(self.pair_mode != "serial")) if self.can_pair else None
+                if pr is not None and self.pair_mode == "same":
+                    pr.same_stream = True
+                mods.append((a, v, pr))
                 sites += [a, v]
             self.work.append(dict(f_a=f_a, f_v=f_v, ga4=g_a.permute(0, 2, 1).unsqueeze(-1), gv4=g_v.permute(0, 2, 1).unsqueeze(-1), mods=mods))
         params = [p for m in sites for p in m.parameters()]
@@ -576,8 +581,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skips the fp32 re-run (value_f32)")
     ap.add_argument("--no-other-configs", action="store_true", help="skips the cfg-1 / cfg-4 / cfg-5 legs of the default (cfg-2, N = 1) run")
-    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "serial", "off"],
-                    help="how the two sites of a layer are run: AdapterPair on two streams / on one stream / two separate calls")
+    ap.add_argument("--pair", default="concurrent", choices=["concurrent", "same", "serial", "off"],
+                    help="how the two sites of a layer are run: AdapterPair on two streams / the two-stream schedule and kernel variants issued on "
+                         "ONE stream (profiling: every launch alone on the GPU) / back to back on one stream / two separate calls")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])

@@ -2,12 +2,12 @@
 # Produces the round's judged artefacts on the GPU box (into gpurun_out/prof_final; copy them to profiles/<round>_* afterwards):
 #   PMC read / write traffic per kernel and per step (first: bench.py's `traffic` field reads the round's pmc_traffic.json), matrix-pipe
 #   utilisation counters, rocprofv3 kernel-trace stats of the default command (+ --pair serial, + every launch alone), then the bench line.
-#   usage: scripts/make_profiles.sh [round tag, default r03]
-R=$PWD; O=$R/gpurun_out/prof_final; T=${1:-r03}; mkdir -p $O
+#   usage: scripts/make_profiles.sh [round tag, default r04]
+R=$PWD; O=$R/gpurun_out/prof_final; T=${1:-r04}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-f32 --reps 1"
 # counters: their own runs, kernel trace only (3 steps: 1 warm-up + 2 timed; the profiling pass of bench.py is off)
-S="--steps 2 --warmup 1 --no-roofline --pair serial"
+S="--steps 2 --warmup 1 --no-roofline --pair same"      # the timed region's kernel variants (dX overwrites, dY accumulates), one stream
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -- $B $S > $O/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -- $B $S > $O/w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/m -- $B $S > $O/m.log 2>&1
@@ -19,8 +19,9 @@ cp $O/pmc_traffic.json $R/profiles/${T}_pmc_traffic.json          # (on the box:
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- $B --pair serial > $O/kts.log 2>&1
-# every launch alone on the GPU (one stream, no helper streams inside a site): what bench.py's profiling pass times with HIP events
-AVMOE_NO_SIDE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kta -- $B --pair serial > $O/kta.log 2>&1
+# every launch alone on the GPU, in the variants of the timed region (--pair same: the two-stream schedule on one stream; no helper streams
+# inside a site): what bench.py's profiling pass times with HIP events
+AVMOE_NO_SIDE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kta -- $B --pair same > $O/kta.log 2>&1
 cd $R
 cp $O/kta/*/*kernel_stats.csv $O/kernel_stats_alone.csv
 cp $O/kt/*/*kernel_stats.csv $O/kernel_stats_default.csv

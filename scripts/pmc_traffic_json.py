@@ -41,7 +41,9 @@ def family(sym: str):
 STREAM = {("5", "0", "2", "12", "64", "false"): "gemm_stream_k160_n384", ("12", "0", "2", "4", "32", "false"): "gemm_stream_k384_n128",
           ("12", "0", "1", "9", "32", "false"): "gemm_stream_k384_n144", ("4", "3", "2", "12", "64", "false"): "gemm_stream_k128+96_n384",
           ("4", "3", "2", "12", "32", "false"): "gemm_stream_k128+96_n384r", ("2", "3", "4", "12", "64", "true"): "gemm_stream_k64+96mn_n768",
-          ("2", "3", "4", "12", "32", "true"): "gemm_stream_k64+96mn_n768r"}
+          ("2", "3", "4", "12", "32", "true"): "gemm_stream_k64+96mn_n768r",
+          ("12", "0", "1", "9", "64", "false"): "gemm_stream_k384_n144", ("12", "0", "1", "12", "64", "false"): "gemm_stream_k384_n128+stats+x64",
+          ("2", "3", "2", "12", "64", "true"): "gemm_stream_k64+96mn_n384", ("2", "3", "2", "12", "32", "true"): "gemm_stream_k64+96mn_n384r"}
 
 
 def load(path, scale):
