@@ -162,34 +162,42 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       const char* Xc = (const char*)X + xo;
       const char* dxc = sc + pl.o_dxr + xo;
       char* dXc = (char*)dX + xo;
-      if (d.nxc < d.S && nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {
-        AVMOE_TRY(k_nxn_att(Xc, ns, d.N, d.C, d.Np, (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N, sv + pl.o_att, 1, st));
-      } else if (d.nxc < d.S) {                            // the forward ran in chunks too: att of these frames again, from the kept row log-sum-exp
-        GemmArgs g = base();
-        g.A = Xc; g.B = Xc; g.C = sv + pl.o_att;
-        g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
-        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
-        g.epi = GEMM_EPI_EXP; g.row_lse = (const float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
-        AVMOE_TRY(run(g, false));
-      }
-      {                                                    // y[s] = att[s] dxr[s]   (fp32): the direct term of dX and the softmax's row term
-        GemmArgs g = base();
-        g.A = sv + pl.o_att; g.B = dxc; g.C = sc + pl.o_nyt;
-        g.M = d.N; g.N = d.C; g.K = d.N; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = ns;
-        g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C;
-        AVMOE_TRY(run(g, true));
-      }
-      // dX[s] += y[s] ; rowdot_i = X_i . y_i  ( = sum_j att_ij d att_ij, with d att_ij = X_i . dxr_j )
-      AVMOE_TRY(k_nxn_rowdot(d.bf16, Xc, (const float*)(sc + pl.o_nyt), (long)ns * d.N, d.C, dXc, (float*)(sc + pl.o_nrd), st));
-      if (nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {            // dSc[s] = att[s] * (X[s] dxr[s]^T - rowdot): d att never leaves the chip
-        AVMOE_TRY(k_nxn_att_bwd(Xc, dxc, ns, d.N, d.C, d.Np, (const float*)(sc + pl.o_nrd), sv + pl.o_att, sc + pl.o_dSc, st));
+      static const bool nxn_old = dev_env("AVMOE_NXN_OLD_BWD") != nullptr;      // development: the round-3 backward (att re-formed into memory)
+      if (nxn_att_ok(d.bf16, d.N, d.C, d.Np) && !nxn_old) {
+        // the strip kernels re-form att from the kept row log-sum-exp in their accumulators: neither the softmax nor y = att dxr exists in memory
+        const float* lse = (const float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
+        AVMOE_TRY(k_nxn_y(Xc, dxc, ns, d.N, d.C, d.Np, lse, (float*)(sc + pl.o_nrd), dXc, st));           // rowdot = X . (att dxr) ; dX += att dxr
+        AVMOE_TRY(k_nxn_ds(Xc, dxc, ns, d.N, d.C, d.Np, lse, (const float*)(sc + pl.o_nrd), sc + pl.o_dSc, st));   // dSc = att * (X dxr^T - rowdot)
       } else {
-        GemmArgs g = base();
-        g.A = Xc; g.B = dxc; g.C = sc + pl.o_dSc;
-        g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
-        g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
-        g.epi = GEMM_EPI_MULSUB; g.row_lse = (const float*)(sc + pl.o_nrd); g.D = sv + pl.o_att; g.sDi = d.Np; g.sD1 = (long)d.N * d.Np;
-        AVMOE_TRY(run(g, false));
+        if (d.nxc < d.S && nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {
+          AVMOE_TRY(k_nxn_att(Xc, ns, d.N, d.C, d.Np, (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N, sv + pl.o_att, 1, st));
+        } else if (d.nxc < d.S) {                            // the forward ran in chunks too: att of these frames again, from the kept row log-sum-exp
+          GemmArgs g = base();
+          g.A = Xc; g.B = Xc; g.C = sv + pl.o_att;
+          g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
+          g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
+          g.epi = GEMM_EPI_EXP; g.row_lse = (const float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
+          AVMOE_TRY(run(g, false));
+        }
+        {                                                    // y[s] = att[s] dxr[s]   (fp32): the direct term of dX and the softmax's row term
+          GemmArgs g = base();
+          g.A = sv + pl.o_att; g.B = dxc; g.C = sc + pl.o_nyt;
+          g.M = d.N; g.N = d.C; g.K = d.N; g.lda = d.Np; g.b_layout = MN_MAJOR; g.ldb = d.C; g.nb1 = ns;
+          g.sA1 = (long)d.N * d.Np; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.N * d.C;
+          AVMOE_TRY(run(g, true));
+        }
+        // dX[s] += y[s] ; rowdot_i = X_i . y_i  ( = sum_j att_ij d att_ij, with d att_ij = X_i . dxr_j )
+        AVMOE_TRY(k_nxn_rowdot(d.bf16, Xc, (const float*)(sc + pl.o_nyt), (long)ns * d.N, d.C, dXc, (float*)(sc + pl.o_nrd), st));
+        if (nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {            // dSc[s] = att[s] * (X[s] dxr[s]^T - rowdot): d att never leaves the chip
+          AVMOE_TRY(k_nxn_att_bwd(Xc, dxc, ns, d.N, d.C, d.Np, (const float*)(sc + pl.o_nrd), sv + pl.o_att, sc + pl.o_dSc, st));
+        } else {
+          GemmArgs g = base();
+          g.A = Xc; g.B = dxc; g.C = sc + pl.o_dSc;
+          g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
+          g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
+          g.epi = GEMM_EPI_MULSUB; g.row_lse = (const float*)(sc + pl.o_nrd); g.D = sv + pl.o_att; g.sDi = d.Np; g.sD1 = (long)d.N * d.Np;
+          AVMOE_TRY(run(g, false));
+        }
       }
       for (int tr = 0; tr < 2; ++tr) {                     // dX[s] += dSc[s] X[s]  and  dSc[s]^T X[s]
         GemmArgs g = base();

@@ -137,6 +137,169 @@ __global__ void __launch_bounds__(256, 2) kk_nxn_att(const unsigned short* __res
   }
 }
 
+
+// ---- the backward WITHOUT the softmax in memory (round 4) ------------------------------------------------------------------------
+// With the row log-sum-exp kept, att[i][j] = exp(X_i . X_j - lse_i) costs one product per tile to re-form -- in the accumulators, where
+// the transposed product leaves lane (r, q) with 32 CONSECUTIVE key columns of query row r.  Eight of them, columns 32 q + 8 s .. + 7,
+// are exactly what lane (r, kb = q) has to supply as the B operand of a 16 x 16 x 32 step whose contraction runs over the keys
+// { 32 q' + 8 s + p } (q' = 0 .. 3 the four k-blocks, p = 0 .. 7): the probabilities go from the accumulators into the next
+// product WITHOUT moving between lanes, and the A operand -- the dxr (or X) tile transposed, channels as rows -- is read from the LDS
+// tile with the transposing read at rows 32 q + 8 s (+ 4).  So:
+//   kk_nxn_y   y = att dxr  (128 query rows x C in the accumulators over all key tiles), then rowdot_i = X_i . y_i and dX_i += y_i
+//              -- replaces [att re-formed and stored] + [GEMM att dxr -> fp32 y] + [row-dot kernel]: att is neither written nor read
+//   kk_nxn_ds  dS = att * (X dxr^T - rowdot) with att re-formed the same way (two products per tile) -- replaces the read of att
+// (the two products against dS stay engine GEMMs on the stored dS).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
+
+template <int KS, bool DS>
+__global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Dx,
+                                                                      const float* __restrict__ lse_g, float* __restrict__ rowdot, unsigned short* __restrict__ out,
+                                                                      int N, int Np) {
+  // DS = false: out = dX (S, N, C), += y ; rowdot written.   DS = true: out = dS (S, N, Np) ; rowdot read.
+  constexpr int C = 32 * KS, RB = C * 2 + 16, CPR = C / 8, NLD = 128 * CPR / 256, CT = C / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sD = smem + 128 * RB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const long f = blockIdx.y;
+  const unsigned short* Xf = X + f * (long)N * C;
+  const unsigned short* Df = Dx + f * (long)N * C;
+  const int i0 = blockIdx.x * 128 + 32 * wave;
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[tm][ks] = *(const bf16x8*)(Xf + (long)(i0 + 16 * tm + r) * C + ks * 32 + 8 * q);
+  const float lse[2] = {lse_g[f * N + i0 + r], lse_g[f * N + i0 + 16 + r]};
+  float rd[2] = {0.f, 0.f};
+  if constexpr (DS) { rd[0] = rowdot[f * N + i0 + r]; rd[1] = rowdot[f * N + i0 + 16 + r]; }
+  f32x4 accY[2][DS ? 1 : CT];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int ct = 0; ct < (DS ? 1 : CT); ++ct) accY[tm][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntile = N / 128;
+  u32x4 st[NLD], sd[NLD];
+  auto gload = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + 256 * i;
+      const long off = (long)(jt * 128 + c / CPR) * C + (c % CPR) * 8;
+      st[i] = *(const u32x4*)(Xf + off);
+      sd[i] = *(const u32x4*)(Df + off);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + 256 * i;
+      *(u32x4*)(sX + (c / CPR) * RB + (c % CPR) * 16) = st[i];
+      *(u32x4*)(sD + (c / CPR) * RB + (c % CPR) * 16) = sd[i];
+    }
+  };
+  gload(0);
+  for (int jt = 0; jt < ntile; ++jt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (jt + 1 < ntile) gload(jt + 1);
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bf16x8 kf = *(const bf16x8*)(sX + ((r >> 2) * 32 + 4 * t + (r & 3)) * RB + ks * 64 + q * 16);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[tm][t][e] = __expf(acc[tm][t][e] - lse[tm]);          // att, this lane's 32 key columns of row r
+    if constexpr (!DS) {
+      // rounded to bf16 as the stored softmax was (same numbers as the path it replaces), as B operands: step s = columns 32 q + 8 s .. + 7
+      bf16x8 pb[2][4];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const f32x4 a = acc[tm][2 * sidx], b = acc[tm][2 * sidx + 1];
+          pb[tm][sidx] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const char* ad = sD + (32 * q + 8 * sidx + (r >> 2)) * RB + (16 * ct + 4 * (r & 3)) * 2;
+          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad));
+          const s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad + 4 * RB));
+          const s16x8_t w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+          const bf16x8 af = __builtin_bit_cast(bf16x8, w);                 // dxr^T: channel 16 ct + r, keys 32 q + 8 s + 0 .. 7
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) accY[tm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pb[tm][sidx], accY[tm][ct], 0, 0, 0);
+        }
+    } else {
+      // G = X_i . dxr_j in the same layout, then dS = att * (G - rowdot), 64 contiguous bytes per lane and query tile
+      f32x4 g[2][8];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) g[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const bf16x8 kf = *(const bf16x8*)(sD + ((r >> 2) * 32 + 4 * t + (r & 3)) * RB + ks * 64 + q * 16);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) g[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], g[tm][t], 0, 0, 0);
+        }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        unsigned short* dst = out + (f * N + i0 + 16 * tm + r) * (long)Np + jt * 128 + 32 * q;
+        auto rb = [](float v) { return (float)(__bf16)v; };                  // (the stored softmax was bf16: the same factor)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const f32x4 a = acc[tm][2 * h], b = acc[tm][2 * h + 1], ga = g[tm][2 * h], gb = g[tm][2 * h + 1];
+          const float l = rd[tm];
+          *(u32x4*)(dst + 8 * h) = u32x4{pack2(rb(a[0]) * (ga[0] - l), rb(a[1]) * (ga[1] - l)), pack2(rb(a[2]) * (ga[2] - l), rb(a[3]) * (ga[3] - l)),
+                                         pack2(rb(b[0]) * (gb[0] - l), rb(b[1]) * (gb[1] - l)), pack2(rb(b[2]) * (gb[2] - l), rb(b[3]) * (gb[3] - l))};
+        }
+      }
+    }
+  }
+  if constexpr (!DS) {
+    // lane (r, q): y[query row][16 ct + 4 q + e]  ->  rowdot = X . y (over the row: the lane's entries, then the four q lanes), dX += y
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const long row = f * N + i0 + 16 * tm + r;
+      float dot = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const long o = row * C + 16 * ct + 4 * q;
+        const unsigned xl = *(const unsigned*)(X + o), xh = *(const unsigned*)(X + o + 2);
+        const unsigned ol = *(const unsigned*)(out + o), oh = *(const unsigned*)(out + o + 2);
+        auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+        auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+        const f32x4 y = accY[tm][ct];
+        dot += (lo(xl) * y[0] + hi(xl) * y[1]) + (lo(xh) * y[2] + hi(xh) * y[3]);
+        *(unsigned*)(out + o) = pack2(lo(ol) + y[0], hi(ol) + y[1]);
+        *(unsigned*)(out + o + 2) = pack2(lo(oh) + y[2], hi(oh) + y[3]);
+      }
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+      if (q == 0) rowdot[row] = dot;
+    }
+  }
+}
+
 }  // namespace
 
 bool nxn_att_ok(int bf16, int N, int C, int Np) { return bf16 && (C == 96 || C == 192) && N % 128 == 0 && N >= 128 && Np % 8 == 0; }
@@ -162,6 +325,35 @@ int k_nxn_att(const void* X, int frames, int N, int C, int Np, float* lse, void*
 // dS = att * (X dxr^T - rowdot): the softmax backward of the same block, the gradient of the scores never stored
 int k_nxn_att_bwd(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* rowdot, const void* att, void* dS, hipStream_t st) {
   return nxn_launch("k_nxn_att_bwd", X, dxr, frames, N, C, Np, (float*)rowdot, dS, att, 1, st);
+}
+
+// y = att dxr without att in memory (re-formed from the kept row log-sum-exp): rowdot = X . y written, dX += y
+static int nxn_bwd_launch(bool ds, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* out, hipStream_t st) {
+  if (!nxn_att_ok(1, N, C, Np)) { set_last_error("nxn_bwd: shape not served (C = 96 / 192, N a multiple of 128)"); return ERR_UNSUPPORTED; }
+  if (frames <= 0) return OK;
+  const double bytes = (double)frames * N * ((double)C * 2 * (ds ? 2 : 4) + (ds ? (double)Np * 2 : 0.0) + 8);
+  const double flops = (ds ? 2.0 : 2.0) * 2.0 * frames * (double)N * N * C;
+  ProfScope ps_(ds ? "k_nxn_ds" : "k_nxn_y", (long)frames * N, bytes, flops, st);
+  const dim3 grid((unsigned)(N / 128), (unsigned)frames);
+  const int lds = 2 * 128 * (C * 2 + 16);
+#define NXB(KS_, DS_)                                                                                                     \
+  do {                                                                                                                    \
+    static LdsAttrOnce attr;                                                                                              \
+    AVMOE_TRY(attr.ensure((const void*)kk_nxn_bwd<KS_, DS_>, lds, "nxn_bwd"));                                            \
+    hipLaunchKernelGGL((kk_nxn_bwd<KS_, DS_>), grid, dim3(256), lds, st, (const unsigned short*)X, (const unsigned short*)dxr, lse, rowdot, \
+                       (unsigned short*)out, N, Np);                                                                      \
+  } while (0)
+  if (C == 96) { if (ds) NXB(3, true); else NXB(3, false); }
+  else { if (ds) NXB(6, true); else NXB(6, false); }
+#undef NXB
+  AVMOE_CHECK_LAUNCH("nxn_bwd");
+  return OK;
+}
+int k_nxn_y(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* dX, hipStream_t st) {
+  return nxn_bwd_launch(false, X, dxr, frames, N, C, Np, lse, rowdot, dX, st);
+}
+int k_nxn_ds(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dS, hipStream_t st) {
+  return nxn_bwd_launch(true, X, dxr, frames, N, C, Np, lse, (float*)rowdot, dS, st);
 }
 
 }  // namespace avmoe
