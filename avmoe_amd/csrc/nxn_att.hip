@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256, 2) kk_nxn_att(const unsigned short* __res
       *(u32x4*)(smem + (c / CPR) * RB + (c % CPR) * 16) = st[i];
     }
   };
-  for (int sweep = have_lse ? 1 : 0; sweep < 2; ++sweep) {
+  for (int sweep = have_lse ? 1 : 0; sweep < (att ? 2 : 1); ++sweep) {       // att == nullptr: the row statistics only (the forward's xr comes from kk_nxn_bwd<.., 2>)
     gload(0);
     for (int jt = 0; jt < ntile; ++jt) {
       __syncthreads();                                             // the previous tile's fragments have been read
@@ -153,26 +153,29 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
 
-template <int KS, bool DS>
+template <int KS, int MODE>      // MODE 0: y = att dxr (+ rowdot, dX += y) ; 1: dS ; 2: the FORWARD's xr = att^T X (the block owns 128 rows of xr; lse per streamed row)
 __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Dx,
                                                                       const float* __restrict__ lse_g, float* __restrict__ rowdot, unsigned short* __restrict__ out,
                                                                       int N, int Np) {
-  // DS = false: out = dX (S, N, C), += y ; rowdot written.   DS = true: out = dS (S, N, Np) ; rowdot read.
+  // MODE 0: out = dX (S, N, C), += y ; rowdot written.   MODE 1: out = dS (S, N, Np) ; rowdot read.   MODE 2: out = xr (S, N, C), Dx unused.
+  constexpr bool DS = MODE == 1, XR = MODE == 2;
   constexpr int C = 32 * KS, RB = C * 2 + 16, CPR = C / 8, NLD = 128 * CPR / 256, CT = C / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
-  char* sD = smem + 128 * RB;
+  char* sD = XR ? smem : smem + 128 * RB;                   // (xr: the second product runs against the streamed X tile itself)
+  float* s_lse = (float*)(smem + (XR ? 1 : 2) * 128 * RB);  // xr: the streamed rows' log-sum-exp
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const long f = blockIdx.y;
   const unsigned short* Xf = X + f * (long)N * C;
-  const unsigned short* Df = Dx + f * (long)N * C;
+  const unsigned short* Df = XR ? Xf : Dx + f * (long)N * C;
   const int i0 = blockIdx.x * 128 + 32 * wave;
   bf16x8 qf[2][KS];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[tm][ks] = *(const bf16x8*)(Xf + (long)(i0 + 16 * tm + r) * C + ks * 32 + 8 * q);
-  const float lse[2] = {lse_g[f * N + i0 + r], lse_g[f * N + i0 + 16 + r]};
+  float lse[2] = {0.f, 0.f};
+  if constexpr (!XR) { lse[0] = lse_g[f * N + i0 + r]; lse[1] = lse_g[f * N + i0 + 16 + r]; }
   float rd[2] = {0.f, 0.f};
   if constexpr (DS) { rd[0] = rowdot[f * N + i0 + r]; rd[1] = rowdot[f * N + i0 + 16 + r]; }
   f32x4 accY[2][DS ? 1 : CT];
@@ -181,23 +184,26 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
 #pragma unroll
     for (int ct = 0; ct < (DS ? 1 : CT); ++ct) accY[tm][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntile = N / 128;
-  u32x4 st[NLD], sd[NLD];
+  u32x4 st[NLD], sd[XR ? 1 : NLD];
+  float lnext = 0.f;
   auto gload = [&](int jt) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + 256 * i;
       const long off = (long)(jt * 128 + c / CPR) * C + (c % CPR) * 8;
       st[i] = *(const u32x4*)(Xf + off);
-      sd[i] = *(const u32x4*)(Df + off);
+      if constexpr (!XR) sd[i] = *(const u32x4*)(Df + off);
     }
+    if constexpr (XR) { if (tid < 128) lnext = lse_g[f * N + jt * 128 + tid]; }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + 256 * i;
       *(u32x4*)(sX + (c / CPR) * RB + (c % CPR) * 16) = st[i];
-      *(u32x4*)(sD + (c / CPR) * RB + (c % CPR) * 16) = sd[i];
+      if constexpr (!XR) *(u32x4*)(sD + (c / CPR) * RB + (c % CPR) * 16) = sd[i];
     }
+    if constexpr (XR) { if (tid < 128) s_lse[tid] = lnext; }
   };
   gload(0);
   for (int jt = 0; jt < ntile; ++jt) {
@@ -218,12 +224,24 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);
       }
+    if constexpr (XR) {                    // att[i][j] for the block's own row j = r: the log-sum-exp belongs to the streamed row i = 32 q + 4 t + e
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int t = 0; t < 8; ++t) {
+        const float4 l4 = *(const float4*)(s_lse + 32 * q + 4 * t);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[tm][t][e] = __expf(acc[tm][t][e] - lse[tm]);          // att, this lane's 32 key columns of row r
+          for (int e = 0; e < 4; ++e) acc[tm][t][e] = __expf(acc[tm][t][e] - lv[e]);
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[tm][t][e] = __expf(acc[tm][t][e] - lse[tm]);          // att, this lane's 32 key columns of row r
+    }
     if constexpr (!DS) {
       // rounded to bf16 as the stored softmax was (same numbers as the path it replaces), as B operands: step s = columns 32 q + 8 s .. + 7
       bf16x8 pb[2][4];
@@ -275,7 +293,18 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
       }
     }
   }
-  if constexpr (!DS) {
+  if constexpr (XR) {                      // xr[own row][16 ct + 4 q + e]
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const long row = f * N + i0 + 16 * tm + r;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 y = accY[tm][ct];
+        unsigned* dst = (unsigned*)(out + row * C + 16 * ct + 4 * q);
+        dst[0] = pack2(y[0], y[1]); dst[1] = pack2(y[2], y[3]);
+      }
+    }
+  } else if constexpr (!DS) {
     // lane (r, q): y[query row][16 ct + 4 q + e]  ->  rowdot = X . y (over the row: the lane's entries, then the four q lanes), dX += y
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -328,14 +357,15 @@ int k_nxn_att_bwd(const void* X, const void* dxr, int frames, int N, int C, int 
 }
 
 // y = att dxr without att in memory (re-formed from the kept row log-sum-exp): rowdot = X . y written, dX += y
-static int nxn_bwd_launch(bool ds, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* out, hipStream_t st) {
+static int nxn_bwd_launch(int mode, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* out, hipStream_t st) {
+  const bool ds = mode == 1;
   if (!nxn_att_ok(1, N, C, Np)) { set_last_error("nxn_bwd: shape not served (C = 96 / 192, N a multiple of 128)"); return ERR_UNSUPPORTED; }
   if (frames <= 0) return OK;
   const double bytes = (double)frames * N * ((double)C * 2 * (ds ? 2 : 4) + (ds ? (double)Np * 2 : 0.0) + 8);
   const double flops = (ds ? 2.0 : 2.0) * 2.0 * frames * (double)N * N * C;
-  ProfScope ps_(ds ? "k_nxn_ds" : "k_nxn_y", (long)frames * N, bytes, flops, st);
+  ProfScope ps_(mode == 2 ? "k_nxn_xr" : (ds ? "k_nxn_ds" : "k_nxn_y"), (long)frames * N, bytes, flops, st);
   const dim3 grid((unsigned)(N / 128), (unsigned)frames);
-  const int lds = 2 * 128 * (C * 2 + 16);
+  const int lds = mode == 2 ? 128 * (C * 2 + 16) + 512 : 2 * 128 * (C * 2 + 16);
 #define NXB(KS_, DS_)                                                                                                     \
   do {                                                                                                                    \
     static LdsAttrOnce attr;                                                                                              \
@@ -343,17 +373,21 @@ static int nxn_bwd_launch(bool ds, const void* X, const void* dxr, int frames, i
     hipLaunchKernelGGL((kk_nxn_bwd<KS_, DS_>), grid, dim3(256), lds, st, (const unsigned short*)X, (const unsigned short*)dxr, lse, rowdot, \
                        (unsigned short*)out, N, Np);                                                                      \
   } while (0)
-  if (C == 96) { if (ds) NXB(3, true); else NXB(3, false); }
-  else { if (ds) NXB(6, true); else NXB(6, false); }
+  if (C == 96) { if (mode == 2) NXB(3, 2); else if (ds) NXB(3, 1); else NXB(3, 0); }
+  else { if (mode == 2) NXB(6, 2); else if (ds) NXB(6, 1); else NXB(6, 0); }
 #undef NXB
   AVMOE_CHECK_LAUNCH("nxn_bwd");
   return OK;
 }
 int k_nxn_y(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* dX, hipStream_t st) {
-  return nxn_bwd_launch(false, X, dxr, frames, N, C, Np, lse, rowdot, dX, st);
+  return nxn_bwd_launch(0, X, dxr, frames, N, C, Np, lse, rowdot, dX, st);
 }
 int k_nxn_ds(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dS, hipStream_t st) {
-  return nxn_bwd_launch(true, X, dxr, frames, N, C, Np, lse, (float*)rowdot, dS, st);
+  return nxn_bwd_launch(1, X, dxr, frames, N, C, Np, lse, (float*)rowdot, dS, st);
+}
+// the forward's xr = att^T X from the row log-sum-exp (k_nxn_att with att == nullptr leaves it): the softmax is never stored
+int k_nxn_xr(const void* X, int frames, int N, int C, int Np, const float* lse, void* xr, hipStream_t st) {
+  return nxn_bwd_launch(2, X, X, frames, N, C, Np, lse, nullptr, xr, st);
 }
 
 }  // namespace avmoe
