@@ -81,8 +81,8 @@ int k_nxn_att(const void* X, int frames, int N, int C, int Np, float* lse, void*
 int k_nxn_att_bwd(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* rowdot, const void* att, void* dS, hipStream_t st);
 // the same backward without the softmax in memory (nxn_att.hip, round 4): att re-formed from the kept row log-sum-exp in the accumulators
 int k_nxn_y(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* dX, hipStream_t st);   // rowdot = X . (att dxr) ; dX += att dxr
-int k_nxn_ds(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dS, hipStream_t st);   // dS = att * (X dxr^T - rowdot)
 int k_nxn_xr(const void* X, int frames, int N, int C, int Np, const float* lse, void* xr, hipStream_t st);      // forward: xr = att^T X (lse from k_nxn_att with att == nullptr)
+int k_nxn_dx(int key, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dX, hipStream_t st);   // dX += dS X (key = 0) / dS^T X (key = 1), dS in the accumulators
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

@@ -162,12 +162,14 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       const char* Xc = (const char*)X + xo;
       const char* dxc = sc + pl.o_dxr + xo;
       char* dXc = (char*)dX + xo;
-      static const bool nxn_old = dev_env("AVMOE_NXN_OLD_BWD") != nullptr;      // development: the round-3 backward (att re-formed into memory)
-      if (nxn_att_ok(d.bf16, d.N, d.C, d.Np) && !nxn_old) {
+      if (d.nflash) {
         // the strip kernels re-form att from the kept row log-sum-exp in their accumulators: neither the softmax nor y = att dxr exists in memory
         const float* lse = (const float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
         AVMOE_TRY(k_nxn_y(Xc, dxc, ns, d.N, d.C, d.Np, lse, (float*)(sc + pl.o_nrd), dXc, st));           // rowdot = X . (att dxr) ; dX += att dxr
-        AVMOE_TRY(k_nxn_ds(Xc, dxc, ns, d.N, d.C, d.Np, lse, (const float*)(sc + pl.o_nrd), sc + pl.o_dSc, st));   // dSc = att * (X dxr^T - rowdot)
+        // dX += dS X + dS^T X, dS = att * (X dxr^T - rowdot) formed in the accumulators of both kernels
+        AVMOE_TRY(k_nxn_dx(0, Xc, dxc, ns, d.N, d.C, d.Np, lse, (const float*)(sc + pl.o_nrd), dXc, st));
+        AVMOE_TRY(k_nxn_dx(1, Xc, dxc, ns, d.N, d.C, d.Np, lse, (const float*)(sc + pl.o_nrd), dXc, st));
+        continue;
       } else {
         if (d.nxc < d.S && nxn_att_ok(d.bf16, d.N, d.C, d.Np)) {
           AVMOE_TRY(k_nxn_att(Xc, ns, d.N, d.C, d.Np, (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N, sv + pl.o_att, 1, st));

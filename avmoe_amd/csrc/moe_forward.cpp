@@ -207,8 +207,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
       // att[s] = softmax_rows(X[s] X[s]^T) without the scores leaving the chip: the product runs twice with softmax epilogues -- (max, sum exp)
       // per row and column tile, then exp(score - lse) straight to att; the row log-sum-exp is kept for the backward
       float* lse = (float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
-      static const bool nxn_old = dev_env("AVMOE_NXN_OLD_BWD") != nullptr;      // development: the round-3 form (softmax stored, engine GEMMs against it)
-      if (nxn_att_ok(d.bf16, d.N, d.C, d.Np) && !nxn_old) {     // the large-N sites: row statistics, then xr = att^T X with att re-formed in the accumulators (nxn_att.hip)
+      if (d.nflash) {     // the large-N sites: row statistics, then xr = att^T X with att re-formed in the accumulators (nxn_att.hip)
         AVMOE_TRY(k_nxn_att(Xc, ns, d.N, d.C, d.Np, lse, nullptr, 0, st));
         AVMOE_TRY(k_nxn_xr(Xc, ns, d.N, d.C, d.Np, lse, sv + pl.o_xr + (size_t)s0 * d.N * d.C * d.esz, st));
         continue;

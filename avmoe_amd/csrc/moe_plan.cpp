@@ -2,6 +2,7 @@
 #include <cstdio>
 #include "moe_plan.h"
 #include "gemm.h"
+#include "kernels.h"
 #include <algorithm>
 #include <cstring>
 
@@ -149,7 +150,10 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   // workspace -- one 4096-token frame per chunk, split-K in every product -- ran 27 % slower at cfg-3): no (S, N, N) tensor in
   // HBM -- at AVVP stage 0 (N = 4096, 640 frames) that would be 21 GB (bf16) + 43 GB (fp32 scores) per site.
   d.nxc = d.S;
-  if (d.nxn && !d.mha) {
+  d.nflash = d.nxn && !d.mha && nxn_att_ok(d.bf16, d.N, d.C, (int)round_up(d.N, 8)) && !dev_env("AVMOE_NXN_OLD_BWD");
+  if (d.nflash) {
+    if (const char* ev = getenv("AVMOE_NXN_CHUNK")) d.nxc = std::max(1, std::min(d.S, atoi(ev)));     // tests: the frame loop of the strip kernels
+  } else if (d.nxn && !d.mha) {
     const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (2 * (size_t)d.esz);      // att + dSc (the scores / d att themselves never leave the chip)
     const size_t keep_all = (size_t)256 << 20;
     size_t budget = (size_t)2048 << 20;          // chunk workspace (scratch, reused by every site)

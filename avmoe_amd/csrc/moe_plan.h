@@ -56,6 +56,7 @@ struct Dims {
   // MultiheadAttention(x) across the frames, PVT_AVSModel_v2.py:210-214) run through the same code with
   // xr = MHA_e(x) - x, gate 1 and one xr slot per expert.
   int nxc;               // frames per chunk of the N x N block (== S: scores / softmax kept for the backward; < S: recomputed there)
+  int nflash;            // N x N block through the strip kernels (nxn_att.hip): neither the softmax nor its gradient is ever in memory -- no chunks, no (frames, N, N) workspace
   int nxr;               // xr slots
   int xr_of_e[MAX_E];    // slot of expert e or -1
   int mha;               // "v1" experts present
@@ -115,18 +116,18 @@ struct Dims {
   X(uvh, 0, 4, (size_t)2 * d.DZ + 2 * d.g * d.E)    /* usum, vh, H1[i][e], H2[i][e]   */       \
   X(Apost, 0, d.esz, (size_t)d.NT * d.g * d.KPp)                                                \
   /* ---- AVVP N x N block (only sized when present) ---- */                                     \
-  X(att, 0, d.esz, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)   /* softmax_rows(X X^T), nxc frames */  \
+  X(att, 0, d.esz, (d.nxn && !d.mha && !d.nflash) ? (size_t)d.nxc * d.N * d.Np : 1)   /* softmax_rows(X X^T), nxc frames */  \
   X(nlse, 0, 4, (d.nxn && !d.mha) ? (size_t)d.NT : 1)                      /* row log-sum-exp of X X^T (the backward re-forms att from it) */  \
   X(xr, 0, d.esz, d.nxn ? (size_t)d.nxr * d.NT * d.C : 1)       /* att^T X  |  MHA_e(X) - X per slot */  \
   X(sxr, 0, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)            /* sum xr, sum xr^2, x . xr  per slot */  \
   X(ZR, 0, 4, d.nxn ? (size_t)d.NT * d.DZ : 1)                  /* xr through Wt                  */  \
-  X(nyt, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.C : 1)            /* y = att dxr of a chunk (fp32) */  \
+  X(nyt, 1, 4, (d.nxn && !d.mha && !d.nflash) ? (size_t)d.nxc * d.N * d.C : 1)            /* y = att dxr of a chunk (fp32) */  \
   X(nrd, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N : 1)                  /* its row dots with X */  \
-  X(npart, 1, 4, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * ((d.N + 127) / 128) * 2 : 1)   /* per column tile (max, sum exp) of the score rows */  \
+  X(npart, 1, 4, (d.nxn && !d.mha && !d.nflash) ? (size_t)d.nxc * d.N * ((d.N + 127) / 128) * 2 : 1)   /* per column tile (max, sum exp) of the score rows */  \
   X(dZR, 1, d.esz, d.nxn ? (size_t)d.NT * d.DZ : 1)                                                    \
   X(dsr, 1, 4, d.nxn ? (size_t)d.nxr * 3 * d.NT : 1)                                                   \
   X(dxr, 1, d.esz, d.nxn ? (size_t)d.NT * d.C : 1)                                                     \
-  X(dSc, 1, d.esz, (d.nxn && !d.mha) ? (size_t)d.nxc * d.N * d.Np : 1)                                     \
+  X(dSc, 1, d.esz, (d.nxn && !d.mha && !d.nflash) ? (size_t)d.nxc * d.N * d.Np : 1)                                     \
   /* ---- AVS "v1" MultiheadAttention across the frames, per slot (only sized when present) ---- */ \
   X(mWin, 0, d.esz, d.mha ? (size_t)d.nxr * 3 * d.C * d.C : 1)      /* in_proj_weight in T              */  \
   X(mWout, 0, d.esz, d.mha ? (size_t)d.nxr * d.C * d.C : 1)         /* out_proj.weight in T             */  \

@@ -153,12 +153,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
 
-template <int KS, int MODE>      // MODE 0: y = att dxr (+ rowdot, dX += y) ; 1: dS ; 2: the FORWARD's xr = att^T X (the block owns 128 rows of xr; lse per streamed row)
+template <int KS, int MODE>      // MODE 0: y = att dxr (+ rowdot, dX += y) ; 2: the FORWARD's xr = att^T X (the block owns 128 rows of xr; lse per streamed row)
 __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Dx,
                                                                       const float* __restrict__ lse_g, float* __restrict__ rowdot, unsigned short* __restrict__ out,
                                                                       int N, int Np) {
-  // MODE 0: out = dX (S, N, C), += y ; rowdot written.   MODE 1: out = dS (S, N, Np) ; rowdot read.   MODE 2: out = xr (S, N, C), Dx unused.
-  constexpr bool DS = MODE == 1, XR = MODE == 2;
+  // MODE 0: out = dX (S, N, C), += y ; rowdot written.   MODE 2: out = xr (S, N, C), Dx unused.
+  constexpr bool XR = MODE == 2;
   constexpr int C = 32 * KS, RB = C * 2 + 16, CPR = C / 8, NLD = 128 * CPR / 256, CT = C / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
@@ -176,13 +176,11 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
     for (int ks = 0; ks < KS; ++ks) qf[tm][ks] = *(const bf16x8*)(Xf + (long)(i0 + 16 * tm + r) * C + ks * 32 + 8 * q);
   float lse[2] = {0.f, 0.f};
   if constexpr (!XR) { lse[0] = lse_g[f * N + i0 + r]; lse[1] = lse_g[f * N + i0 + 16 + r]; }
-  float rd[2] = {0.f, 0.f};
-  if constexpr (DS) { rd[0] = rowdot[f * N + i0 + r]; rd[1] = rowdot[f * N + i0 + 16 + r]; }
-  f32x4 accY[2][DS ? 1 : CT];
+  f32x4 accY[2][CT];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int ct = 0; ct < (DS ? 1 : CT); ++ct) accY[tm][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < CT; ++ct) accY[tm][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntile = N / 128;
   u32x4 st[NLD], sd[XR ? 1 : NLD];
   float lnext = 0.f;
@@ -242,7 +240,7 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[tm][t][e] = __expf(acc[tm][t][e] - lse[tm]);          // att, this lane's 32 key columns of row r
     }
-    if constexpr (!DS) {
+    {
       // rounded to bf16 as the stored softmax was (same numbers as the path it replaces), as B operands: step s = columns 32 q + 8 s .. + 7
       bf16x8 pb[2][4];
 #pragma unroll
@@ -264,33 +262,6 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm) accY[tm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pb[tm][sidx], accY[tm][ct], 0, 0, 0);
         }
-    } else {
-      // G = X_i . dxr_j in the same layout, then dS = att * (G - rowdot), 64 contiguous bytes per lane and query tile
-      f32x4 g[2][8];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) g[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const bf16x8 kf = *(const bf16x8*)(sD + ((r >> 2) * 32 + 4 * t + (r & 3)) * RB + ks * 64 + q * 16);
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) g[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], g[tm][t], 0, 0, 0);
-        }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        unsigned short* dst = out + (f * N + i0 + 16 * tm + r) * (long)Np + jt * 128 + 32 * q;
-        auto rb = [](float v) { return (float)(__bf16)v; };                  // (the stored softmax was bf16: the same factor)
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const f32x4 a = acc[tm][2 * h], b = acc[tm][2 * h + 1], ga = g[tm][2 * h], gb = g[tm][2 * h + 1];
-          const float l = rd[tm];
-          *(u32x4*)(dst + 8 * h) = u32x4{pack2(rb(a[0]) * (ga[0] - l), rb(a[1]) * (ga[1] - l)), pack2(rb(a[2]) * (ga[2] - l), rb(a[3]) * (ga[3] - l)),
-                                         pack2(rb(b[0]) * (gb[0] - l), rb(b[1]) * (gb[1] - l)), pack2(rb(b[2]) * (gb[2] - l), rb(b[3]) * (gb[3] - l))};
-        }
-      }
     }
   }
   if constexpr (XR) {                      // xr[own row][16 ct + 4 q + e]
@@ -304,7 +275,7 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
         dst[0] = pack2(y[0], y[1]); dst[1] = pack2(y[2], y[3]);
       }
     }
-  } else if constexpr (!DS) {
+  } else {
     // lane (r, q): y[query row][16 ct + 4 q + e]  ->  rowdot = X . y (over the row: the lane's entries, then the four q lanes), dX += y
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -325,6 +296,158 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
       dot += __shfl_xor(dot, 16, 64);
       dot += __shfl_xor(dot, 32, 64);
       if (q == 0) rowdot[row] = dot;
+    }
+  }
+}
+
+// The two products of the scores' gradient against X, dS formed in the accumulators and never stored (dS_ij = att_ij (X_i . dxr_j - rowdot_i)):
+//   KEY = false: the block owns 128 QUERY rows i (X_i as fragments), streams (X_j, dxr_j) tiles:            dX_i += sum_j dS_ij X_j
+//   KEY = true : the block owns 128 KEY rows j (X_j AND dxr_j as fragments), streams X_i tiles with the rows' (lse_i, rowdot_i):   dX_j += sum_i dS_ij X_i
+// Same accumulator trick as kk_nxn_bwd: lane (r, q) holds 32 consecutive streamed columns of own row r, which is the B operand of the
+// second product as it stands; its A operand is the streamed X tile read transposed.  A tile goes through in two halves of 64 streamed rows
+// (scores, their gradient and dS of a half are 80 registers instead of 160).
+template <int KS, bool KEY>
+__global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_dx(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Dx,
+                                                                     const float* __restrict__ lse_g, const float* __restrict__ rowdot,
+                                                                     unsigned short* __restrict__ out, int N) {
+  constexpr int C = 32 * KS, RB = C * 2 + 16, CPR = C / 8, NLD = 128 * CPR / 256, CT = C / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sD = smem + 128 * RB;                               // (query owner: the streamed dxr tile)
+  float* s_lse = (float*)(smem + 128 * RB);                 // (key owner: the streamed rows' log-sum-exp and row dots)
+  float* s_rd = s_lse + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const long f = blockIdx.y;
+  const unsigned short* Xf = X + f * (long)N * C;
+  const unsigned short* Df = Dx + f * (long)N * C;
+  const int i0 = blockIdx.x * 128 + 32 * wave;
+  bf16x8 qf[2][KS], df[KEY ? 2 : 1][KEY ? KS : 1];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[tm][ks] = *(const bf16x8*)(Xf + (long)(i0 + 16 * tm + r) * C + ks * 32 + 8 * q);
+      if constexpr (KEY) df[tm][ks] = *(const bf16x8*)(Df + (long)(i0 + 16 * tm + r) * C + ks * 32 + 8 * q);
+    }
+  float lse[2] = {0.f, 0.f}, rd[2] = {0.f, 0.f};
+  if constexpr (!KEY) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) { lse[tm] = lse_g[f * N + i0 + 16 * tm + r]; rd[tm] = rowdot[f * N + i0 + 16 * tm + r]; }
+  }
+  f32x4 accY[2][CT];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) accY[tm][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntile = N / 128;
+  u32x4 st[NLD], sd[KEY ? 1 : NLD];
+  float lnext = 0.f;
+  auto gload = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + 256 * i;
+      const long off = (long)(jt * 128 + c / CPR) * C + (c % CPR) * 8;
+      st[i] = *(const u32x4*)(Xf + off);
+      if constexpr (!KEY) sd[i] = *(const u32x4*)(Df + off);
+    }
+    if constexpr (KEY) lnext = tid < 128 ? lse_g[f * N + jt * 128 + tid] : rowdot[f * N + jt * 128 + tid - 128];
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + 256 * i;
+      *(u32x4*)(sX + (c / CPR) * RB + (c % CPR) * 16) = st[i];
+      if constexpr (!KEY) *(u32x4*)(sD + (c / CPR) * RB + (c % CPR) * 16) = sd[i];
+    }
+    if constexpr (KEY) s_lse[tid] = lnext;                  // (s_rd follows s_lse)
+  };
+  auto rb = [](float v) { return (float)(__bf16)v; };       // (the softmax the engine's products read was bf16: the same factor)
+  gload(0);
+  for (int jt = 0; jt < ntile; ++jt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (jt + 1 < ntile) gload(jt + 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                           // streamed rows 32 q + 16 h + 4 t + e of the tile
+      f32x4 acc[2][4], g[2][4];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; g[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = (r >> 2) * 32 + 16 * h + 4 * t + (r & 3);
+          const bf16x8 kf = *(const bf16x8*)(sX + row * RB + ks * 64 + q * 16);
+          if constexpr (KEY) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+              acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);      // X_i . X_j
+              g[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, df[tm][ks], g[tm][t], 0, 0, 0);          // X_i . dxr_j
+            }
+          } else {
+            const bf16x8 kd = *(const bf16x8*)(sD + row * RB + ks * 64 + q * 16);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+              acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);      // X_j . X_i
+              g[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kd, qf[tm][ks], g[tm][t], 0, 0, 0);          // dxr_j . X_i
+            }
+          }
+        }
+      bf16x8 pb[2][2];
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        float ds[2][2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * sp + u;
+          float lv[4], rv[4];
+          if constexpr (KEY) {
+            const float4 l4 = *(const float4*)(s_lse + 32 * q + 16 * h + 4 * t), r4 = *(const float4*)(s_rd + 32 * q + 16 * h + 4 * t);
+            lv[0] = l4.x; lv[1] = l4.y; lv[2] = l4.z; lv[3] = l4.w; rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+          }
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float l = KEY ? lv[e] : lse[tm], d0 = KEY ? rv[e] : rd[tm];
+              ds[tm][u][e] = rb(__expf(acc[tm][t][e] - l)) * (g[tm][t][e] - d0);
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          pb[tm][sp] = bf16x8{(__bf16)ds[tm][0][0], (__bf16)ds[tm][0][1], (__bf16)ds[tm][0][2], (__bf16)ds[tm][0][3],
+                              (__bf16)ds[tm][1][0], (__bf16)ds[tm][1][1], (__bf16)ds[tm][1][2], (__bf16)ds[tm][1][3]};
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const char* ad = sX + (32 * q + 16 * h + 8 * sp + (r >> 2)) * RB + (16 * ct + 4 * (r & 3)) * 2;
+          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad));
+          const s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad + 4 * RB));
+          const s16x8_t w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+          const bf16x8 af = __builtin_bit_cast(bf16x8, w);                 // X^T: channel 16 ct + r, streamed rows 32 q + 16 h + 8 sp + 0 .. 7
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) accY[tm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pb[tm][sp], accY[tm][ct], 0, 0, 0);
+        }
+    }
+  }
+  // lane (r, q): the sum for own row 16 tm + r, channels 16 ct + 4 q + e  ->  dX += it
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const long row = f * N + i0 + 16 * tm + r;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const long o = row * C + 16 * ct + 4 * q;
+      const unsigned ol = *(const unsigned*)(out + o), oh = *(const unsigned*)(out + o + 2);
+      auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+      auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+      const f32x4 y = accY[tm][ct];
+      *(unsigned*)(out + o) = pack2(lo(ol) + y[0], hi(ol) + y[1]);
+      *(unsigned*)(out + o + 2) = pack2(lo(oh) + y[2], hi(oh) + y[3]);
     }
   }
 }
@@ -358,12 +481,11 @@ int k_nxn_att_bwd(const void* X, const void* dxr, int frames, int N, int C, int 
 
 // y = att dxr without att in memory (re-formed from the kept row log-sum-exp): rowdot = X . y written, dX += y
 static int nxn_bwd_launch(int mode, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* out, hipStream_t st) {
-  const bool ds = mode == 1;
   if (!nxn_att_ok(1, N, C, Np)) { set_last_error("nxn_bwd: shape not served (C = 96 / 192, N a multiple of 128)"); return ERR_UNSUPPORTED; }
   if (frames <= 0) return OK;
-  const double bytes = (double)frames * N * ((double)C * 2 * (ds ? 2 : 4) + (ds ? (double)Np * 2 : 0.0) + 8);
-  const double flops = (ds ? 2.0 : 2.0) * 2.0 * frames * (double)N * N * C;
-  ProfScope ps_(mode == 2 ? "k_nxn_xr" : (ds ? "k_nxn_ds" : "k_nxn_y"), (long)frames * N, bytes, flops, st);
+  const double bytes = (double)frames * N * ((double)C * 2 * (mode == 2 ? 2 : 4) + 8);
+  const double flops = 2.0 * 2.0 * frames * (double)N * N * C;
+  ProfScope ps_(mode == 2 ? "k_nxn_xr" : "k_nxn_y", (long)frames * N, bytes, flops, st);
   const dim3 grid((unsigned)(N / 128), (unsigned)frames);
   const int lds = mode == 2 ? 128 * (C * 2 + 16) + 512 : 2 * 128 * (C * 2 + 16);
 #define NXB(KS_, DS_)                                                                                                     \
@@ -373,8 +495,8 @@ static int nxn_bwd_launch(int mode, const void* X, const void* dxr, int frames, 
     hipLaunchKernelGGL((kk_nxn_bwd<KS_, DS_>), grid, dim3(256), lds, st, (const unsigned short*)X, (const unsigned short*)dxr, lse, rowdot, \
                        (unsigned short*)out, N, Np);                                                                      \
   } while (0)
-  if (C == 96) { if (mode == 2) NXB(3, 2); else if (ds) NXB(3, 1); else NXB(3, 0); }
-  else { if (mode == 2) NXB(6, 2); else if (ds) NXB(6, 1); else NXB(6, 0); }
+  if (C == 96) { if (mode == 2) NXB(3, 2); else NXB(3, 0); }
+  else { if (mode == 2) NXB(6, 2); else NXB(6, 0); }
 #undef NXB
   AVMOE_CHECK_LAUNCH("nxn_bwd");
   return OK;
@@ -382,12 +504,32 @@ static int nxn_bwd_launch(int mode, const void* X, const void* dxr, int frames, 
 int k_nxn_y(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* dX, hipStream_t st) {
   return nxn_bwd_launch(0, X, dxr, frames, N, C, Np, lse, rowdot, dX, st);
 }
-int k_nxn_ds(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dS, hipStream_t st) {
-  return nxn_bwd_launch(1, X, dxr, frames, N, C, Np, lse, (float*)rowdot, dS, st);
-}
 // the forward's xr = att^T X from the row log-sum-exp (k_nxn_att with att == nullptr leaves it): the softmax is never stored
 int k_nxn_xr(const void* X, int frames, int N, int C, int Np, const float* lse, void* xr, hipStream_t st) {
   return nxn_bwd_launch(2, X, X, frames, N, C, Np, lse, nullptr, xr, st);
+}
+
+// dX += dS X (query owner) or dS^T X (key owner) with dS re-formed in the accumulators: neither att nor dS exists in memory
+int k_nxn_dx(int key, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dX, hipStream_t st) {
+  if (!nxn_att_ok(1, N, C, Np)) { set_last_error("nxn_dx: shape not served (C = 96 / 192, N a multiple of 128)"); return ERR_UNSUPPORTED; }
+  if (frames <= 0) return OK;
+  const double bytes = (double)frames * N * ((double)C * 2 * (key ? 4 : 4) + 8);
+  const double flops = 3.0 * 2.0 * frames * (double)N * N * C;
+  ProfScope ps_(key ? "k_nxn_dxk" : "k_nxn_dxq", (long)frames * N, bytes, flops, st);
+  const dim3 grid((unsigned)(N / 128), (unsigned)frames);
+  const int lds = key ? 128 * (C * 2 + 16) + 1024 : 2 * 128 * (C * 2 + 16);
+#define NXD(KS_, KEY_)                                                                                                   \
+  {                                                                                                                      \
+    static LdsAttrOnce attr;                                                                                             \
+    AVMOE_TRY(attr.ensure((const void*)kk_nxn_dx<KS_, KEY_>, lds, "nxn_dx"));                                            \
+    hipLaunchKernelGGL((kk_nxn_dx<KS_, KEY_>), grid, dim3(256), lds, st, (const unsigned short*)X, (const unsigned short*)dxr, lse, rowdot, \
+                       (unsigned short*)dX, N);                                                                          \
+  }
+  if (C == 96) { if (key) NXD(3, true) else NXD(3, false) }
+  else { if (key) NXD(6, true) else NXD(6, false) }
+#undef NXD
+  AVMOE_CHECK_LAUNCH("nxn_dx");
+  return OK;
 }
 
 }  // namespace avmoe

@@ -220,7 +220,10 @@ def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
     g0 = whole.backward(G, lb_weight=lbw)
     monkeypatch.setenv("AVMOE_NXN_CHUNK", str(chunk))
     run = MoeRun(cfg, P, B, X, Y, bf16=bf16, training=True).forward()
-    assert run.table["att"][2] < whole.table["att"][2]                  # the (frames, N, N) workspace shrank
+    if whole.table["att"][2] > 64:
+        assert run.table["att"][2] < whole.table["att"][2]              # the (frames, N, N) workspace shrank
+    else:                                                               # strip kernels (bf16, N a multiple of 128, C = 96 / 192): no such workspace, the
+        assert bf16 and cfg.Nx % 128 == 0                               # chunk is only the frame range of a launch
     g1 = run.backward(G, lb_weight=lbw)
     monkeypatch.delenv("AVMOE_NXN_CHUNK")
     assert torch.equal(run.idx, whole.idx)
