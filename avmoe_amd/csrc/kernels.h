@@ -83,6 +83,9 @@ int k_nxn_att_bwd(const void* X, const void* dxr, int frames, int N, int C, int 
 int k_nxn_y(const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, float* rowdot, void* dX, hipStream_t st);   // rowdot = X . (att dxr) ; dX += att dxr
 int k_nxn_xr(const void* X, int frames, int N, int C, int Np, const float* lse, void* xr, hipStream_t st);      // forward: xr = att^T X (lse from k_nxn_att with att == nullptr)
 int k_nxn_dx(int key, const void* X, const void* dxr, int frames, int N, int C, int Np, const float* lse, const float* rowdot, void* dX, hipStream_t st);   // dX += dS X (key = 0) / dS^T X (key = 1), dS in the accumulators
+// dApost = dOut Bpost and dBpost = dOut^T Apost from one pass over dOut (dpost_pair.hip); 1 = shape not served
+int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long sBg, const void* Apost, long lda, void* dAp, long ldc, float* dApx, long ldx, int XW,
+                 float* dBp, int ntok, int G, int Cg, int nmain, int KP, int KPp, float* slabs, size_t slab_cap, hipStream_t st);
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

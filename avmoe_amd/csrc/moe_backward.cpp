@@ -58,7 +58,17 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   // (the engine's Gram path splits K itself: it needs the slabs; sites on the generalised kernels keep post_small_bwd off the GPU while
   // a GEMM of the helper stream runs -- tile_gen.inc::gen_lds_request has the reason)
   const bool fork1 = side && (side_mask() & 2) && (d.gram64 || !d.ln_post) && !d.gen;
-  {
+  int dap16 = 0;     // dApost stored as [E x 32 bottleneck columns in T | 3 E scalar columns in fp32 (dApx)]: the register-resident bf16 path
+  bool pair1 = false;                                      // both products from one pass over dOut (dpost_pair.hip: the tuned bf16 shape)
+  if (d.zsz == 2 && d.bf16 && !dev_env("AVMOE_NO_DPAIR")) {
+    const int rc = k_dpost_pair(dOut, d.C, sv + pl.o_Bpost, d.KPp, (long)d.Cg * d.KPp, sv + pl.o_Apost, (long)d.g * d.KPp, sc + pl.o_dAp, (long)d.g * d.E * d.dgp,
+                                (float*)(sc + pl.o_dApx), (long)d.g * d.XW, d.XW, (float*)(sc + pl.o_dBp), d.NT, d.g, d.Cg, d.E * d.dgp, d.KP, d.KPp,
+                                slabs, slab_cap, st);
+    if (rc < 0) return rc;
+    pair1 = rc == OK;
+    if (pair1) dap16 = 1;
+  }
+  if (!pair1) {
     GemmArgs g = base();
     g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
     g.M = d.Cg; g.N = d.KP; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = (long)d.g * d.KPp; g.nb2 = d.g;
@@ -66,8 +76,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     if (fork1) AVMOE_TRY(fk1.fork());
     AVMOE_TRY(run_on(g, true, fork1 ? side->s : st));
   }
-  int dap16 = 0;     // dApost stored as [E x 32 bottleneck columns in T | 3 E scalar columns in fp32 (dApx)]: the register-resident bf16 path
-  {
+  if (!pair1) {
     GemmArgs g = base();
     g.A = dOut; g.B = sv + pl.o_Bpost; g.C = sc + pl.o_dAp;
     // N = KP, or the padded KPp when KP is not a multiple of 4 (2 or 3 experts): Bpost's padding columns are zero, the streaming
