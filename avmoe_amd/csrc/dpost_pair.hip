@@ -59,6 +59,32 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* ad, int rb) {      // [k =
   return __builtin_bit_cast(bf16x8, w);
 }
 
+// The transposing LDS reads of the dBpost phase as inline assembly: for the intrinsic the compiler waits for EVERY outstanding direct-to-LDS
+// load first (it cannot tell that they go to the other buffer), which left the next tile's loads overlapping the dApost phase only.  The waits
+// for these reads are explicit (tr_wait*: the fragments pass through the wait so that their consumers stay behind it).
+template <int OFF>
+__device__ __forceinline__ void tr_issue(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory"); }
+template <int TK, int C0>     // three column tiles C0 .. C0 + 2 of the Apost tile, K step TK
+__device__ __forceinline__ void tr_issue_b3(u32x2 (&b)[3][2], unsigned lb) {
+  tr_issue<TK * 32 * RBA + (C0 + 0) * 32>(b[0][0], lb); tr_issue<TK * 32 * RBA + (C0 + 0) * 32 + 4 * RBA>(b[0][1], lb);
+  tr_issue<TK * 32 * RBA + (C0 + 1) * 32>(b[1][0], lb); tr_issue<TK * 32 * RBA + (C0 + 1) * 32 + 4 * RBA>(b[1][1], lb);
+  tr_issue<TK * 32 * RBA + (C0 + 2) * 32>(b[2][0], lb); tr_issue<TK * 32 * RBA + (C0 + 2) * 32 + 4 * RBA>(b[2][1], lb);
+}
+template <int TK>
+__device__ __forceinline__ void tr_issue_a3(u32x2 (&a)[3][2], unsigned la) {
+  tr_issue<TK * 32 * RB + 0>(a[0][0], la); tr_issue<TK * 32 * RB + 0 + 4 * RB>(a[0][1], la);
+  tr_issue<TK * 32 * RB + 32>(a[1][0], la); tr_issue<TK * 32 * RB + 32 + 4 * RB>(a[1][1], la);
+  tr_issue<TK * 32 * RB + 64>(a[2][0], la); tr_issue<TK * 32 * RB + 64 + 4 * RB>(a[2][1], la);
+}
+__device__ __forceinline__ void tr_wait3(u32x2 (&x)[3][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]) :: "memory");
+}
+__device__ __forceinline__ void tr_wait6(u32x2 (&x)[3][2], u32x2 (&y)[3][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]),
+               "+v"(y[0][0]), "+v"(y[0][1]), "+v"(y[1][0]), "+v"(y[1][1]), "+v"(y[2][0]), "+v"(y[2][1]) :: "memory");
+}
+__device__ __forceinline__ bf16x8 tr_pack(const u32x2 (&f)[2]) { return __builtin_bit_cast(bf16x8, u32x4{f[0][0], f[0][1], f[1][0], f[1][1]}); }
+
 __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sB8 = smem + 2 * STG + 2 * STGA;
@@ -122,19 +148,24 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
     const int nxt = tile + step, m0 = tile * BM;
     if (nxt < p.ntiles) gload((it + 1) & 1, nxt);         // (the other buffer: its readers passed the barrier that ended the previous iteration)
     // ---- dApost: the tile's 64 rows against this wave's column tile (and the scalar tile for slab mt == wave) ----
+#ifndef DPAIR_CH
+#define DPAIR_CH 2               // 16-token slabs done together (independent accumulator chains; 4: the same time, 8 more registers)
+#endif
 #pragma unroll
-    for (int mp = 0; mp < ((DPAIR_DISSECT & 1) ? 0 : 2); ++mp) {      // two 16-token slabs at a time: two independent accumulator chains
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int mp = 0; mp < ((DPAIR_DISSECT & 1) ? 0 : 4 / DPAIR_CH); ++mp) {
+      f32x4 acc[DPAIR_CH];
+#pragma unroll
+      for (int h = 0; h < DPAIR_CH; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bf16x8 af = *(const bf16x8*)(sA + (16 * (2 * mp + h) + r) * RB + ks * 64 + q * 16);
+        for (int h = 0; h < DPAIR_CH; ++h) {
+          const bf16x8 af = *(const bf16x8*)(sA + (16 * (DPAIR_CH * mp + h) + r) * RB + ks * 64 + q * 16);
           acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks], af, acc[h], 0, 0, 0);
         }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                        // lane (r, q): token r of the slab, columns 4 q .. 4 q + 3 of the tile
-        const long m = m0 + 16 * (2 * mp + h) + r;
+      for (int h = 0; h < DPAIR_CH; ++h) {                 // lane (r, q): token r of the slab, columns 4 q .. 4 q + 3 of the tile
+        const long m = m0 + 16 * (DPAIR_CH * mp + h) + r;
         *(u32x2*)(p.dAp + (m * p.ldc + g * 128 + 16 * wave + 4 * q) * 2) = u32x2{f2bf(acc[h][0]) | (f2bf(acc[h][1]) << 16), f2bf(acc[h][2]) | (f2bf(acc[h][3]) << 16)};
       }
     }
@@ -148,17 +179,26 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
       if (4 * q < p.NX) *(f32x4*)(p.dApx + (long)(m0 + 16 * wave + r) * p.ldx + g * p.XW + 4 * q) = a8[0] + a8[1];
     }
     // ---- dBpost += dOut_tile^T Apost_tile : channel tiles 3 wave .. + 2 x nine column tiles, 32 tokens per step ----
+    if constexpr ((DPAIR_DISSECT & 2) == 0) {
+      const unsigned l0 = (unsigned)(size_t)(lptr_t)sA;
+      const unsigned la = l0 + (8 * q + (r >> 2)) * RB + (3 * wave * 16 + 4 * (r & 3)) * 2;
+      const unsigned lb = l0 + STG + (8 * q + (r >> 2)) * RBA + (4 * (r & 3)) * 2;
+      u32x2 fa[3][2], fb0[3][2], fb1[3][2];
+      auto mm = [&](int c0, const u32x2 (&fb)[3][2]) {
 #pragma unroll
-    for (int tk = 0; tk < ((DPAIR_DISSECT & 2) ? 0 : BM / 32); ++tk) {
-      bf16x8 afr[3];
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) afr[i] = tr_frag(sA + (tk * 32 + 8 * q + (r >> 2)) * RB + ((3 * wave + i) * 16 + 4 * (r & 3)) * 2, RB);
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const bf16x8 bf = tr_frag(sP + (tk * 32 + 8 * q + (r >> 2)) * RBA + (c * 16 + 4 * (r & 3)) * 2, RBA);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) accB[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bf, accB[i][c], 0, 0, 0);
-      }
+          for (int i = 0; i < 3; ++i) accB[i][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pack(fa[i]), tr_pack(fb[c]), accB[i][c0 + c], 0, 0, 0);
+      };
+      // (the reads of the next three column tiles are in flight during the nine matrix instructions of the current three)
+      tr_issue_a3<0>(fa, la); tr_issue_b3<0, 0>(fb0, lb); tr_wait6(fa, fb0);
+      tr_issue_b3<0, 3>(fb1, lb); mm(0, fb0); tr_wait3(fb1);
+      tr_issue_b3<0, 6>(fb0, lb); mm(3, fb1); tr_wait3(fb0);
+      mm(6, fb0);
+      tr_issue_a3<1>(fa, la); tr_issue_b3<1, 0>(fb0, lb); tr_wait6(fa, fb0);
+      tr_issue_b3<1, 3>(fb1, lb); mm(0, fb0); tr_wait3(fb1);
+      tr_issue_b3<1, 6>(fb0, lb); mm(3, fb1); tr_wait3(fb0);
+      mm(6, fb0);
     }
     __syncthreads();                                      // (waits for the direct loads above: the next tile is in place)
   }

@@ -108,7 +108,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.nb2 = d.g * d.E; g.sA2 = g.sB2 = d.dgp; g.sCi = d.dgp; g.sC2 = (long)d.dgp * d.dgp;
     AVMOE_TRY(run(g, true));
   }
-  if (fork1) AVMOE_TRY(fk1.join());
+  if (fork1 && !pair1) AVMOE_TRY(fk1.join());
   BWD_STOP(3);
   AVMOE_TRY(k_post_prep_bwd(pl, sv, sc, prm, grads, st));
   BWD_STOP(4);

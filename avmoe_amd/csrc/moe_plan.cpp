@@ -22,7 +22,10 @@ size_t slab_floats(const Dims& d) {
   const size_t out5 = (size_t)(d.KL ? d.KL : 1) * (d.Cy > d.C ? d.Cy : d.C);
   const size_t out6 = d.mha ? (size_t)3 * d.C * d.C : 0;              // d in_proj_weight
   size_t m = std::max(std::max(std::max(out1, out2), std::max(std::max(out3, out4), out5)), out6);
-  return m * 96 + 1024;
+  size_t need = m * 96 + 1024;
+  // dpost_pair.hip (bf16, 384 channels per group, 128 + <= 16 columns): one partial dBpost per block, one block per CU
+  if (d.bf16 && d.Cg == 384 && d.E * d.dgp == 128 && d.KPp == 144) need = std::max(need, (size_t)320 * d.Cg * d.KPp + 1024);
+  return need;
 }
 
 int make_plan(const avmoe_moe_desc* q, Plan* pl) {
