@@ -18,7 +18,7 @@ with open(sys.argv[1]) as fh:
         m = re.search(r"(k[fg]_\w+?)I[DfL]|(gemm_stream_kernel<[^>]*>)|(k[kwg]_\w+?)I[DfL]|(gemm_kernelI\w+?)EEv|avmoe::(\w+)", name)
         if m:
             name = next(g for g in m.groups() if g)
-        name = re.sub(r"\(.*", "", re.sub(r"^void ", "", name))
+        name = re.sub(r"\(.*", "", re.sub(r"^void ", "", name.replace("(anonymous namespace)::", "")))
         tot[name][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] == "SQ_BUSY_CYCLES":
             cnt[name] += 1

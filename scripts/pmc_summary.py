@@ -14,7 +14,7 @@ def load(path):
             m = re.search(r"(kf_\w+?)I[DfL]|(gemm_stream_kernel<[^>]*>)|(k[kw]_\w+?)I[DfL]|(gemm_kernelI\w+?)EEv|avmoe::(\w+)", name)
             if m:
                 name = next(g for g in m.groups() if g)
-            name = re.sub(r"\(.*", "", name)
+            name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
             name = re.sub(r"^void ", "", name)
             tot[name] += float(row["Counter_Value"])
             cnt[name] += 1

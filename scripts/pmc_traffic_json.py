@@ -31,6 +31,10 @@ def family(sym: str):
         return "gemm_splitk_reduce"
     if "kk_xstats" in sym:
         return "k_xstats"
+    if "kk_dpair_reduce" in sym:
+        return "k_dpair_reduce"
+    if "kk_dpair" in sym:
+        return "k_dpost_pair"
     m = re.search(r"gemm_stream_kernel<([^>]*)>", sym)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
