@@ -52,6 +52,11 @@ struct GemmArgs {
   int ksplit = 1;
   float* slabs = nullptr;
   int keep_slabs = 0;                   // split-K: leave the partial sums in `slabs` (no reduce pass): the caller's consumer adds them
+  // fp32 operands only: the product on the bf16 matrix pipe in THREE-PLANE form -- every value as three bf16 planes (x = p0 + p1 + p2 up to
+  // 2^-24 |x|), the six plane products of order <= 2, fp32 accumulation: 5.8e-9 relative per product (the fp32 rounding of the sum itself is
+  // 2 - 4e-7) at 6 x 16 instead of 8 x 32 matrix-pipe cycles per 16 x 16 x 32 block.  The site's BACKWARD sets it; the forward keeps
+  // v_mfma_f32_16x16x4_f32 (same values to the last bit as rounds 1 - 3: which ReLU units sit on which side of zero does not move).
+  int split3 = 0;
   int tile = 0;                         // 0 = auto, 64 or 128 = force block tile
   // optional second K segment, accumulated into the same tile before the epilogue:
   //   C += alpha * A2[b][i][k2] * B2[b][j][k2]   with A2 K_MAJOR (lda2), B2 MN_MAJOR (ldb2), own batch strides.

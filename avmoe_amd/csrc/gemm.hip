@@ -21,6 +21,7 @@
 #include "prof.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace avmoe {
 
@@ -67,6 +68,8 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int valid) {
 // bytes of K per operand row and stage: 128; 256 for the 64 x 64 tile with both operands MN-major (the token contractions: their K
 // loop is bound by one memory round trip per step, and half the steps measured 140 -> 117 us on dQ = sum_s dR[s] Y[s]; for K-major
 // operands -- 256-byte row pieces -- the same change measured 3 - 60 % SLOWER)
+// Element-type tag of the fp32 instances that run on the bf16 matrix pipe in three-plane form (GemmArgs::split3; gemm_segment has the arithmetic)
+struct f32s3 { float v; };
 constexpr int stage_kbytes(int BM, int BN, bool AMN, bool BMN) { return (BM <= 64 && BN <= 64 && AMN && BMN) ? 256 : 128; }
 
 // One K segment of the block's tile: 2-stage LDS pipeline over [kbeg, kend), accumulating into acc.
@@ -194,6 +197,51 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
           for (int tn = 0; tn < TN; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
       }
+    } else if constexpr (std::is_same<T, f32s3>::value) {
+      // fp32 operands on the bf16 matrix pipe WITHOUT giving up fp32 products: every value as three bf16 planes (8 + 8 + 8 mantissa bits:
+      // x = p0 + p1 + p2 exactly up to 2^-24 |x|), the six plane products of order <= 2 as v_mfma_f32_16x16x32_bf16, fp32 accumulation:
+      // 5.8e-9 relative per product against 2 - 4e-7 for the fp32 rounding of the sum itself (measured) at
+      // 6 x 16 instead of 8 x 32 matrix-pipe cycles per 16 x 16 x 32 block.  The planes are formed in registers from the fp32 LDS tile.
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 af[TM][3];
+        auto frag = [&](const char* base, int rowb, bool mn, int col0, bf16x8 (&p)[3]) {
+          float x[8];
+          if (!mn) {
+            const f32x4 v0 = *(const f32x4*)(base + (col0 + r) * rowb + ks * 128 + q * 32);
+            const f32x4 v1 = *(const f32x4*)(base + (col0 + r) * rowb + ks * 128 + q * 32 + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = v0[j]; x[4 + j] = v1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = *(const float*)(base + (32 * ks + 8 * q + j) * rowb + (col0 + r) * 4);
+          }
+          float rr[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const __bf16 h = (__bf16)x[j]; p[0][j] = h; rr[j] = x[j] - (float)h; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const __bf16 h = (__bf16)rr[j]; p[1][j] = h; rr[j] -= (float)h; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p[2][j] = (__bf16)rr[j];
+        };
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) frag(sA, A_ROWB, AMN, wm0 + 16 * tm, af[tm]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bf16x8 bf[3];
+          frag(sB, B_ROWB, BMN, wn0 + 16 * tn, bf);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            f32x4 c = acc[tm][tn];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][2], bf[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][1], bf[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][1], bf[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[1], c, 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[0], c, 0, 0, 0);
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int kc = 0; kc < BK / 16; ++kc) {
@@ -244,7 +292,7 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
 }
 
 template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2>
-__global__ void __launch_bounds__(256) gemm_kernel(const DevArgs p) {
+__global__ void __launch_bounds__(256, (std::is_same<T, f32s3>::value ? 2 : 1)) gemm_kernel(const DevArgs p) {
   constexpr int ESZ = sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -759,7 +807,7 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];
-  if (!name[0]) snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : "f32", BM);
+  if (!name[0]) snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : "f32"), BM);
   static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
   const char* pname = name;
   if (shapes && prof_enabled()) {            // debug only: one family per distinct call shape (leaks the small strings)
@@ -943,15 +991,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   } else if (tile == 128) {
     d.tiles_n = cdiv(a.N, 128);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 128, 128>(a, d, bz, stream)
-                              : launch_layout<float, 128, 128>(a, d, bz, stream);
+                              : (a.split3 ? launch_layout<f32s3, 128, 128>(a, d, bz, stream) : launch_layout<float, 128, 128>(a, d, bz, stream));
   } else if (tile == 64) {
     d.tiles_n = cdiv(a.N, 64);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 64, 64>(a, d, bz, stream)
-                              : launch_layout<float, 64, 64>(a, d, bz, stream);
+                              : (a.split3 ? launch_layout<f32s3, 64, 64>(a, d, bz, stream) : launch_layout<float, 64, 64>(a, d, bz, stream));
   } else if (tile == 32) {                                   // small per-batch problems (K x K latent matrices, S x S frame attention)
     d.tiles_n = cdiv(a.N, 32);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 32, 32>(a, d, bz, stream)
-                              : launch_layout<float, 32, 32>(a, d, bz, stream);
+                              : (a.split3 ? launch_layout<f32s3, 32, 32>(a, d, bz, stream) : launch_layout<float, 32, 32>(a, d, bz, stream));      // (every tile: the result must not depend on the tile the block count picks)
   } else {
     set_last_error("gemm: tile %d not built", tile);
     return ERR_UNSUPPORTED;

@@ -34,7 +34,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
-  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
+  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; g.split3 = 1; return g; };      // (split3: fp32 sites only, gemm.h)
   auto run_on = [&](GemmArgs& g, bool split, hipStream_t on) {
     if (split) g.ksplit = choose_ksplit(g, slab_cap);
     return launch_gemm(g, on);
@@ -188,6 +188,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
           g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
           g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
           g.epi = GEMM_EPI_EXP; g.row_lse = (const float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
+          g.split3 = 0;                                      // (the forward's arithmetic: the chunked site must re-form the very att the unchunked one kept)
           AVMOE_TRY(run(g, false));
         }
         {                                                    // y[s] = att[s] dxr[s]   (fp32): the direct term of dX and the softmax's row term
