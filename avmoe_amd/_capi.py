@@ -20,7 +20,7 @@ class AvmoeError(RuntimeError):
 
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "nb1", "nb2", "dtype", "out_dtype", "a_layout",
-                                         "b_layout", "accumulate", "ksplit", "tile")] + \
+                                         "b_layout", "accumulate", "ksplit", "tile", "fp32_planes")] + \
                [("alpha", C.c_float)] + \
                [(n, C.c_int64) for n in ("lda", "ldb", "sA1", "sA2", "sB1", "sB2", "sCi", "sCj", "sC1", "sC2",
                                          "sRS1", "sRS2", "sDi", "sD1", "sD2")]

@@ -216,18 +216,28 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
     }
 }
 
-// dBp[g][ch][col] = sum over the blocks' slabs, in block order: eight lanes per element (slabs p, p + 8, ...), fixed xor tree
+// dBp[g][ch][col] = sum over the blocks' slabs, in a fixed order: a wave covers 16 consecutive 4-element vectors, four lanes per vector
+// (lane = part * 16 + vector: 256 contiguous bytes per part and slab; part p sums slabs p, p + 4, ...), fixed xor tree over the parts
 __global__ void __launch_bounds__(256) kk_dpair_reduce(const float* __restrict__ slabs, int nslab, int G, int KP, int KPp, float* __restrict__ out) {
-  const long per = (long)G * 384 * KP;
-  const long el = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
-  const int part = threadIdx.x & 7;
-  float s = 0.f;
-  if (el < per)
-    for (int b = part; b < nslab; b += 8) s += slabs[(long)b * per + el];
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (el < per && part == 0) {
-    const long row = el / KP; const int col = (int)(el - row * KP);
-    out[row * KPp + col] = s;
+  const long per = (long)G * 384 * KP, nvec = per / 4;                    // (KP % 4 == 0: the launcher checks)
+  const int lane = threadIdx.x & 63, part = lane >> 4;
+  const long v = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (v < nvec) {
+    const float* sl = slabs + v * 4;
+    int b = part;
+    for (; b + 12 < nslab; b += 16) {
+      const f32x4 a0 = *(const f32x4*)(sl + (long)b * per), a1 = *(const f32x4*)(sl + (long)(b + 4) * per);
+      const f32x4 a2 = *(const f32x4*)(sl + (long)(b + 8) * per), a3 = *(const f32x4*)(sl + (long)(b + 12) * per);
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < nslab; b += 4) s += *(const f32x4*)(sl + (long)b * per);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s[e] += __shfl_xor(s[e], 16, 64); s[e] += __shfl_xor(s[e], 32, 64); }
+  if (v < nvec && part == 0) {
+    const long el = v * 4, row = el / KP; const int col = (int)(el - row * KP);
+    *(f32x4*)(out + row * KPp + col) = s;
   }
 }
 
@@ -236,7 +246,7 @@ __global__ void __launch_bounds__(256) kk_dpair_reduce(const float* __restrict__
 // 0 = launched, 1 = shape not served (the caller runs the two kernels), < 0 error
 int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long sBg, const void* Apost, long lda, void* dAp, long ldc, float* dApx, long ldx, int XW,
                  float* dBp, int ntok, int G, int Cg, int nmain, int KP, int KPp, float* slabs, size_t slab_cap, hipStream_t st) {
-  if (Cg != 384 || nmain != 128 || KPp != 144 || KP <= 128 || KP > 144 || XW < 16 || ntok < 4096 || ntok % BM || ldo % 8 || lda % 8 || !slabs ||
+  if (Cg != 384 || nmain != 128 || KPp != 144 || KP <= 128 || KP > 144 || KP % 4 || ((uintptr_t)dBp % 16) || XW < 16 || ntok < 4096 || ntok % BM || ldo % 8 || lda % 8 || !slabs ||
       ((uintptr_t)dOut % 16) || ((uintptr_t)Apost % 16) || ((uintptr_t)dAp % 8) || ((uintptr_t)dApx % 16) || ldx % 4 || (G * XW) % 4)
     return 1;
   static int cus = 0;
@@ -264,7 +274,7 @@ int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long s
   }
   {
     ProfScope ps("k_dpair_reduce", (long)per, (double)per * 4.0 * (gx + 1), 0.0, st);
-    hipLaunchKernelGGL(kk_dpair_reduce, dim3((unsigned)((per * 8 + 255) / 256)), dim3(256), 0, st, slabs, gx, G, KP, KPp, dBp);
+    hipLaunchKernelGGL(kk_dpair_reduce, dim3((unsigned)((per / 4 + 63) / 64)), dim3(256), 0, st, slabs, gx, G, KP, KPp, dBp);
     AVMOE_CHECK_LAUNCH("dpair_reduce");
   }
   return OK;

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 8
+#define AVMOE_ABI_VERSION 9
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -42,6 +42,9 @@ typedef struct avmoe_gemm_desc {
   int32_t dtype, out_dtype;         /* AVMOE_F32 | AVMOE_BF16 */
   int32_t a_layout, b_layout;       /* AVMOE_K_MAJOR | AVMOE_MN_MAJOR */
   int32_t accumulate, ksplit, tile;
+  int32_t fp32_planes;              /* ABI 9, fp32 operands: 0 = products on v_mfma_f32_16x16x4_f32, 1 = on the bf16 matrix pipe with every value as three
+                                       bf16 planes (six plane products of order <= 2: 5.8e-9 relative per product, fp32 accumulation) -- what the site's
+                                       backward uses; avmoe_amd/csrc/gemm.h::GemmArgs::split3 */
   float alpha;
   int64_t lda, ldb, sA1, sA2, sB1, sB2;
   int64_t sCi, sCj, sC1, sC2;

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=False, out_bf16=False,
-              accumulate=False, epilogue=False, ksplit=1, bcast_a=False, seed=0, exact_ints=False, bcast_b=False):
+              accumulate=False, epilogue=False, ksplit=1, bcast_a=False, seed=0, exact_ints=False, bcast_b=False, planes=0, wide_range=False):
     from avmoe_amd import _capi as capi
     L = capi.lib()
     dev = torch.device("cuda:0")
@@ -23,7 +23,10 @@ def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=Fal
     def rnd(*shape):
         if exact_ints:
             return torch.randint(-3, 4, shape, generator=g).double()
-        return torch.randn(*shape, generator=g, dtype=torch.float64)
+        x = torch.randn(*shape, generator=g, dtype=torch.float64)
+        if wide_range:                      # magnitudes over 2^-20 .. 2^20: every plane of the three-plane form carries bits somewhere
+            x = x * torch.exp2(torch.randint(-20, 21, shape, generator=g).double())
+        return x
 
     Kp, Mp, Np = -(-K // epc) * epc, -(-M // epc) * epc, -(-N // epc) * epc
     A = rnd(1 if bcast_a else nb, M, K)
@@ -69,6 +72,7 @@ def _run_gemm(M, N, K, dtype, a_mn, b_mn, nb1=1, nb2=1, tile=0, c_transposed=Fal
     d.dtype, d.out_dtype = dtype, (capi.BF16 if out_bf16 else capi.F32)
     d.a_layout, d.b_layout = int(a_mn), int(b_mn)
     d.accumulate, d.ksplit, d.tile, d.alpha = int(accumulate), ksplit, tile, 0.5
+    d.fp32_planes = planes
     d.lda, d.ldb = lda, ldb
     d.sA1, d.sA2 = (0, 0) if bcast_a else (sA * nb2, sA)
     d.sB1, d.sB2 = (0, 0) if bcast_b else (sB * nb2, sB)
@@ -145,6 +149,27 @@ def test_split_k(dtype):
     assert (got - ref).abs().max() / ref.abs().max() < 5 * _tol(dtype)
     got, ref = _run_gemm(70, 130, 700, dtype, False, False, ksplit=3, c_transposed=True, seed=12)
     assert (got - ref).abs().max() / ref.abs().max() < 5 * _tol(dtype)
+
+
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+@pytest.mark.parametrize("tile", [32, 64, 128])
+def test_fp32_three_plane_form_is_an_fp32_product(a_mn, b_mn, tile):
+    """ABI 9 `fp32_planes` (what a site's backward uses for its fp32 products): three bf16 planes per value, six plane products --
+    as close to the fp64 product as the fp32 matrix pipe is (both are bounded by the fp32 rounding of the accumulated sum), on
+    every tile and layout, for values whose bits spread over all three planes, with exact integers exact, and the same numbers
+    whatever tile runs them."""
+    got_i, ref_i = _run_gemm(80, 48, 96, 0, a_mn, b_mn, tile=tile, exact_ints=True, seed=tile, planes=1)
+    assert torch.equal(got_i, ref_i)
+    for shape, kw in (((200, 136, 196), {}), ((333, 70, 1030), {}), ((96, 40, 5000), dict(ksplit=7, nb1=2)), ((150, 92, 72), dict(accumulate=True, epilogue=True))):
+        M, N, K = shape
+        got3, ref = _run_gemm(M, N, K, 0, a_mn, b_mn, tile=tile, seed=M + K, planes=1, wide_range=True, **kw)
+        got1, _ = _run_gemm(M, N, K, 0, a_mn, b_mn, tile=tile, seed=M + K, planes=0, wide_range=True, **kw)
+        n = float(ref.norm())
+        e3, e1 = float((got3 - ref).norm()) / n, float((got1 - ref).norm()) / n
+        assert e3 < 1e-6 and e3 < 2.0 * e1 + 1e-8, (shape, e3, e1)
+    g128, _ = _run_gemm(200, 136, 196, 0, a_mn, b_mn, tile=128, seed=3, planes=1)
+    gt, _ = _run_gemm(200, 136, 196, 0, a_mn, b_mn, tile=tile, seed=3, planes=1)
+    assert torch.equal(g128, gt)
 
 
 def test_alignment_contract_is_enforced():
