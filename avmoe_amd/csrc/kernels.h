@@ -86,6 +86,9 @@ int k_nxn_dx(int key, const void* X, const void* dxr, int frames, int N, int C, 
 // dApost = dOut Bpost and dBpost = dOut^T Apost from one pass over dOut (dpost_pair.hip); 1 = shape not served
 int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long sBg, const void* Apost, long lda, void* dAp, long ldc, float* dApx, long ldx, int XW,
                  float* dBp, int ntok, int G, int Cg, int nmain, int KP, int KPp, float* slabs, size_t slab_cap, hipStream_t st);
+// dWt = dZx^T X and dT[s] = dL2[s]^T X[s] as one streaming pass (tok_pair2.hip); 1 = shape not served
+int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int S, int N, int G, int Cg, int M1, int KL,
+                float* dWt, float* dT, float* slabs, size_t slab_cap, hipStream_t st);
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

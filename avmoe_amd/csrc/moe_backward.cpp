@@ -233,7 +233,13 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(run(g, false));
   }
   bool pair_done = false;                                  // dWt = dZx^T X and dT[s] = dL2[s]^T X[s] in ONE pass over X (bf16 sites with latent tokens)
-  if (d.bf16 && d.El > 0) {
+  if (d.bf16 && d.El > 0 && !dev_env("AVMOE_NO_TOKPAIR2")) {      // ... as one streaming pass with every accumulator in registers (tok_pair2.hip: the tuned shape)
+    const int rc = k_tok_pair2(X, d.C, dZx, d.DZ, sc + pl.o_dL2x, d.KLp, d.S, d.N, d.g, d.Cg, d.E * d.dgp, d.KL, (float*)(sc + pl.o_dWt), (float*)(sc + pl.o_dT),
+                               slabs, slab_cap, st);
+    if (rc < 0) return rc;
+    pair_done = rc == OK;
+  }
+  if (d.bf16 && d.El > 0 && !pair_done) {
     TokPairArgs t;
     t.A1 = dZx; t.lda1 = d.DZ; t.M1 = d.E * d.dgp; t.sA1g = (long)d.E * d.dgp;
     t.A2 = sc + pl.o_dL2x; t.lda2 = d.KLp; t.M2 = d.KL;

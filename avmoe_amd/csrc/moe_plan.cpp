@@ -24,7 +24,7 @@ size_t slab_floats(const Dims& d) {
   size_t m = std::max(std::max(std::max(out1, out2), std::max(std::max(out3, out4), out5)), out6);
   size_t need = m * 96 + 1024;
   // dpost_pair.hip (bf16, 384 channels per group, 128 + <= 16 columns): one partial dBpost per block, one block per CU
-  if (d.bf16 && d.Cg == 384 && d.E * d.dgp == 128 && d.KPp == 144) need = std::max(need, (size_t)320 * d.Cg * d.KPp + 1024);
+  if (d.bf16 && d.Cg == 384 && d.E * d.dgp == 128 && d.KPp == 144) need = std::max(need, (size_t)352 * d.Cg * d.KPp + 1024);      // (tok_pair2.hip: 256 x (128 + 64) x 384 floats)
   return need;
 }
 
