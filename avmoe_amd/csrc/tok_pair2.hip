@@ -210,9 +210,10 @@ __global__ void __launch_bounds__(256) kk_tp2_finish(const float* __restrict__ s
 int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int S, int N, int G, int Cg, int M1, int KL,
                 float* dWt, float* dT, float* slabs, size_t slab_cap, hipStream_t st) {
   if (Cg != 384 || M1 != 128 || KL < 1 || KL > 64 || ldl < 72 || N % BM || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || !slabs ||
-      ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dWt % 16) || ((uintptr_t)dT % 16) || (G * 384) % 4 ||
-      (long)S * N < 65536)
+      ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dWt % 16) || ((uintptr_t)dT % 16) || (G * 384) % 4)
     return 1;
+  const bool force = getenv("AVMOE_TOKPAIR2_FORCE") != nullptr;             // test hook (read by the product build too): small sites as well -- every frame then spans two blocks
+  if (!force && (long)S * N < 65536) return 1;                              // small sites: the tiled form fills the chip better
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -224,7 +225,7 @@ int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* 
   const long U = (long)S * (tpf / ut);
   int nb = std::max(1, cus / G);
   while (nb > 1 && U % nb) --nb;                          // one block per CU where the units divide evenly; else the next smaller count that does
-  if (nb * G * 4 < cus * 3) return 1;                       // ... unless that leaves a quarter of the chip idle
+  if (!force && nb * G * 4 < cus * 3) return 1;             // ... unless that leaves a quarter of the chip idle
   const size_t need = (size_t)nb * G * (128 + 64) * 384;
   if (need > slab_cap) return 1;
   TP2Args p;
