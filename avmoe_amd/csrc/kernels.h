@@ -89,6 +89,9 @@ int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long s
 // dWt = dZx^T X and dT[s] = dL2[s]^T X[s] as one streaming pass (tok_pair2.hip); 1 = shape not served
 int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int S, int N, int G, int Cg, int M1, int KL,
                 float* dWt, float* dT, float* slabs, size_t slab_cap, hipStream_t st);
+// dX = dZx Wt + dL2x T[s] + rs X in the eight-wave direct-load form (dx_stream2.hip); 1 = shape not served
+int k_dx_stream2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int K2, const float* rs, const void* Wt, long ldw, long sWg,
+                 const void* Text, long ldt, long sT1, void* dX, long ldc, int S, int N, int G, int Cg, int K1, hipStream_t st);
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

@@ -137,7 +137,13 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
     g.accumulate = d.acc_dx;
     if (fork2) AVMOE_TRY(fk2.fork());
-    AVMOE_TRY(run_on(g, false, fork2 ? side->s : st));
+    int dx2 = 1;                                           // the eight-wave direct-load form (dx_stream2.hip: tuned bf16 shape, dX overwritten); 1 = not served
+    if (d.bf16 && !d.acc_dx && !dev_env("AVMOE_NO_DX2")) {
+      dx2 = k_dx_stream2(X, d.C, dZx, d.DZ, sc + pl.o_dL2x, d.KLp, d.KLT, (const float*)(sc + pl.o_rs2x), sv + pl.o_Wt, d.Cg, (long)d.E * d.dgp * d.Cg,
+                         sv + pl.o_Text, d.C, (long)d.KLT * d.C, dX, d.C, d.S, d.N, d.g, d.Cg, d.E * d.dgp, fork2 ? side->s : st);
+      if (dx2 < 0) return dx2;
+    }
+    if (dx2 != OK) AVMOE_TRY(run_on(g, false, fork2 ? side->s : st));
   }
   if (d.mha) {   // ---- AVS "v1": per expert back through ZR = xr Wt_e^T, the row sums and xr = MHA_e(X) - X -------------------
     for (int e = 0; e < d.E; ++e) {
