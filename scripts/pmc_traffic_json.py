@@ -31,6 +31,12 @@ def family(sym: str):
         return "gemm_splitk_reduce"
     if "kk_xstats" in sym:
         return "k_xstats"
+    if "kk_tp2_finish" in sym:
+        return "k_tp2_finish"
+    if "kk_tok_pair2" in sym:
+        return "k_tok_pair2"
+    if "kk_dx_stream2" in sym:
+        return "k_dx_stream2"
     if "kk_dpair_reduce" in sym:
         return "k_dpair_reduce"
     if "kk_dpair" in sym:
