@@ -246,9 +246,11 @@ __global__ void __launch_bounds__(256) kk_dpair_reduce(const float* __restrict__
 // 0 = launched, 1 = shape not served (the caller runs the two kernels), < 0 error
 int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long sBg, const void* Apost, long lda, void* dAp, long ldc, float* dApx, long ldx, int XW,
                  float* dBp, int ntok, int G, int Cg, int nmain, int KP, int KPp, float* slabs, size_t slab_cap, hipStream_t st) {
-  if (Cg != 384 || nmain != 128 || KPp != 144 || KP <= 128 || KP > 144 || KP % 4 || ((uintptr_t)dBp % 16) || XW < 16 || ntok < 4096 || ntok % BM || ldo % 8 || lda % 8 || !slabs ||
+  if (Cg != 384 || nmain != 128 || KPp != 144 || KP <= 128 || KP > 144 || KP % 4 || ((uintptr_t)dBp % 16) || XW < 16 || ntok % BM || ldo % 8 || lda % 8 || !slabs ||
       ((uintptr_t)dOut % 16) || ((uintptr_t)Apost % 16) || ((uintptr_t)dAp % 8) || ((uintptr_t)dApx % 16) || ldx % 4 || (G * XW) % 4)
     return 1;
+  // small sites: the two kernels (the 128-slab reduction alone costs 11 us; measured at 20 480 tokens: 44 us against 37); AVMOE_DPAIR_FORCE: test hook
+  if (ntok < 32768 && !(ntok >= 4096 && getenv("AVMOE_DPAIR_FORCE"))) return 1;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;

@@ -1,8 +1,8 @@
 // dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + rs2x X[s]   (moe_backward.cpp, phase 5) in the persistent eight-wave form of
-// dpost_pair.hip / tok_pair2.hip, for the tuned bf16 shape (384 channels per group, 128 bottleneck columns, <= 72 latent columns, whole
-// 64-token tiles per frame, dX overwritten); every other case keeps gemm_stream.hip's twelve-wave kernel.
+// dpost_pair.hip / tok_pair2.hip, for the tuned bf16 shape (384 channels per group, 128 bottleneck columns, <= 72 latent columns,
+// dX overwritten); every other case keeps gemm_stream.hip's twelve-wave kernel.
 //
-// 64-token tiles of X (the row-scale operand), dZx and dL2x, and the tile's 64 row scales, go global -> LDS directly (two buffers, the
+// 64-token tiles of X (the row-scale operand), dZx and dL2x (per frame; the last tile of a frame ragged when 64 does not divide its tokens), and the tile's 64 row scales, go global -> LDS directly (two buffers, the
 // next tile in flight during the arithmetic).  Wave w keeps the fragments of ITS three 16-channel tiles of Wt (four K steps) and of the
 // frame's T[s] (three K steps, re-gathered when the block moves on to the next frame: contiguous tile ranges) in registers and computes
 // the products transposed, so that lane (r, q) ends up with four consecutive channels of token r: the row-scale term is added from the X
@@ -34,7 +34,7 @@ struct DX2Args {
   const unsigned short* Wt; long ldw, sWg;      // bf16 [g][128][ldw]: row = bottleneck column, column = channel
   const unsigned short* Text; long ldt, sT1;    // bf16 [frame][K2][ldt], group g at column g * 384
   char* dX; long ldc;                  // bf16 [tokens][ldc], group g at column g * 384
-  int tps, ntiles, K2;                 // 64-token tiles per frame, tiles in all, rows of T[s]
+  int N, tps, ntiles, K2;              // tokens per frame, 64-token tiles per frame (the last one ragged when 64 does not divide N), tiles in all, rows of T[s]
 };
 
 constexpr int BM = 64, NTHR = 512;
@@ -85,11 +85,13 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream2(const DX2Args p) {
   }
 
   auto gload = [&](int buf, int tile) {
-    const long m0 = (long)tile * BM;
+    const int fs = tile / p.tps, fj = tile - fs * p.tps;
+    const long m0 = (long)fs * p.N + (long)fj * BM;         // first token of the tile
+    const int last = p.N - fj * BM - 1;                     // rows beyond the frame's last token re-read it (a ragged last tile; never stored)
     char* dst = smem + buf * BUF + 1024 * wave;
-    auto src_x = [&](int j) { const int slot = 64 * j + lane, row = slot / 49, cc = min(slot % 49, 47); return Xb + ((m0 + row) * ldx + cc * 8) * 2; };
-    auto src_z = [&](int j) { const int slot = 64 * j + lane, row = slot / 17, cc = min(slot % 17, 15); return Zb + ((m0 + row) * ldz + cc * 8) * 2; };
-    auto src_l = [&](int j) { const int slot = 64 * j + lane, row = slot / 10, cc = min(slot % 10, 8); return Lb + ((m0 + row) * ldl + cc * 8) * 2; };
+    auto src_x = [&](int j) { const int slot = 64 * j + lane, row = min(slot / 49, last), cc = min(slot % 49, 47); return Xb + ((m0 + row) * ldx + cc * 8) * 2; };
+    auto src_z = [&](int j) { const int slot = 64 * j + lane, row = min(slot / 17, last), cc = min(slot % 17, 15); return Zb + ((m0 + row) * ldz + cc * 8) * 2; };
+    auto src_l = [&](int j) { const int slot = 64 * j + lane, row = min(slot / 10, last), cc = min(slot % 10, 8); return Lb + ((m0 + row) * ldl + cc * 8) * 2; };
 #pragma unroll
     for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_x(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, 0);
     if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_x(48), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream2(const DX2Args p) {
     if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 15), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
     else __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave - 2), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
     if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave + 6), (lptr_t)(dst + 8192 * 9), 16, 0, 0);
-    else if (wave == 4) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + lane), (lptr_t)(smem + buf * BUF + OFFR), 4, 0, 0);      // the tile's 64 row scales
+    else if (wave == 4) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, last)), (lptr_t)(smem + buf * BUF + OFFR), 4, 0, 0);      // the tile's 64 row scales
   };
 
   // contiguous tile ranges (few frame changes per block)
@@ -123,7 +125,8 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream2(const DX2Args p) {
         for (int ks = 0; ks < 3; ++ks) bt[ct][ks] = frag_mn(T, p.ldt, c0 + 16 * ct + r, 32 * ks + 8 * q, p.K2);
     }
     if (tile + 1 < t_end) gload((it + 1) & 1, tile + 1);
-    const long m0 = (long)tile * BM;
+    const int fj = tile - s * p.tps, valid = p.N - fj * BM;      // rows of this tile inside the frame (>= 64: all of them)
+    const long m0 = (long)s * p.N + (long)fj * BM;
 #pragma unroll
     for (int mp = 0; mp < 2; ++mp) {                       // two 16-token slabs at a time (independent accumulator chains)
       f32x4 acc[2][3];
@@ -153,6 +156,7 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream2(const DX2Args p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                        // lane (r, q): token r of the slab, channels c0 + 16 ct + 4 q .. + 3
         const int row = 16 * (2 * mp + h) + r;
+        if (row >= valid) continue;
         const float rs = sR[row];
         char* out = p.dX + ((m0 + row) * p.ldc + (long)g * 384 + c0 + 4 * q) * 2;
 #pragma unroll
@@ -173,8 +177,8 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream2(const DX2Args p) {
 // 0 = launched, 1 = shape not served (the caller runs the twelve-wave streaming GEMM), < 0 error
 int k_dx_stream2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int K2, const float* rs, const void* Wt, long ldw, long sWg,
                  const void* Text, long ldt, long sT1, void* dX, long ldc, int S, int N, int G, int Cg, int K1, hipStream_t st) {
-  if (Cg != 384 || K1 != 128 || K2 < 1 || K2 > 72 || ldl < 72 || N % BM || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || ldc % 4 || !rs ||
-      ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dX % 8) || ((uintptr_t)rs % 4) || (long)S * N < 4096)
+  if (Cg != 384 || K1 != 128 || K2 < 1 || K2 > 72 || ldl < 72 || N < BM || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || ldc % 4 || !rs ||
+      ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dX % 8) || ((uintptr_t)rs % 4) || (long)S * N < 2048)
     return 1;
   static int cus = 0;
   if (!cus) {
@@ -185,7 +189,7 @@ int k_dx_stream2(const void* X, long ldx, const void* dZx, long ldz, const void*
   DX2Args p;
   p.X = (const char*)X; p.ldx = ldx; p.dZx = (const char*)dZx; p.ldz = ldz; p.dL2 = (const char*)dL2; p.ldl = ldl; p.rs = rs;
   p.Wt = (const unsigned short*)Wt; p.ldw = ldw; p.sWg = sWg; p.Text = (const unsigned short*)Text; p.ldt = ldt; p.sT1 = sT1;
-  p.dX = (char*)dX; p.ldc = ldc; p.tps = N / BM; p.ntiles = S * (N / BM); p.K2 = K2;
+  p.dX = (char*)dX; p.ldc = ldc; p.N = N; p.tps = (N + BM - 1) / BM; p.ntiles = S * p.tps; p.K2 = K2;
   const int gx = std::min(std::max(1, cus / G), p.ntiles);
   static LdsAttrOnce attr;
   AVMOE_TRY(attr.ensure((const void*)kk_dx_stream2, DX2_LDS, "dx_stream2"));

@@ -71,6 +71,7 @@ def test_cfg2_shape_bf16_within_the_bf16_budget_of_the_reference_formulation(sit
     from tests.moe_gpu_util import MoeRun
     if tokpair2:
         monkeypatch.setenv("AVMOE_TOKPAIR2_FORCE", "1")
+        monkeypatch.setenv("AVMOE_DPAIR_FORCE", "1")          # ... and dApost + dBpost from one pass over dOut (csrc/dpost_pair.hip: from 32 768 tokens on)
     cfg = _cfg(site)
     P, B = O.init_params(cfg, seed=5)
     X, Y, G = _data(cfg, 20, 99)
