@@ -203,6 +203,25 @@ def cpu_baseline(c, budget_s=15.0, min_timed=3):
 
 
 def parity_check(c, material, device, pair_mode="concurrent"):
+    """parity_check_ with the library's size thresholds lifted (test hooks AVMOE_TOKPAIR2_FORCE / AVMOE_DPAIR_FORCE, read per call): the
+    B = 2 shapes then run through the SAME streaming kernels (dpost_pair, tok_pair2) the timed region's full batch takes."""
+    hooks = ("AVMOE_TOKPAIR2_FORCE", "AVMOE_DPAIR_FORCE")
+    old = {k: os.environ.get(k) for k in hooks}
+    for k in hooks:
+        os.environ[k] = "1"
+    try:
+        res = parity_check_(c, material, device, pair_mode)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    res["kernels"] = "the timed region's: size thresholds of dpost_pair / tok_pair2 lifted for the B = 2 shapes (AVMOE_*_FORCE)"
+    return res
+
+
+def parity_check_(c, material, device, pair_mode="concurrent"):
     """This build against the oracle at the benchmarked shapes, B = 2 clips, through the C ABI behind the module API -- the two
     sites of a pair run the way the timed region runs them (AdapterPair in `pair_mode`; two module calls with --pair off), so each token tensor's gradient is the sum of its dX from one site and its dY from the other.
     fp32: outputs max-abs relative to the tensor's max, indices bit-exact, gradients norm-wise per tensor (+ token rows of the
