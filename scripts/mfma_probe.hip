@@ -1,13 +1,15 @@
 // dev probe (round 4): do the fp32-MFMA mat-vecs of the bottleneck-space kernels (mmT: A operand from LDS, four dependent
 // v_mfma_f32_16x16x4_f32 per 16-column tile, results consumed by VALU right away) return the same bits when ANOTHER kernel hammers the
 // matrix pipe of the same SIMDs from a second stream?   build:  hipcc --offload-arch=gfx950 -O3 scripts/mfma_probe.hip -o avmoe_amd/lib/variants/mfma_probe
-//   ./mfma_probe [iters] [aggressor: 0 none, 1 bf16 32x32x16 MFMA loop, 2 LDS + MFMA loop]
+//   ./mfma_probe [reps] [aggressor mode: 0 none, 1 bf16 32x32x16 MFMA loop, 2 + ds_read_b32, 3 + ds_read_b128, 4 / 5 LDS reads only, 6 / 7 16x16 MFMAs + b128, 8 / 9 sixteen chains of bf16 16x16x32 (+ b128)] [victim dynamic LDS bytes] [aggressor blocks, default 1024] [victim launches per rep, default 8; 0 = aggressor alone]
+//   -DMIT=n: mitigations under test (see mmT); 8 = the A operand as two ds_read_b64; scripts/run_mfma_probe.sh runs the matrix kept in profiles/r05_mfma_probe.txt
 // The victim computes, per tile step, W = P x M (16 tokens x 32 -> 32) with mmT and the same numbers with plain FMAs through shuffles,
 // and counts the lanes whose results differ by more than 1e-4 relative.  Expected: 0, with or without the aggressor.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -25,8 +27,18 @@ __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const fl
 #define MIT 0      // mitigation under test: 1 = drain the LDS counter + s_nop before the MFMAs, 2 = the LDS data through a VALU move, 3 = both
 #endif
   float4 a[NJ];
+#if MIT == 8       // the same 16 bytes per lane as two 8-byte LDS reads (ds_read_b64 x 2 instead of ds_read_b128)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float2 lo, hi;
+    const unsigned ad = (unsigned)(size_t)(mp + 16 * j);
+    asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(ad) : "memory");
+    a[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+  }
+#else
 #pragma unroll
   for (int j = 0; j < NJ; ++j) a[j] = *(const float4*)(mp + 16 * j);
+#endif
 #if MIT == 1 || MIT == 3
   __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
   asm volatile("s_nop 7" ::: "memory");
@@ -94,10 +106,8 @@ __global__ void __launch_bounds__(256) victim(const float* __restrict__ M, const
   __builtin_amdgcn_s_setprio(3);
 #endif
   __shared__ float s_M[2][32 * LD];
-#if MIT == 7
-  extern __shared__ float hog[];
+  extern __shared__ float hog[];      // dynamic LDS request (argv[3] / MIT 7): sets how many victim blocks fit a compute unit and what is left for the aggressor
   if (threadIdx.x == 0 && tiles < 0) hog[0] = 1.f;
-#endif
   for (int i = threadIdx.x; i < 2 * 32 * 32; i += 256) { const int m = i >> 10, n = (i >> 5) & 31, k = i & 31; s_M[m][n * LD + k] = M[i]; }
   __syncthreads();
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
@@ -164,6 +174,23 @@ __global__ void __launch_bounds__(256) aggressor16(int iters, int lds, int f32, 
   }
   sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + acc;
 }
+__global__ void __launch_bounds__(256) aggressor16w(int iters, int lds, float* __restrict__ sink) {      // 16 chains of 16x16x32 bf16 (64 accumulator registers, like a GEMM tile)
+  __shared__ float s[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) s[i] = (float)i * 1e-6f;
+  __syncthreads();
+  const bf16x8 a = {(__bf16)1.f, (__bf16)0.5f, (__bf16)0.25f, (__bf16)1.f, (__bf16)0.5f, (__bf16)0.25f, (__bf16)1.f, (__bf16)0.5f};
+  f32x4 c[16] = {};
+  float acc = 0.f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c[k], 0, 0, 0);
+    if (lds & 2) { const float4 t4 = *(const float4*)(s + ((threadIdx.x * 4 + 16 * i) & 4092)); acc += t4.x + t4.w; }
+  }
+  float r = acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r += c[k][k & 3];
+  sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
 __global__ void __launch_bounds__(256) aggressor(int iters, int lds, float* __restrict__ sink) {
   __shared__ float s[4096];
   for (int i = threadIdx.x; i < 4096; i += 256) s[i] = (float)i * 1e-6f;
@@ -184,6 +211,7 @@ __global__ void __launch_bounds__(256) aggressor(int iters, int lds, float* __re
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20, mode = argc > 2 ? atoi(argv[2]) : 1;
+  const int agrid = argc > 4 ? atoi(argv[4]) : 1024, nvict = argc > 5 ? atoi(argv[5]) : 8;      // aggressor blocks ; victim launches per rep (0: aggressor alone, for its duration)
   const int tiles = 1 << 17;
   std::vector<float> hM(2 * 32 * 32), hP((size_t)tiles * 16 * 32);
   unsigned seed = 12345u;
@@ -197,23 +225,31 @@ int main(int argc, char** argv) {
   std::vector<float> hU((size_t)tiles * 64), hV((size_t)tiles * 64);
   unsigned long badU = 0, badV = 0;
 #if MIT == 7
-  const int vict_lds = 140 * 1024;      // with the 9 KB of static LDS: 149 KB -- no 16 KB block of the aggressor fits beside it on the CU
-  hipFuncSetAttribute((const void*)victim, hipFuncAttributeMaxDynamicSharedMemorySize, vict_lds);
+  const int vict_lds = argc > 3 ? atoi(argv[3]) : 140 * 1024;      // with the 9 KB of static LDS: 149 KB -- no 16 KB block of the aggressor fits beside it on the CU
 #else
-  const int vict_lds = 0;
+  const int vict_lds = argc > 3 ? atoi(argv[3]) : 0;               // argv[3]: dynamic LDS bytes per victim block (own blocks per CU = 160 KB / (9 KB + this))
 #endif
+  if (vict_lds > 0) hipFuncSetAttribute((const void*)victim, hipFuncAttributeMaxDynamicSharedMemorySize, vict_lds);
+  {
+    int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)victim, 256, vict_lds);
+    printf("victim: %d B dynamic + 9216 B static LDS per block -> %d resident blocks per CU (aggressor blocks take 16384 B each)\n", vict_lds, nb);
+  }
   hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
   unsigned total = 0;
   for (int rep = 0; rep < reps; ++rep) {
     hipMemsetAsync(dbad, 0, 4, s1);
     hipStreamSynchronize(s1);
+    const auto t0 = std::chrono::steady_clock::now();
     // mode: 1 MFMA only ; 2 MFMA + ds_read_b32 ; 3 MFMA + ds_read_b128 ; 4 ds_read_b32 only ; 5 ds_read_b128 only
-    if (mode >= 1 && mode <= 3) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, s2, 20000, mode == 2 ? 1 : (mode == 3 ? 2 : 0), sink2);
-    if (mode == 6 || mode == 7) hipLaunchKernelGGL(aggressor16, dim3(1024), dim3(256), 0, s2, 60000, 2, mode == 7, sink2);      // 6: bf16 16x16x32 + b128 ; 7: f32 16x16x4 + b128
-    if (mode == 4 || mode == 5) hipLaunchKernelGGL(aggressor_lds, dim3(1024), dim3(256), 0, s2, 80000, mode == 4 ? 1 : 2, sink2);
-    for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(victim, dim3(1024), dim3(256), vict_lds, s1, dM, dP, tiles, dbad, sink1, k == 3 ? dU : nullptr, k == 3 ? dV : nullptr);
+    if (mode >= 1 && mode <= 3) hipLaunchKernelGGL(aggressor, dim3(agrid), dim3(256), 0, s2, 20000, mode == 2 ? 1 : (mode == 3 ? 2 : 0), sink2);
+    if (mode == 6 || mode == 7) hipLaunchKernelGGL(aggressor16, dim3(agrid), dim3(256), 0, s2, 60000, 2, mode == 7, sink2);      // 6: bf16 16x16x32 + b128 ; 7: f32 16x16x4 + b128
+    if (mode == 8 || mode == 9) hipLaunchKernelGGL(aggressor16w, dim3(agrid), dim3(256), 0, s2, 10000, mode == 9 ? 2 : 0, sink2);      // 8: 16 chains of bf16 16x16x32 ; 9: + b128
+    if (mode == 4 || mode == 5) hipLaunchKernelGGL(aggressor_lds, dim3(agrid), dim3(256), 0, s2, 80000, mode == 4 ? 1 : 2, sink2);
+    for (int k = 0; k < nvict; ++k) hipLaunchKernelGGL(victim, dim3(1024), dim3(256), vict_lds, s1, dM, dP, tiles, dbad, sink1, k == 3 ? dU : nullptr, k == 3 ? dV : nullptr);
     hipDeviceSynchronize();
-    if (rep < 3) {      // which of the two methods is off?  exact reference (double) on the host for the lanes the GPU flagged (u3 != v3)
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep == reps - 1) printf("last rep: %.2f ms for the aggressor (%d blocks) + %d victim launches on two streams\n", ms, mode ? agrid : 0, nvict);
+    if (rep < 3 && nvict > 3) {      // which of the two methods is off?  exact reference (double) on the host for the lanes the GPU flagged (u3 != v3)
       hipMemcpy(hU.data(), dU, hU.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hV.data(), dV, hV.size() * 4, hipMemcpyDeviceToHost);
       int shown = 0;
       for (long i = 0; i < (long)tiles * 64; ++i) {
@@ -237,7 +273,7 @@ int main(int argc, char** argv) {
     if (b) printf("rep %d: %u mismatching lanes\n", rep, b);
     total += b;
   }
-  printf("MFMA_PROBE MIT %d mode %d: %u mismatches over %d reps; of the lanes checked exactly: MFMA path wrong %lu, VALU path wrong %lu (%s)\n", MIT, mode, total, reps,
+  printf("MFMA_PROBE MIT %d mode %d lds %d: %u mismatches over %d reps; of the lanes checked exactly: MFMA path wrong %lu, VALU path wrong %lu (%s)\n", MIT, mode, vict_lds, total, reps,
          badU, badV, hipGetErrorString(hipGetLastError()));
   return 0;
 }
