@@ -60,10 +60,38 @@ def _scratch(dev: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
     return buf
 
 
-def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=False):
+_SHARED_GPU = None          # process-wide override of avmoe_moe_desc.shared_gpu: None = decide per call (below), True / False = always / never
+
+
+def set_shared_gpu(mode):
+    """avmoe_moe_desc.shared_gpu for every site call of this process: True = always ask for the protected launches (another stream's
+    kernels may be on the GPU: a second adapter site, a backbone GEMM), False = never (the caller asserts that nothing else runs
+    on the GPU while adapter calls do), None (default) = per call: protected whenever the call is issued on a stream other than the
+    device's default stream, and always in AdapterPair's two-stream mode.  A module attribute `shared_gpu` (True / False) overrides
+    this for one site.  include/avmoe.h says which kernel families the flag protects and what it costs."""
+    global _SHARED_GPU
+    if mode not in (None, True, False):
+        raise ValueError("set_shared_gpu: None, True or False")
+    _SHARED_GPU = mode
+
+
+def _shared_gpu_of(module, dev, asked):
+    """The shared_gpu flag of one call: AdapterPair's explicit request, else the site's attribute, else the process-wide mode,
+    else 'is this call on a side stream?' (a caller that left the default stream did so to overlap something)."""
+    if asked:
+        return True
+    own = module.__dict__.get("shared_gpu", None)
+    if own is not None:
+        return bool(own)
+    if _SHARED_GPU is not None:
+        return _SHARED_GPU
+    return torch.cuda.current_stream(dev).cuda_stream != torch.cuda.default_stream(dev).cuda_stream
+
+
+def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=None):
     """One avmoe_moe_forward call.  Returns (out, probs, idx, lb, state) with state = what the backward needs.
     add_to: a contiguous tensor like X that receives `+= adapter(X, Y)` in place (avmoe_moe_desc.accumulate_out) and is
-    returned as `out`."""
+    returned as `out`.  shared_gpu: True = another stream's kernels may run beside this call (AdapterPair); None = _shared_gpu_of."""
     if not (X.is_cuda and Y.is_cuda):
         raise capi.AvmoeError("avmoe_amd runs on MI355X only: tensors must live on a GPU (no CPU fallback)")
     if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
@@ -73,7 +101,8 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=Fa
     Y = Y.contiguous()
     S, N, Cc = X.shape
     desc = module._desc(S, N, Y.shape[1], X.dtype == torch.bfloat16)
-    desc.shared_gpu = int(bool(shared_gpu))               # (include/avmoe.h: kernels of another stream may be on the GPU during this call and its backward)
+    shared_gpu = _shared_gpu_of(module, X.device, shared_gpu)
+    desc.shared_gpu = int(shared_gpu)                     # (include/avmoe.h: kernels of another stream may be on the GPU during this call and its backward)
     keep = module._attention_keep(S, N, X.device)
     ptrs = module._fill_ptrs(params, keep, names=names, device=X.device)
     wkey = (S, N, Y.shape[1], X.dtype, module.training, bool(shared_gpu))

@@ -13,6 +13,17 @@ void set_last_error(const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
+int cu_count() {
+  static int cus[64] = {};      // (written once per device with the same value: a race between two host threads is benign)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev < 64 && cus[dev] > 0) return cus[dev];
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (dev < 64) cus[dev] = prop.multiProcessorCount;
+  return prop.multiProcessorCount;
+}
+
 int LdsAttrOnce::ensure(const void* fn, int bytes, const char* what) {
   if (bytes <= 65536) return OK;
   int dev = 0;

@@ -52,6 +52,9 @@ struct LdsAttrOnce {
   int ensure(const void* fn, int bytes, const char* what);      // OK / ERR_LAUNCH ; no-op for <= 64 KiB and after the first call per device
 };
 
+// compute units of the current device (cached per device; <= 0 on a failed query)
+int cu_count();
+
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -92,6 +92,10 @@ int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* 
 // dX = dZx Wt + dL2x T[s] + rs X in the eight-wave direct-load form (dx_stream2.hip); 1 = shape not served
 int k_dx_stream2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int K2, const float* rs, const void* Wt, long ldw, long sWg,
                  const void* Text, long ldt, long sT1, void* dX, long ldc, int S, int N, int G, int Cg, int K1, hipStream_t st);
+// the hop-1 chain's per-frame products against Y as streaming kernels (hop1_stream.hip; bf16, tuned widths); 1 = shape not served
+int k_hop1_yk(const void* Y, long ldy, int S, int M, int Cy, const void* A, long lda, long sA1, int rows, void* C, long ldc, long sC1, int c_bf16, void* dump, hipStream_t st);   // C[s] = A[(s)] Y[s]^T ; dump: 16 writable bytes
+int k_hop1_yt_frames(const void* Y, long ldy, int S, int M, int Cy, const void* A, long lda, long sA1, int rows, void* C, long ldc, long sC1, int c_bf16, hipStream_t st);   // C[s] = A[s] Y[s]
+int k_hop1_yt_sum(const void* Y, long ldy, long ntok, int Cy, const void* A, long lda, int rows, void* C, long ldc, int c_bf16, float* slabs, size_t slab_cap, hipStream_t st);   // C = A^T Y over all tokens
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

@@ -40,6 +40,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     return launch_gemm(g, on);
   };
   auto run = [&](GemmArgs& g, bool split) { return run_on(g, split, st); };
+  const bool hop1s = d.bf16 && !dev_env("AVMOE_NO_HOP1S");    // the per-frame products against Y as streaming kernels (hop1_stream.hip)
   // Independent branches run on a helper stream (side.h) and are joined before their first consumer and before the section ends:
   //   section 1: dBpost = dOut^T Apost (+ its split-K reduce; the only user of the slabs until the join) beside dApost -> post_small_bwd -> Gram
   //   section 2: the dX GEMM (nothing in this call reads dX) beside the dWt / dT chain
@@ -337,11 +338,14 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     AVMOE_TRY(run(g, true));
   }
   {                                                        // dBm[s] = dV[s] Y[s]^T
+    int rc = 1;                                            // (hop1_stream.hip: dV[s] stationary per frame; 1 = shape not served)
+    if (hop1s) rc = k_hop1_yk(Y, d.Cy, d.S, d.M, d.Cy, sc + pl.o_dV, d.Cy, (long)d.Kcyb * d.Cy, d.Kcyb, sc + pl.o_dBm, d.Mb, (long)d.Kcyb * d.Mb, 0, slabs, st);
+    if (rc < 0) return rc;
     GemmArgs g = base();
     g.A = sc + pl.o_dV; g.B = Y; g.C = sc + pl.o_dBm;
     g.M = d.Kcyb; g.N = d.M; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.nb1 = d.S;
     g.sA1 = (long)d.Kcyb * d.Cy; g.sB1 = (long)d.M * d.Cy; g.sCi = d.Mb; g.sC1 = (long)d.Kcyb * d.Mb;
-    AVMOE_TRY(run(g, false));
+    if (rc != OK) AVMOE_TRY(run(g, false));
   }
   AVMOE_TRY(k_prep_dBm(pl, sc, st));
   }
@@ -379,10 +383,13 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     }
     AVMOE_TRY(k_dqrqb(pl, sc, prm.conv_b, st));
     {                                                      // dQ = sum_s dR[s] Y[s]
+      int rc = 1;                                          // (hop1_stream.hip: one pass over Y with every accumulator in registers + a slab sum)
+      if (hop1s) rc = k_hop1_yt_sum(Y, d.Cy, (long)d.S * d.M, d.Cy, sc + pl.o_dRT, d.Kcyp, d.Kcy, sc + pl.o_dQT, d.Cy, 1, slabs, slab_cap, st);
+      if (rc < 0) return rc;
       GemmArgs g = base();
       g.A = sc + pl.o_dRT; g.B = Y; g.C = sc + pl.o_dQT; g.out_dtype = dt;      // (straight in the operand dtype of its two consumers)
       g.M = d.Kcy; g.N = d.Cy; g.K = d.S * d.M; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Kcyp; g.ldb = d.Cy; g.sCi = d.Cy;
-      AVMOE_TRY(run(g, true));
+      if (rc != OK) AVMOE_TRY(run(g, true));
     }
     }
     if (do6b)

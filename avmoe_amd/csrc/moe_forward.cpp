@@ -42,6 +42,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
   auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
+  const bool hop1s = d.bf16 && !dev_env("AVMOE_NO_HOP1S");    // the per-frame products against Y as streaming kernels (hop1_stream.hip)
 
   // ---- weights-derived operands --------------------------------------------------------------
   AVMOE_TRY(k_prep_all(pl, sv, prm, st));                  // (also scal[1] = 1: the unit gate of with_unit_gates)
@@ -91,11 +92,14 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   AVMOE_TRY(k_qrqb_fill(pl, sv, prm.fc_b, st));
   if (d.Kcy > 0) {
     {                                                      // R[s] = Q Y[s]^T
+      int rc = 1;                                          // (hop1_stream.hip: Q stationary, Y streamed in whole token rows; 1 = shape not served)
+      if (hop1s) rc = k_hop1_yk(Y, d.Cy, d.S, d.M, d.Cy, sv + pl.o_Qx, d.Cy, 0, d.Kcy, sv + pl.o_Rext, d.Mk, (long)d.Kcyb * d.Mk, 1, slabs, st);
+      if (rc < 0) return rc;
       GemmArgs g = base();
       g.A = sv + pl.o_Qx; g.B = Y; g.C = sv + pl.o_Rext;
       g.M = d.Kcy; g.N = d.M; g.K = d.Cy; g.lda = d.Cy; g.ldb = d.Cy; g.nb1 = d.S; g.sB1 = (long)d.M * d.Cy;
       g.sCi = d.Mk; g.sC1 = (long)d.Kcyb * d.Mk; g.out_dtype = dt;
-      AVMOE_TRY(launch_gemm(g, st));
+      if (rc != OK) AVMOE_TRY(launch_gemm(g, st));
     }
     {                                                      // L1[s] = [R | qr | qb] [Wc | bc | 1]^T
       GemmArgs g = base();
@@ -115,11 +119,14 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
     }
   }
   {                                                        // V[s] = [Bm ; wbar][s] Y[s]   (token contraction)
+    int rc = 1;
+    if (hop1s) rc = k_hop1_yt_frames(Y, d.Cy, d.S, d.M, d.Cy, sv + pl.o_BmX, d.Mb, (long)d.Kcyb * d.Mb, d.Kcyb, sv + pl.o_V, d.Cy, (long)d.Kcyb * d.Cy, 1, st);
+    if (rc < 0) return rc;
     GemmArgs g = base();
     g.A = sv + pl.o_BmX; g.B = Y; g.C = sv + pl.o_V;
     g.M = d.Kcyb; g.N = d.Cy; g.K = d.M; g.lda = d.Mb; g.b_layout = MN_MAJOR; g.ldb = d.Cy; g.nb1 = d.S;
     g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.M * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.Kcyb * d.Cy; g.out_dtype = dt;
-    AVMOE_TRY(launch_gemm(g, st));
+    if (rc != OK) AVMOE_TRY(launch_gemm(g, st));
   }
   {                                                        // TV = V Wf^T
     GemmArgs g = base();

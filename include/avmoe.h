@@ -87,12 +87,26 @@ typedef struct avmoe_moe_desc {
    * "+ adapter residual", net_trans_v3.py:706-709) takes the adapter's contribution inside the output GEMM's epilogue */
   int32_t accumulate_out;
   /* ABI 8: 1 = kernels of OTHER streams may be on the GPU while this call runs (a caller that overlaps two sites on two streams:
-   * AdapterPair's two-stream mode).  The bottleneck-space kernels then launch with a compute unit's LDS to themselves (one block
-   * per CU): on MI355X / ROCm 7.2 a block of theirs that shares a CU with a block of another kernel doing wide LDS reads beside
-   * matrix instructions occasionally gets wrong 16-byte LDS reads (one 16-token tile in ~10^3; scripts/mfma_probe.hip reproduces
-   * it outside this library).  0 = the call is alone on the GPU (its own helper stream never runs beside those kernels).
-   * The flag changes the block shape of those kernels, i.e. the summation order of the per-block BatchNorm column sums: results
-   * agree to fp32 rounding of those sums, and repeat bit for bit for a given flag. */
+   * AdapterPair's two-stream mode; a backbone GEMM on another stream).  0 = the call is alone on the GPU (its own helper stream
+   * never runs beside the kernels below).
+   * Why: on MI355X / ROCm 7.2 a workgroup that shares a COMPUTE UNIT with a workgroup of another kernel that keeps the matrix pipe busy
+   * (v_mfma_f32_32x32x16_bf16 chains, a GEMM tile's 16 independent v_mfma_f32_16x16x32_bf16 chains) occasionally gets wrong results in
+   * its own upper lanes: v_mfma_f32_16x16x4_f32 sums (lanes 48 - 51) and per-block column sums.  scripts/mfma_probe.hip shows it with two
+   * stand-alone kernels; every mode and mitigation of it, run on an MI355X, is kept in profiles/r05_mfma_probe.txt (+ _part2): 0
+   * mismatches alone or beside LDS-only / sparse-MFMA aggressors, 10^5 - 10^6 per run beside a dense-MFMA aggressor whatever the
+   * victim's LDS read width (ds_read_b128 or two ds_read_b64) and whatever wait states follow its MFMAs, and 0 again -- at the same
+   * time on other CUs -- once the victim's blocks take a whole CU's LDS (no other block fits beside them).
+   * What the flag does: the bottleneck-space kernels of the generalised family (csrc/tile_gen.inc: every site shape of the reference's
+   * models except the tuned one) and of the any-shape fallback (csrc/tile_kernels.hip) launch with 150 KB of dynamic LDS, one block per
+   * CU; the backward does not fork its dBpost product beside them.  NOT covered: the tuned instance csrc/tile_fast.hip (bottleneck 64
+   * in 2 groups, 32 latent tokens: BASELINE config 2) -- its mat-vecs run on the bf16 matrix pipe in split form and its blocks fill a
+   * CU's LDS among themselves; it has not moved in > 130 two-stream repetitions (tests/test_two_stream_repeat_gpu.py guards it), but
+   * nothing excludes a foreign block beside its first block on a CU.
+   * Cost: residency of those kernels where the grid exceeds the chip (BASELINE config 4: 80 -> 90 ms per step).  The flag changes their
+   * block shape, i.e. the summation order of the per-block BatchNorm column sums: results agree to fp32 rounding of those sums, and
+   * repeat bit for bit for a given flag.
+   * The Python wrappers set it in AdapterPair's two-stream mode and, by default, for every call issued on a stream other than the
+   * device's default stream (avmoe_amd.adapters.set_shared_gpu). */
   int32_t shared_gpu;
 } avmoe_moe_desc;
 

@@ -5,6 +5,7 @@
 # then on the GPU box:  gpurun -- bash scripts/run_mfma_probe.sh
 P=avmoe_amd/lib/variants/probe; O=gpurun_out/r5; mkdir -p $O; L=$O/mfma_probe.txt; : > $L
 run() { echo "--- $*" >> $L; timeout 120 "$@" 2>&1 | grep -v "amdgpu.ids" >> $L; }
+if [ "${1:-1}" = 1 ]; then
 echo "## aggressor modes, victim as built (MIT 0: ds_read_b128 A operand, 9 KB static LDS, up to 8 blocks per CU)" >> $L
 for mode in 0 1 2 3 4 5 6 7; do run $P/mfma_probe_mit0 6 $mode; done
 echo "## mitigations in the victim's instruction stream, aggressor mode 3 (MFMA + ds_read_b128)" >> $L
@@ -19,7 +20,9 @@ for lds in 28672 67584 143360; do run $P/mfma_probe_mit0 6 3 $lds; done
 echo "## (b) again with aggressor mode 6 (16x16x32 bf16 MFMA + ds_read_b128)" >> $L
 for lds in 0 28672 67584 143360; do run $P/mfma_probe_mit0 6 6 $lds; done
 cat $L
-# ---- part 2 (second call of the round): what in the aggressor matters, and is it the compute unit or the chip? ----
+exit 0
+fi
+# ---- part 2 (scripts/run_mfma_probe.sh 2) (second call of the round): what in the aggressor matters, and is it the compute unit or the chip? ----
 L2=$O/mfma_probe_part2.txt; : > $L2; L=$L2
 echo "## aggressors with GEMM-like register use: sixteen independent chains of v_mfma_f32_16x16x32_bf16 (mode 8), + ds_read_b128 (mode 9)" >> $L
 run $P/mfma_probe_mit0 6 8; run $P/mfma_probe_mit0 6 9

@@ -103,6 +103,17 @@ CASES = {
     "fast_v1": dict(cfg=dict(Cx=128, Nx=70, Cy=64, Ny=50, reduction=2, groups=2, K=32, variant="avs", self_attn="v1", lb_loss=True), S=5, keep=True),
     "avs_v2_mid": dict(cfg=dict(Cx=96, Nx=333, Cy=128, Ny=77, reduction=3, groups=2, K=20, variant="avs", self_attn="v2", lb_loss=True), S=4),
     "avvp_mid": dict(cfg=dict(Cx=64, Nx=200, Cy=96, Ny=130, reduction=2, groups=4, K=9, variant="avvp", lb_loss=True), S=3),
+    # round 5 ("site shapes benchmarked but in no -m gpu case"): cfg-3 stage 3 both sides (AVVP, C = 768 / 1536, 64 / 36 tokens),
+    # cfg-4 stage 0 visual side and stages 1 / 3 (AVQA: 4 groups, 2 latent tokens, 1 + 2 experts), cfg-5 stage 1 (87 latent tokens, r = 4)
+    "cfg3_avvp_stage3_audio_side": dict(cfg=dict(Cx=768, Nx=64, Cy=1536, Ny=36, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=4),
+    "cfg3_avvp_stage3_visual_side": dict(cfg=dict(Cx=1536, Nx=36, Cy=768, Ny=64, reduction=8, groups=2, K=32, variant="avvp", lb_loss=True), S=4),
+    "cfg4_avqa_stage0_visual_side": dict(cfg=dict(Cx=192, Nx=2304, Cy=96, Ny=4096, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    "cfg4_avqa_stage1_audio_side": dict(cfg=dict(Cx=192, Nx=1024, Cy=384, Ny=576, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    "cfg4_avqa_stage1_visual_side": dict(cfg=dict(Cx=384, Nx=576, Cy=192, Ny=1024, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=2),
+    "cfg4_avqa_stage3_audio_side": dict(cfg=dict(Cx=768, Nx=64, Cy=1536, Ny=36, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=4),
+    "cfg4_avqa_stage3_visual_side": dict(cfg=dict(Cx=1536, Nx=36, Cy=768, Ny=64, reduction=8, groups=4, K=2, variant="avqa", E_m=1, E_s=2), S=4),
+    "cfg5_stage1_audio_k87": dict(cfg=dict(Cx=192, Nx=1024, Cy=128, Ny=784, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
+    "cfg5_stage1_visual_k87": dict(cfg=dict(Cx=128, Nx=784, Cy=192, Ny=1024, reduction=4, groups=2, K=87, variant="avs", E_m=4, E_s=4, lb_loss=True), S=5),
 }
 
 
@@ -167,7 +178,10 @@ def test_midsize_matches_oracle_fp32(name):
                                   # round 4: the shapes the other configurations are BENCHMARKED in bf16 at -- cfg-4 (AVQA: merged groups,
                                   # 2 latent tokens, 1 + 2 experts), cfg-3 stage 2, the 64 / 36-token stage-3 sites
                                   "cfg4_avqa_stage0_audio_side", "cfg4_avqa_stage2_audio_side", "cfg4_avqa_stage2_visual_side", "cfg4_avqa_stage2_audio_side_b2",
-                                  "cfg3_avvp_stage2_audio_side", "cfg3_avvp_stage2_visual_side", "cfg1_stage3_audio_side", "cfg1_stage3_visual_side"])
+                                  "cfg3_avvp_stage2_audio_side", "cfg3_avvp_stage2_visual_side", "cfg1_stage3_audio_side", "cfg1_stage3_visual_side",
+                                  # round 5: the remaining benchmarked site shapes
+                                  "cfg3_avvp_stage3_audio_side", "cfg3_avvp_stage3_visual_side", "cfg4_avqa_stage0_visual_side", "cfg4_avqa_stage1_audio_side",
+                                  "cfg4_avqa_stage1_visual_side", "cfg4_avqa_stage3_audio_side", "cfg4_avqa_stage3_visual_side", "cfg5_stage1_audio_k87", "cfg5_stage1_visual_k87"])
 def test_midsize_bf16_close_to_oracle(name):
     """The bf16 production path (bf16 activations AND bottleneck-space tensors, streaming GEMMs, streaming Gram) against the fp32 oracle
     on the bf16-rounded inputs: router indices bit-exact, outputs within 1e-2 (max-abs relative; 4e-2 for the frame-attention

@@ -28,6 +28,13 @@ SHAPES = {
     "stage3_swinl_htsat_8clips": (dict(reduction=8, groups=2, K=32, E_m=2, E_s=2), (768, 64), (1536, 36), 80),
     # the benchmarked shape (tuned register-resident kernels): has never moved -- kept as a guard
     "cfg2": (dict(reduction=12, groups=2, K=32, E_m=2, E_s=2), (768, 1024), (768, 196), 20),
+    # fp32, the mode BASELINE config 1 is benchmarked in (two streams, Swin-B x HTS-AT): stage 0 and stage 2
+    "f32_stage0_swinb_htsat": (dict(reduction=8, groups=2, K=32, E_m=2, E_s=2), (96, 4096), (128, 2304), 20, torch.float32),
+    "f32_stage2_swinb_htsat_8clips": (dict(reduction=8, groups=2, K=32, E_m=2, E_s=2), (384, 256), (512, 144), 80, torch.float32),
+    # three groups: no register-resident instance -- the any-shape kernels of csrc/tile_kernels.hip (fp32 matrix pipe with LDS operands),
+    # which take the CU-exclusive launch since round 5
+    "anyshape_3groups": (dict(reduction=8, groups=3, K=32, E_m=2, E_s=2), (96, 4096), (192, 2304), 20),
+    "anyshape_3groups_f32_8clips": (dict(reduction=8, groups=3, K=32, E_m=2, E_s=2), (384, 256), (768, 144), 80, torch.float32),
 }
 
 
@@ -36,14 +43,15 @@ SHAPES = {
 def test_two_stream_pair_repeats_bit_for_bit(shape):
     from avmoe_amd.adapters import release_workspaces
     dev = torch.device("cuda:0")
-    kw, (Ca, Na), (Cv, Nv), S = SHAPES[shape]
+    kw, (Ca, Na), (Cv, Nv), S, *rest = SHAPES[shape]
+    dt = rest[0] if rest else torch.bfloat16
     ca = O.AdapterConfig(Cx=Ca, Nx=Na, Cy=Cv, Ny=Nv, **kw)
     cv = O.AdapterConfig(Cx=Cv, Nx=Nv, Cy=Ca, Ny=Na, **kw)
     Pa, Ba = O.init_params(ca, seed=0)
     Pv, Bv = O.init_params(cv, seed=1)
     g = torch.Generator().manual_seed(1234)
     fa, fv = 0.3 * torch.randn(S, ca.Nx, ca.Cx, generator=g), 0.3 * torch.randn(S, cv.Nx, cv.Cx, generator=g)
-    ga, gv = torch.randn(fa.shape, generator=g).bfloat16(), torch.randn(fv.shape, generator=g).bfloat16()
+    ga, gv = torch.randn(fa.shape, generator=g).to(dt), torch.randn(fv.shape, generator=g).to(dt)
 
     def run(concurrent):
         release_workspaces()
@@ -52,8 +60,8 @@ def test_two_stream_pair_repeats_bit_for_bit(shape):
         torch.cuda.synchronize()
         del junk
         ma, mv, pair = _pair(dev, concurrent, Pa, Ba, Pv, Bv, ca, cv)
-        xa = fa.to(dev, torch.bfloat16).requires_grad_(True)
-        xv = fv.to(dev, torch.bfloat16).requires_grad_(True)
+        xa = fa.to(dev, dt).requires_grad_(True)
+        xv = fv.to(dev, dt).requires_grad_(True)
         out_a, _ia, out_v, _iv = pair(xa.permute(0, 2, 1).unsqueeze(-1), xv.permute(0, 2, 1).unsqueeze(-1))
         torch.autograd.backward([out_a, out_v], [ga.to(dev).permute(0, 2, 1).unsqueeze(-1), gv.to(dev).permute(0, 2, 1).unsqueeze(-1)])
         torch.cuda.synchronize()
