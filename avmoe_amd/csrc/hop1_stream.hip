@@ -157,8 +157,9 @@ __global__ void __launch_bounds__(128 * NRT, 1) kk_hop1_yk(const YKArgs p) {
 // ======================================================================================================================================
 // yt:  C[row][ch] = sum_tok A[row][tok] Y[tok][ch]     -- per frame (PER_FRAME: A = [frame][row][tokens], K-major rows) or over all tokens
 // (A = [token][rows], token-major; the blocks' partial sums go to a slab and kk_hop1_sum adds them in block order).  tok_pair2.hip's
-// scheme: 64-token tiles of Y (this block's 128 NCT channels) and of A by direct loads into two buffers, every accumulator in registers:
-// wave w owns channel tiles NCT w .. NCT w + NCT - 1 against all NRT row tiles; Y is read transposed (the contraction index is the token).
+// scheme -- every accumulator in registers: wave w owns channel tiles NCT w .. NCT w + NCT - 1 of this block's 128 NCT channels against
+// all NRT row tiles; Y is read transposed (the contraction index is the token) -- on 32-token tiles (one K step) of Y and A in FOUR LDS
+// buffers with counted waits (kk_hop1_yk): three tiles in flight while one is multiplied.
 // ======================================================================================================================================
 struct YTArgs {
   const char* Y; long ldy;                         // bf16 [tokens][ldy]; this block's channels from column 128 NCT blockIdx.y
@@ -167,7 +168,7 @@ struct YTArgs {
   char* C; long ldc, sC1; int c_bf16;              // PER_FRAME: [frame][row][ldc] bf16 or fp32
   float* slab;                                     // sum: [gridDim.x][rows16][ldslab] fp32, this block's channels from column 128 NCT blockIdx.y
   long ldslab;
-  int M, tpf;                                      // PER_FRAME: tokens per frame, 64-token tiles per frame (the last one ragged)
+  int M, tpf;                                      // PER_FRAME: tokens per frame, 32-token tiles per frame (the last one ragged)
   int S;                                           // PER_FRAME: frames ; blocks take contiguous frame ranges
   long ntok; int ntiles;                           // sum: tokens / tiles in all (the last tile ragged)
 };
@@ -186,15 +187,22 @@ __device__ __forceinline__ void tr_wait(u32x2 (&x)[N][2]) {
   for (int i = 0; i < N; ++i) asm volatile("" : "+v"(x[i][0]), "+v"(x[i][1]) :: "memory");
 }
 
+constexpr int YT_BM = 32, YT_NBUF = 4;
+template <int NCT, int NRT, bool PER_FRAME> struct YTGeom {
+  static constexpr int CB = 128 * NCT, CHY = CB / 8 + 1, RBY = 16 * CHY, NPY = (YT_BM * CHY + 63) / 64;      // Y tile: 32 rows x CHY chunks (the last one a pad)
+  static constexpr int RA = PER_FRAME ? 16 * NRT : YT_BM, CHA = (PER_FRAME ? YT_BM / 8 : 2 * NRT) + 1, RBA = 16 * CHA, NPA = (RA * CHA + 63) / 64;
+  static constexpr int OFFA = NPY * 1024, BUF = OFFA + NPA * 1024, NP = NPY + NPA, NLO = NP / 8, NI = (NP + 7) / 8, LDS = YT_NBUF * BUF;
+};
+
 template <int NCT, int NRT, bool PER_FRAME>
 __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
-  constexpr int BM = 64, CB = 128 * NCT, CHY = CB / 8 + 1, RBY = 16 * CHY, NPY = CHY;                 // Y tile: 64 rows x CHY chunks = CHY pieces
-  constexpr int RA = PER_FRAME ? 16 * NRT : 64, CHA = (PER_FRAME ? 8 : 2 * NRT) + 1, RBA = 16 * CHA, NPA = (RA * CHA + 63) / 64;
-  constexpr int OFFA = NPY * 1024, BUF = OFFA + NPA * 1024, NP = NPY + NPA, NI = (NP + 7) / 8;
+  using G = YTGeom<NCT, NRT, PER_FRAME>;
+  constexpr int BM = YT_BM, CB = G::CB, CHY = G::CHY, RBY = G::RBY, NPY = G::NPY, CHA = G::CHA, RBA = G::RBA, OFFA = G::OFFA, BUF = G::BUF, NP = G::NP, NLO = G::NLO, NI = G::NI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const char* Yb = p.Y + (long)blockIdx.y * CB * 2;
   const long ldy = p.ldy, lda = p.lda;
+  const bool extra = NP % 8 != 0 && wave < NP % 8;        // this wave issues NLO + 1 direct loads per tile (wave-uniform)
 
   f32x4 acc[NRT][NCT];
 #pragma unroll
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
       };
       auto ld_a = [&]() {
         const int slot = 64 * (j0 + wave - NPY) + lane;
-        if constexpr (PER_FRAME) {                           // [row][tokens of the tile]: 8 chunks of 8 tokens + the pad chunk
+        if constexpr (PER_FRAME) {                           // [row][tokens of the tile]: 4 chunks of 8 tokens + the pad chunk
           const int row = min(slot / CHA, p.rows - 1), cc = min(min(slot % CHA, CHA - 2), acol_max);
           __builtin_amdgcn_global_load_lds((gptr_t)(Asrc + ((long)row * lda + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, 0);
         } else {                                             // [token][rows]
@@ -225,16 +233,15 @@ __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
       };
       // (i is a constant after unrolling: only the round that holds the Y / A boundary and the last round keep a wave-uniform branch)
       if (j0 + 8 <= NPY) ld_y();
-      else if (j0 >= NPY) { if (j0 + 8 <= NP || j0 + wave < NP) ld_a(); }
-      else { if (j0 + wave < NPY) ld_y(); else if (j0 + 8 <= NP || j0 + wave < NP) ld_a(); }
+      else if (j0 >= NPY) { if (i < NLO || extra) ld_a(); }
+      else { if (j0 + wave < NPY) ld_y(); else if (i < NLO || extra) ld_a(); }
     }
   };
 
   // the work of this block: PER_FRAME frames [f0, f1) ; sum: tiles [t0, t1) of the flat token list
-  int f0 = 0, f1 = 0, t0 = 0, t1 = 0;
+  int t0 = 0, t1 = 0;
   if constexpr (PER_FRAME) {
-    f0 = (int)((long)p.S * blockIdx.x / gridDim.x); f1 = (int)((long)p.S * (blockIdx.x + 1) / gridDim.x);
-    t0 = f0 * p.tpf; t1 = f1 * p.tpf;
+    t0 = (int)((long)p.S * blockIdx.x / gridDim.x) * p.tpf; t1 = (int)((long)p.S * (blockIdx.x + 1) / gridDim.x) * p.tpf;
   } else {
     t0 = (int)((long)p.ntiles * blockIdx.x / gridDim.x); t1 = (int)((long)p.ntiles * (blockIdx.x + 1) / gridDim.x);
   }
@@ -248,10 +255,21 @@ __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
     }
   };
   issue(0, t0);
-  __syncthreads();
+  if (t0 + 1 < t1) issue(1, t0 + 1);
+  if (t0 + 2 < t1) issue(2, t0 + 2);
   for (int it = 0, tile = t0; tile < t1; ++it, ++tile) {
-    const char* sY = smem + (it & 1) * BUF;
-    if (tile + 1 < t1) issue((it + 1) & 1, tile + 1);
+    // this tile has landed once everything but the (up to two) tiles requested after it is complete; the stores of a frame's end are
+    // issued behind a request and only ever make the count an over-estimate of what has to be waited for (in-order counter)
+    {
+      const int ahead = min(2, t1 - 1 - tile);
+      if (ahead == 2) { if (extra) wait_vm<2 * NLO + 2>(); else wait_vm<2 * NLO>(); }
+      else if (ahead == 1) { if (extra) wait_vm<NLO + 1>(); else wait_vm<NLO>(); }
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sY = smem + (it % YT_NBUF) * BUF;
+    if (tile + 3 < t1) issue((it + 3) % YT_NBUF, tile + 3);      // (its buffer was read in the previous iteration: every wave has passed this barrier since)
     int valid;                                            // tokens of this tile that are data
     if constexpr (PER_FRAME) { const int fj = tile % p.tpf; valid = p.M - fj * BM; }
     else valid = (int)min((long)BM, p.ntok - (long)tile * BM);
@@ -260,53 +278,42 @@ __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
       const unsigned ly = l0 + (8 * q + (r >> 2)) * RBY + (NCT * wave * 16 + 4 * (r & 3)) * 2;
       const unsigned la = l0 + OFFA + (8 * q + (r >> 2)) * RBA + (4 * (r & 3)) * 2;      // (token-major A: transposed reads, as Y)
       const char* pa = sY + OFFA + r * RBA + q * 16;                                   // (row-major A: plain 16-byte reads)
-      u32x2 fb[2][NCT][2];
-      u32x4 fa[2][NRT];                                      // row-major A: plain reads
-      u32x2 ft[2][NRT][2];                                   // token-major A: transposing reads
-      // both 32-token steps of the tile: the fragments of step 1 are in flight during the matrix instructions of step 0
-      auto rd = [&](auto TKc) {
-        constexpr int TK = decltype(TKc)::value;
+      u32x2 fb[NCT][2];
+      u32x4 fa[NRT];                                         // row-major A: plain reads
+      u32x2 ft[NRT][2];                                      // token-major A: transposing reads
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          if (c == 0) tr_frag2<TK * 32 * RBY + 0, RBY>(fb[TK][0], ly);
-          if (c == 1) tr_frag2<TK * 32 * RBY + 32, RBY>(fb[TK][1 % NCT], ly);
-          if (c == 2) tr_frag2<TK * 32 * RBY + 64, RBY>(fb[TK][2 % NCT], ly);
-        }
-        if constexpr (PER_FRAME) {
+      for (int c = 0; c < NCT; ++c) {
+        if (c == 0) tr_frag2<0, RBY>(fb[0], ly);
+        if (c == 1) tr_frag2<32, RBY>(fb[1 % NCT], ly);
+        if (c == 2) tr_frag2<64, RBY>(fb[2 % NCT], ly);
+      }
+      if constexpr (PER_FRAME) {
 #pragma unroll
-          for (int i = 0; i < NRT; ++i) fa[TK][i] = *(const u32x4*)(pa + 16 * i * RBA + TK * 64);
-        } else {
-#pragma unroll
-          for (int i = 0; i < NRT; ++i) {
-            if (i == 0) tr_frag2<TK * 32 * RBA + 0, RBA>(ft[TK][0], la);
-            if (i == 1) tr_frag2<TK * 32 * RBA + 32, RBA>(ft[TK][1 % NRT], la);
-            if (i == 2) tr_frag2<TK * 32 * RBA + 64, RBA>(ft[TK][2 % NRT], la);
-            if (i == 3) tr_frag2<TK * 32 * RBA + 96, RBA>(ft[TK][3 % NRT], la);
-            if (i == 4) tr_frag2<TK * 32 * RBA + 128, RBA>(ft[TK][4 % NRT], la);
-          }
-        }
-      };
-      auto mm = [&](int TK) {
-        // tokens 32 TK + 8 q + j of the tile beyond `valid` are not data (a ragged last tile): their A entries are zeroed
-        const int nv = valid - (32 * TK + 8 * q);
-        u32x4 mk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mk[e] = (2 * e + 1 < nv) ? 0xffffffffu : ((2 * e < nv) ? 0x0000ffffu : 0u);
+        for (int i = 0; i < NRT; ++i) fa[i] = *(const u32x4*)(pa + 16 * i * RBA);
+      } else {
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-          const u32x4 av = PER_FRAME ? fa[TK][i] : u32x4{ft[TK][i][0][0], ft[TK][i][0][1], ft[TK][i][1][0], ft[TK][i][1][1]};
-          const bf16x8 a = __builtin_bit_cast(bf16x8, av & mk);
-#pragma unroll
-          for (int c = 0; c < NCT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tr_pack(fb[TK][c]), acc[i][c], 0, 0, 0);
+          if (i == 0) tr_frag2<0, RBA>(ft[0], la);
+          if (i == 1) tr_frag2<32, RBA>(ft[1 % NRT], la);
+          if (i == 2) tr_frag2<64, RBA>(ft[2 % NRT], la);
+          if (i == 3) tr_frag2<96, RBA>(ft[3 % NRT], la);
+          if (i == 4) tr_frag2<128, RBA>(ft[4 % NRT], la);
         }
-      };
-      auto wt = [&](int TK) { tr_wait<NCT>(fb[TK]); if constexpr (!PER_FRAME) tr_wait<NRT>(ft[TK]); };
-      rd(std::integral_constant<int, 0>{});
-      wt(0);
-      rd(std::integral_constant<int, 1>{});
-      mm(0);
-      wt(1);
-      mm(1);
+      }
+      tr_wait<NCT>(fb);
+      if constexpr (!PER_FRAME) tr_wait<NRT>(ft);
+      // tokens 8 q + j of the tile beyond `valid` are not data (a ragged last tile): their A entries are zeroed
+      const int nv = valid - 8 * q;
+      u32x4 mk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mk[e] = (2 * e + 1 < nv) ? 0xffffffffu : ((2 * e < nv) ? 0x0000ffffu : 0u);
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) {
+        const u32x4 av = PER_FRAME ? fa[i] : u32x4{ft[i][0][0], ft[i][0][1], ft[i][1][0], ft[i][1][1]};
+        const bf16x8 a = __builtin_bit_cast(bf16x8, av & mk);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tr_pack(fb[c]), acc[i][c], 0, 0, 0);
+      }
     }
     if constexpr (PER_FRAME) {
       if ((tile + 1) % p.tpf == 0) {                       // the frame ends: its rows (block-uniform)
@@ -328,7 +335,6 @@ __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
           }
       }
     }
-    __syncthreads();                                      // (waits for the direct loads above: the next tile is in place)
   }
   if constexpr (!PER_FRAME) {
     float* sl = p.slab + (long)blockIdx.x * 16 * NRT * p.ldslab + (long)blockIdx.y * CB;
@@ -400,8 +406,7 @@ int k_hop1_yk(const void* Y, long ldy, int S, int M, int Cy, const void* A, long
 namespace {
 template <int NCT, int NRT, bool PF>
 int launch_yt(const YTArgs& p, int gx, int gy, hipStream_t st) {
-  constexpr int CHY = 128 * NCT / 8 + 1, RA = PF ? 16 * NRT : 64, CHA = (PF ? 8 : 2 * NRT) + 1, NPA = (RA * CHA + 63) / 64;
-  constexpr int LDS = 2 * (CHY + NPA) * 1024;
+  constexpr int LDS = YTGeom<NCT, NRT, PF>::LDS;
   static LdsAttrOnce attr;
   AVMOE_TRY(attr.ensure((const void*)kk_hop1_yt<NCT, NRT, PF>, LDS, "hop1_yt"));
   hipLaunchKernelGGL((kk_hop1_yt<NCT, NRT, PF>), dim3((unsigned)gx, (unsigned)gy), dim3(512), LDS, st, p);
@@ -427,7 +432,7 @@ int k_hop1_yt_frames(const void* Y, long ldy, int S, int M, int Cy, const void* 
   const int gy = Cy / cb, gx = std::max(1, std::min(S, cus / gy));
   YTArgs p{};
   p.Y = (const char*)Y; p.ldy = ldy; p.A = (const char*)A; p.lda = lda; p.sA1 = sA1; p.rows = rows; p.C = (char*)C; p.ldc = ldc; p.sC1 = sC1; p.c_bf16 = c_bf16;
-  p.M = M; p.tpf = (M + 63) / 64; p.S = S;
+  p.M = M; p.tpf = (M + YT_BM - 1) / YT_BM; p.S = S;
   const double bytes = (double)S * M * Cy * 2 + (double)S * rows * M * 2 * gy + (double)S * rows * Cy * (c_bf16 ? 2 : 4);
   ProfScope ps("k_hop1_yt_frames", (long)S * M, bytes, 2.0 * S * M * Cy * rows, st);
   if (rows <= 64) return cb == 384 ? launch_yt<3, 4, true>(p, gx, gy, st) : launch_yt<2, 4, true>(p, gx, gy, st);
@@ -436,12 +441,12 @@ int k_hop1_yt_frames(const void* Y, long ldy, int S, int M, int Cy, const void* 
 
 // over all tokens: C (rows x Cy) = A^T Y with A = [token][lda] (columns 0 .. rows - 1), C bf16 or fp32 ; slabs: fp32 workspace
 int k_hop1_yt_sum(const void* Y, long ldy, long ntok, int Cy, const void* A, long lda, int rows, void* C, long ldc, int c_bf16, float* slabs, size_t slab_cap, hipStream_t st) {
-  if (Cy % 384 || rows < 17 || rows > 64 || lda < 64 || ntok < 64 || ldy % 8 || lda % 8 || ldc % 4 || !slabs ||
+  if (Cy % 384 || rows < 17 || rows > 64 || lda < 64 || ntok < YT_BM || ldy % 8 || lda % 8 || ldc % 4 || !slabs ||
       ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 16) || ((uintptr_t)slabs % 16))
     return 1;
   const int cus = cu_count();
   if (cus <= 0) { set_last_error("hop1_yt: device query"); return ERR_LAUNCH; }
-  const int gy = Cy / 384, ntiles = (int)((ntok + 63) / 64), gx = std::max(1, std::min(ntiles, cus / gy));
+  const int gy = Cy / 384, ntiles = (int)((ntok + YT_BM - 1) / YT_BM), gx = std::max(1, std::min(ntiles, cus / gy));
   if ((size_t)gx * 64 * Cy > slab_cap) return 1;
   YTArgs p{};
   p.Y = (const char*)Y; p.ldy = ldy; p.A = (const char*)A; p.lda = lda; p.rows = rows; p.slab = slabs; p.ldslab = Cy; p.ntok = ntok; p.ntiles = ntiles;
