@@ -60,6 +60,7 @@ def _scratch(dev: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
     return buf
 
 
+_FUSED_DX = os.environ.get("AVMOE_NO_FUSED_DX") is None      # development A/B: the token gradients as two kernels each (dX overwrites, the other site's dY adds)
 _SHARED_GPU = None          # process-wide override of avmoe_moe_desc.shared_gpu: None = decide per call (below), True / False = always / never
 
 
@@ -187,6 +188,19 @@ class _SiteBackward:
         capi.check(st, "avmoe_moe_backward")
         return self
 
+    def fused_ok(self, other):
+        """Does the library serve `token gradient = this site's dX + the other site's dY` as ONE kernel (avmoe_moe_backward_dx_dy)?"""
+        return self.L.avmoe_moe_backward_dx_dy(C.byref(self.desc), None, None, None, C.byref(other.desc), None, None, None, None) == 0
+
+    def run_fused(self, other):
+        """dX (this site) + dY (the other site) written once into self.dX: after sections 1 + 32 + 8 of both sites, in place of this
+        site's section 64 and the other site's section 16; the current stream must be ordered behind the other site's section 8."""
+        st = self.L.avmoe_moe_backward_dx_dy(C.byref(self.desc), self.X.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(),
+                                             C.byref(other.desc), other.saved.data_ptr(), other.scratch.data_ptr(), self.dX.data_ptr(),
+                                             torch.cuda.current_stream(self.X.device).cuda_stream)
+        capi.check(st, "avmoe_moe_backward_dx_dy")
+        return self
+
     def finish(self):
         sink = self.sink
         if self.use_sink:
@@ -262,7 +276,7 @@ class _PairFunction(torch.autograd.Function):
         def join(ev):
             ev.record(side); main.wait_event(ev)
         if side is not None:                           # site B on the side stream, concurrently with site A
-            ctx_ev = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
+            ctx_ev = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(6))
             fork(ctx_ev[2])
             two = side.cuda_stream != main.cuda_stream      # (same_stream: the schedule of the two-stream mode on one stream -- nothing overlaps)
             with torch.cuda.stream(side):
@@ -317,22 +331,45 @@ class _PairFunction(torch.autograd.Function):
             # the two dY GEMMs are ordered behind the events.  (Measured on MI355X at cfg-2, round 2: 5.79 ms per step against 5.97 for
             # two buffers + a fused add and 6.04 / 6.06 for the variants that serialise one site's tail behind the other -- dropped.)
             side, main = ctx.side, torch.cuda.current_stream(Xa.device)
-            ev_a, ev_b, ev_fork, ev_join = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(4))
+            ev_a, ev_b, ev_fork, ev_join, ev_a6, ev_b6 = ctx.events if ctx.events else tuple(torch.cuda.Event() for _ in range(6))
             ev_fork.record(main); side.wait_event(ev_fork)
             slot_b = 1 if side.cuda_stream == main.cuda_stream else 0      # (same_stream: the two sites' sections interleave on ONE stream)
             with torch.cuda.stream(side):
                 cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, d_lbb, gXb, gXa, acc_dx=False, acc_dy=True,
-                                    scratch_slot=slot_b).run(3)
-                ev_b.record(side)
-                cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
-            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, d_lba, gXa, gXb, acc_dx=False, acc_dy=True).run(3)
-            ev_a.record(main)
-            cak.run(8)
+                                    scratch_slot=slot_b)
+            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, d_lba, gXa, gXb, acc_dx=False, acc_dy=True)
+            # Round 5: where the library serves it (avmoe_moe_backward_dx_dy: the tuned bf16 shapes), a token gradient is written ONCE -- the
+            # dX product of its own site with the other site's dY product folded in as two more contraction segments -- instead of
+            # overwritten by one site and read back + added by the other.  That product moves to the END of its site's backward (it
+            # needs the other site's hop-1 chain, section 8); decided per tensor.
+            fuse_a = _FUSED_DX and cak.fused_ok(cbk)     # gXa = A's dX + B's dY
+            fuse_b = _FUSED_DX and cbk.fused_ok(cak)     # gXb = B's dX + A's dY
             with torch.cuda.stream(side):
-                side.wait_event(ev_a)                    # gXa holds site A's dX
-                pgb = cbk.run(16).finish()
-            main.wait_event(ev_b)                        # gXb holds site B's dX
-            pga = cak.run(16).finish()
+                cbk.run(1 | 32 if fuse_b else 3)
+                if not fuse_b:
+                    ev_b.record(side)                    # gXb holds site B's dX
+                cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
+                ev_b6.record(side)
+            cak.run(1 | 32 if fuse_a else 3)
+            if not fuse_a:
+                ev_a.record(main)                        # gXa holds site A's dX
+            cak.run(8)
+            ev_a6.record(main)
+            with torch.cuda.stream(side):
+                if fuse_b:
+                    side.wait_event(ev_a6)
+                    cbk.run_fused(cak)                   # gXb complete
+                if not fuse_a:
+                    side.wait_event(ev_a)                # gXa holds site A's dX
+                    cbk.run(16)                          # += site B's dY
+                pgb = cbk.finish()
+            if fuse_a:
+                main.wait_event(ev_b6)
+                cak.run_fused(cbk)                       # gXa complete
+            if not fuse_b:
+                main.wait_event(ev_b)                    # gXb holds site B's dX
+                cak.run(16)
+            pga = cak.finish()
             ev_join.record(side); main.wait_event(ev_join)
             for t_ in tuple(g_ for g_ in pgb if g_ is not None) + (cbk.d_out,):
                 t_.record_stream(main)
@@ -687,7 +724,7 @@ class AdapterPair(nn.Module):
         Pa, Pb = self.site_a._param_tensors(), self.site_b._param_tensors()
         if self.concurrent and self._side is None:
             self._side = side_stream(x_a.device)
-            self._events = tuple(torch.cuda.Event() for _ in range(4))      # backward hand-over (2), fork, join
+            self._events = tuple(torch.cuda.Event() for _ in range(6))      # backward hand-over (2), fork, join, hop-1 chains done (2)
         for base, X in zip(add_to, (Xa, Xb)):
             if base is not None and not _safe_inplace(base, (Xa, Xb)):
                 raise capi.AvmoeError("add_to must own its storage (no view) and must not overlap the token tensors")

@@ -71,13 +71,22 @@ int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const voi
                             const avmoe_moe_ptrs* grads, int32_t parts, void* stream) {
   Plan pl;
   AVMOE_TRY(make_plan(desc, &pl));
-  if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads || parts < 0 || parts > 31) {
-    set_last_error("avmoe_moe_backward_part: null pointer or parts not in 0..31"); return ERR_BAD_ARG;
+  if (!X || !Y || !params || !dOut || !saved || !scratch || !dX || !dY || !grads || parts < 0 || parts > 127) {
+    set_last_error("avmoe_moe_backward_part: null pointer or parts not in 0..127"); return ERR_BAD_ARG;
   }
   if ((parts & 4) && (parts & 24)) {        // 4 IS sections 8 + 16: asking for both would run the hop-1 chain twice into the same accumulators
     set_last_error("avmoe_moe_backward_part: parts %d combines section 4 with its halves 8 / 16", parts); return ERR_BAD_ARG;
   }
   return moe_backward(pl, X, Y, *params, dOut, lb_grad, (char*)saved, (char*)scratch, dX, dY, *grads, (hipStream_t)stream, parts);
+}
+
+int avmoe_moe_backward_dx_dy(const avmoe_moe_desc* desc_a, const void* X_a, void* saved_a, void* scratch_a,
+                             const avmoe_moe_desc* desc_b, void* saved_b, void* scratch_b, void* dT, void* stream) {
+  Plan pa, pb;
+  AVMOE_TRY(make_plan(desc_a, &pa));
+  AVMOE_TRY(make_plan(desc_b, &pb));
+  if (dT && (!X_a || !saved_a || !scratch_a || !saved_b || !scratch_b)) { set_last_error("avmoe_moe_backward_dx_dy: null pointer"); return ERR_BAD_ARG; }
+  return moe_backward_dx_dy(pa, X_a, (char*)saved_a, (char*)scratch_a, pb, (char*)saved_b, (char*)scratch_b, dT, dT != nullptr, (hipStream_t)stream);
 }
 
 int avmoe_router_forward(const avmoe_moe_desc* desc, const float* rin, const avmoe_moe_ptrs* params, const float* noise,

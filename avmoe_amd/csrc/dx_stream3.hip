@@ -1,0 +1,287 @@
+// The gradient of a token tensor that is X of site A and Y of site B (the two adapter sites of one backbone layer, net_trans_v3.py:695-698),
+// written ONCE (round 5):
+//
+//   dT[s] =  dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + rs2x X[s]          site A's dX   (moe_backward.cpp, phase 5)
+//          + [Bm ; wbar]_B[s]^T dV_B[s] + dR_B[s]^T Q_B                             site B's dY   (moe_backward.cpp, phase 6)
+//
+// As two kernels (kk_dx_stream2 overwriting, the twelve-wave streaming GEMM adding behind an event) the tensor crossed the memory interface
+// three times -- written, read, written: 1 GB more than necessary at the cfg-2 audio tokens -- and site B's dY operands are skinny (65 + 64
+// values per token) beside the row it adds to.  Here they are two more K segments of the dX pass.
+//
+// Shape of the kernel: dx_stream2.hip's (eight waves, one block per CU and group, wave w = 48 channels of the group: every B-side matrix
+// as stationary MFMA fragments -- Wt and Q_B for the whole kernel, T[s] and dV_B[s] re-gathered at a frame change --, token tiles by
+// direct global -> LDS loads, products computed transposed so that a lane ends up with four consecutive channels of a token) on 32-token
+// tiles in THREE LDS buffers with counted waits (hop1_stream.hip::kk_hop1_yk: two tiles in flight while one is multiplied; the in-order
+// memory counter leaves the newest tile's loads and the last two iterations' stores pending).  Every wave issues exactly six store
+// instructions per tile (rows beyond a ragged frame end go to a dump word) so that the counts are exact.
+#include "gemm.h"
+#include "common.h"
+#include "prof.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+
+namespace avmoe {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct DX3Args {
+  // site A (the tensor is its X)
+  const char* X; long ldx;             // bf16 [tokens][ldx], group g at column g * 384 (the operand of the row-scale term)
+  const char* dZx; long ldz;           // bf16 [tokens][ldz], group g at column g * 128
+  const char* dL2; long ldl;           // bf16 [tokens][ldl >= 72]: columns 0 .. K2 - 1 used
+  const float* rs;                     // fp32 [tokens]
+  const unsigned short* Wt; long ldw, sWg;      // bf16 [g][128][ldw]: row = bottleneck column, column = channel
+  const unsigned short* Text; long ldt, sT1;    // bf16 [frame][K2][ldt], group g at column g * 384
+  // site B (the tensor is its Y)
+  const char* Bm; long ldb, sB1;       // bf16 [frame][rows >= KB][ldb]: [Bm ; wbar], tokens along the row
+  const char* dRT; long ldr;           // bf16 [tokens][ldr]: columns 0 .. KQ - 1 used (ldr >= 8 ncr)
+  const unsigned short* dV; long ldv, sV1;      // bf16 [frame][KB][ldv], group g at column g * 384
+  const unsigned short* Q; long ldq;            // bf16 [KQ][ldq], group g at column g * 384
+  char* dX; long ldc;                  // bf16 [tokens][ldc], group g at column g * 384
+  char* dump;                          // >= 16 writable bytes nobody reads
+  int N, tps, ntiles, K2, KB, KQ, ncr; // tokens per frame, 32-token tiles per frame (the last one ragged), tiles in all, rows of T[s] / [Bm ; wbar] / Q, 16-byte chunks of a dRT row
+};
+
+constexpr int BM = 32, NWV = 4, NTHR = 64 * NWV, NCT = 24 / NWV, NBUF = 3;      // four waves, one per SIMD: 6 channel tiles each (the 72 stationary fragments need the whole register file of a SIMD lane: 512 registers per wave)
+constexpr int CHX = 49, CHZ = 17, CHL = 10, CHR = 9, CHB = 5;                       // 16-byte chunks per LDS row (the last one a pad)
+constexpr int RBX = 16 * CHX, RBZ = 16 * CHZ, RBL = 16 * CHL, RBR = 16 * CHR, RBB = 16 * CHB;
+constexpr int PX = 25, PZ = 9, PL = 5, PR = 5, PB = 8;                              // 1 KB pieces per sub-tile (32 x 49, 32 x 17, 32 x 10, 32 x 9, 96 x 5 chunks, rounded up)
+constexpr int OFFZ = PX * 1024, OFFL = OFFZ + PZ * 1024, OFFR = OFFL + PL * 1024, OFFB = OFFR + PR * 1024, OFFS = OFFB + PB * 1024, BUF = OFFS + 256;
+constexpr int DX3_LDS = NBUF * BUF;
+static_assert(DX3_LDS <= 160 * 1024, "three buffers in one CU's LDS");
+
+__device__ __forceinline__ unsigned int f2bf(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bflo(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bfhi(unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void tr_issue(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory"); }
+
+__global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;      // (wave: a scalar -- the piece dealing below branches on it)
+  const int g = blockIdx.y;
+  const char* Xb = p.X + (long)g * 384 * 2;
+  const char* Zb = p.dZx + (long)g * 128 * 2;
+  const long ldx = p.ldx, ldz = p.ldz, ldl = p.ldl, ldr = p.ldr, ldb = p.ldb;
+  const int c0 = 16 * NCT * wave;                           // this wave's channels c0 .. c0 + 16 NCT - 1 of the group
+
+  // eight consecutive contraction rows k0 .. k0 + 7 of column n of an MN-major matrix ([row][column]); rows >= kend read as zero
+  auto frag_mn = [&](const unsigned short* base, long ld, int n, int k0, int kend) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned int h = (unsigned int)base[(long)min(k0 + j, kend - 1) * ld + n];      // (every load unconditional: a load under a condition is waited for one by one)
+      h = (k0 + j < kend) ? h : 0u;
+      v[j >> 1] |= (j & 1) ? (h << 16) : h;
+    }
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  bf16x8 bw[NCT][4], bt[NCT][3], bq[NCT][2], bv[NCT][3];
+  {
+    const unsigned short* W = p.Wt + (long)g * p.sWg;
+    const unsigned short* Qg = p.Q + (long)g * 384;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bw[ct][ks] = frag_mn(W, p.ldw, c0 + 16 * ct + r, 32 * ks + 8 * q, 128);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bq[ct][ks] = frag_mn(Qg, p.ldq, c0 + 16 * ct + r, 32 * ks + 8 * q, p.KQ);
+    }
+  }
+  const bool extra = wave == 0;                            // (PX + PZ + PL + PR + PB) / NWV direct loads per tile and wave, one more (the row scales) for wave 0
+  constexpr int NLO = (PX + PZ + PL + PR + PB) / NWV, NS = 2 * NCT;      // loads / stores per tile and wave
+
+  // One buffer image = [X 25 | dZx 9 | dL2 5 | dRT 5 | [Bm ; wbar] 8] pieces of 1 KB + the tile's 32 row scales; piece P = wave + 8 i.
+  auto gload = [&](int buf, int tile) {
+    const int fs = tile / p.tps, fj = tile - fs * p.tps;
+    const long m0 = (long)fs * p.N + (long)fj * BM;         // first token of the tile
+    const int last = min(p.N - fj * BM, BM) - 1;            // rows beyond the frame's last token re-read it (a ragged last tile; never stored)
+    char* dst = smem + buf * BUF + 1024 * wave;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                            // (opaque: the per-piece row / chunk arithmetic stays in the loop instead of being hoisted into -- and spilled from -- 26 registers)
+    auto src_x = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHX, last), cc = min(slot % CHX, CHX - 2); return Xb + ((m0 + row) * ldx + cc * 8) * 2; };
+    auto src_z = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHZ, last), cc = min(slot % CHZ, CHZ - 2); return Zb + ((m0 + row) * ldz + cc * 8) * 2; };
+    auto src_l = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHL, last), cc = min(slot % CHL, CHL - 2); return p.dL2 + ((m0 + row) * ldl + cc * 8) * 2; };
+    auto src_r = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHR, last), cc = min(slot % CHR, p.ncr - 1); return p.dRT + ((m0 + row) * ldr + cc * 8) * 2; };
+    // [Bm ; wbar] of the frame: row l (those beyond KB - 1 re-read the last one: their B-side fragments are zero), the tile's 32 tokens as
+    // 4 chunks (a chunk that would leave the row re-reads the row's last one: tokens beyond the frame are never stored)
+    const int bmax = (int)((ldb - (long)fj * BM) / 8) - 1;
+    auto src_b = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHB, p.KB - 1), cc = min(min(slot % CHB, CHB - 2), bmax);
+                              return p.Bm + ((long)fs * p.sB1 + (long)row * ldb + (long)fj * BM + cc * 8) * 2; };
+    // piece P = wave + NWV i (i is a constant after unrolling: only the rounds that hold a boundary between two sub-tiles keep a wave-uniform branch)
+    constexpr int B1 = PX, B2 = B1 + PZ, B3 = B2 + PL, B4 = B3 + PR, B5 = B4 + PB;
+#pragma unroll
+    for (int i = 0; i < (B5 + NWV - 1) / NWV; ++i) {
+      const int P = wave + NWV * i;
+      char* d = dst + 1024 * NWV * i;
+      if (NWV * i + NWV <= B1) __builtin_amdgcn_global_load_lds((gptr_t)src_x(P), (lptr_t)d, 16, 0, 0);
+      else if (NWV * i >= B1 && NWV * i + NWV <= B2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(P - B1), (lptr_t)d, 16, 0, 0);
+      else if (NWV * i >= B2 && NWV * i + NWV <= B3) __builtin_amdgcn_global_load_lds((gptr_t)src_l(P - B2), (lptr_t)d, 16, 0, 0);
+      else if (NWV * i >= B3 && NWV * i + NWV <= B4) __builtin_amdgcn_global_load_lds((gptr_t)src_r(P - B3), (lptr_t)d, 16, 0, 0);
+      else if (NWV * i >= B4 && NWV * i + NWV <= B5) __builtin_amdgcn_global_load_lds((gptr_t)src_b(P - B4), (lptr_t)d, 16, 0, 0);
+      else if (P < B1) __builtin_amdgcn_global_load_lds((gptr_t)src_x(P), (lptr_t)d, 16, 0, 0);
+      else if (P < B2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(P - B1), (lptr_t)d, 16, 0, 0);
+      else if (P < B3) __builtin_amdgcn_global_load_lds((gptr_t)src_l(P - B2), (lptr_t)d, 16, 0, 0);
+      else if (P < B4) __builtin_amdgcn_global_load_lds((gptr_t)src_r(P - B3), (lptr_t)d, 16, 0, 0);
+      else if (P < B5) __builtin_amdgcn_global_load_lds((gptr_t)src_b(P - B4), (lptr_t)d, 16, 0, 0);
+    }
+    static_assert(B5 % NWV == 0, "every wave issues the same number of pieces");
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(ln, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);       // the tile's row scales
+  };
+
+  // contiguous tile ranges (few frame changes per block)
+  int tile = (int)((long)p.ntiles * blockIdx.x / gridDim.x);
+  const int t_end = (int)((long)p.ntiles * (blockIdx.x + 1) / gridDim.x);
+  if (tile >= t_end) return;
+  gload(0, tile);
+  if (tile + 1 < t_end) gload(1, tile + 1);
+  int cur_s = -1;
+  for (int it = 0; tile < t_end; ++it, ++tile) {
+    // In-order counter, issue order per iteration i: [loads of tile i + 2] [the 2 NCT stores of tile i].  Tile `tile` has landed once everything
+    // but what was issued after its loads is complete: the loads of tile + 1 and the stores of the two previous iterations.
+    if (tile + 1 < t_end) {
+      if (it == 0) { if (extra) wait_vm<NLO + 1>(); else wait_vm<NLO>(); }
+      else if (it == 1) { if (extra) wait_vm<NLO + 1 + NS>(); else wait_vm<NLO + NS>(); }
+      else { if (extra) wait_vm<NLO + 1 + 2 * NS>(); else wait_vm<NLO + 2 * NS>(); }
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sX = smem + (it % NBUF) * BUF;
+    const char* sZ = sX + OFFZ;
+    const char* sL = sX + OFFL;
+    const char* sR = sX + OFFR;
+    const float* sS = (const float*)(sX + OFFS);
+    const int s = tile / p.tps;
+    if (s != cur_s) {          // this frame's T[s] and dV_B[s] (block-uniform, a few times per block; ordinary loads, complete when the branch ends)
+      cur_s = s;
+      const unsigned short* T = p.Text + (long)s * p.sT1 + (long)g * 384;
+      const unsigned short* V = p.dV + (long)s * p.sV1 + (long)g * 384;
+      // (two batches of 72 two-byte loads: all 144 at once do not fit the registers the stationary fragments leave)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) bt[ct][ks] = frag_mn(T, p.ldt, c0 + 16 * ct + r, 32 * ks + 8 * q, p.K2);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) asm volatile("" : "+v"(bt[ct][ks]));
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) bv[ct][ks] = frag_mn(V, p.ldv, c0 + 16 * ct + r, 32 * ks + 8 * q, p.KB);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) asm volatile("" : "+v"(bv[ct][ks]));
+    }
+    // the request for tile + 2 (its buffer was read in the previous iteration: every wave has passed this iteration's barrier since) before
+    // the arithmetic: two tiles are in flight while this one is multiplied
+    if (tile + 2 < t_end) gload((it + 2) % NBUF, tile + 2);
+    const int fj = tile - s * p.tps, valid = p.N - fj * BM;      // rows of this tile inside the frame (>= 32: all of them)
+    const long m0 = (long)s * p.N + (long)fj * BM;
+    // one 16-token slab at a time (three independent accumulator chains; two slabs at once do not fit beside the 36 stationary fragments)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 acc[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // [Bm ; wbar]^T dV_B: the tile is [l][token] -- read transposed (lane (r, q): token r of the slab, rows 8 q .. 8 q + 7 of the K step)
+      {
+        const unsigned lb = (unsigned)(size_t)(lptr_t)(sX + OFFB) + (8 * q + (r >> 2)) * RBB + (4 * (r & 3)) * 2 + 32 * h;
+        u32x2 f[3][2];                                     // [K step][half]
+        tr_issue<0 * 32 * RBB>(f[0][0], lb); tr_issue<0 * 32 * RBB + 4 * RBB>(f[0][1], lb);
+        tr_issue<1 * 32 * RBB>(f[1][0], lb); tr_issue<1 * 32 * RBB + 4 * RBB>(f[1][1], lb);
+        tr_issue<2 * 32 * RBB>(f[2][0], lb); tr_issue<2 * 32 * RBB + 4 * RBB>(f[2][1], lb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          asm volatile("" : "+v"(f[ks][0]), "+v"(f[ks][1]) :: "memory");
+          const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4{f[ks][0][0], f[ks][0][1], f[ks][1][0], f[ks][1][1]});
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[ct][ks], af, acc[ct], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                      // dZx Wt
+        const bf16x8 af = *(const bf16x8*)(sZ + (16 * h + r) * RBZ + ks * 64 + q * 16);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ct][ks], af, acc[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {                      // [dL2 | dsx | 1] [T ; 1 ; dm1/N]  (the lane's columns 32 ks + 8 q .. beyond K2 are not data)
+        u32x4 v = *(const u32x4*)(sL + (16 * h + r) * RBL + ks * 64 + q * 16);
+        const int nvk = p.K2 - (32 * ks + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] &= (2 * e + 1 < nvk) ? 0xffffffffu : ((2 * e < nvk) ? 0x0000ffffu : 0u);
+        const bf16x8 af = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bt[ct][ks], af, acc[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                      // dR_B^T Q_B  (the fragments of Q are zero beyond its KQ rows)
+        const bf16x8 af = *(const bf16x8*)(sR + (16 * h + r) * RBR + ks * 64 + q * 16);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ct][ks], af, acc[ct], 0, 0, 0);
+      }
+      {                                                    // lane (r, q): token r of the slab, channels c0 + 16 ct + 4 q .. + 3 ; three stores per slab, always
+        const int row = 16 * h + r;
+        const bool ok = row < valid;
+        const float rs = sS[row];
+        char* out = ok ? p.dX + ((m0 + row) * p.ldc + (long)g * 384 + c0 + 4 * q) * 2 : p.dump;
+        const int step = ok ? 32 : 0;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const u32x2 xv = *(const u32x2*)(sX + row * RBX + (c0 + 16 * ct + 4 * q) * 2);
+          const f32x4 a = acc[ct];
+          *(u32x2*)(out + step * ct) = u32x2{f2bf(a[0] + rs * bflo(xv[0])) | (f2bf(a[1] + rs * bfhi(xv[0])) << 16),
+                                             f2bf(a[2] + rs * bflo(xv[1])) | (f2bf(a[3] + rs * bfhi(xv[1])) << 16)};
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// 0 = launched, 1 = shape not served (the caller runs the dX product and site B's dY product separately), < 0 error
+int k_dx_stream3(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int K2, const float* rs, const void* Wt, long ldw, long sWg,
+                 const void* Text, long ldt, long sT1, const void* Bm, long ldb, long sB1, int KB, const void* dRT, long ldr, const void* dV, long ldv, long sV1,
+                 const void* Q, long ldq, int KQ, void* dX, long ldc, void* dump, int S, int N, int G, int Cg, int K1, hipStream_t st) {
+  if (Cg != 384 || K1 != 128 || K2 < 1 || K2 > 72 || ldl < 72 || KB < 1 || KB > 96 || KQ < 1 || KQ > 64 || ldr < 8 || ldb < N || N < 4 || S < 1 ||
+      ldx % 8 || ldz % 8 || ldl % 8 || ldr % 8 || ldb % 8 || sB1 % 8 || ldc % 4 || !rs || !dump ||
+      ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dRT % 16) || ((uintptr_t)Bm % 16) || ((uintptr_t)dX % 8) ||
+      ((uintptr_t)rs % 4) || ((uintptr_t)dump % 16) || (long)S * N < 2048)
+    return 1;
+  const int cus = cu_count();
+  if (cus <= 0) { set_last_error("dx_stream3: device query"); return ERR_LAUNCH; }
+  DX3Args p;
+  p.X = (const char*)X; p.ldx = ldx; p.dZx = (const char*)dZx; p.ldz = ldz; p.dL2 = (const char*)dL2; p.ldl = ldl; p.rs = rs;
+  p.Wt = (const unsigned short*)Wt; p.ldw = ldw; p.sWg = sWg; p.Text = (const unsigned short*)Text; p.ldt = ldt; p.sT1 = sT1;
+  p.Bm = (const char*)Bm; p.ldb = ldb; p.sB1 = sB1; p.dRT = (const char*)dRT; p.ldr = ldr; p.dV = (const unsigned short*)dV; p.ldv = ldv; p.sV1 = sV1;
+  p.Q = (const unsigned short*)Q; p.ldq = ldq;
+  p.dX = (char*)dX; p.ldc = ldc; p.dump = (char*)dump; p.N = N; p.tps = (N + BM - 1) / BM; p.ntiles = S * p.tps; p.K2 = K2; p.KB = KB; p.KQ = KQ;
+  p.ncr = (int)std::min<long>(8, ldr / 8);
+  const int gx = std::min(std::max(1, cus / G), p.ntiles);
+  static LdsAttrOnce attr;
+  AVMOE_TRY(attr.ensure((const void*)kk_dx_stream3, DX3_LDS, "dx_stream3"));
+  const double ntok = (double)S * N;
+  const double bytes = ntok * G * (384.0 * 2 * 2 + 128.0 * 2) + ntok * (ldl * 2.0 + 4.0) + ntok * G * (64.0 + KB) * 2.0;
+  ProfScope ps("k_dx_stream3", (long)ntok, bytes, 2.0 * ntok * G * 384.0 * (128 + K2 + KB + KQ), st);
+  hipLaunchKernelGGL(kk_dx_stream3, dim3((unsigned)gx, (unsigned)G), dim3(NTHR), DX3_LDS, st, p);
+  AVMOE_CHECK_LAUNCH("dx_stream3");
+  return OK;
+}
+
+}  // namespace avmoe

@@ -96,6 +96,10 @@ int k_dx_stream2(const void* X, long ldx, const void* dZx, long ldz, const void*
 int k_hop1_yk(const void* Y, long ldy, int S, int M, int Cy, const void* A, long lda, long sA1, int rows, void* C, long ldc, long sC1, int c_bf16, void* dump, hipStream_t st);   // C[s] = A[(s)] Y[s]^T ; dump: 16 writable bytes
 int k_hop1_yt_frames(const void* Y, long ldy, int S, int M, int Cy, const void* A, long lda, long sA1, int rows, void* C, long ldc, long sC1, int c_bf16, hipStream_t st);   // C[s] = A[s] Y[s]
 int k_hop1_yt_sum(const void* Y, long ldy, long ntok, int Cy, const void* A, long lda, int rows, void* C, long ldc, int c_bf16, float* slabs, size_t slab_cap, hipStream_t st);   // C = A^T Y over all tokens
+// site A's dX product + site B's dY product into one tensor, written once (dx_stream3.hip); 1 = shape not served
+int k_dx_stream3(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int K2, const float* rs, const void* Wt, long ldw, long sWg,
+                 const void* Text, long ldt, long sT1, const void* Bm, long ldb, long sB1, int KB, const void* dRT, long ldr, const void* dV, long ldv, long sV1,
+                 const void* Q, long ldq, int KQ, void* dX, long ldc, void* dump, int S, int N, int G, int Cg, int K1, hipStream_t st);
 int k_nxn_rowdot(int bf16, const void* X, const float* y, long rows, int C, void* dX, float* rowdot, hipStream_t st);   // dX += y ; rowdot = sum_c X y
 // register-resident variants for bottleneck 64 / 2 groups / 32 latent tokens / 4 experts (tile_fast.hip)
 bool tile_fast_ok(const Dims& d);

@@ -18,7 +18,8 @@ avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* 
 
 // parts: bit mask of the sections to run, 0 = 7 = the whole backward:
 //   1  phases 1-4: the GEMMs against dOut and the bottleneck / weight space (touches neither dX nor dY)
-//   2  phase 5: the GEMMs against X -- every writer of dX
+//   2  phase 5: the GEMMs against X -- every writer of dX ;  in two steps (plain sites only): 32 = phase 5 without the dX product
+//      (touches neither dX nor dY), 64 = the dX product alone -- or moe_backward_dx_dy below in its place
 //   4  phase 6: the hop-1 chain back to Y and the remap parameters -- every writer of dY;  in two steps: 8 = phase 6 without the
 //      GEMM(s) that write dY (touches neither dX nor dY), 16 = those GEMMs alone (after 8)
 // Sections are stream-ordered through `scratch`: a caller may put event records / waits between them (AdapterPair orders the
@@ -27,6 +28,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
                  char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads_in, hipStream_t st, int parts) {
   const Dims& d = pl.d;
   if (parts == 0) parts = 7;
+  if ((parts & (32 | 64)) && (d.Kcx > 0 || d.mha || d.nxn)) { set_last_error("split backward: sections 32 / 64 serve plain sites only (this one goes on accumulating into dX)"); return ERR_UNSUPPORTED; }
+  if ((parts & 2) && (parts & (32 | 64))) { set_last_error("split backward: section 2 IS sections 32 + 64"); return ERR_BAD_ARG; }
   if ((parts & 7) != 7 && d.Kcx > 0) { set_last_error("split backward: sites with latent self attention write dX in the last section"); return ERR_UNSUPPORTED; }
   avmoe_moe_ptrs prm = with_unit_gates(pl, prm_in, sv);
   avmoe_moe_ptrs grads = grads_in;
@@ -122,12 +125,13 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   if (d.nxn) MEMSET0(sc + pl.o_dZR, (size_t)d.NT * d.DZ * esz);
   AVMOE_TRY(k_pre_small_bwd(pl, sv, sc, prm, grads, st));
   }
-  if (parts & 2) {   // =============================== section 2: phase 5 ====================================
+  if (parts & (2 | 32 | 64)) {   // =============================== section 2: phase 5 ====================================
   const char* dZx = sc + pl.o_Zw;
-  const bool fork2 = side && (side_mask() & 4) && !d.mha && !d.nxn;             // (those variants go on accumulating into dX below)
+  const bool do_dx = (parts & (2 | 64)) != 0, do_rest = (parts & (2 | 32)) != 0;
+  const bool fork2 = side && (side_mask() & 4) && !d.mha && !d.nxn && (parts & 2);             // (those variants go on accumulating into dX below)
 
   // ---- phase 5: GEMMs against X --------------------------------------------------------------------
-  {   // dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + 2 dSxx X[s]   -- one pass: two K segments + row-scale epilogue
+  if (do_dx) {   // dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + 2 dSxx X[s]   -- one pass: two K segments + row-scale epilogue
     GemmArgs g = base();
     g.A = dZx; g.B = sv + pl.o_Wt; g.C = dX;
     g.M = d.N; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
@@ -146,6 +150,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     }
     if (dx2 != OK) AVMOE_TRY(run_on(g, false, fork2 ? side->s : st));
   }
+  if (do_rest) {
   if (d.mha) {   // ---- AVS "v1": per expert back through ZR = xr Wt_e^T, the row sums and xr = MHA_e(X) - X -------------------
     for (int e = 0; e < d.E; ++e) {
       if (!d.nxn_of_e[e]) continue;
@@ -317,6 +322,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   AVMOE_TRY(k_finish_dT(pl, sv, sc, st));                  // + dtbar / C ; dTy (T, with the dm2 row) ; dTx ; dT0 ; drw, dbf
   AVMOE_TRY(k_down_bwd(pl, sc, prm, grads, st));
   if (d.mg) AVMOE_TRY(k_merge_gather(pl, sc, grads_in, st));   // diagonal blocks of the dense weight gradients -> the caller's grouped ones
+  }
   if (fork2) AVMOE_TRY(fk2.join());
   }
   // ======================= section 3: phase 6 (4 = all of it; 8 = everything but the writers of dY; 16 = the writers of dY) ==========
@@ -463,6 +469,21 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   }
   if (do6a) AVMOE_TRY(k_hop1_finalize(pl, sv, sc, prm, grads, st));
   return OK;
+}
+
+// The gradient of a token tensor that is X of site A and Y of site B (the two sites of one backbone layer), written once: site A's dX
+// product with site B's dY product as two more K segments (dx_stream3.hip).  After sections 1 + 32 + 8 of BOTH sites; replaces section 64 of
+// A and section 16 of B.  launch = false: only says whether the shapes are served.  0 = served (launched), 1 = not served, < 0 error.
+int moe_backward_dx_dy(const Plan& pa, const void* X, char* sva, char* sca, const Plan& pb, char* svb, char* scb, void* dX, bool launch, hipStream_t st) {
+  const Dims& a = pa.d;
+  const Dims& b = pb.d;
+  if (!a.bf16 || !b.bf16 || a.mha || a.nxn || a.Kcx > 0 || a.mg || b.mg || a.Cg != 384 || a.E * a.dgp != 128 || a.KLT > 72 || a.KLp < 72 ||
+      b.M != a.N || b.Cy != a.C || b.S != a.S || b.Kcy < 1 || b.Kcy > 64 || b.Kcyb > 96 || b.Kcx > 0 || (long)a.S * a.N < 2048)
+    return 1;
+  if (!launch) return OK;
+  return k_dx_stream3(X, a.C, sca + pa.o_Zw, a.DZ, sca + pa.o_dL2x, a.KLp, a.KLT, (const float*)(sca + pa.o_rs2x), sva + pa.o_Wt, a.Cg, (long)a.E * a.dgp * a.Cg,
+                      sva + pa.o_Text, a.C, (long)a.KLT * a.C, svb + pb.o_BmX, b.Mb, (long)b.Kcyb * b.Mb, b.Kcyb, scb + pb.o_dRT, b.Kcyp,
+                      scb + pb.o_dV, b.Cy, (long)b.Kcyb * b.Cy, svb + pb.o_Qx, b.Cy, b.Kcy, dX, a.C, sca + pa.o_slabs, a.S, a.N, a.g, a.Cg, a.E * a.dgp, st);
 }
 
 }  // namespace avmoe

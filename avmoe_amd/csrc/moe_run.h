@@ -23,6 +23,9 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, const void* dOut, const float* lb_grad,
                  char* saved, char* scratch, void* dX, void* dY, const avmoe_moe_ptrs& grads, hipStream_t st, int parts = 0);
 
+// site A's dX + site B's dY into one token gradient, written once (moe_backward.cpp / dx_stream3.hip); 1 = shapes not served
+int moe_backward_dx_dy(const Plan& pa, const void* X, char* sva, char* sca, const Plan& pb, char* svb, char* scb, void* dX, bool launch, hipStream_t st);
+
 // sub-ops of the C ABI (moe_forward.cpp): one expert's output alone ; the remap materialised
 int expert_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm, int e, void* out, char* saved, char* scratch,
                    hipStream_t st);

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 9
+#define AVMOE_ABI_VERSION 10
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -159,10 +159,24 @@ int avmoe_moe_backward(const avmoe_moe_desc* desc, const void* X, const void* Y,
  * runs through and overwrites (its dY / dX), an event orders the larger site's sections 2 and 4 behind it, and that site adds
  * its dX / dY in the GEMM epilogues (accumulate_dx / accumulate_dy); or, cross-wise: each site overwrites its own tokens' gradient
  * (sections 1, 2, 8), then adds its dY to the other tensor (16) once the other site's section 2 is done.
- * Not available (AVMOE_ERR_UNSUPPORTED) for sites with latent self attention (AVS v2), whose last section writes dX too.        */
+ * Not available (AVMOE_ERR_UNSUPPORTED) for sites with latent self attention (AVS v2), whose last section writes dX too.
+ * ABI 10: section 2 in two steps (plain sites: no N x N / frame / latent self attention) -- 32 = the GEMMs against X without the dX
+ * product (touches neither dX nor dY), 64 = the dX product alone (after 1; independent of 32 and 8).                              */
 int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const void* Y, const avmoe_moe_ptrs* params,
                             const void* dOut, const float* lb_grad, void* saved, void* scratch,
                             void* dX, void* dY, const avmoe_moe_ptrs* grads, int32_t parts, void* stream);
+
+/* ABI 10 -- the gradient of a token tensor T that is X of site A and Y of site B (the two adapter sites of one backbone layer:
+ * the audio tokens are X of the audio site and Y of the visual site, net_trans_v3.py:695-698), written ONCE:
+ *     dT = dX_A + dY_B
+ * with site B's dY product ([Bm ; wbar]^T dV + dR^T Q) as two more contraction segments of site A's dX pass, instead of one kernel that
+ * overwrites dT and a second one that reads it back and adds (1 GB of HBM traffic less at BASELINE config 2's audio tokens).
+ * Call after sections 1 + 32 + 8 of BOTH sites (their `saved` / `scratch` as those calls left them; B's workspaces are only read), in
+ * place of section 64 of A and section 16 of B; the stream must be ordered behind both sites' section 8.  dT is overwritten.
+ * Returns 0 = launched, 1 = these shapes are not served (nothing launched: run section 64 of A, then section 16 of B with
+ * accumulate_dy), < 0 = error.  dT == NULL: nothing is launched, the return value only says whether the shapes are served. */
+int avmoe_moe_backward_dx_dy(const avmoe_moe_desc* desc_a, const void* X_a, void* saved_a, void* scratch_a,
+                             const avmoe_moe_desc* desc_b, void* saved_b, void* scratch_b, void* dT, void* stream);
 
 /* Sub-op (tests / partial adoption): the router alone -- Sequential(Linear(2C,128), ReLU, Linear(128,32), ReLU,
  * Linear(32,E)) + optional logit noise + softmax + first-max argmax  (net_trans_v3.py:460-466,477-479).
