@@ -51,18 +51,46 @@ struct DX3Args {
   int N, tps, ntiles, K2, KB, KQ, ncr; // tokens per frame, 32-token tiles per frame (the last one ragged), tiles in all, rows of T[s] / [Bm ; wbar] / Q, 16-byte chunks of a dRT row
 };
 
-constexpr int BM = 32, NWV = 4, NTHR = 64 * NWV, NCT = 24 / NWV, NBUF = 3;      // four waves, one per SIMD: 6 channel tiles each (the 72 stationary fragments need the whole register file of a SIMD lane: 512 registers per wave)
-constexpr int CHX = 49, CHZ = 17, CHL = 10, CHR = 9, CHB = 5;                       // 16-byte chunks per LDS row (the last one a pad)
+#ifndef DX3_DISSECT
+#define DX3_DISSECT 0      // development builds (timing only): bit 0 = no matrix phase, bit 1 = stores to the dump word
+#endif
+// Block shape, measured on MI355X (cfg-2 audio tokens, 327 680 x 768, every launch alone on the GPU; the two kernels it replaces: 270 + 241 us):
+//   4 waves (one per SIMD: 512 registers each, the 72 stationary fragments fit), 32-token tiles x 3 buffers   344 - 352 us   <- built
+//   4 waves, 16-token tiles x 5 (x 4) buffers                                                                 417 us (per-tile overhead: waits, barrier, addresses)
+//   8 waves (256 registers: the frame-change gathers spill, the tile loop does not), 32 x 3 / 16 x 5           362 / 395 us
+// Timing-only builds of the first (DX3_DISSECT): the tile stream alone 159 us (5.1 TB/s), + the stores 270 us (4.85 TB/s over the
+// 1.31 GB moved: the memory-bound floor), + the matrix phase instead of the stores 258 us; everything 349 us -- the 77 us of matrix-pipe
+// time (193 GFLOP) are not hidden behind the memory traffic in this one-role-per-wave loop.
+#ifndef DX3_NWV
+#define DX3_NWV 4
+#endif
+#ifndef DX3_BM
+#define DX3_BM 32
+#define DX3_NBUF 3
+#endif
+constexpr int BM = DX3_BM, NSL = BM / 16, NWV = DX3_NWV, NTHR = 64 * NWV, NCT = 24 / NWV, NBUF = DX3_NBUF;      // four waves, one per SIMD: 6 channel tiles each (the 72 stationary fragments need the whole register file of a SIMD lane: 512 registers per wave)
+constexpr int CHX = 49, CHZ = 17, CHL = 10, CHR = 9, CHB = BM / 8 + 1;              // 16-byte chunks per LDS row (the last one a pad)
 constexpr int RBX = 16 * CHX, RBZ = 16 * CHZ, RBL = 16 * CHL, RBR = 16 * CHR, RBB = 16 * CHB;
-constexpr int PX = 25, PZ = 9, PL = 5, PR = 5, PB = 8;                              // 1 KB pieces per sub-tile (32 x 49, 32 x 17, 32 x 10, 32 x 9, 96 x 5 chunks, rounded up)
+constexpr int PX = (BM * CHX + 63) / 64, PZ = (BM * CHZ + 63) / 64, PL = (BM * CHL + 63) / 64, PR = (BM * CHR + 63) / 64, PB = (96 * CHB + 63) / 64;      // 1 KB pieces per sub-tile
 constexpr int OFFZ = PX * 1024, OFFL = OFFZ + PZ * 1024, OFFR = OFFL + PL * 1024, OFFB = OFFR + PR * 1024, OFFS = OFFB + PB * 1024, BUF = OFFS + 256;
 constexpr int DX3_LDS = NBUF * BUF;
-static_assert(DX3_LDS <= 160 * 1024, "three buffers in one CU's LDS");
+static_assert(DX3_LDS <= 160 * 1024, "the buffers fit one CU's LDS");
 
 __device__ __forceinline__ unsigned int f2bf(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bflo(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bfhi(unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the immediate has to be a constant
+__device__ __forceinline__ void wait_vm_n(int n) {
+  switch (n) {
+#define W1(k) case k: wait_vm<k>(); break;
+#define W8(k) W1(k) W1(k + 1) W1(k + 2) W1(k + 3) W1(k + 4) W1(k + 5) W1(k + 6) W1(k + 7)
+    W8(0) W8(8) W8(16) W8(24) W8(32) W8(40) W8(48) W1(56) W1(57) W1(58) W1(59) W1(60) W1(61) W1(62)
+#undef W8
+#undef W1
+    default: wait_vm<63>(); break;
+  }
+}
 template <int OFF>
 __device__ __forceinline__ void tr_issue(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory"); }
 
@@ -98,8 +126,8 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
       for (int ks = 0; ks < 2; ++ks) bq[ct][ks] = frag_mn(Qg, p.ldq, c0 + 16 * ct + r, 32 * ks + 8 * q, p.KQ);
     }
   }
-  const bool extra = wave == 0;                            // (PX + PZ + PL + PR + PB) / NWV direct loads per tile and wave, one more (the row scales) for wave 0
-  constexpr int NLO = (PX + PZ + PL + PR + PB) / NWV, NS = 2 * NCT;      // loads / stores per tile and wave
+  constexpr int NPC = PX + PZ + PL + PR + PB, NS = NSL * NCT;            // pieces per tile ; stores per tile and wave
+  const int nl = (NPC - 1 - wave) / NWV + 1 + (wave == NWV - 1 ? 1 : 0);       // direct loads per tile of this wave: pieces wave + NWV i, + the row scales for the last wave
 
   // One buffer image = [X 25 | dZx 9 | dL2 5 | dRT 5 | [Bm ; wbar] 8] pieces of 1 KB + the tile's 32 row scales; piece P = wave + 8 i.
   auto gload = [&](int buf, int tile) {
@@ -135,27 +163,22 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
       else if (P < B4) __builtin_amdgcn_global_load_lds((gptr_t)src_r(P - B3), (lptr_t)d, 16, 0, 0);
       else if (P < B5) __builtin_amdgcn_global_load_lds((gptr_t)src_b(P - B4), (lptr_t)d, 16, 0, 0);
     }
-    static_assert(B5 % NWV == 0, "every wave issues the same number of pieces");
-    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(ln, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);       // the tile's row scales
+    if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(ln, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);       // the tile's row scales
   };
 
   // contiguous tile ranges (few frame changes per block)
   int tile = (int)((long)p.ntiles * blockIdx.x / gridDim.x);
   const int t_end = (int)((long)p.ntiles * (blockIdx.x + 1) / gridDim.x);
   if (tile >= t_end) return;
-  gload(0, tile);
-  if (tile + 1 < t_end) gload(1, tile + 1);
+#pragma unroll
+  for (int j = 0; j < NBUF - 1; ++j)
+    if (tile + j < t_end) gload(j, tile + j);
   int cur_s = -1;
   for (int it = 0; tile < t_end; ++it, ++tile) {
-    // In-order counter, issue order per iteration i: [loads of tile i + 2] [the 2 NCT stores of tile i].  Tile `tile` has landed once everything
-    // but what was issued after its loads is complete: the loads of tile + 1 and the stores of the two previous iterations.
-    if (tile + 1 < t_end) {
-      if (it == 0) { if (extra) wait_vm<NLO + 1>(); else wait_vm<NLO>(); }
-      else if (it == 1) { if (extra) wait_vm<NLO + 1 + NS>(); else wait_vm<NLO + NS>(); }
-      else { if (extra) wait_vm<NLO + 1 + 2 * NS>(); else wait_vm<NLO + 2 * NS>(); }
-    } else {
-      wait_vm<0>();
-    }
+    // In-order counter, issue order per iteration i: [loads of tile i + NBUF - 1] [the NS stores of tile i].  Tile `tile` has landed once
+    // everything but what was issued after its loads is complete: the loads of the (up to NBUF - 2) tiles requested after it and the stores of
+    // the last (up to NBUF - 1) iterations.
+    wait_vm_n(min(NBUF - 2, t_end - 1 - tile) * nl + min(it, NBUF - 1) * NS);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const char* sX = smem + (it % NBUF) * BUF;
@@ -186,19 +209,19 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) asm volatile("" : "+v"(bv[ct][ks]));
     }
-    // the request for tile + 2 (its buffer was read in the previous iteration: every wave has passed this iteration's barrier since) before
-    // the arithmetic: two tiles are in flight while this one is multiplied
-    if (tile + 2 < t_end) gload((it + 2) % NBUF, tile + 2);
-    const int fj = tile - s * p.tps, valid = p.N - fj * BM;      // rows of this tile inside the frame (>= 32: all of them)
+    // the request for tile + NBUF - 1 (its buffer was read in the previous iteration: every wave has passed this iteration's barrier since)
+    // before the arithmetic: NBUF - 1 tiles are in flight while this one is multiplied
+    if (tile + NBUF - 1 < t_end) gload((it + NBUF - 1) % NBUF, tile + NBUF - 1);
+    const int fj = tile - s * p.tps, valid = p.N - fj * BM;      // rows of this tile inside the frame (>= BM: all of them)
     const long m0 = (long)s * p.N + (long)fj * BM;
     // one 16-token slab at a time (three independent accumulator chains; two slabs at once do not fit beside the 36 stationary fragments)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NSL; ++h) {
       f32x4 acc[NCT];
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
       // [Bm ; wbar]^T dV_B: the tile is [l][token] -- read transposed (lane (r, q): token r of the slab, rows 8 q .. 8 q + 7 of the K step)
-      {
+      if (!(DX3_DISSECT & 1)) {
         const unsigned lb = (unsigned)(size_t)(lptr_t)(sX + OFFB) + (8 * q + (r >> 2)) * RBB + (4 * (r & 3)) * 2 + 32 * h;
         u32x2 f[3][2];                                     // [K step][half]
         tr_issue<0 * 32 * RBB>(f[0][0], lb); tr_issue<0 * 32 * RBB + 4 * RBB>(f[0][1], lb);
@@ -214,13 +237,13 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
         }
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {                      // dZx Wt
+      for (int ks = 0; ks < ((DX3_DISSECT & 1) ? 0 : 4); ++ks) {                      // dZx Wt
         const bf16x8 af = *(const bf16x8*)(sZ + (16 * h + r) * RBZ + ks * 64 + q * 16);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ct][ks], af, acc[ct], 0, 0, 0);
       }
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {                      // [dL2 | dsx | 1] [T ; 1 ; dm1/N]  (the lane's columns 32 ks + 8 q .. beyond K2 are not data)
+      for (int ks = 0; ks < ((DX3_DISSECT & 1) ? 0 : 3); ++ks) {                      // [dL2 | dsx | 1] [T ; 1 ; dm1/N]  (the lane's columns 32 ks + 8 q .. beyond K2 are not data)
         u32x4 v = *(const u32x4*)(sL + (16 * h + r) * RBL + ks * 64 + q * 16);
         const int nvk = p.K2 - (32 * ks + 8 * q);
 #pragma unroll
@@ -230,14 +253,14 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bt[ct][ks], af, acc[ct], 0, 0, 0);
       }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {                      // dR_B^T Q_B  (the fragments of Q are zero beyond its KQ rows)
+      for (int ks = 0; ks < ((DX3_DISSECT & 1) ? 0 : 2); ++ks) {                      // dR_B^T Q_B  (the fragments of Q are zero beyond its KQ rows)
         const bf16x8 af = *(const bf16x8*)(sR + (16 * h + r) * RBR + ks * 64 + q * 16);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ct][ks], af, acc[ct], 0, 0, 0);
       }
       {                                                    // lane (r, q): token r of the slab, channels c0 + 16 ct + 4 q .. + 3 ; three stores per slab, always
         const int row = 16 * h + r;
-        const bool ok = row < valid;
+        const bool ok = row < valid && !(DX3_DISSECT & 2);
         const float rs = sS[row];
         char* out = ok ? p.dX + ((m0 + row) * p.ldc + (long)g * 384 + c0 + 4 * q) * 2 : p.dump;
         const int step = ok ? 32 : 0;
