@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--f32", action="store_true")
     ap.add_argument("--pair", default="concurrent")
     ap.add_argument("--clips", type=int, default=2)
+    ap.add_argument("--eager", action="store_true", help="adds the error of the reference formulation itself under torch.autocast(bfloat16) (the oracle run eagerly on the GPU) and the ratio")
+    ap.add_argument("--exact-weights", action="store_true", help="experiment: every parameter rounded to a bf16-representable value first (what is left is NOT the rounding of the raw weights)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     c = dict(bench.CONFIGS[a.config], name=a.config)
@@ -39,6 +41,9 @@ def main():
         ca, cv = bench._oracle_cfgs(c, (Ca, Na, Cv, Nv))
         Pa, Ba = O.init_params(ca, seed=2 * i)
         Pv, Bv = O.init_params(cv, seed=2 * i + 1)
+        if a.exact_weights:
+            Pa = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in Pa.items()}
+            Pv = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in Pv.items()}
         fa = 0.3 * torch.randn(S, Na, Ca, generator=g)
         fv = 0.3 * torch.randn(S, Nv, Cv, generator=g)
         Ga, Gv = torch.randn(fa.shape, generator=g), torch.randn(fv.shape, generator=g)
@@ -79,14 +84,30 @@ def main():
         items += [("v." + k, dict(mv.named_parameters())[k].grad.float().cpu(), v) for k, v in rv[1].items() if k not in ("X", "Y")]
         items += [("tok.f_a", xa_.grad.float().cpu(), ra[1]["X"] + rv[1]["Y"]), ("tok.f_v", xv_.grad.float().cpu(), rv[1]["X"] + ra[1]["Y"])]
         nmax = max(float(v.norm()) for _k, _g, v in items)
+        eager = {}
+        if a.eager and bf16:          # the reference formulation itself in bf16: the oracle eagerly on the GPU under autocast, same inputs, own mask
+            def run_eager(P, B, X, Y, cfg, G):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    return O.moe_forward_backward({k: v.to(dev) for k, v in P.items()}, {k: v.to(dev) for k, v in B.items()}, X.to(dev), Y.to(dev), cfg, G.to(dev),
+                                                  training=True, lb_weight=lbw)[1]
+            ea, ev = run_eager(Pa, Ba, fa, fv, ca, Ga), run_eager(Pv, Bv, fv, fa, cv, Gv)
+            eager = {"a." + k: v.float().cpu() for k, v in ea.items() if k not in ("X", "Y")}
+            eager.update({"v." + k: v.float().cpu() for k, v in ev.items() if k not in ("X", "Y")})
+            eager["tok.f_a"] = (ea["X"] + ev["Y"]).float().cpu(); eager["tok.f_v"] = (ev["X"] + ea["Y"]).float().cpu()
         rows = []
         for k, gg, v in items:
-            e = float((gg - v).norm()) / max(float(v.norm()), 1e-3 * nmax)
-            rows.append((e, k, float(v.norm()) / nmax, float((gg - v).abs().max() / v.abs().max().clamp_min(1e-30)), v.numel()))
+            den = max(float(v.norm()), 1e-3 * nmax)
+            e = float((gg - v).norm()) / den
+            ee = float((eager[k] - v).norm()) / den if k in eager else float("nan")
+            rows.append((e, k, float(v.norm()) / nmax, float((gg - v).abs().max() / v.abs().max().clamp_min(1e-30)), v.numel(), ee))
         rows.sort(reverse=True)
-        print(f"== {a.config} shape {i}: C_a={Ca} N_a={Na} C_v={Cv} N_v={Nv}  {'bf16' if bf16 else 'f32'}  out_rel {eo:.3e}", flush=True)
-        for e, k, rn, em, n in rows[:a.top]:
-            print(f"   {k:52s} err {e:.3e}   norm/max {rn:.2e}   maxabs {em:.2e}   n={n}", flush=True)
+        print(f"== {a.config} shape {i}: C_a={Ca} N_a={Na} C_v={Cv} N_v={Nv}  {'bf16' if bf16 else 'f32'}{'  exact-weights' if a.exact_weights else ''}  out_rel {eo:.3e}", flush=True)
+        for e, k, rn, em, n, ee in rows[:a.top]:
+            extra = f"   eager {ee:.3e}  hip/eager {e / ee:5.2f}" if ee == ee and ee > 0 else ""
+            print(f"   {k:52s} err {e:.3e}   norm/max {rn:.2e}   maxabs {em:.2e}   n={n}{extra}", flush=True)
+        if eager:
+            above = [(k, e, ee) for e, k, _rn, _em, _n, ee in rows if e > 0.05 and e > ee]
+            print(f"   -- tensors above 5 % AND above the eager-autocast error: {len(above)} of {len(rows)}: " + ", ".join(f"{k} {e:.3f} ({ee:.3f})" for k, e, ee in above), flush=True)
 
 
 if __name__ == "__main__":
