@@ -209,6 +209,14 @@ class _SiteBackward:
             sink.done()
             return (None,) * len(self.names)
         if sink is not None:
+            # a sink is attached but this backward did not go through it (a parameter frozen after the reducer was built, a layout
+            # mismatch): autograd ADDS the tensors returned below into param.grad -- views of the sink's slice.  After a lazy zero_grad
+            # the slice still holds the previous step's values: zero it first, and take it out of the `stale` state so that the
+            # reducer's finish() does not wipe what autograd is about to add
+            if sink.stale:
+                sink.flat.zero_()
+            sink.stale = False
+            sink.fresh = False
             sink.calls -= 1
         return tuple(self.grads[k] for k in self.names)
 

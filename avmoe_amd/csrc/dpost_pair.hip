@@ -251,12 +251,8 @@ int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long s
     return 1;
   // small sites: the two kernels (the 128-slab reduction alone costs 11 us; measured at 20 480 tokens: 44 us against 37); AVMOE_DPAIR_FORCE: test hook
   if (ntok < 32768 && !(ntok >= 4096 && getenv("AVMOE_DPAIR_FORCE"))) return 1;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_last_error("dpost_pair: device query"); return ERR_LAUNCH; }
-    cus = prop.multiProcessorCount;
-  }
+  const int cus = cu_count();                             // (cached per device: common.cpp)
+  if (cus <= 0) { set_last_error("dpost_pair: device query"); return ERR_LAUNCH; }
   const int ntiles = cdiv(ntok, BM);
   const size_t per = (size_t)G * 384 * KP;
   int gx = std::max(1, cus / G);

@@ -180,12 +180,8 @@ int k_dx_stream2(const void* X, long ldx, const void* dZx, long ldz, const void*
   if (Cg != 384 || K1 != 128 || K2 < 1 || K2 > 72 || ldl < 72 || N < BM || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || ldc % 4 || !rs ||
       ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dX % 8) || ((uintptr_t)rs % 4) || (long)S * N < 2048)
     return 1;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_last_error("dx_stream2: device query"); return ERR_LAUNCH; }
-    cus = prop.multiProcessorCount;
-  }
+  const int cus = cu_count();                             // (cached per device: common.cpp)
+  if (cus <= 0) { set_last_error("dx_stream2: device query"); return ERR_LAUNCH; }
   DX2Args p;
   p.X = (const char*)X; p.ldx = ldx; p.dZx = (const char*)dZx; p.ldz = ldz; p.dL2 = (const char*)dL2; p.ldl = ldl; p.rs = rs;
   p.Wt = (const unsigned short*)Wt; p.ldw = ldw; p.sWg = sWg; p.Text = (const unsigned short*)Text; p.ldt = ldt; p.sT1 = sT1;

@@ -56,6 +56,8 @@ struct GemmArgs {
   // 2^-24 |x|), the six plane products of order <= 2, fp32 accumulation: 5.8e-9 relative per product (the fp32 rounding of the sum itself is
   // 2 - 4e-7) at 6 x 16 instead of 8 x 32 matrix-pipe cycles per 16 x 16 x 32 block.  The site's BACKWARD sets it; the forward keeps
   // v_mfma_f32_16x16x4_f32 (same values to the last bit as rounds 1 - 3: which ReLU units sit on which side of zero does not move).
+  // Non-finite operands: an Inf splits into (Inf, NaN, NaN) -- the residual planes are Inf - Inf -- so a product that exact fp32 arithmetic
+  // would return as Inf comes out NaN; finite inputs only (as everywhere on this path: workspaces are NaN-poisoned in the tests).
   int split3 = 0;
   int tile = 0;                         // 0 = auto, 64 or 128 = force block tile
   // optional second K segment, accumulated into the same tile before the epilogue:

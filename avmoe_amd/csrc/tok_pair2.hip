@@ -212,14 +212,10 @@ int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* 
   if (Cg != 384 || M1 != 128 || KL < 1 || KL > 64 || ldl < 72 || N % BM || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || !slabs ||
       ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dWt % 16) || ((uintptr_t)dT % 16) || (G * 384) % 4)
     return 1;
-  const bool force = getenv("AVMOE_TOKPAIR2_FORCE") != nullptr;             // test hook (read by the product build too): small sites as well -- every frame then spans two blocks
+  const bool force = getenv("AVMOE_TOKPAIR2_FORCE") != nullptr;             // test hook (read by the product build too, per call: tests / bench.py's parity leg switch it inside one process): small sites as well -- every frame then spans two blocks
   if (!force && (long)S * N < 65536) return 1;                              // small sites: the tiled form fills the chip better
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_last_error("tok_pair2: device query"); return ERR_LAUNCH; }
-    cus = prop.multiProcessorCount;
-  }
+  const int cus = cu_count();                             // (cached per device: common.cpp)
+  if (cus <= 0) { set_last_error("tok_pair2: device query"); return ERR_LAUNCH; }
   const int tpf = N / BM;
   const int ut = (tpf % 2 == 0) ? tpf / 2 : tpf;            // tiles per unit: half a frame (a whole one when its tile count is odd)
   const long U = (long)S * (tpf / ut);

@@ -113,6 +113,41 @@ def test_gradient_sink_matches_autograd_accumulation():
     assert all(float(q.grad.abs().max()) == 0.0 for q in fused.parameters())
 
 
+def test_lazy_zero_grad_with_a_site_that_falls_off_its_sink():
+    """a parameter frozen AFTER the reducer was built makes the site's backward take the autograd path although a sink is
+    attached; after zero_grad(lazy=True) its slice still holds the previous step's gradients -- they must not be added to, and
+    finish() must not wipe the new ones."""
+    import copy
+    from avmoe_amd.dp import AdapterGradReducer
+    dev = torch.device("cuda:0")
+    cfg = O.AdapterConfig(Cx=64, Nx=50, Cy=48, Ny=20, reduction=4, groups=2, K=6)
+    ref = build_module("ave", cfg).to(dev).train()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k.endswith(("gate", "gate_av")):
+                p.fill_(0.4)
+    fused = copy.deepcopy(ref)
+    red = AdapterGradReducer(list(fused.parameters()), sites=[fused])
+    g = torch.Generator().manual_seed(6)
+    def batch():
+        return (torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev), torch.randn(4, cfg.Cy, cfg.Ny, 1, generator=g).to(dev),
+                torch.randn(4, cfg.Cx, cfg.Nx, 1, generator=g).to(dev))
+    X, Y, G = batch()
+    red.begin(sync=True); fused(X, Y)[0].backward(G); red.finish()          # step 1 through the sink: the slice holds its gradients
+    red.zero_grad(lazy=True)
+    frozen = "fc.bias"
+    dict(fused.named_parameters())[frozen].requires_grad_(False)            # ... now the site falls off the sink
+    dict(ref.named_parameters())[frozen].requires_grad_(False)
+    X, Y, G = batch()
+    ref(X, Y)[0].backward(G)
+    red.begin(sync=True); fused(X, Y)[0].backward(G); red.finish()
+    for (k, p), (_, q) in zip(ref.named_parameters(), fused.named_parameters()):
+        if k == frozen:
+            continue
+        scale = float(p.grad.abs().max()) + 1e-6
+        assert float((p.grad - q.grad).abs().max()) <= 1e-5 * scale, k
+
+
 @pytest.mark.parametrize("concurrent", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_adapter_pair_equals_two_sites(dtype, concurrent):
