@@ -94,8 +94,9 @@ typedef struct avmoe_moe_desc {
    * its own upper lanes: v_mfma_f32_16x16x4_f32 sums (lanes 48 - 51) and per-block column sums.  scripts/mfma_probe.hip shows it with two
    * stand-alone kernels; every mode and mitigation of it, run on an MI355X, is kept in profiles/r05_mfma_probe.txt (+ _part2): 0
    * mismatches alone or beside LDS-only / sparse-MFMA aggressors, 10^5 - 10^6 per run beside a dense-MFMA aggressor whatever the
-   * victim's LDS read width (ds_read_b128 or two ds_read_b64) and whatever wait states follow its MFMAs, and 0 again -- at the same
-   * time on other CUs -- once the victim's blocks take a whole CU's LDS (no other block fits beside them).
+   * victim's LDS read width (ds_read_b128 or two ds_read_b64) and whatever wait states follow its MFMAs, and 0 again once the
+   * victim's blocks take a whole CU's LDS each (no other block fits beside them; requests with which 2 or 4 of them fill a CU do not
+   * suffice: a block can land beside foreign blocks that are already there).
    * What the flag does: the bottleneck-space kernels of the generalised family (csrc/tile_gen.inc: every site shape of the reference's
    * models except the tuned one) and of the any-shape fallback (csrc/tile_kernels.hip) launch with 150 KB of dynamic LDS, one block per
    * CU; the backward does not fork its dBpost product beside them.  NOT covered: the tuned instance csrc/tile_fast.hip (bottleneck 64
