@@ -84,9 +84,10 @@ def declare(L):
     L.avmoe_moe_backward_part.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.POINTER(MoePtrs), C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoePtrs),
                                           C.c_int32, C.c_void_p]
-    L.avmoe_moe_backward_dx_dy.restype = C.c_int
-    L.avmoe_moe_backward_dx_dy.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoeDesc), C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_void_p]
+    if hasattr(L, "avmoe_moe_backward_dx_dy"):       # (ABI 10; a development A/B may load an older library through AVMOE_LIB, with AVMOE_NO_FUSED_DX=1)
+        L.avmoe_moe_backward_dx_dy.restype = C.c_int
+        L.avmoe_moe_backward_dx_dy.argtypes = [C.POINTER(MoeDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MoeDesc), C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
     L.avmoe_moe_buffer_info.restype = C.c_int
     L.avmoe_moe_buffer_info.argtypes = [C.POINTER(MoeDesc), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]

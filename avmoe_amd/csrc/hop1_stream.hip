@@ -374,12 +374,17 @@ __global__ void __launch_bounds__(256) kk_hop1_sum(const float* __restrict__ sla
   }
 }
 
+// Sites of fewer than 32 768 tokens of Y keep the tiled engine: a persistent block per CU then has two or three tiles (or a single frame)
+// to amortise its prologue over and the engine's small tiles fill the chip better (measured at 20 480 tokens: yk 20.7 us against 12 - 15,
+// per-frame yt 32.9 against ~18).  AVMOE_HOP1S_FORCE (test hook, read per call like AVMOE_TOKPAIR2_FORCE): small sites as well.
+bool hop1s_small(long ntok) { return ntok < 32768 && getenv("AVMOE_HOP1S_FORCE") == nullptr; }
+
 }  // namespace
 
 // 0 = launched, 1 = shape not served (the caller runs the tiled engine), < 0 error
 int k_hop1_yk(const void* Y, long ldy, int S, int M, int Cy, const void* A, long lda, long sA1, int rows, void* C, long ldc, long sC1, int c_bf16, void* dump, hipStream_t st) {
   if (Cy != 768 || rows < 1 || rows > 80 || M < 4 || M % 4 || S < 1 || ldy % 8 || lda % 8 || sA1 % 8 || ldc % 4 || sC1 % 4 || !dump ||
-      ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 16) || ((uintptr_t)dump % 16))
+      ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 16) || ((uintptr_t)dump % 16) || hop1s_small((long)S * M))
     return 1;
   const int cus = cu_count();
   if (cus <= 0) { set_last_error("hop1_yk: device query"); return ERR_LAUNCH; }
@@ -418,7 +423,7 @@ int launch_yt(const YTArgs& p, int gx, int gy, hipStream_t st) {
 // per frame: C[s] (rows x Cy) = A[s] (rows x M, K-major rows of lda elements) Y[s]
 int k_hop1_yt_frames(const void* Y, long ldy, int S, int M, int Cy, const void* A, long lda, long sA1, int rows, void* C, long ldc, long sC1, int c_bf16, hipStream_t st) {
   if (Cy % 256 || rows < 17 || rows > 80 || M < 1 || S < 1 || ldy % 8 || lda % 8 || sA1 % 8 || lda < M ||
-      ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 4))
+      ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 4) || hop1s_small((long)S * M))
     return 1;
   const int cus = cu_count();
   if (cus <= 0) { set_last_error("hop1_yt: device query"); return ERR_LAUNCH; }
@@ -442,7 +447,7 @@ int k_hop1_yt_frames(const void* Y, long ldy, int S, int M, int Cy, const void* 
 // over all tokens: C (rows x Cy) = A^T Y with A = [token][lda] (columns 0 .. rows - 1), C bf16 or fp32 ; slabs: fp32 workspace
 int k_hop1_yt_sum(const void* Y, long ldy, long ntok, int Cy, const void* A, long lda, int rows, void* C, long ldc, int c_bf16, float* slabs, size_t slab_cap, hipStream_t st) {
   if (Cy % 384 || rows < 17 || rows > 64 || lda < 64 || ntok < YT_BM || ldy % 8 || lda % 8 || ldc % 4 || !slabs ||
-      ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 16) || ((uintptr_t)slabs % 16))
+      ((uintptr_t)Y % 16) || ((uintptr_t)A % 16) || ((uintptr_t)C % 16) || ((uintptr_t)slabs % 16) || hop1s_small(ntok))
     return 1;
   const int cus = cu_count();
   if (cus <= 0) { set_last_error("hop1_yt: device query"); return ERR_LAUNCH; }

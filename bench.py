@@ -205,7 +205,7 @@ def cpu_baseline(c, budget_s=15.0, min_timed=3):
 def parity_check(c, material, device, pair_mode="concurrent"):
     """parity_check_ with the library's size thresholds lifted (test hooks AVMOE_TOKPAIR2_FORCE / AVMOE_DPAIR_FORCE, read per call): the
     B = 2 shapes then run through the SAME streaming kernels (dpost_pair, tok_pair2) the timed region's full batch takes."""
-    hooks = ("AVMOE_TOKPAIR2_FORCE", "AVMOE_DPAIR_FORCE")
+    hooks = ("AVMOE_TOKPAIR2_FORCE", "AVMOE_DPAIR_FORCE", "AVMOE_HOP1S_FORCE")
     old = {k: os.environ.get(k) for k in hooks}
     for k in hooks:
         os.environ[k] = "1"
@@ -217,7 +217,7 @@ def parity_check(c, material, device, pair_mode="concurrent"):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    res["kernels"] = "the timed region's: size thresholds of dpost_pair / tok_pair2 lifted for the B = 2 shapes (AVMOE_*_FORCE)"
+    res["kernels"] = "the timed region's: size thresholds of dpost_pair / tok_pair2 / hop1_stream lifted for the B = 2 shapes (AVMOE_*_FORCE)"
     return res
 
 

@@ -70,6 +70,7 @@ def test_cfg2_shape_bf16_within_the_bf16_budget_of_the_reference_formulation(sit
     40 half-frame blocks per group, every frame's dT then comes in two parts (the leading-half-frame path of kk_tp2_finish)."""
     from tests.moe_gpu_util import MoeRun
     if tokpair2:
+        monkeypatch.setenv("AVMOE_HOP1S_FORCE", "1")          # ... the hop-1 products against Y as streaming kernels (csrc/hop1_stream.hip: from 32 768 tokens of Y on)
         monkeypatch.setenv("AVMOE_TOKPAIR2_FORCE", "1")
         monkeypatch.setenv("AVMOE_DPAIR_FORCE", "1")          # ... and dApost + dBpost from one pass over dOut (csrc/dpost_pair.hip: from 32 768 tokens on)
     cfg = _cfg(site)
