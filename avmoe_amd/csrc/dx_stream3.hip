@@ -178,7 +178,14 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
     // In-order counter, issue order per iteration i: [loads of tile i + NBUF - 1] [the NS stores of tile i].  Tile `tile` has landed once
     // everything but what was issued after its loads is complete: the loads of the (up to NBUF - 2) tiles requested after it and the stores of
     // the last (up to NBUF - 1) iterations.
+#ifndef DX3_ISSUE
+#define DX3_ISSUE 0        // development: 1 = the next request between the two slabs of a tile instead of in front of them (NBUF 3, two slabs)
+#endif
+#if DX3_ISSUE == 1
+    wait_vm_n(min(1, t_end - 1 - tile) * nl + (it == 0 ? 0 : (it == 1 ? NS : NS + NS / 2)));
+#else
     wait_vm_n(min(NBUF - 2, t_end - 1 - tile) * nl + min(it, NBUF - 1) * NS);
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const char* sX = smem + (it % NBUF) * BUF;
@@ -211,12 +218,17 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
     }
     // the request for tile + NBUF - 1 (its buffer was read in the previous iteration: every wave has passed this iteration's barrier since)
     // before the arithmetic: NBUF - 1 tiles are in flight while this one is multiplied
+#if DX3_ISSUE != 1
     if (tile + NBUF - 1 < t_end) gload((it + NBUF - 1) % NBUF, tile + NBUF - 1);
+#endif
     const int fj = tile - s * p.tps, valid = p.N - fj * BM;      // rows of this tile inside the frame (>= BM: all of them)
     const long m0 = (long)s * p.N + (long)fj * BM;
     // one 16-token slab at a time (three independent accumulator chains; two slabs at once do not fit beside the 36 stationary fragments)
 #pragma unroll
     for (int h = 0; h < NSL; ++h) {
+#if DX3_ISSUE == 1
+      if (h == 1 && tile + NBUF - 1 < t_end) gload((it + NBUF - 1) % NBUF, tile + NBUF - 1);
+#endif
       f32x4 acc[NCT];
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
