@@ -121,6 +121,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+HOST_LIB = os.path.join(LIBDIR, "libavmoe_host.so")
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """g++ the CPU implementation of the ABI (csrc/host_*.cpp, include/avmoe_host.h) into libavmoe_host.so: TEST / CI infrastructure
+    (tests/test_host_golden.py), never loaded by the product path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.startswith("host_") and f.endswith(".cpp")]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = srcs + [os.path.join(inc, "avmoe.h"), os.path.join(inc, "avmoe_host.h")]
+    if not force and os.path.isfile(HOST_LIB) and all(os.path.getmtime(HOST_LIB) >= os.path.getmtime(p) for p in deps):
+        return HOST_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter"] + srcs + ["-o", HOST_LIB]
+    if verbose:
+        print("[avmoe_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    print(build_host(force="--force" in sys.argv))
