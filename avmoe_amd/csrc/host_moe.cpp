@@ -10,8 +10,10 @@
 //   cross-modal expert         ExpertAdapter.forward       net_trans_v3.py:377-403, 430-435
 //   unimodal expert                                        net_trans_v3.py:405-422, 430-435
 //   AVS logit noise, probs, load-balancing loss            AVS/avs_scripts/avs_s4/model/PVT_AVSModel_v2.py:294-296, 312-318
-// Served: variants AVE / AVQA / AVS without self attention, train and eval BatchNorm, every flag of the descriptor.  Not served
-// (AVMOE_ERR_UNSUPPORTED): the AVVP N x N block and the AVS self-attention versions (the HIP library and the Python oracle have them).
+//   AVVP unimodal N x N block                              AVVP/nets/mgn.py:132-139
+//   AVS "v2" latent self attention                         PVT_AVSModel_v2.py:215-227
+// Served: every variant but AVS self_attention_version "v1" (MultiheadAttention across the frames: AVMOE_ERR_UNSUPPORTED here; the HIP
+// library and the Python oracle have it), train and eval BatchNorm, every flag of the descriptor.
 #include "../../include/avmoe_host.h"
 #include <cmath>
 #include <cstdarg>
@@ -130,7 +132,10 @@ void gconv_bwd(const float* x, const float* dy, float* dx, float* dW, long rows,
 }
 
 struct Expert {      // what one expert's forward leaves for its backward (all (S N, .) token-major)
-  bool lat = false;
+  bool lat = false;                 // two-hop latent attention in front (cross-modal experts: over the remapped tokens; AVS v2 unimodal: over x itself)
+  bool self = false;                // ... over x itself
+  bool nxn = false;                 // AVVP unimodal: x' = x + gate_av softmax_rows(x x^T)^T x   (A1 holds the (S, N, N) softmax)
+  bool relu = false;                // cross-modal experts only
   V A1, T, A2, Xr, Xp;              // cross-modal: (S, K, N) ; (S, K, C) ; (S, N, K) ; (S N, C) ; x' = x + gate_av xr
   V U, Z, Zb, O, Ob, Op, pre;       // LN_before(x') ; down ; BN1 (+ ReLU applied into Za) ; up ; BN2 ; LN_post ; = what the gate multiplies
   V Za;
@@ -139,6 +144,7 @@ struct Expert {      // what one expert's forward leaves for its backward (all (
 
 struct Ctx {
   int S, N, C, M, Cy, E, Em, d, g, K;
+  bool avvp, v2;
   bool bn, gate, lnb, lnp, train, lb;
   float bn_eps, ln_eps, mom;
   V Yt, Yf, rin, h1, h2, logit, p;
@@ -148,11 +154,13 @@ struct Ctx {
 int setup(const avmoe_moe_desc* q, Ctx& c) {
   if (!q) return fail(AVMOE_ERR_BAD_ARG, "host: null descriptor");
   if (q->dtype != AVMOE_F32) return fail(AVMOE_ERR_UNSUPPORTED, "host: fp32 activations only");
-  if (q->variant == AVMOE_VARIANT_AVVP || q->self_attn != AVMOE_SELF_ATTN_NONE)
-    return fail(AVMOE_ERR_UNSUPPORTED, "host: the AVVP N x N block / AVS self attention are not built on the host (HIP library, Python oracle)");
+  if (q->self_attn == AVMOE_SELF_ATTN_MHA_V1)
+    return fail(AVMOE_ERR_UNSUPPORTED, "host: self_attention_version v1 (MultiheadAttention across the frames) is not built on the host (HIP library, Python oracle)");
   c.S = q->S; c.N = q->N; c.C = q->C; c.M = q->M; c.Cy = q->Cy; c.Em = q->E_m; c.E = q->E_m + q->E_s; c.d = q->d; c.g = q->groups; c.K = q->K;
   if (c.S <= 0 || c.N <= 0 || c.C <= 0 || c.M <= 0 || c.Cy <= 0 || c.E <= 0 || c.E > AVMOE_MAX_EXPERTS || c.d <= 0 || c.g <= 0 || c.d % c.g || c.C % c.g || (c.Em > 0 && c.K <= 0))
     return fail(AVMOE_ERR_BAD_ARG, "host: bad extents");
+  c.avvp = q->variant == AVMOE_VARIANT_AVVP || q->self_attn == AVMOE_SELF_ATTN_NXN; c.v2 = q->self_attn == AVMOE_SELF_ATTN_LATENT_V2;
+  if (c.v2 && c.K <= 0) return fail(AVMOE_ERR_BAD_ARG, "host: bad extents");
   c.bn = q->use_bn; c.gate = q->use_gate; c.lnb = q->ln_before; c.lnp = q->ln_post; c.train = q->training; c.lb = q->lb_loss;
   c.bn_eps = q->bn_eps; c.ln_eps = q->ln_eps; c.mom = q->bn_momentum;
   return AVMOE_OK;
@@ -205,14 +213,16 @@ int forward(Ctx& c, const float* X, const float* Y, const avmoe_moe_ptrs& P, con
   for (int e = 0; e < E; ++e) {
     Expert& x = c.ex[e];
     const avmoe_expert_ptrs& q = P.e[e];
-    x.lat = e < c.Em;
+    x.relu = e < c.Em;
+    x.lat = e < c.Em || c.v2; x.self = !(e < c.Em); x.nxn = !(e < c.Em) && c.avvp;
     if (!q.down_w || !q.up_w) return fail(AVMOE_ERR_BAD_ARG, "host: expert %d lacks its projections", e);
     const float* xin = X;
     if (x.lat) {
-      if (!q.my_tokens || !q.gate_lat) return fail(AVMOE_ERR_BAD_ARG, "host: cross-modal expert %d lacks my_tokens / gate_av", e);
+      if (!q.my_tokens || !q.gate_lat) return fail(AVMOE_ERR_BAD_ARG, "host: expert %d lacks my_tokens / gate_av (gate_self)", e);
       x.A1.assign((long)S * K * N, 0.f); x.T.assign((long)S * K * C, 0.f); x.A2.assign(NT * K, 0.f); x.Xr.assign(NT * C, 0.f); x.Xp.assign(NT * C, 0.f);
       for (int s = 0; s < S; ++s) {
-        const float* Yf = c.Yf.data() + (long)s * N * C; const float* Xs = X + (long)s * N * C;
+        const float* Xs = X + (long)s * N * C;
+        const float* Yf = x.self ? Xs : c.Yf.data() + (long)s * N * C;                         // the token set the latent tokens summarise
         float* A1 = x.A1.data() + (long)s * K * N; float* T = x.T.data() + (long)s * K * C; float* A2 = x.A2.data() + (long)s * N * K;
         gemm(false, true, K, N, C, 1.f, q.my_tokens, C, Yf, C, 0.f, A1, N);                    // hop 1 (:380-383): latent tokens read the remapped tokens
         softmax_rows(A1, K, N, N);
@@ -223,6 +233,17 @@ int forward(Ctx& c, const float* X, const float* Y, const avmoe_moe_ptrs& P, con
         gemm(false, false, N, C, K, 1.f, A2, K, T, C, 0.f, x.Xr.data() + (long)s * N * C, C);
       }
       for (long i = 0; i < NT * C; ++i) x.Xp[i] = X[i] + q.gate_lat[0] * x.Xr[i];              // (:390)
+      xin = x.Xp.data();
+    } else if (x.nxn) {
+      if (!q.gate_lat) return fail(AVMOE_ERR_BAD_ARG, "host: expert %d lacks gate_av", e);
+      x.A1.assign((long)S * N * N, 0.f); x.Xr.assign(NT * C, 0.f); x.Xp.assign(NT * C, 0.f);
+      for (int s = 0; s < S; ++s) {
+        const float* Xs = X + (long)s * N * C; float* att = x.A1.data() + (long)s * N * N;
+        gemm(false, true, N, N, C, 1.f, Xs, C, Xs, C, 0.f, att, N);                            // mgn.py:134-136
+        softmax_rows(att, N, N, N);
+        gemm(true, false, N, C, N, 1.f, att, N, Xs, C, 0.f, x.Xr.data() + (long)s * N * C, C);  // xr = att^T x (mgn.py:137-139: x_cn @ att)
+      }
+      for (long i = 0; i < NT * C; ++i) x.Xp[i] = X[i] + q.gate_lat[0] * x.Xr[i];
       xin = x.Xp.data();
     }
     const float* u = xin;
@@ -237,7 +258,7 @@ int forward(Ctx& c, const float* X, const float* Y, const avmoe_moe_ptrs& P, con
       x.Zb.assign(NT * c.d, 0.f); bn_fwd(z, x.Zb.data(), NT, c.d, q.bn1_w, q.bn1_b, c.bn_eps, c.train, c.mom, q.bn1_rm, q.bn1_rv, q.bn1_nbt, update, x.bn1); z = x.Zb.data();
     }
     x.Za.assign(z, z + NT * c.d);
-    if (x.lat) for (auto& v : x.Za) v = std::fmax(v, 0.f);                                      // ReLU: cross-modal expert only (:400)
+    if (x.relu) for (auto& v : x.Za) v = std::fmax(v, 0.f);                                     // ReLU: cross-modal expert only (:400)
     x.O.assign(NT * C, 0.f); gconv_fwd(x.Za.data(), x.O.data(), NT, c.d, C, c.g, q.up_w);
     const float* o = x.O.data();
     if (c.bn) { x.Ob.assign(NT * C, 0.f); bn_fwd(o, x.Ob.data(), NT, C, q.bn2_w, q.bn2_b, c.bn_eps, c.train, c.mom, q.bn2_rm, q.bn2_rv, q.bn2_nbt, update, x.bn2); o = x.Ob.data(); }
@@ -304,9 +325,9 @@ int avmoe_host_moe_backward(const avmoe_moe_desc* desc, const float* X, const fl
     if (c.bn) { bn_bwd(x.O.data(), g, h, NT, C, q.bn2_w, c.train, x.bn2, gq.bn2_w, gq.bn2_b); std::swap(g, h); }
     gconv_bwd(x.Za.data(), g, tz.data(), gq.up_w, NT, d, C, c.g, q.up_w);
     float* gz = tz.data(); float* hz = tz2.data();
-    if (x.lat) for (long i = 0; i < NT * d; ++i) if (!(x.Za[i] > 0.f)) gz[i] = 0.f;
+    if (x.relu) for (long i = 0; i < NT * d; ++i) if (!(x.Za[i] > 0.f)) gz[i] = 0.f;
     if (c.bn) { bn_bwd(x.Z.data(), gz, hz, NT, d, q.bn1_w, c.train, x.bn1, gq.bn1_w, gq.bn1_b); std::swap(gz, hz); }
-    const float* xin = x.lat ? x.Xp.data() : X;
+    const float* xin = (x.lat || x.nxn) ? x.Xp.data() : X;
     gconv_bwd(c.lnb ? x.U.data() : xin, gz, g, gq.down_w, NT, C, d, c.g, q.down_w);      // g: gradient of LN_before's output (or of x')
     if (c.lnb) { ln_bwd(xin, g, h, NT, C, q.lnb_w, x.lnb, gq.lnb_w, gq.lnb_b); std::swap(g, h); }
     for (long i = 0; i < NT * C; ++i) dX[i] += g[i];                                       // x' = x + ...
@@ -316,7 +337,9 @@ int avmoe_host_moe_backward(const avmoe_moe_desc* desc, const float* X, const fl
       if (gq.gate_lat) gq.gate_lat[0] = (float)dga;
       V dT0((long)K * C, 0.f), dT((long)K * C), dA2((long)N * K), dA1((long)K * N);
       for (int s = 0; s < S; ++s) {
-        const float* Yf = c.Yf.data() + (long)s * N * C; const float* Xs = X + (long)s * N * C;
+        const float* Xs = X + (long)s * N * C;
+        const float* Yf = x.self ? Xs : c.Yf.data() + (long)s * N * C;
+        float* dsrc = (x.self ? dX : dYf.data()) + (long)s * N * C;                            // gradient of the summarised token set
         const float* A1 = x.A1.data() + (long)s * K * N; const float* T = x.T.data() + (long)s * K * C; const float* A2 = x.A2.data() + (long)s * N * K;
         const float* dxr = g + (long)s * N * C;
         gemm(false, true, N, K, C, 1.f, dxr, C, T, C, 0.f, dA2.data(), K);                     // xr = A2 T
@@ -326,12 +349,26 @@ int avmoe_host_moe_backward(const avmoe_moe_desc* desc, const float* X, const fl
         gemm(true, false, K, C, N, 1.f, dA2.data(), K, Xs, C, 1.f, dT.data(), C);
         for (long i = 0; i < (long)K * C; ++i) dT0[i] += dT[i];                                // T = T0 + A1 Yf
         gemm(false, true, K, N, C, 1.f, dT.data(), C, Yf, C, 0.f, dA1.data(), N);
-        gemm(true, false, N, C, K, 1.f, A1, N, dT.data(), C, 1.f, dYf.data() + (long)s * N * C, C);
+        gemm(true, false, N, C, K, 1.f, A1, N, dT.data(), C, 1.f, dsrc, C);
         softmax_rows_bwd(A1, dA1.data(), K, N, N);                                             // -> dL1 ; L1 = T0 Yf^T
         gemm(false, false, K, C, N, 1.f, dA1.data(), N, Yf, C, 1.f, dT0.data(), C);
-        gemm(true, false, N, C, K, 1.f, dA1.data(), N, q.my_tokens, C, 1.f, dYf.data() + (long)s * N * C, C);
+        gemm(true, false, N, C, K, 1.f, dA1.data(), N, q.my_tokens, C, 1.f, dsrc, C);
       }
       if (gq.my_tokens) std::memcpy(gq.my_tokens, dT0.data(), sizeof(float) * K * C);
+    } else if (x.nxn) {
+      double dga = 0.0;
+      for (long i = 0; i < NT * C; ++i) { dga += (double)g[i] * x.Xr[i]; g[i] *= q.gate_lat[0]; }      // g = d xr
+      if (gq.gate_lat) gq.gate_lat[0] = (float)dga;
+      V datt((long)N * N);
+      for (int s = 0; s < S; ++s) {
+        const float* Xs = X + (long)s * N * C; const float* att = x.A1.data() + (long)s * N * N; const float* dxr = g + (long)s * N * C;
+        float* dXs = dX + (long)s * N * C;
+        gemm(false, true, N, N, C, 1.f, Xs, C, dxr, C, 0.f, datt.data(), N);                   // xr = att^T x : d att[i][j] = x_i . dxr_j
+        gemm(false, false, N, C, N, 1.f, att, N, dxr, C, 1.f, dXs, C);                         //               dx_i += sum_j att[i][j] dxr_j
+        softmax_rows_bwd(att, datt.data(), N, N, N);                                           // -> d scores ; scores = x x^T
+        gemm(false, false, N, C, N, 1.f, datt.data(), N, Xs, C, 1.f, dXs, C);
+        gemm(true, false, N, C, N, 1.f, datt.data(), N, Xs, C, 1.f, dXs, C);
+      }
     }
   }
   // ---- router: p = softmax(logits) ; + the load-balancing loss -sum_e log(mean_s p)
