@@ -218,12 +218,15 @@ class AdapterGradReducer:
         # never be reduced: fail loudly (every backward of a sync step but the last belongs in begin(sync=False) micro-steps)
         if b.work is not None:
             raise RuntimeError("AdapterGradReducer: a gradient was produced after its bucket's all-reduce had been launched "
-                               "(a second backward in one begin(sync=True) step?) -- run all but the last backward under "
-                               "begin(sync=False)")
+                               "(a second forward + backward of the same site inside one begin(sync=True) step: the first backward "
+                               "completed the bucket) -- run all but the last forward + backward of a step under begin(sync=False)")
 
     def _maybe_launch(self, b):
         # a bucket goes out when every sink / hooked parameter has reported ONCE since begin() and no site of it still owes a
-        # backward (a site may report several times: forward + backward twice in sequence, or two backward passes)
+        # backward.  A site that runs forward, forward, backward, backward inside one sync step is covered (`calls` counts the forwards
+        # still owed); forward, backward, forward, backward is NOT once this site was the last of its bucket to report: the first
+        # backward sends the bucket out and the second one raises in _late() -- run all but the last pass of a step under
+        # begin(sync=False) (tests/test_dp_gloo.py::test_gradient_after_the_collective_went_out_fails_loudly)
         if b.pending <= 0 and self._sync and self.world > 1 and b.work is None and all(s.calls <= 0 for s in b.sinks):
             self._launch(b)
 
