@@ -189,8 +189,15 @@ class _SiteBackward:
         return self
 
     def fused_ok(self, other):
-        """Does the library serve `token gradient = this site's dX + the other site's dY` as ONE kernel (avmoe_moe_backward_dx_dy)?"""
-        return self.L.avmoe_moe_backward_dx_dy(C.byref(self.desc), None, None, None, C.byref(other.desc), None, None, None, None) == 0
+        """Does the library serve `token gradient = this site's dX + the other site's dY` as ONE kernel (avmoe_moe_backward_dx_dy)?
+        (asked once per pair of call shapes: the answer is a function of the two descriptors)"""
+        da, db = self.desc, other.desc
+        key = (id(other.module), da.S, da.N, da.M, da.dtype, da.training, db.S, db.N, db.M, db.dtype, db.training)
+        cache = self.module.__dict__.setdefault("_fused_ok", {})
+        ok = cache.get(key)
+        if ok is None:
+            ok = cache[key] = self.L.avmoe_moe_backward_dx_dy(C.byref(da), None, None, None, C.byref(db), None, None, None, None) == 0
+        return ok
 
     def run_fused(self, other):
         """dX (this site) + dY (the other site) written once into self.dX: after sections 1 + 32 + 8 of both sites, in place of this

@@ -131,7 +131,8 @@ def test_cfg2_full_size_bf16_gradients_vs_fp32(site):
             continue
         tol = 0.20 if (k.startswith("multimodal") and ".bn1." in k) else 0.06
         if k.endswith("gate_av"):
-            tol = 0.5          # one scalar: a sum over every token of terms of both signs (eager bf16: 24 % at S = 20)
+            tol = 0.08         # one scalar: a sum over every token of terms of both signs (measured, round 5: 0.8 - 3.1 % at S = 320; 5 - 11 % at S = 20,
+                               # where eager bf16 sits at 4 - 24 %: profiles/r05_bf16_tensor_table.txt)
         if err > tol * float(v.norm()):
             bad[k] = (err / float(v.norm()), float(v.norm()) / nmax)
     assert not bad, bad
