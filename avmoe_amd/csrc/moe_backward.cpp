@@ -200,7 +200,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
           g.M = d.N; g.N = d.N; g.K = d.C; g.lda = d.C; g.ldb = d.C; g.nb1 = ns; g.sA1 = g.sB1 = (long)d.N * d.C;
           g.sCi = d.Np; g.sC1 = (long)d.N * d.Np; g.out_dtype = dt;
           g.epi = GEMM_EPI_EXP; g.row_lse = (const float*)(sv + pl.o_nlse) + (size_t)s0 * d.N;
-          g.split3 = 0;                                      // (the forward's arithmetic: the chunked site must re-form the very att the unchunked one kept)
+          g.split3 = AVMOE_FWD_SPLIT3;                       // (the forward's arithmetic: the chunked site must re-form the very att the unchunked one kept)
           AVMOE_TRY(run(g, false));
         }
         {                                                    // y[s] = att[s] dxr[s]   (fp32): the direct term of dX and the softmax's row term

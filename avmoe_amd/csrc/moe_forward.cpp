@@ -41,7 +41,7 @@ int moe_forward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_pt
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
-  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; return g; };
+  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; g.split3 = AVMOE_FWD_SPLIT3; return g; };      // (split3: fp32 sites only, gemm.h)
   const bool hop1s = d.bf16 && !dev_env("AVMOE_NO_HOP1S");    // the per-frame products against Y as streaming kernels (hop1_stream.hip)
 
   // ---- weights-derived operands --------------------------------------------------------------

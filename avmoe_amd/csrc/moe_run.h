@@ -6,6 +6,15 @@
 #include <algorithm>
 #include <cstdlib>
 
+// fp32 sites: the FORWARD's engine products on the bf16 matrix pipe in three-plane form too (gemm.h: GemmArgs::split3: 5.8e-9 relative per product;
+// the backward's have been since round 4).  Round 4 kept v_mfma_f32_16x16x4_f32 here because ONE ReLU unit of the 32-site block-loop fixture sat
+// within rounding of zero and changed side; with this round's arithmetic every fp32 test (412, block loop included) passes either way, and the
+// three-plane form is worth 5 % of the fp32 step (cfg-2: 15.61 -> 14.84 ms, 2050 -> 2156 clip-pairs/s; the router's products stay exact fp32).
+// -DAVMOE_FWD_SPLIT3=0: the exact-fp32 matrix pipe, bit-identical to rounds 1 - 4.
+#ifndef AVMOE_FWD_SPLIT3
+#define AVMOE_FWD_SPLIT3 1
+#endif
+
 namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap);
