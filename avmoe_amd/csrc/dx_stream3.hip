@@ -28,6 +28,8 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -47,7 +49,7 @@ struct DX3Args {
   const unsigned short* dV; long ldv, sV1;      // bf16 [frame][KB][ldv], group g at column g * 384
   const unsigned short* Q; long ldq;            // bf16 [KQ][ldq], group g at column g * 384
   char* dX; long ldc;                  // bf16 [tokens][ldc], group g at column g * 384
-  char* dump;                          // >= 16 writable bytes nobody reads
+  char* dump;                          // >= 256 writable bytes nobody reads
   int N, tps, ntiles, K2, KB, KQ, ncr; // tokens per frame, 32-token tiles per frame (the last one ragged), tiles in all, rows of T[s] / [Bm ; wbar] / Q, 16-byte chunks of a dRT row
 };
 
@@ -91,8 +93,14 @@ __device__ __forceinline__ void wait_vm_n(int n) {
     default: wait_vm<63>(); break;
   }
 }
+// LDS reads issued and waited for by hand (the tile is read-only between two barriers: no memory clobber, the compiler's own reads may move)
 template <int OFF>
-__device__ __forceinline__ void tr_issue(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory"); }
+__device__ __forceinline__ void tr_issue(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF>
+__device__ __forceinline__ void rd128(u32x4& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+// wait until at most N LDS reads are pending; the registers named are those the reads before them filled (their users stay behind the wait)
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void wait_lgkm2(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 
 __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,41 +137,69 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
   constexpr int NPC = PX + PZ + PL + PR + PB, NS = NSL * NCT;            // pieces per tile ; stores per tile and wave
   const int nl = (NPC - 1 - wave) / NWV + 1 + (wave == NWV - 1 ? 1 : 0);       // direct loads per tile of this wave: pieces wave + NWV i, + the row scales for the last wave
 
-  // One buffer image = [X 25 | dZx 9 | dL2 5 | dRT 5 | [Bm ; wbar] 8] pieces of 1 KB + the tile's 32 row scales; piece P = wave + 8 i.
+  // One buffer image = [X 25 | dZx 9 | dL2 5 | dRT 5 | [Bm ; wbar] 8] pieces of 1 KB + the tile's 32 row scales; piece P = wave + NWV i.
+  // Where a lane's 16 bytes of piece P come from, relative to the tile's first row of that tensor, does not depend on the tile: the
+  // offsets are computed ONCE (32 bits each; one register per piece of this wave) and a tile costs five scalar base addresses + one
+  // instruction per piece.  (Computed per tile -- a division by the padded row length, two clamps and a 64-bit multiply-add per piece -- the
+  // addresses were ~500 vector instructions per tile on a wave that has its SIMD to itself: as long as the whole matrix phase.)
+  constexpr int B1 = PX, B2 = B1 + PZ, B3 = B2 + PL, B4 = B3 + PR, B5 = B4 + PB, NPW = (B5 + NWV - 1) / NWV;
+  // source of slot (64 j + ln) of a sub-tile: `last` = last row of the tile inside the frame, `bmax` = last 16-byte chunk inside a [Bm ; wbar] row
+  auto off_x = [&](int j, int ln, int last) { const int slot = 64 * j + ln, row = min(slot / CHX, last), cc = min(slot % CHX, CHX - 2); return (unsigned)((row * ldx + cc * 8) * 2); };
+  auto off_z = [&](int j, int ln, int last) { const int slot = 64 * j + ln, row = min(slot / CHZ, last), cc = min(slot % CHZ, CHZ - 2); return (unsigned)((row * ldz + cc * 8) * 2); };
+  auto off_l = [&](int j, int ln, int last) { const int slot = 64 * j + ln, row = min(slot / CHL, last), cc = min(slot % CHL, CHL - 2); return (unsigned)((row * ldl + cc * 8) * 2); };
+  auto off_r = [&](int j, int ln, int last) { const int slot = 64 * j + ln, row = min(slot / CHR, last), cc = min(slot % CHR, p.ncr - 1); return (unsigned)((row * ldr + cc * 8) * 2); };
+  // [Bm ; wbar] of the frame: row l (those beyond KB - 1 re-read the last one: their B-side fragments are zero), the tile's 32 tokens as 4 chunks
+  auto off_b = [&](int j, int ln, int bmax) { const int slot = 64 * j + ln, row = min(slot / CHB, p.KB - 1), cc = min(min(slot % CHB, CHB - 2), bmax); return (unsigned)((row * ldb + cc * 8) * 2); };
+  auto off_p = [&](int P, int ln, int last, int bmax) {          // (P: wave-uniform)
+    return P < B1 ? off_x(P, ln, last) : P < B2 ? off_z(P - B1, ln, last) : P < B3 ? off_l(P - B2, ln, last) : P < B4 ? off_r(P - B3, ln, last) : P < B5 ? off_b(P - B4, ln, bmax) : 0u;
+  };
+  unsigned voff[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    voff[i] = off_p(wave + NWV * i, lane, BM - 1, CHB - 2);
+    asm volatile("" : "+v"(voff[i]));                       // (opaque: one register each for the whole kernel, not re-derived per tile)
+  }
+  const int nfr = p.ntiles / p.tps;
   auto gload = [&](int buf, int tile) {
     const int fs = tile / p.tps, fj = tile - fs * p.tps;
     const long m0 = (long)fs * p.N + (long)fj * BM;         // first token of the tile
-    const int last = min(p.N - fj * BM, BM) - 1;            // rows beyond the frame's last token re-read it (a ragged last tile; never stored)
+    const int last = min(p.N - fj * BM, BM) - 1;            // last row of the tile inside the frame (a ragged last tile: the rows beyond are never stored)
     char* dst = smem + buf * BUF + 1024 * wave;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));                            // (opaque: the per-piece row / chunk arithmetic stays in the loop instead of being hoisted into -- and spilled from -- 26 registers)
-    auto src_x = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHX, last), cc = min(slot % CHX, CHX - 2); return Xb + ((m0 + row) * ldx + cc * 8) * 2; };
-    auto src_z = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHZ, last), cc = min(slot % CHZ, CHZ - 2); return Zb + ((m0 + row) * ldz + cc * 8) * 2; };
-    auto src_l = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHL, last), cc = min(slot % CHL, CHL - 2); return p.dL2 + ((m0 + row) * ldl + cc * 8) * 2; };
-    auto src_r = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHR, last), cc = min(slot % CHR, p.ncr - 1); return p.dRT + ((m0 + row) * ldr + cc * 8) * 2; };
-    // [Bm ; wbar] of the frame: row l (those beyond KB - 1 re-read the last one: their B-side fragments are zero), the tile's 32 tokens as
-    // 4 chunks (a chunk that would leave the row re-reads the row's last one: tokens beyond the frame are never stored)
-    const int bmax = (int)((ldb - (long)fj * BM) / 8) - 1;
-    auto src_b = [&](int j) { const int slot = 64 * j + ln, row = min(slot / CHB, p.KB - 1), cc = min(min(slot % CHB, CHB - 2), bmax);
-                              return p.Bm + ((long)fs * p.sB1 + (long)row * ldb + (long)fj * BM + cc * 8) * 2; };
+    // five tensors, five scalar bases
+    const char* base[5] = {Xb + m0 * ldx * 2, Zb + m0 * ldz * 2, p.dL2 + m0 * ldl * 2, p.dRT + m0 * ldr * 2, p.Bm + ((long)fs * p.sB1 + (long)fj * BM) * 2};
+    // A ragged tile's rows beyond the frame read the next frame's first rows ([Bm ; wbar]: the next row's first tokens) -- finite or not, they
+    // only reach outputs that are not stored.  The last frame has no next one: its ragged tile takes the clamped addresses, computed on the spot.
+    const bool clamp = last < BM - 1 && fs == nfr - 1;
+    if (clamp) {                                            // (wave-uniform; once per launch, in one block)
+      const int bmax = (int)((ldb - (long)fj * BM) / 8) - 1;
+#pragma unroll 1
+      for (int i = 0; i < NPW; ++i) {
+        const int P = wave + NWV * i;
+        if (P >= B5) break;
+        const int t = P < B1 ? 0 : P < B2 ? 1 : P < B3 ? 2 : P < B4 ? 3 : 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base[t] + off_p(P, lane, last, bmax)), (lptr_t)(dst + 1024 * NWV * i), 16, 0, 0);
+      }
+      if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);
+      return;
+    }
     // piece P = wave + NWV i (i is a constant after unrolling: only the rounds that hold a boundary between two sub-tiles keep a wave-uniform branch)
-    constexpr int B1 = PX, B2 = B1 + PZ, B3 = B2 + PL, B4 = B3 + PR, B5 = B4 + PB;
 #pragma unroll
-    for (int i = 0; i < (B5 + NWV - 1) / NWV; ++i) {
+    for (int i = 0; i < NPW; ++i) {
       const int P = wave + NWV * i;
       char* d = dst + 1024 * NWV * i;
-      if (NWV * i + NWV <= B1) __builtin_amdgcn_global_load_lds((gptr_t)src_x(P), (lptr_t)d, 16, 0, 0);
-      else if (NWV * i >= B1 && NWV * i + NWV <= B2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(P - B1), (lptr_t)d, 16, 0, 0);
-      else if (NWV * i >= B2 && NWV * i + NWV <= B3) __builtin_amdgcn_global_load_lds((gptr_t)src_l(P - B2), (lptr_t)d, 16, 0, 0);
-      else if (NWV * i >= B3 && NWV * i + NWV <= B4) __builtin_amdgcn_global_load_lds((gptr_t)src_r(P - B3), (lptr_t)d, 16, 0, 0);
-      else if (NWV * i >= B4 && NWV * i + NWV <= B5) __builtin_amdgcn_global_load_lds((gptr_t)src_b(P - B4), (lptr_t)d, 16, 0, 0);
-      else if (P < B1) __builtin_amdgcn_global_load_lds((gptr_t)src_x(P), (lptr_t)d, 16, 0, 0);
-      else if (P < B2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(P - B1), (lptr_t)d, 16, 0, 0);
-      else if (P < B3) __builtin_amdgcn_global_load_lds((gptr_t)src_l(P - B2), (lptr_t)d, 16, 0, 0);
-      else if (P < B4) __builtin_amdgcn_global_load_lds((gptr_t)src_r(P - B3), (lptr_t)d, 16, 0, 0);
-      else if (P < B5) __builtin_amdgcn_global_load_lds((gptr_t)src_b(P - B4), (lptr_t)d, 16, 0, 0);
+      int t;                                                // which tensor
+      if (NWV * i + NWV <= B1) t = 0;
+      else if (NWV * i >= B1 && NWV * i + NWV <= B2) t = 1;
+      else if (NWV * i >= B2 && NWV * i + NWV <= B3) t = 2;
+      else if (NWV * i >= B3 && NWV * i + NWV <= B4) t = 3;
+      else if (NWV * i >= B4 && NWV * i + NWV <= B5) t = 4;
+      else t = P < B1 ? 0 : P < B2 ? 1 : P < B3 ? 2 : P < B4 ? 3 : P < B5 ? 4 : -1;
+      if (t < 0) continue;
+      unsigned o = voff[i];
+      asm volatile("" : "+v"(o));                           // (the zero-extension stays here, beside the scalar base: the load takes `scalar base + 32-bit lane offset` as it is)
+      __builtin_amdgcn_global_load_lds((gptr_t)(base[t] + o), (lptr_t)d, 16, 0, 0);
     }
-    if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(ln, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);       // the tile's row scales
+    if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, BM - 1)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);       // the tile's row scales
   };
 
   // contiguous tile ranges (few frame changes per block)
@@ -232,56 +268,66 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
       f32x4 acc[NCT];
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // [Bm ; wbar]^T dV_B: the tile is [l][token] -- read transposed (lane (r, q): token r of the slab, rows 8 q .. 8 q + 7 of the K step)
+      // The slab's A-side fragments, one K step of 32 each, in the order they are multiplied:
+      //    0 ..  2   [Bm ; wbar]_B^T (the tile is [l][token]: transposing reads, two per step; lane (r, q): token r, rows 8 q .. 8 q + 7 of the step)   x dV_B
+      //    3 ..  6   dZx                                              x Wt
+      //    7 ..  9   [dL2 | dsx | 1] (columns beyond K2 masked)       x [T ; 1 ; dm1/N]
+      //   10 .. 11   dR_B^T                                           x Q_B  (its fragments are zero beyond KQ rows)
+      // software-pipelined by hand: step k + 1's read is issued BEFORE step k's six products and waited for with a counted lgkmcnt -- this
+      // wave has its SIMD to itself, nobody else covers the 100+ cycles of an LDS read (as the compiler schedules it, read -> wait -> six
+      // products, the matrix pipe idles for one read latency per step: as long as the products themselves).
       if (!(DX3_DISSECT & 1)) {
-        const unsigned lb = (unsigned)(size_t)(lptr_t)(sX + OFFB) + (8 * q + (r >> 2)) * RBB + (4 * (r & 3)) * 2 + 32 * h;
-        u32x2 f[3][2];                                     // [K step][half]
-        tr_issue<0 * 32 * RBB>(f[0][0], lb); tr_issue<0 * 32 * RBB + 4 * RBB>(f[0][1], lb);
-        tr_issue<1 * 32 * RBB>(f[1][0], lb); tr_issue<1 * 32 * RBB + 4 * RBB>(f[1][1], lb);
-        tr_issue<2 * 32 * RBB>(f[2][0], lb); tr_issue<2 * 32 * RBB + 4 * RBB>(f[2][1], lb);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-          asm volatile("" : "+v"(f[ks][0]), "+v"(f[ks][1]) :: "memory");
-          const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4{f[ks][0][0], f[ks][0][1], f[ks][1][0], f[ks][1][1]});
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[ct][ks], af, acc[ct], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < ((DX3_DISSECT & 1) ? 0 : 4); ++ks) {                      // dZx Wt
-        const bf16x8 af = *(const bf16x8*)(sZ + (16 * h + r) * RBZ + ks * 64 + q * 16);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ct][ks], af, acc[ct], 0, 0, 0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < ((DX3_DISSECT & 1) ? 0 : 3); ++ks) {                      // [dL2 | dsx | 1] [T ; 1 ; dm1/N]  (the lane's columns 32 ks + 8 q .. beyond K2 are not data)
-        u32x4 v = *(const u32x4*)(sL + (16 * h + r) * RBL + ks * 64 + q * 16);
-        const int nvk = p.K2 - (32 * ks + 8 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] &= (2 * e + 1 < nvk) ? 0xffffffffu : ((2 * e < nvk) ? 0x0000ffffu : 0u);
-        const bf16x8 af = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bt[ct][ks], af, acc[ct], 0, 0, 0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < ((DX3_DISSECT & 1) ? 0 : 2); ++ks) {                      // dR_B^T Q_B  (the fragments of Q are zero beyond its KQ rows)
-        const bf16x8 af = *(const bf16x8*)(sR + (16 * h + r) * RBR + ks * 64 + q * 16);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ct][ks], af, acc[ct], 0, 0, 0);
+        const unsigned aB = (unsigned)(size_t)(lptr_t)(sX + OFFB) + (8 * q + (r >> 2)) * RBB + (4 * (r & 3)) * 2 + 32 * h;
+        const unsigned aZ = (unsigned)(size_t)(lptr_t)(sZ + (16 * h + r) * RBZ + q * 16);
+        const unsigned aL = (unsigned)(size_t)(lptr_t)(sL + (16 * h + r) * RBL + q * 16);
+        const unsigned aR = (unsigned)(size_t)(lptr_t)(sR + (16 * h + r) * RBR + q * 16);
+        u32x2 pa, pb, qa, qb;
+        u32x4 u, w;
+#define DX3_MM(frag, ks, af_)                                                                                                     \
+  {                                                                                                                               \
+    const bf16x8 af__ = __builtin_bit_cast(bf16x8, af_);                                                                          \
+    _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[ct][ks], af__, acc[ct], 0, 0, 0); \
+  }
+#define DX3_MASK(v, ks)                                                                                                           \
+  {                                                                                                                               \
+    const int nvk = p.K2 - (32 * (ks) + 8 * q);                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] &= (2 * e + 1 < nvk) ? 0xffffffffu : ((2 * e < nvk) ? 0x0000ffffu : 0u);   \
+  }
+        tr_issue<0 * 32 * RBB>(pa, aB); tr_issue<0 * 32 * RBB + 4 * RBB>(pb, aB);
+        tr_issue<1 * 32 * RBB>(qa, aB); tr_issue<1 * 32 * RBB + 4 * RBB>(qb, aB);
+        wait_lgkm2<2>(pa, pb);
+        DX3_MM(bv, 0, (u32x4{pa[0], pa[1], pb[0], pb[1]}));
+        tr_issue<2 * 32 * RBB>(pa, aB); tr_issue<2 * 32 * RBB + 4 * RBB>(pb, aB);
+        wait_lgkm2<2>(qa, qb);
+        DX3_MM(bv, 1, (u32x4{qa[0], qa[1], qb[0], qb[1]}));
+        rd128<0>(u, aZ);
+        wait_lgkm2<1>(pa, pb);
+        DX3_MM(bv, 2, (u32x4{pa[0], pa[1], pb[0], pb[1]}));
+        rd128<64>(w, aZ);  wait_lgkm<1>(u); DX3_MM(bw, 0, u);
+        rd128<128>(u, aZ); wait_lgkm<1>(w); DX3_MM(bw, 1, w);
+        rd128<192>(w, aZ); wait_lgkm<1>(u); DX3_MM(bw, 2, u);
+        rd128<0>(u, aL);   wait_lgkm<1>(w); DX3_MM(bw, 3, w);
+        rd128<64>(w, aL);  wait_lgkm<1>(u); DX3_MASK(u, 0); DX3_MM(bt, 0, u);
+        rd128<128>(u, aL); wait_lgkm<1>(w); DX3_MASK(w, 1); DX3_MM(bt, 1, w);
+        rd128<0>(w, aR);   wait_lgkm<1>(u); DX3_MASK(u, 2); DX3_MM(bt, 2, u);
+        rd128<64>(u, aR);  wait_lgkm<1>(w); DX3_MM(bq, 0, w);
+        wait_lgkm<0>(u);   DX3_MM(bq, 1, u);
+#undef DX3_MM
+#undef DX3_MASK
       }
       {                                                    // lane (r, q): token r of the slab, channels c0 + 16 ct + 4 q .. + 3 ; three stores per slab, always
         const int row = 16 * h + r;
         const bool ok = row < valid && !(DX3_DISSECT & 2);
         const float rs = sS[row];
-        char* out = ok ? p.dX + ((m0 + row) * p.ldc + (long)g * 384 + c0 + 4 * q) * 2 : p.dump;
-        const int step = ok ? 32 : 0;
+        char* out = ok ? p.dX + ((m0 + row) * p.ldc + (long)g * 384 + c0 + 4 * q) * 2 : p.dump;      // (the dump: 32 (NCT - 1) + 8 bytes)
+        constexpr int step = 32;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           const u32x2 xv = *(const u32x2*)(sX + row * RBX + (c0 + 16 * ct + 4 * q) * 2);
           const f32x4 a = acc[ct];
-          *(u32x2*)(out + step * ct) = u32x2{f2bf(a[0] + rs * bflo(xv[0])) | (f2bf(a[1] + rs * bfhi(xv[0])) << 16),
-                                             f2bf(a[2] + rs * bflo(xv[1])) | (f2bf(a[3] + rs * bfhi(xv[1])) << 16)};
+          const bf16x2 lo = __builtin_convertvector(f32x2{a[0] + rs * bflo(xv[0]), a[1] + rs * bfhi(xv[0])}, bf16x2);      // (one v_cvt_pk_bf16_f32 per pair)
+          const bf16x2 hi = __builtin_convertvector(f32x2{a[2] + rs * bflo(xv[1]), a[3] + rs * bfhi(xv[1])}, bf16x2);
+          *(u32x2*)(out + step * ct) = u32x2{__builtin_bit_cast(unsigned int, lo), __builtin_bit_cast(unsigned int, hi)};
         }
       }
     }
