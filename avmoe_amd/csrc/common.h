@@ -5,6 +5,16 @@
 #include <cstdio>
 #include <cstdlib>
 
+// Cache policy of the streaming kernels' direct global -> LDS loads: the `aux` argument of __builtin_amdgcn_global_load_lds (gfx950: 1 = sc0,
+// 2 = nt, 16 = sc1).  2, the non-temporal hint: a tile that is read once is not kept in the L2 / Infinity Cache in place of lines somebody
+// will come back to.  Measured on the tile loop of kk_hop1_yk rebuilt without its kernel (scripts/lds_stream_probe.hip, MI355X): with the
+// loop's one small store per wave and tile (32-byte runs: the partly written lines now survive until their other parts arrive) 4.58 -> 5.08
+// TB/s, without the store no difference (5.9 TB/s); sc0 alone: none.  Applied per kernel where the two-stream STEP gains (hop1_stream.hip: the
+// Y streams, -1.1 %); the X-side kernels (tok_pair2 / dpost_pair / dx_stream3) measured neutral to +1 % with it and keep 0.
+#ifndef AVMOE_LDS_AUX
+#define AVMOE_LDS_AUX 2
+#endif
+
 namespace avmoe {
 
 enum Status : int {

@@ -22,6 +22,10 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef DPAIR_AUX
+#define DPAIR_AUX 0      // cache policy of the direct loads (common.h::AVMOE_LDS_AUX): the non-temporal hint measured neutral or worse here (its X is re-read by the next kernel of the chain)
+#endif
+
 namespace avmoe {
 
 namespace {
@@ -131,11 +135,11 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
     // (i < 6 for every wave, i = 6 for wave 0), the rest Apost's -- no per-piece select between the two sources (a select of loaded
     // strides made the compiler wait for every load in flight in front of the next piece)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_o(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, 0);
-    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_o(48), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gptr_t)src_p(wave + 48), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src_p(wave + 56), (lptr_t)(dst + 8192 * 7), 16, 0, 0);
-    if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_p(wave + 64), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
+    for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_o(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, DPAIR_AUX);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_o(48), (lptr_t)(dst + 8192 * 6), 16, 0, DPAIR_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)src_p(wave + 48), (lptr_t)(dst + 8192 * 6), 16, 0, DPAIR_AUX);
+    __builtin_amdgcn_global_load_lds((gptr_t)src_p(wave + 56), (lptr_t)(dst + 8192 * 7), 16, 0, DPAIR_AUX);
+    if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_p(wave + 64), (lptr_t)(dst + 8192 * 8), 16, 0, DPAIR_AUX);
   };
 
   int tile = blockIdx.x;

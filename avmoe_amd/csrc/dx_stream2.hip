@@ -15,6 +15,10 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef DX2_AUX
+#define DX2_AUX 0      // cache policy of the direct loads (common.h::AVMOE_LDS_AUX)
+#endif
+
 namespace avmoe {
 
 namespace {
@@ -93,14 +97,14 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream2(const DX2Args p) {
     auto src_z = [&](int j) { const int slot = 64 * j + lane, row = min(slot / 17, last), cc = min(slot % 17, 15); return Zb + ((m0 + row) * ldz + cc * 8) * 2; };
     auto src_l = [&](int j) { const int slot = 64 * j + lane, row = min(slot / 10, last), cc = min(slot % 10, 8); return Lb + ((m0 + row) * ldl + cc * 8) * 2; };
 #pragma unroll
-    for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_x(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, 0);
-    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_x(48), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave - 1), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 7), (lptr_t)(dst + 8192 * 7), 16, 0, 0);
-    if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 15), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave - 2), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
-    if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave + 6), (lptr_t)(dst + 8192 * 9), 16, 0, 0);
-    else if (wave == 4) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, last)), (lptr_t)(smem + buf * BUF + OFFR), 4, 0, 0);      // the tile's 64 row scales
+    for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_x(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, DX2_AUX);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_x(48), (lptr_t)(dst + 8192 * 6), 16, 0, DX2_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave - 1), (lptr_t)(dst + 8192 * 6), 16, 0, DX2_AUX);
+    __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 7), (lptr_t)(dst + 8192 * 7), 16, 0, DX2_AUX);
+    if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 15), (lptr_t)(dst + 8192 * 8), 16, 0, DX2_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave - 2), (lptr_t)(dst + 8192 * 8), 16, 0, DX2_AUX);
+    if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave + 6), (lptr_t)(dst + 8192 * 9), 16, 0, DX2_AUX);
+    else if (wave == 4) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, last)), (lptr_t)(smem + buf * BUF + OFFR), 4, 0, DX2_AUX);      // the tile's 64 row scales
   };
 
   // contiguous tile ranges (few frame changes per block)

@@ -22,6 +22,10 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef DX3_AUX
+#define DX3_AUX 0      // cache policy of the direct loads (common.h::AVMOE_LDS_AUX): the non-temporal hint measured neutral or worse here (its X is re-read by the next kernel of the chain)
+#endif
+
 namespace avmoe {
 
 namespace {
@@ -61,8 +65,17 @@ struct DX3Args {
 //   4 waves, 16-token tiles x 5 (x 4) buffers                                                                 417 us (per-tile overhead: waits, barrier, addresses)
 //   8 waves (256 registers: the frame-change gathers spill, the tile loop does not), 32 x 3 / 16 x 5           362 / 395 us
 // Timing-only builds of the first (DX3_DISSECT): the tile stream alone 159 us (5.1 TB/s), + the stores 270 us (4.85 TB/s over the
-// 1.31 GB moved: the memory-bound floor), + the matrix phase instead of the stores 258 us; everything 349 us -- the 77 us of matrix-pipe
-// time (193 GFLOP) are not hidden behind the memory traffic in this one-role-per-wave loop.
+// 1.31 GB moved: the memory-bound floor), + the matrix phase instead of the stores 258 us; everything 349 us.  A wave that has its SIMD to
+// itself hides nothing: what the instruction stream of a tile costs beyond the matrix instructions is added to the step.  Three changes took
+// 344 - 366 us to 310 - 317 us (same boxes; visual tokens 123 -> 108 - 112 us):
+//   * the per-piece source addresses (a division by the padded row length, two clamps, a 64-bit multiply-add each: ~500 vector instructions
+//     per tile, as many cycles as the matrix phase) -> lane offsets computed once, `scalar base + 32-bit lane offset` loads;
+//   * read -> wait -> six products per K step (the pipe idles for one LDS latency per step) -> the next step's read issued in front of
+//     the products, counted lgkmcnt waits (two steps ahead: no further gain);
+//   * the stationary fragments that do not fit the 256 architectural registers were copied in and out of the accumulation registers around
+//     every product (four v_accvgpr_read per matrix instruction) -> pinned there, read in place.
+// Built and dropped: the slabs as one software pipeline across tiles (slab j's row-scale term, conversion and stores between the products
+// of slab j + 1: a second accumulator set and the slab's X values held in registers) -- 538 registers, 24 - 48 of them spilled.
 #ifndef DX3_NWV
 #define DX3_NWV 4
 #endif
@@ -133,6 +146,16 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) bq[ct][ks] = frag_mn(Qg, p.ldq, c0 + 16 * ct + r, 32 * ks + 8 * q, p.KQ);
     }
+    // Wt and Q_B (stationary for the whole kernel: 144 registers) pinned to the accumulation half of the register file, where the matrix
+    // instructions read them directly.  Left alone the compiler keeps every fragment in the 256 architectural registers and copies the
+    // overflow in and out of the other 256 around each product: four v_accvgpr_read per matrix instruction, 320 per tile (-5.5 %).
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+a"(bw[ct][ks]));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+a"(bq[ct][ks]));
+    }
   }
   constexpr int NPC = PX + PZ + PL + PR + PB, NS = NSL * NCT;            // pieces per tile ; stores per tile and wave
   const int nl = (NPC - 1 - wave) / NWV + 1 + (wave == NWV - 1 ? 1 : 0);       // direct loads per tile of this wave: pieces wave + NWV i, + the row scales for the last wave
@@ -177,9 +200,9 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
         const int P = wave + NWV * i;
         if (P >= B5) break;
         const int t = P < B1 ? 0 : P < B2 ? 1 : P < B3 ? 2 : P < B4 ? 3 : 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)(base[t] + off_p(P, lane, last, bmax)), (lptr_t)(dst + 1024 * NWV * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(base[t] + off_p(P, lane, last, bmax)), (lptr_t)(dst + 1024 * NWV * i), 16, 0, DX3_AUX);
       }
-      if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);
+      if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, last)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, DX3_AUX);
       return;
     }
     // piece P = wave + NWV i (i is a constant after unrolling: only the rounds that hold a boundary between two sub-tiles keep a wave-uniform branch)
@@ -197,9 +220,9 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
       if (t < 0) continue;
       unsigned o = voff[i];
       asm volatile("" : "+v"(o));                           // (the zero-extension stays here, beside the scalar base: the load takes `scalar base + 32-bit lane offset` as it is)
-      __builtin_amdgcn_global_load_lds((gptr_t)(base[t] + o), (lptr_t)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base[t] + o), (lptr_t)d, 16, 0, DX3_AUX);
     }
-    if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, BM - 1)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, 0);       // the tile's row scales
+    if (wave == NWV - 1) __builtin_amdgcn_global_load_lds((gptr_t)(p.rs + m0 + min(lane, BM - 1)), (lptr_t)(smem + buf * BUF + OFFS), 4, 0, DX3_AUX);       // the tile's row scales
   };
 
   // contiguous tile ranges (few frame changes per block)

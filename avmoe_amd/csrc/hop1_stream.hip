@@ -55,8 +55,21 @@ struct YKArgs {
 };
 
 constexpr int YK_BT = 32, YK_NBUF = 3;
+// cache policy of the direct loads (common.h::AVMOE_LDS_AUX): Y is streamed non-temporally by all three kernels.  Alone on the GPU the
+// hint moves time between them (yk 128 -> 109 us and the all-token sum 112 -> 98 us, but the per-frame kernel that re-reads Y behind yk
+// 126 -> 155 us: it had been finding part of Y in the Infinity Cache); what counts is the two-stream step, where the other site's kernels
+// keep what the Y streams no longer evict: 4.621 -> 4.570 ms (four interleaved repetitions of the default bench command per setting).
+#ifndef YK_AUX
+#define YK_AUX AVMOE_LDS_AUX
+#endif
+#ifndef YTS_AUX
+#define YTS_AUX AVMOE_LDS_AUX
+#endif
+#ifndef YTF_AUX
+#define YTF_AUX AVMOE_LDS_AUX
+#endif
 #ifndef HOP1_DISSECT
-#define HOP1_DISSECT 0      // development builds (timing only): bit 0 = no matrix phase, bit 1 = no store, bit 2 = no direct loads
+#define HOP1_DISSECT 0      // development builds (timing only): bit 0 = no matrix phase, bit 1 = no store, bit 2 = no direct loads, bit 3 = tiles dealt round-robin
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -80,7 +93,7 @@ __global__ void __launch_bounds__(128 * NRT, 1) kk_hop1_yk(const YKArgs p) {
     for (int i = 0; i < NI; ++i) {
       if ((i < NLO || extra) && !(HOP1_DISSECT & 4)) {       // (compile-time true except for the last round of pieces: wave-uniform)
         const int slot = 64 * (wave + NW * i) + lane, row = slot / CH, cc = (slot % CH) ^ (row & 15);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.Y + ((m0 + min(row, last)) * ldy + cc * 8) * 2), (lptr_t)(dst + 1024 * NW * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.Y + ((m0 + min(row, last)) * ldy + cc * 8) * 2), (lptr_t)(dst + 1024 * NW * i), 16, 0, YK_AUX);
       }
     }
   };
@@ -219,16 +232,16 @@ __global__ void __launch_bounds__(512, 1) kk_hop1_yt(const YTArgs p) {
       const int j0 = 8 * i;                                  // pieces j0 .. j0 + 7 of this round: piece j0 + wave is this wave's
       auto ld_y = [&]() {
         const int slot = 64 * (j0 + wave) + lane, row = min(slot / CHY, last), cc = min(slot % CHY, CHY - 2);
-        __builtin_amdgcn_global_load_lds((gptr_t)(Yb + ((m0 + row) * ldy + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Yb + ((m0 + row) * ldy + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, (PER_FRAME ? YTF_AUX : YTS_AUX));
       };
       auto ld_a = [&]() {
         const int slot = 64 * (j0 + wave - NPY) + lane;
         if constexpr (PER_FRAME) {                           // [row][tokens of the tile]: 4 chunks of 8 tokens + the pad chunk
           const int row = min(slot / CHA, p.rows - 1), cc = min(min(slot % CHA, CHA - 2), acol_max);
-          __builtin_amdgcn_global_load_lds((gptr_t)(Asrc + ((long)row * lda + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(Asrc + ((long)row * lda + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, (PER_FRAME ? YTF_AUX : YTS_AUX));
         } else {                                             // [token][rows]
           const int row = min(slot / CHA, last), cc = min(slot % CHA, CHA - 2);
-          __builtin_amdgcn_global_load_lds((gptr_t)(Asrc + ((long)row * lda + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(Asrc + ((long)row * lda + cc * 8) * 2), (lptr_t)(dst + 8192 * i), 16, 0, (PER_FRAME ? YTF_AUX : YTS_AUX));
         }
       };
       // (i is a constant after unrolling: only the round that holds the Y / A boundary and the last round keep a wave-uniform branch)

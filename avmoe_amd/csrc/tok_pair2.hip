@@ -18,6 +18,10 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef TP2_AUX
+#define TP2_AUX 0      // cache policy of the direct loads (common.h::AVMOE_LDS_AUX): the non-temporal hint measured neutral or worse here (its X is re-read by the next kernel of the chain)
+#endif
+
 namespace avmoe {
 
 namespace {
@@ -95,13 +99,13 @@ __global__ void __launch_bounds__(NTHR, 1) kk_tok_pair2(const TP2Args p) {
     auto src_z = [&](int j) { const int slot = 64 * j + lane, row = slot / 17, cc = min(slot % 17, 15); return Zb + ((m0 + row) * ldz + cc * 8) * 2; };
     auto src_l = [&](int j) { const int slot = 64 * j + lane, row = slot / 10, cc = min(slot % 10, 8); return Lb + ((m0 + row) * ldl + cc * 8) * 2; };
 #pragma unroll
-    for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_x(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, 0);
-    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_x(48), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave - 1), (lptr_t)(dst + 8192 * 6), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 7), (lptr_t)(dst + 8192 * 7), 16, 0, 0);
-    if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 15), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave - 2), (lptr_t)(dst + 8192 * 8), 16, 0, 0);
-    if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave + 6), (lptr_t)(dst + 8192 * 9), 16, 0, 0);
+    for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((gptr_t)src_x(wave + 8 * i), (lptr_t)(dst + 8192 * i), 16, 0, TP2_AUX);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)src_x(48), (lptr_t)(dst + 8192 * 6), 16, 0, TP2_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave - 1), (lptr_t)(dst + 8192 * 6), 16, 0, TP2_AUX);
+    __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 7), (lptr_t)(dst + 8192 * 7), 16, 0, TP2_AUX);
+    if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)src_z(wave + 15), (lptr_t)(dst + 8192 * 8), 16, 0, TP2_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave - 2), (lptr_t)(dst + 8192 * 8), 16, 0, TP2_AUX);
+    if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)src_l(wave + 6), (lptr_t)(dst + 8192 * 9), 16, 0, TP2_AUX);
   };
 
   const int t0 = blockIdx.x * p.tpb, t1 = t0 + p.tpb;
