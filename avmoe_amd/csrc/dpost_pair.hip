@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
 __global__ void __launch_bounds__(256) kk_dpair_reduce(const float* __restrict__ slabs, int nslab, int G, int KP, int KPp, float* __restrict__ out) {
   const long per = (long)G * 384 * KP, nvec = per / 4;                    // (KP % 4 == 0: the launcher checks)
   const int lane = threadIdx.x & 63, part = lane >> 4;
-  const long v = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
+  const long v = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (lane & 15);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (v < nvec) {
     const float* sl = slabs + v * 4;

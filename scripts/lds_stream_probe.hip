@@ -3,7 +3,7 @@
 // function of the tile size, the number of buffers and waves, the barrier and the tile-to-block assignment -- beside hbm_probe.hip's plain
 // reader (ordinary loads, thousands of waves).
 //   build (here):   hipcc --offload-arch=gfx950 -O3 scripts/lds_stream_probe.hip -o avmoe_amd/lib/variants/lds_stream_probe
-//   run (GPU box):  avmoe_amd/lib/variants/lds_stream_probe [MiB, default 480]
+//   run (GPU box):  avmoe_amd/lib/variants/lds_stream_probe [MiB, default 480] [1 = pseudo-random contents instead of a constant byte]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -217,6 +217,68 @@ int run_dx3mem(const char* a, long bytes, char* dst, unsigned* out, int cus, hip
   return 0;
 }
 
+// the group split of the X-side kernels: grid (cus / 2, 2), block (x, g) streams bytes [768 g, 768 g + 768) of every 1536-byte row of its row
+// range (32-row tiles = 24 pieces, 8 waves x 3, four buffers) -- against the same bytes as whole rows (grid cus, 16-row tiles)
+template <bool SPLIT>
+__global__ void __launch_bounds__(512, 1) k_halfrows(const char* __restrict__ src, long nrows, unsigned* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 8, PPW = 3, TILE = NW * PPW * 1024, NBUF = 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpt = SPLIT ? 32 : 16;                                  // rows per tile
+  const long ntiles = nrows / rpt;
+  const long t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+  unsigned voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int slot = 64 * (wave * PPW + i) + lane;                  // 16-byte chunk of the tile
+    if (SPLIT) { const int row = slot / 48, cc = slot % 48; voff[i] = (unsigned)(row * 1536 + 768 * blockIdx.y + cc * 16); }
+    else voff[i] = (unsigned)(slot * 16);
+  }
+  auto gload = [&](int buf, long tile) {
+    const char* base = src + tile * rpt * 1536;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[i]), (lptr_t)(smem + buf * TILE + (wave * PPW + i) * 1024), 16, 0, 0);
+  };
+  long tile = t0;
+#pragma unroll
+  for (int j = 0; j < NBUF - 1; ++j)
+    if (tile + j < t1) gload(j, tile + j);
+  unsigned acc = 0;
+  for (int it = 0; tile < t1; ++it, ++tile) {
+    if (t1 - 1 - tile >= NBUF - 2) wait_vm<(NBUF - 2) * PPW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    acc += *(const unsigned*)(smem + (it % NBUF) * TILE + threadIdx.x * 4);
+    if (tile + NBUF - 1 < t1) gload((it + NBUF - 1) % NBUF, tile + NBUF - 1);
+  }
+  if (acc == 0x12345u) out[blockIdx.x] = 1u;
+}
+template <bool SPLIT>
+int run_halfrows(const char* a, long bytes, unsigned* out, int cus, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int LDS = 4 * 24 * 1024;
+  auto fn = k_halfrows<SPLIT>;
+  if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return 1;
+  const long nrows = bytes / 1536 / 32 * 32;
+  double best = 0;
+  for (int rep = 0; rep < 6; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(fn, SPLIT ? dim3(cus / 2, 2) : dim3(cus), dim3(512), LDS, 0, a, nrows, out);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    const double gbs = (double)nrows * 1536 / (ms * 1e-3) / 1e9;
+    if (rep > 0 && gbs > best) best = gbs;
+  }
+  printf("rows of 1536 bytes, 24 KB tiles x 4: %s  %6.0f GB/s\n", SPLIT ? "two blocks per row range, 768 bytes of every row each (the group split)" : "whole rows                                                            ", best);
+  return 0;
+}
+
+__global__ void k_fill_random(unsigned* d, long n) {          // pseudo-random words (a constant fill flatters the memory system: fewer toggles, less power)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    d[i] = (x & 0x7fff7fffu) % 0x3f803f80u;                    // (finite bf16 pairs)
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int NW, int PPW, int NBUF, bool BARRIER, bool RR>
@@ -243,7 +305,11 @@ int main(int argc, char** argv) {
   const long mib = argc > 1 ? atol(argv[1]) : 480;
   const long bytes = mib << 20;
   char* a; unsigned* out;
-  CK(hipMalloc(&a, bytes)); CK(hipMalloc(&out, 1 << 20)); CK(hipMemset(a, 1, bytes));
+  CK(hipMalloc(&a, bytes)); CK(hipMalloc(&out, 1 << 20));
+  const bool rnd = argc > 2 && atoi(argv[2]) != 0;
+  if (rnd) { hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, (unsigned*)a, bytes / 4); CK(hipDeviceSynchronize()); }
+  else CK(hipMemset(a, 1, bytes));
+  printf("buffer filled with %s\n", rnd ? "pseudo-random words" : "a constant byte");
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
   const int cus = pr.multiProcessorCount;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -300,5 +366,7 @@ int main(int argc, char** argv) {
   run_dx3mem<64, 2>(a, bytes, dst2, out, cus, e0, e1);
   run_dx3mem<0, 0>(a, bytes, dst2, out, cus, e0, e1);
   run_dx3mem<0, 2>(a, bytes, dst2, out, cus, e0, e1);
+  run_halfrows<false>(a, bytes, out, cus, e0, e1);
+  run_halfrows<true>(a, bytes, out, cus, e0, e1);
   return 0;
 }
