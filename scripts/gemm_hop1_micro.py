@@ -49,6 +49,8 @@ def main():
     L = capi.lib()
     run(L, dev, "as in the step (b320, 64-tile, fp32 out)")
     run(L, dev, "bf16 output", out_bf16=True)
+    run(L, dev, "32-tile", tile=32)
+    run(L, dev, "128-tile", tile=128)
     run(L, dev, "K = 192", K=192)
     run(L, dev, "K = 128", K=128)
     run(L, dev, "K = 64", K=64)
