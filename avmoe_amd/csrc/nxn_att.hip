@@ -10,10 +10,18 @@
 // and slab, stored straight from registers.  With the row log-sum-exp given (the backward of a chunked site) only sweep 2 runs.
 // Built for C = 96 and C = 192 (bf16, N a multiple of 128): the stage-0 / stage-1 sites, where N is large; everything else takes
 // the engine's softmax epilogues (gemm.hip).
+//
+// Round 5: every fragment read of the product loops is issued by hand two to three steps ahead of the matrix instructions that use it
+// (inline assembly + counted lgkmcnt, compile-time offsets through static_for).  The C = 192 instances keep 414 - 461 registers, so a block
+// is alone on its CU with one wave per SIMD, and the compiler's `ds_read -> s_waitcnt lgkmcnt(0) -> 2 - 4 products` on ONE register quad left
+// the matrix pipe idle for an LDS latency per read: dx (query / key owner) 5.67 / 5.46 -> 4.59 / 4.33 ms, y 4.80 -> 3.72, xr 4.14 -> 3.05 ms
+// per launch at the cfg-3 stage-0 visual site (64 x 10 frames of 2304 tokens), cfg-3 step 550 -> 528 - 536 ms.  The C = 96 instances (two
+// blocks per CU, two waves per SIMD) measure the same as before: there the second wave had been covering the latency.
 #include "kernels.h"
 #include "common.h"
 #include "prof.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace avmoe {
 
@@ -27,8 +35,27 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
   return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
 }
 
+
+// LDS reads issued and waited for by hand (round 5, from dx_stream3.hip): where a block keeps 450 registers it is alone on its CU, one wave
+// per SIMD, and the compiler's `read -> s_waitcnt lgkmcnt(0) -> products` leaves the matrix pipe idle for one LDS latency per read.  The
+// offsets have to be immediates: the loops run over compile-time indices (static_for).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF> __device__ __forceinline__ void lds_rd128(u32x4& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_rdtr(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void lds_wait(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_wait2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_waittr(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int I, int END> struct static_for_t {
+  template <typename F> static __device__ __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); static_for_t<I + 1, END>::run(f); }
+};
+template <int END> struct static_for_t<END, END> { template <typename F> static __device__ __forceinline__ void run(F&&) {} };
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_t<B, E>::run(f); }
+
+#ifndef NXN_ATT_MINB6
+#define NXN_ATT_MINB6 2      // blocks per CU the C = 192 instance of kk_nxn_att is compiled for (2: 256 registers, 36 spilled; 1: 512)
+#endif
 template <int KS>          // C = 32 KS
-__global__ void __launch_bounds__(256, 2) kk_nxn_att(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Kt, float* __restrict__ lse_g,
+__global__ void __launch_bounds__(256, (KS <= 3 ? 2 : NXN_ATT_MINB6)) kk_nxn_att(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Kt, float* __restrict__ lse_g,
                                                       unsigned short* __restrict__ att, const unsigned short* __restrict__ att_in, int N, int Np, int have_lse) {
   // att_in != nullptr (have_lse set): the softmax BACKWARD instead -- keys = dxr, lse_g = the row dots, output = att_in * (X dxr^T - rowdot)
   constexpr int C = 32 * KS, RB = C * 2 + 16, CPR = C / 8, NLD = 128 * CPR / 256;          // LDS row pitch, 16-byte chunks per key row, loads per thread
@@ -73,15 +100,27 @@ __global__ void __launch_bounds__(256, 2) kk_nxn_att(const unsigned short* __res
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          // key row of fragment row r of tile t: column (r >> 2) * 32 + 4 t + (r & 3) of this key tile  ->  lane (r, q) owns columns 32 q + 4 t + e
-          const bf16x8 kf = *(const bf16x8*)(smem + ((r >> 2) * 32 + 4 * t + (r & 3)) * RB + ks * 64 + q * 16);
+      {   // key row of fragment row r of tile t: column (r >> 2) * 32 + 4 t + (r & 3) of this key tile  ->  lane (r, q) owns columns 32 q + 4 t + e
+          // 8 KS steps (ks, t), the fragment reads issued by hand three steps ahead of the two products that use each
+        constexpr int NA = 8 * KS;
+        const unsigned aX = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem + ((r >> 2) * 32 + (r & 3)) * RB + q * 16);
+        u32x4 kfr[4];
+        auto issue = [&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ks = st_ / 8, t = st_ % 8;
+          lds_rd128<4 * t * RB + ks * 64>(kfr[st_ % 4], aX);
+        };
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        issue(std::integral_constant<int, 2>{});
+        static_for<0, NA>([&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ks = st_ / 8, t = st_ % 8;
+          if constexpr (st_ + 3 < NA) issue(std::integral_constant<int, st_ + 3>{});
+          lds_wait<(NA - 1 - st_ < 3 ? NA - 1 - st_ : 3)>(kfr[st_ % 4]);
+          const bf16x8 kf = __builtin_bit_cast(bf16x8, kfr[st_ % 4]);
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm) acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);
-        }
+        });
+      }
       if (sweep == 0) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
@@ -214,14 +253,26 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const bf16x8 kf = *(const bf16x8*)(sX + ((r >> 2) * 32 + 4 * t + (r & 3)) * RB + ks * 64 + q * 16);
+    {   // 8 KS steps (ks, t): the streamed rows' fragments, three steps ahead of the two products that use each (hand-issued LDS reads)
+      constexpr int NA = 8 * KS;
+      const unsigned aX = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sX + ((r >> 2) * 32 + (r & 3)) * RB + q * 16);
+      u32x4 kfr[4];
+      auto issue = [&](auto ic) {
+        constexpr int st_ = decltype(ic)::value, ks = st_ / 8, t = st_ % 8;
+        lds_rd128<4 * t * RB + ks * 64>(kfr[st_ % 4], aX);
+      };
+      issue(std::integral_constant<int, 0>{});
+      issue(std::integral_constant<int, 1>{});
+      issue(std::integral_constant<int, 2>{});
+      static_for<0, NA>([&](auto ic) {
+        constexpr int st_ = decltype(ic)::value, ks = st_ / 8, t = st_ % 8;
+        if constexpr (st_ + 3 < NA) issue(std::integral_constant<int, st_ + 3>{});
+        lds_wait<(NA - 1 - st_ < 3 ? NA - 1 - st_ : 3)>(kfr[st_ % 4]);
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, kfr[st_ % 4]);
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);
-      }
+      });
+    }
     if constexpr (XR) {                    // att[i][j] for the block's own row j = r: the log-sum-exp belongs to the streamed row i = 32 q + 4 t + e
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -250,18 +301,27 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_bwd(const unsig
           const f32x4 a = acc[tm][2 * sidx], b = acc[tm][2 * sidx + 1];
           pb[tm][sidx] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
         }
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-          const char* ad = sD + (32 * q + 8 * sidx + (r >> 2)) * RB + (16 * ct + 4 * (r & 3)) * 2;
-          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad));
-          const s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad + 4 * RB));
-          const s16x8_t w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
-          const bf16x8 af = __builtin_bit_cast(bf16x8, w);                 // dxr^T: channel 16 ct + r, keys 32 q + 8 s + 0 .. 7
+      {   // 4 CT steps (ct, s): dxr^T fragments (channel 16 ct + r, keys 32 q + 8 s + 0 .. 7) by transposing reads, three steps ahead
+        constexpr int NC = 4 * CT;
+        const unsigned aT = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sD + (32 * q + (r >> 2)) * RB + (4 * (r & 3)) * 2);
+        u32x2 t1[4], t2[4];
+        auto issue = [&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ct = st_ / 4, sidx = st_ % 4, off = 8 * sidx * RB + 32 * ct;
+          lds_rdtr<off>(t1[st_ % 4], aT);
+          lds_rdtr<off + 4 * RB>(t2[st_ % 4], aT);
+        };
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        issue(std::integral_constant<int, 2>{});
+        static_for<0, NC>([&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ct = st_ / 4, sidx = st_ % 4;
+          if constexpr (st_ + 3 < NC) issue(std::integral_constant<int, st_ + 3>{});
+          lds_waittr<2 * (NC - 1 - st_ < 3 ? NC - 1 - st_ : 3)>(t1[st_ % 4], t2[st_ % 4]);
+          const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4{t1[st_ % 4][0], t1[st_ % 4][1], t2[st_ % 4][0], t2[st_ % 4][1]});
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm) accY[tm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pb[tm][sidx], accY[tm][ct], 0, 0, 0);
-        }
+        });
+      }
     }
   }
   if constexpr (XR) {                      // xr[own row][16 ct + 4 q + e]
@@ -375,12 +435,24 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_dx(const unsign
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; g[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int row = (r >> 2) * 32 + 16 * h + 4 * t + (r & 3);
-          const bf16x8 kf = *(const bf16x8*)(sX + row * RB + ks * 64 + q * 16);
+      {   // 4 KS steps (ks, t): the streamed rows' fragments, two steps ahead of the products that use them
+        constexpr int NA = 4 * KS, NRD = KEY ? 1 : 2;
+        const unsigned aX = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sX + ((r >> 2) * 32 + 16 * h + (r & 3)) * RB + q * 16);
+        const unsigned aD = aX + (unsigned)(sD - sX);
+        u32x4 kfr[3], kdr[3];
+        auto issue = [&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ks = st_ / 4, t = st_ % 4, off = 4 * t * RB + ks * 64;
+          lds_rd128<off>(kfr[st_ % 3], aX);
+          if constexpr (!KEY) lds_rd128<off>(kdr[st_ % 3], aD);
+        };
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        static_for<0, NA>([&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ks = st_ / 4, t = st_ % 4;
+          if constexpr (st_ + 2 < NA) issue(std::integral_constant<int, st_ + 2>{});
+          constexpr int pend = NRD * (NA - 1 - st_ < 2 ? NA - 1 - st_ : 2);
+          if constexpr (KEY) lds_wait<pend>(kfr[st_ % 3]); else lds_wait2<pend>(kfr[st_ % 3], kdr[st_ % 3]);
+          const bf16x8 kf = __builtin_bit_cast(bf16x8, kfr[st_ % 3]);
           if constexpr (KEY) {
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
@@ -388,14 +460,15 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_dx(const unsign
               g[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, df[tm][ks], g[tm][t], 0, 0, 0);          // X_i . dxr_j
             }
           } else {
-            const bf16x8 kd = *(const bf16x8*)(sD + row * RB + ks * 64 + q * 16);
+            const bf16x8 kd = __builtin_bit_cast(bf16x8, kdr[st_ % 3]);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
               acc[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[tm][ks], acc[tm][t], 0, 0, 0);      // X_j . X_i
               g[tm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kd, qf[tm][ks], g[tm][t], 0, 0, 0);          // dxr_j . X_i
             }
           }
-        }
+        });
+      }
       bf16x8 pb[2][2];
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
@@ -421,18 +494,28 @@ __global__ void __launch_bounds__(256, (KS <= 3 ? 2 : 1)) kk_nxn_dx(const unsign
           pb[tm][sp] = bf16x8{(__bf16)ds[tm][0][0], (__bf16)ds[tm][0][1], (__bf16)ds[tm][0][2], (__bf16)ds[tm][0][3],
                               (__bf16)ds[tm][1][0], (__bf16)ds[tm][1][1], (__bf16)ds[tm][1][2], (__bf16)ds[tm][1][3]};
       }
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const char* ad = sX + (32 * q + 16 * h + 8 * sp + (r >> 2)) * RB + (16 * ct + 4 * (r & 3)) * 2;
-          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad));
-          const s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(ad + 4 * RB));
-          const s16x8_t w = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
-          const bf16x8 af = __builtin_bit_cast(bf16x8, w);                 // X^T: channel 16 ct + r, streamed rows 32 q + 16 h + 8 sp + 0 .. 7
+      {   // 2 CT steps (ct, sp): X^T fragments (channel 16 ct + r, streamed rows 32 q + 16 h + 8 sp + 0 .. 7) by transposing reads, three steps ahead
+        constexpr int NC = 2 * CT;
+        const unsigned aT = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sX + (32 * q + 16 * h + (r >> 2)) * RB + (4 * (r & 3)) * 2);
+        u32x2 t1[4], t2[4];
+        auto issue = [&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ct = st_ / 2, sp = st_ % 2, off = 8 * sp * RB + 32 * ct;
+          lds_rdtr<off>(t1[st_ % 4], aT);
+          lds_rdtr<off + 4 * RB>(t2[st_ % 4], aT);
+        };
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        issue(std::integral_constant<int, 2>{});
+        static_for<0, NC>([&](auto ic) {
+          constexpr int st_ = decltype(ic)::value, ct = st_ / 2, sp = st_ % 2;
+          if constexpr (st_ + 3 < NC) issue(std::integral_constant<int, st_ + 3>{});
+          constexpr int pend = 2 * (NC - 1 - st_ < 3 ? NC - 1 - st_ : 3);
+          lds_waittr<pend>(t1[st_ % 4], t2[st_ % 4]);
+          const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4{t1[st_ % 4][0], t1[st_ % 4][1], t2[st_ % 4][0], t2[st_ % 4][1]});
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm) accY[tm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pb[tm][sp], accY[tm][ct], 0, 0, 0);
-        }
+        });
+      }
     }
   }
   // lane (r, q): the sum for own row 16 tm + r, channels 16 ct + 4 q + e  ->  dX += it
