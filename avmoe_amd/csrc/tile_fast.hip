@@ -249,6 +249,25 @@ __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const fl
   return acc;
 }
 
+// A block's per-frame constants go global -> LDS in BATCHES: U independent loads per thread in flight, then their stores.  As plain loops
+// (`for (i = tid; i < n; i += threads) lds[f(i)] = g[h(i)]`) the compiler kept them rolled -- load, s_waitcnt vmcnt(0), store, branch: one
+// memory round trip per element and thread, 24 in a row in kf_pre_lat_bwd's prologue (19 us per block, a quarter of the kernel; a
+// timing-only build without the fills: -103 us per cfg-2 step over the six kernels).  The loads are unconditional (clamped index: a load under a
+// condition is waited for on the spot), the stores conditional.  Used for the latent-token matrices (kf_pre_small, kf_pre_lat_bwd: 126 -> 101 us
+// and 47 -> 36 us at the two cfg-2 sites); the d x d matrices of mid_bwd / post_small / post_small_bwd measured the same either way and keep
+// the plain loops.
+template <int U, typename LD, typename ST>
+__device__ __forceinline__ void kf_fill(int n, int nthr, LD&& ld, ST&& st) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += U * nthr) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld(min(i0 + u * nthr, n - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * nthr < n) st(i0 + u * nthr, v[u]);
+  }
+}
+
 // ---- wave-per-expert form --------------------------------------------------------------------------------------------------
 // The waves of a block take DIFFERENT experts of the SAME 16-token tiles (wave = tile slot * E + expert), so the E 64-byte segments
 // of a Z-space row [group][expert][32] are requested within the same few hundred cycles -- one DRAM page, neighbouring sectors of
@@ -764,11 +783,10 @@ __global__ void __launch_bounds__(WE<E>::NTHR, LB_PRE) kf_pre_small(FPreArgs a, 
     if (ll < 0) continue;
     float* lt = s_dyn + ll * LATF;
     const float* tt = TT + ((long)s * t.El + ll) * FK * FK;
-    for (int i = threadIdx.x; i < FK * FK; i += NTHR) lt[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
-    for (int i = threadIdx.x; i < FK * FDD; i += NTHR) {
-      const int k = i >> 6, dd = i & 63;
-      lt[FK * LD32 + dd * LD32 + k] = TW[((long)s * t.KLT + (long)ll * FK + k) * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31)];
-    }
+    kf_fill<4>(FK * FK, NTHR, [&](int i) { return tt[i]; }, [&](int i, float v) { lt[(i & 31) * LD32 + (i >> 5)] = v; });     // transposed (mmT)
+    kf_fill<8>(FK * FDD, NTHR,
+               [&](int i) { const int k = i >> 6, dd = i & 63; return TW[((long)s * t.KLT + (long)ll * FK + k) * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31)]; },
+               [&](int i, float v) { const int k = i >> 6, dd = i & 63; lt[FK * LD32 + dd * LD32 + k] = v; });
     if (threadIdx.x < FK) lt[FK * LD32 + FDD * LD32 + threadIdx.x] = Tsum[(long)s * t.KLT + (long)ll * FK + threadIdx.x] / (float)t.C;
   }
   for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
@@ -1097,13 +1115,10 @@ __global__ void __launch_bounds__(256, LB_PRELB) kf_pre_lat_bwd(FPreLArgs a, con
     const int ee = a.e_of_lat[ll];
     float* lt = s_dyn + ll * LATF;
     const float* tt = TT + ((long)s * t.El + ll) * FK * FK;
-    for (int i = threadIdx.x; i < FK * FK; i += 256) lt[(i & 31) * LD32 + (i >> 5)] = tt[i];     // transposed (mmT)
-    for (int i = threadIdx.x; i < FK * FDD; i += 256) {
-      const int k = i >> 6, dd = i & 63;
-      const float v = TW[((long)s * t.KLT + (long)ll * FK + k) * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31)];
-      lt[FK * LD32 + k * LD64 + dd] = v;
-      lt[FK * LD32 + FK * LD64 + dd * LD32 + k] = v;
-    }
+    kf_fill<4>(FK * FK, 256, [&](int i) { return tt[i]; }, [&](int i, float v) { lt[(i & 31) * LD32 + (i >> 5)] = v; });     // transposed (mmT)
+    kf_fill<8>(FK * FDD, 256,
+               [&](int i) { const int k = i >> 6, dd = i & 63; return TW[((long)s * t.KLT + (long)ll * FK + k) * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31)]; },
+               [&](int i, float v) { const int k = i >> 6, dd = i & 63; lt[FK * LD32 + k * LD64 + dd] = v; lt[FK * LD32 + FK * LD64 + dd * LD32 + k] = v; });
     if (threadIdx.x < FK) lt[FK * LD32 + FK * LD64 + FDD * LD32 + threadIdx.x] = Tsum[(long)s * t.KLT + (long)ll * FK + threadIdx.x] / (float)t.C;
   }
   const float* s_TT = s_dyn + l * LATF;
