@@ -323,10 +323,63 @@ __global__ void __launch_bounds__(256) kk_softmax_rows_bwd(const void* a_, const
     }
   }
 }
+// the same with the row in registers (round 5): NV 4-entry vectors per lane (rows of up to 256 NV entries, ld % 4 == 0), every load
+// unconditional and in flight at once (clamped offset, entries beyond n zeroed afterwards), ONE pass over a and da.  The loops above stayed
+// rolled -- a two- and a four-byte load, a wait, an FMA per entry: 2 x 16 memory round trips per 1024-entry row.
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) kk_softmax_rows_bwd_reg(const void* a_, const float* da, long rows, int n, int ld, void* out_,
+                                                               void* outT_, int grp, int ld_t) {
+  const T* a = (const T*)a_;
+  T* out = (T*)out_; T* outT = (T*)outT_;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float4 av[NV], dv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = 4 * lane + 256 * k, jc = j < ld ? j : 0;
+      av[k] = ld4T<T>(a, row * ld + jc);
+      dv[k] = *(const float4*)(da + row * ld + jc);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = 4 * lane + 256 * k;
+      float* ae = (float*)&av[k];
+      const float* de = (const float*)&dv[k];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { if (j + x >= n) ae[x] = 0.f; dot += ae[x] * (j + x < n ? de[x] : 0.f); }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = 4 * lane + 256 * k;
+      if (j >= ld) continue;
+      const float* ae = (const float*)&av[k];
+      const float* de = (const float*)&dv[k];
+      float4 v;
+      float* ve = (float*)&v;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) ve[x] = j + x < n ? ae[x] * (de[x] - dot) : 0.f;
+      st4T<T>(out, row * ld + j, v);
+      if (outT) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          if (j + x < n) stT<T>(outT, ((row / grp) * n + j + x) * ld_t + (row % grp), ve[x]);
+      }
+    }
+  }
+}
 int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int n, int ld, void* out_dl, void* out_t, int grp,
                        int ldT, hipStream_t st) {
   ProfScope ps_("k_softmax_rows_bwd", 0.0, 0.0, st);
   if (rows <= 0) return OK;
+  if (ld % 4 == 0 && ld <= 1024 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)da % 16) == 0 && ((uintptr_t)out_dl % 16) == 0) {
+    const dim3 grid((unsigned)std::min<long>((rows + 3) / 4, 8192));
+    if (bf16) hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<__bf16, 4>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+    else hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<float, 4>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+    AVMOE_CHECK_LAUNCH("softmax_rows_bwd");
+    return OK;
+  }
   DISPATCH_T(bf16, kk_softmax_rows_bwd, dim3((unsigned)std::min<long>((rows + 3) / 4, 8192)), dim3(256), 0, st, a, da, rows, n, ld,
              out_dl, out_t, grp, ldT);
   AVMOE_CHECK_LAUNCH("softmax_rows_bwd");

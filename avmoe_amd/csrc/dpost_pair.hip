@@ -95,15 +95,16 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dpair(const DPairArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int g = blockIdx.y;
   const unsigned short* Bb = (const unsigned short*)p.Bpost + (long)g * p.sBg;
-  auto frag_mn = [&](int n, int k0) {          // channels k0 .. k0 + 7 of column n of Bpost ([channel][column])
+  auto frag_mn = [&](int n, int k0) {          // channels k0 .. k0 + 7 of column n of Bpost ([channel][column]); columns >= KP read as zero
+    // (every load unconditional -- clamped column, masked afterwards: under `if (n < KP)` each fragment was its own branch and full wait,
+    //  fourteen memory round trips in a row in front of the block's first tile)
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (n < p.KP) {
-      const unsigned short* bp = Bb + (long)k0 * p.ldb + n;
+    const unsigned short* bp = Bb + (long)k0 * p.ldb + min(n, p.KP - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned int h = (unsigned int)bp[(long)j * p.ldb];
-        v[j >> 1] |= (j & 1) ? (h << 16) : h;
-      }
+    for (int j = 0; j < 8; ++j) {
+      unsigned int h = (unsigned int)bp[(long)j * p.ldb];
+      h = n < p.KP ? h : 0u;
+      v[j >> 1] |= (j & 1) ? (h << 16) : h;
     }
     return v;
   };

@@ -644,11 +644,14 @@ __global__ void __launch_bounds__(256) kk_softmax_rows_reg(const float* in, long
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int j = 4 * lane + 256 * k;
-      v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      if (j < ld_in) {                                        // (a whole vector lies inside the padded row: ld_in % 4 == 0)
-        v[k] = *(const float4*)(p + j);
-        if (j + 3 >= n) { float* e = (float*)&v[k]; for (int x = 0; x < 4; ++x) if (j + x >= n) e[x] = -INFINITY; }
-      }
+      // (a whole vector lies inside the padded row: ld_in % 4 == 0.  The loads are UNCONDITIONAL -- clamped offset, entries beyond n replaced
+      //  afterwards -- so that all NV of a lane are in flight at once: under `if (j < ld_in)` each was its own branch and full wait.)
+      v[k] = *(const float4*)(p + (j < ld_in ? j : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = 4 * lane + 256 * k;
+      if (j + 3 >= n) { float* e = (float*)&v[k]; for (int x = 0; x < 4; ++x) if (j + x >= n) e[x] = -INFINITY; }
       mx = fmaxf(mx, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
     }
     mx = wave_max(mx);
