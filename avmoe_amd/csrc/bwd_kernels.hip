@@ -373,10 +373,15 @@ int k_softmax_rows_bwd(int bf16, const void* a, const float* da, long rows, int 
                        int ldT, hipStream_t st) {
   ProfScope ps_("k_softmax_rows_bwd", 0.0, 0.0, st);
   if (rows <= 0) return OK;
-  if (ld % 4 == 0 && ld <= 1024 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)da % 16) == 0 && ((uintptr_t)out_dl % 16) == 0) {
+  if (ld % 4 == 0 && ld <= 4096 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)da % 16) == 0 && ((uintptr_t)out_dl % 16) == 0) {
     const dim3 grid((unsigned)std::min<long>((rows + 3) / 4, 8192));
-    if (bf16) hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<__bf16, 4>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
-    else hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<float, 4>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+    if (ld <= 1024) {
+      if (bf16) hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<__bf16, 4>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+      else hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<float, 4>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+    } else {
+      if (bf16) hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<__bf16, 16>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+      else hipLaunchKernelGGL((kk_softmax_rows_bwd_reg<float, 16>), grid, dim3(256), 0, st, a, da, rows, n, ld, out_dl, out_t, grp, ldT);
+    }
     AVMOE_CHECK_LAUNCH("softmax_rows_bwd");
     return OK;
   }
@@ -671,16 +676,32 @@ __global__ void __launch_bounds__(256) kk_down_bwd(DownBwdArgs a, const float* d
   const float gb = (a.ln_before && on) ? a.lnbw.p[e][gi * a.Cg + c] : 1.f;
   const float bb = (a.ln_before && on) ? a.lnbb.p[e][gi * a.Cg + c] : 0.f;
   float dgb = 0.f, dbb = 0.f;
-  if (on)
-    for (int jp = u; jp < a.dg; jp += 4) {
-      const int row = (gi * a.E + e) * a.dgp + jp;
-      float dwt = dWt[(long)row * a.Cg + c];
-      float ddc = 0.f;
-      if (a.ln_before) { dwt += dsm[6 * a.DZ + row]; ddc = dsm[5 * a.DZ + row]; }
-      const float wd = a.down.p[e][(long)(gi * a.dg + jp) * a.Cg + c];
-      if (a.gdown.p[e]) a.gdown.p[e][(long)(gi * a.dg + jp) * a.Cg + c] = dwt * gb + ddc * bb;
-      dgb += dwt * wd; dbb += ddc * wd;
+  if (on) {
+    // batches of four rows: every load of a batch in flight before its stores (as one loop -- load, store, next row -- the store to the
+    // gradient, which the compiler cannot tell apart from the inputs, kept each row's loads behind the previous row's store: a memory
+    // round trip per row)
+    const float* dsm6 = a.ln_before ? dsm + 6 * a.DZ : nullptr;
+    const float* dsm5 = a.ln_before ? dsm + 5 * a.DZ : nullptr;
+    for (int jp0 = u; jp0 < a.dg; jp0 += 16) {
+      float dwt[4], ddc[4], wd[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int jp = min(jp0 + 4 * b, a.dg - 1), row = (gi * a.E + e) * a.dgp + jp;
+        dwt[b] = dWt[(long)row * a.Cg + c];
+        ddc[b] = 0.f;
+        if (a.ln_before) { dwt[b] += dsm6[row]; ddc[b] = dsm5[row]; }          // (a.ln_before: block-uniform)
+        wd[b] = a.down.p[e][(long)(gi * a.dg + jp) * a.Cg + c];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int jp = jp0 + 4 * b;
+        if (jp < a.dg) {
+          if (a.gdown.p[e]) a.gdown.p[e][(long)(gi * a.dg + jp) * a.Cg + c] = dwt[b] * gb + ddc[b] * bb;
+          dgb += dwt[b] * wd[b]; dbb += ddc[b] * wd[b];
+        }
+      }
     }
+  }
   red[0][u][l] = dgb; red[1][u][l] = dbb;
   __syncthreads();
   if (u == 0 && on && a.ln_before) {
