@@ -114,6 +114,8 @@ enum { GEMM_EPI_NONE = 0, GEMM_EPI_ROWSTATS = 1, GEMM_EPI_EXP = 2, GEMM_EPI_MULS
 // lse[r] = log sum_j exp(v[r][j]) from the (max, sum) parts of GEMM_EPI_ROWSTATS (rows = batch * M, tiles = ceil(N / 128))
 int gemm_row_lse(const float* row_part, long rows, int tiles, float* lse, hipStream_t stream);
 int launch_gemm_stream(const GemmArgs& args, hipStream_t stream);
+// Per-frame products of <= 64 rows against ONE shared K-major matrix (frame_gemm.hip); 0 = launched, 1 = shape not covered, < 0 error.
+int launch_gemm_frames(const GemmArgs& args, hipStream_t stream);
 
 // Two token contractions against the same (S, N, g * Cg) bf16 tensor X in ONE pass over it:
 //   C1[gi][i][j]  = sum over ALL tokens t   A1[t][gi * sA1g + i] * X[t][gi * Cg + j]      i < M1 <= 128   (split over frame chunks: slabs + reduce)

@@ -934,6 +934,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (!nostream && a.epi == GEMM_EPI_NONE && a.nb3 <= 1) {
       const int s = launch_gemm_stream(a, stream);
       if (s <= 0) return s;
+      const int f = launch_gemm_frames(a, stream);           // a few rows per frame against one shared matrix (frame_gemm.hip)
+      if (f <= 0) return f;
     }
   }
   if (a.Cx) { set_last_error("gemm: a split fp32 side output (Cx) is a feature of the streaming kernel only"); return ERR_UNSUPPORTED; }

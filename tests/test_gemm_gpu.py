@@ -373,3 +373,62 @@ def test_batch_fold_onto_the_big_tile(kw):
     assert err < (1e-2 if kw.get("out_bf16") else 1e-4), float(err)
     got, ref = _run_gemm(384, 1100, 520, 1, False, False, nb1=6, bcast_b=True, exact_ints=True, seed=4)
     assert torch.equal(got, ref)
+
+
+FRAME_SHAPES = [  # M, N, K, frames, rows per frame, bf16 output, C stored [n][m]     (K <= 256: the inner dimension frame_gemm.hip keeps B in registers for)
+    (64, 1024, 196, 40, 65, False, False), (64, 1025, 196, 33, 65, True, False), (64, 1024, 198, 32, 64, False, False), (64, 1024, 197, 48, 65, False, False),
+    (64, 200, 256, 40, 65, True, False), (17, 77, 225, 36, 20, False, False), (33, 130, 70, 35, 40, False, False), (1, 64, 32, 32, 1, True, False),
+    (48, 321, 135, 700, 50, False, False), (64, 801, 40, 64, 66, False, False),
+    (65, 1024, 197, 40, 65, False, False), (65, 130, 100, 33, 65, True, False), (50, 200, 60, 41, 50, False, False),      # frames without gaps: one tall matrix in groups of 64 rows
+    (64, 1024, 196, 40, 65, True, True), (64, 1024, 196, 36, 65, False, True), (62, 131, 250, 33, 70, True, True), (5, 64, 33, 32, 8, False, True),
+]
+
+
+@pytest.mark.parametrize("shape", FRAME_SHAPES)
+def test_frame_products_against_one_shared_matrix(shape):
+    """frame_gemm.hip (the hop-1 chain's middle: L1[s] = [R | qr | qb][s] [Wc | bc | 1]^T and its twins, moe_forward.cpp / moe_backward.cpp):
+    a few rows per frame against ONE shared K-major matrix over a short inner dimension.  Rows between the frames' blocks and the K padding
+    of A hold NaN, B's K padding garbage: none of it may leak; C outside the (frames, M, N) blocks keeps its sentinel; the kernel family must
+    be the one that ran."""
+    from avmoe_amd import _capi as capi
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    M, N, K, nb, rps, out_bf16, tr = shape
+    g = torch.Generator().manual_seed(5 + M + N + K)
+    Kp = -(-K // 8) * 8
+    A = torch.full((nb, rps, Kp), float("nan"), dtype=torch.bfloat16)
+    A[:, :M, :K] = torch.randn(nb, M, K, generator=g).to(torch.bfloat16)
+    Bm = torch.full((N, Kp), 7.0, dtype=torch.bfloat16)
+    Bm[:, :K] = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    ref = 0.5 * torch.matmul(A[:, :M, :K].double(), Bm[:, :K].double().t())
+    Nld, Mld = -(-N // 8) * 8 + 8, -(-M // 8) * 8 + 8
+    odt = torch.bfloat16 if out_bf16 else torch.float32
+    Cd = torch.full((nb, N + 3, Mld) if tr else (nb, rps, Nld), -5.0, dtype=odt)
+    Ad, Bd, Cd = A.to(dev), Bm.to(dev), Cd.to(dev)
+    d = capi.GemmDesc()
+    d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb, 1
+    d.dtype, d.out_dtype, d.a_layout, d.b_layout = capi.BF16, (capi.BF16 if out_bf16 else capi.F32), 0, 0
+    d.accumulate, d.ksplit, d.tile, d.alpha = 0, 1, 0, 0.5
+    d.lda, d.ldb, d.sA1, d.sA2, d.sB1, d.sB2 = Kp, Kp, rps * Kp, 0, 0, 0
+    if tr:
+        d.sCi, d.sCj, d.sC1 = 1, Mld, (N + 3) * Mld
+    else:
+        d.sCi, d.sCj, d.sC1 = Nld, 1, rps * Nld
+    L.avmoe_prof_reset(); L.avmoe_prof_enable(1)
+    try:
+        st = L.avmoe_gemm(C.byref(d), Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), None, None, None, torch.cuda.current_stream().cuda_stream)
+        capi.check(st, "avmoe_gemm")
+        torch.cuda.synchronize()
+        ran = [f["name"] for f in capi.prof_report()]
+    finally:
+        L.avmoe_prof_enable(0); L.avmoe_prof_reset()
+    assert any(n.startswith("gemm_frames") for n in ran), ran
+    got = Cd.double().cpu()
+    if tr:
+        val, rest = got[:, :N, :M].transpose(1, 2), torch.cat([got[:, N:, :].reshape(-1), got[:, :N, M:].reshape(-1)])
+    else:
+        val, rest = got[:, :M, :N], torch.cat([got[:, M:, :].reshape(-1), got[:, :M, N:].reshape(-1)])
+    assert torch.isfinite(val).all()
+    tol = (6e-3 if out_bf16 else 1e-4) * float(ref.abs().max())
+    assert float((val - ref).abs().max()) <= tol
+    assert bool((rest == -5.0).all())
