@@ -375,12 +375,16 @@ def test_batch_fold_onto_the_big_tile(kw):
     assert torch.equal(got, ref)
 
 
-FRAME_SHAPES = [  # M, N, K, frames, rows per frame, bf16 output, C stored [n][m]     (K <= 256: the inner dimension frame_gemm.hip keeps B in registers for)
+FRAME_SHAPES = [  # M, N, K, frames, rows per frame, bf16 output, C stored [n][m]     (K <= 256: B in registers; longer K: few columns only)
     (64, 1024, 196, 40, 65, False, False), (64, 1025, 196, 33, 65, True, False), (64, 1024, 198, 32, 64, False, False), (64, 1024, 197, 48, 65, False, False),
     (64, 200, 256, 40, 65, True, False), (17, 77, 225, 36, 20, False, False), (33, 130, 70, 35, 40, False, False), (1, 64, 32, 32, 1, True, False),
     (48, 321, 135, 700, 50, False, False), (64, 801, 40, 64, 66, False, False),
     (65, 1024, 197, 40, 65, False, False), (65, 130, 100, 33, 65, True, False), (50, 200, 60, 41, 50, False, False),      # frames without gaps: one tall matrix in groups of 64 rows
     (64, 1024, 196, 40, 65, True, True), (64, 1024, 196, 36, 65, False, True), (62, 131, 250, 33, 70, True, True), (5, 64, 33, 32, 8, False, True),
+    # K > 256 and N <= 224: the long form (frame pairs x all columns, K chunks streamed)
+    (64, 196, 1024, 48, 65, False, False), (64, 197, 1024, 41, 65, True, False), (64, 196, 1026, 36, 65, False, False), (65, 196, 1025, 33, 65, False, False),
+    (64, 196, 1024, 40, 65, True, True), (30, 100, 300, 33, 31, False, True), (64, 224, 257, 34, 64, True, False), (17, 64, 700, 35, 17, False, False),
+    (64, 130, 264, 33, 66, False, False),
 ]
 
 
