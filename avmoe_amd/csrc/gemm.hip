@@ -291,6 +291,108 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
 
 }
 
+// The K loop of a tile for two K-major bf16 operands (round 5, frame_gemm.hip's recipe; every tile size): chunks of BK K entries, [A BM rows | B BN rows]
+// of 2 BK bytes, go global -> LDS directly (1 KB pieces dealt to the waves, lane offsets once; the 16-byte pieces of a row XOR-swizzled by the row
+// index: fragment reads without bank conflicts and no pad), NST stages with counted vmcnt waits, one barrier per chunk; nothing is staged in
+// registers, nothing is written to the LDS by the waves, no condition inside the loop -- rows beyond M / N re-read the last one (never stored),
+// pieces beyond a row's K entries its last piece, and the chunk that holds kend masks its fragments.  Same accumulator layout as gemm_segment: the
+// epilogue is shared.
+#ifndef GEMM_BIG_DIRECT
+#define GEMM_BIG_DIRECT 1      // development: 0 = the register-staged loop (gemm_segment) for an A/B
+#endif
+#ifndef GEMM_TILE_DIRECT
+#define GEMM_TILE_DIRECT 1     // the same for the four-wave tiles (128 / 64 / 32)
+#endif
+#ifndef GEMM_BIG_BK
+#define GEMM_BIG_BK 64         // 64: two stages of 64 KB; 32: four stages of 32 KB (three chunks in flight)
+#endif
+template <int N> __device__ __forceinline__ void gemm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int BM, int BN, int NTHR, int WGN, int TM, int TN, int BK, int NST>
+__device__ __forceinline__ void gemm_segment_direct(char* smem, const char* Ab, const char* Bb, long lda, long ldb, int M, int N, int K, int m0, int n0,
+                                                    int kbeg, int kend, f32x4 (&acc)[TM][TN]) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int ROWB = 2 * BK, PPR = ROWB / 16, RPP = 64 / PPR;      // bytes / 16-byte pieces per row; rows per 1 KB piece
+  constexpr int NW = NTHR / 64, HA = BM * ROWB, HALF = HA, STAGE = (BM + BN) * ROWB, KS = BK / 32;      // K steps per chunk
+  constexpr int NLA = HA / 1024 / NW, NLB = BN * ROWB / 1024 / NW;      // 1 KB pieces per wave, of A and of B
+  static_assert(NLA >= 1 && NLB >= 1 && NLA * NW * 1024 == HA && NLB * NW * 1024 == BN * ROWB, "whole pieces per wave");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  const int wm0 = (wave / WGN) * (16 * TM), wn0 = (wave % WGN) * (16 * TN);
+  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const int cmax8 = (K + 7) / 8 - 1;                       // last 16-byte piece of a row that starts inside its K entries
+  auto swz = [](int row) { return PPR == 8 ? (row & 7) : ((row >> 2) & 3); };
+  // wave w loads pieces NLA w .. NLA w + NLA - 1 of A and NLB w .. of B
+  long offa[NLA], offb[NLB]; int ca[NLA], cb[NLB];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int row = (NLA * wave + i) * RPP + lane / PPR;
+    ca[i] = (lane % PPR) ^ swz(row);
+    offa[i] = (long)min(m0 + row, M - 1) * lda * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    const int row = (NLB * wave + i) * RPP + lane / PPR;
+    cb[i] = (lane % PPR) ^ swz(row);
+    offb[i] = (long)min(n0 + row, N - 1) * ldb * 2;
+  }
+  auto gload = [&](int kt) {
+    char* d = smem + (kt % NST) * STAGE;
+    const int k8 = (kbeg + kt * BK) / 8;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + offa[i] + min(k8 + ca[i], cmax8) * 16), (lptr_t)(d + 1024 * (NLA * wave + i)), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NLB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bb + offb[i] + min(k8 + cb[i], cmax8) * 16), (lptr_t)(d + HALF + 1024 * (NLB * wave + i)), 16, 0, 0);
+  };
+  int fa[KS], fb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    fa[ks] = (wm0 + r) * ROWB + (((4 * ks + q) ^ swz(r)) * 16);
+    fb[ks] = HALF + (wn0 + r) * ROWB + (((4 * ks + q) ^ swz(r)) * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (j < nkt) gload(j);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // in-order counter: the NLA + NLB loads of each chunk requested after chunk kt may stay in flight
+    const int newer = min(NST - 2, nkt - 1 - kt);
+    if (newer <= 0) gemm_wait_vm<0>();
+    else if (newer == 1) gemm_wait_vm<NLA + NLB>();
+    else gemm_wait_vm<2 * (NLA + NLB)>();
+    __builtin_amdgcn_s_barrier();                            // everybody's pieces of chunk kt have landed, and everybody is done reading the stage requested next
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nkt) gload(kt + NST - 1);
+    const char* sS = smem + (kt % NST) * STAGE;
+    const int k0 = kbeg + kt * BK;
+    const bool tail = k0 + BK > kend;                        // (block-uniform)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 af[TM], bfr[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) af[tm] = *(const u32x4*)(sS + fa[ks] + tm * 16 * ROWB);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bfr[tn] = *(const u32x4*)(sS + fb[ks] + tn * 16 * ROWB);
+      if (tail) {
+        const int nv = kend - (k0 + 32 * ks + 8 * q);        // this lane's eight K entries that belong to the segment
+        u32x4 mk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mk[e] = (2 * e + 1 < nv) ? 0xffffffffu : ((2 * e < nv) ? 0x0000ffffu : 0u);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) af[tm] &= mk;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfr[tn] &= mk;
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[tm]), __builtin_bit_cast(bf16x8, bfr[tn]), acc[tm][tn], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                           // the epilogue reuses the buffer
+}
+
 template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2>
 __global__ void __launch_bounds__(256, (std::is_same<T, f32s3>::value ? 2 : 1)) gemm_kernel(const DevArgs p) {
   constexpr int ESZ = sizeof(T);
@@ -325,7 +427,8 @@ __global__ void __launch_bounds__(256, (std::is_same<T, f32s3>::value ? 2 : 1)) 
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  gemm_segment<T, BM, BN, AMN, BMN, TM, TN>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend, acc);
+  if constexpr (std::is_same<T, __bf16>::value && !AMN && !BMN && GEMM_TILE_DIRECT) gemm_segment_direct<BM, BN, 256, 2, TM, TN, 64, 2>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, p.K, m0, n0, kbeg, kend, acc);
+  else gemm_segment<T, BM, BN, AMN, BMN, TM, TN>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend, acc);
   if constexpr (SEG2) {     // second K segment: A2 K-major, B2 MN-major, own batch strides (C += A2 . B2^T)
     const char* A2 = p.A2 + ((long)b1 * p.s2A1 + (long)b2 * p.s2A2) * ESZ;
     const char* B2 = p.B2 + ((long)b1 * p.s2B1 + (long)b2 * p.s2B2) * ESZ;
@@ -512,80 +615,6 @@ __global__ void __launch_bounds__(256, (std::is_same<T, f32s3>::value ? 2 : 1)) 
   }
 }
 
-// The K loop of the 256 x 256 tile for two K-major bf16 operands (round 5, frame_gemm.hip's recipe): 64-K chunks [A 256 x 128 B | B 256 x 128 B] go
-// global -> LDS directly (1 KB pieces, eight per wave and chunk, lane offsets once; 16-byte piece c of row t at position c ^ (t & 7): fragment
-// reads without bank conflicts and no pad), two stages, one barrier per chunk; nothing is staged in registers, nothing is written to the LDS by
-// the waves, no condition inside the loop -- rows beyond M / N re-read the last one (never stored), pieces beyond a row's K entries its last piece,
-// and the chunk that holds kend masks its fragments.  Same accumulator layout as gemm_segment: the epilogue is shared.
-#ifndef GEMM_BIG_DIRECT
-#define GEMM_BIG_DIRECT 1      // development: 0 = the register-staged loop (gemm_segment) for an A/B
-#endif
-__device__ __forceinline__ void gemm_segment_direct256(char* smem, const char* Ab, const char* Bb, long lda, long ldb, int M, int N, int K, int m0, int n0,
-                                                       int kbeg, int kend, f32x4 (&acc)[8][4]) {
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  constexpr int BK = 64, HALF = 256 * 128, STAGE = 2 * HALF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
-  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-  const int cmax8 = (K + 7) / 8 - 1;                       // last 16-byte piece of a row that starts inside its K entries
-  // wave w loads pieces 4 w .. 4 w + 3 of A and of B (piece = eight rows)
-  long offa[4], offb[4]; int cc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (4 * wave + i) * 8 + (lane >> 3);
-    cc[i] = (lane & 7) ^ (row & 7);
-    offa[i] = (long)min(m0 + row, M - 1) * lda * 2;
-    offb[i] = (long)min(n0 + row, N - 1) * ldb * 2;
-  }
-  auto gload = [&](int kt) {
-    char* d = smem + (kt & 1) * STAGE + 4096 * wave;
-    const int k8 = (kbeg + kt * BK) / 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = min(k8 + cc[i], cmax8) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + offa[i] + c), (lptr_t)(d + 1024 * i), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Bb + offb[i] + c), (lptr_t)(d + HALF + 1024 * i), 16, 0, 0);
-    }
-  };
-  const int fa0 = (wm0 + r) * 128 + ((q ^ (r & 7)) * 16), fa1 = (wm0 + r) * 128 + (((4 + q) ^ (r & 7)) * 16);
-  const int fb0 = HALF + (wn0 + r) * 128 + ((q ^ (r & 7)) * 16), fb1 = HALF + (wn0 + r) * 128 + (((4 + q) ^ (r & 7)) * 16);
-  if (nkt > 0) gload(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk kt have landed ...
-    __builtin_amdgcn_s_barrier();                            // ... everybody's have, and everybody is done reading the other stage
-    asm volatile("" ::: "memory");
-    if (kt + 1 < nkt) gload(kt + 1);
-    const char* sS = smem + (kt & 1) * STAGE;
-    const int k0 = kbeg + kt * BK;
-    const bool tail = k0 + BK > kend;                        // (block-uniform)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4 af[8], bfr[4];
-#pragma unroll
-      for (int tm = 0; tm < 8; ++tm) af[tm] = *(const u32x4*)(sS + (ks ? fa1 : fa0) + tm * 2048);
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) bfr[tn] = *(const u32x4*)(sS + (ks ? fb1 : fb0) + tn * 2048);
-      if (tail) {
-        const int nv = kend - (k0 + 32 * ks + 8 * q);        // this lane's eight K entries that belong to the segment
-        u32x4 mk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mk[e] = (2 * e + 1 < nv) ? 0xffffffffu : ((2 * e < nv) ? 0x0000ffffu : 0u);
-#pragma unroll
-        for (int tm = 0; tm < 8; ++tm) af[tm] &= mk;
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) bfr[tn] &= mk;
-      }
-#pragma unroll
-      for (int tm = 0; tm < 8; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[tm]), __builtin_bit_cast(bf16x8, bfr[tn]), acc[tm][tn], 0, 0, 0);
-    }
-  }
-  __syncthreads();                                           // the epilogue reuses the buffer
-}
-
 // Large plain products (both extents in the thousands: the token remap's logits / weight gradients at the stage-0 sites of the real
 // backbones, N x M = 4096 x 2304 ..): 256 x 256 block tile, 8 waves (2 x 4, a wave owns 128 x 64 = 32 MFMA tiles: 12 LDS fragment
 // reads feed 32 MFMAs per K step, against 8 for 16 on the 128 x 128 tile, whose LDS traffic bounds it at ~0.55 PFLOP/s).  bf16
@@ -617,7 +646,7 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(const DevArgs p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (!AMN && !BMN && GEMM_BIG_DIRECT) gemm_segment_direct256(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, p.K, m0, n0, kbeg, kend, acc);
+  if constexpr (!AMN && !BMN && GEMM_BIG_DIRECT) gemm_segment_direct<256, 256, 512, 4, 8, 4, GEMM_BIG_BK, (GEMM_BIG_BK == 64 ? 2 : 4)>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, p.K, m0, n0, kbeg, kend, acc);
   else gemm_segment<__bf16, BM, BN, AMN, BMN, TM, TN, NTHR, WGN>(smem, Ab, Bb, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend, acc);
 
   constexpr int CLD = BN + 4;
