@@ -53,10 +53,39 @@ def lib():
     L.avmoe_prof_reset.restype = None
     L.avmoe_prof_report.restype = C.c_size_t
     L.avmoe_prof_report.argtypes = [C.c_char_p, C.c_size_t]
+    L.avmoe_test_hooks.restype = C.c_uint32
+    L.avmoe_test_hooks.argtypes = [C.c_uint32, C.c_int32]
     from . import _capi_moe
     _capi_moe.declare(L)
     _lib = L
     return L
+
+
+HOOK_TOKPAIR2_FORCE, HOOK_DPAIR_FORCE, HOOK_HOP1S_FORCE, HOOK_KFS_FORCE, HOOK_KFS_OFF = 1, 2, 4, 8, 16
+HOOK_ALL_FORCE = 1 | 2 | 4 | 8          # every size threshold lifted: small shapes through the benchmarked kernels
+# what this process last set (force mask, nxn chunk); like the library's own initial values, seeded from the environment once
+_hooks = [(1 if os.environ.get("AVMOE_TOKPAIR2_FORCE") is not None else 0) | (2 if os.environ.get("AVMOE_DPAIR_FORCE") is not None else 0)
+          | (4 if os.environ.get("AVMOE_HOP1S_FORCE") is not None else 0) | (8 if os.environ.get("AVMOE_KFS_FORCE") is not None else 0)
+          | (16 if os.environ.get("AVMOE_KFS_OFF") is not None else 0), max(0, int(os.environ.get("AVMOE_NXN_CHUNK", "0") or 0))]
+
+
+class test_hooks:
+    """Context manager around avmoe_test_hooks (include/avmoe.h): lifts the streaming kernels' size thresholds / sets the N x N
+    block's frames per chunk for the calls inside it, and restores what was set before.  Tests and bench.py's parity leg only."""
+
+    def __init__(self, force_mask: int = 0, nxn_chunk: int = 0):
+        self.new = (int(force_mask), int(nxn_chunk))
+
+    def __enter__(self):
+        self.old = tuple(_hooks)
+        _hooks[:] = self.new
+        lib().avmoe_test_hooks(*self.new)
+        return self
+
+    def __exit__(self, *exc):
+        _hooks[:] = self.old
+        lib().avmoe_test_hooks(*self.old)
+        return False
 
 
 def check(status: int, what: str = "avmoe"):

@@ -140,6 +140,12 @@ int avmoe_moe_buffer_info(const avmoe_moe_desc* desc, int32_t index, const char*
 }
 
 
+uint32_t avmoe_test_hooks(uint32_t force_mask, int32_t nxn_chunk) {
+  const unsigned prev = test_hook_mask();
+  set_test_hooks(force_mask, nxn_chunk);
+  return prev;
+}
+
 void avmoe_prof_enable(int on) { prof_enable(on != 0); }
 void avmoe_prof_reset(void) { prof_reset(); }
 size_t avmoe_prof_report(char* buf, size_t cap) { return prof_report(buf, cap); }

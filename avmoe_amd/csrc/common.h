@@ -46,9 +46,11 @@ const char* last_error();
 
 // Development switches (A/B toggles, sweep overrides: scripts/README.md) exist only in builds made with -DAVMOE_DEV
 // (AVMOE_DEV_BUILD=1 python -m avmoe_amd.build); the product library never reads them.  Four environment variables are part of
-// the product and read with plain getenv: AVMOE_PROF_SHAPES (profiler families per launch shape, prof.cpp), AVMOE_NO_SIDE /
-// AVMOE_SIDE_MIN (helper streams inside a call: off / smallest site in token elements that forks, side.cpp, moe_run.h) and
-// AVMOE_NXN_CHUNK (test hook: frames per chunk of the AVVP N x N block, moe_plan.cpp).
+// the product and read with plain getenv, ONCE per process: AVMOE_PROF_SHAPES (profiler families per launch shape, prof.cpp),
+// AVMOE_NO_SIDE / AVMOE_SIDE_MIN (helper streams inside a call: off / smallest site in token elements that forks, side.cpp,
+// moe_run.h).  The test hooks (size thresholds of the streaming kernels lifted, frames per chunk of the AVVP N x N block) are
+// process state set through avmoe_test_hooks (include/avmoe.h); the environment variables of the same names seed them when the
+// library is first asked -- no kernel choice depends on the environment at call time.
 #ifdef AVMOE_DEV
 static inline const char* dev_env(const char* name) { return getenv(name); }
 #else
@@ -61,6 +63,12 @@ struct LdsAttrOnce {
   bool done[64] = {};
   int ensure(const void* fn, int bytes, const char* what);      // OK / ERR_LAUNCH ; no-op for <= 64 KiB and after the first call per device
 };
+
+// test hooks (include/avmoe.h: avmoe_test_hooks); seeded once from AVMOE_TOKPAIR2_FORCE / AVMOE_DPAIR_FORCE / AVMOE_HOP1S_FORCE / AVMOE_NXN_CHUNK
+enum { HOOK_TOKPAIR2_FORCE = 1, HOOK_DPAIR_FORCE = 2, HOOK_HOP1S_FORCE = 4, HOOK_KFS_FORCE = 8, HOOK_KFS_OFF = 16 };
+unsigned test_hook_mask();
+int test_hook_nxn_chunk();                   // 0 = the library's own choice
+void set_test_hooks(unsigned mask, int nxn_chunk);
 
 // compute units of the current device (cached per device; <= 0 on a failed query)
 int cu_count();

@@ -254,8 +254,8 @@ int k_dpost_pair(const void* dOut, long ldo, const void* Bpost, long ldb, long s
   if (Cg != 384 || nmain != 128 || KPp != 144 || KP <= 128 || KP > 144 || KP % 4 || ((uintptr_t)dBp % 16) || XW < 16 || ntok % BM || ldo % 8 || lda % 8 || !slabs ||
       ((uintptr_t)dOut % 16) || ((uintptr_t)Apost % 16) || ((uintptr_t)dAp % 8) || ((uintptr_t)dApx % 16) || ldx % 4 || (G * XW) % 4)
     return 1;
-  // small sites: the two kernels (the 128-slab reduction alone costs 11 us; measured at 20 480 tokens: 44 us against 37); AVMOE_DPAIR_FORCE: test hook
-  if (ntok < 32768 && !(ntok >= 4096 && getenv("AVMOE_DPAIR_FORCE"))) return 1;
+  // small sites: the two kernels (the 128-slab reduction alone costs 11 us; measured at 20 480 tokens: 44 us against 37); avmoe_test_hooks bit 2: test hook
+  if (ntok < 32768 && !(ntok >= 4096 && (test_hook_mask() & HOOK_DPAIR_FORCE))) return 1;
   const int cus = cu_count();                             // (cached per device: common.cpp)
   if (cus <= 0) { set_last_error("dpost_pair: device query"); return ERR_LAUNCH; }
   const int ntiles = cdiv(ntok, BM);

@@ -389,8 +389,8 @@ __global__ void __launch_bounds__(256) kk_hop1_sum(const float* __restrict__ sla
 
 // Sites of fewer than 32 768 tokens of Y keep the tiled engine: a persistent block per CU then has two or three tiles (or a single frame)
 // to amortise its prologue over and the engine's small tiles fill the chip better (measured at 20 480 tokens: yk 20.7 us against 12 - 15,
-// per-frame yt 32.9 against ~18).  AVMOE_HOP1S_FORCE (test hook, read per call like AVMOE_TOKPAIR2_FORCE): small sites as well.
-bool hop1s_small(long ntok) { return ntok < 32768 && getenv("AVMOE_HOP1S_FORCE") == nullptr; }
+// per-frame yt 32.9 against ~18).  avmoe_test_hooks bit 4 (test hook): small sites as well.
+bool hop1s_small(long ntok) { return ntok < 32768 && !(test_hook_mask() & HOOK_HOP1S_FORCE); }
 
 }  // namespace
 

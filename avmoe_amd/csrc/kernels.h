@@ -111,6 +111,11 @@ int kf_mid(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 int kf_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 int kf_pre_lat_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+// the same kernels in streaming form (tile_stream.hip: one persistent block per CU, wave-private LDS rings filled by direct loads);
+// 0 = launched, 1 = not served (run the kf_* kernel), < 0 error
+bool tile_stream_ok(const Dims& d);
+bool kfs_serves_post_small_bwd(const Dims& d, int dap16);
+int kfs_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st, int dap16);
 // register-resident kernels generalised over groups (1 / 2 / 4), per-group bottleneck (16 .. 96) and latent slots (16 / 32 / 96): tile_gen.hip
 bool tile_gen_ok(const Dims& d);
 int kg_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);

@@ -102,7 +102,9 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   // ---- phase 2: bottleneck space (LayerNorm-post statistics), then weight space ------------------
   AVMOE_TRY(k_post_small_bwd(pl, sv, sc, prm, grads, st, dap16));
   BWD_STOP(2);
-  if (d.ln_post && d.gram64) {                             // dG[i][e] = sum_t dSoo z' z'^T : one streaming pass over z (z' formed on the fly)
+  if (d.ln_post && d.gram64 && tile_fast_ok(d) && kfs_serves_post_small_bwd(d, dap16)) {
+    // (dGq came out of post_small_bwd's own pass: tile_stream.hip)
+  } else if (d.ln_post && d.gram64) {                      // dG[i][e] = sum_t dSoo z' z'^T : one streaming pass over z (z' formed on the fly)
     AVMOE_TRY(k_gram64(pl, sv + pl.o_Z, (const float*)(sc + pl.o_dSooT), 1.f, (float*)(sc + pl.o_gpartT), (float*)(sc + pl.o_dGq), st,
                        (const float*)(sv + pl.o_bn1)));
   } else if (d.ln_post) {                                  // ... as batched engine GEMMs on Zw = dSoo z'

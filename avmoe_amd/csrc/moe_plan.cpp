@@ -155,14 +155,14 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.nxc = d.S;
   d.nflash = d.nxn && !d.mha && nxn_att_ok(d.bf16, d.N, d.C, (int)round_up(d.N, 8)) && !dev_env("AVMOE_NXN_OLD_BWD");
   if (d.nflash) {
-    if (const char* ev = getenv("AVMOE_NXN_CHUNK")) d.nxc = std::max(1, std::min(d.S, atoi(ev)));     // tests: the frame loop of the strip kernels
+    if (const int ch = test_hook_nxn_chunk()) d.nxc = std::max(1, std::min(d.S, ch));     // tests (avmoe_test_hooks): the frame loop of the strip kernels
   } else if (d.nxn && !d.mha) {
     const size_t per_frame = (size_t)d.N * round_up(d.N, 8) * (2 * (size_t)d.esz);      // att + dSc (the scores / d att themselves never leave the chip)
     const size_t keep_all = (size_t)256 << 20;
     size_t budget = (size_t)2048 << 20;          // chunk workspace (scratch, reused by every site)
     if (const char* ev = dev_env("AVMOE_NXN_BUDGET_MB")) budget = (size_t)std::max(1, atoi(ev)) << 20;      // dev: sweep
     if ((size_t)d.S * per_frame > keep_all) d.nxc = (int)std::max<size_t>(1, std::min<size_t>((size_t)d.S, budget / per_frame));
-    if (const char* ev = getenv("AVMOE_NXN_CHUNK")) d.nxc = std::max(1, std::min(d.S, atoi(ev)));     // tests: force the chunked path on small shapes
+    if (const int ch = test_hook_nxn_chunk()) d.nxc = std::max(1, std::min(d.S, ch));     // tests (avmoe_test_hooks): force the chunked path on small shapes
   }
   d.Mk = (int)round_up(d.M + 2, 8);
   d.Mb = (int)round_up(d.M + 1, 8);

@@ -14,6 +14,7 @@ namespace avmoe {
 
 constexpr int MAX_E = AVMOE_MAX_EXPERTS;
 constexpr int GRAM_BLOCKS = 512;   // blocks (= partial sums) of the streaming Gram kernel
+constexpr int GRAM_SLABS = 1024;   // slabs of the Gram partial-sum workspace (tile_stream.hip: blocks x tile slots)
 
 struct Dims {
   // raw
@@ -147,7 +148,7 @@ struct Dims {
   X(Zp, 1, d.esz, (size_t)d.NT * d.DZ)              /* z'                              */       \
   X(gcolT, 1, 4, d.gram64 ? (size_t)GRAM_BLOCKS * d.DZ : 1)   /* per-block column sums of z' (Gram kernel)   */    \
   X(dSooT, 1, 4, d.gram64 ? (size_t)d.E * d.NT : 1)      /* dSoo per (expert, token)            */    \
-  X(gpartT, 1, 4, d.gram64 ? (size_t)GRAM_BLOCKS * d.g * d.E * d.dgp * d.dgp : 1)  /* Gram partials */ \
+  X(gpartT, 1, 4, d.gram64 ? (size_t)GRAM_SLABS * d.g * d.E * d.dgp * d.dgp : 1)  /* Gram partials */ \
   X(Zw, 1, d.esz, (size_t)d.NT * d.DZ)              /* dSoo z' ; later dZx            */       \
   X(colpart, 1, 4, (size_t)d.nblk_tok * 4 * d.DZ)   /* per-block column partial sums  */       \
   X(colsum, 1, 4, (size_t)4 * d.DZ)                 /* colpart summed over blocks     */       \

@@ -1072,10 +1072,13 @@ static int pick_waves(size_t fixed_floats, size_t per_wave_floats, size_t* bytes
 
 int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st, int dap16) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_post_small_bwd", (long)d.NT, bytes_post_small_bwd(d) - (dap16 ? (double)d.NT * d.g * (d.E * d.dgp * 2.0 + (d.KPp - 16) * 4.0 - d.E * d.dgp * 2.0) : 0.0), 0.0, st);
+  const bool stream = tile_fast_ok(d) && kfs_serves_post_small_bwd(d, dap16);
+  ProfScope ps_(stream ? "k_post_small_bwd (stream)" : "k_post_small_bwd", (long)d.NT, bytes_post_small_bwd(d) - (dap16 ? (double)d.NT * d.g * (d.E * d.dgp * 2.0 + (d.KPp - 16) * 4.0 - d.E * d.dgp * 2.0) : 0.0), 0.0, st);
   if (dap16 && !tile_fast_ok(d) && !d.gen) { set_last_error("post_small_bwd: split dApost needs a register-resident path"); return ERR_BAD_ARG; }
   if (tile_fast_ok(d)) {
-    AVMOE_TRY(kf_post_small_bwd(pl, saved, scratch, prm, st, dap16));
+    const int rc = kfs_post_small_bwd(pl, saved, scratch, prm, st, dap16);       // streaming form (large bf16 sites); 1 = not served
+    if (rc < 0) return rc;
+    if (rc == 1) AVMOE_TRY(kf_post_small_bwd(pl, saved, scratch, prm, st, dap16));
     return k_post_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
   }
   if (d.gen) {

@@ -317,7 +317,7 @@ int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* 
   if (Cg != 384 || M1 != 128 || KL < 1 || KL > 64 || ldl < 72 || N < 8 || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || !slabs ||
       ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dWt % 16) || ((uintptr_t)dT % 16) || (G * 384) % 4)
     return 1;
-  const bool force = getenv("AVMOE_TOKPAIR2_FORCE") != nullptr;             // test hook (read by the product build too, per call: tests / bench.py's parity leg switch it inside one process): small sites as well
+  const bool force = (test_hook_mask() & HOOK_TOKPAIR2_FORCE) != 0;          // test hook (avmoe_test_hooks: tests / bench.py's parity leg switch it inside one process): small sites as well
   if (!force && (long)S * N < 32768) return 1;                              // small sites: the tiled form fills the chip better
   const int cus = cu_count();                             // (cached per device: common.cpp)
   if (cus <= 0) { set_last_error("tok_pair2: device query"); return ERR_LAUNCH; }

@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
-ROUND = "r05"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
+ROUND = "r06"                    # profiles/<ROUND>_pmc_traffic.json is the PMC pass that belongs to this build
 
 # ---- workloads --------------------------------------------------------------------------------
 # a site pair: (C_a, N_a, C_v, N_v, count) -- `count` identical pairs (block pairs of the stage x positions p1, p2)
@@ -203,21 +203,12 @@ def cpu_baseline(c, budget_s=15.0, min_timed=3):
 
 
 def parity_check(c, material, device, pair_mode="concurrent"):
-    """parity_check_ with the library's size thresholds lifted (test hooks AVMOE_TOKPAIR2_FORCE / AVMOE_DPAIR_FORCE, read per call): the
+    """parity_check_ with the library's size thresholds lifted (avmoe_test_hooks): the
     B = 2 shapes then run through the SAME streaming kernels (dpost_pair, tok_pair2) the timed region's full batch takes."""
-    hooks = ("AVMOE_TOKPAIR2_FORCE", "AVMOE_DPAIR_FORCE", "AVMOE_HOP1S_FORCE")
-    old = {k: os.environ.get(k) for k in hooks}
-    for k in hooks:
-        os.environ[k] = "1"
-    try:
+    from avmoe_amd import _capi
+    with _capi.test_hooks(_capi.HOOK_ALL_FORCE):
         res = parity_check_(c, material, device, pair_mode)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    res["kernels"] = "the timed region's: size thresholds of dpost_pair / tok_pair2 / hop1_stream lifted for the B = 2 shapes (AVMOE_*_FORCE)"
+    res["kernels"] = "the timed region's: size thresholds of dpost_pair / tok_pair2 / hop1_stream / tile_stream lifted for the B = 2 shapes (avmoe_test_hooks)"
     return res
 
 
@@ -497,7 +488,9 @@ class Workload:
                     pr.same_stream = bool(on)
         return prev
 
-    def step(self, sync=True):
+    def step(self, sync=True, keep=None):
+        """keep: a list that receives clones of every gradient of the step (token gradients per pair, then the flat parameter-gradient
+        buckets) -- the two-stream / one-stream comparison after the timed region"""
         import torch
         c, reducer = self.c, self.reducer
         reducer.begin(sync=sync)
@@ -528,10 +521,28 @@ class Workload:
                 torch.autograd.backward([out_a, out_v] + extra, [w["ga4"], w["gv4"]] + [None] * len(extra))
                 # the pairs of a shape share the synthetic inputs, not the modules: every pair's input gradients are its own (in the
                 # model they flow into different layers), so they are dropped here instead of being summed over the pairs
+                if keep is not None:
+                    keep += [w["f_a"].grad.detach().clone(), w["f_v"].grad.detach().clone()]
                 w["f_a"].grad = None
                 w["f_v"].grad = None
         reducer.finish()
+        if keep is not None:
+            torch.cuda.synchronize()
+            keep += [b.flat.detach().clone() for b in reducer.buckets if b.flat is not None]
         reducer.zero_grad(lazy=True)           # site slices are overwritten by the next backward: no fill launch (dp.py)
+
+    def two_stream_bit_equal(self):
+        """One step in the mode of the timed region (two streams per pair) and one with the same schedule issued on ONE stream, on the
+        same inputs and parameters: every gradient equal bit for bit?  (The kernels, their launch shapes and summation orders are the
+        same; what differs is that another stream's kernels share the GPU -- DESIGN section 5, the compute-unit co-residency effect.)"""
+        import torch
+        a, b = [], []
+        self.step(sync=False, keep=a)
+        prev = self.set_same_stream(True)
+        self.step(sync=False, keep=b)
+        self.set_same_stream(prev)
+        torch.cuda.synchronize()
+        return len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
 
     def timed(self, steps, warmup):
         """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over the ranks."""
@@ -750,6 +761,11 @@ def main():
                                                 gbs=round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1))
                                            for r in rep], key=lambda r: -r["ms_per_step"])[:12]
 
+    if isinstance(roofline, dict) and rank == 0 and pair_mode == "concurrent":
+        reps = [wl.two_stream_bit_equal() for _ in range(3)]
+        roofline["two_stream_bit_equal"] = all(reps)
+        roofline["two_stream_note"] = ("3 x (one step on two streams, one with the same schedule on one stream; same inputs): every token and parameter "
+                                       "gradient bit-identical -- the co-residency guard of include/avmoe.h (shared_gpu) on the timed configuration")
     wl.release()
     value_f32 = None
     if dtype == "bf16" and not args.no_f32 and world == 1:
@@ -842,6 +858,17 @@ def main():
             roofline["ok_bf16_grads"] = (parity or {}).get("ok_bf16_grads")
             roofline["b2_ms_per_step"] = b2["ms_per_step"] if b2 else None
             roofline["launches_per_step_b2"] = b2["launches_per_step"] if b2 else None
+            # the scalars a reader wants first come first (a record that keeps only the leading scalar members keeps these); long strings,
+            # per-config parity flags and the list-valued members go last
+            lead = ("bound", "achieved", "peak", "unit", "frac", "traffic", "f32_value", "f32_ms_per_step", "parity_ok", "ok_bf16_grads",
+                    "cfg1_ms_per_step", "cfg3_ms_per_step", "cfg4_ms_per_step", "cfg5_ms_per_step", "b2_ms_per_step", "launches_per_step",
+                    "dominant_kernel", "dominant_frac", "dominant_us", "dominant_traffic", "two_stream_bit_equal", "gpu_time_ms_per_step",
+                    "launches_per_step_b2", "dominant_gbs", "mfma_frac", "mfma_tflops")
+            tail = ("level", "traffic_source", "traffic_note", "dominant_variant", "dominant_detail", "families")
+            ordered = {k: roofline[k] for k in lead if k in roofline}
+            ordered.update({k: v for k, v in roofline.items() if k not in lead and k not in tail})
+            ordered.update({k: roofline[k] for k in tail if k in roofline})
+            roofline = line["roofline"] = ordered
         if rccl:
             line.update(rccl_ranks=rccl["rccl_ranks"], grad_allreduce_bytes=rccl["grad_allreduce_bytes"], allreduce_buckets=rccl["buckets"],
                         exposed_allreduce_ms=rccl["exposed_allreduce_ms"], rccl=rccl)

@@ -9,7 +9,8 @@
  *   - every pointer is a DEVICE pointer unless said otherwise; the library never allocates or frees
  *     caller memory; scratch comes from a caller-provided workspace
  *   - all entry points are asynchronous on `stream`, re-entrant across streams, and keep no global
- *     mutable state besides a thread-local error string
+ *     mutable state besides a thread-local error string, the optional profiler (avmoe_prof_*) and the
+ *     test hooks (avmoe_test_hooks); the environment is read ONCE per process, never per call
  *   - return 0 on success, negative on error (avmoe_last_error() has the message)
  */
 #ifndef AVMOE_H_
@@ -22,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AVMOE_ABI_VERSION 10
+#define AVMOE_ABI_VERSION 11
 
 enum { AVMOE_OK = 0, AVMOE_ERR_BAD_ARG = -1, AVMOE_ERR_UNSUPPORTED = -2, AVMOE_ERR_ALIGNMENT = -3,
        AVMOE_ERR_WORKSPACE = -4, AVMOE_ERR_LAUNCH = -5 };
@@ -226,6 +227,17 @@ int avmoe_add2(void* dst1, const void* src1, int64_t n1, void* dst2, const void*
  * every frame from probs (S, E) f32, most probable first, equal probabilities in expert order -- column 0 is the forward's
  * first-max argmax.  The mixture itself stays dense (net_trans_v3.py:482-486).                                          */
 int avmoe_router_topk(const float* probs, int64_t S, int32_t E, int32_t k, int64_t* idx, void* stream);
+
+/* ---- test hooks (ABI 11; process-wide; tests and bench.py's parity leg only) ---------------------------
+ * The streaming kernels (csrc/dpost_pair.hip, tok_pair2.hip, hop1_stream.hip) serve sites from 32 768 tokens on; below that the
+ * tiled engine is faster.  force_mask lifts those thresholds so that a test can run the benchmarked kernels on shapes its oracle
+ * finishes in seconds: bit 1 = tok_pair2, 2 = dpost_pair (from 4096 tokens), 4 = the hop-1 products against Y, 8 = the streaming form of the
+ * bottleneck-space kernels (csrc/tile_stream.hip); bit 16 switches that form OFF (the A/B against csrc/tile_fast.hip).  nxn_chunk > 0:
+ * frames per chunk of the AVVP N x N block (0 = the library's own choice).  Returns the previous force_mask.  The initial values
+ * come from the environment variables AVMOE_TOKPAIR2_FORCE / AVMOE_DPAIR_FORCE / AVMOE_HOP1S_FORCE / AVMOE_KFS_FORCE / AVMOE_KFS_OFF / AVMOE_NXN_CHUNK, read once
+ * when the library is first asked -- no kernel choice depends on the environment at call time.                                  */
+enum { AVMOE_HOOK_TOKPAIR2_FORCE = 1, AVMOE_HOOK_DPAIR_FORCE = 2, AVMOE_HOOK_HOP1S_FORCE = 4, AVMOE_HOOK_KFS_FORCE = 8, AVMOE_HOOK_KFS_OFF = 16 };
+uint32_t avmoe_test_hooks(uint32_t force_mask, int32_t nxn_chunk);
 
 /* ---- optional per-launch timing (HIP events on the launch stream; off by default; process-wide) --------
  * avmoe_prof_report writes a JSON array of {"name","calls","total_ms","alg_bytes","flops"} per kernel family

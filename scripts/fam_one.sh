@@ -1,7 +1,7 @@
 #!/bin/bash
 # development: per-family launch durations (HIP events, every launch alone on the GPU) of ONE library for the cfg-2 step
 #   scripts/fam_one.sh tag [grep pattern] [extra bench args]      AVMOE_LIB=... selects the library
-O=gpurun_out/r5; mkdir -p $O; T=$1; PAT=${2:-.}; shift; shift
+O=${FAM_OUT:-gpurun_out/r6}; mkdir -p $O; T=$1; PAT=${2:-.}; shift; shift
 AVMOE_PROF_SHAPES=1 AVMOE_FAMILIES_OUT=$O/fam_$T.json python bench.py --pair same --steps 10 --warmup 3 --reps 1 --no-cpu-baseline --no-f32 --no-other-configs "$@" > $O/bench_$T.json 2>$O/bench_$T.err
 python - $O/fam_$T.json "$PAT" <<'PY'
 import json, sys, re

@@ -27,6 +27,16 @@ def family(sym: str):
     m = re.search(r"kf_(\w+?)I(?:DF16b|f)Li", sym) or re.search(r"kf_(\w+?)<", sym)
     if m:
         return "k_" + m.group(1)
+    m = re.search(r"kfs_(\w+?)ILi", sym) or re.search(r"kfs_(\w+?)<", sym)      # streaming form (tile_stream.hip)
+    if m:
+        return "k_" + m.group(1) + " (stream)"
+    for sym_part, fam in (("kk_dx_stream3", "k_dx_stream3"), ("kk_hop1_yk", "k_hop1_yk"), ("kk_hop1_sum", "k_hop1_sum"),
+                          ("kk_frame_gemm_long", "gemm_frames"), ("kk_frame_gemm", "gemm_frames"), ("kg_gram64", "k_gram64")):
+        if sym_part in sym:
+            return fam
+    m = re.search(r"kk_hop1_yt(?:ILi\d+ELi\d+ELb([01])E|<\d+, \d+, (true|false)>)", sym)
+    if m:
+        return "k_hop1_yt_frames" if (m.group(1) == "1" or m.group(2) == "true") else "k_hop1_yt_sum"
     if "gemm_splitk_reduce" in sym:
         return "gemm_splitk_reduce"
     if "kk_xstats" in sym:

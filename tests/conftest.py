@@ -27,3 +27,20 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def avmoe_hooks():
+    """Setter for the library's test hooks (include/avmoe.h: avmoe_test_hooks) -- `avmoe_hooks(force_mask, nxn_chunk=0)`; whatever
+    was set before the test is restored at its end."""
+    from avmoe_amd import _capi
+    stack = []
+
+    def set_(force_mask=0, nxn_chunk=0):
+        cm = _capi.test_hooks(force_mask, nxn_chunk)
+        cm.__enter__()
+        stack.append(cm)
+
+    yield set_
+    while stack:
+        stack.pop().__exit__(None, None, None)

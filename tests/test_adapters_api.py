@@ -78,7 +78,7 @@ def test_library_exports_every_declared_symbol():
     L = _capi.lib()
     for sym in _capi.exported_symbols():
         assert hasattr(L, sym), sym
-    assert L.avmoe_abi_version() == 10
+    assert L.avmoe_abi_version() == 11
 
 
 def test_descriptor_validation_without_a_gpu():

@@ -65,14 +65,14 @@ def test_cfg2_shape_fp32_matches_oracle(site):
 
 @pytest.mark.parametrize("tokpair2", [False, True])
 @pytest.mark.parametrize("site", list(SITES))
-def test_cfg2_shape_bf16_within_the_bf16_budget_of_the_reference_formulation(site, tokpair2, monkeypatch):
+def test_cfg2_shape_bf16_within_the_bf16_budget_of_the_reference_formulation(site, tokpair2, avmoe_hooks):
     """tokpair2: the streaming form of dWt / dT (csrc/tok_pair2.hip), which the plan takes from 65 536 tokens on, forced onto these 20 frames --
     40 half-frame blocks per group, every frame's dT then comes in two parts (the leading-half-frame path of kk_tp2_finish)."""
     from tests.moe_gpu_util import MoeRun
     if tokpair2:
-        monkeypatch.setenv("AVMOE_HOP1S_FORCE", "1")          # ... the hop-1 products against Y as streaming kernels (csrc/hop1_stream.hip: from 32 768 tokens of Y on)
-        monkeypatch.setenv("AVMOE_TOKPAIR2_FORCE", "1")
-        monkeypatch.setenv("AVMOE_DPAIR_FORCE", "1")          # ... and dApost + dBpost from one pass over dOut (csrc/dpost_pair.hip: from 32 768 tokens on)
+        # ... the hop-1 products against Y as streaming kernels (csrc/hop1_stream.hip: from 32 768 tokens of Y on) and dApost + dBpost from
+        # one pass over dOut (csrc/dpost_pair.hip: from 32 768 tokens on)
+        avmoe_hooks(1 | 2 | 4 | 8)          # (8: the bottleneck-space kernels in their streaming form, csrc/tile_stream.hip)
     cfg = _cfg(site)
     P, B = O.init_params(cfg, seed=5)
     X, Y, G = _data(cfg, 20, 99)

@@ -217,7 +217,7 @@ def test_midsize_bf16_close_to_oracle(name):
 @pytest.mark.parametrize("name,chunk", [("fast_avvp", 1), ("cfg3_avvp_stage2_audio_side", 1), ("avvp_mid", 2), ("cfg3_avvp_stage0_audio_side_n512", 2),
                                         ("cfg3_avvp_stage0_audio_full", 1), ("cfg3_avvp_stage0_visual_full", 1)])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
+def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, avmoe_hooks):
     """The AVVP N x N block run a few frames at a time through one workspace, scores and softmax recomputed in the backward (what
     the plan does by itself once the (frames, N, N) tensors outgrow the Infinity Cache: stage 0, N = 4096 / 2304) == the same site
     with everything kept -- bit for bit in fp32 (same kernels on the same rows), and within 1e-3 of the oracle."""
@@ -233,14 +233,14 @@ def test_avvp_nxn_block_in_frame_chunks(name, chunk, bf16, monkeypatch):
     lbw = 0.01 if cfg.lb_loss else 0.0
     whole = MoeRun(cfg, P, B, X, Y, bf16=bf16, training=True).forward()
     g0 = whole.backward(G, lb_weight=lbw)
-    monkeypatch.setenv("AVMOE_NXN_CHUNK", str(chunk))
+    avmoe_hooks(0, chunk)
     run = MoeRun(cfg, P, B, X, Y, bf16=bf16, training=True).forward()
     if whole.table["att"][2] > 64:
         assert run.table["att"][2] < whole.table["att"][2]              # the (frames, N, N) workspace shrank
     else:                                                               # strip kernels (bf16, N a multiple of 128, C = 96 / 192): no such workspace, the
         assert bf16 and cfg.Nx % 128 == 0                               # chunk is only the frame range of a launch
     g1 = run.backward(G, lb_weight=lbw)
-    monkeypatch.delenv("AVMOE_NXN_CHUNK")
+    avmoe_hooks(0, 0)
     assert torch.equal(run.idx, whole.idx)
     if name.endswith("_full"):
         # at the real token counts the skinny products of a chunk (att^T X: few frames x few column tiles) are split over the token

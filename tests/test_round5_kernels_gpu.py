@@ -3,7 +3,7 @@ the shapes csrc/hop1_stream.hip and csrc/dx_stream3.hip are built for).  Both si
 agree far more tightly than either agrees with the fp32 oracle: a wrong row of a ragged tile or a mis-counted wait shows up as an O(1)
 error here where the bf16-vs-oracle budget (1e-2) could hide it.
 
-  * hop-1 products against Y (R, V, dBm, dQ): streaming kernels (test hook AVMOE_HOP1S_FORCE lifts their size threshold) == tiled engine
+  * hop-1 products against Y (R, V, dBm, dQ): streaming kernels (test hook avmoe_test_hooks lifts their size threshold) == tiled engine
   * token gradients: avmoe_moe_backward_dx_dy (one kernel per tensor) == dX overwriting + the other site's dY adding behind an event
 """
 import pytest
@@ -46,10 +46,11 @@ def _run_site(cfg, S, seed):
 def test_hop1_streaming_kernels_equal_the_engine(shape, monkeypatch):
     S, N, M, E_m, E_s = SHAPES[shape]
     cfg = _cfg(N, M, E_m, E_s)
-    monkeypatch.delenv("AVMOE_HOP1S_FORCE", raising=False)
-    out_e, idx_e, g_e = _run_site(cfg, S, 3)                        # below the size threshold: the tiled engine
-    monkeypatch.setenv("AVMOE_HOP1S_FORCE", "1")
-    out_s, idx_s, g_s = _run_site(cfg, S, 3)                        # the streaming kernels wherever they serve the shape
+    from avmoe_amd import _capi
+    with _capi.test_hooks(0):
+        out_e, idx_e, g_e = _run_site(cfg, S, 3)                    # below the size threshold: the tiled engine
+    with _capi.test_hooks(_capi.HOOK_HOP1S_FORCE):
+        out_s, idx_s, g_s = _run_site(cfg, S, 3)                    # the streaming kernels wherever they serve the shape
     assert torch.equal(idx_e, idx_s)
     assert all(torch.isfinite(v).all() for v in g_s.values()) and torch.isfinite(out_s).all()
     # R / V are stored in bf16 by both paths but summed in another order: a last-bit difference there passes through two unscaled softmaxes
@@ -76,14 +77,14 @@ def test_token_contractions_streaming_equal_the_tiled_engine(shape, monkeypatch)
     accumulation in another order -- every parameter gradient within 1e-3 norm-wise (2 % for the tensors below 1 % of the largest)."""
     S, N, M = TP2_SHAPES[shape]
     cfg = _cfg(N, M, 2, 2)
-    monkeypatch.delenv("AVMOE_TOKPAIR2_FORCE", raising=False)
-    out_e, idx_e, g_e = _run_site(cfg, S, 5)
-    monkeypatch.setenv("AVMOE_TOKPAIR2_FORCE", "1")
     from avmoe_amd import _capi
+    with _capi.test_hooks(0):
+        out_e, idx_e, g_e = _run_site(cfg, S, 5)
     L = _capi.lib()
     L.avmoe_prof_reset(); L.avmoe_prof_enable(1)
     try:
-        out_s, idx_s, g_s = _run_site(cfg, S, 5)
+        with _capi.test_hooks(_capi.HOOK_TOKPAIR2_FORCE):
+            out_s, idx_s, g_s = _run_site(cfg, S, 5)
         ran = [f["name"] for f in _capi.prof_report()]
     finally:
         L.avmoe_prof_enable(0); L.avmoe_prof_reset()
