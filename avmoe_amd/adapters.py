@@ -61,6 +61,7 @@ def _scratch(dev: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
 
 
 _FUSED_DX = os.environ.get("AVMOE_NO_FUSED_DX") is None      # development A/B: the token gradients as two kernels each (dX overwrites, the other site's dY adds)
+_warned_side_stream = False
 _SHARED_GPU = None          # process-wide override of avmoe_moe_desc.shared_gpu: None = decide per call (below), True / False = always / never
 
 
@@ -86,7 +87,14 @@ def _shared_gpu_of(module, dev, asked):
         return bool(own)
     if _SHARED_GPU is not None:
         return _SHARED_GPU
-    return torch.cuda.current_stream(dev).cuda_stream != torch.cuda.default_stream(dev).cuda_stream
+    side = torch.cuda.current_stream(dev).cuda_stream != torch.cuda.default_stream(dev).cuda_stream
+    global _warned_side_stream
+    if side and not _warned_side_stream:      # said once: the protected launches change the BatchNorm summation order of some kernel families and cost residency
+        _warned_side_stream = True
+        import warnings
+        warnings.warn("avmoe_amd: adapter call on a non-default stream -> avmoe_moe_desc.shared_gpu = 1 (CU-exclusive launches of the generalised "
+                      "bottleneck-space kernels, include/avmoe.h); avmoe_amd.adapters.set_shared_gpu(False) if nothing else runs on the GPU", stacklevel=3)
+    return side
 
 
 def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=None):
@@ -196,7 +204,9 @@ class _SiteBackward:
         cache = self.module.__dict__.setdefault("_fused_ok", {})
         ok = cache.get(key)
         if ok is None:
-            ok = cache[key] = self.L.avmoe_moe_backward_dx_dy(C.byref(da), None, None, None, C.byref(db), None, None, None, None) == 0
+            # (a library older than ABI 10 loaded through AVMOE_LIB lacks the entry point: the two-kernel hand-over then)
+            ok = cache[key] = hasattr(self.L, "avmoe_moe_backward_dx_dy") and \
+                self.L.avmoe_moe_backward_dx_dy(C.byref(da), None, None, None, C.byref(db), None, None, None, None) == 0
         return ok
 
     def run_fused(self, other):

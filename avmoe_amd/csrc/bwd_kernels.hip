@@ -63,7 +63,7 @@ int k_post_small_bwd_finalize(const Plan& pl, char* saved, char* scratch, const 
   const Dims& d = pl.d;
   PostFinArgs f;
   for (int e = 0; e < MAX_E; ++e) { f.gate.p[e] = prm.e[e].gate; f.ggate.p[e] = grads.e[e].gate; }
-  f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S; f.use_gate = d.use_gate;
+  f.S = d.S; f.E = d.E; f.DZ = d.DZ; f.nblk = d.nblk_tok; f.bps = d.nblk_tok / d.S; f.use_gate = d.use_gate && !d.gate_w;      // (gate_w: dAp already carries the gate -- dp = dq, and dgate comes from weight space)
   return launch_colsum_fin((const float*)(scratch + pl.o_colpart), d.nblk_tok, d.DZ, 4L * d.DZ, d.DZ,
                            PostFin{f, (const float*)(scratch + pl.o_blkscal), (const float*)(saved + pl.o_probs), (float*)(scratch + pl.o_dsm),
                                    (float*)(scratch + pl.o_dp)}, st, d.E);

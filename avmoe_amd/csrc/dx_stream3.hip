@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(NTHR, 1) kk_dx_stream3(const DX3Args p) {
 int k_dx_stream3(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int K2, const float* rs, const void* Wt, long ldw, long sWg,
                  const void* Text, long ldt, long sT1, const void* Bm, long ldb, long sB1, int KB, const void* dRT, long ldr, const void* dV, long ldv, long sV1,
                  const void* Q, long ldq, int KQ, void* dX, long ldc, void* dump, int S, int N, int G, int Cg, int K1, hipStream_t st) {
-  if (Cg != 384 || K1 != 128 || K2 < 1 || K2 > 72 || ldl < 72 || KB < 1 || KB > 96 || KQ < 1 || KQ > 64 || ldr < 8 || ldb < N || N < 4 || S < 1 ||
+  if (Cg != 384 || K1 != 128 || K2 < 1 || K2 > 72 || ldl < 72 || KB < 1 || KB > 96 || KQ < 1 || KQ > 64 || ldr < 8 || ldb < N || N < 16 || S < 1 ||      // (N < 16: a ragged tile of a non-final frame would read 32 - 2 N rows past its successor)
+     
       ldx % 8 || ldz % 8 || ldl % 8 || ldr % 8 || ldb % 8 || sB1 % 8 || ldc % 4 || !rs || !dump ||
       ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dRT % 16) || ((uintptr_t)Bm % 16) || ((uintptr_t)dX % 8) ||
       ((uintptr_t)rs % 4) || ((uintptr_t)dump % 16) || (long)S * N < 2048)

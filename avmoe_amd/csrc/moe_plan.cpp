@@ -35,7 +35,7 @@ int make_plan(const avmoe_moe_desc* q, Plan* pl) {
   d.S = q->S; d.N = q->N; d.C = q->C; d.M = q->M; d.Cy = q->Cy;
   d.E_m = q->E_m; d.E_s = q->E_s; d.E = q->E_m + q->E_s;
   d.g = q->groups; d.d = q->d; d.K = q->K;
-  d.use_bn = q->use_bn; d.use_gate = q->use_gate; d.ln_before = q->ln_before; d.ln_post = q->ln_post;
+  d.use_bn = q->use_bn; d.use_gate = q->use_gate; d.gate_w = q->use_gate && !dev_env("AVMOE_GATE_TOKEN"); d.ln_before = q->ln_before; d.ln_post = q->ln_post;
   d.variant = q->variant; d.self_attn = q->self_attn; d.lb_loss = q->lb_loss; d.training = q->training;
   d.bf16 = q->dtype == AVMOE_BF16;
   d.bn_eps = q->bn_eps; d.ln_eps = q->ln_eps; d.bn_momentum = q->bn_momentum;

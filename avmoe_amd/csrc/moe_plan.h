@@ -20,6 +20,8 @@ struct Dims {
   // raw
   int S, N, C, M, Cy, E, E_m, E_s, g, d, K;
   int use_bn, use_gate, ln_before, ln_post, variant, self_attn, lb_loss, training, bf16;
+  int gate_w;     // the experts' output gates live in WEIGHT space: Bpost_e is scaled by gate_e, the token-space kernels run with gate 1, and
+                  // dgate_e = <dBpost_e, Bpost_e / gate_e> comes out of post_prep_bwd in fp32 (weight_kernels.hip) -- no token-space rounding in it
   int acc_dx, acc_dy;   // backward: accumulate into dX / dY
   int acc_out;          // forward: accumulate into out
   float bn_eps, ln_eps, bn_momentum;
@@ -174,7 +176,7 @@ struct Dims {
   X(dGq, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp)                                               \
   X(sdSzz, 1, 4, (size_t)d.g * d.E * d.dgp * d.dgp) /* 2 dSzz / NT                    */       \
   X(dsm, 1, 4, (size_t)8 * d.DZ + 8 * d.E)          /* dusum,dvh,dmz/NT,mdy,mdyz,ddconst,dwsum ; dH1,dH2 */ \
-  X(dmodv, 1, 4, (size_t)2 * d.E * d.C)             /* dmo, dv2 per (e, c)            */       \
+  X(dmodv, 1, 4, (size_t)3 * d.E * d.C)             /* dmo, dv2, dgate per (e, c)     */       \
   X(dp, 1, 4, (size_t)d.S * d.E)                                                                \
   X(rbw, 1, 4, (size_t)d.S * (d.E + 32 + 128 + 2 * d.C))   /* dlog, dh2r, dh1, drin   */       \
   X(dsxs, 1, 4, (size_t)2 * d.NT)                                                               \

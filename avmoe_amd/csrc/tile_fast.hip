@@ -1107,7 +1107,7 @@ int kf_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_pt
   dim3 grid; int per; fast_grid(d, &grid, &per);
   FPostArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
+  a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate && !d.gate_w; a.ln_eps = d.ln_eps;
   LAUNCH_TE(d.bf16, kf_post_small, 0, a, (const void*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq),
             (const float*)(saved + pl.o_uvh), (const float*)(saved + pl.o_probs), (void*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
   AVMOE_CHECK_LAUNCH("post_small (64/32)");
@@ -1119,7 +1119,7 @@ int kf_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_mo
   dim3 grid; int per; fast_grid(d, &grid, &per);
   FPostBArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  a.t = make_fd(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate && !d.gate_w;
   a.ZpS = nullptr;          // z' is recomputed from z (no stored copy any more: the Gram kernel forms it on the fly too)
   a.dSooT = d.gram64 ? (float*)(scratch + pl.o_dSooT) : nullptr;
   a.dApx = (const float*)(scratch + pl.o_dApx); a.dapw = d.E * d.dgp;

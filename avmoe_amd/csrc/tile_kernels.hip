@@ -548,7 +548,7 @@ int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptr
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.t = make_td(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate; a.ln_eps = d.ln_eps;
+  a.t = make_td(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate && !d.gate_w; a.ln_eps = d.ln_eps;
   const TileDims& t = a.t;
   const int g4 = cdiv(t.dgp, 4);
   size_t sh = (size_t)(t.g * 4 * g4 * t.ldb_g + 4 * t.DD + 4 * 16 * t.lda_d) * sizeof(float);
@@ -1088,7 +1088,7 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostBTArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.t = make_td(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  a.t = make_td(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate && !d.gate_w;
   const TileDims& t = a.t;
   const int g4 = cdiv(t.dgp, 4);
   size_t sh;

@@ -486,7 +486,7 @@ int kfs_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_m
   const int bps = gm.bps, gx = gm.gx;
   SPostBArgs a;
   for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
-  a.t = make_fd_s(d, (int)round_up(cdiv(d.N, bps), 16)); a.ln_post = d.ln_post; a.use_gate = d.use_gate;
+  a.t = make_fd_s(d, (int)round_up(cdiv(d.N, bps), 16)); a.ln_post = d.ln_post; a.use_gate = d.use_gate && !d.gate_w;
   a.bps = bps; a.nvb = gm.nvb; a.nfr = gm.nfr;
   a.dApx = (const float*)(scratch + pl.o_dApx); a.dapw = d.E * d.dgp; a.gpart = (float*)(scratch + pl.o_gpartT);
   if (d.E == 4) return launch_psb<4>(a, gx, pl, saved, scratch, st);

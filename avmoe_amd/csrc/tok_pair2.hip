@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) kk_tp2_finish(const float* __restrict__ s
 // 0 = launched, 1 = shape not served (the caller runs gemm_tokpair), < 0 error
 int k_tok_pair2(const void* X, long ldx, const void* dZx, long ldz, const void* dL2, long ldl, int S, int N, int G, int Cg, int M1, int KL,
                 float* dWt, float* dT, float* slabs, size_t slab_cap, hipStream_t st) {
-  if (Cg != 384 || M1 != 128 || KL < 1 || KL > 64 || ldl < 72 || N < 8 || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || !slabs ||
+  if (Cg != 384 || M1 != 128 || KL < 1 || KL > 64 || ldl < 72 || N < 16 || S < 1 || ldx % 8 || ldz % 8 || ldl % 8 || !slabs ||
       ((uintptr_t)X % 16) || ((uintptr_t)dZx % 16) || ((uintptr_t)dL2 % 16) || ((uintptr_t)dWt % 16) || ((uintptr_t)dT % 16) || (G * 384) % 4)
     return 1;
   const bool force = (test_hook_mask() & HOOK_TOKPAIR2_FORCE) != 0;          // test hook (avmoe_test_hooks: tests / bench.py's parity leg switch it inside one process): small sites as well

@@ -22,8 +22,9 @@ static inline unsigned grid1dw(long n, int cap = 4096) { return (unsigned)std::m
 constexpr int GCS = 8;       // channel chunks of the Gram kernels
 
 struct WArgs {
-  P16 up, w2, b2, lpw, lpb; W16 rm, rv, gup, gw2, gb2, glpw, glpb; N16 nbt2;
+  P16 up, w2, b2, lpw, lpb, gate; W16 rm, rv, gup, gw2, gb2, glpw, glpb, ggate; N16 nbt2;
   int E, g, dg, dgp, Cg, C, KPp, NT, DZ, use_bn, training, ln_post;
+  int gate_w;            // Dims::gate_w: Bpost_e carries gate_e ; dgate_e is formed here
   float eps, momentum;
 };
 static void fill_w(const Dims& d, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs* grads, WArgs* a) {
@@ -34,7 +35,9 @@ static void fill_w(const Dims& d, const avmoe_moe_ptrs& prm, const avmoe_moe_ptr
     a->gup.p[e] = grads ? grads->e[e].up_w : nullptr; a->gw2.p[e] = grads ? grads->e[e].bn2_w : nullptr;
     a->gb2.p[e] = grads ? grads->e[e].bn2_b : nullptr; a->glpw.p[e] = grads ? grads->e[e].lnp_w : nullptr;
     a->glpb.p[e] = grads ? grads->e[e].lnp_b : nullptr;
+    a->gate.p[e] = prm.e[e].gate; a->ggate.p[e] = grads ? grads->e[e].gate : nullptr;
   }
+  a->gate_w = d.use_gate && d.gate_w;
   a->E = d.E; a->g = d.g; a->dg = d.dg; a->dgp = d.dgp; a->Cg = d.Cg; a->C = d.C; a->KPp = d.KPp; a->NT = d.NT; a->DZ = d.DZ;
   a->use_bn = d.use_bn; a->training = d.training; a->ln_post = d.ln_post; a->eps = d.bn_eps; a->momentum = d.bn_momentum;
 }
@@ -119,6 +122,7 @@ __device__ __forceinline__ void build_bpost_body(const WArgs& a, const float* bn
       const float h2 = bn2[3 * EC + (long)e * a.C + c];
       v = w == 0 ? gp * h2 : (w == 1 ? gp : bp);
     }
+    if (a.gate_w && kp < a.E * a.dgp + 3 * a.E) v *= a.gate.p[kp < a.E * a.dgp ? kp / a.dgp : (kp - a.E * a.dgp) / 3][0];      // the expert's gate (net_trans_v3.py:434)
     stT<T>(Bpost, idx, v);
   }
 }
@@ -153,7 +157,7 @@ __device__ __forceinline__ void gram_body(const WArgs& a, int mode, const float*
   }
   for (int k = threadIdx.x; k < nc; k += 256) {
     if (mode == 0) { s_w[k] = 1.f; s_x1[k] = 1.f; s_x2[k] = bn2[3 * EC + cbase + c0 + k]; }
-    else { s_w[k] = dmodv[EC + cbase + c0 + k]; s_x1[k] = dmodv[cbase + c0 + k]; s_x2[k] = 0.f; }
+    else { s_w[k] = dmodv[EC + cbase + c0 + k]; s_x1[k] = dmodv[cbase + c0 + k]; s_x2[k] = a.gate_w ? dmodv[2 * EC + cbase + c0 + k] : 0.f; }      // (x2: the per-channel dgate terms, summed as s1)
   }
   __syncthreads();
   const int stride = dgp * dgp + 2 * dgp + 2;
@@ -206,6 +210,11 @@ __global__ void kw_gram_finish(WArgs a, int mode, const float* gpart, float* out
     } else if (mode == 0) {
       const int w = k - dgp * dgp - 2 * dgp;
       outV[2 * a.DZ + (long)w * nb + cb] = acc;
+    } else if (a.gate_w && k == dgp * dgp + 2 * dgp && cb < a.E) {        // mode 1: dgate_e = the s1 sums of the expert's groups, in group order
+      float tot = 0.f;
+      for (int i = 0; i < a.g; ++i)
+        for (int ch = 0; ch < GCS; ++ch) tot += gpart[((long)ch * nb + (long)i * a.E + cb) * stride + k];
+      if (a.ggate.p[cb]) a.ggate.p[cb][0] = tot;
     }
   }
 }
@@ -286,7 +295,11 @@ __global__ void __launch_bounds__(256) kw_post_prep_bwd(WArgs a, const float* bn
   const float gp = (a.ln_post && on) ? a.lpw.p[e][c] : 1.f;
   const float* dBrow = dBp + (long)(on ? c : 0) * a.KPp;
   const float* dBmain = dBrow + e * dgp;
-  const float dBh = dBrow[a.E * dgp + 3 * e + 0], dBg = dBrow[a.E * dgp + 3 * e + 1], dBb = dBrow[a.E * dgp + 3 * e + 2];
+  // gate_w: dBp is the gradient of the GATED weights gate_e * Bpost_e.  dgate_e = sum over the expert's columns of dBp * Bpost (ungated), per
+  // channel here (summed over the channels by kw_gram mode 1 / kw_gram_finish); everything below sees gt * dBp = the gradient of Bpost itself.
+  const float gt = a.gate_w ? a.gate.p[e][0] : 1.f;
+  const float dBh_r = dBrow[a.E * dgp + 3 * e + 0], dBg_r = dBrow[a.E * dgp + 3 * e + 1], dBb_r = dBrow[a.E * dgp + 3 * e + 2];
+  const float dBh = gt * dBh_r, dBg = gt * dBg_r, dBb = gt * dBb_r;
   float dH1 = 0.f, dH2 = 0.f;
   if (a.ln_post) { dH1 = dsm[8 * a.DZ + e]; dH2 = dsm[8 * a.DZ + a.E + e]; }
   float dWh[PB_JMAX];
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(256) kw_post_prep_bwd(WArgs a, const float* bn
     const int j = jl + 32 * jj;
     dWh[jj] = 0.f;
     if (j < dg) {
-      float v = gp * dBmain[j];
+      float v = gp * gt * dBmain[j];
       if (a.ln_post) {
         float acc = 0.f;
         for (int l = 0; l < dg; ++l) acc += s_dG[j * ldm + l] * wu[l];
@@ -304,12 +317,17 @@ __global__ void __launch_bounds__(256) kw_post_prep_bwd(WArgs a, const float* bn
       }
       dWh[jj] = v;
       dk2 += v * wu[j];
-      dgp_acc += dBmain[j] * (wu[j] * k2);
+      dgp_acc += dBmain[j] * (wu[j] * k2);          // (ungated: scaled below)
       if (a.ln_post) dh2p += s_v[dgp + j] * (wu[j] * k2);
     }
   }
 #pragma unroll
   for (int o = 1; o < 32; o <<= 1) { dk2 += __shfl_xor(dk2, o, 64); dgp_acc += __shfl_xor(dgp_acc, o, 64); dh2p += __shfl_xor(dh2p, o, 64); }
+  if (a.gate_w) {
+    const float bp = (a.ln_post && on) ? a.lpb.p[e][c] : 0.f;
+    if (on && jl == 0) dmodv[2 * EC + idx] = gp * dgp_acc + gp * h2 * dBh_r + gp * dBg_r + bp * dBb_r;
+  }
+  dgp_acc *= gt;
   float dh2 = gp * dBh + dh2p;
   if (a.ln_post) {
     dh2 += dH1 + 2.f * h2 * dH2;

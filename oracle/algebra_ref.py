@@ -249,16 +249,20 @@ class AlgebraRef:
                 rp = torch.ones(S, N, dtype=X.dtype)
                 mup = torch.zeros(S, N, dtype=X.dtype)
             gate = P[f"{pre}.gate"] if cfg.use_gate else torch.ones(1, dtype=X.dtype)
-            q = (p[:, ex.j] * gate)[:, None].expand(S, N)
+            # The expert's gate lives in WEIGHT space (round 6, csrc/weight_kernels.hip: Dims::gate_w): the token-space rows carry the router
+            # probability only, the expert's columns of Bpost carry gate_e.  Same product; dgate_e = <dBpost_e, Bpost_e / gate_e> then needs no
+            # token-space intermediate (a zero-initialised gate, net_trans_v3.py:309, leaves every token-space gradient of the expert exactly 0).
+            q = p[:, ex.j][:, None].expand(S, N)
             # ---- the ONE output GEMM  out += Apost Bpost^T ----
             Az = (q * rp)[..., None, None] * zp
             c1, c2, c3 = q * rp, -q * rp * mup, q
-            Bmain = Wh * gp[..., None]
-            Bh, Bg, Bb = (gp * h2).reshape(-1), gp.reshape(-1), bp.reshape(-1)
+            Bmain0 = Wh * gp[..., None]                                         # ungated
+            Bh0, Bg0, Bb0 = (gp * h2).reshape(-1), gp.reshape(-1), bp.reshape(-1)
+            Bmain, Bh, Bg, Bb = gate * Bmain0, gate * Bh0, gate * Bg0, gate * Bb0
             out = out + torch.einsum("snij,icj->snic", Az, Bmain).reshape(S, N, C) + \
                 c1[..., None] * Bh + c2[..., None] * Bg + c3[..., None] * Bb
             e.update(gp=gp, rp=rp, mup=mup, gate=gate, q=q, Az=Az, c1=c1, c2=c2, c3=c3, Bmain=Bmain,
-                     Bh=Bh, Bg=Bg, Bb=Bb)
+                     Bh=Bh, Bg=Bg, Bb=Bb, Bmain0=Bmain0, Bh0=Bh0, Bg0=Bg0, Bb0=Bb0)
         if cfg.use_bn and training:
             for ex in self.experts:
                 for bn in ("bn1", "bn2"):
@@ -294,6 +298,10 @@ class AlgebraRef:
             dBh = torch.einsum("snc,sn->c", dout, e["c1"]).reshape(g, Cg)
             dBg = torch.einsum("snc,sn->c", dout, e["c2"]).reshape(g, Cg)
             dBb = torch.einsum("snc,sn->c", dout, e["c3"]).reshape(g, Cg)
+            if cfg.use_gate:          # gradients of the GATED weights so far: the gate's own gradient, then the chain to the ungated ones
+                G_[f"{pre}.gate"] += (dBmain * e["Bmain0"]).sum() + (dBh.reshape(-1) * e["Bh0"]).sum() + \
+                    (dBg.reshape(-1) * e["Bg0"]).sum() + (dBb.reshape(-1) * e["Bb0"]).sum()
+                dBmain, dBh, dBg, dBb = e["gate"] * dBmain, e["gate"] * dBh, e["gate"] * dBg, e["gate"] * dBb
             # ---- POST_SMALL backward (per token, d-space) ----
             zz = (dAz * zp).sum((-1, -2))
             dq = rp * zz + rp * da1 - rp * mup * da2 + da3
@@ -314,9 +322,7 @@ class AlgebraRef:
                 dG = torch.einsum("sn,snij,snil->ijl", dSoo, zp, zp)
                 dvh = 2 * torch.einsum("sn,snij->ij", dSoo, zp)
                 dH2 = dSoo.sum()
-            dp[:, ex.j] = e["gate"] * dq.sum(1)
-            if cfg.use_gate:
-                G_[f"{pre}.gate"] += (p[:, ex.j, None] * dq).sum()
+            dp[:, ex.j] = dq.sum(1)                                             # (dAz already carries the gate)
             # ---- phase 2: weight space (C x d sized) ----
             if cfg.ln_post:
                 dWh = gp[..., None] * dBmain + torch.einsum("ijl,icl->icj", _sym(dG), Wh) + dusum[:, None, :] + \

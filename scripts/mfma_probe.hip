@@ -19,10 +19,32 @@ __device__ __forceinline__ int opaque0() { int v = 0; asm volatile("" : "+v"(v))
 __device__ __forceinline__ float& at(float4& v, int x) { return ((float*)&v)[x]; }
 __device__ __forceinline__ float at(const float4& v, int x) { return ((const float*)&v)[x]; }
 
+// MIT 20 / 21 (round 6): the mat-vec in the form the TUNED kernels run (csrc/tile_fast.hip::mmT_split, csrc/tile_stream.hip::mm_presplit): both
+// operands as two bf16 planes, hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 -- does THAT form move beside a dense-MFMA aggressor?
+// 21: + the per-block column sums of those kernels (DPP row sums, rsum16) against a shuffle butterfly over the same values.
+__device__ __forceinline__ void split8(const float4& v0, const float4& v1, bf16x8& hi, bf16x8& lo) {
+  const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const __bf16 h = (__bf16)f[i]; hi[i] = h; lo[i] = (__bf16)(f[i] - (float)h); }
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float rsum16(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v); return v; }
 template <int NJ>
 __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* mp = Mt + (col0 + r) * ld + 4 * q;
+#if defined(MIT) && (MIT == 20 || MIT == 21)
+#pragma unroll
+  for (int j = 0; j < NJ; j += 2) {
+    bf16x8 ah, al, ph, pl;
+    split8(*(const float4*)(mp + 16 * j), *(const float4*)(mp + 16 * (j + 1)), ah, al);
+    split8(p[j], p[j + 1], ph, pl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph, acc, 0, 0, 0);
+  }
+  return acc;
+#endif
 #ifndef MIT
 #define MIT 0      // mitigation under test: 1 = drain the LDS counter + s_nop before the MFMAs, 2 = the LDS data through a VALU move, 3 = both
 #endif
@@ -136,6 +158,14 @@ __global__ void __launch_bounds__(256) victim(const float* __restrict__ M, const
         for (int x = 0; x < 4; ++x) v3 += w[x] * at(p[ct], x);
       }
     if (fabsf(u3 - v3) > 1e-4f * fmaxf(fabsf(v3), 1.f)) ++nbad;
+#if defined(MIT) && MIT == 21
+    {
+      const float cs = rsum16(u3);                     // column sum over the tile's 16 tokens, as flush_cols_we forms it
+      float bs = u3;
+      for (int o = 1; o < 16; o <<= 1) bs += __shfl_xor(bs, o, 64);
+      if (fabsf(cs - bs) > 1e-5f * fmaxf(fabsf(bs), 1.f)) ++nbad;
+    }
+#endif
     if (outU) { outU[(long)t * 64 + lane] = u3; outV[(long)t * 64 + lane] = v3; }
     keep += u3;
   }
