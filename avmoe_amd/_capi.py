@@ -53,8 +53,9 @@ def lib():
     L.avmoe_prof_reset.restype = None
     L.avmoe_prof_report.restype = C.c_size_t
     L.avmoe_prof_report.argtypes = [C.c_char_p, C.c_size_t]
-    L.avmoe_test_hooks.restype = C.c_uint32
-    L.avmoe_test_hooks.argtypes = [C.c_uint32, C.c_int32]
+    if hasattr(L, "avmoe_test_hooks"):          # (ABI 11; a development A/B may load an older library through AVMOE_LIB)
+        L.avmoe_test_hooks.restype = C.c_uint32
+        L.avmoe_test_hooks.argtypes = [C.c_uint32, C.c_int32]
     from . import _capi_moe
     _capi_moe.declare(L)
     _lib = L

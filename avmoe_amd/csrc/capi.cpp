@@ -11,7 +11,7 @@ static GemmArgs to_args(const avmoe_gemm_desc* d) {
   GemmArgs a;
   a.M = d->M; a.N = d->N; a.K = d->K; a.nb1 = d->nb1; a.nb2 = d->nb2;
   a.dtype = d->dtype; a.out_dtype = d->out_dtype; a.a_layout = d->a_layout; a.b_layout = d->b_layout;
-  a.accumulate = d->accumulate; a.ksplit = d->ksplit; a.tile = d->tile; a.split3 = d->fp32_planes != 0 && d->dtype == AVMOE_F32; a.alpha = d->alpha;
+  a.accumulate = d->accumulate; a.ksplit = d->ksplit; a.tile = d->tile; a.split3 = d->dtype == AVMOE_F32 ? (d->fp32_planes == 2 ? 2 : (d->fp32_planes != 0 ? 1 : 0)) : 0; a.alpha = d->alpha;
   a.lda = d->lda; a.ldb = d->ldb; a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2;
   a.sCi = d->sCi; a.sCj = d->sCj; a.sC1 = d->sC1; a.sC2 = d->sC2;
   a.sRS1 = d->sRS1; a.sRS2 = d->sRS2; a.sDi = d->sDi; a.sD1 = d->sD1; a.sD2 = d->sD2;

@@ -58,6 +58,8 @@ struct GemmArgs {
   // v_mfma_f32_16x16x4_f32 (same values to the last bit as rounds 1 - 3: which ReLU units sit on which side of zero does not move).
   // Non-finite operands: an Inf splits into (Inf, NaN, NaN) -- the residual planes are Inf - Inf -- so a product that exact fp32 arithmetic
   // would return as Inf comes out NaN; finite inputs only (as everywhere on this path: workspaces are NaN-poisoned in the tests).
+  // 2 = TWO planes (split once at the LDS store), the three plane products of order <= 1: 2^-16 relative per product, half the matrix-pipe work --
+  // available through avmoe_gemm (fp32_planes = 2); the site calls do not use it (moe_run.h: AVMOE_BWD_PLANES has the measurement and the reason).
   int split3 = 0;
   int tile = 0;                         // 0 = auto, 64 or 128 = force block tile
   // optional second K segment, accumulated into the same tile before the epilogue:

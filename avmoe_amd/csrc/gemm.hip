@@ -70,6 +70,12 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int valid) {
 // operands -- 256-byte row pieces -- the same change measured 3 - 60 % SLOWER)
 // Element-type tag of the fp32 instances that run on the bf16 matrix pipe in three-plane form (GemmArgs::split3; gemm_segment has the arithmetic)
 struct f32s3 { float v; };
+// ... and in TWO-plane form (GemmArgs::split3 == 2): x ~ p0 + p1 (16 mantissa bits), the three plane products of order <= 1 -- 2^-16 relative per
+// product (1.5e-5), half the matrix-pipe work, the split done once per element on the way into the LDS.  Offered through avmoe_gemm
+// (fp32_planes = 2); the site calls keep three planes (moe_run.h: AVMOE_BWD_PLANES -- measured -18 % of the fp32 step, but structurally cancelling
+// gradients leave the 1e-3 bar)
+struct f32s2 { float v; };
+template <typename T> struct is_split : std::integral_constant<bool, std::is_same<T, f32s3>::value || std::is_same<T, f32s2>::value> {};
 constexpr int stage_kbytes(int BM, int BN, bool AMN, bool BMN) { return (BM <= 64 && BN <= 64 && AMN && BMN) ? 256 : 128; }
 
 // One K segment of the block's tile: 2-stage LDS pipeline over [kbeg, kend), accumulating into acc.
@@ -143,6 +149,39 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
   auto lstore = [&](int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_BYTES;
+    if constexpr (std::is_same<T, f32s2>::value) {
+      // two-plane form: the split happens ONCE per element, here -- a row of the stage keeps its bytes, first half the hi plane (bf16), second
+      // half the lo plane; compute() then reads ready bf16 fragments (16-byte / transposing reads, as the bf16 instances do) and issues three
+      // matrix instructions per block: no conversion arithmetic in the K loop, and none repeated by the waves that share an operand
+      auto split4 = [](const u32x4& v, u32x2& hi, u32x2& lo) {
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = __uint_as_float(v[j]);
+          const __bf16 hb = (__bf16)x;
+          h[j] = __builtin_bit_cast(unsigned short, hb);
+          l[j] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)hb));
+        }
+        hi = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+        lo = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+      };
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        const int c = tid + NTHR * i;
+        u32x2 hi, lo;
+        split4(ra[i], hi, lo);
+        char* d = AMN ? sA + (c / A_CPR) * A_ROWB + (c % A_CPR) * 8 : sA + (c / CPK) * A_ROWB + (c % CPK) * 8;
+        *(u32x2*)d = hi; *(u32x2*)(d + (AMN ? BM * 2 : KBY / 2)) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) {
+        const int c = tid + NTHR * i;
+        u32x2 hi, lo;
+        split4(rb[i], hi, lo);
+        char* d = BMN ? sB + (c / B_CPR) * B_ROWB + (c % B_CPR) * 8 : sB + (c / CPK) * B_ROWB + (c % CPK) * 8;
+        *(u32x2*)d = hi; *(u32x2*)(d + (BMN ? BN * 2 : KBY / 2)) = lo;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
       const int c = tid + NTHR * i;
@@ -154,6 +193,7 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
       const int c = tid + NTHR * i;
       if constexpr (!BMN) *(u32x4*)(sB + (c / CPK) * B_ROWB + (c % CPK) * 16) = rb[i];
       else *(u32x4*)(sB + (c / B_CPR) * B_ROWB + (c % B_CPR) * 16) = rb[i];
+    }
     }
   };
 
@@ -197,7 +237,42 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
           for (int tn = 0; tn < TN; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
       }
-    } else if constexpr (std::is_same<T, f32s3>::value) {
+    } else if constexpr (std::is_same<T, f32s2>::value) {
+      // two planes, split at lstore: bf16 fragments of the hi / lo images (plane offset: half a K-major row / BM (BN) bf16 of an MN-major row)
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 ah[TM], al[TM];
+        auto frag = [&](const char* base, int rowb, bool mn, int col0, int plane_off, bf16x8& h, bf16x8& l) {
+          if (!mn) {
+            const char* ad = base + (col0 + r) * rowb + ks * 64 + q * 16;
+            h = *(const bf16x8*)ad; l = *(const bf16x8*)(ad + plane_off);
+          } else {
+            const char* ad = base + (ks * 32 + 8 * q + (r >> 2)) * rowb + (col0 + 4 * (r & 3)) * 2;
+            const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad)), h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + 4 * rowb));
+            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + plane_off)), l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ad + plane_off + 4 * rowb));
+            h = __builtin_bit_cast(bf16x8, s16x8{h1[0], h1[1], h1[2], h1[3], h2[0], h2[1], h2[2], h2[3]});
+            l = __builtin_bit_cast(bf16x8, s16x8{l1[0], l1[1], l1[2], l1[3], l2[0], l2[1], l2[2], l2[3]});
+          }
+        };
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) frag(sA, A_ROWB, AMN, wm0 + 16 * tm, AMN ? BM * 2 : KBY / 2, ah[tm], al[tm]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bf16x8 bh, bl;
+          frag(sB, B_ROWB, BMN, wn0 + 16 * tn, BMN ? BN * 2 : KBY / 2, bh, bl);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            f32x4 c = acc[tm][tn];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl, c, 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh, c, 0, 0, 0);
+          }
+        }
+      }
+    } else if constexpr (is_split<T>::value) {
+      constexpr bool TWO = std::is_same<T, f32s2>::value;      // (kept: the in-register two-plane form; f32s2 takes the branch above)
       // fp32 operands on the bf16 matrix pipe WITHOUT giving up fp32 products: every value as three bf16 planes (8 + 8 + 8 mantissa bits:
       // x = p0 + p1 + p2 exactly up to 2^-24 |x|), the six plane products of order <= 2 as v_mfma_f32_16x16x32_bf16, fp32 accumulation:
       // 5.8e-9 relative per product against 2 - 4e-7 for the fp32 rounding of the sum itself (measured) at
@@ -221,8 +296,10 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
           for (int j = 0; j < 8; ++j) { const __bf16 h = (__bf16)x[j]; p[0][j] = h; rr[j] = x[j] - (float)h; }
 #pragma unroll
           for (int j = 0; j < 8; ++j) { const __bf16 h = (__bf16)rr[j]; p[1][j] = h; rr[j] -= (float)h; }
+          if constexpr (!TWO) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) p[2][j] = (__bf16)rr[j];
+            for (int j = 0; j < 8; ++j) p[2][j] = (__bf16)rr[j];
+          }
         };
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) frag(sA, A_ROWB, AMN, wm0 + 16 * tm, af[tm]);
@@ -233,9 +310,11 @@ __device__ __forceinline__ void gemm_segment(char* smem, const char* Ab, const c
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm) {
             f32x4 c = acc[tm][tn];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][2], bf[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][1], bf[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[2], c, 0, 0, 0);
+            if constexpr (!TWO) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][2], bf[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][1], bf[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[2], c, 0, 0, 0);
+            }
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][1], bf[0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[1], c, 0, 0, 0);
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm][0], bf[0], c, 0, 0, 0);
@@ -394,7 +473,7 @@ __device__ __forceinline__ void gemm_segment_direct(char* smem, const char* Ab, 
 }
 
 template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2>
-__global__ void __launch_bounds__(256, (std::is_same<T, f32s3>::value ? 2 : 1)) gemm_kernel(const DevArgs p) {
+__global__ void __launch_bounds__(256, (is_split<T>::value ? 2 : 1)) gemm_kernel(const DevArgs p) {
   constexpr int ESZ = sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -911,7 +990,7 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];
-  if (!name[0]) snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : "f32"), BM);
+  if (!name[0]) snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : (std::is_same<T, f32s2>::value ? "f32s2" : "f32")), BM);
   static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
   const char* pname = name;
   if (shapes && prof_enabled()) {            // debug only: one family per distinct call shape (leaks the small strings)
@@ -1097,15 +1176,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   } else if (tile == 128) {
     d.tiles_n = cdiv(a.N, 128);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 128, 128>(a, d, bz, stream)
-                              : (a.split3 ? launch_layout<f32s3, 128, 128>(a, d, bz, stream) : launch_layout<float, 128, 128>(a, d, bz, stream));
+                              : (a.split3 == 2 ? launch_layout<f32s2, 128, 128>(a, d, bz, stream) : a.split3 ? launch_layout<f32s3, 128, 128>(a, d, bz, stream) : launch_layout<float, 128, 128>(a, d, bz, stream));
   } else if (tile == 64) {
     d.tiles_n = cdiv(a.N, 64);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 64, 64>(a, d, bz, stream)
-                              : (a.split3 ? launch_layout<f32s3, 64, 64>(a, d, bz, stream) : launch_layout<float, 64, 64>(a, d, bz, stream));
+                              : (a.split3 == 2 ? launch_layout<f32s2, 64, 64>(a, d, bz, stream) : a.split3 ? launch_layout<f32s3, 64, 64>(a, d, bz, stream) : launch_layout<float, 64, 64>(a, d, bz, stream));
   } else if (tile == 32) {                                   // small per-batch problems (K x K latent matrices, S x S frame attention)
     d.tiles_n = cdiv(a.N, 32);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 32, 32>(a, d, bz, stream)
-                              : (a.split3 ? launch_layout<f32s3, 32, 32>(a, d, bz, stream) : launch_layout<float, 32, 32>(a, d, bz, stream));      // (every tile: the result must not depend on the tile the block count picks)
+                              : (a.split3 == 2 ? launch_layout<f32s2, 32, 32>(a, d, bz, stream) : a.split3 ? launch_layout<f32s3, 32, 32>(a, d, bz, stream) : launch_layout<float, 32, 32>(a, d, bz, stream));      // (every tile: the result must not depend on the tile the block count picks)
   } else {
     set_last_error("gemm: tile %d not built", tile);
     return ERR_UNSUPPORTED;

@@ -37,7 +37,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   const int dt = d.bf16 ? GEMM_BF16 : GEMM_F32;
   float* slabs = (float*)(sc + pl.o_slabs);
   const size_t slab_cap = slab_floats(d);
-  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; g.split3 = 1; return g; };      // (split3: fp32 sites only, gemm.h)
+  auto base = [&]() { GemmArgs g; g.dtype = dt; g.out_dtype = GEMM_F32; g.slabs = slabs; g.split3 = AVMOE_BWD_PLANES; return g; };      // (split3: fp32 sites only, gemm.h; moe_run.h: two planes in the backward)
   auto run_on = [&](GemmArgs& g, bool split, hipStream_t on) {
     if (split) g.ksplit = choose_ksplit(g, slab_cap);
     return launch_gemm(g, on);

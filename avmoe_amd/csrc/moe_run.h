@@ -15,6 +15,14 @@
 #define AVMOE_FWD_SPLIT3 1
 #endif
 
+// fp32 sites, BACKWARD: GemmArgs::split3 of its engine products.  1 = three planes (rounds 4 - 6).  2 = TWO planes split once on the way into
+// the LDS (gemm.hip: f32s2, round 6) was built and measured: the fp32 cfg-2 step 15.8 -> 13.0 ms of kernel time (dBpost 867 -> 425 us, dWt 566 -> 314,
+// the output-bound dX / dY products unchanged), but gradients that cancel structurally (bn1.bias of the unimodal experts: 5.7e-6 against a largest
+// gradient of ~0.1) come out at 1.2e-4 -- past the 1e-3 bar of the fixture tests (tests/test_adapters_gpu.py).  fp32 is THE parity mode: not used.
+#ifndef AVMOE_BWD_PLANES
+#define AVMOE_BWD_PLANES 1
+#endif
+
 namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap);

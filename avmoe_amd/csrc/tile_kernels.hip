@@ -407,10 +407,14 @@ static double bytes_pre_small_bwd(const Dims& d) {
 }
 int k_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_pre_small", (long)d.NT, bytes_pre_small(d), 0.0, st);
+  const bool stream = tile_fast_ok(d) && kfs_serves_pre_small(d);
+  ProfScope ps_(stream ? "k_pre_small (stream)" : "k_pre_small", (long)d.NT, bytes_pre_small(d), 0.0, st);
   for (int e = 0; e < d.E; ++e)
     if (d.nxn_of_e[e] && !prm.e[e].gate_lat) { set_last_error("moe: expert %d lacks gate_av", e); return ERR_BAD_ARG; }
-  if (tile_fast_ok(d)) return kf_pre_small(pl, saved, scratch, prm, st);
+  if (tile_fast_ok(d)) {
+    const int rc = kfs_pre_small(pl, saved, scratch, prm, st);       // streaming form (large bf16 sites); 1 = not served
+    return rc == 1 ? kf_pre_small(pl, saved, scratch, prm, st) : rc;
+  }
   if (d.gen) return kg_pre_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PreTArgs a;
@@ -542,8 +546,12 @@ __global__ void __launch_bounds__(256) kt_post_small(PostTArgs a, const float* _
 
 int k_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_post_small", (long)d.NT, bytes_post_small(d), 0.0, st);
-  if (tile_fast_ok(d)) return kf_post_small(pl, saved, scratch, prm, st);
+  const bool stream = tile_fast_ok(d) && kfs_serves_post_small(d);
+  ProfScope ps_(stream ? "k_post_small (stream)" : "k_post_small", (long)d.NT, bytes_post_small(d), 0.0, st);
+  if (tile_fast_ok(d)) {
+    const int rc = kfs_post_small(pl, saved, scratch, prm, st);       // streaming form (large bf16 sites); 1 = not served
+    return rc == 1 ? kf_post_small(pl, saved, scratch, prm, st) : rc;
+  }
   if (d.gen) return kg_post_small(pl, saved, scratch, prm, st);
   dim3 grid; int per; tile_grid(d, &grid, &per);
   PostTArgs a;
@@ -1113,9 +1121,12 @@ int k_post_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe
 
 int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
-  ProfScope ps_("k_mid_bwd", (long)d.NT, bytes_mid_bwd(d), 0.0, st);
+  const bool stream = tile_fast_ok(d) && kfs_serves_mid_bwd(d);
+  ProfScope ps_(stream ? "k_mid_bwd (stream)" : "k_mid_bwd", (long)d.NT, bytes_mid_bwd(d), 0.0, st);
   if (tile_fast_ok(d)) {
-    AVMOE_TRY(kf_mid_bwd(pl, saved, scratch, st));
+    const int rc = kfs_mid_bwd(pl, saved, scratch, st);       // streaming form (large bf16 sites); 1 = not served
+    if (rc < 0) return rc;
+    if (rc == 1) AVMOE_TRY(kf_mid_bwd(pl, saved, scratch, st));
     return k_mid_bwd_finalize(pl, saved, scratch, prm, grads, st);
   }
   if (d.gen) {

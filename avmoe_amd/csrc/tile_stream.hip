@@ -104,13 +104,13 @@ __device__ __forceinline__ void lds_wr1(unsigned addr, float v) { asm volatile("
 __device__ __forceinline__ uint4 as_u4(const f32x4& v) { return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])); }
 
 // wait until this wave's tile `it` has landed: `newer` tiles were requested after it, `stored` tiles' stores were issued since its request
-// (in-order counter: everything but those may still be in flight).  NL / NST: ring loads / stores per wave and tile.
+// (in-order counter: everything but those may still be in flight; whatever else was issued in between -- a flush's stores, the next frame's
+// constants -- only makes the wait stricter).  NL / NST: ring loads / stores per wave and tile.
 template <int NL, int NST>
 __device__ __forceinline__ void wait_tile(int newer, int stored) {
-  static_assert(KFS_P >= 1 && KFS_P <= 3, "tiles ahead");
   if (!KFS_EXACT) stored = 0;
-  if (newer <= 0) { wait_vm<0>(); return; }          // (the last tiles of the block: no count to rely on behind a flush)
 #define KFS_W(M_, K_) if (newer == M_ && stored == K_) { wait_vm<M_ * NL + K_ * NST>(); return; }
+  KFS_W(0, 1) KFS_W(0, 2) KFS_W(0, 3)
   KFS_W(1, 0) KFS_W(1, 1) KFS_W(1, 2) KFS_W(1, 3)
   KFS_W(2, 0) KFS_W(2, 1) KFS_W(2, 2) KFS_W(2, 3)
 #undef KFS_W
@@ -444,6 +444,566 @@ int launch_psb(const SPostBArgs& a, int gx, const Plan& pl, char* saved, char* s
   return OK;
 }
 
+// =====================================================================================================
+// MID backward (bf16)      tile_fast.hip::kf_mid_bwd<__bf16, E>: BN2-moment terms + BatchNorm-1 / ReLU mask, dz' rewritten in place
+// =====================================================================================================
+struct SMidBArgs { int relu_of_e[MAX_E]; FastDims t; int moments, bps, nvb; };
+
+constexpr int MDB_NL = 4, MDB_NST = 2;                      // ring loads / stores per wave and tile
+constexpr int MDB_TILE = 4 * 1024;                          // Z (2 x 1 KB), dz' (2 x 1 KB)
+template <int E> constexpr int mdb_fixed_floats() { return 2 * WS<E>::NW * fold_stride<2>() + E * 5 * FDD; }
+template <int E> constexpr size_t mdb_lds() { return (size_t)mdb_fixed_floats<E>() * 4 + (size_t)WS<E>::NW * (KFS_P + 1) * MDB_TILE; }
+
+template <int E>
+__global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_mid_bwd(SMidBArgs a, const unsigned short* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ dsm,
+                                                           const float* __restrict__ sdSzz, unsigned short* __restrict__ dzp, float* __restrict__ colpart) {
+  constexpr int DZ = E * FDD, NS = WS<E>::NS, NW = WS<E>::NW, NTHR = WS<E>::NTHR, D = KFS_P + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_fold = (float*)smem;                             // [2][NW][2 * 64 + 4]
+  float* s_bn = s_fold + 2 * NW * fold_stride<2>();         // [E][mean | rstd | sc | sh | dm]
+  const FastDims& t = a.t;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
+  char* ring = smem + (size_t)mdb_fixed_floats<E>() * 4 + (size_t)wave * D * MDB_TILE;
+  const unsigned ring_a = lds_off(ring), fold_a = lds_off(s_fold), bn_a = lds_off(s_bn + e * 5 * FDD);
+  const int vb0 = (int)((long)a.nvb * blockIdx.x / gridDim.x), vb1 = (int)((long)a.nvb * (blockIdx.x + 1) / gridDim.x);
+  const int bps = a.bps, per = t.per, N = t.N;
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    float* b = s_bn + ee * 5 * FDD;
+    b[dd] = bn1[col]; b[FDD + dd] = bn1[DZ + col]; b[2 * FDD + dd] = bn1[2 * DZ + col];
+    b[3 * FDD + dd] = bn1[3 * DZ + col]; b[4 * FDD + dd] = a.moments ? dsm[2 * DZ + col] : 0.f;
+  }
+  __syncthreads();                 // (no C++-level LDS access from here on)
+  auto request = [&](int slot, const TileIt& it) {
+    const long tk = (long)it.s * N + min(it.n0 + r, N - 1);
+    char* dst = ring + slot * MDB_TILE;
+    const char* zs = (const char*)(Z + tk * DZ + e * FDG + seg_off8(q));
+    glds16(zs, dst); glds16(zs + E * FDG * 2, dst + 1024);
+    const char* ds = (const char*)(dzp + tk * DZ + e * FDG + seg_off8(q));
+    glds16(ds, dst + 2048); glds16(ds + E * FDG * 2, dst + 3072);
+  };
+  TileIt pf = it_first<NS>(vb0, vb1, bps, per, N, ts);
+  int nreq = 0;
+#pragma unroll
+  for (int k = 0; k < KFS_P; ++k)
+    if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+  kf_bf16x8 gh[2][2], gl[2][2];                     // sdSzz^T rows 16 ct + r of group gi as bf16 planes (mm_presplit)
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float* g = sdSzz + (long)(gi * E + e) * FDG * FDG + 16 * ct + r;
+      float4 m0 = zero4(), m1 = zero4();
+      if (a.moments) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { at(m0, x) = g[(4 * q + x) * FDG]; at(m1, x) = g[(16 + 4 * q + x) * FDG]; }
+      }
+      kf_split8(m0, m1, gh[gi][ct], gl[gi][ct]);
+    }
+  const bool relu = a.relu_of_e[e];
+  int it = 0;
+  int s = vb0 / bps, vbb = vb0 - s * bps;
+  for (int vb = vb0; vb < vb1; ++vb, s += (vbb + 1 == bps), vbb = (vbb + 1 == bps) ? 0 : vbb + 1) {
+    const int n_beg = vbb * per, n_end = min(N, n_beg + per);
+    float4 cs0[4], cs1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, ++it) {
+      wait_tile<MDB_NL, MDB_NST>(min(KFS_P - 1, nreq - it - 1), min(it, KFS_P));
+      if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+      const bool ok = n0 + r < N;
+      const long tok = (long)s * N + n0 + r;
+      const unsigned sl = ring_a + (it % D) * MDB_TILE;
+      f32x4 rz0, rz1, rd0, rd1, sc[4], sh[4];
+      lds_rd16<0>(rz0, sl + lane * 16); lds_rd16<1024>(rz1, sl + lane * 16); lds_rd16<2048>(rd0, sl + lane * 16); lds_rd16<3072>(rd1, sl + lane * 16);
+      lds_rd16<512>(sc[0], bn_a + 16 * q); lds_rd16<576>(sc[1], bn_a + 16 * q); lds_rd16<640>(sc[2], bn_a + 16 * q); lds_rd16<704>(sc[3], bn_a + 16 * q);
+      lds_rd16<768>(sh[0], bn_a + 16 * q); lds_rd16<832>(sh[1], bn_a + 16 * q); lds_rd16<896>(sh[2], bn_a + 16 * q); lds_rd16<960>(sh[3], bn_a + 16 * q);
+      lds_wait();
+      lds_use(rz0, rz1, rd0, rd1);
+      lds_use(sc[0], sc[1], sc[2], sc[3]); lds_use(sh[0], sh[1], sh[2], sh[3]);
+      float4 z[4], dz[4], zp[4], dyo[4];
+      unpack_seg(as_u4(rz0), z[0], z[1]); unpack_seg(as_u4(rz1), z[2], z[3]);
+      unpack_seg(as_u4(rd0), dz[0], dz[1]); unpack_seg(as_u4(rd1), dz[2], dz[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float y = at(z[c], x) * sc[c][x] + sh[c][x];
+          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+        }
+      f32x4 mean[4], rstd[4], dm[4];
+      lds_rd16<0>(mean[0], bn_a + 16 * q); lds_rd16<64>(mean[1], bn_a + 16 * q); lds_rd16<128>(mean[2], bn_a + 16 * q); lds_rd16<192>(mean[3], bn_a + 16 * q);
+      lds_rd16<256>(rstd[0], bn_a + 16 * q); lds_rd16<320>(rstd[1], bn_a + 16 * q); lds_rd16<384>(rstd[2], bn_a + 16 * q); lds_rd16<448>(rstd[3], bn_a + 16 * q);
+      lds_rd16<1024>(dm[0], bn_a + 16 * q); lds_rd16<1088>(dm[1], bn_a + 16 * q); lds_rd16<1152>(dm[2], bn_a + 16 * q); lds_rd16<1216>(dm[3], bn_a + 16 * q);
+      lds_wait();
+      lds_use(mean[0], mean[1], mean[2], mean[3]); lds_use(rstd[0], rstd[1], rstd[2], rstd[3]); lds_use(dm[0], dm[1], dm[2], dm[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gi = c >> 1, ct = c & 1;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (a.moments) w = mm_presplit(gh[gi][ct], gl[gi][ct], zp[2 * gi], zp[2 * gi + 1]);
+        float4 dy;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float zv = at(z[c], x);
+          const float zh = (zv - mean[c][x]) * rstd[c][x];
+          const float d = at(dz[c], x) + dm[c][x] + w[x];
+          const float v = (!ok || (relu && at(zp[c], x) <= 0.f)) ? 0.f : rndT<__bf16>(d);     // as stored: the BN1 sums see the same numbers
+          at(dy, x) = v;
+          at(cs0[c], x) += v; at(cs1[c], x) += v * zh;
+        }
+        dyo[c] = dy;
+      }
+      if (ok) st_row<__bf16, E>((__bf16*)dzp + tok * DZ, e, q, dyo);
+    }
+    const unsigned fb_a = fold_a + 4 * ((vb - vb0) & 1) * NW * fold_stride<2>();
+    fold_put_cols<2>(fb_a, 0, cs0, wave, lane); fold_put_cols<2>(fb_a, 1, cs1, wave, lane);
+    lds_barrier();
+    if (ts == 0) {
+      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      const int idx[2] = {dd, FDD + dd};
+      float v[2];
+      fold_get<E, NS, 2, 2>(fb_a, idx, e, v);
+      colpart[((long)vb * 4 + 2) * (E * FDD) + col] = v[0];
+      colpart[((long)vb * 4 + 3) * (E * FDD) + col] = v[1];
+    }
+  }
+}
+
+template <int E>
+int launch_mdb(const SMidBArgs& a, int gx, const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  static LdsAttrOnce attr;
+  AVMOE_TRY(attr.ensure((const void*)kfs_mid_bwd<E>, 160 * 1024, "mid_bwd (streaming)"));
+  hipLaunchKernelGGL((kfs_mid_bwd<E>), dim3((unsigned)gx), dim3(WS<E>::NTHR), pl.d.excl ? (size_t)160 * 1024 : mdb_lds<E>(), st, a, (const unsigned short*)(saved + pl.o_Z),
+                     (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const float*)(scratch + pl.o_sdSzz), (unsigned short*)(scratch + pl.o_dzp),
+                     (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("mid_bwd (streaming)");
+  return OK;
+}
+
+// =====================================================================================================
+// POST_SMALL forward (bf16)      tile_fast.hip::kf_post_small<__bf16, E>     (net_trans_v3.py:430-434,485-486)
+//   z' = act(BN1(z)), LayerNorm-post statistics from the d x d quadratic form, Apost rows [q rp z' | q rp, -q rp mup, q per expert].
+//   The 3 E scalar columns of a virtual block's rows are written after its tiles, from rp / mup kept in the LDS (tile_fast.hip re-reads
+//   them from global memory): one thread per (token, group) row writes its 6 E bytes as a run.
+// =====================================================================================================
+struct SPostArgs { P16 gate; int relu_of_e[MAX_E]; FastDims t; int ln_post, use_gate, bps, nvb, nfr; float ln_eps; };
+
+constexpr int PSF_NL = 2, PSF_NST = 4;                      // ring loads / stores per wave and tile
+constexpr int PSF_TILE = 2 * 1024;                          // Z (2 x 1 KB)
+template <int E> constexpr int psf_fixed_floats(int nfr, int per) { return E * 4 * FDD + ((nfr * E + 3) & ~3) + 2 * E * per; }
+template <int E> constexpr size_t psf_lds(int nfr, int per) { return (size_t)psf_fixed_floats<E>(nfr, per) * 4 + (size_t)WS<E>::NW * (KFS_P + 1) * PSF_TILE; }
+
+template <int E>
+__global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_post_small(SPostArgs a, const unsigned short* __restrict__ Z, const float* __restrict__ bn1, const float* __restrict__ Gq,
+                                                              const float* __restrict__ uvh, const float* __restrict__ probs, unsigned short* __restrict__ Apost,
+                                                              float* __restrict__ rpmup) {
+  constexpr int DZ = E * FDD, NS = WS<E>::NS, NTHR = WS<E>::NTHR, D = KFS_P + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_uv = (float*)smem;                       // [E][us | vh | sc | sh]
+  float* s_qv = s_uv + E * 4 * FDD;                 // [nfr][E]   probs * gate of the block's frames
+  float* s_rm = s_qv + ((a.nfr * E + 3) & ~3);      // [per][E][rp, mup]  of the virtual block's tokens
+  const FastDims& t = a.t;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
+  char* ring = smem + (size_t)psf_fixed_floats<E>(a.nfr, t.per) * 4 + (size_t)wave * D * PSF_TILE;
+  const unsigned ring_a = lds_off(ring), qv_a = lds_off(s_qv), uv_a = lds_off(s_uv + e * 4 * FDD), rm_a = lds_off(s_rm);
+  const int vb0 = (int)((long)a.nvb * blockIdx.x / gridDim.x), vb1 = (int)((long)a.nvb * (blockIdx.x + 1) / gridDim.x);
+  const int bps = a.bps, per = t.per, N = t.N;
+  const int s_first = vb0 / bps;
+  for (int i = threadIdx.x; i < a.nfr * E; i += NTHR) {
+    const int ee = i % E, s = min(s_first + i / E, t.S - 1);
+    s_qv[i] = probs[(long)s * E + ee] * (a.use_gate ? a.gate.p[ee][0] : 1.f);
+  }
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    float* u = s_uv + ee * 4 * FDD;
+    u[dd] = uvh[col]; u[FDD + dd] = uvh[DZ + col]; u[2 * FDD + dd] = bn1[2 * DZ + col]; u[3 * FDD + dd] = bn1[3 * DZ + col];
+  }
+  float H1 = 0.f, H2 = 0.f;
+  for (int gi = 0; gi < 2; ++gi) { H1 += uvh[2 * DZ + gi * E + e]; H2 += uvh[2 * DZ + 2 * E + gi * E + e]; }
+  __syncthreads();                 // (no C++-level LDS access from here on)
+  auto request = [&](int slot, const TileIt& it) {
+    const long tk = (long)it.s * N + min(it.n0 + r, N - 1);
+    char* dst = ring + slot * PSF_TILE;
+    const char* zs = (const char*)(Z + tk * DZ + e * FDG + seg_off8(q));
+    glds16(zs, dst); glds16(zs + E * FDG * 2, dst + 1024);
+  };
+  TileIt pf = it_first<NS>(vb0, vb1, bps, per, N, ts);
+  int nreq = 0;
+#pragma unroll
+  for (int k = 0; k < KFS_P; ++k)
+    if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+  kf_bf16x8 gh[2][2], gl[2][2];                     // Gq^T rows as bf16 planes (mm_presplit)
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float* g = Gq + (long)(gi * E + e) * FDG * FDG + 16 * ct + r;
+      float4 m0, m1;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { at(m0, x) = g[(4 * q + x) * FDG]; at(m1, x) = g[(16 + 4 * q + x) * FDG]; }
+      kf_split8(m0, m1, gh[gi][ct], gl[gi][ct]);
+    }
+  const bool relu = a.relu_of_e[e];
+  const float fC = (float)t.C;
+  int it = 0;
+  int s = s_first, vbb = vb0 - s_first * bps;
+  for (int vb = vb0; vb < vb1; ++vb, s += (vbb + 1 == bps), vbb = (vbb + 1 == bps) ? 0 : vbb + 1) {
+    const int n_beg = vbb * per, n_end = min(N, n_beg + per);
+    const float qv = lds_rd1(qv_a + 4 * ((s - s_first) * E + e));
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, ++it) {
+      wait_tile<PSF_NL, PSF_NST>(min(KFS_P - 1, nreq - it - 1), min(it, KFS_P));
+      if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+      const bool ok = n0 + r < N;
+      const long tok = (long)s * N + n0 + r;
+      const unsigned sl = ring_a + (it % D) * PSF_TILE;
+      f32x4 rz0, rz1, sc[4], sh[4];
+      lds_rd16<0>(rz0, sl + lane * 16); lds_rd16<1024>(rz1, sl + lane * 16);
+      lds_rd16<512>(sc[0], uv_a + 16 * q); lds_rd16<576>(sc[1], uv_a + 16 * q); lds_rd16<640>(sc[2], uv_a + 16 * q); lds_rd16<704>(sc[3], uv_a + 16 * q);
+      lds_rd16<768>(sh[0], uv_a + 16 * q); lds_rd16<832>(sh[1], uv_a + 16 * q); lds_rd16<896>(sh[2], uv_a + 16 * q); lds_rd16<960>(sh[3], uv_a + 16 * q);
+      lds_wait();
+      lds_use(rz0, rz1); lds_use(sc[0], sc[1], sc[2], sc[3]); lds_use(sh[0], sh[1], sh[2], sh[3]);
+      float4 zraw[4], zp[4];
+      unpack_seg(as_u4(rz0), zraw[0], zraw[1]); unpack_seg(as_u4(rz1), zraw[2], zraw[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float y = at(zraw[c], x) * sc[c][x] + sh[c][x];
+          at(zp[c], x) = relu ? fmaxf(y, 0.f) : y;
+        }
+      float rp = 1.f, mup = 0.f;
+      if (a.ln_post) {
+        f32x4 us[4], vh[4];
+        lds_rd16<0>(us[0], uv_a + 16 * q); lds_rd16<64>(us[1], uv_a + 16 * q); lds_rd16<128>(us[2], uv_a + 16 * q); lds_rd16<192>(us[3], uv_a + 16 * q);
+        lds_rd16<256>(vh[0], uv_a + 16 * q); lds_rd16<320>(vh[1], uv_a + 16 * q); lds_rd16<384>(vh[2], uv_a + 16 * q); lds_rd16<448>(vh[3], uv_a + 16 * q);
+        lds_wait();
+        lds_use(us[0], us[1], us[2], us[3]); lds_use(vh[0], vh[1], vh[2], vh[3]);
+        float so = 0.f, soo = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gi = c >> 1, ct = c & 1;
+          const f32x4 w = mm_presplit(gh[gi][ct], gl[gi][ct], zp[2 * gi], zp[2 * gi + 1]);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float zv = at(zp[c], x);
+            so += zv * us[c][x];
+            soo += zv * (w[x] + 2.f * vh[c][x]);
+          }
+        }
+        const float So = qsum4(so) + H1, Soo = qsum4(soo) + H2;
+        mup = So / fC;
+        rp = rsqrtf(fmaxf(Soo / fC - mup * mup, 0.f) + a.ln_eps);
+      }
+      if (q == 2) {                                  // (this virtual block's rp / mup, for its scalar-column pass below)
+        const unsigned o = rm_a + 4 * (((n0 - n_beg) + r) * E + e) * 2;
+        lds_wr1(o, rp); lds_wr1(o + 4, mup);
+      }
+      if (ok) {
+        const float scl = qv * rp;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const float4 v0 = make_float4(scl * zp[2 * gi].x, scl * zp[2 * gi].y, scl * zp[2 * gi].z, scl * zp[2 * gi].w);
+          const float4 v1 = make_float4(scl * zp[2 * gi + 1].x, scl * zp[2 * gi + 1].y, scl * zp[2 * gi + 1].z, scl * zp[2 * gi + 1].w);
+          st_seg<__bf16>((__bf16*)Apost + (tok * 2 + gi) * t.KPp + e * FDG, v0, v1, q);
+        }
+        if (q == 2) { rpmup[(long)e * t.NT + tok] = rp; rpmup[(long)t.NT * E + (long)e * t.NT + tok] = mup; }
+      }
+    }
+    // the 3 E scalar columns [q rp, -q rp mup, q] of the virtual block's (token, group) rows, for all experts at once
+    lds_barrier();
+    {
+      float qe[E];
+#pragma unroll
+      for (int ee = 0; ee < E; ++ee) qe[ee] = lds_rd1(qv_a + 4 * ((s - s_first) * E + ee));
+      for (int idx = threadIdx.x; idx < 2 * (n_end - n_beg); idx += NTHR) {
+        const int tl = idx >> 1;
+        const long tok = (long)s * N + n_beg + tl;
+        float v[3 * E], rm[2 * E];
+#pragma unroll
+        for (int ee = 0; ee < 2 * E; ++ee) lds_rd1_issue(rm[ee], rm_a + 4 * (tl * E * 2 + ee));
+        lds_wait();
+#pragma unroll
+        for (int ee = 0; ee < E; ++ee) {
+          lds_use(rm[2 * ee]); lds_use(rm[2 * ee + 1]);
+          v[3 * ee] = qe[ee] * rm[2 * ee]; v[3 * ee + 1] = -qe[ee] * rm[2 * ee] * rm[2 * ee + 1]; v[3 * ee + 2] = qe[ee];
+        }
+        unsigned* d32 = (unsigned*)(Apost + (tok * 2 + (idx & 1)) * t.KPp + E * FDG);      // (E * FDG even, KPp a multiple of 4: 4-byte aligned)
+#pragma unroll
+        for (int j = 0; j + 1 < 3 * E; j += 2) d32[j >> 1] = (unsigned)f2bf(v[j]) | ((unsigned)f2bf(v[j + 1]) << 16);
+        if constexpr ((3 * E) & 1) Apost[(tok * 2 + (idx & 1)) * t.KPp + E * FDG + 3 * E - 1] = f2bf(v[3 * E - 1]);
+      }
+    }
+    lds_barrier();                 // (s_rm is rewritten by the next virtual block's tiles)
+  }
+}
+
+template <int E>
+int launch_psf(const SPostArgs& a, int gx, const Plan& pl, char* saved, hipStream_t st) {
+  static LdsAttrOnce attr;
+  AVMOE_TRY(attr.ensure((const void*)kfs_post_small<E>, 160 * 1024, "post_small (streaming)"));
+  hipLaunchKernelGGL((kfs_post_small<E>), dim3((unsigned)gx), dim3(WS<E>::NTHR), pl.d.excl ? (size_t)160 * 1024 : psf_lds<E>(a.nfr, a.t.per), st, a,
+                     (const unsigned short*)(saved + pl.o_Z), (const float*)(saved + pl.o_bn1), (const float*)(saved + pl.o_Gq), (const float*)(saved + pl.o_uvh),
+                     (const float*)(saved + pl.o_probs), (unsigned short*)(saved + pl.o_Apost), (float*)(saved + pl.o_rpmup));
+  AVMOE_CHECK_LAUNCH("post_small (streaming)");
+  return OK;
+}
+
+// =====================================================================================================
+// PRE_SMALL forward (bf16, fused hop-2 logits)      tile_fast.hip::kf_pre_small<__bf16, E, false>     (net_trans_v3.py:385-395)
+//   hop-2 softmax over the latent tokens, the folded LayerNorm-before, z in place, BatchNorm-1 column sums.
+//   One tile ahead (the cross-modal waves' tiles are 6.4 KB: Z, two planes of logits, row sums); the per-FRAME constants of the cross-modal
+//   experts (TT^T, TW^T, Tsum: 14 KB per latent slot) sit in two LDS buffers -- the next frame's are requested by direct dword loads whose
+//   per-lane SOURCE addresses do the transposition and the padding, at the start of the current frame, and published by the barrier of the
+//   frame's last virtual block (in-order counter: a wave that has waited for a tile requested after them has them).
+// =====================================================================================================
+struct SPreArgs { P16 glat; int lat_of_e[MAX_E]; FastDims t; int ln_before, bps, nvb; float ln_eps; const float* L2g; float* L2w; };
+
+constexpr int PRS_P = 1, PRS_D = PRS_P + 1;
+constexpr int PRS_LATF = 55 * 64;                           // dwords of a latent slot's constants: TT^T 32 x 36 | TW^T 64 x 36 | Tsum 32 | pad (whole 64-dword pieces)
+constexpr int PRS_TILE_X = 2 * 1024 + 4 * 1024 + 256, PRS_TILE_U = 2 * 1024 + 256;      // ring bytes per tile: cross-modal / unimodal wave
+constexpr int PRS_NL_X = 7, PRS_NST_X = 7, PRS_NL_U = 3, PRS_NST_U = 4;
+template <int E> constexpr int prs_fixed_floats(int El) { return 2 * WS<E>::NW * fold_stride<2>() + E * 2 * FDD + 2 * El * PRS_LATF; }
+template <int E> constexpr size_t prs_lds(int El) { return (size_t)prs_fixed_floats<E>(El) * 4 + (size_t)WS<E>::NS * PRS_D * ((size_t)El * PRS_TILE_X + (size_t)(E - El) * PRS_TILE_U); }
+
+// a transposed mat-vec step with the matrix rows in the LDS (fp32, leading dimension LD32): A-operand rows (col0 + r), entries 4 q .. and 16 + 4 q ..
+__device__ __forceinline__ void mm_lds_issue(f32x4& a0, f32x4& a1, unsigned mt_a, int col0, int r, int q) {
+  const unsigned ad = mt_a + 4 * ((col0 + r) * LD32 + 4 * q);
+  lds_rd16<0>(a0, ad); lds_rd16<64>(a1, ad);
+}
+__device__ __forceinline__ f32x4 mm_lds_finish(const f32x4& a0, const f32x4& a1, const float4& p0, const float4& p1) {
+  kf_bf16x8 ah, al;
+  kf_split8(make_float4(a0[0], a0[1], a0[2], a0[3]), make_float4(a1[0], a1[1], a1[2], a1[3]), ah, al);
+  return mm_presplit(ah, al, p0, p1);
+}
+
+template <int E>
+__global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_pre_small(SPreArgs a, unsigned short* __restrict__ Z, const float* __restrict__ sxs, const float* __restrict__ TT,
+                                                             const float* __restrict__ TW, const float* __restrict__ Tsum, const float* __restrict__ wsum,
+                                                             const float* __restrict__ dconst, unsigned short* __restrict__ aout, float* __restrict__ rmu,
+                                                             float* __restrict__ colpart) {
+  constexpr int DZ = E * FDD, NS = WS<E>::NS, NW = WS<E>::NW, NTHR = WS<E>::NTHR, D = PRS_D;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FastDims& t = a.t;
+  const int El = t.El;
+  float* s_fold = (float*)smem;                             // [2][NW][2 * 64 + 4]
+  float* s_ce = s_fold + 2 * NW * fold_stride<2>();         // [E][wsum | dconst]
+  float* s_lat = s_ce + E * 2 * FDD;                        // [2 buffers][El][PRS_LATF]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int e = wave % E, ts = wave / E;
+  const int l = a.lat_of_e[e];
+  const bool lat = l >= 0;
+  // this wave's ring: the cross-modal waves' tiles are larger (tile slots ts, experts in order: cross-modal experts first or not -- a prefix sum)
+  int roff = ts * (El * PRS_TILE_X + (E - El) * PRS_TILE_U);
+  for (int ee = 0; ee < e; ++ee) roff += a.lat_of_e[ee] >= 0 ? PRS_TILE_X : PRS_TILE_U;
+  const int tile_b = lat ? PRS_TILE_X : PRS_TILE_U;
+  char* ring = smem + (size_t)prs_fixed_floats<E>(El) * 4 + (size_t)roff * D;
+  const unsigned ring_a = lds_off(ring), fold_a = lds_off(s_fold), ce_a = lds_off(s_ce + e * 2 * FDD), lat_a = lds_off(s_lat);
+  const int vb0 = (int)((long)a.nvb * blockIdx.x / gridDim.x), vb1 = (int)((long)a.nvb * (blockIdx.x + 1) / gridDim.x);
+  const int bps = a.bps, per = t.per, N = t.N;
+  const int s_first = vb0 / bps, s_last = (vb1 - 1) / bps;
+  const float gv = lat ? a.glat.p[e][0] : 0.f;
+  const float fC = (float)t.C, invC = 1.f / (float)t.C;
+
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    s_ce[ee * 2 * FDD + dd] = wsum[col]; s_ce[ee * 2 * FDD + FDD + dd] = dconst[col];
+  }
+  __syncthreads();                 // (no C++-level LDS access from here on)
+
+  // frame s's constants of every latent slot -> buffer s & 1: 55 dword pieces per slot dealt to the waves; LDS dword p of a slot <- the source
+  // element that belongs there (transposition and padding by address)
+  auto request_lat = [&](int s) {
+    for (int ll = 0; ll < El; ++ll) {
+      int ee = 0;
+      for (int x = 0; x < E; ++x) if (a.lat_of_e[x] == ll) ee = x;
+      const float* tt = TT + ((long)s * El + ll) * FK * FK;
+      const float* tw = TW + ((long)s * t.KLT + (long)ll * FK) * DZ;
+      const float* tsu = Tsum + (long)s * t.KLT + (long)ll * FK;
+      char* dst = (char*)(s_lat + ((s & 1) * El + ll) * PRS_LATF);
+      for (int j = wave; j < PRS_LATF / 64; j += NW) {
+        const int p = 64 * j + lane;
+        const float* src = tt;
+        if (p < FK * LD32) { const int c = p / LD32, k = p - c * LD32; if (k < FK) src = tt + k * FK + c; }
+        else if (p < FK * LD32 + FDD * LD32) { const int pp = p - FK * LD32, dd = pp / LD32, k = pp - dd * LD32; if (k < FK) src = tw + (long)k * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31); }
+        else if (p < FK * LD32 + FDD * LD32 + FK) src = tsu + (p - FK * LD32 - FDD * LD32);
+        glds4(src, dst + 256 * j);
+      }
+    }
+  };
+  auto request = [&](int slot, const TileIt& it) {
+    const long f0 = (long)it.s * N;
+    const long tk = f0 + min(it.n0 + r, N - 1);
+    char* dst = ring + slot * tile_b;
+    const char* zs = (const char*)(Z + tk * DZ + e * FDG + seg_off8(q));
+    glds16(zs, dst); glds16(zs + E * FDG * 2, dst + 1024);
+    const long t2 = f0 + min(it.n0 + (lane >> 2), N - 1);
+    glds4(sxs + ((lane & 1) ? (long)t.NT : 0L) + t2, dst + 2048);          // [token][Sx, Sxx, Sx, Sxx]
+    if (lat) {
+      const char* lg = (const char*)(a.L2g + tk * t.KL + (long)l * FK + 4 * q);
+      glds16(lg, dst + 2304); glds16(lg + 64, dst + 3328);
+      glds16(lg + (long)t.NT * t.KL * 4, dst + 4352); glds16(lg + (long)t.NT * t.KL * 4 + 64, dst + 5376);
+    }
+  };
+  if (El > 0) request_lat(s_first);
+  TileIt pf = it_first<NS>(vb0, vb1, bps, per, N, ts);
+  int nreq = 0;
+  if (pf.vb < vb1) { request(0, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+  wait_vm<0>();
+  lds_barrier();                   // the first frame's constants (and nothing of the ring is read before its own wait)
+  wait_vm<0>();
+
+  int it = 0;
+  int s = s_first, vbb = vb0 - s_first * bps;
+  int since = 2;                   // tiles this wave has waited for since its last request_lat (>= 2: those loads have landed)
+  bool fresh = true;               // the next tile is the wave's first of a frame whose successor's constants are not requested yet
+  for (int vb = vb0; vb < vb1; ++vb) {
+    const int n_beg = vbb * per, n_end = min(N, n_beg + per);
+    const unsigned lt_a = lat_a + 4 * (((s & 1) * El + (lat ? l : 0)) * PRS_LATF);      // TT^T | TW^T | Tsum of this wave's slot, this frame
+    float4 cs0[4], cs1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+    if (fresh && El > 0 && s < s_last) { request_lat(s + 1); since = 0; }       // (every wave, whether it has a tile in this virtual block or not)
+    fresh = false;
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, ++it) {
+      if (lat) wait_tile<PRS_NL_X, PRS_NST_X>(min(PRS_P - 1, nreq - it - 1), min(it, PRS_P));
+      else wait_tile<PRS_NL_U, PRS_NST_U>(min(PRS_P - 1, nreq - it - 1), min(it, PRS_P));
+      ++since;
+      if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+      const bool ok = n0 + r < N;
+      const long tok = (long)s * N + n0 + r;
+      const unsigned sl = ring_a + (it % D) * tile_b;
+      f32x4 rz0, rz1, rs, ws[4], dc[4];
+      lds_rd16<0>(rz0, sl + lane * 16); lds_rd16<1024>(rz1, sl + lane * 16); lds_rd16<2048>(rs, sl + r * 16);
+      lds_rd16<0>(ws[0], ce_a + 16 * q); lds_rd16<64>(ws[1], ce_a + 16 * q); lds_rd16<128>(ws[2], ce_a + 16 * q); lds_rd16<192>(ws[3], ce_a + 16 * q);
+      lds_rd16<256>(dc[0], ce_a + 16 * q); lds_rd16<320>(dc[1], ce_a + 16 * q); lds_rd16<384>(dc[2], ce_a + 16 * q); lds_rd16<448>(dc[3], ce_a + 16 * q);
+      float Sx, Sxx;
+      float4 z[4], zo[4], lg[2], av[2] = {zero4(), zero4()};
+      f32x4 pw[4];                                   // (a TW) for the four 16-entry chunks
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pw[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (lat) {
+        f32x4 a0, a1, b0, b1, tb0, tb1;
+        lds_rd16<2304>(a0, sl + lane * 16); lds_rd16<3328>(a1, sl + lane * 16); lds_rd16<4352>(b0, sl + lane * 16); lds_rd16<5376>(b1, sl + lane * 16);
+        lds_rd16<0>(tb0, lt_a + 4 * (FK * LD32 + FDD * LD32) + 16 * q); lds_rd16<64>(tb1, lt_a + 4 * (FK * LD32 + FDD * LD32) + 16 * q);
+        lds_wait();
+        lds_use(rz0, rz1, rs, a0, a1, b0, b1, tb0, tb1);
+        lds_use(ws[0], ws[1], ws[2], ws[3]); lds_use(dc[0], dc[1], dc[2], dc[3]);
+        Sx = ok ? rs[0] : 0.f; Sxx = ok ? rs[1] : 1.f;
+        lg[0] = make_float4(a0[0] + b0[0], a0[1] + b0[1], a0[2] + b0[2], a0[3] + b0[3]);
+        lg[1] = make_float4(a1[0] + b1[0], a1[1] + b1[1], a1[2] + b1[2], a1[3] + b1[3]);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) mx = fmaxf(mx, at(lg[j], x));
+        mx = qmax4(mx);
+        float sum = 0.f;
+        float4 ex[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { at(ex[j], x) = __expf(at(lg[j], x) - mx); sum += at(ex[j], x); }
+        sum = qsum4(sum);
+        const float inv = ok ? 1.f / sum : 0.f;
+        float u1 = 0.f, u2 = 0.f;
+        const f32x4 tbv[2] = {tb0, tb1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float v = rndT<__bf16>(at(ex[j], x) * inv);
+            at(av[j], x) = v;
+            u1 += v * (tbv[j][x] / fC); u2 += v * at(lg[j], x);
+          }
+        u1 = qsum4(u1); u2 = qsum4(u2);
+        // mat-vecs against this frame's TT and TW (matrix rows from the LDS, all reads of a step issued together)
+        f32x4 m[12];
+        mm_lds_issue(m[0], m[1], lt_a, 0, r, q); mm_lds_issue(m[2], m[3], lt_a, 16, r, q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mm_lds_issue(m[4 + 2 * c], m[5 + 2 * c], lt_a + 4 * FK * LD32, 16 * c, r, q);
+        lds_wait();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) lds_use(m[i]);
+        float u3 = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 w = mm_lds_finish(m[2 * ct], m[2 * ct + 1], av[0], av[1]);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) u3 += w[x] * at(av[ct], x);
+        }
+        u3 = qsum4(u3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pw[c] = mm_lds_finish(m[4 + 2 * c], m[5 + 2 * c], av[0], av[1]);
+        Sx += gv * fC * u1;
+        Sxx += 2.f * gv * u2 + gv * gv * u3;
+      } else {
+        lds_wait();
+        lds_use(rz0, rz1, rs);
+        lds_use(ws[0], ws[1], ws[2], ws[3]); lds_use(dc[0], dc[1], dc[2], dc[3]);
+        Sx = ok ? rs[0] : 0.f; Sxx = ok ? rs[1] : 1.f;
+        lg[0] = lg[1] = zero4();
+      }
+      unpack_seg(as_u4(rz0), z[0], z[1]); unpack_seg(as_u4(rz1), z[2], z[3]);
+      float mu = 0.f, rr = 1.f;
+      if (a.ln_before) {
+        mu = Sx / fC;
+        rr = rsqrtf(fmaxf(Sxx / fC - mu * mu, 0.f) + a.ln_eps);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 o;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float zr = at(z[c], x) + gv * pw[c][x];
+          const float zv = rndT<__bf16>(a.ln_before ? rr * (zr - mu * ws[c][x]) + dc[c][x] : zr);   // as stored: BN1 statistics of the stored z
+          at(o, x) = zv;
+          if (ok) { at(cs0[c], x) += zv; at(cs1[c], x) += zv * zv; }
+        }
+        zo[c] = o;
+      }
+      // PRS_NST_X / PRS_NST_U store instructions per tile, exactly (lane r = 0 of a tile in range is valid)
+      if (ok) {
+        if (lat) {
+          st_seg<__bf16>((__bf16*)aout + (long)l * t.aL + tok * FK, av[0], av[1], q);
+          float* lw = a.L2w + tok * t.KL + (long)l * FK + 4 * q;         // the logits themselves (the backward's hop-2 block reads them)
+          *(float4*)lw = lg[0]; *(float4*)(lw + 16) = lg[1];
+        }
+        st_row<__bf16, E>((__bf16*)Z + tok * DZ, e, q, zo);
+        if (q == 0) { rmu[(long)e * t.NT + tok] = rr; rmu[(long)t.NT * E + (long)e * t.NT + tok] = mu; }
+      }
+    }
+    const unsigned fb_a = fold_a + 4 * ((vb - vb0) & 1) * NW * fold_stride<2>();
+    fold_put_cols<2>(fb_a, 0, cs0, wave, lane); fold_put_cols<2>(fb_a, 1, cs1, wave, lane);
+    const bool frame_ends = vbb + 1 == bps;
+    if (frame_ends && since < 2) wait_vm<0>();        // the next frame's constants this wave requested: landed before the barrier publishes them
+    lds_barrier();
+    if (ts == 0) {
+      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      const int idx[2] = {dd, FDD + dd};
+      float v[2];
+      fold_get<E, NS, 2, 2>(fb_a, idx, e, v);
+      colpart[((long)vb * 4 + 0) * (E * FDD) + col] = v[0];
+      colpart[((long)vb * 4 + 1) * (E * FDD) + col] = v[1];
+    }
+    if (frame_ends) { vbb = 0; ++s; fresh = true; } else ++vbb;
+  }
+}
+
+template <int E>
+int launch_prs(const SPreArgs& a, int gx, const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  static LdsAttrOnce attr;
+  AVMOE_TRY(attr.ensure((const void*)kfs_pre_small<E>, 160 * 1024, "pre_small (streaming)"));
+  hipLaunchKernelGGL((kfs_pre_small<E>), dim3((unsigned)gx), dim3(WS<E>::NTHR), pl.d.excl ? (size_t)160 * 1024 : prs_lds<E>(a.t.El), st, a, (unsigned short*)(saved + pl.o_Z),
+                     (const float*)(saved + pl.o_sx), (const float*)(saved + pl.o_TT), (const float*)(saved + pl.o_TW), (const float*)(saved + pl.o_Tsum),
+                     (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (unsigned short*)(saved + pl.o_a), (float*)(saved + pl.o_rmu),
+                     (float*)(scratch + pl.o_colpart));
+  AVMOE_CHECK_LAUNCH("pre_small (streaming)");
+  return OK;
+}
+
 FastDims make_fd_s(const Dims& d, int per) {
   FastDims t;
   t.S = d.S; t.N = d.N; t.C = d.C; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp; t.KPp = d.KPp; t.NT = d.NT; t.per = per; t.aL = d.aL;
@@ -457,6 +1017,68 @@ FastDims make_fd_s(const Dims& d, int per) {
 bool tile_stream_ok(const Dims& d) {
   const unsigned hooks = test_hook_mask();            // (include/avmoe.h: avmoe_test_hooks -- small test shapes through these kernels / the A/B against tile_fast.hip)
   return tile_fast_ok(d) && d.bf16 && d.zsz == 2 && (d.NT >= 32768 || (hooks & HOOK_KFS_FORCE)) && !(hooks & HOOK_KFS_OFF);
+}
+
+static bool psf_geom(const Dims& d, int* gx, int* nfr, int* per) {
+  const int cus = cu_count();
+  if (cus <= 0) return false;
+  const int bps = d.nblk_tok / d.S;
+  *gx = std::min(cus, d.nblk_tok);
+  *nfr = cdiv(cdiv(d.nblk_tok, *gx) + 1, bps) + 1;
+  *per = (int)round_up(cdiv(d.N, bps), 16);
+  const size_t lds = d.E == 4 ? psf_lds<4>(*nfr, *per) : d.E == 2 ? psf_lds<2>(*nfr, *per) : psf_lds<3>(*nfr, *per);
+  return lds <= 160 * 1024;
+}
+bool kfs_serves_post_small(const Dims& d) { int a, b, c; return tile_stream_ok(d) && psf_geom(d, &a, &b, &c); }
+// 0 = launched, 1 = not served (the caller runs tile_fast.hip's kernel), < 0 error
+int kfs_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!kfs_serves_post_small(d)) return 1;
+  int gx, nfr, per;
+  psf_geom(d, &gx, &nfr, &per);
+  SPostArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.gate.p[e] = prm.e[e].gate; a.relu_of_e[e] = d.relu_of_e[e]; }
+  a.t = make_fd_s(d, per); a.ln_post = d.ln_post; a.use_gate = d.use_gate && !d.gate_w; a.ln_eps = d.ln_eps;
+  a.bps = d.nblk_tok / d.S; a.nvb = d.nblk_tok; a.nfr = nfr;
+  if (d.E == 4) return launch_psf<4>(a, gx, pl, saved, st);
+  if (d.E == 2) return launch_psf<2>(a, gx, pl, saved, st);
+  return launch_psf<3>(a, gx, pl, saved, st);
+}
+
+// (cross-modal experts need the fused hop-2 logits of the down projection's pass: Dims::fuse_l2; no x + g xr experts)
+bool kfs_serves_pre_small(const Dims& d) {
+  if (!tile_stream_ok(d) || d.nxn || (d.El > 0 && !d.fuse_l2) || cu_count() <= 0) return false;
+  const size_t lds = d.E == 4 ? prs_lds<4>(d.El) : d.E == 2 ? prs_lds<2>(d.El) : prs_lds<3>(d.El);
+  return lds <= 160 * 1024;
+}
+// 0 = launched, 1 = not served (the caller runs tile_fast.hip's kernel), < 0 error
+int kfs_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!kfs_serves_pre_small(d)) return 1;
+  const int bps = d.nblk_tok / d.S;
+  SPreArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.t = make_fd_s(d, (int)round_up(cdiv(d.N, bps), 16)); a.ln_before = d.ln_before; a.ln_eps = d.ln_eps; a.bps = bps; a.nvb = d.nblk_tok;
+  a.L2g = d.El > 0 ? (const float*)(scratch + pl.o_L2g) : nullptr; a.L2w = d.El > 0 ? (float*)(saved + pl.o_L2) : nullptr;
+  const int gx = std::min(cu_count(), a.nvb);
+  if (d.E == 4) return launch_prs<4>(a, gx, pl, saved, scratch, st);
+  if (d.E == 2) return launch_prs<2>(a, gx, pl, saved, scratch, st);
+  return launch_prs<3>(a, gx, pl, saved, scratch, st);
+}
+
+bool kfs_serves_mid_bwd(const Dims& d) { return tile_stream_ok(d) && cu_count() > 0; }
+// 0 = launched, 1 = not served (the caller runs tile_fast.hip's kernel), < 0 error
+int kfs_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!kfs_serves_mid_bwd(d)) return 1;
+  const int bps = d.nblk_tok / d.S;
+  SMidBArgs a;
+  for (int e = 0; e < MAX_E; ++e) a.relu_of_e[e] = d.relu_of_e[e];
+  a.t = make_fd_s(d, (int)round_up(cdiv(d.N, bps), 16)); a.moments = d.use_bn && d.training; a.bps = bps; a.nvb = d.nblk_tok;
+  const int gx = std::min(cu_count(), a.nvb);
+  if (d.E == 4) return launch_mdb<4>(a, gx, pl, saved, scratch, st);
+  if (d.E == 2) return launch_mdb<2>(a, gx, pl, saved, scratch, st);
+  return launch_mdb<3>(a, gx, pl, saved, scratch, st);
 }
 
 // launch geometry of the streaming kernels: persistent blocks, frames a block's range of virtual blocks can touch

@@ -45,7 +45,8 @@ typedef struct avmoe_gemm_desc {
   int32_t accumulate, ksplit, tile;
   int32_t fp32_planes;              /* ABI 9, fp32 operands: 0 = products on v_mfma_f32_16x16x4_f32, 1 = on the bf16 matrix pipe with every value as three
                                        bf16 planes (six plane products of order <= 2: 5.8e-9 relative per product, fp32 accumulation) -- what the site's
-                                       backward uses; avmoe_amd/csrc/gemm.h::GemmArgs::split3 */
+                                       site calls use; 2 (ABI 11) = two planes, the three plane products of order <= 1: 1.5e-5 relative per product at half the
+                                       matrix-pipe work (not used by the site calls: csrc/moe_run.h); avmoe_amd/csrc/gemm.h::GemmArgs::split3 */
   float alpha;
   int64_t lda, ldb, sA1, sA2, sB1, sB2;
   int64_t sCi, sCj, sC1, sC2;

@@ -33,6 +33,35 @@ template <int NJ>
 __device__ __forceinline__ f32x4 mmT(const float* Mt, int ld, int col0, const float4* p, int r, int q) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* mp = Mt + (col0 + r) * ld + 4 * q;
+#if defined(MIT) && MIT == 22      // the split form with NO dependent matrix instructions: every product into a zero accumulator, summed by the VALU
+#pragma unroll
+  for (int j = 0; j < NJ; j += 2) {
+    bf16x8 ah, al, ph, pl;
+    split8(*(const float4*)(mp + 16 * j), *(const float4*)(mp + 16 * (j + 1)), ah, al);
+    split8(p[j], p[j + 1], ph, pl);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph, z, 0, 0, 0);
+    const f32x4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl, z, 0, 0, 0);
+    const f32x4 a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph, z, 0, 0, 0);
+    acc += (a0 + a1) + a2;
+  }
+  return acc;
+#endif
+#if defined(MIT) && MIT == 23      // the exact-fp32 form with no dependent matrix instructions
+  {
+    f32x4 part[NJ * 4];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 av = *(const float4*)(mp + 16 * j);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) part[4 * j + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(at(av, x), at(p[j], x), z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NJ * 4; ++i) acc += part[i];
+    return acc;
+  }
+#endif
 #if defined(MIT) && (MIT == 20 || MIT == 21)
 #pragma unroll
   for (int j = 0; j < NJ; j += 2) {

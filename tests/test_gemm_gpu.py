@@ -172,6 +172,24 @@ def test_fp32_three_plane_form_is_an_fp32_product(a_mn, b_mn, tile):
     assert torch.equal(g128, gt)
 
 
+@pytest.mark.parametrize("a_mn,b_mn", LAYOUTS)
+@pytest.mark.parametrize("tile", [32, 64, 128])
+def test_fp32_two_plane_form(a_mn, b_mn, tile):
+    """ABI 11 `fp32_planes = 2` (csrc/gemm.hip: f32s2 -- two bf16 planes per value, split once on the way into the LDS, three plane products):
+    2^-16 relative per product, exact on integers that fit two planes, every tile and layout, ragged shapes, split K, epilogue; the same numbers
+    whatever tile runs them.  (Offered through avmoe_gemm; the site calls keep three planes: csrc/moe_run.h.)"""
+    got_i, ref_i = _run_gemm(80, 48, 96, 0, a_mn, b_mn, tile=tile, exact_ints=True, seed=tile, planes=2)
+    assert torch.equal(got_i, ref_i)
+    for shape, kw in (((200, 136, 196), {}), ((333, 70, 1030), {}), ((96, 40, 5000), dict(ksplit=7, nb1=2)), ((150, 92, 72), dict(accumulate=True, epilogue=True))):
+        M, N, K = shape
+        got2, ref = _run_gemm(M, N, K, 0, a_mn, b_mn, tile=tile, seed=M + K, planes=2, **kw)
+        e2 = float((got2 - ref).norm()) / float(ref.norm())
+        assert e2 < 3e-5, (shape, e2)
+    g128, _ = _run_gemm(200, 136, 196, 0, a_mn, b_mn, tile=128, seed=3, planes=2)
+    gt, _ = _run_gemm(200, 136, 196, 0, a_mn, b_mn, tile=tile, seed=3, planes=2)
+    assert torch.equal(g128, gt)
+
+
 def test_alignment_contract_is_enforced():
     from avmoe_amd import _capi as capi
     L = capi.lib()
