@@ -198,7 +198,7 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
   static bool attr = false;
   if (!attr) {
     for (const void* k : kerns)
-      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * GT * (256 * 2 + 16) + 2 * 4 * GT * sizeof(float))) != hipSuccess) {
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
         set_last_error("gram64: LDS attribute"); return ERR_LAUNCH;
       }
     attr = true;
@@ -208,7 +208,10 @@ int k_gram64(const Plan& pl, const void* Zp, const float* w, float scale, float*
   unsigned relu_mask = 0;
   for (int e = 0; e < d.E; ++e) relu_mask |= d.relu_of_e[e] ? (1u << e) : 0u;
   if (mz && !colpart) { set_last_error("gram64: column means need the per-block workspace"); return ERR_BAD_ARG; }
-#define GRAM_LAUNCH(WT, GE_, XF_) hipLaunchKernelGGL((kg_gram64<WT, GE_, XF_>), dim3(used), dim3(256), sh, st, zp, w, part, (long)d.NT, tpb, bn1, relu_mask, mz ? colpart : nullptr)
+  // Dims::excl (shared_gpu): 80 KB per block -- two blocks (the residency the kernel has anyway at 4 experts) fill the CU, no block of another
+  // stream's kernel beside this matrix-pipe kernel (tile_fast.hip has the reason)
+  const size_t shx = d.excl ? std::max(sh, (size_t)80 * 1024) : sh;
+#define GRAM_LAUNCH(WT, GE_, XF_) hipLaunchKernelGGL((kg_gram64<WT, GE_, XF_>), dim3(used), dim3(256), shx, st, zp, w, part, (long)d.NT, tpb, bn1, relu_mask, mz ? colpart : nullptr)
   if (d.E == 4) {
     if (bn1) { if (w) GRAM_LAUNCH(true, 4, true); else GRAM_LAUNCH(false, 4, true); }
     else { if (w) GRAM_LAUNCH(true, 4, false); else GRAM_LAUNCH(false, 4, false); }

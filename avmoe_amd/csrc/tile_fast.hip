@@ -1019,17 +1019,46 @@ bool tile_fast_ok(const Dims& d) { return tile_fast_shape(d) && !d.gen; }      /
 // (kernels still in the expert-outer form run 256 threads whatever E is: LAUNCH_TEX*)
 #define NTHR_OF(NE) (WE<NE>::NTHR)
 // dynamic LDS above the default limit needs the attribute once per kernel function
-static int fast_lds(const void* fn, size_t bytes, const char* what) {
-  if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    set_last_error("%s: %zu bytes of dynamic LDS refused", what, bytes); return ERR_UNSUPPORTED;
+// per kernel function: its static LDS (asked once) and the per-device flag of the dynamic-LDS limit (raised once to what the CU has left)
+struct FastFn { const void* fn; size_t stat; LdsAttrOnce once; };
+static FastFn* fast_fn(const void* fn) {
+  static FastFn cache[128] = {};      // (a few dozen instantiations; a race between two host threads writes the same values twice)
+  for (int i = 0; i < 128; ++i) {
+    if (cache[i].fn == fn) return &cache[i];
+    if (!cache[i].fn) {
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      cache[i].stat = fa.sharedSizeBytes; cache[i].fn = fn;
+      return &cache[i];
+    }
   }
-  return OK;
+  return nullptr;
+}
+// dynamic LDS above the default limit needs the attribute once per kernel function (and device)
+static int fast_lds(const void* fn, size_t bytes, const char* what) {
+  if (bytes <= 64 * 1024) return OK;
+  FastFn* f = fast_fn(fn);
+  if (!f) { set_last_error("%s: kernel attributes", what); return ERR_LAUNCH; }
+  if (f->stat + bytes > 160 * 1024) { set_last_error("%s: %zu + %zu bytes of LDS", what, f->stat, bytes); return ERR_UNSUPPORTED; }
+  return f->once.ensure(fn, (int)(160 * 1024 - f->stat), what);
+}
+// Dims::excl (avmoe_moe_desc::shared_gpu: kernels of another stream may be on the GPU).  scripts/mfma_probe.hip, round 6 (profiles/r06_mfma_probe.txt):
+// the split-bf16 mat-vecs of these kernels go wrong beside another kernel's long matrix instructions exactly like the fp32 ones, so this family
+// takes the CU's LDS too: a grid of at most one block per CU (every small site) asks for 150 KB per block -- nothing fits beside it, and nothing is
+// lost; a larger grid asks for 80 KB, two blocks fill a CU (eight waves instead of twelve; a foreign block can only slip in beside the first or
+// the last block of a CU).  Large bf16 sites run the passes that use the matrix pipe in csrc/tile_stream.hip, whose blocks own their CU anyway.
+static size_t fast_excl_lds(const void* fn, size_t sh, unsigned nblocks, int excl) {
+  if (!excl) return sh;
+  const FastFn* f = fast_fn(fn);
+  if (!f) return sh;
+  const size_t target = (int)nblocks <= cu_count() ? (size_t)150 * 1024 : (size_t)80 * 1024;
+  return std::max(sh, target > f->stat ? target - f->stat : (size_t)0);
 }
 #define LAUNCH_K(FN, NTH, SH, ...)                                                                     \
   do {                                                                                                 \
-    AVMOE_TRY(fast_lds((const void*)(FN), (SH), #FN));                                                 \
-    hipLaunchKernelGGL((FN), grid, dim3(NTH), (SH), st, __VA_ARGS__);                                  \
+    const size_t sh__ = fast_excl_lds((const void*)(FN), (SH), grid.x * grid.y, d.excl);               \
+    AVMOE_TRY(fast_lds((const void*)(FN), sh__, #FN));                                                 \
+    hipLaunchKernelGGL((FN), grid, dim3(NTH), sh__, st, __VA_ARGS__);                                  \
   } while (0)
 #define LAUNCH_TE1(bf16, KERN, NE, NTH, SH, ...)                                                       \
   do {                                                                                                 \

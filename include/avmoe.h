@@ -99,17 +99,27 @@ typedef struct avmoe_moe_desc {
    * victim's LDS read width (ds_read_b128 or two ds_read_b64) and whatever wait states follow its MFMAs, and 0 again once the
    * victim's blocks take a whole CU's LDS each (no other block fits beside them; requests with which 2 or 4 of them fill a CU do not
    * suffice: a block can land beside foreign blocks that are already there).
-   * What the flag does: the bottleneck-space kernels of the generalised family (csrc/tile_gen.inc: every site shape of the reference's
-   * models except the tuned one) and of the any-shape fallback (csrc/tile_kernels.hip) launch with 150 KB of dynamic LDS, one block per
-   * CU; the backward does not fork its dBpost product beside them.  NOT covered: the tuned instance csrc/tile_fast.hip (bottleneck 64
-   * in 2 groups, 32 latent tokens: BASELINE config 2) -- its mat-vecs run on the bf16 matrix pipe in split form and its blocks fill a
-   * CU's LDS among themselves; it has not moved in > 130 two-stream repetitions (tests/test_two_stream_repeat_gpu.py guards it), but
-   * nothing excludes a foreign block beside its first block on a CU.
+   * Round 6 (profiles/r06_mfma_probe.txt): the same victim with its mat-vecs in the split-bf16 form of the tuned kernels (two bf16 planes,
+   * v_mfma_f32_16x16x32_bf16) is corrupted just the same beside an aggressor that issues v_mfma_f32_32x32x16_bf16 (7 x 10^7 mismatches in 200
+   * repetitions; 4 x 10^5 .. 1.5 x 10^6 beside sixteen independent chains of 16x16x32; 0 alone, 0 beside an aggressor of its own instruction
+   * shape) -- no form of these kernels is immune by construction, only placement protects them.
+   * What the flag does: every bottleneck-space kernel that uses the matrix pipe keeps other kernels' blocks off its compute units --
+   *   - the generalised family (csrc/tile_gen.inc) and the any-shape fallback (csrc/tile_kernels.hip) launch with 150 KB of dynamic LDS, one
+   *     block per CU; the backward does not fork its dBpost product beside them;
+   *   - the tuned instance at LARGE bf16 sites (csrc/tile_stream.hip: pre_small, post_small, post_small_bwd, mid_bwd -- one persistent block
+   *     per CU by design) asks for the whole 160 KB;
+   *   - the tuned instance elsewhere (csrc/tile_fast.hip: every small site; pre_small_bwd / pre_lat_bwd of large sites) asks for 150 KB per
+   *     block where the grid has at most one block per CU (nothing is lost) and for 80 KB where it is larger (two blocks fill a CU; a foreign
+   *     block can only land beside the first or the last block of a CU); the streaming Gram kernel (csrc/gram.hip) asks for 80 KB likewise.
+   * The streaming GEMM kernels and the tiled engine are not touched: their products have not moved in any two-stream repetition (they issue
+   * long independent chains; what goes wrong in the probe is a short dependent chain whose result the VALU consumes at once).
+   * bench.py reports `roofline.two_stream_bit_equal` (three steps on two streams against the same schedule on one stream, every gradient bit for
+   * bit) on every default run; tests/test_two_stream_repeat_gpu.py is the longer guard.
    * Cost: residency of those kernels where the grid exceeds the chip (BASELINE config 4: 80 -> 90 ms per step).  The flag changes their
    * block shape, i.e. the summation order of the per-block BatchNorm column sums: results agree to fp32 rounding of those sums, and
    * repeat bit for bit for a given flag.
-   * The Python wrappers set it in AdapterPair's two-stream mode and, by default, for every call issued on a stream other than the
-   * device's default stream (avmoe_amd.adapters.set_shared_gpu). */
+   * The Python wrappers set it in AdapterPair's two-stream mode and, by default (warned once), for every call issued on a stream other than
+   * the device's default stream (avmoe_amd.adapters.set_shared_gpu). */
   int32_t shared_gpu;
 } avmoe_moe_desc;
 

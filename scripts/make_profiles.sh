@@ -2,8 +2,8 @@
 # Produces the round's judged artefacts on the GPU box (into gpurun_out/prof_final; copy them to profiles/<round>_* afterwards):
 #   PMC read / write traffic per kernel and per step (first: bench.py's `traffic` field reads the round's pmc_traffic.json), matrix-pipe
 #   utilisation counters, rocprofv3 kernel-trace stats of the default command (+ --pair serial, + every launch alone), then the bench line.
-#   usage: scripts/make_profiles.sh [round tag, default r05]
-R=$PWD; O=$R/gpurun_out/prof_final; T=${1:-r05}; mkdir -p $O
+#   usage: scripts/make_profiles.sh [round tag, default r06]
+R=$PWD; O=$R/gpurun_out/prof_final; T=${1:-r06}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-f32 --reps 1"
 # counters: their own runs, kernel trace only (3 steps: 1 warm-up + 2 timed; the profiling pass of bench.py is off)
