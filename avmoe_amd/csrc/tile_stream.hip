@@ -265,13 +265,18 @@ __global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_post_small_bwd(SPostBArgs 
   const float fC = (float)t.C;
   int it = 0;                       // tiles this wave has computed
   int s = s_first, vbb = vb0 - s_first * bps;      // frame / index inside the frame of the virtual block
+  // Partial sums.  The finishing kernels need: the column sums and dSo / dSoo totals over ALL blocks' rows, dq per FRAME (sum over the frame's
+  // rows).  So the column accumulators and sdSo / sdSoo run over the block's whole range and are folded ONCE, into the rows of its last
+  // virtual block; sdq is folded when the frame ends (or the range does), into that virtual block's row; every other row gets zeros.  One
+  // barrier per frame instead of one per virtual block, and the fold's ~600 VALU instructions once per block.
+  float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
+  float4 cs0[4], cs1[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+  int nfold = 0;
   for (int vb = vb0; vb < vb1; ++vb, s += (vbb + 1 == bps), vbb = (vbb + 1 == bps) ? 0 : vbb + 1) {
     const int n_beg = vbb * per, n_end = min(N, n_beg + per);
     const float qv = lds_rd1(qv_a + 4 * ((s - s_first) * E + e));
-    float sdq = 0.f, sdSo = 0.f, sdSoo = 0.f;
-    float4 cs0[4], cs1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
     int qsel = 0;      // the lane (of the four that hold a token) that takes this tile's scalar terms: four times as many partial sums
     for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, qsel = (qsel + 1) & 3, ++it) {
       // In-order counter; issue order per tile i: [wait for tile i] [requests of tile i + P] [stores of tile i]
@@ -390,21 +395,30 @@ __global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_post_small_bwd(SPostBArgs 
       // exactly PSB_NST store instructions per tile (lane r = 0 of a tile in range is valid: none of them is skipped)
       if (ok && !(KFS_DISSECT & 2)) st_row<__bf16, E>((__bf16*)dzp + tok * DZ, e, q, dzo);
     }
-    // the virtual block's partial sums: column sums of dSo z' and dSoo z' (slots 0, 1 of colpart), three scalars per expert.  Two LDS
-    // buffers, ONE barrier per virtual block: buffer k & 1 is rewritten two virtual blocks later, behind the next barrier, which the
-    // reading waves pass only after they have read it.
-    const unsigned fb_a = fold_a + 4 * ((vb - vb0) & 1) * NW * fold_stride<2>();
-    fold_put_cols<2>(fb_a, 0, cs0, wave, lane); fold_put_cols<2>(fb_a, 1, cs1, wave, lane);
-    fold_put_scalar<2>(fb_a, 0, wave_sum(sdq), wave, lane); fold_put_scalar<2>(fb_a, 1, wave_sum(sdSo), wave, lane); fold_put_scalar<2>(fb_a, 2, wave_sum(sdSoo), wave, lane);
-    lds_barrier();
-    if (ts == 0) {
-      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      const int idx[3] = {dd, FDD + dd, 2 * FDD + min(lane, 2)};
-      float v[3];
-      fold_get<E, NS, 2, 3>(fb_a, idx, e, v);
-      colpart[((long)vb * 4 + 0) * (E * FDD) + col] = v[0];
-      colpart[((long)vb * 4 + 1) * (E * FDD) + col] = v[1];
-      if (lane < 3) blkscal[((long)vb * E + e) * 4 + lane] = v[2];
+    const bool final = vb + 1 == vb1, fend = final || vbb + 1 == bps;
+    const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+    if (fend) {        // two LDS buffers, one barrier per fold: buffer k & 1 is rewritten two folds later, behind the next barrier
+      const unsigned fb_a = fold_a + 4 * (nfold & 1) * NW * fold_stride<2>();
+      ++nfold;
+      if (final) {
+        fold_put_cols<2>(fb_a, 0, cs0, wave, lane); fold_put_cols<2>(fb_a, 1, cs1, wave, lane);
+        fold_put_scalar<2>(fb_a, 1, wave_sum(sdSo), wave, lane); fold_put_scalar<2>(fb_a, 2, wave_sum(sdSoo), wave, lane);
+      }
+      fold_put_scalar<2>(fb_a, 0, wave_sum(sdq), wave, lane);
+      sdq = 0.f;
+      lds_barrier();
+      if (ts == 0) {
+        const int idx[3] = {dd, FDD + dd, 2 * FDD + min(lane, 2)};
+        float v[3];
+        fold_get<E, NS, 2, 3>(fb_a, idx, e, v);
+        colpart[((long)vb * 4 + 0) * (E * FDD) + col] = final ? v[0] : 0.f;
+        colpart[((long)vb * 4 + 1) * (E * FDD) + col] = final ? v[1] : 0.f;
+        if (lane < 3) blkscal[((long)vb * E + e) * 4 + lane] = (final || lane == 0) ? v[2] : 0.f;
+      }
+    } else if (ts == 0) {
+      colpart[((long)vb * 4 + 0) * (E * FDD) + col] = 0.f;
+      colpart[((long)vb * 4 + 1) * (E * FDD) + col] = 0.f;
+      if (lane < 3) blkscal[((long)vb * E + e) * 4 + lane] = 0.f;
     }
   }
   // the Gram partial sums of this wave (all its tiles): slab blockIdx * NS + ts, matrices [group * E + e][32][32] (gram.hip's layout: lane
@@ -504,11 +518,11 @@ __global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_mid_bwd(SMidBArgs a, const
   const bool relu = a.relu_of_e[e];
   int it = 0;
   int s = vb0 / bps, vbb = vb0 - s * bps;
+  float4 cs0[4], cs1[4];            // (column sums over the block's whole range: folded once, into the rows of its last virtual block -- see kfs_post_small_bwd)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
   for (int vb = vb0; vb < vb1; ++vb, s += (vbb + 1 == bps), vbb = (vbb + 1 == bps) ? 0 : vbb + 1) {
     const int n_beg = vbb * per, n_end = min(N, n_beg + per);
-    float4 cs0[4], cs1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
     for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, ++it) {
       wait_tile<MDB_NL, MDB_NST>(min(KFS_P - 1, nreq - it - 1), min(it, KFS_P));
       if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
@@ -557,16 +571,20 @@ __global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_mid_bwd(SMidBArgs a, const
       }
       if (ok) st_row<__bf16, E>((__bf16*)dzp + tok * DZ, e, q, dyo);
     }
-    const unsigned fb_a = fold_a + 4 * ((vb - vb0) & 1) * NW * fold_stride<2>();
-    fold_put_cols<2>(fb_a, 0, cs0, wave, lane); fold_put_cols<2>(fb_a, 1, cs1, wave, lane);
-    lds_barrier();
-    if (ts == 0) {
-      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      const int idx[2] = {dd, FDD + dd};
-      float v[2];
-      fold_get<E, NS, 2, 2>(fb_a, idx, e, v);
-      colpart[((long)vb * 4 + 2) * (E * FDD) + col] = v[0];
-      colpart[((long)vb * 4 + 3) * (E * FDD) + col] = v[1];
+    const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+    if (vb + 1 == vb1) {
+      fold_put_cols<2>(fold_a, 0, cs0, wave, lane); fold_put_cols<2>(fold_a, 1, cs1, wave, lane);
+      lds_barrier();
+      if (ts == 0) {
+        const int idx[2] = {dd, FDD + dd};
+        float v[2];
+        fold_get<E, NS, 2, 2>(fold_a, idx, e, v);
+        colpart[((long)vb * 4 + 2) * (E * FDD) + col] = v[0];
+        colpart[((long)vb * 4 + 3) * (E * FDD) + col] = v[1];
+      }
+    } else if (ts == 0) {
+      colpart[((long)vb * 4 + 2) * (E * FDD) + col] = 0.f;
+      colpart[((long)vb * 4 + 3) * (E * FDD) + col] = 0.f;
     }
   }
 }
@@ -859,12 +877,12 @@ __global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_pre_small(SPreArgs a, unsi
   int s = s_first, vbb = vb0 - s_first * bps;
   int since = 2;                   // tiles this wave has waited for since its last request_lat (>= 2: those loads have landed)
   bool fresh = true;               // the next tile is the wave's first of a frame whose successor's constants are not requested yet
+  float4 cs0[4], cs1[4];            // (column sums over the block's whole range: folded once, into the rows of its last virtual block -- see kfs_post_small_bwd)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
   for (int vb = vb0; vb < vb1; ++vb) {
     const int n_beg = vbb * per, n_end = min(N, n_beg + per);
     const unsigned lt_a = lat_a + 4 * (((s & 1) * El + (lat ? l : 0)) * PRS_LATF);      // TT^T | TW^T | Tsum of this wave's slot, this frame
-    float4 cs0[4], cs1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
     if (fresh && El > 0 && s < s_last) { request_lat(s + 1); since = 0; }       // (every wave, whether it has a tile in this virtual block or not)
     fresh = false;
     for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, ++it) {
@@ -975,18 +993,25 @@ __global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_pre_small(SPreArgs a, unsi
         if (q == 0) { rmu[(long)e * t.NT + tok] = rr; rmu[(long)t.NT * E + (long)e * t.NT + tok] = mu; }
       }
     }
-    const unsigned fb_a = fold_a + 4 * ((vb - vb0) & 1) * NW * fold_stride<2>();
-    fold_put_cols<2>(fb_a, 0, cs0, wave, lane); fold_put_cols<2>(fb_a, 1, cs1, wave, lane);
-    const bool frame_ends = vbb + 1 == bps;
-    if (frame_ends && since < 2) wait_vm<0>();        // the next frame's constants this wave requested: landed before the barrier publishes them
-    lds_barrier();
-    if (ts == 0) {
-      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
-      const int idx[2] = {dd, FDD + dd};
-      float v[2];
-      fold_get<E, NS, 2, 2>(fb_a, idx, e, v);
-      colpart[((long)vb * 4 + 0) * (E * FDD) + col] = v[0];
-      colpart[((long)vb * 4 + 1) * (E * FDD) + col] = v[1];
+    const bool frame_ends = vbb + 1 == bps, final = vb + 1 == vb1;
+    const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+    if (final) { fold_put_cols<2>(fold_a, 0, cs0, wave, lane); fold_put_cols<2>(fold_a, 1, cs1, wave, lane); }
+    if (frame_ends && !final && El > 0) {
+      if (since < 2) wait_vm<0>();                    // the next frame's constants this wave requested: landed before the barrier publishes them
+      lds_barrier();
+    }
+    if (final) {
+      lds_barrier();
+      if (ts == 0) {
+        const int idx[2] = {dd, FDD + dd};
+        float v[2];
+        fold_get<E, NS, 2, 2>(fold_a, idx, e, v);
+        colpart[((long)vb * 4 + 0) * (E * FDD) + col] = v[0];
+        colpart[((long)vb * 4 + 1) * (E * FDD) + col] = v[1];
+      }
+    } else if (ts == 0) {
+      colpart[((long)vb * 4 + 0) * (E * FDD) + col] = 0.f;
+      colpart[((long)vb * 4 + 1) * (E * FDD) + col] = 0.f;
     }
     if (frame_ends) { vbb = 0; ++s; fresh = true; } else ++vbb;
   }
