@@ -120,6 +120,8 @@ bool kfs_serves_pre_small(const Dims& d);
 int kfs_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 bool kfs_serves_post_small(const Dims& d);
 int kfs_post_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
+bool kfs_serves_pre_bwd(const Dims& d);      // pre_small_bwd + pre_lat_bwd in one pass
+int kfs_pre_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st);
 bool kfs_serves_mid_bwd(const Dims& d);
 int kfs_mid_bwd(const Plan& pl, char* saved, char* scratch, hipStream_t st);
 // register-resident kernels generalised over groups (1 / 2 / 4), per-group bottleneck (16 .. 96) and latent slots (16 / 32 / 96): tile_gen.hip

@@ -1152,6 +1152,14 @@ int k_mid_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& 
 
 int k_pre_small_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, const avmoe_moe_ptrs& grads, hipStream_t st) {
   const Dims& d = pl.d;
+  if (tile_fast_ok(d) && kfs_serves_pre_bwd(d)) {      // large bf16 sites: both parts in one streaming pass (tile_stream.hip)
+    {
+      ProfScope ps_("k_pre_bwd (stream)", (long)d.NT, (double)d.NT * ((double)d.DZ * (2.0 * d.zsz + d.esz) + 8.0 * d.E + 4.0 + (d.KL ? (double)d.KL * (4 + 4 * d.esz) + d.KLp * d.esz - d.KL * d.esz : 0.0)), 0.0, st);
+      AVMOE_TRY(kfs_pre_bwd(pl, saved, scratch, prm, st));
+    }
+    ProfScope ps_("k_pre_bwd_finalize", 0.0, 0.0, st);
+    return k_pre_small_bwd_finalize(pl, saved, scratch, prm, grads, st);
+  }
   if (tile_fast_ok(d)) {      // two kernels: every expert's BN1 / LayerNorm part, then the cross-modal experts' hop-2 block (tile_fast.hip)
     const double lat = (double)d.NT * ((double)d.El * d.DD * d.esz + (d.KL ? (double)d.KL * (4 + 4 * d.esz) : 0.0) + 8.0 * d.El);
     {

