@@ -1402,11 +1402,13 @@ FastDims make_fd_s(const Dims& d, int per) {
 
 }  // namespace
 
-// Sites the streaming form serves: the tuned shape in bf16, enough virtual blocks to give every CU a few (a persistent block
-// amortises its prologue over them); smaller sites keep tile_fast.hip's grid.
+// Sites the streaming form serves: the tuned shape in bf16 from 2048 tokens on.  (Round 6 first drew the line at 32 768 tokens -- a persistent
+// block amortises its prologue over its range -- but measured at the reference's batch of 2 clips, 20 480 / 3920 tokens, every pass is as
+// fast or faster in this form too: mid_bwd 28.6 -> 25.0 us, post_small 19.8 -> 17.0, pre_small_bwd + pre_lat_bwd 19.7 + 19.7 -> 33.8,
+// post_small_bwd + Gram 33.6 + 16.0 -> 39.1; 1.615 -> 1.567 ms of kernel time per pair-step and four launches less.)
 bool tile_stream_ok(const Dims& d) {
   const unsigned hooks = test_hook_mask();            // (include/avmoe.h: avmoe_test_hooks -- small test shapes through these kernels / the A/B against tile_fast.hip)
-  return tile_fast_ok(d) && d.bf16 && d.zsz == 2 && (d.NT >= 32768 || (hooks & HOOK_KFS_FORCE)) && !(hooks & HOOK_KFS_OFF);
+  return tile_fast_ok(d) && d.bf16 && d.zsz == 2 && (d.NT >= 2048 || (hooks & HOOK_KFS_FORCE)) && !(hooks & HOOK_KFS_OFF);
 }
 
 static bool psf_geom(const Dims& d, int* gx, int* nfr, int* per) {
