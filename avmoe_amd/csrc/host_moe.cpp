@@ -12,7 +12,7 @@
 //   AVS logit noise, probs, load-balancing loss            AVS/avs_scripts/avs_s4/model/PVT_AVSModel_v2.py:294-296, 312-318
 //   AVVP unimodal N x N block                              AVVP/nets/mgn.py:132-139
 //   AVS "v2" latent self attention                         PVT_AVSModel_v2.py:215-227
-// Served: every variant but AVS self_attention_version "v1" (MultiheadAttention across the frames: AVMOE_ERR_UNSUPPORTED here; the HIP
+// Served: every variant, AVS self_attention_version "v1" (MultiheadAttention across the frames) included since round 6 (it was AVMOE_ERR_UNSUPPORTED here; the HIP
 // library and the Python oracle have it), train and eval BatchNorm, every flag of the descriptor.
 #include "../../include/avmoe_host.h"
 #include <cmath>
@@ -135,6 +135,9 @@ struct Expert {      // what one expert's forward leaves for its backward (all (
   bool lat = false;                 // two-hop latent attention in front (cross-modal experts: over the remapped tokens; AVS v2 unimodal: over x itself)
   bool self = false;                // ... over x itself
   bool nxn = false;                 // AVVP unimodal: x' = x + gate_av softmax_rows(x x^T)^T x   (A1 holds the (S, N, N) softmax)
+  bool mha = false;                 // AVS unimodal, self_attention_version "v1": x' = MultiheadAttention_4(x, x, x) ACROSS THE FRAMES (sequence = S, batch = N;
+                                    // PVT_AVSModel_v2.py:210-214) -- Xp = x', QKV (S N, 3C), A1 = the (N 4, S, S) softmax before the dropout multiplier, Xr = heads' outputs (S N, C)
+  V QKV;
   bool relu = false;                // cross-modal experts only
   V A1, T, A2, Xr, Xp;              // cross-modal: (S, K, N) ; (S, K, C) ; (S, N, K) ; (S N, C) ; x' = x + gate_av xr
   V U, Z, Zb, O, Ob, Op, pre;       // LN_before(x') ; down ; BN1 (+ ReLU applied into Za) ; up ; BN2 ; LN_post ; = what the gate multiplies
@@ -144,7 +147,7 @@ struct Expert {      // what one expert's forward leaves for its backward (all (
 
 struct Ctx {
   int S, N, C, M, Cy, E, Em, d, g, K;
-  bool avvp, v2;
+  bool avvp, v2, v1;
   bool bn, gate, lnb, lnp, train, lb;
   float bn_eps, ln_eps, mom;
   V Yt, Yf, rin, h1, h2, logit, p;
@@ -154,12 +157,12 @@ struct Ctx {
 int setup(const avmoe_moe_desc* q, Ctx& c) {
   if (!q) return fail(AVMOE_ERR_BAD_ARG, "host: null descriptor");
   if (q->dtype != AVMOE_F32) return fail(AVMOE_ERR_UNSUPPORTED, "host: fp32 activations only");
-  if (q->self_attn == AVMOE_SELF_ATTN_MHA_V1)
-    return fail(AVMOE_ERR_UNSUPPORTED, "host: self_attention_version v1 (MultiheadAttention across the frames) is not built on the host (HIP library, Python oracle)");
+  if (q->self_attn == AVMOE_SELF_ATTN_MHA_V1 && q->C % 4) return fail(AVMOE_ERR_BAD_ARG, "host: self_attention_version v1 needs C divisible by its 4 heads");
   c.S = q->S; c.N = q->N; c.C = q->C; c.M = q->M; c.Cy = q->Cy; c.Em = q->E_m; c.E = q->E_m + q->E_s; c.d = q->d; c.g = q->groups; c.K = q->K;
   if (c.S <= 0 || c.N <= 0 || c.C <= 0 || c.M <= 0 || c.Cy <= 0 || c.E <= 0 || c.E > AVMOE_MAX_EXPERTS || c.d <= 0 || c.g <= 0 || c.d % c.g || c.C % c.g || (c.Em > 0 && c.K <= 0))
     return fail(AVMOE_ERR_BAD_ARG, "host: bad extents");
   c.avvp = q->variant == AVMOE_VARIANT_AVVP || q->self_attn == AVMOE_SELF_ATTN_NXN; c.v2 = q->self_attn == AVMOE_SELF_ATTN_LATENT_V2;
+  c.v1 = q->self_attn == AVMOE_SELF_ATTN_MHA_V1;
   if (c.v2 && c.K <= 0) return fail(AVMOE_ERR_BAD_ARG, "host: bad extents");
   c.bn = q->use_bn; c.gate = q->use_gate; c.lnb = q->ln_before; c.lnp = q->ln_post; c.train = q->training; c.lb = q->lb_loss;
   c.bn_eps = q->bn_eps; c.ln_eps = q->ln_eps; c.mom = q->bn_momentum;
@@ -214,7 +217,7 @@ int forward(Ctx& c, const float* X, const float* Y, const avmoe_moe_ptrs& P, con
     Expert& x = c.ex[e];
     const avmoe_expert_ptrs& q = P.e[e];
     x.relu = e < c.Em;
-    x.lat = e < c.Em || c.v2; x.self = !(e < c.Em); x.nxn = !(e < c.Em) && c.avvp;
+    x.lat = e < c.Em || c.v2; x.self = !(e < c.Em); x.nxn = !(e < c.Em) && c.avvp && !c.v1; x.mha = !(e < c.Em) && c.v1;
     if (!q.down_w || !q.up_w) return fail(AVMOE_ERR_BAD_ARG, "host: expert %d lacks its projections", e);
     const float* xin = X;
     if (x.lat) {
@@ -245,6 +248,40 @@ int forward(Ctx& c, const float* X, const float* Y, const avmoe_moe_ptrs& P, con
       }
       for (long i = 0; i < NT * C; ++i) x.Xp[i] = X[i] + q.gate_lat[0] * x.Xr[i];
       xin = x.Xp.data();
+    }
+    else if (x.mha) {                // torch.nn.functional.multi_head_attention_forward, batch_first = False: q scaled by 1 / sqrt(dh), softmax over the key
+                                     // frames, the caller's dropout multiplier on the weights (sa_keep: (N 4, S, S), or NULL), out_proj
+      if (!q.sa_in_w || !q.sa_in_b || !q.sa_out_w || !q.sa_out_b) return fail(AVMOE_ERR_BAD_ARG, "host: expert %d lacks self_attention.*", e);
+      constexpr int H = 4;
+      const int dh = C / H;
+      const float scale = 1.f / std::sqrt((float)dh);
+      x.QKV.assign(NT * 3 * C, 0.f); x.A1.assign((long)N * H * S * S, 0.f); x.Xr.assign(NT * C, 0.f); x.Xp.assign(NT * C, 0.f);
+      gemm(false, true, (int)NT, 3 * C, C, 1.f, X, C, q.sa_in_w, C, 0.f, x.QKV.data(), 3 * C);
+      for (long i = 0; i < NT; ++i) for (int k = 0; k < 3 * C; ++k) x.QKV[i * 3 * C + k] += q.sa_in_b[k];
+#pragma omp parallel for schedule(static)
+      for (int nh = 0; nh < N * H; ++nh) {
+        const int n = nh / H, hh = nh % H;
+        float* att = x.A1.data() + (long)nh * S * S;
+        for (int s = 0; s < S; ++s)
+          for (int u2 = 0; u2 < S; ++u2) {
+            const float* qv = x.QKV.data() + ((long)s * N + n) * 3 * C + hh * dh;
+            const float* kv = x.QKV.data() + ((long)u2 * N + n) * 3 * C + C + hh * dh;
+            double a = 0.0;
+            for (int j = 0; j < dh; ++j) a += (double)(qv[j] * scale) * kv[j];
+            att[(long)s * S + u2] = (float)a;
+          }
+        softmax_rows(att, S, S, S);
+        const float* keep = q.sa_keep ? q.sa_keep + (long)nh * S * S : nullptr;
+        for (int s = 0; s < S; ++s)
+          for (int j = 0; j < dh; ++j) {
+            double a = 0.0;
+            for (int u2 = 0; u2 < S; ++u2) a += (double)(att[(long)s * S + u2] * (keep ? keep[(long)s * S + u2] : 1.f)) * x.QKV[((long)u2 * N + n) * 3 * C + 2 * C + hh * dh + j];
+            x.Xr[((long)s * N + n) * C + hh * dh + j] = (float)a;
+          }
+      }
+      gemm(false, true, (int)NT, C, C, 1.f, x.Xr.data(), C, q.sa_out_w, C, 0.f, x.Xp.data(), C);
+      for (long i = 0; i < NT; ++i) for (int k = 0; k < C; ++k) x.Xp[i * C + k] += q.sa_out_b[k];
+      xin = x.Xp.data();             // REPLACES x (no residual, no gate)
     }
     const float* u = xin;
     if (c.lnb) {
@@ -327,10 +364,50 @@ int avmoe_host_moe_backward(const avmoe_moe_desc* desc, const float* X, const fl
     float* gz = tz.data(); float* hz = tz2.data();
     if (x.relu) for (long i = 0; i < NT * d; ++i) if (!(x.Za[i] > 0.f)) gz[i] = 0.f;
     if (c.bn) { bn_bwd(x.Z.data(), gz, hz, NT, d, q.bn1_w, c.train, x.bn1, gq.bn1_w, gq.bn1_b); std::swap(gz, hz); }
-    const float* xin = (x.lat || x.nxn) ? x.Xp.data() : X;
+    const float* xin = (x.lat || x.nxn || x.mha) ? x.Xp.data() : X;
     gconv_bwd(c.lnb ? x.U.data() : xin, gz, g, gq.down_w, NT, C, d, c.g, q.down_w);      // g: gradient of LN_before's output (or of x')
     if (c.lnb) { ln_bwd(xin, g, h, NT, C, q.lnb_w, x.lnb, gq.lnb_w, gq.lnb_b); std::swap(g, h); }
-    for (long i = 0; i < NT * C; ++i) dX[i] += g[i];                                       // x' = x + ...
+    if (x.mha) {                      // x' = out_proj(heads(softmax(q k^T / sqrt(dh)) keep . v)): back through out_proj, the heads, in_proj -- into dX
+      constexpr int H = 4;
+      const int dh = C / H;
+      const float scale = 1.f / std::sqrt((float)dh);
+      if (gq.sa_out_w) gemm(true, false, C, C, (int)NT, 1.f, g, C, x.Xr.data(), C, 0.f, gq.sa_out_w, C);
+      if (gq.sa_out_b) for (int k = 0; k < C; ++k) { double a = 0.0; for (long i = 0; i < NT; ++i) a += g[i * C + k]; gq.sa_out_b[k] = (float)a; }
+      gemm(false, false, (int)NT, C, C, 1.f, g, C, q.sa_out_w, C, 0.f, h, C);                // h = d heads' outputs
+      V dQKV(NT * 3 * C, 0.f);
+#pragma omp parallel for schedule(static)
+      for (int nh = 0; nh < N * H; ++nh) {
+        const int n = nh / H, hh = nh % H;
+        const float* att = x.A1.data() + (long)nh * S * S;
+        const float* keep = q.sa_keep ? q.sa_keep + (long)nh * S * S : nullptr;
+        V dP((long)S * S);
+        for (int s = 0; s < S; ++s)
+          for (int u2 = 0; u2 < S; ++u2) {
+            const float kp = keep ? keep[(long)s * S + u2] : 1.f;
+            double a = 0.0;
+            for (int j = 0; j < dh; ++j) {
+              const float dho = h[((long)s * N + n) * C + hh * dh + j];
+              a += (double)dho * x.QKV[((long)u2 * N + n) * 3 * C + 2 * C + hh * dh + j];
+              dQKV[((long)u2 * N + n) * 3 * C + 2 * C + hh * dh + j] += att[(long)s * S + u2] * kp * dho;      // dv (this (n, head) alone writes these entries)
+            }
+            dP[(long)s * S + u2] = (float)a * kp;
+          }
+        softmax_rows_bwd(att, dP.data(), S, S, S);                                             // -> d scores
+        for (int s = 0; s < S; ++s)
+          for (int u2 = 0; u2 < S; ++u2) {
+            const float ds = dP[(long)s * S + u2];
+            for (int j = 0; j < dh; ++j) {
+              dQKV[((long)s * N + n) * 3 * C + hh * dh + j] += ds * scale * x.QKV[((long)u2 * N + n) * 3 * C + C + hh * dh + j];
+              dQKV[((long)u2 * N + n) * 3 * C + C + hh * dh + j] += ds * scale * x.QKV[((long)s * N + n) * 3 * C + hh * dh + j];
+            }
+          }
+      }
+      if (gq.sa_in_w) gemm(true, false, 3 * C, C, (int)NT, 1.f, dQKV.data(), 3 * C, X, C, 0.f, gq.sa_in_w, C);
+      if (gq.sa_in_b) for (int k = 0; k < 3 * C; ++k) { double a = 0.0; for (long i = 0; i < NT; ++i) a += dQKV[i * 3 * C + k]; gq.sa_in_b[k] = (float)a; }
+      gemm(false, false, (int)NT, C, 3 * C, 1.f, dQKV.data(), 3 * C, q.sa_in_w, C, 1.f, dX, C);
+    } else {
+      for (long i = 0; i < NT * C; ++i) dX[i] += g[i];                                     // x' = x + ...
+    }
     if (x.lat) {
       double dga = 0.0;
       for (long i = 0; i < NT * C; ++i) { dga += (double)g[i] * x.Xr[i]; g[i] *= q.gate_lat[0]; }      // g = d xr

@@ -7,8 +7,9 @@
  * (avmoe_amd/csrc/host_moe.cpp, built with g++ by avmoe_amd.build.build_host()).  TEST / CI infrastructure: the product path
  * (libavmoe_hip.so) never loads it and has no CPU fallback.
  *
- * Served: AVE / AVQA / AVVP (N x N block) / AVS (incl. self_attention_version "v2"), training and eval BatchNorm, every flag, logit noise,
- * load-balancing loss.  AVMOE_ERR_UNSUPPORTED: dtype != AVMOE_F32, AVS self_attention_version "v1".                                    */
+ * Served: AVE / AVQA / AVVP (N x N block) / AVS (self_attention_version "v2" and, since round 6, "v1": MultiheadAttention across the frames with
+ * the caller's dropout multipliers, avmoe_expert_ptrs::sa_keep), training and eval BatchNorm, every flag, logit noise, load-balancing loss.
+ * AVMOE_ERR_UNSUPPORTED: dtype != AVMOE_F32.                                                                                             */
 #ifndef AVMOE_HOST_H
 #define AVMOE_HOST_H
 #include "avmoe.h"

@@ -1,17 +1,17 @@
 """The host (CPU, C++) implementation of the ABI -- include/avmoe_host.h, avmoe_amd/csrc/host_moe.cpp: SURVEY 8(b)'s "restatement used for
 no-GPU CI" -- pinned on the vectors captured from the real reference modules (tests/golden/*.npz), like the Python oracle: outputs,
 probabilities, bit-exact argmax, load-balancing loss, gradients wrt both inputs and every parameter, updated BatchNorm buffers.
-CPU only; 18 of the 21 fixtures (the frame-attention experts are not built on the host).  (Checker-side code: the product library has no CPU path and never loads this one.)"""
+CPU only; all 21 fixtures (round 6: the frame-attention "v1" experts too).  (Checker-side code: the product library has no CPU path and never loads this one.)"""
 import ctypes as C
 
 import pytest
 import torch
 
 from avmoe_amd import _capi_moe as cm
-from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close
+from tests.golden_util import golden_names, load_golden, split_params, assert_grads_close, mha_keep_of
 from tests.moe_gpu_util import make_desc
 
-SERVED = [n for n in golden_names() if "_v1" not in n]          # everything but the frame-attention ("v1") experts
+SERVED = list(golden_names())          # every fixture (round 6: the frame-attention "v1" experts too)
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +36,7 @@ def _rel(a, b):
 
 def test_the_fixture_selection_covers_ave_avqa_avs():
     assert {"ave_train", "ave_eval", "ave_nobn", "ave_noln_nogate", "avqa_train", "avs_train_noise", "avs_k87_train", "avvp_train", "avvp_eval",
-            "avs_v2_train"} <= set(SERVED) and len(SERVED) == 18
+            "avs_v2_train", "avs_v1_train", "avs_v1_eval"} <= set(SERVED) and len(SERVED) == 21
 
 
 @pytest.mark.parametrize("name", SERVED)
@@ -48,7 +48,8 @@ def test_host_implementation_matches_reference_vectors(host, name):
     desc = make_desc(cfg, S, False, training)
     params = {k: v.clone().contiguous() for k, v in P.items()}
     bufs = {k: v.clone().contiguous() for k, v in B.items()}
-    ptrs = cm.make_ptrs({**params, **bufs}, cfg.E_m, cfg.E_s)
+    keep = {f"{pre}.{cm.SA_KEEP}": v.to(torch.float32).contiguous() for pre, v in (mha_keep_of(t) or {}).items()}      # "v1": the recorded dropout multipliers
+    ptrs = cm.make_ptrs({**params, **bufs, **keep}, cfg.E_m, cfg.E_s)
     X, Y, G = t["X"].contiguous(), t["Y"].contiguous(), t["grad_out"].contiguous()
     noise = t["noise"].contiguous() if "noise" in t else None
     nz = noise.data_ptr() if noise is not None else None
@@ -81,8 +82,8 @@ def test_host_implementation_matches_reference_vectors(host, name):
 
 
 def test_host_refuses_what_it_does_not_serve(host):
-    meta, cfg, t = load_golden("avs_v1_train")
-    desc = make_desc(cfg, t["X"].shape[0], False, True)
+    meta, cfg, t = load_golden("ave_train")
+    desc = make_desc(cfg, t["X"].shape[0], True, True)          # bf16 activations: the host library is fp32 only
     ptrs = cm.MoePtrs()
     st = host.avmoe_host_moe_forward(C.byref(desc), t["X"].data_ptr(), t["Y"].data_ptr(), C.byref(ptrs), None, torch.empty_like(t["X"]).data_ptr(), None, None, None, None)
-    assert st == -2 and b"v1" in host.avmoe_host_last_error()
+    assert st == -2 and b"fp32" in host.avmoe_host_last_error()
