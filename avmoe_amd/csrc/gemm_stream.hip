@@ -652,6 +652,11 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
 #ifndef SC_DXN_PC
 #define SC_DXN_PC 4
 #endif
+#ifndef SC_X64_TPW
+#define SC_X64_TPW 1         // the down projection + extra columns: column tiles per wave (12 / TPW waves), rows per tile, blocks per CU
+#define SC_X64_BM 64
+#define SC_X64_PC 1
+#endif
 #ifndef SC_DXN_BM
 #define SC_DXN_BM 32
 #endif
@@ -671,10 +676,10 @@ int launch_gemm_stream(const GemmArgs& a_in, hipStream_t st) {
         return 1;
       s.contig = 1;                 // (contiguous tile ranges: a block changes sample once or twice)
       if (a.N != 128) return 1;     // (eight stationary tiles + four per-sample ones: twelve waves, one tile each, one 64-row block per CU)
-      s.tps = cdiv(a.M, 64); s.ntiles = s.tps * a.nb1; *a.st_tiles = s.tps;
+      s.tps = cdiv(a.M, SC_X64_BM); s.ntiles = s.tps * a.nb1; *a.st_tiles = s.tps;
       const double b3 = nb * a.N3 * (double)a.K * 2.0 + nb * a.M * (double)a.N3 * 4.0;
       ProfScope ps("gemm_stream_k384_n128+stats+x64", (long)a.M * a.nb1, abytes + b3, flops + 2.0 * nb * a.M * (double)a.N3 * a.K, st);
-      return launch_inst<12, 0, 1, 12, 64, false, false, stream_minw(12, 1), true, 1>(s, a.nb2, 1, st);
+      return launch_inst<12, 0, SC_X64_TPW, 12 / SC_X64_TPW, SC_X64_BM, false, false, stream_minw(12 / SC_X64_TPW, SC_X64_PC), true, 1>(s, a.nb2, SC_X64_PC, st);
     }
 #define STATS_CASE(COND, KS_, TPW_, NW_, BM_, PERCU_, NAME)                                                   \
     if ((COND) && ks <= KS_ && tiles <= TPW_ * NW_) {                                                         \

@@ -234,7 +234,7 @@ def parity_check_(c, material, device, pair_mode="concurrent"):
                out_rel_f32=0.0, grad_rel_f32=0.0, worst_f32=None, grad_rel_f32_own_mask=0.0, worst_f32_own_mask=None,
                relu_units=0, relu_units_flipped=0, flipped_preact_max_rel=0.0,
                out_rel_bf16=None, grad_relnorm_bf16=None, worst_bf16=None, grad_relnorm_bf16_same_mask=None, worst_bf16_same_mask=None,
-               grad_relnorm_bf16_major=None, worst_bf16_major=None, grad_relnorm_bf16_tiny_joint=None,
+               grad_relnorm_bf16_major=None, worst_bf16_major=None, grad_relnorm_bf16_tiny_joint=None, grad_eps_bf16_single_sums=None, worst_bf16_single_sums=None, grad_relnorm_bf16_vectors=None, worst_bf16_vectors=None,
                dx_rows=0, **{"dx_rows_above_1e-3": 0}, dx_row_maxabs_f32=0.0,
                measures="out_*: max-abs / max ; grad_*: norm-wise per tensor, worst tensor (floor 1e-3 of the largest gradient norm) ; "
                         "grad_rel_f32, *_same_mask, dx_rows*: against the oracle run with the HIP path's ReLU mask (kink-aware) ; "
@@ -300,14 +300,14 @@ def parity_check_(c, material, device, pair_mode="concurrent"):
         items += [("tok", "f_a", tok["fa"], ra[1]["X"] + rv[1]["Y"]), ("tok", "f_v", tok["fv"], rv[1]["X"] + ra[1]["Y"])]
         return items
 
-    def worst(items, floor_rel=1e-3, skip_small=False):
+    def worst(items, floor_rel=1e-3, skip_small=False, min_numel=0, log=True):
         nmax = max(float(v.norm()) for _t, _k, _g, v in items)
         e_w, k_w = 0.0, None
         for tag, k, g, v in items:
-            if skip_small and float(v.norm()) < floor_rel * nmax:
+            if (skip_small and float(v.norm()) < floor_rel * nmax) or v.numel() < min_numel:
                 continue
             e = float((g - v).norm()) / max(float(v.norm()), floor_rel * nmax)
-            if detail is not None:
+            if detail is not None and log:
                 detail.append((tag, k, e))
             if e > e_w:
                 e_w, k_w = e, f"{k} ({tag})"
@@ -396,8 +396,67 @@ def parity_check_(c, material, device, pair_mode="concurrent"):
                     res["grad_relnorm_bf16_tiny_joint"] = max(res.get("grad_relnorm_bf16_tiny_joint") or 0.0, tj)
                 if rj is not None:
                     res["grad_relnorm_bf16_rest"] = max(res.get("grad_relnorm_bf16_rest") or 0.0, rj)
+                # ---- every tensor ONE BY ONE, anchored on the reference formulation's own bf16 error ----
+                # (a) tensors of more than 16 elements (>= 1e-3 of the largest gradient norm; the structurally zero ones have their own view above):
+                #     norm-wise error on this draw, next to the error of the reference formulation run eagerly under torch.autocast(bfloat16) on the
+                #     same inputs (own mask).  Listed when above 5 % AND above that eager error.
+                # (b) single-sum tensors (<= 16 elements: the scalar gates, the router's last bias) over SEVERAL draws of the upstream gradient with
+                #     the forward fixed.  <G, y> for a random G: value and rounding error are both zero-mean sums over the same ~1e6 terms, so the
+                #     relative error of ONE draw is a ratio of two normals -- heavy-tailed; 10 - 50 x outliers on a few of ~100 scalars are chance
+                #     (profiles/r06_gate_grad_draws.txt: the eager-autocast run shows the same tail).  The estimate without that tail is
+                #     eps = rms_k(hip_k - oracle_k) / rms_k(oracle_k) over the draws k.  Listed when above 5 % AND above the eager eps.
+                if SINGLE_SUM_DRAWS > 1:
+                    def eager_run(P, B, X, Y, cfg, Gl, keys):
+                        """the oracle's formulation eagerly on the GPU under bf16 autocast: (all gradients of the first draw, `keys` for the others)"""
+                        Pd, Bd = {k: v.to(device) for k, v in P.items()}, {k: v.to(device) for k, v in B.items()}
+                        with torch.autocast("cuda", dtype=torch.bfloat16):
+                            full = O.moe_forward_backward(Pd, Bd, X.to(device), Y.to(device), cfg, Gl[0].to(device), training=True, lb_weight=lbw)[1]
+                            rest = O.moe_grads_over_draws(Pd, Bd, X.to(device), Y.to(device), cfg, [g_.to(device) for g_ in Gl[1:]], keys, training=True, lb_weight=lbw)
+                        return {k: v.float().cpu() for k, v in full.items()}, [{k: v.float().cpu() for k, v in r_.items()} for r_ in rest]
+                    keys_a = [k for k, v in sa[1].items() if k not in ("X", "Y") and v.numel() <= 16]
+                    keys_v = [k for k, v in sv[1].items() if k not in ("X", "Y") and v.numel() <= 16]
+                    gd = torch.Generator().manual_seed(4321)
+                    draws = [(torch.randn(fa.shape, generator=gd).bfloat16().float(), torch.randn(fv.shape, generator=gd).bfloat16().float())
+                             for _ in range(SINGLE_SUM_DRAWS - 1)]
+                    refs_a = O.moe_grads_over_draws(w["Pa"], w["Ba"], fa, fv, w["ca"], [d_[0] for d_ in draws], keys_a, lb_weight=lbw, relu_masks=mka)
+                    refs_v = O.moe_grads_over_draws(w["Pv"], w["Bv"], fv, fa, w["cv"], [d_[1] for d_ in draws], keys_v, lb_weight=lbw, relu_masks=mkv)
+                    ea, ea_d = eager_run(w["Pa"], w["Ba"], fa, fv, w["ca"], [Ga] + [d_[0] for d_ in draws], keys_a)
+                    ev, ev_d = eager_run(w["Pv"], w["Bv"], fv, fa, w["cv"], [Gv] + [d_[1] for d_ in draws], keys_v)
+                    tok_e = dict(fa=ea["X"] + ev["Y"], fv=ev["X"] + ea["Y"])
+                    items_h, items_e = grad_items((ga, gv, tok), sa, sv), grad_items((ea, ev, tok_e), sa, sv)
+                    nmax = max(float(v.norm()) for _t, _k, _g, v in items_h)
+                    above = res.setdefault("bf16_tensors_above_5pct_and_eager", [])
+                    for (tag, k, g_h, v), (_t2, _k2, g_e, _v2) in zip(items_h, items_e):
+                        if v.numel() <= 16 or float(v.norm()) < 1e-3 * nmax:
+                            continue
+                        e_h, e_e = float((g_h - v).norm() / v.norm()), float((g_e - v).norm() / v.norm())
+                        upd("grad_relnorm_bf16_vectors", "worst_bf16_vectors", e_h, f"{k} ({tag}) [{shape_tag}] (eager {e_e:.3f})")
+                        res["bf16_tensors_compared"] = res.get("bf16_tensors_compared", 0) + 1
+                        if e_h > 5e-2 and e_h > e_e:
+                            above.append(f"{k} ({tag}) [{shape_tag}] {e_h:.3f} (eager {e_e:.3f})")
+                    acc = {}
+                    def add(tag, k, g, g_e, v):
+                        s_ = acc.setdefault(f"{k} ({tag})", [0.0, 0.0, 0.0])
+                        s_[0] += float((g - v).pow(2).sum()); s_[1] += float((g_e - v).pow(2).sum()); s_[2] += float(v.pow(2).sum())
+                    for k in keys_a: add("a", k, ga[k], ea[k], sa[1][k])
+                    for k in keys_v: add("v", k, gv[k], ev[k], sv[1][k])
+                    for (Ga_k, Gv_k), r_a, r_v, e_a, e_v in zip(draws, refs_a, refs_v, ea_d, ev_d):
+                        _oa, _ov, _ia, _iv, ga_k, gv_k, _tok, mka_k, mkv_k = hip(w, True, Ga_k, Gv_k)
+                        assert all(torch.equal(mka_k[p_], mka[p_]) for p_ in mka) and all(torch.equal(mkv_k[p_], mkv[p_]) for p_ in mkv), "the forward does not depend on the upstream gradient"
+                        for k in keys_a: add("a", k, ga_k[k], e_a[k], r_a[k])
+                        for k in keys_v: add("v", k, gv_k[k], e_v[k], r_v[k])
+                    for name, (se, see, sr) in acc.items():
+                        rms = (sr / SINGLE_SUM_DRAWS) ** 0.5
+                        if rms < 1e-3 * nmax:          # below 1e-3 of the largest gradient norm (incl. the structurally zero ones: a bias in front of a train-mode BatchNorm)
+                            continue
+                        e_h, e_e = (se / sr) ** 0.5, (see / sr) ** 0.5
+                        upd("grad_eps_bf16_single_sums", "worst_bf16_single_sums", e_h, f"{name} [{shape_tag}] (eager {e_e:.3f})")
+                        res["bf16_tensors_compared"] = res.get("bf16_tensors_compared", 0) + 1
+                        if e_h > 5e-2 and e_h > e_e:
+                            above.append(f"{name} [{shape_tag}] eps {e_h:.3f} (eager {e_e:.3f})")
+                    res["single_sum_draws"] = SINGLE_SUM_DRAWS
     for k in ("out_rel_f32", "grad_rel_f32", "grad_rel_f32_own_mask", "flipped_preact_max_rel", "out_rel_bf16", "grad_relnorm_bf16",
-              "grad_relnorm_bf16_same_mask", "grad_relnorm_bf16_major", "grad_relnorm_bf16_tiny_joint", "grad_relnorm_bf16_rest", "grad_abs_bf16_structural_zero", "dx_row_maxabs_f32"):
+              "grad_relnorm_bf16_same_mask", "grad_eps_bf16_single_sums", "grad_relnorm_bf16_vectors", "grad_relnorm_bf16_major", "grad_relnorm_bf16_tiny_joint", "grad_relnorm_bf16_rest", "grad_abs_bf16_structural_zero", "dx_row_maxabs_f32"):
         if res.get(k) is not None:
             res[k] = float(f"{res[k]:.3e}")
     if detail:
@@ -411,6 +470,7 @@ def parity_check_(c, material, device, pair_mode="concurrent"):
 # printed): the fp32 path is the one held to north_star's 1e-3, indices are bit-exact, and a bf16 output off by more than the test
 # bound is a bug (round 3: a run-to-run blip of the cfg-3 forward went unnoticed because this leg only printed numbers).  The bf16
 # gradient bar is reported as `ok_bf16_grads` (SOFT: bf16 activations have an error budget of their own).
+SINGLE_SUM_DRAWS = 6          # upstream-gradient draws of the bf16 parity leg's single-sum view (1 = off)
 PARITY_BARS = dict(out_rel_f32=1e-3, grad_rel_f32=1e-3, out_rel_bf16=1e-2, grad_relnorm_bf16_same_mask=5e-2, grad_relnorm_bf16_major=5e-2,
                    grad_relnorm_bf16_tiny_joint=5e-2, grad_relnorm_bf16_rest=5e-2, grad_abs_bf16_structural_zero=1e-2)
 
@@ -423,7 +483,11 @@ def parity_verdict(res):
             failed.append(k)
     soft = res.get("grad_relnorm_bf16_same_mask")
     res["ok"] = not failed
-    res["ok_bf16_grads"] = None if soft is None else bool(soft <= PARITY_BARS["grad_relnorm_bf16_same_mask"])      # every tensor >= 1e-3 of the largest norm, one by one
+    res["ok_bf16_grads_single_draw"] = None if soft is None else bool(soft <= PARITY_BARS["grad_relnorm_bf16_same_mask"])      # rounds 2 - 5's `ok_bf16_grads`: every tensor >= 1e-3 of the largest norm one by one on ONE draw of the upstream gradient, 5 % flat (for a single sum: a ratio of two normals)
+    above = res.get("bf16_tensors_above_5pct_and_eager")
+    # every tensor >= 1e-3 of the largest norm one by one (vectors on the one draw, single sums as rms error / rms value over `single_sum_draws` draws):
+    # none above 5 % AND above the error of the reference formulation itself under bf16 autocast on the same inputs
+    res["ok_bf16_grads"] = res["ok_bf16_grads_single_draw"] if above is None else bool(len(above) == 0)
     mj, tj, rj = res.get("grad_relnorm_bf16_major"), res.get("grad_relnorm_bf16_tiny_joint"), res.get("grad_relnorm_bf16_rest")
     res["ok_bf16_grads_as_tested"] = None if mj is None else bool(mj <= PARITY_BARS["grad_relnorm_bf16_major"] and (tj is None or tj <= PARITY_BARS["grad_relnorm_bf16_tiny_joint"])
                                                                   and (rj is None or rj <= PARITY_BARS["grad_relnorm_bf16_rest"])

@@ -343,6 +343,23 @@ def moe_forward_backward(P, B, X, Y, cfg: AdapterConfig, grad_out, training=True
     return fwd, grads
 
 
+def moe_grads_over_draws(P, B, X, Y, cfg: AdapterConfig, grad_outs, keys, training=True, noise=None, lb_weight: float = 0.0,
+                         mha_keep=None, relu_masks=None):
+    """The gradients of the parameters `keys` for SEVERAL upstream gradients `grad_outs` of one forward (inputs, parameters and ReLU
+    mask fixed): [{key: grad} per draw].  One forward, one pruned autograd pass per draw -- what the checkers use to estimate the
+    error of single-sum gradients (scalar gates) as a ratio of RMS values over draws instead of a ratio of two random sums."""
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    fwd = moe_forward(Pg, B, X, Y, cfg, training=training, noise=noise, update_buffers=False, mha_keep=mha_keep, relu_masks=relu_masks)
+    res = []
+    for G in grad_outs:
+        loss = (fwd["out"] * G).sum()
+        if cfg.lb_loss and lb_weight != 0.0:
+            loss = loss + lb_weight * fwd["lb"]
+        gs = torch.autograd.grad(loss, [Pg[k] for k in keys], retain_graph=True, allow_unused=True)
+        res.append({k: (g.detach() if g is not None else torch.zeros_like(Pg[k])) for k, g in zip(keys, gs)})
+    return res
+
+
 # ----------------------------------------------------------------------------------------------
 # work model (SURVEY 8d / BASELINE.md 4) -- used by bench.py for the roofline line
 # ----------------------------------------------------------------------------------------------

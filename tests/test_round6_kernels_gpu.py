@@ -162,3 +162,49 @@ def test_split_bf16_matvecs_with_large_mean_small_variance_activations(stream):
     e_hip = float((out - fwd["out"]).norm() / fwd["out"].norm())
     e_eager = float((fe["out"].float().cpu() - fwd["out"]).norm() / fwd["out"].norm())
     assert e_hip <= max(1e-2, 2.0 * e_eager), (e_hip, e_eager)
+
+
+@pytest.mark.parametrize("site", ["audio", "visual"])
+def test_scalar_gate_gradients_over_draws_of_the_upstream_gradient(site, avmoe_hooks):
+    """The one-number gradients (`gate`, `gate_av` of every expert; the benchmarked cfg-2 site shapes at B = 2 clips, bf16, the streaming kernels
+    forced) judged WITHOUT the ratio-of-two-random-sums tail: <G, y> for a random G has value and rounding error both zero-mean over the
+    same ~1e7 terms, so the relative error of ONE draw is heavy-tailed (10 - 50 x outliers on a few of ~100 scalars are chance; the reference
+    formulation under autocast shows the same: profiles/r06_gate_grad_draws.txt).  Over 6 draws of G with the forward fixed,
+
+        eps = rms_k(hip_k - oracle_k) / rms_k(oracle_k)       (oracle: fp32 on the bf16-rounded inputs, the HIP path's ReLU mask)
+
+    Bars: eps <= 1.5 % for the output gates (formed in fp32 in weight space since round 6; measured 0.2 - 0.8 %, eager autocast 0.3 - 0.9 %),
+    <= 4 % for gate_av (measured 0.5 - 1.2 %; eager autocast 4 - 9 %), and never above 1.5 x the eager-autocast eps of the same tensor + 0.5 %."""
+    from tests.moe_gpu_util import MoeRun
+    from avmoe_amd import debug as dbg
+    avmoe_hooks(1 | 2 | 4 | 8)
+    dims = {"audio": dict(Cx=768, Nx=1024, Cy=768, Ny=196), "visual": dict(Cx=768, Nx=196, Cy=768, Ny=1024)}[site]
+    cfg = O.AdapterConfig(**dims, reduction=12, groups=2, K=32, E_m=2, E_s=2)
+    P, B = O.init_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(99)
+    S, D = 20, 6
+    X = (0.3 * torch.randn(S, cfg.Nx, cfg.Cx, generator=g)).bfloat16().float()
+    Y = (0.3 * torch.randn(S, cfg.Ny, cfg.Cy, generator=g)).bfloat16().float()
+    Gs = [torch.randn(S, cfg.Nx, cfg.Cx, generator=g).bfloat16().float() for _ in range(D)]
+    keys = [k for k, v in P.items() if v.numel() == 1]
+    assert len(keys) >= 6          # four output gates + the cross-modal experts' gate_av
+    run = MoeRun(cfg, P, B, X, Y, bf16=True, training=True).forward()
+    masks = dbg.relu_masks_of(run.desc, run.saved)
+    refs = O.moe_grads_over_draws(P, B, X, Y, cfg, Gs, keys, training=True, relu_masks=masks)
+    dev = torch.device("cuda:0")
+    Pd, Bd = {k: v.to(dev) for k, v in P.items()}, {k: v.to(dev) for k, v in B.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):          # the reference formulation itself in bf16 (own mask)
+        eag = O.moe_grads_over_draws(Pd, Bd, X.to(dev), Y.to(dev), cfg, [G.to(dev) for G in Gs], keys, training=True)
+    acc = {k: [0.0, 0.0, 0.0] for k in keys}
+    for G, r, e in zip(Gs, refs, eag):
+        got = run.backward(G)
+        for k in keys:
+            acc[k][0] += float((got[k] - r[k]).pow(2).sum()); acc[k][1] += float((e[k].float().cpu() - r[k]).pow(2).sum()); acc[k][2] += float(r[k].pow(2).sum())
+    assert run.guards_intact()
+    bad = {}
+    for k, (sh, se, sr) in acc.items():
+        eh, ee = (sh / sr) ** 0.5, (se / sr) ** 0.5
+        bar = 4e-2 if k.endswith("gate_av") else 1.5e-2
+        if eh > bar or eh > 1.5 * ee + 5e-3:
+            bad[k] = (eh, ee)
+    assert not bad, f"(eps hip, eps eager autocast): {bad}"
