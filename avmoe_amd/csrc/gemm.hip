@@ -21,6 +21,7 @@
 #include "prof.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace avmoe {
@@ -528,12 +529,12 @@ __global__ void __launch_bounds__(256, (is_split<T>::value ? 2 : 1)) gemm_kernel
 
   if (p.ksplit > 1) {
     float* dst = p.slabs + ((long)split * p.nbatch + b) * (long)p.M * p.N;
-    constexpr int TPR = BN / 4, RPP = 256 / TPR;
+    constexpr int TPR = BN / 4, RPP = 256 / TPR;      // (BN = 160: 40 threads per row, 6 rows per pass, 16 threads idle, a partial last pass)
 #pragma unroll 1
-    for (int pass = 0; pass < BM / RPP; ++pass) {
+    for (int pass = 0; pass < (BM + RPP - 1) / RPP; ++pass) {
       const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
       const int gi = m0 + i, gj = n0 + j;
-      if (gi < p.M && gj < p.N) {
+      if (gi < p.M && gj < p.N && tid < RPP * TPR && i < BM) {
         const f32x4 v = *(const f32x4*)&Cs[i * CLD + j];
         float* d = dst + (long)gi * p.N + gj;
 #pragma unroll
@@ -582,10 +583,10 @@ __global__ void __launch_bounds__(256, (is_split<T>::value ? 2 : 1)) gemm_kernel
   if (p.sCj == 1) {
     constexpr int TPR = BN / 4, RPP = 256 / TPR;
 #pragma unroll 1
-    for (int pass = 0; pass < BM / RPP; ++pass) {
+    for (int pass = 0; pass < (BM + RPP - 1) / RPP; ++pass) {
       const int i = pass * RPP + tid / TPR, j = (tid % TPR) * 4;
       const int gi = m0 + i, gj = n0 + j;
-      if (gi >= p.M || gj >= p.N) continue;
+      if (gi >= p.M || gj >= p.N || tid >= RPP * TPR || i >= BM) continue;
       long crow = (long)gi * p.sCi;
       if (p.fold_rps) {                                   // row gi of the folded GEMM = row ri of sample sidx; gap rows are not stored
         const int sidx = gi / p.fold_rps, ri = gi - sidx * p.fold_rps;
@@ -990,7 +991,10 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];
-  if (!name[0]) snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : (std::is_same<T, f32s2>::value ? "f32s2" : "f32")), BM);
+  if (!name[0]) {
+    snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : (std::is_same<T, f32s2>::value ? "f32s2" : "f32")), BM);
+    if (BN != BM) snprintf(name + strlen(name), sizeof(name) - strlen(name), "x%d", BN);
+  }
   static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
   const char* pname = name;
   if (shapes && prof_enabled()) {            // debug only: one family per distinct call shape (leaks the small strings)
@@ -1173,6 +1177,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     const bool amn = a.a_layout == MN_MAJOR, bmn = a.b_layout == MN_MAJOR;
     st = amn ? (bmn ? launch_big_inst<true, true>(d, bz, stream) : launch_big_inst<true, false>(d, bz, stream))
              : (bmn ? launch_big_inst<false, true>(d, bz, stream) : launch_big_inst<false, false>(d, bz, stream));
+  } else if (tile == 128 && a.tile == 0 && a.dtype == GEMM_F32 && a.split3 == 1 && a.epi == GEMM_EPI_NONE && !a.A2 && a.b_layout == MN_MAJOR &&
+             round_up(a.N, 160) * 23 <= round_up(a.N, 128) * 20) {
+    // 128 x 160 tile (round 6): fp32 three-plane products -- matrix-pipe-bound, six plane products per K step -- whose N leaves the last
+    // 128-column tile mostly empty: the 128 + 3 E columns of dApost / dBpost (N = 140: 160 instead of 256 columns computed; fp32 cfg-2,
+    // audio tokens: dApost 884 -> 761 us, dBpost 876 -> 630).  Same K order per output element: the same bits as every other tile.
+    d.tiles_n = cdiv(a.N, 160);
+    st = a.a_layout == MN_MAJOR ? launch_inst<f32s3, 128, 160, true, true>(d, bz, stream) : launch_inst<f32s3, 128, 160, false, true>(d, bz, stream);
   } else if (tile == 128) {
     d.tiles_n = cdiv(a.N, 128);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 128, 128>(a, d, bz, stream)

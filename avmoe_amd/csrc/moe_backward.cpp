@@ -43,6 +43,10 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     return launch_gemm(g, on);
   };
   auto run = [&](GemmArgs& g, bool split) { return run_on(g, split, st); };
+  // fp32 sites: products whose result is a parameter gradient or a token gradient (nothing downstream forms a cancelling sum from it) in the
+  // TWO-plane form (gemm.hip: f32s2; moe_run.h: AVMOE_LEAF2 has the classes and the measurement).  bf16 sites ignore split3.
+  static const int leaf2 = dev_env("AVMOE_LEAF2") ? atoi(dev_env("AVMOE_LEAF2")) : AVMOE_LEAF2;
+  auto leaf = [&](GemmArgs& g, int cls) { if (leaf2 & cls) g.split3 = 2; };
   const bool hop1s = d.bf16 && !dev_env("AVMOE_NO_HOP1S");    // the per-frame products against Y as streaming kernels (hop1_stream.hip)
   // Independent branches run on a helper stream (side.h) and are joined before their first consumer and before the section ends:
   //   section 1: dBpost = dOut^T Apost (+ its split-K reduce; the only user of the slabs until the join) beside dApost -> post_small_bwd -> Gram
@@ -77,6 +81,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A = dOut; g.B = sv + pl.o_Apost; g.C = sc + pl.o_dBp;
     g.M = d.Cg; g.N = d.KP; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = (long)d.g * d.KPp; g.nb2 = d.g;
     g.sA2 = d.Cg; g.sB2 = d.KPp; g.sCi = d.KPp; g.sC2 = (long)d.Cg * d.KPp;
+    leaf(g, 1);
     if (fork1) AVMOE_TRY(fk1.fork());
     AVMOE_TRY(run_on(g, true, fork1 ? side->s : st));
   }
@@ -143,6 +148,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
     g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
     g.accumulate = d.acc_dx;
+    leaf(g, 16);
     if (fork2) AVMOE_TRY(fk2.fork());
     int dx2 = 1;                                           // the eight-wave direct-load form (dx_stream2.hip: tuned bf16 shape, dX overwritten); 1 = not served
     if (d.bf16 && !d.acc_dx && !dev_env("AVMOE_NO_DX2")) {
@@ -268,6 +274,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     g.A = dZx; g.B = X; g.C = sc + pl.o_dWt;
     g.M = d.E * d.dgp; g.N = d.Cg; g.K = d.NT; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.DZ; g.ldb = d.C; g.nb2 = d.g;
     g.sA2 = (long)d.E * d.dgp; g.sB2 = d.Cg; g.sCi = d.Cg; g.sC2 = (long)d.E * d.dgp * d.Cg;
+    leaf(g, 2);
     if (!pair_done) AVMOE_TRY(run(g, true));
     if (d.El > 0) {
       GemmArgs h = g;
@@ -294,6 +301,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.A = sc + pl.o_dL2x; g.B = X; g.C = sc + pl.o_dT;
       g.M = d.KL; g.N = d.C; g.K = d.N; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.KLp; g.ldb = d.C; g.nb1 = d.S;
       g.sA1 = (long)d.N * d.KLp; g.sB1 = (long)d.N * d.C; g.sCi = d.C; g.sC1 = (long)d.KL * d.C;
+      leaf(g, 4);
       AVMOE_TRY(run(g, false));
     }
     {                                                      // dT += dTW Wt
@@ -343,6 +351,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
     GemmArgs g = base();
     g.A = sc + pl.o_dTy; g.B = sv + pl.o_V; g.C = sc + pl.o_dWf;
     g.M = d.C; g.N = d.Cy; g.K = d.S * d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = d.Cy; g.sCi = d.Cy;
+    leaf(g, 8);
     AVMOE_TRY(run(g, true));
   }
   {                                                        // dBm[s] = dV[s] Y[s]^T
@@ -371,6 +380,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.A = sv + pl.o_A1y; g.B = sc + pl.o_dBmT; g.C = sc + pl.o_dWcK;
       g.M = d.N; g.N = d.M + 1; g.K = d.S * d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.Mb;
       g.sCi = d.Mk; g.accumulate = 1;
+      leaf(g, 8);
       AVMOE_TRY(run(g, true));
     }
     AVMOE_TRY(k_softmax_rows_bwd(d.bf16, sv + pl.o_A1y, (const float*)(sc + pl.o_L1), (long)d.S * d.Kcyb, d.N, d.Np,
@@ -387,6 +397,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.A = sc + pl.o_dL1; g.B = sv + pl.o_Rext; g.C = sc + pl.o_dWcK;
       g.M = d.N; g.N = d.M + 2; g.K = d.S * d.Kcyb; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.Np; g.ldb = d.Mk;
       g.sCi = d.Mk; g.accumulate = 1;
+      leaf(g, 8);
       AVMOE_TRY(run(g, true));
     }
     AVMOE_TRY(k_dqrqb(pl, sc, prm.conv_b, st));
@@ -408,6 +419,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.sA1 = (long)d.Kcyb * d.Mb; g.sB1 = (long)d.Kcyb * d.Cy; g.sCi = d.Cy; g.sC1 = (long)d.M * d.Cy; g.out_dtype = dt;
       g.A2 = sc + pl.o_dRT; g.B2 = sv + pl.o_Qx; g.K2 = d.Kcy; g.lda2 = d.Kcyp; g.ldb2 = d.Cy; g.s2A1 = (long)d.M * d.Kcyp;
       g.accumulate = d.acc_dy;
+      leaf(g, 16);
       AVMOE_TRY(run(g, false));
     }
     if (do6a) {
@@ -422,6 +434,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
       g.A = sv + pl.o_T0T; g.B = sc + pl.o_dQT; g.C = sc + pl.o_dWf;
       g.M = d.C; g.N = d.Cy; g.K = d.Kcy; g.a_layout = g.b_layout = MN_MAJOR; g.lda = d.C; g.ldb = d.Cy; g.sCi = d.Cy;
       g.accumulate = 1;
+      leaf(g, 8);
       AVMOE_TRY(run(g, false));
     }
     }

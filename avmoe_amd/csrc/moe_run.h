@@ -23,6 +23,15 @@
 #define AVMOE_BWD_PLANES 1
 #endif
 
+// fp32 sites, BACKWARD, round 6 (second half): the two-plane form for the products NOTHING DOWNSTREAM FORMS A CANCELLING SUM FROM -- a bit mask over
+// classes of call sites in moe_backward.cpp:  1 dBpost = dOut^T Apost ;  2 dWt = dZx^T X ;  4 dT[s] = dL2[s]^T X[s] ;  8 dWf, dWcK (four products) ;
+// 16 the token gradients dX / dY.  Measured on MI355X (fp32 cfg-2 step, moe_backward.cpp rebuilt per mask, the fp32 fixture / cfg-2 / block-loop
+// tests under each):  0: 14.60 ms ; 1: FAILS (dBpost feeds the BatchNorm-2 sums of post_prep_bwd: it is not a leaf) ; 10: 14.05 ; 16: 14.22 ;
+// 26: 13.88 (2306 clip-pairs/s) ; 30: 13.98 ; 27: 13.23, fails.  26 it is: all 198 mid-size / fuzz / training-loop cases pass under 30 as well.
+#ifndef AVMOE_LEAF2
+#define AVMOE_LEAF2 26
+#endif
+
 namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap);

@@ -454,3 +454,27 @@ def test_frame_products_against_one_shared_matrix(shape):
     tol = (6e-3 if out_bf16 else 1e-4) * float(ref.abs().max())
     assert float((val - ref).abs().max()) <= tol
     assert bool((rest == -5.0).all())
+
+
+@pytest.mark.parametrize("a_mn", [False, True])
+@pytest.mark.parametrize("case", ["plain", "accumulate_epilogue", "ksplit", "ragged_rows"])
+def test_fp32_three_plane_wide_tile_equals_the_square_tiles(a_mn, case):
+    """Round 6: the 128 x 160 tile the engine picks by itself for fp32 three-plane products with an MN-major B whose N leaves the last 128-column
+    tile mostly empty (the 128 + 3 E = 140 columns of dApost / dBpost) -- the same bits as the 64 x 64 tile on the same operands (same K order per
+    output element), every row and column of every tile written exactly once (accumulate + epilogue: a row stored twice would show), ragged
+    last row tile, split K."""
+    kw = dict(plain={}, accumulate_epilogue=dict(accumulate=True, epilogue=True), ksplit=dict(ksplit=5), ragged_rows={})[case]
+    M = 5200 + (37 if case == "ragged_rows" else 0)
+    N, K = 140, 96 if case != "ksplit" else 1500
+    from avmoe_amd import _capi
+    L = _capi.lib()
+    L.avmoe_prof_reset(); L.avmoe_prof_enable(1)
+    try:
+        got, ref = _run_gemm(M, N, K, 0, a_mn, True, nb2=2, tile=0, seed=11, planes=1, **kw)      # (nb2 and M: >= 160 of the 128-row tiles, or the engine steps down to 64 x 64)
+        ran = [f["name"] for f in _capi.prof_report()]
+    finally:
+        L.avmoe_prof_enable(0); L.avmoe_prof_reset()
+    assert any("128x160" in n for n in ran), ran
+    g64, _ = _run_gemm(M, N, K, 0, a_mn, True, nb2=2, tile=64, seed=11, planes=1, **kw)
+    assert torch.equal(got, g64)
+    assert float((got - ref).norm() / ref.norm()) < 1e-6
