@@ -69,6 +69,17 @@ struct GemmArgs {
   const void* B2 = nullptr;
   int K2 = 0;
   long lda2 = 0, ldb2 = 0, s2A1 = 0, s2A2 = 0, s2B1 = 0, s2B2 = 0;
+  // optional THIRD and FOURTH K segments (tiled engine, A K_MAJOR / B MN_MAJOR first segment with a second segment; both or none):
+  //   C += alpha * ( A3[b][i][k3] B3s[b][j][k3]  +  A4[b][i][k4] B4s[b][j][k4] )      A3 MN_MAJOR, A4 K_MAJOR, B3s / B4s MN_MAJOR
+  // -- the OTHER adapter site's dY = [Bm ; wbar]^T dV + dR^T Q folded into this site's dX product (moe_backward_dx_dy): the token gradient is
+  // written once instead of written by one site and read back + added by the other.  K4 may be 0 (no cross-modal chain).
+  const void* A3s = nullptr;
+  const void* B3s = nullptr;
+  const void* A4s = nullptr;
+  const void* B4s = nullptr;
+  int K3s = 0, K4s = 0;
+  long lda3s = 0, ldb3s = 0, s3sA1 = 0, s3sB1 = 0, s3sB2 = 0;
+  long lda4s = 0, ldb4s = 0, s4sA1 = 0, s4sB1 = 0, s4sB2 = 0;
   // optional split output (streaming kernel only; launch_gemm_stream returns 1 when it cannot honour it): columns >= nsplit
   // (a multiple of 32) go, in fp32, to Cx[b2][i][j - nsplit] (row stride ldcx, group stride sCx2) instead of C -- lets the
   // wide part of a product be stored in bf16 while a few columns that feed long fp32 sums keep full precision.

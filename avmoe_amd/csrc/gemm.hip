@@ -41,6 +41,8 @@ struct DevArgs {
   int fold_rps, fold_valid;      // batch folded into M: rows per sample / stored rows per sample (0 = no fold)
   const char* A2; const char* B2; int K2; long lda2, ldb2, s2A1, s2A2, s2B1, s2B2;
   int epi; float* row_part; const float* row_lse;          // softmax epilogues (GemmArgs::epi)
+  const char* A3s; const char* B3s; const char* A4s; const char* B4s; int K3s, K4s;      // third / fourth K segment (GemmArgs::A3s ..)
+  long lda3s, ldb3s, s3sA1, s3sB1, s3sB2, lda4s, ldb4s, s4sA1, s4sB1, s4sB2;
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
@@ -473,7 +475,7 @@ __device__ __forceinline__ void gemm_segment_direct(char* smem, const char* Ab, 
   __syncthreads();                                           // the epilogue reuses the buffer
 }
 
-template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2>
+template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2, bool SEG4 = false>
 __global__ void __launch_bounds__(256, (is_split<T>::value ? 2 : 1)) gemm_kernel(const DevArgs p) {
   constexpr int ESZ = sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
@@ -513,6 +515,16 @@ __global__ void __launch_bounds__(256, (is_split<T>::value ? 2 : 1)) gemm_kernel
     const char* A2 = p.A2 + ((long)b1 * p.s2A1 + (long)b2 * p.s2A2) * ESZ;
     const char* B2 = p.B2 + ((long)b1 * p.s2B1 + (long)b2 * p.s2B2) * ESZ;
     gemm_segment<T, BM, BN, false, true, TM, TN>(smem, A2, B2, p.lda2, p.ldb2, p.M, p.N, m0, n0, 0, p.K2, acc);
+  }
+  if constexpr (SEG4) {     // third (A MN-major) and fourth (A K-major) K segments, B MN-major: the other site's dY folded into this dX product
+    const char* A3 = p.A3s + (long)b1 * p.s3sA1 * ESZ;
+    const char* B3 = p.B3s + ((long)b1 * p.s3sB1 + (long)b2 * p.s3sB2) * ESZ;
+    gemm_segment<T, BM, BN, true, true, TM, TN>(smem, A3, B3, p.lda3s, p.ldb3s, p.M, p.N, m0, n0, 0, p.K3s, acc);
+    if (p.K4s > 0) {
+      const char* A4 = p.A4s + (long)b1 * p.s4sA1 * ESZ;
+      const char* B4 = p.B4s + ((long)b1 * p.s4sB1 + (long)b2 * p.s4sB2) * ESZ;
+      gemm_segment<T, BM, BN, false, true, TM, TN>(smem, A4, B4, p.lda4s, p.ldb4s, p.M, p.N, m0, n0, 0, p.K4s, acc);
+    }
   }
 
   // ---- epilogue through LDS ----
@@ -973,26 +985,27 @@ __global__ void __launch_bounds__(256, 2) gemm_tokpair_kernel(const TokPairDev p
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2 = false>
+template <typename T, int BM, int BN, bool AMN, bool BMN, bool SEG2 = false, bool SEG4 = false>
 static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   constexpr int ESZ = sizeof(T);
   constexpr int KBY = stage_kbytes(BM, BN, AMN, BMN), BK = KBY / ESZ, BK2 = stage_kbytes(BM, BN, false, true) / ESZ;
   constexpr int A_BYTES = (AMN ? BK : BM) * (AMN ? BM * ESZ + 16 : KBY + 16);
   constexpr int B_BYTES = (BMN ? BK : BN) * (BMN ? BN * ESZ + 16 : KBY + 16);
   constexpr int A2_BYTES = BM * (BK2 * ESZ + 16), B2_BYTES = BK2 * (BN * ESZ + 16);
-  constexpr int S1 = 2 * (A_BYTES + B_BYTES), S2 = SEG2 ? 2 * (A2_BYTES + B2_BYTES) : 0;
-  constexpr int STAGES = S1 > S2 ? S1 : S2;
+  constexpr int KBY3 = stage_kbytes(BM, BN, true, true), BK3 = KBY3 / ESZ;      // third segment: both operands MN-major
+  constexpr int S1 = 2 * (A_BYTES + B_BYTES), S2 = SEG2 ? 2 * (A2_BYTES + B2_BYTES) : 0, S3 = SEG4 ? 2 * BK3 * ((BM + BN) * ESZ + 32) : 0;
+  constexpr int STAGES = (S1 > S2 ? S1 : S2) > S3 ? (S1 > S2 ? S1 : S2) : S3;
   constexpr int EPI = BM * (BN + 4) * 4;
   constexpr int LDS = STAGES > EPI ? STAGES : EPI;
   static LdsAttrOnce attr;
-  auto kern = gemm_kernel<T, BM, BN, AMN, BMN, SEG2>;
+  auto kern = gemm_kernel<T, BM, BN, AMN, BMN, SEG2, SEG4>;
   AVMOE_TRY(attr.ensure((const void*)kern, LDS, "gemm"));
   const int tiles_m = cdiv(d.M, BM);
   dim3 grid((unsigned)(tiles_m * d.tiles_n), (unsigned)batch_z, 1);
   static const char* const names[2][2] = {{"gemm_KK", "gemm_KM"}, {"gemm_MK", "gemm_MM"}};
   static char name[64];
   if (!name[0]) {
-    snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG2 ? "+KM" : "", sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : (std::is_same<T, f32s2>::value ? "f32s2" : "f32")), BM);
+    snprintf(name, sizeof(name), "%s%s_%s_%d", names[AMN][BMN], SEG4 ? "+KM+MM+KM" : (SEG2 ? "+KM" : ""), sizeof(T) == 2 ? "bf16" : (std::is_same<T, f32s3>::value ? "f32s3" : (std::is_same<T, f32s2>::value ? "f32s2" : "f32")), BM);
     if (BN != BM) snprintf(name + strlen(name), sizeof(name) - strlen(name), "x%d", BN);
   }
   static const bool shapes = getenv("AVMOE_PROF_SHAPES") != nullptr;
@@ -1006,9 +1019,9 @@ static int launch_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
   const double esz = sizeof(T), osz = d.ksplit > 1 ? 4.0 : (d.out_bf16 ? 2.0 : 4.0);
   // algorithmic bytes: every operand element once (broadcast operands counted once), C written once (+ read if accumulating)
   const double abytes = ((d.sA1 == 0 && d.sA2 == 0 ? 1.0 : nb) * d.M * (double)d.K + (d.sB1 == 0 && d.sB2 == 0 ? 1.0 : nb) * d.N * (double)d.K +
-                         (SEG2 ? nb * (d.M + d.N) * (double)d.K2 : 0.0)) * esz +
+                         (SEG2 ? nb * (d.M + d.N) * (double)d.K2 : 0.0) + (SEG4 ? nb * (d.M + d.N) * (double)(d.K3s + d.K4s) : 0.0)) * esz +
                         nb * d.M * (double)d.N * osz * (d.accumulate ? 2.0 : 1.0) + (d.D ? nb * d.M * (double)d.N * esz : 0.0);
-  ProfScope ps(pname, abytes, 2.0 * nb * d.M * (double)d.N * (d.K + (SEG2 ? d.K2 : 0)), stream);
+  ProfScope ps(pname, abytes, 2.0 * nb * d.M * (double)d.N * (d.K + (SEG2 ? d.K2 : 0) + (SEG4 ? d.K3s + d.K4s : 0)), stream);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, d);
   AVMOE_CHECK_LAUNCH("gemm_kernel");
   return OK;
@@ -1051,6 +1064,10 @@ static int launch_big_inst(const DevArgs& d, int batch_z, hipStream_t stream) {
 template <typename T, int BM, int BN>
 static int launch_layout(const GemmArgs& a, const DevArgs& d, int bz, hipStream_t s) {
   const bool amn = a.a_layout == MN_MAJOR, bmn = a.b_layout == MN_MAJOR;
+  if (a.A3s) {
+    if constexpr (BM == BN && !std::is_same<T, float>::value) return launch_inst<T, BM, BN, false, true, true, true>(d, bz, s);      // (validated: K-major A, MN-major B, a second segment)
+    else { set_last_error("gemm: third / fourth K segments are built for the square tiles of the bf16 and the plane forms"); return ERR_UNSUPPORTED; }
+  }
   if (a.A2) {
     if (!amn && bmn) return launch_inst<T, BM, BN, false, true, true>(d, bz, s);
     if (amn && bmn) return launch_inst<T, BM, BN, true, true, true>(d, bz, s);
@@ -1103,6 +1120,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   d.alpha = a.alpha; d.accumulate = a.accumulate; d.out_bf16 = a.out_dtype == GEMM_BF16;
   d.A2 = (const char*)a.A2; d.B2 = (const char*)a.B2; d.K2 = a.K2; d.lda2 = a.lda2; d.ldb2 = a.ldb2;
   d.s2A1 = a.s2A1; d.s2A2 = a.s2A2; d.s2B1 = a.s2B1; d.s2B2 = a.s2B2;
+  d.A3s = (const char*)a.A3s; d.B3s = (const char*)a.B3s; d.A4s = (const char*)a.A4s; d.B4s = (const char*)a.B4s; d.K3s = a.K3s; d.K4s = a.K4s;
+  d.lda3s = a.lda3s; d.ldb3s = a.ldb3s; d.s3sA1 = a.s3sA1; d.s3sB1 = a.s3sB1; d.s3sB2 = a.s3sB2;
+  d.lda4s = a.lda4s; d.ldb4s = a.ldb4s; d.s4sA1 = a.s4sA1; d.s4sB1 = a.s4sB1; d.s4sB2 = a.s4sB2;
+  if (a.A3s) {
+    const bool ok = a.A2 && a.B3s && a.K3s > 0 && a.a_layout == K_MAJOR && a.b_layout == MN_MAJOR && a.ksplit <= 1 && a.epi == GEMM_EPI_NONE && d.nb3 == 1 &&
+                    (a.dtype == GEMM_BF16 || a.split3) && aligned16(a.A3s) && aligned16(a.B3s) && mult16(a.lda3s) && mult16(a.ldb3s) && mult16(a.s3sA1) &&
+                    mult16(a.s3sB1) && mult16(a.s3sB2) &&
+                    (a.K4s == 0 || (a.A4s && a.B4s && aligned16(a.A4s) && aligned16(a.B4s) && mult16(a.lda4s) && mult16(a.ldb4s) && mult16(a.s4sA1) && mult16(a.s4sB1) && mult16(a.s4sB2)));
+    if (!ok) { set_last_error("gemm: third / fourth K segments need a K-major A / MN-major B product with a second segment, no split-K, aligned operands"); return ERR_BAD_ARG; }
+  }
   d.epi = a.epi; d.row_part = a.row_part; d.row_lse = a.row_lse;
   if (a.epi != GEMM_EPI_NONE) {
     if (a.ksplit > 1 || a.sCj != 1 || (a.D != nullptr) != (a.epi == GEMM_EPI_MULSUB) || a.row_scale || a.accumulate || a.A2 || a.Cx || a.st_rows ||
@@ -1118,7 +1145,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   {
     static const bool nostream = dev_env("AVMOE_GEMM_NOSTREAM") != nullptr;     // dev switch: A/B against the tiled engine
-    if (!nostream && a.epi == GEMM_EPI_NONE && a.nb3 <= 1) {
+    if (!nostream && a.epi == GEMM_EPI_NONE && a.nb3 <= 1 && !a.A3s) {
       const int s = launch_gemm_stream(a, stream);
       if (s <= 0) return s;
       const int f = launch_gemm_frames(a, stream);           // a few rows per frame against one shared matrix (frame_gemm.hip)

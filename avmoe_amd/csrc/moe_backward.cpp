@@ -24,6 +24,18 @@ avmoe_moe_ptrs with_unit_gates(const Plan& pl, const avmoe_moe_ptrs& prm, char* 
 //      GEMM(s) that write dY (touches neither dX nor dY), 16 = those GEMMs alone (after 8)
 // Sections are stream-ordered through `scratch`: a caller may put event records / waits between them (AdapterPair orders the
 // two sites' accumulations into the shared token gradients this way) but nothing that touches the workspaces.
+// the operands of  dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + 2 dSxx X[s]  (phase 5; moe_backward_dx_dy adds the other site's dY to it)
+static void fill_dx_args(GemmArgs& g, const Plan& pl, const void* X, const char* sv, const char* sc, void* dX) {
+  const Dims& d = pl.d;
+  g.A = sc + pl.o_Zw; g.B = sv + pl.o_Wt; g.C = dX;
+  g.M = d.N; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
+  g.sA1 = (long)d.N * d.DZ; g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg;
+  g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.sC2 = d.Cg; g.out_dtype = d.bf16 ? GEMM_BF16 : GEMM_F32;
+  g.row_scale = (const float*)(sc + pl.o_rs2x); g.sRS1 = d.N; g.D = X; g.sDi = d.C; g.sD1 = (long)d.N * d.C; g.sD2 = d.Cg;
+  g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
+  g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
+}
+
 int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_ptrs& prm_in, const void* dOut, const float* lb_grad,
                  char* sv, char* sc, void* dX, void* dY, const avmoe_moe_ptrs& grads_in, hipStream_t st, int parts) {
   const Dims& d = pl.d;
@@ -140,13 +152,7 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
   // ---- phase 5: GEMMs against X --------------------------------------------------------------------
   if (do_dx) {   // dX[s] = dZx[s] Wt + [dL2 | dsx | 1][s] [T ; 1 ; dm1/N][s] + 2 dSxx X[s]   -- one pass: two K segments + row-scale epilogue
     GemmArgs g = base();
-    g.A = dZx; g.B = sv + pl.o_Wt; g.C = dX;
-    g.M = d.N; g.N = d.Cg; g.K = d.E * d.dgp; g.lda = d.DZ; g.b_layout = MN_MAJOR; g.ldb = d.Cg; g.nb1 = d.S; g.nb2 = d.g;
-    g.sA1 = (long)d.N * d.DZ; g.sA2 = (long)d.E * d.dgp; g.sB2 = (long)d.E * d.dgp * d.Cg;
-    g.sCi = d.C; g.sC1 = (long)d.N * d.C; g.sC2 = d.Cg; g.out_dtype = dt;
-    g.row_scale = (const float*)(sc + pl.o_rs2x); g.sRS1 = d.N; g.D = X; g.sDi = d.C; g.sD1 = (long)d.N * d.C; g.sD2 = d.Cg;
-    g.A2 = sc + pl.o_dL2x; g.B2 = sv + pl.o_Text; g.K2 = d.KLT; g.lda2 = d.KLp; g.ldb2 = d.C;
-    g.s2A1 = (long)d.N * d.KLp; g.s2B1 = (long)d.KLT * d.C; g.s2B2 = d.Cg;
+    fill_dx_args(g, pl, X, sv, sc, dX);
     g.accumulate = d.acc_dx;
     leaf(g, 16);
     if (fork2) AVMOE_TRY(fk2.fork());
@@ -492,9 +498,22 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
 int moe_backward_dx_dy(const Plan& pa, const void* X, char* sva, char* sca, const Plan& pb, char* svb, char* scb, void* dX, bool launch, hipStream_t st) {
   const Dims& a = pa.d;
   const Dims& b = pb.d;
-  if (!a.bf16 || !b.bf16 || a.mha || a.nxn || a.Kcx > 0 || a.mg || b.mg || a.Cg != 384 || a.E * a.dgp != 128 || a.KLT > 72 || a.KLp < 72 ||
-      b.M != a.N || b.Cy != a.C || b.S != a.S || b.Kcy < 1 || b.Kcy > 64 || b.Kcyb > 96 || b.Kcx > 0 || (long)a.S * a.N < 2048)
-    return 1;
+  if (a.bf16 != b.bf16 || a.mha || a.nxn || a.Kcx > 0 || a.mg || b.mg || b.M != a.N || b.Cy != a.C || b.S != a.S || b.Kcx > 0) return 1;
+  if (!a.bf16 || a.Cg != 384 || a.E * a.dgp != 128 || a.KLT > 72 || a.KLp < 72 || b.Kcy < 1 || b.Kcy > 64 || b.Kcyb > 96 || (long)a.S * a.N < 2048) {
+    // Any other shape, round 6: the same sum on the tiled engine -- site A's dX product with site B's  dY[s] = [Bm ; wbar][s]^T dV[s] + dR[s]^T Q
+    // as a third and a fourth K segment (gemm.h: A3s ..): the token gradient is written once instead of written by site A and read back + added by
+    // site B.  fp32 sites only (AVMOE_DXDY_GEN = 1; 3 = bf16 sites of the generalised shapes too: measured, moe_run.h).
+    if (!(AVMOE_DXDY_GEN & (a.bf16 ? 2 : 1))) return 1;
+    if (!launch) return OK;
+    GemmArgs g; g.dtype = a.bf16 ? GEMM_BF16 : GEMM_F32; g.split3 = (AVMOE_LEAF2 & 16) ? 2 : AVMOE_BWD_PLANES;
+    fill_dx_args(g, pa, X, sva, sca, dX);
+    g.A3s = svb + pb.o_BmX; g.B3s = scb + pb.o_dV; g.K3s = b.Kcyb; g.lda3s = b.Mb; g.ldb3s = b.Cy;
+    g.s3sA1 = (long)b.Kcyb * b.Mb; g.s3sB1 = (long)b.Kcyb * b.Cy; g.s3sB2 = a.Cg;
+    if (b.Kcy > 0) {
+      g.A4s = scb + pb.o_dRT; g.B4s = svb + pb.o_Qx; g.K4s = b.Kcy; g.lda4s = b.Kcyp; g.ldb4s = b.Cy; g.s4sA1 = (long)b.M * b.Kcyp; g.s4sB1 = 0; g.s4sB2 = a.Cg;
+    }
+    return launch_gemm(g, st);
+  }
   if (!launch) return OK;
   return k_dx_stream3(X, a.C, sca + pa.o_Zw, a.DZ, sca + pa.o_dL2x, a.KLp, a.KLT, (const float*)(sca + pa.o_rs2x), sva + pa.o_Wt, a.Cg, (long)a.E * a.dgp * a.Cg,
                       sva + pa.o_Text, a.C, (long)a.KLT * a.C, svb + pb.o_BmX, b.Mb, (long)b.Kcyb * b.Mb, b.Kcyb, scb + pb.o_dRT, b.Kcyp,

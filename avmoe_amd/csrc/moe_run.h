@@ -32,6 +32,12 @@
 #define AVMOE_LEAF2 26
 #endif
 
+// moe_backward_dx_dy on the tiled engine (the other site's dY as a third and fourth K segment of this site's dX product): bit 0 = fp32 sites,
+// bit 1 = bf16 sites whose shape the streaming form (dx_stream3.hip) does not serve.
+#ifndef AVMOE_DXDY_GEN
+#define AVMOE_DXDY_GEN 1
+#endif
+
 namespace avmoe {
 
 int choose_ksplit(const GemmArgs& g, size_t slab_floats_cap);

@@ -30,6 +30,18 @@ A._SiteBackward.__init__ = timed("py _SiteBackward.__init__", A._SiteBackward.__
 A._SiteBackward.run = timed("py _SiteBackward.run (incl. C)", A._SiteBackward.run)
 A._SiteBackward.finish = timed("py _SiteBackward.finish", A._SiteBackward.finish)
 A._PairFunction.backward = staticmethod(timed("py pair backward (all)", A._PairFunction.backward))
+# the torch calls of the facade (events, stream contexts, allocations, record_stream): where the Python share of a backward goes
+if os.environ.get("HOST_SPLIT_TORCH", "1") != "0":
+    torch.cuda.Event.record = timed("torch Event.record", torch.cuda.Event.record)
+    torch.cuda.Stream.wait_event = timed("torch Stream.wait_event", torch.cuda.Stream.wait_event)
+    torch.Tensor.record_stream = timed("torch Tensor.record_stream", torch.Tensor.record_stream)
+    torch.cuda.StreamContext.__enter__ = timed("torch stream ctx enter", torch.cuda.StreamContext.__enter__)
+    torch.cuda.StreamContext.__exit__ = timed("torch stream ctx exit", torch.cuda.StreamContext.__exit__)
+    for fn in ("empty", "empty_like", "zeros", "zeros_like", "full"):
+        setattr(torch, fn, timed("torch." + fn, getattr(torch, fn)))
+    torch.cuda.current_stream = timed("torch.cuda.current_stream", torch.cuda.current_stream)
+    A._PairFunction.forward = staticmethod(timed("py pair forward (all)", A._PairFunction.forward))
+    wl.step = timed("bench step (all)", wl.step)
 n = 10
 t0 = time.perf_counter()
 for _ in range(n): wl.step()
