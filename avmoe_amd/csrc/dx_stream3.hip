@@ -382,7 +382,9 @@ int k_dx_stream3(const void* X, long ldx, const void* dZx, long ldz, const void*
   static LdsAttrOnce attr;
   AVMOE_TRY(attr.ensure((const void*)kk_dx_stream3, DX3_LDS, "dx_stream3"));
   const double ntok = (double)S * N;
-  const double bytes = ntok * G * (384.0 * 2 * 2 + 128.0 * 2) + ntok * (ldl * 2.0 + 4.0) + ntok * G * (64.0 + KB) * 2.0;
+  // UNIQUE algorithmic bytes: X, dX (384 channels x 2 bytes each per group), dZx (128 per group), one dL2 row + its row scale, site B's operands
+  // (dR^T: 64 values, [Bm ; wbar]: KB values per token) ONCE -- each channel group's block fetches them again (PMC: 4 236 B per token at cfg-2)
+  const double bytes = ntok * G * (384.0 * 2 * 2 + 128.0 * 2) + ntok * (ldl * 2.0 + 4.0) + ntok * (64.0 + KB) * 2.0;
   ProfScope ps("k_dx_stream3", (long)ntok, bytes, 2.0 * ntok * G * 384.0 * (128 + K2 + KB + KQ), st);
   hipLaunchKernelGGL(kk_dx_stream3, dim3((unsigned)gx, (unsigned)G), dim3(NTHR), DX3_LDS, st, p);
   AVMOE_CHECK_LAUNCH("dx_stream3");

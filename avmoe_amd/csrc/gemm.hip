@@ -1211,6 +1211,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     // audio tokens: dApost 884 -> 761 us, dBpost 876 -> 630).  Same K order per output element: the same bits as every other tile.
     d.tiles_n = cdiv(a.N, 160);
     st = a.a_layout == MN_MAJOR ? launch_inst<f32s3, 128, 160, true, true>(d, bz, stream) : launch_inst<f32s3, 128, 160, false, true>(d, bz, stream);
+  } else if (tile == 128 && a.tile == 0 && a.dtype == GEMM_F32 && a.split3 == 1 && a.epi == GEMM_EPI_NONE && !a.A2 && a.a_layout == K_MAJOR && !d.fold_rps &&
+             d.ksplit == 1 && round_up(d.M, 96) * 23 <= round_up(d.M, 128) * 20) {
+    // 96 x 128 tile: the same for M -- the 65 rows ([latent tokens ; wbar]) of the per-frame hop-1 products against Y fill half of a 128-row tile
+    d.tiles_n = cdiv(a.N, 128);
+    st = a.b_layout == MN_MAJOR ? launch_inst<f32s3, 96, 128, false, true>(d, bz, stream) : launch_inst<f32s3, 96, 128, false, false>(d, bz, stream);
   } else if (tile == 128) {
     d.tiles_n = cdiv(a.N, 128);
     st = a.dtype == GEMM_BF16 ? launch_layout<__bf16, 128, 128>(a, d, bz, stream)

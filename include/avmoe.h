@@ -187,7 +187,9 @@ int avmoe_moe_backward_part(const avmoe_moe_desc* desc, const void* X, const voi
  * Call after sections 1 + 32 + 8 of BOTH sites (their `saved` / `scratch` as those calls left them; B's workspaces are only read), in
  * place of section 64 of A and section 16 of B; the stream must be ordered behind both sites' section 8.  dT is overwritten.
  * Returns 0 = launched, 1 = these shapes are not served (nothing launched: run section 64 of A, then section 16 of B with
- * accumulate_dy), < 0 = error.  dT == NULL: nothing is launched, the return value only says whether the shapes are served. */
+ * accumulate_dy), < 0 = error.  dT == NULL: nothing is launched, the return value only says whether the shapes are served.
+ * Served: bf16 pairs of the tuned shape (one streaming kernel, csrc/dx_stream3.hip) and -- round 6 -- fp32 pairs of ANY shape without the AVVP N x N /
+ * frame-attention / latent-self-attention variants on site A (the tiled engine with site B's product as a third and fourth K segment). */
 int avmoe_moe_backward_dx_dy(const avmoe_moe_desc* desc_a, const void* X_a, void* saved_a, void* scratch_a,
                              const avmoe_moe_desc* desc_b, void* saved_b, void* scratch_b, void* dT, void* stream);
 

@@ -478,3 +478,22 @@ def test_fp32_three_plane_wide_tile_equals_the_square_tiles(a_mn, case):
     g64, _ = _run_gemm(M, N, K, 0, a_mn, True, nb2=2, tile=64, seed=11, planes=1, **kw)
     assert torch.equal(got, g64)
     assert float((got - ref).norm() / ref.norm()) < 1e-6
+
+
+@pytest.mark.parametrize("b_mn", [False, True])
+def test_fp32_three_plane_96_row_tile_equals_the_square_tiles(b_mn):
+    """Round 6: the 96 x 128 tile the engine picks for fp32 three-plane products with a K-major A whose M leaves a 128-row tile half empty (the
+    65 rows of the per-frame hop-1 products): the bits of the 64 x 64 tile, every row written once (accumulate + epilogue)."""
+    from avmoe_amd import _capi
+    L = _capi.lib()
+    for kw in ({}, dict(accumulate=True, epilogue=True)):
+        L.avmoe_prof_reset(); L.avmoe_prof_enable(1)
+        try:
+            got, ref = _run_gemm(65, 256, 200, 0, False, b_mn, nb1=100, tile=0, seed=5, planes=1, **kw)
+            ran = [f["name"] for f in _capi.prof_report()]
+        finally:
+            L.avmoe_prof_enable(0); L.avmoe_prof_reset()
+        assert any("_96x128" in n for n in ran), ran
+        g64, _ = _run_gemm(65, 256, 200, 0, False, b_mn, nb1=100, tile=64, seed=5, planes=1, **kw)
+        assert torch.equal(got, g64)
+        assert float((got - ref).norm() / ref.norm()) < 1e-6
