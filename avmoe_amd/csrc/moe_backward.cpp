@@ -498,8 +498,8 @@ int moe_backward(const Plan& pl, const void* X, const void* Y, const avmoe_moe_p
 int moe_backward_dx_dy(const Plan& pa, const void* X, char* sva, char* sca, const Plan& pb, char* svb, char* scb, void* dX, bool launch, hipStream_t st) {
   const Dims& a = pa.d;
   const Dims& b = pb.d;
-  if (a.bf16 != b.bf16 || a.mha || a.nxn || a.Kcx > 0 || a.mg || b.mg || b.M != a.N || b.Cy != a.C || b.S != a.S || b.Kcx > 0) return 1;
-  if (!a.bf16 || a.Cg != 384 || a.E * a.dgp != 128 || a.KLT > 72 || a.KLp < 72 || b.Kcy < 1 || b.Kcy > 64 || b.Kcyb > 96 || (long)a.S * a.N < 2048) {
+  if (a.bf16 != b.bf16 || a.mha || a.nxn || a.Kcx > 0 || b.M != a.N || b.Cy != a.C || b.S != a.S || b.Kcx > 0) return 1;
+  if (!a.bf16 || a.mg || b.mg || a.Cg != 384 || a.E * a.dgp != 128 || a.KLT > 72 || a.KLp < 72 || b.Kcy < 1 || b.Kcy > 64 || b.Kcyb > 96 || (long)a.S * a.N < 2048) {
     // Any other shape, round 6: the same sum on the tiled engine -- site A's dX product with site B's  dY[s] = [Bm ; wbar][s]^T dV[s] + dR[s]^T Q
     // as a third and a fourth K segment (gemm.h: A3s ..): the token gradient is written once instead of written by site A and read back + added by
     // site B.  fp32 sites only (AVMOE_DXDY_GEN = 1; 3 = bf16 sites of the generalised shapes too: measured, moe_run.h).

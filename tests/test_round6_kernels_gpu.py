@@ -208,3 +208,55 @@ def test_scalar_gate_gradients_over_draws_of_the_upstream_gradient(site, avmoe_h
         if eh > bar or eh > 1.5 * ee + 5e-3:
             bad[k] = (eh, ee)
     assert not bad, f"(eps hip, eps eager autocast): {bad}"
+
+
+@pytest.mark.parametrize("reductions", [(6, 3), (8, 8)])      # bottleneck 16 per group ; 12 / 6 per group (merged-group weights, moe_plan.h: mg)
+def test_fp32_site_pair_writes_each_token_gradient_once(reductions):
+    """Round 6: fp32 site pairs of ANY shape get `token gradient = this site's dX + the other site's dY` from ONE engine product (the other site's
+    [Bm ; wbar]^T dV + dR^T Q as a third and fourth K segment: avmoe_moe_backward_dx_dy on the tiled engine) -- it runs (profiler family), and
+    the gradients equal those of the two sites called one after the other (overwrite, then read back + add) to summation-order noise."""
+    from avmoe_amd.adapters import AdapterPair
+    from avmoe_amd import _capi
+    from tests.test_adapters_gpu import build_module
+    dev = torch.device("cuda:0")
+    ca = O.AdapterConfig(Cx=192, Nx=300, Cy=96, Ny=77, reduction=reductions[0], groups=2, K=12)
+    cb = O.AdapterConfig(Cx=96, Nx=77, Cy=192, Ny=300, reduction=reductions[1], groups=2, K=12)
+    torch.manual_seed(4)
+    sa, sb = build_module("ave", ca).to(dev).train(), build_module("ave", cb).to(dev).train()
+    with torch.no_grad():
+        for m in (sa, sb):
+            for k, p in m.named_parameters():
+                if k.endswith(("gate", "gate_av")):
+                    p.fill_(0.4)
+    g = torch.Generator().manual_seed(10)
+    S = 6
+    fa, fv = (0.5 * torch.randn(S, ca.Cx, ca.Nx, 1, generator=g)).to(dev), (0.5 * torch.randn(S, cb.Cx, cb.Nx, 1, generator=g)).to(dev)
+    ga, gv = torch.randn(S, ca.Cx, ca.Nx, 1, generator=g).to(dev), torch.randn(S, cb.Cx, cb.Nx, 1, generator=g).to(dev)
+    bufs = [{k: b.clone() for k, b in m.named_buffers()} for m in (sa, sb)]
+
+    def run(paired):
+        for m, bb in zip((sa, sb), bufs):
+            m.zero_grad()
+            m.load_state_dict({**m.state_dict(), **bb})
+        xa, xv = fa.clone().requires_grad_(True), fv.clone().requires_grad_(True)
+        if paired:
+            oa, _ia, ov, _iv = AdapterPair(sa, sb, concurrent=True)(xa, xv)
+        else:
+            (oa, _ia), (ov, _iv) = sa(xa, xv), sb(xv, xa)
+        torch.autograd.backward([oa, ov], [ga, gv])
+        torch.cuda.synchronize()
+        return xa.grad, xv.grad, [p.grad.clone() for m in (sa, sb) for p in m.parameters()]
+
+    ref = run(False)
+    L = _capi.lib()
+    L.avmoe_prof_reset(); L.avmoe_prof_enable(1)
+    try:
+        got = run(True)
+        ran = [f["name"] for f in _capi.prof_report()]
+    finally:
+        L.avmoe_prof_enable(0); L.avmoe_prof_reset()
+    assert sum("+KM+MM+KM" in n for n in ran) >= 1, ran
+    for r_, g_ in ((ref[0], got[0]), (ref[1], got[1])):
+        assert float((r_ - g_).abs().max()) <= 2e-6 * float(r_.abs().max())
+    for r_, g_ in zip(ref[2], got[2]):
+        assert torch.equal(r_, g_)
