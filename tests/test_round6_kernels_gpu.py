@@ -210,7 +210,7 @@ def test_scalar_gate_gradients_over_draws_of_the_upstream_gradient(site, avmoe_h
     assert not bad, f"(eps hip, eps eager autocast): {bad}"
 
 
-@pytest.mark.parametrize("reductions,em_b", [((6, 3), 2), ((8, 8), 2), ((6, 3), 0)])      # bottleneck 16 per group ; 12 / 6 per group (merged-group weights, moe_plan.h: mg) ; site B without a cross-modal expert (its dY is the wbar row alone: no fourth segment)
+@pytest.mark.parametrize("reductions,em_b", [((6, 3), 2), ((8, 8), 2), ((6, 3), 0), ((6, 3), -1)])      # bottleneck 16 per group ; 12 / 6 per group (merged-group weights, moe_plan.h: mg) ; site B without a cross-modal expert (its dY is the wbar row alone: no fourth segment)
 def test_fp32_site_pair_writes_each_token_gradient_once(reductions, em_b):
     """Round 6: fp32 site pairs of ANY shape get `token gradient = this site's dX + the other site's dY` from ONE engine product (the other site's
     [Bm ; wbar]^T dV + dR^T Q as a third and fourth K segment: avmoe_moe_backward_dx_dy on the tiled engine) -- it runs (profiler family), and
@@ -219,7 +219,9 @@ def test_fp32_site_pair_writes_each_token_gradient_once(reductions, em_b):
     from avmoe_amd import _capi
     from tests.test_adapters_gpu import build_module
     dev = torch.device("cuda:0")
-    ca = O.AdapterConfig(Cx=192, Nx=300, Cy=96, Ny=77, reduction=reductions[0], groups=2, K=12)
+    em_a = 0 if em_b < 0 else 2          # (-1: site A is the one without a cross-modal expert -- its dX product has no latent-token segment to speak of)
+    em_b = 2 if em_b < 0 else em_b
+    ca = O.AdapterConfig(Cx=192, Nx=300, Cy=96, Ny=77, reduction=reductions[0], groups=2, K=12, E_m=em_a, E_s=2 if em_a else 3)
     cb = O.AdapterConfig(Cx=96, Nx=77, Cy=192, Ny=300, reduction=reductions[1], groups=2, K=12, E_m=em_b, E_s=2 if em_b else 3)
     torch.manual_seed(4)
     sa, sb = build_module("ave", ca).to(dev).train(), build_module("ave", cb).to(dev).train()
