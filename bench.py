@@ -842,7 +842,7 @@ def main():
         k32 = max(3, args.steps // 2)
         dt32 = wl.timed(k32, 2)
         value_f32 = dict(value=round(c["B"] * world / (dt32 / k32), 2), unit="clip-pairs/s", ms_per_step=round(1e3 * dt32 / k32, 4), steps=k32,
-                         dtype="f32", note="fp32 activations, every product in three-plane form on the bf16 matrix pipe (six plane products of order <= 2, 5.8e-9 relative per product, fp32 accumulation; csrc/moe_run.h: AVMOE_FWD_SPLIT3): the configuration held to the 1e-3 parity bar")
+                         dtype="f32", note="fp32 activations on the bf16 matrix pipe: three bf16 planes per value (six plane products of order <= 2, 5.8e-9 relative per product, fp32 accumulation; csrc/moe_run.h: AVMOE_FWD_SPLIT3) for the forward and every product of the backward a cancelling sum is formed from, two planes (three products, 1.5e-5 per product) for its leaf gradients dWt / dWf / dWcK / dX / dY (AVMOE_LEAF2): the configuration held to the 1e-3 parity bar")
         wl.release()
 
     # the reference's own batch (AVE/train.sh:33: 2 clips): the same step at B = 2, where the launch rate binds -- step time and launches per step
