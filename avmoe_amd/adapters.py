@@ -49,10 +49,13 @@ def release_workspaces():
     _SCRATCH.clear()
 
 
-def _scratch(dev: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
+def _scratch(dev: torch.device, nbytes: int, slot: int = 0, stream: int = None) -> torch.Tensor:
     """Transient workspace per (device, stream), grown on demand and reused (its users are ordered by that stream).
-    slot: a second workspace on the same stream (AdapterPair.same_stream interleaves the sections of two sites on ONE stream)."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, slot)
+    slot: a second workspace on the same stream (AdapterPair.same_stream interleaves the sections of two sites on ONE stream).
+    stream: the handle of the stream the caller is on, when it has it at hand (a torch.cuda.current_stream() lookup costs ~3 us; at the
+    reference's batch of 2 clips a pair-step made 20 of them)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
+           stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream, slot)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -97,12 +100,15 @@ def _shared_gpu_of(module, dev, asked):
     return side
 
 
-def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=None):
+def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=None, stream=None):
     """One avmoe_moe_forward call.  Returns (out, probs, idx, lb, state) with state = what the backward needs.
     add_to: a contiguous tensor like X that receives `+= adapter(X, Y)` in place (avmoe_moe_desc.accumulate_out) and is
-    returned as `out`.  shared_gpu: True = another stream's kernels may run beside this call (AdapterPair); None = _shared_gpu_of."""
+    returned as `out`.  shared_gpu: True = another stream's kernels may run beside this call (AdapterPair); None = _shared_gpu_of.
+    stream: the handle (int) of the CURRENT stream when the caller already has it (AdapterPair), else looked up."""
     if not (X.is_cuda and Y.is_cuda):
         raise capi.AvmoeError("avmoe_amd runs on MI355X only: tensors must live on a GPU (no CPU fallback)")
+    if stream is None:
+        stream = torch.cuda.current_stream(X.device).cuda_stream
     if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
         raise capi.AvmoeError(f"activations must both be float32 or bfloat16, got {X.dtype} / {Y.dtype}")
     L = capi.lib()
@@ -122,7 +128,7 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=No
             raise capi.AvmoeError(L.avmoe_last_error().decode())
         module.__dict__["_ws_sizes"][wkey] = sizes
     saved = torch.empty(sizes[0], dtype=torch.uint8, device=X.device)
-    scratch = _scratch(X.device, sizes[1])
+    scratch = _scratch(X.device, sizes[1], stream=stream)
     if add_to is not None:
         if add_to.shape != X.shape or add_to.dtype != X.dtype or not add_to.is_contiguous() or add_to.device != X.device:
             raise capi.AvmoeError("add_to must be a contiguous tensor with the shape, dtype and device of the tokens")
@@ -137,13 +143,12 @@ def _site_forward(module, X, Y, noise, names, params, add_to=None, shared_gpu=No
         noise = noise.to(torch.float32).contiguous()
     st = L.avmoe_moe_forward(C.byref(desc), X.data_ptr(), Y.data_ptr(), C.byref(ptrs),
                              noise.data_ptr() if noise is not None else None, out.data_ptr(), probs.data_ptr(),
-                             idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
-                             torch.cuda.current_stream(X.device).cuda_stream)
+                             idx.data_ptr(), lb.data_ptr(), saved.data_ptr(), scratch.data_ptr(), stream)
     desc.accumulate_out = 0
     capi.check(st, "avmoe_moe_forward")
     if module.__dict__.get("_keep_saved"):                # avmoe_amd.debug.keep_saved: checker-side view of the last call's workspace
         module.__dict__["_last_saved"] = (desc, saved)
-    return out, probs, idx, lb, ((desc, keep), saved, X, Y)
+    return out, probs, idx, lb, ((desc, keep, ptrs), saved, X, Y)
 
 
 class _SiteBackward:
@@ -152,12 +157,15 @@ class _SiteBackward:
     writer of dX, 4: every writer of dY), in this order.  finish() returns the parameter gradients in `names` order (None where not needed,
     or for all of them when a gradient sink took them)."""
 
-    def __init__(self, module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False, scratch_slot=0):
+    def __init__(self, module, state, names, params, needs, d_out, d_lb, dX, dY, acc_dx=False, acc_dy=False, scratch_slot=0, stream=None):
         self.L = capi.lib()
-        (desc, keep), self.saved, self.X, self.Y = state
+        (desc, keep, fwd_ptrs), self.saved, self.X, self.Y = state
         self.desc, self.names, self.module = desc, names, module
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.X.device).cuda_stream      # (the stream this object is built AND run on)
         tensors = dict(zip(names, params))
-        self.ptrs = module._fill_ptrs(params, keep)
+        # the forward's pointer struct, as long as it was built from these very parameters (autograd's saved-tensor version checks -- or, with an
+        # anchor parameter, the pair's own stamp -- refuse a backward on anything else); "v1" sites rebuild (their struct carries dropout draws)
+        self.ptrs = fwd_ptrs if (fwd_ptrs is not None and not keep) else module._fill_ptrs(params, keep)
         # Parameter gradients.  With a gradient sink attached (avmoe_amd.dp.AdapterGradReducer(sites=...)) the kernels
         # write straight into the reducer's flat bucket -- `param.grad` are views of it -- and autograd gets None: no
         # per-parameter accumulation kernels.  Otherwise: fresh tensors, accumulated by autograd as usual.
@@ -182,7 +190,7 @@ class _SiteBackward:
         self.lbg = d_lb.to(torch.float32).reshape(1).contiguous() if (d_lb is not None and desc.lb_loss) else None
         wkey = (desc.S, desc.N, desc.M, self.X.dtype, bool(desc.training), bool(desc.shared_gpu))
         sizes = module.__dict__.get("_ws_sizes", {}).get(wkey)
-        self.scratch = _scratch(self.X.device, sizes[1] if sizes else self.L.avmoe_moe_scratch_bytes(C.byref(desc)), scratch_slot)
+        self.scratch = _scratch(self.X.device, sizes[1] if sizes else self.L.avmoe_moe_scratch_bytes(C.byref(desc)), scratch_slot, stream=self.stream)
         self.dX, self.dY, self.acc = dX, dY, (int(acc_dx), int(acc_dy))
 
     def run(self, parts=0):
@@ -191,7 +199,7 @@ class _SiteBackward:
         st = self.L.avmoe_moe_backward_part(C.byref(d), self.X.data_ptr(), self.Y.data_ptr(), C.byref(self.ptrs), self.d_out.data_ptr(),
                                             self.lbg.data_ptr() if self.lbg is not None else None, self.saved.data_ptr(),
                                             self.scratch.data_ptr(), self.dX.data_ptr(), self.dY.data_ptr(), C.byref(self.gptrs),
-                                            int(parts), torch.cuda.current_stream(self.X.device).cuda_stream)
+                                            int(parts), self.stream)
         d.accumulate_dx = d.accumulate_dy = 0
         capi.check(st, "avmoe_moe_backward")
         return self
@@ -213,10 +221,13 @@ class _SiteBackward:
         """dX (this site) + dY (the other site) written once into self.dX: after sections 1 + 32 + 8 of both sites, in place of this
         site's section 64 and the other site's section 16; the current stream must be ordered behind the other site's section 8."""
         st = self.L.avmoe_moe_backward_dx_dy(C.byref(self.desc), self.X.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(),
-                                             C.byref(other.desc), other.saved.data_ptr(), other.scratch.data_ptr(), self.dX.data_ptr(),
-                                             torch.cuda.current_stream(self.X.device).cuda_stream)
+                                             C.byref(other.desc), other.saved.data_ptr(), other.scratch.data_ptr(), self.dX.data_ptr(), self.stream)
         capi.check(st, "avmoe_moe_backward_dx_dy")
         return self
+
+    def finish_needs_stream(self):
+        """does finish() issue a torch op (which runs on the CURRENT stream)?"""
+        return self.sink is not None and ((self.use_sink and not self.sink.fresh) or (not self.use_sink and self.sink.stale))
 
     def finish(self):
         sink = self.sink
@@ -305,14 +316,14 @@ class _PairFunction(torch.autograd.Function):
             fork(ctx_ev[2])
             two = side.cuda_stream != main.cuda_stream      # (same_stream: the schedule of the two-stream mode on one stream -- nothing overlaps)
             with torch.cuda.stream(side):
-                out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, Xb, Xa, noises[1], names_b, pb, add_to=base_b, shared_gpu=two)
-            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a, shared_gpu=two)
+                out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, Xb, Xa, noises[1], names_b, pb, add_to=base_b, shared_gpu=two, stream=side.cuda_stream)
+            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a, shared_gpu=two, stream=main.cuda_stream)
             join(ctx_ev[3])
             for t_ in (out_b, idx_b, pr_b, lb_b, st_b[1]):
                 t_.record_stream(main)
         else:
-            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a)
-            out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, st_a[3], st_a[2], noises[1], names_b, pb, add_to=base_b)
+            out_a, pr_a, idx_a, lb_a, st_a = _site_forward(site_a, Xa, Xb, noises[0], names_a, pa, add_to=base_a, stream=main.cuda_stream)
+            out_b, pr_b, idx_b, lb_b, st_b = _site_forward(site_b, st_a[3], st_a[2], noises[1], names_b, pb, add_to=base_b, stream=main.cuda_stream)
         dirty = [t for t in (base_a, base_b) if t is not None]
         if dirty:
             ctx.mark_dirty(*dirty)
@@ -361,32 +372,36 @@ class _PairFunction(torch.autograd.Function):
             slot_b = 1 if side.cuda_stream == main.cuda_stream else 0      # (same_stream: the two sites' sections interleave on ONE stream)
             with torch.cuda.stream(side):
                 cbk = _SiteBackward(site_b, (*ctx.states[1], Xb, Xa), names_b, params[na:], needs_b, d_b, d_lbb, gXb, gXa, acc_dx=False, acc_dy=True,
-                                    scratch_slot=slot_b)
-            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, d_lba, gXa, gXb, acc_dx=False, acc_dy=True)
+                                    scratch_slot=slot_b, stream=side.cuda_stream)
+            cak = _SiteBackward(site_a, (*ctx.states[0], Xa, Xb), names_a, params[:na], needs_a, d_a, d_lba, gXa, gXb, acc_dx=False, acc_dy=True,
+                                stream=main.cuda_stream)
             # Round 5: where the library serves it (avmoe_moe_backward_dx_dy: the tuned bf16 shapes), a token gradient is written ONCE -- the
             # dX product of its own site with the other site's dY product folded in as two more contraction segments -- instead of
             # overwritten by one site and read back + added by the other.  That product moves to the END of its site's backward (it
             # needs the other site's hop-1 chain, section 8); decided per tensor.
             fuse_a = _FUSED_DX and cak.fused_ok(cbk)     # gXa = A's dX + B's dY
             fuse_b = _FUSED_DX and cbk.fused_ok(cak)     # gXb = B's dX + A's dY
-            with torch.cuda.stream(side):
-                cbk.run(1 | 32 if fuse_b else 3)
-                if not fuse_b:
-                    ev_b.record(side)                    # gXb holds site B's dX
-                cbk.run(8)                               # the hop-1 chain up to (not including) the GEMM that writes dY
-                ev_b6.record(side)
+            # (the backward objects carry their stream's handle: their C calls need no stream context around them)
+            cbk.run(1 | 32 if fuse_b else 3)
+            if not fuse_b:
+                ev_b.record(side)                        # gXb holds site B's dX
+            cbk.run(8)                                   # the hop-1 chain up to (not including) the GEMM that writes dY
+            ev_b6.record(side)
             cak.run(1 | 32 if fuse_a else 3)
             if not fuse_a:
                 ev_a.record(main)                        # gXa holds site A's dX
             cak.run(8)
             ev_a6.record(main)
-            with torch.cuda.stream(side):
-                if fuse_b:
-                    side.wait_event(ev_a6)
-                    cbk.run_fused(cak)                   # gXb complete
-                if not fuse_a:
-                    side.wait_event(ev_a)                # gXa holds site A's dX
-                    cbk.run(16)                          # += site B's dY
+            if fuse_b:
+                side.wait_event(ev_a6)
+                cbk.run_fused(cak)                       # gXb complete
+            if not fuse_a:
+                side.wait_event(ev_a)                    # gXa holds site A's dX
+                cbk.run(16)                              # += site B's dY
+            if cbk.finish_needs_stream():
+                with torch.cuda.stream(side):            # (an accumulation micro-step adds its bucket with a torch op: on the site's stream)
+                    pgb = cbk.finish()
+            else:
                 pgb = cbk.finish()
             if fuse_a:
                 main.wait_event(ev_b6)
